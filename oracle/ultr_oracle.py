@@ -1,0 +1,493 @@
+"""CPU oracle for the ULTRA_pytorch hot path  (TEST INFRASTRUCTURE — not product code).
+
+A from-scratch, vectorised torch-CPU / numpy restatement of the reference's
+`model.train(input_feed)` / `model.validation(input_feed)` path for the DNN ranking
+model with the NA / IPW / DLA / PairDebias / LambdaRank losses.  Every function cites
+the reference file:line it restates (paths relative to the ULTRA_pytorch repo root).
+
+Rules:
+  * Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may import
+    this module.  The product package `ultra_pytorch_amd` never imports it and has no
+    CPU fallback: it raises if the HIP library is missing.
+  * Parity is PINNED: tests/test_oracle_golden.py checks every function here against
+    golden vectors captured by running the reference itself in the build container
+    (tests/golden/make_golden.py -> tests/golden/*.npz).  The reference's own tests
+    hold no numerical fixtures for this path, so those captured vectors
+    are the pin.
+  * Arithmetic is fp32 torch-CPU — the same library the reference computes with.
+  * Quirk-exact: SURVEY.md Appendix A items 1-11 are reproduced on purpose.
+
+Layouts: `features` [n_docs, F] f32; `docids` [L, B] int (position-major, pad id ==
+n_docs -> all-zero row); `labels` [L, B] f32 (clicks or relevance); scores [B, L].
+Parameters travel as ONE flat f32 vector in `state_dict()` order of the reference's
+`DNN.sequential`: for j in 0..k: layer_norm{j}.weight[K_j], layer_norm{j}.bias[K_j],
+linear{j}.weight[M_j, K_j] (row-major), linear{j}.bias[M_j]   (DNN.py:41-55).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+LN_EPS = 1e-5  # nn.LayerNorm default (DNN.py:46)
+PADDING_SCORE = -100000.0  # base_algorithm.py:36
+
+
+# --------------------------------------------------------------------------------------
+# parameter layout
+# --------------------------------------------------------------------------------------
+def layer_dims(feature_size: int, hidden: Sequence[int]) -> List[Tuple[int, int]]:
+    """[(K_j, M_j)] for Linear_j, j = 0..k.  DNN.py:38,41-55: output_sizes = hidden + [1]."""
+    outs = list(hidden) + [1]
+    dims, k = [], feature_size
+    for m in outs:
+        dims.append((k, m))
+        k = m
+    return dims
+
+
+def param_layout(feature_size: int, hidden: Sequence[int]) -> List[Tuple[str, Tuple[int, ...], int]]:
+    """[(state_dict key, shape, flat offset)] in reference parameter order (DNN.py:41-55)."""
+    out, off = [], 0
+    for j, (k, m) in enumerate(layer_dims(feature_size, hidden)):
+        for name, shape in (("sequential.layer_norm%d.weight" % j, (k,)),
+                            ("sequential.layer_norm%d.bias" % j, (k,)),
+                            ("sequential.linear%d.weight" % j, (m, k)),
+                            ("sequential.linear%d.bias" % j, (m,))):
+            out.append((name, shape, off))
+            off += int(np.prod(shape))
+    return out
+
+
+def num_params(feature_size: int, hidden: Sequence[int]) -> int:
+    name, shape, off = param_layout(feature_size, hidden)[-1]
+    return off + int(np.prod(shape))
+
+
+def unflatten(flat: torch.Tensor, feature_size: int, hidden: Sequence[int]) -> Dict[str, torch.Tensor]:
+    return {n: flat[o:o + int(np.prod(s))].view(*s) for n, s, o in param_layout(feature_size, hidden)}
+
+
+def init_params(feature_size: int, hidden: Sequence[int], seed: int = 0) -> np.ndarray:
+    """nn.LayerNorm / nn.Linear default init (what DNN.__init__ gets, DNN.py:44-52).
+    Parity tests never rely on this (they load golden weights); bench/smoke use it."""
+    g = torch.Generator().manual_seed(seed)
+    parts = []
+    for k, m in layer_dims(feature_size, hidden):
+        bound = 1.0 / math.sqrt(k)  # kaiming_uniform(a=sqrt(5)) on [m,k] == U(-1/sqrt(k), 1/sqrt(k))
+        parts += [torch.ones(k), torch.zeros(k),
+                  (torch.rand(m, k, generator=g) * 2 - 1) * bound,
+                  (torch.rand(m, generator=g) * 2 - 1) * bound]
+    return torch.cat([p.reshape(-1) for p in parts]).numpy().astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# a1/a2: marshal + gather    (base_algorithm.py:134-154, 169-186)
+# --------------------------------------------------------------------------------------
+def gather_rows(features: np.ndarray, docids: np.ndarray) -> torch.Tensor:
+    """np.take over features ++ zero PAD row, position-major rows (row = l*B + b).
+    base_algorithm.py:148-153 + DNN.py:72-73 (cat dim 0, cast to f32)."""
+    feats = np.asarray(features, dtype=np.float32).reshape(-1, features.shape[-1] if np.ndim(features) == 2 else 0)
+    pad = np.zeros((1, feats.shape[1]), dtype=np.float32)
+    table = np.concatenate((feats, pad), axis=0)
+    ids = np.asarray(docids).astype(np.int64).reshape(-1)
+    return torch.from_numpy(np.take(table, ids, axis=0))
+
+
+# --------------------------------------------------------------------------------------
+# a3: DNN forward   (DNN.py:41-55, 58-88)
+# --------------------------------------------------------------------------------------
+def _act(name: str):
+    # base_ranking_model.py:63-69 ACT_FUNC_DIC; elu alpha = 1
+    return {"elu": F.elu, "relu": F.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid}[name]
+
+
+def dnn_forward(params: torch.Tensor, feature_size: int, hidden: Sequence[int], x: torch.Tensor,
+                act: str = "elu") -> torch.Tensor:
+    """[LayerNorm -> Linear -> act] x k, LayerNorm -> Linear(.,1).  LayerNorm precedes
+    EVERY Linear (Appendix A.1; DNN.py:43-47: self.layer_norm is never set)."""
+    p = unflatten(params, feature_size, hidden)
+    dims = layer_dims(feature_size, hidden)
+    h = x
+    for j, (k, m) in enumerate(dims):
+        h = F.layer_norm(h, (k,), p["sequential.layer_norm%d.weight" % j], p["sequential.layer_norm%d.bias" % j], LN_EPS)
+        h = F.linear(h, p["sequential.linear%d.weight" % j], p["sequential.linear%d.bias" % j])
+        if j != len(dims) - 1:
+            h = _act(act)(h)
+    return h  # [N, 1]
+
+
+def ranking_scores(params: torch.Tensor, feature_size: int, hidden: Sequence[int], features: np.ndarray,
+                   docids: np.ndarray, act: str = "elu") -> torch.Tensor:
+    """base_algorithm.py:118-132: split position-major output into L x [B,1], cat dim 1 -> [B, L]."""
+    L, B = docids.shape
+    out = dnn_forward(params, feature_size, hidden, gather_rows(features, docids), act)
+    return out.view(L, B).t()
+
+
+def dnn_backward_manual(params: np.ndarray, feature_size: int, hidden: Sequence[int], x: np.ndarray,
+                        dscore: np.ndarray, act: str = "elu") -> np.ndarray:
+    """Closed-form backward of dnn_forward (what autograd does for DNN.py:41-55) in numpy
+    float64-free fp32 — this is the written-out spec the HIP backward kernels implement.
+    Returns the flat gradient."""
+    assert act in ("elu", "relu")
+    x = np.asarray(x, np.float32)
+    dims = layer_dims(feature_size, hidden)
+    lay = {n: (s, o) for n, s, o in param_layout(feature_size, hidden)}
+
+    def get(n):
+        s, o = lay[n]
+        return params[o:o + int(np.prod(s))].reshape(s)
+
+    xs, xhats, rstds, us = [], [], [], []
+    h = x
+    for j, (k, m) in enumerate(dims):
+        mu = h.mean(axis=1, keepdims=True, dtype=np.float32)
+        var = ((h - mu) ** 2).mean(axis=1, keepdims=True, dtype=np.float32)
+        r = (1.0 / np.sqrt(var + np.float32(LN_EPS))).astype(np.float32)
+        xhat = (h - mu) * r
+        u = xhat * get("sequential.layer_norm%d.weight" % j) + get("sequential.layer_norm%d.bias" % j)
+        z = u @ get("sequential.linear%d.weight" % j).T + get("sequential.linear%d.bias" % j)
+        xs.append(h), xhats.append(xhat), rstds.append(r), us.append(u)
+        if j != len(dims) - 1:
+            h = np.where(z > 0, z, np.expm1(np.minimum(z, 0))).astype(np.float32) if act == "elu" else np.maximum(z, 0)
+    grads = np.zeros_like(params)
+
+    def put(n, g):
+        s, o = lay[n]
+        grads[o:o + int(np.prod(s))] = g.reshape(-1)
+
+    dz = np.asarray(dscore, np.float32).reshape(-1, 1)
+    for j in reversed(range(len(dims))):
+        W = get("sequential.linear%d.weight" % j)
+        put("sequential.linear%d.weight" % j, dz.T @ us[j])
+        put("sequential.linear%d.bias" % j, dz.sum(axis=0))
+        du = dz @ W
+        put("sequential.layer_norm%d.weight" % j, (du * xhats[j]).sum(axis=0))
+        put("sequential.layer_norm%d.bias" % j, du.sum(axis=0))
+        if j == 0:
+            break
+        dxhat = du * get("sequential.layer_norm%d.weight" % j)
+        c1 = dxhat.mean(axis=1, keepdims=True)
+        c2 = (dxhat * xhats[j]).mean(axis=1, keepdims=True)
+        dx = rstds[j] * (dxhat - c1 - xhats[j] * c2)
+        a = xs[j]  # = act(z_{j-1})
+        dact = np.where(a > 0, 1.0, a + 1.0) if act == "elu" else (a > 0).astype(np.float32)
+        dz = (dx * dact).astype(np.float32)
+    return grads
+
+
+# --------------------------------------------------------------------------------------
+# a4: listwise softmax cross entropy   (base_algorithm.py:18-30, 309-330)
+# --------------------------------------------------------------------------------------
+def softmax_loss(output: torch.Tensor, labels: torch.Tensor, propensity_weights: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if propensity_weights is None:
+        propensity_weights = torch.ones_like(labels)
+    weighted_labels = (labels + 0.0000001) * propensity_weights  # the 1e-7 smoothing (Appendix A.2)
+    label_dis = weighted_labels / torch.sum(weighted_labels, 1, keepdim=True)
+    label_dis = torch.nan_to_num(label_dis)
+    loss = torch.sum(-label_dis * F.log_softmax(output, -1), -1) * torch.sum(weighted_labels, 1)
+    return torch.sum(loss) / torch.sum(weighted_labels)  # GLOBAL normaliser
+
+
+def softmax_loss_closed_form(scores: np.ndarray, labels: np.ndarray, pw: Optional[np.ndarray]):
+    """Closed form used as the kernel spec:  w=(y+1e-7)pw, S_b=sum_l w, D=sum w,
+    loss=sum_b( -sum_l w*log_softmax(s) )/D,  dloss/ds = (softmax(s)*S_b - w)/D."""
+    s = torch.as_tensor(scores, dtype=torch.float32)
+    y = torch.as_tensor(labels, dtype=torch.float32)
+    w = (y + 0.0000001) * (torch.ones_like(y) if pw is None else torch.as_tensor(pw, dtype=torch.float32))
+    Sb = w.sum(1, keepdim=True)
+    D = w.sum()
+    lsm = F.log_softmax(s, -1)
+    loss = (-(w * lsm).sum()) / D
+    ds = (lsm.exp() * Sb - w) / D
+    return float(loss), ds.numpy(), float(D)
+
+
+# --------------------------------------------------------------------------------------
+# a8: IPW weights   (propensity_estimator.py:22-42, ipw_rank.py:115-138)
+# --------------------------------------------------------------------------------------
+def ipw_weights(clicks_LB: np.ndarray, ipw_list: Sequence[float]) -> torch.Tensor:
+    """pw[b,l] = IPW_list[min(l, len-1)] if click[l,b] > 0 else 0  ->  f32 [B, L]."""
+    L, B = clicks_LB.shape
+    table = np.asarray([ipw_list[l] if l < len(ipw_list) else ipw_list[-1] for l in range(L)], dtype=np.float64)
+    pw = np.where(np.asarray(clicks_LB).T > 0, table[None, :], 0.0)
+    return torch.as_tensor(pw.tolist())  # list of python floats -> f32, as ipw_rank.py:138
+
+
+# --------------------------------------------------------------------------------------
+# a5/a6: clip + optimizer   (base_algorithm.py:208-226; torch.optim.Adagrad / SGD)
+# --------------------------------------------------------------------------------------
+def clip_coef(total_norm: float, max_norm: float) -> float:
+    """torch.nn.utils.clip_grad_norm_: coef = max_norm/(norm+1e-6) clamped to 1."""
+    return min(1.0, max_norm / (total_norm + 1e-6))
+
+
+def grad_norm(g: torch.Tensor) -> torch.Tensor:
+    return torch.linalg.vector_norm(g, 2)
+
+
+def adagrad_update(p: torch.Tensor, g: torch.Tensor, state_sum: torch.Tensor, lr: float, eps: float = 1e-10):
+    """torch.optim.Adagrad (lr_decay 0, weight_decay 0, initial_accumulator 0): s += g*g; p -= lr*g/(sqrt(s)+eps)."""
+    s = state_sum + g * g
+    return p - lr * g / (s.sqrt() + eps), s
+
+
+def apply_update(p, g, state_sum, lr, max_norm, strategy="ada", stateless=False):
+    """opt_step (base_algorithm.py:208-226): clip_grad_norm_(max_norm) then optimizer.step().
+    stateless=True restates DLA's per-step optimizer re-construction (dla.py:153-154): the
+    Adagrad accumulator is always empty when step() runs."""
+    n = grad_norm(g)
+    if max_norm > 0:
+        g = g * min(1.0, float(max_norm / (n + 1e-6)))
+    if strategy == "sgd":
+        return p - lr * g, state_sum, n, g
+    if stateless:
+        state_sum = torch.zeros_like(p)
+    p2, s2 = adagrad_update(p, g, state_sum, lr)
+    return p2, s2, n, g
+
+
+# --------------------------------------------------------------------------------------
+# a7/a8: NA and IPW train steps   (navie_algorithm.py:76-120, ipw_rank.py:102-182)
+# --------------------------------------------------------------------------------------
+def train_step_softmax(params, state_sum, F_, hidden, features, docids, labels_LB, ipw_list=None, lr=0.05,
+                       max_norm=5.0, strategy="ada", act="elu"):
+    """One NA (ipw_list None) / IPW step.  Returns dict(loss, scores, grads, norm, params, state)."""
+    p = torch.as_tensor(params, dtype=torch.float32).clone().requires_grad_(True)
+    scores = ranking_scores(p, F_, hidden, features, docids, act)
+    labels = torch.from_numpy(np.ascontiguousarray(np.transpose(labels_LB))).float()  # base_algorithm.py:182
+    pw = None if ipw_list is None else ipw_weights(labels_LB, ipw_list)
+    loss = softmax_loss(scores, labels, pw)
+    (g,) = torch.autograd.grad(loss, p)
+    with torch.no_grad():
+        p2, s2, n, gc = apply_update(p.detach(), g, torch.as_tensor(state_sum, dtype=torch.float32), lr, max_norm, strategy)
+    return dict(loss=float(loss.detach()), scores=scores.detach().numpy(), grads=g.numpy(), norm=float(n),
+                params=p2.numpy(), state=s2.numpy(), pw=None if pw is None else pw.numpy())
+
+
+# --------------------------------------------------------------------------------------
+# a9: DLA   (dla.py:24-48, 141-177, 179-266, 287-306)
+# --------------------------------------------------------------------------------------
+def denoising_net(prop_params: torch.Tensor, B: int, L: int) -> torch.Tensor:
+    """DenoisingNet.forward (dla.py:33-48): one-hot(l) -> Linear(L,1) -> ELU, i.e.
+    propensity[b,l] = ELU(W[0,l] + bias), batch-independent.  prop_params = [W(L) | bias(1)]."""
+    w, b = prop_params[:L], prop_params[L]
+    return F.elu(w + b).unsqueeze(0).expand(B, L)
+
+
+def normalized_weights(prob: torch.Tensor) -> torch.Tensor:
+    """get_normalized_weights (dla.py:287-306): w[:,l] = prob[:,0]/prob[:,l]; the
+    max_propensity_weight clamp acts on a grad-less tensor's .grad -> inert (Appendix A.5)."""
+    return prob[:, :1] / prob
+
+
+def logits_to_prob(x: torch.Tensor, kind: str = "softmax") -> torch.Tensor:
+    if kind == "sigmoid":  # dla.py:21-22
+        return torch.sigmoid(x - torch.mean(x, -1, keepdim=True))
+    return torch.softmax(x, dim=-1)
+
+
+def dla_step(params, prop_params, F_, hidden, features, docids, labels_LB, lr=0.05, prop_lr=None, max_norm=5.0,
+             ranker_loss_weight=1.0, strategy="ada", l2p="softmax", act="elu"):
+    prop_lr = lr if prop_lr is None or prop_lr < 0 else prop_lr
+    L, B = docids.shape
+    p = torch.as_tensor(params, dtype=torch.float32).clone().requires_grad_(True)
+    q = torch.as_tensor(prop_params, dtype=torch.float32).clone().requires_grad_(True)
+    scores = ranking_scores(p, F_, hidden, features, docids, act)
+    labels = torch.from_numpy(np.ascontiguousarray(np.transpose(labels_LB))).float()
+    propensity = denoising_net(q, B, L)
+    with torch.no_grad():
+        pw = normalized_weights(logits_to_prob(propensity, l2p))  # dla.py:200-202
+    rank_loss = softmax_loss(scores, labels, pw)  # dla.py:203
+    with torch.no_grad():
+        rw = normalized_weights(logits_to_prob(scores, l2p))  # dla.py:217-219
+    exam_loss = softmax_loss(propensity, labels, rw)  # dla.py:221-224
+    loss = exam_loss + ranker_loss_weight * rank_loss  # dla.py:237
+    gp, gq = torch.autograd.grad(loss, (p, q))
+    with torch.no_grad():
+        # separate clips (dla.py:161-163), fresh optimizers (dla.py:153-154) => stateless Adagrad
+        q2, _, nq, _ = apply_update(q.detach(), gq, torch.zeros_like(gq), prop_lr, max_norm, strategy, stateless=True)
+        p2, _, np_, _ = apply_update(p.detach(), gp, torch.zeros_like(gp), lr, max_norm, strategy, stateless=True)
+    return dict(loss=float(loss.detach()), rank_loss=float(rank_loss.detach()), exam_loss=float(exam_loss.detach()), scores=scores.detach().numpy(),
+                grads=gp.numpy(), norm=float(np_), prop_grads=gq.numpy(), prop_norm=float(nq), params=p2.numpy(),
+                prop_params=q2.numpy(), propensity_weights=pw.numpy(), relevance_weights=rw.numpy())
+
+
+# --------------------------------------------------------------------------------------
+# a10: PairDebias   (pairwise_debias.py:106-174, base_algorithm.py:228-248)
+# --------------------------------------------------------------------------------------
+def pairdebias_loss(scores: torch.Tensor, clicks_LB: torch.Tensor, t_plus: torch.Tensor, t_minus: torch.Tensor):
+    """Vectorised restatement of the 2-level Python pair loop (pairwise_debias.py:142-157).
+    PL[i,j] = B * sum_b min(1,relu(c_i-c_j)) * (-log_softmax([s_i,s_j])[0]);  the factor B is the
+    reference's [B]*[B,1] broadcast (Appendix A.6).  Returns (loss, PL[L,L], t_plus_loss[L], t_minus_loss[L])."""
+    B, L = scores.shape
+    c = clicks_LB.t()  # [B, L]
+    mask = torch.minimum(torch.ones(()), F.relu(c.unsqueeze(2) - c.unsqueeze(1)))  # [B, i, j]
+    pair = F.softplus(scores.unsqueeze(1) - scores.unsqueeze(2))  # [B,i,j] = log(1+exp(s_j - s_i))
+    offdiag = 1.0 - torch.eye(L)
+    PL = float(B) * (mask * pair).sum(0) * offdiag  # [L, L]
+    tp, tm = t_plus.view(-1), t_minus.view(-1)
+    t_plus_loss = (PL / tm.unsqueeze(0)).sum(1)
+    t_minus_loss = (PL / tp.unsqueeze(1)).sum(0)
+    loss = (PL / tp.unsqueeze(1) / tm.unsqueeze(0)).sum()
+    return loss, PL, t_plus_loss, t_minus_loss
+
+
+def em_update(t, t_loss, alpha, p, safe=False):
+    """pairwise_debias.py:160-163 (plain /) and lambda_rank.py:138-142 (_safe_div)."""
+    ratio = torch.where(t_loss[0] == 0, torch.zeros_like(t_loss), t_loss / t_loss[0]) if safe else t_loss / t_loss[0]
+    return (1 - alpha) * t + alpha * torch.pow(ratio, 1.0 / (p + 1)).view_as(t)
+
+
+def pairdebias_step(params, state_sum, t_plus, t_minus, F_, hidden, features, docids, labels_LB, lr=0.005,
+                    max_norm=5.0, em_step=0.05, reg_p=1, strategy="ada", act="elu"):
+    p = torch.as_tensor(params, dtype=torch.float32).clone().requires_grad_(True)
+    tp = torch.as_tensor(t_plus, dtype=torch.float32)
+    tm = torch.as_tensor(t_minus, dtype=torch.float32)
+    scores = ranking_scores(p, F_, hidden, features, docids, act)
+    loss, PL, tpl, tml = pairdebias_loss(scores, torch.as_tensor(labels_LB, dtype=torch.float32), tp, tm)
+    (g,) = torch.autograd.grad(loss, p)
+    with torch.no_grad():
+        tp2 = em_update(tp, tpl, em_step, reg_p)
+        tm2 = em_update(tm, tml, em_step, reg_p)
+        p2, s2, n, _ = apply_update(p.detach(), g, torch.as_tensor(state_sum, dtype=torch.float32), lr, max_norm, strategy)
+    return dict(loss=float(loss.detach()), scores=scores.detach().numpy(), grads=g.numpy(), norm=float(n), params=p2.numpy(),
+                state=s2.numpy(), t_plus=tp2.numpy(), t_minus=tm2.numpy(), pair_loss=PL.detach().numpy())
+
+
+# --------------------------------------------------------------------------------------
+# a11: LambdaRank   (lambda_rank.py:96-216, 247-291)
+# --------------------------------------------------------------------------------------
+def _safe_div(n: torch.Tensor, d: torch.Tensor) -> torch.Tensor:
+    """metrics.py:156-170."""
+    return torch.where(torch.eq(d, 0), torch.zeros_like(n), torch.div(n, d))
+
+
+def lambdarank_loss(scores: torch.Tensor, labels: torch.Tensor, t_plus: torch.Tensor, t_minus: torch.Tensor, sigma: float = 1.0):
+    B, L = scores.shape
+    preds_sorted, inds = torch.sort(scores, dim=1, descending=True)  # :116
+    labs = torch.gather(labels, 1, inds)  # :117
+    S = torch.clamp(labs.unsqueeze(2) - labs.unsqueeze(1), -1.0, 1.0)  # :119-121
+    Pbar = 0.5 * (1.0 + S)
+    s_ij = preds_sorted.unsqueeze(2) - preds_sorted.unsqueeze(1)
+    p_ij = 1.0 / (torch.exp(-sigma * s_ij) + 1.0)  # :125
+    ideal, _ = torch.sort(labels, dim=1, descending=True)
+    # dcg(): batch-GLOBAL scalar, natural log (lambda_rank.py:247-266; Appendix A.7)
+    pos = torch.arange(1, L + 1, dtype=torch.float32)
+    idcg = torch.sum(_safe_div(torch.pow(torch.tensor(2.0), ideal) - 1.0, torch.log(pos + 1)))
+    gains = (torch.pow(2.0, labs) - 1.0) / idcg  # :280-282
+    disc = 1.0 / torch.log2(torch.arange(L, dtype=torch.float32) + 2.0)
+    delta = torch.abs(gains.unsqueeze(2) - gains.unsqueeze(1)) * torch.abs(disc.view(1, L, 1) - disc.view(1, 1, L))
+    # BCE-with-LOGITS applied to the probability p_ij (lambda_rank.py:128; Appendix A.7)
+    l = F.binary_cross_entropy_with_logits(p_ij, Pbar, weight=delta, reduction="none")
+    PL = l.sum(0)  # [L, L] incl. diagonal (delta = 0 there)
+    tp, tm = t_plus.view(-1), t_minus.view(-1)
+    t_plus_loss = (PL / tm.unsqueeze(0)).sum(1)  # :130
+    t_minus_loss = (PL.t() / tp.unsqueeze(0)).sum(1)  # :131-132
+    loss = _safe_div(PL, tp.unsqueeze(1) * tm.unsqueeze(0)).sum()  # :133-135
+    return loss, PL, t_plus_loss, t_minus_loss
+
+
+def lambdarank_step(params, state_sum, t_plus, t_minus, F_, hidden, features, docids, labels_LB, lr=0.05, max_norm=5.0,
+                    em_step=0.05, reg_p=1, sigma=1.0, strategy="ada", act="elu"):
+    p = torch.as_tensor(params, dtype=torch.float32).clone().requires_grad_(True)
+    tp = torch.as_tensor(t_plus, dtype=torch.float32)
+    tm = torch.as_tensor(t_minus, dtype=torch.float32)
+    scores = ranking_scores(p, F_, hidden, features, docids, act)
+    labels = torch.from_numpy(np.ascontiguousarray(np.transpose(labels_LB))).float()
+    loss, PL, tpl, tml = lambdarank_loss(scores, labels, tp, tm, sigma)
+    (g,) = torch.autograd.grad(loss, p)
+    with torch.no_grad():
+        tp2 = em_update(tp, tpl, em_step, reg_p, safe=True)
+        tm2 = em_update(tm, tml, em_step, reg_p, safe=True)
+        p2, s2, n, _ = apply_update(p.detach(), g, torch.as_tensor(state_sum, dtype=torch.float32), lr, max_norm, strategy)
+    return dict(loss=float(loss.detach()), scores=scores.detach().numpy(), grads=g.numpy(), norm=float(n), params=p2.numpy(),
+                state=s2.numpy(), t_plus=tp2.numpy(), t_minus=tm2.numpy(), pair_loss=PL.detach().numpy())
+
+
+# --------------------------------------------------------------------------------------
+# a12/a13: validation  (base_algorithm.py:88-116; metrics.py:156-336, 456-495)
+# --------------------------------------------------------------------------------------
+def mask_padding(scores: torch.Tensor, docids_LB: np.ndarray, n_docs: int) -> torch.Tensor:
+    """remove_padding_for_metric_eval: score := -100000 where docid == n_docs (the PAD row)."""
+    valid = torch.from_numpy(np.asarray(docids_LB).T != n_docs)
+    return torch.where(valid, scores, torch.full_like(scores, PADDING_SCORE))
+
+
+def _prepare(labels: torch.Tensor, predictions: torch.Tensor, topn: Sequence[int]):
+    """metrics.py:224-265 with weights=None."""
+    list_size = predictions.shape[1]
+    topn = [min(n, list_size) for n in topn]
+    ok = labels >= 0.0  # metric_utils.py:44-46
+    labels = torch.where(ok, labels, torch.zeros_like(labels))
+    predictions = torch.where(ok, predictions, -1e-6 * torch.ones_like(predictions) + torch.min(predictions, dim=1, keepdim=True).values)
+    return labels, predictions, topn
+
+
+def _dcg(prediction: torch.Tensor, labels: torch.Tensor, topn: Sequence[int]) -> torch.Tensor:
+    """metrics.py:191-221 with weights = 1."""
+    L = labels.shape[1]
+    _, idx = prediction.sort(descending=True, dim=-1)
+    sl = torch.gather(labels, 1, idx)
+    disc = torch.tensor(1) / torch.log2(torch.arange(L, dtype=torch.float) + 2.0)
+    gains = torch.pow(torch.tensor(2.0), sl.to(torch.float32)) - 1.0
+    cum = torch.cumsum((gains * disc)[:, :int(np.max(topn))], dim=1)
+    return cum[:, torch.tensor(topn, dtype=torch.long) - 1]
+
+
+def ndcg(labels: torch.Tensor, predictions: torch.Tensor, topn: Sequence[int]) -> torch.Tensor:
+    """normalized_discounted_cumulative_gain, weights=None branch (metrics.py:486-494)."""
+    labels, predictions, topn = _prepare(labels, predictions, topn)
+    d = _dcg(predictions, labels, topn)
+    i = _dcg(labels, labels, topn)
+    return torch.mean(_safe_div(d, i), dim=0)
+
+
+def argsort_desc(labels: torch.Tensor, predictions: torch.Tensor) -> torch.Tensor:
+    """The permutation metrics sort with (metrics.py:208)."""
+    labels, predictions, _ = _prepare(labels, predictions, [1])
+    return predictions.sort(descending=True, dim=-1)[1]
+
+
+def mrr(labels: torch.Tensor, predictions: torch.Tensor, topn: Sequence[int]) -> torch.Tensor:
+    """mean_reciprocal_rank (metrics.py:268-298)."""
+    L = predictions.shape[-1]
+    labels, predictions, topn = _prepare(labels, predictions, topn)
+    _, idx = predictions.sort(descending=True, dim=-1)
+    rel = torch.ge(torch.gather(labels, 1, idx), 1.0).float()
+    rr = 1.0 / torch.arange(1, L + 1, dtype=torch.float32)
+    return torch.mean(torch.max(rel * rr, dim=1, keepdim=True).values).repeat(len(topn))
+
+
+def err(labels: torch.Tensor, predictions: torch.Tensor, topn: Sequence[int], max_label: float) -> torch.Tensor:
+    """expected_reciprocal_rank (metrics.py:300-336)."""
+    labels, predictions, topn = _prepare(labels, predictions, topn)
+    _, idx = predictions.sort(descending=True, dim=-1)
+    sl = torch.gather(labels, 1, idx)
+    L = sl.shape[-1]
+    two = torch.as_tensor(2.0)
+    rel = (torch.pow(two, sl) - 1) / torch.pow(two, torch.as_tensor(max_label))
+    non_rel = torch.cumprod(1.0 - rel, dim=1) / (1.0 - rel)
+    rr = 1.0 / torch.arange(1, L + 1, dtype=torch.float32)
+    outs = []
+    for n in topn:
+        m = torch.ge(rr, 1.0 / n).float()
+        outs.append(torch.sum(rel * non_rel * rr * m, dim=1, keepdim=True))
+    return torch.mean(torch.stack(outs, dim=0), dim=1).view(-1)
+
+
+def validation(params, F_, hidden, features, docids, labels_LB, topn=(1, 3, 5, 10), max_label=4.0, act="elu"):
+    """*.validation (ipw_rank.py:184-211): returns UNMASKED scores + metrics on masked scores (Appendix A.10)."""
+    with torch.no_grad():
+        p = torch.as_tensor(params, dtype=torch.float32)
+        scores = ranking_scores(p, F_, hidden, features, docids, act)
+        labels = torch.from_numpy(np.ascontiguousarray(np.transpose(labels_LB))).float()
+        masked = mask_padding(scores, docids, np.asarray(features).reshape(-1, F_).shape[0])
+        out = dict(scores=scores.numpy(), masked=masked.numpy(), ndcg=ndcg(labels, masked, topn).numpy(),
+                   mrr=mrr(labels, masked, topn).numpy(), err=err(labels, masked, topn, max_label).numpy(),
+                   argsort=argsort_desc(labels, masked).numpy())
+    return out

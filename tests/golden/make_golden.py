@@ -1,0 +1,380 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by RUNNING the reference (ULTRA_pytorch) here.
+
+Runs only in the build container, where /root/reference exists.  It imports the
+reference's own `ultra` package (never copied into this repo), drives
+`model.train(input_feed)` / `model.validation(input_feed)` on seeded synthetic
+data, and records — per step, teacher-forced — the inputs, the pre-state, and
+every output the hot path produces (scores, loss, pre-clip grads, grad norm,
+post-step params / Adagrad state / EM state, NDCG...).  The resulting `.npz`
+files are DATA (inputs + expected outputs) and are committed under
+tests/golden/; they are what pins the oracle (oracle/) and the HIP path.
+
+Harness-side shims (reference untouched), per SURVEY.md Appendix B:
+  (1) stub `tensorflow` (dead import, ultra/ranking_model/base_ranking_model.py:8)
+  (2) stub `torch.utils.tensorboard.SummaryWriter` (tensorboard pkg absent)
+  (3) `torch.as_tensor` of list-of-ndarray -> np.asarray first (base_algorithm.py:186)
+  (4) `nn.utils.clip_grad_value_` no-op on grad-less tensors (ipw_rank.py:164)
+
+Usage:  python tests/golden/make_golden.py [--only NAME]
+"""
+import argparse
+import importlib.machinery
+import io
+import contextlib
+import json
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def install_shims():
+    tf = types.ModuleType("tensorflow")
+    tf.__spec__ = importlib.machinery.ModuleSpec("tensorflow", None)
+    sys.modules["tensorflow"] = tf
+    tb = types.ModuleType("torch.utils.tensorboard")
+    tb.__spec__ = importlib.machinery.ModuleSpec("torch.utils.tensorboard", None)
+
+    class SummaryWriter:
+        def __init__(self, *a, **k):
+            pass
+
+        def add_scalars(self, *a, **k):
+            pass
+
+        def add_scalar(self, *a, **k):
+            pass
+
+        def close(self):
+            pass
+
+    tb.SummaryWriter = SummaryWriter
+    sys.modules["torch.utils.tensorboard"] = tb
+    torch.utils.tensorboard = tb
+    _as = torch.as_tensor
+
+    def as_tensor(data, dtype=None, device=None):
+        if isinstance(data, (list, tuple)) and data and isinstance(data[0], np.ndarray):
+            data = np.asarray(data)
+        return _as(data, dtype=dtype, device=device)
+
+    torch.as_tensor = as_tensor
+    _cgv = nn.utils.clip_grad_value_
+
+    def cgv(params, clip_value, foreach=None):
+        params = [params] if isinstance(params, torch.Tensor) else list(params)
+        params = [p for p in params if p.grad is not None]
+        return None if not params else _cgv(params, clip_value, foreach=foreach)
+
+    nn.utils.clip_grad_value_ = cgv
+
+
+def import_reference():
+    os.chdir(REF)
+    sys.path.insert(0, REF)
+    install_shims()
+    import ultra  # noqa: F401
+    import ultra.utils  # noqa: F401
+    import ultra.learning_algorithm  # noqa: F401
+    import ultra.ranking_model  # noqa: F401
+    import ultra.input_layer  # noqa: F401
+    return ultra
+
+
+# ----------------------------------------------------------------------------
+# synthetic in-memory dataset (Raw_data() with no args)
+# ----------------------------------------------------------------------------
+def make_dataset(ultra, seed, n_queries, list_lens, F, max_label=4):
+    """list_lens: int (fixed) or (lo, hi) inclusive range of docs per query."""
+    rng = np.random.RandomState(seed)
+    ds = ultra.utils.data_utils.Raw_data()
+    ds.feature_size = F
+    feats, init_list, labels, qids, lens = [], [], [], [], []
+    did = 0
+    for q in range(n_queries):
+        n = list_lens if isinstance(list_lens, int) else int(rng.randint(list_lens[0], list_lens[1] + 1))
+        f = rng.uniform(-1.0, 1.0, size=(n, F)).astype(np.float32)
+        lab = rng.randint(0, max_label + 1, size=n)
+        if lab.sum() == 0:
+            lab[0] = 1
+        feats.extend([[float(v) for v in row] for row in f])
+        init_list.append(list(range(did, did + n)))
+        labels.append([int(v) for v in lab])
+        qids.append("q%d" % q)
+        lens.append(n)
+        did += n
+    ds.features = feats
+    ds.dids = ["d%d" % i for i in range(did)]
+    ds.qids = qids
+    ds.initial_list = init_list
+    ds.labels = labels
+    ds.initial_list_lengths = lens
+    ds.rank_list_size = max(lens)
+    ultra.utils.metrics.RankingMetricKey.MAX_LABEL = float(max_label)
+    return ds
+
+
+def flat_state(module):
+    return {k: v.detach().cpu().numpy().copy() for k, v in module.state_dict().items()}
+
+
+def flat_params(module):
+    return np.concatenate([p.detach().cpu().numpy().ravel() for p in module.parameters()]).astype(np.float32)
+
+
+def adagrad_state(opt, module):
+    out = []
+    for p in module.parameters():
+        st = opt.state.get(p, {})
+        if "sum" in st:
+            out.append(st["sum"].detach().cpu().numpy().ravel())
+        else:
+            out.append(np.zeros(p.numel(), np.float32))
+    return np.concatenate(out).astype(np.float32)
+
+
+class Recorder:
+    """Hooks into the algorithm object to record scores and pre-clip grads."""
+
+    def __init__(self, algo):
+        self.algo = algo
+        self.scores = None
+        self.clips = []  # list of (flat grads pre-clip, total_norm)
+        orig_rm = algo.ranking_model
+
+        def rm(model, list_size):
+            out = orig_rm(model, list_size)
+            self.scores = out.detach().cpu().numpy().copy()
+            return out
+
+        algo.ranking_model = rm
+        self._orig_clip = torch.nn.utils.clip_grad_norm_
+
+        def clip(parameters, max_norm, *a, **k):
+            ps = [parameters] if isinstance(parameters, torch.Tensor) else list(parameters)
+            g = np.concatenate([p.grad.detach().cpu().numpy().ravel() for p in ps]).astype(np.float32)
+            tn = self._orig_clip(ps, max_norm, *a, **k)
+            self.clips.append((g, float(tn)))
+            return tn
+
+        torch.nn.utils.clip_grad_norm_ = clip
+        nn.utils.clip_grad_norm_ = clip
+
+    def reset(self):
+        self.scores = None
+        self.clips = []
+
+    def close(self):
+        torch.nn.utils.clip_grad_norm_ = self._orig_clip
+        nn.utils.clip_grad_norm_ = self._orig_clip
+
+
+def feed_arrays(algo, input_feed, L):
+    feats = np.asarray(input_feed["letor_features"], dtype=np.float32)
+    if feats.ndim != 2:  # empty batch guard
+        feats = feats.reshape(0, algo.feature_size)
+    docids = np.stack([np.asarray(input_feed[algo.docid_inputs_name[l]]) for l in range(L)]).astype(np.int32)
+    labels = np.stack([np.asarray(input_feed[algo.labels_name[l]]) for l in range(L)]).astype(np.float32)
+    return feats, docids, labels
+
+
+def quiet(fn, *a, **k):
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        return fn(*a, **k)
+
+
+ALGOS = {
+    "na": "ultra.learning_algorithm.NavieAlgorithm",
+    "ipw": "ultra.learning_algorithm.IPWrank",
+    "dla": "ultra.learning_algorithm.DLA",
+    "pairdebias": "ultra.learning_algorithm.PairDebias",
+    "lambdarank": "ultra.learning_algorithm.LambdaRank",
+}
+
+
+def run_train_case(ultra, name, algo_key, F, L, B, hidden, n_steps, seed, n_queries=64,
+                   model_cls="ultra.ranking_model.DNN", algo_hparams="", model_extra=""):
+    torch.manual_seed(seed)
+    random.seed(seed)
+    np.random.seed(seed)
+    ds = make_dataset(ultra, seed, n_queries, L, F)
+    exp = {
+        "learning_algorithm": ALGOS[algo_key],
+        "learning_algorithm_hparams": algo_hparams,
+        "ranking_model": model_cls,
+        "ranking_model_hparams": ("hidden_layer_sizes=%s" % json.dumps(hidden) if hidden is not None else "") + model_extra,
+        "max_candidate_num": L,
+        "selection_bias_cutoff": L,
+        "metrics": ["ndcg", "mrr", "err"],
+        "metrics_topn": [1, 3, 5, 10],
+    }
+    ds.pad(L)
+    algo = quiet(ultra.utils.find_class(exp["learning_algorithm"]), ds, exp)
+    if algo_key == "na":
+        feed = quiet(ultra.utils.find_class("ultra.input_layer.DirectLabelFeed"), algo, B, "")
+    else:
+        feed = quiet(ultra.utils.find_class("ultra.input_layer.ClickSimulationFeed"), algo, B, "")
+    rec = Recorder(algo)
+    out = {"meta": json.dumps({
+        "name": name, "algo": algo_key, "F": F, "L": L, "B": B, "hidden": hidden, "n_steps": n_steps,
+        "seed": seed, "model": model_cls.rsplit(".", 1)[1], "algo_hparams": algo_hparams,
+        "param_keys": list(algo.model.state_dict().keys()),
+        "param_shapes": [list(v.shape) for v in algo.model.state_dict().values()],
+        "lr": float(algo.learning_rate), "max_gradient_norm": float(algo.hparams.max_gradient_norm),
+    })}
+    if algo_key == "ipw":
+        out["ipw_list"] = np.asarray(algo.propensity_estimator.IPW_list, dtype=np.float64)
+    for t in range(n_steps):
+        rec.reset()
+        # DirectLabelFeed.get_batch may return < B lists (all-zero lists skipped); our
+        # synthetic lists always have a positive label so it returns exactly B.
+        input_feed, _ = feed.get_batch(ds, check_validation=True)
+        feats, docids, labels = feed_arrays(algo, input_feed, L)
+        pre = {"params": flat_params(algo.model)}
+        if algo_key in ("na", "ipw", "pairdebias", "lambdarank"):
+            pre["adagrad"] = adagrad_state(algo.optimizer_func, algo.model)
+        if algo_key in ("pairdebias", "lambdarank"):
+            pre["t_plus"] = algo.t_plus.detach().cpu().numpy().copy()
+            pre["t_minus"] = algo.t_minus.detach().cpu().numpy().copy()
+        if algo_key == "dla":
+            pre["prop_params"] = flat_params(algo.propensity_model)
+        loss, _, _ = quiet(algo.train, input_feed)
+        p = "s%d_" % t
+        out[p + "features"] = feats
+        out[p + "docids"] = docids
+        out[p + "labels"] = labels
+        for k, v in pre.items():
+            out[p + "pre_" + k] = v
+        out[p + "scores"] = rec.scores.astype(np.float32)
+        out[p + "loss"] = np.float32(loss)
+        out[p + "post_params"] = flat_params(algo.model)
+        if algo_key == "dla":
+            # clip order in dla.py:161-163: propensity model first, then ranker
+            (gp, np_), (gm, nm) = rec.clips
+            out[p + "prop_grads"] = gp
+            out[p + "prop_norm"] = np.float32(np_)
+            out[p + "grads"] = gm
+            out[p + "norm"] = np.float32(nm)
+            out[p + "post_prop_params"] = flat_params(algo.propensity_model)
+            out[p + "rank_loss"] = np.float32(algo.rank_loss.item())
+            out[p + "exam_loss"] = np.float32(algo.exam_loss.item())
+            out[p + "propensity_weights"] = algo.propensity_weights.detach().cpu().numpy().astype(np.float32)
+            out[p + "relevance_weights"] = algo.relevance_weights.detach().cpu().numpy().astype(np.float32)
+        else:
+            (g, n_), = rec.clips
+            out[p + "grads"] = g
+            out[p + "norm"] = np.float32(n_)
+            out[p + "post_adagrad"] = adagrad_state(algo.optimizer_func, algo.model)
+        if algo_key in ("pairdebias", "lambdarank"):
+            out[p + "post_t_plus"] = algo.t_plus.detach().cpu().numpy().copy()
+            out[p + "post_t_minus"] = algo.t_minus.detach().cpu().numpy().copy()
+        if algo_key == "ipw":
+            out[p + "pw"] = np.asarray(algo.propensity_weights, dtype=np.float32)  # [B, L]
+    rec.close()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in list(out.items())[:0]})
+
+
+def run_valid_case(ultra, name, F, Lmax, B, hidden, seed, list_lens, n_queries=24):
+    """validation() on ragged lists (pads present): scores, masked scores, metrics, argsort."""
+    torch.manual_seed(seed)
+    random.seed(seed)
+    np.random.seed(seed)
+    ds = make_dataset(ultra, seed, n_queries, list_lens, F)
+    exp = {
+        "learning_algorithm": ALGOS["ipw"],
+        "learning_algorithm_hparams": "",
+        "ranking_model": "ultra.ranking_model.DNN",
+        "ranking_model_hparams": "hidden_layer_sizes=%s" % json.dumps(hidden),
+        "max_candidate_num": Lmax,
+        "selection_bias_cutoff": min(10, Lmax),
+        "metrics": ["ndcg", "mrr", "err"],
+        "metrics_topn": [1, 3, 5, 10],
+    }
+    ds.pad(Lmax)
+    algo = quiet(ultra.utils.find_class(exp["learning_algorithm"]), ds, exp)
+    feed = quiet(ultra.utils.find_class("ultra.input_layer.DirectLabelFeed"), algo, B, "")
+    out = {"meta": json.dumps({
+        "name": name, "F": F, "L": Lmax, "B": B, "hidden": hidden, "seed": seed, "max_label": 4.0,
+        "metrics": exp["metrics"], "topn": exp["metrics_topn"],
+        "param_keys": list(algo.model.state_dict().keys()),
+        "param_shapes": [list(v.shape) for v in algo.model.state_dict().values()],
+    })}
+    out["params"] = flat_params(algo.model)
+    it, bi = 0, 0
+    while it < len(ds.initial_list):
+        input_feed, info = feed.get_next_batch(it, ds, check_validation=False)
+        nb = len(info["input_list"])
+        feats, docids, labels = feed_arrays(algo, input_feed, Lmax)
+        _, scores, summary = quiet(algo.validation, input_feed)
+        p = "b%d_" % bi
+        out[p + "features"] = feats
+        out[p + "docids"] = docids
+        out[p + "labels"] = labels
+        out[p + "scores"] = scores.detach().cpu().numpy().astype(np.float32)
+        masked = algo.remove_padding_for_metric_eval(algo.docid_inputs, algo.output)
+        out[p + "masked_scores"] = masked.detach().cpu().numpy().astype(np.float32)
+        # the permutation the metric code sorts with (metrics.py:208), after label validation
+        lab_t, pred_t, _, _ = ultra.utils.metrics._prepare_and_validate_params(algo.labels, masked, None, [1])
+        out[p + "argsort_desc"] = pred_t.sort(descending=True, dim=-1)[1].numpy().astype(np.int32)
+        for k, v in summary.items():
+            out[p + "metric_" + k] = np.float32(v)
+        it += nb
+        bi += 1
+    out["n_batches"] = np.int32(bi)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name)
+
+
+CASES = {
+    # tiny, two teacher-forced steps each
+    "na_tiny": lambda u: run_train_case(u, "na_tiny", "na", 136, 10, 8, [32, 16], 2, 11),
+    "ipw_tiny": lambda u: run_train_case(u, "ipw_tiny", "ipw", 136, 10, 8, [32, 16], 2, 12),
+    "dla_tiny": lambda u: run_train_case(u, "dla_tiny", "dla", 136, 10, 8, [32, 16], 2, 13),
+    "pairdebias_tiny": lambda u: run_train_case(u, "pairdebias_tiny", "pairdebias", 136, 10, 8, [32, 16], 2, 14),
+    "lambdarank_tiny": lambda u: run_train_case(u, "lambdarank_tiny", "lambdarank", 136, 10, 8, [32, 16], 2, 15),
+    # ragged / odd shapes: nothing a multiple of 4, 16 or 64
+    "ipw_odd": lambda u: run_train_case(u, "ipw_odd", "ipw", 7, 3, 5, [5], 2, 16, n_queries=16),
+    "dla_odd": lambda u: run_train_case(u, "dla_odd", "dla", 13, 7, 9, [19, 6, 3], 2, 17, n_queries=32),
+    "pairdebias_odd": lambda u: run_train_case(u, "pairdebias_odd", "pairdebias", 13, 7, 9, [19, 6, 3], 2, 18, n_queries=32),
+    "lambdarank_odd": lambda u: run_train_case(u, "lambdarank_odd", "lambdarank", 13, 7, 9, [19, 6, 3], 2, 19, n_queries=32),
+    # k = 0 (the Linear ranking model: LayerNorm -> Linear(F,1))
+    "na_linear": lambda u: run_train_case(u, "na_linear", "na", 136, 10, 8, None, 2, 20,
+                                          model_cls="ultra.ranking_model.Linear"),
+    # relu activation
+    "ipw_relu": lambda u: run_train_case(u, "ipw_relu", "ipw", 24, 10, 8, [16, 8], 1, 21,
+                                         model_extra=",activation_func=relu"),
+    # sgd strategy
+    "ipw_sgd": lambda u: run_train_case(u, "ipw_sgd", "ipw", 24, 10, 8, [16, 8], 2, 22,
+                                        algo_hparams="grad_strategy=sgd"),
+    # one config-2-shaped step (BASELINE.json configs[1]): F136 L10 B256 DNN[256,256] IPW
+    "ipw_cfg2": lambda u: run_train_case(u, "ipw_cfg2", "ipw", 136, 10, 256, [256, 256], 1, 2, n_queries=512),
+    # validation with pads
+    "valid_tiny": lambda u: run_valid_case(u, "valid_tiny", 136, 12, 8, [32, 16], 31, (2, 12)),
+    "valid_odd": lambda u: run_valid_case(u, "valid_odd", 13, 37, 5, [19, 6, 3], 32, (2, 37), n_queries=13),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    torch.set_num_threads(1)  # bit-stable fixtures (reference is deterministic at a fixed thread count)
+    ultra = import_reference()
+    for name, fn in CASES.items():
+        if args.only and args.only != name:
+            continue
+        fn(ultra)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,120 @@
+"""Pin the oracle (oracle/ultr_oracle.py) against golden vectors captured from the
+reference itself (tests/golden/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ultr_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    d = np.load(os.path.join(GOLDEN, name + ".npz"))
+    return d, json.loads(str(d["meta"]))
+
+
+def check_common(d, m, t, r, atol_scores=1e-5):
+    p = "s%d_" % t
+    np.testing.assert_allclose(r["scores"], d[p + "scores"], atol=atol_scores, rtol=0)
+    lt = 1e-5 * max(1.0, abs(float(d[p + "loss"])))
+    assert abs(r["loss"] - float(d[p + "loss"])) <= lt
+    g = d[p + "grads"]
+    np.testing.assert_allclose(r["grads"], g, rtol=1e-5, atol=1e-7 * max(1.0, float(np.abs(g).max())))
+    assert abs(r["norm"] - float(d[p + "norm"])) <= 1e-5 * max(1.0, float(d[p + "norm"]))
+    # params only where |g| is not ~0 (sign-like first Adagrad step is ill-conditioned at g~0)
+    sel = np.abs(g) > 1e-6 * max(1.0, float(np.abs(g).max()))
+    np.testing.assert_allclose(r["params"][sel], d[p + "post_params"][sel], atol=2e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["na_tiny", "ipw_tiny", "ipw_odd", "na_linear", "ipw_relu", "ipw_sgd", "ipw_cfg2"])
+def test_softmax_algorithms(name):
+    d, m = load(name)
+    hidden = m["hidden"] or []
+    act = "relu" if "relu" in name else "elu"
+    strat = "sgd" if "sgd" in name else "ada"
+    for t in range(m["n_steps"]):
+        p = "s%d_" % t
+        r = O.train_step_softmax(d[p + "pre_params"], d[p + "pre_adagrad"], m["F"], hidden, d[p + "features"],
+                                 d[p + "docids"], d[p + "labels"], ipw_list=d["ipw_list"] if m["algo"] == "ipw" else None,
+                                 lr=m["lr"], max_norm=m["max_gradient_norm"], strategy=strat, act=act)
+        check_common(d, m, t, r)
+        if m["algo"] == "ipw":
+            np.testing.assert_array_equal(r["pw"], d[p + "pw"])
+        if strat == "ada":
+            np.testing.assert_allclose(r["state"], d[p + "post_adagrad"], rtol=5e-4, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["dla_tiny", "dla_odd"])
+def test_dla(name):
+    d, m = load(name)
+    for t in range(m["n_steps"]):
+        p = "s%d_" % t
+        r = O.dla_step(d[p + "pre_params"], d[p + "pre_prop_params"], m["F"], m["hidden"], d[p + "features"],
+                       d[p + "docids"], d[p + "labels"], lr=m["lr"], max_norm=m["max_gradient_norm"])
+        check_common(d, m, t, r)
+        assert abs(r["rank_loss"] - float(d[p + "rank_loss"])) < 1e-5
+        assert abs(r["exam_loss"] - float(d[p + "exam_loss"])) < 1e-5
+        np.testing.assert_allclose(r["propensity_weights"], d[p + "propensity_weights"], rtol=1e-6)
+        np.testing.assert_allclose(r["relevance_weights"], d[p + "relevance_weights"], rtol=2e-5)
+        np.testing.assert_allclose(r["prop_grads"], d[p + "prop_grads"], rtol=1e-5, atol=1e-7)
+        assert abs(r["prop_norm"] - float(d[p + "prop_norm"])) < 1e-6
+        np.testing.assert_allclose(r["prop_params"], d[p + "post_prop_params"], atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["pairdebias_tiny", "pairdebias_odd", "lambdarank_tiny", "lambdarank_odd"])
+def test_pairwise_em(name):
+    d, m = load(name)
+    step = O.pairdebias_step if m["algo"] == "pairdebias" else O.lambdarank_step
+    for t in range(m["n_steps"]):
+        p = "s%d_" % t
+        r = step(d[p + "pre_params"], d[p + "pre_adagrad"], d[p + "pre_t_plus"], d[p + "pre_t_minus"], m["F"],
+                 m["hidden"], d[p + "features"], d[p + "docids"], d[p + "labels"], lr=m["lr"],
+                 max_norm=m["max_gradient_norm"])
+        check_common(d, m, t, r)
+        np.testing.assert_allclose(r["t_plus"], d[p + "post_t_plus"], atol=1e-6)
+        np.testing.assert_allclose(r["t_minus"], d[p + "post_t_minus"], atol=1e-6)
+        np.testing.assert_allclose(r["state"], d[p + "post_adagrad"], rtol=5e-4, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["valid_tiny", "valid_odd"])
+def test_validation(name):
+    d, m = load(name)
+    for b in range(int(d["n_batches"])):
+        p = "b%d_" % b
+        r = O.validation(d["params"], m["F"], m["hidden"], d[p + "features"], d[p + "docids"], d[p + "labels"],
+                         topn=m["topn"], max_label=m["max_label"])
+        np.testing.assert_allclose(r["scores"], d[p + "scores"], atol=1e-5)
+        np.testing.assert_allclose(r["masked"], d[p + "masked_scores"], atol=1e-5)
+        np.testing.assert_array_equal(r["argsort"], d[p + "argsort_desc"])
+        for i, n in enumerate(m["topn"]):
+            assert abs(r["ndcg"][i] - float(d[p + "metric_ndcg_%d" % n])) < 1e-6
+            assert abs(r["mrr"][i] - float(d[p + "metric_mrr_%d" % n])) < 1e-6
+            assert abs(r["err"][i] - float(d[p + "metric_err_%d" % n])) < 1e-6
+
+
+def test_manual_backward_matches_autograd():
+    """The written-out backward (kernel spec) == autograd of the forward restatement."""
+    d, m = load("ipw_tiny")
+    x = O.gather_rows(d["s0_features"], d["s0_docids"])
+    p = torch.tensor(d["s0_pre_params"], requires_grad=True)
+    s = O.dnn_forward(p, m["F"], m["hidden"], x)
+    ds = torch.randn(s.shape, generator=torch.Generator().manual_seed(0))
+    (g,) = torch.autograd.grad((s * ds).sum(), p)
+    gm = O.dnn_backward_manual(d["s0_pre_params"], m["F"], m["hidden"], x.numpy(), ds.numpy())
+    np.testing.assert_allclose(gm, g.numpy(), rtol=2e-4, atol=2e-5)
+
+
+def test_softmax_closed_form():
+    d, m = load("ipw_tiny")
+    s = torch.tensor(d["s0_scores"], requires_grad=True)
+    y = torch.from_numpy(d["s0_labels"].T.copy())
+    pw = torch.from_numpy(d["s0_pw"])
+    loss = O.softmax_loss(s, y, pw)
+    (g,) = torch.autograd.grad(loss, s)
+    l2, g2, D = O.softmax_loss_closed_form(d["s0_scores"], d["s0_labels"].T, d["s0_pw"])
+    assert abs(l2 - float(loss.detach())) < 1e-6
+    np.testing.assert_allclose(g2, g.numpy(), atol=1e-7)
