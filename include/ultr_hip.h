@@ -1,0 +1,186 @@
+/*
+ * ultr_hip.h — C ABI of libultr_hip.so, the MI355X (gfx950) hot path of the unbiased
+ * learning-to-rank engine.
+ *
+ * This is the drop-in boundary.  Every entry point replaces one stretch of the
+ * reference's (ULTR-Community/ULTRA_pytorch) pure-PyTorch hot path; the reference
+ * file:line each one stands in for is cited on the declaration.  The Python plugin
+ * classes in ultra_pytorch_amd/ (same constructor / train / validation / build
+ * contracts as ultra.learning_algorithm.* and ultra.ranking_model.DNN) bind these
+ * symbols with ctypes — see INTEGRATION.md for the stub a reference maintainer adds.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes.  No torch types.
+ *   - ALL data pointers are DEVICE pointers owned by the caller, fp32 unless noted.
+ *   - Every function enqueues work on `stream` (a hipStream_t passed as void*) and
+ *     returns immediately: 0 on success, a hipError_t value (>0) on a HIP failure,
+ *     or a negative ULTR_E_* code for a bad argument.  Nothing throws, nothing syncs,
+ *     nothing allocates: scratch comes from caller-provided workspaces sized by the
+ *     ultr_*_workspace_bytes() queries (host-only arithmetic, callable without a GPU).
+ *   - Layouts follow the reference's feed (click_simulation_feed.py:141-156):
+ *       features  [n_docs, F]   row-major; the PAD document has id == n_docs and is an
+ *                               all-zero row that is NOT stored (base_algorithm.py:148-149)
+ *       docids    [L, B] int32  position-major (docid_input{l}[b])
+ *       labels    [L, B]        position-major (label{l}[b]) — clicks or relevance
+ *       scores    [B, L]        list-major, what BaseAlgorithm.ranking_model returns
+ *                               (base_algorithm.py:118-132)
+ *     Internally a "row" is one (query, position) document: row n = b*L + l.
+ *   - Parameters travel as ONE flat fp32 vector in the reference's state_dict order
+ *     (DNN.py:41-55): for j = 0..k:  layer_norm{j}.weight[K_j], layer_norm{j}.bias[K_j],
+ *     linear{j}.weight[M_j,K_j] row-major, linear{j}.bias[M_j]; K_0 = F, M_k = 1.
+ */
+#ifndef ULTR_HIP_H
+#define ULTR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ULTR_ABI_VERSION 1
+#define ULTR_MAX_HIDDEN 7 /* hidden layers; Linear layers = hidden + 1 <= 8 */
+
+#define ULTR_E_BADARG (-1)
+#define ULTR_E_UNSUPPORTED (-2)
+#define ULTR_E_WORKSPACE (-3)
+
+enum ultr_activation { ULTR_ACT_ELU = 0, ULTR_ACT_RELU = 1 };
+
+/* DNN.__init__ hyper-parameters (DNN.py:25-38).  norm is always 'layer'
+ * (LayerNorm before EVERY Linear, DNN.py:43-47). */
+typedef struct ultr_dnn_desc {
+  int32_t feature_size;            /* F = K_0 */
+  int32_t n_hidden;                /* k; 0 reproduces ultra.ranking_model.Linear */
+  int32_t hidden[ULTR_MAX_HIDDEN]; /* hidden_layer_sizes */
+  int32_t activation;              /* ultr_activation */
+} ultr_dnn_desc;
+
+/* ---- host-only queries ------------------------------------------------------------- */
+int ultr_abi_version(void);
+/* number of fp32 parameters P (0 on bad desc) */
+int64_t ultr_dnn_param_count(const ultr_dnn_desc* d);
+/* offsets[4*(k+1)] of ln.weight, ln.bias, linear.weight, linear.bias per layer */
+int ultr_dnn_param_offsets(const ultr_dnn_desc* d, int64_t* offsets);
+/* bytes of `saved` (activations + LayerNorm statistics kept by a training forward) */
+int64_t ultr_dnn_saved_bytes(const ultr_dnn_desc* d, int64_t n_rows);
+/* bytes of `bwd_ws` (dz buffers + deterministic partial-sum slabs) */
+int64_t ultr_dnn_bwd_workspace_bytes(const ultr_dnn_desc* d, int64_t n_rows);
+/* floats in the step vector that follows the P gradients in `grads` (see ultr_dnn_backward) */
+int64_t ultr_step_tail_floats(int32_t list_size);
+/* bytes of `loss_ws` for B lists of size L */
+int64_t ultr_loss_workspace_bytes(int64_t batch, int32_t list_size);
+
+/* ---- a2 + a3: gather + DNN forward --------------------------------------------------
+ * Replaces BaseAlgorithm.get_ranking_scores + ranking_model (base_algorithm.py:118-154)
+ * and DNN.build (DNN.py:58-88): np.take of feature rows (zero PAD row for id == n_docs),
+ * then [LayerNorm -> Linear -> act] x k -> LayerNorm -> Linear(.,1), scores as [B, L].
+ * saved == NULL: inference (validation) forward; otherwise activations and LayerNorm
+ * statistics are kept for ultr_dnn_backward. */
+int ultr_dnn_forward(const ultr_dnn_desc* d, const float* params, const float* features, int64_t n_docs,
+                     const int32_t* docids, int32_t batch, int32_t list_size, float* scores, void* saved,
+                     void* stream);
+
+/* ---- a5 (backward half): what loss.backward() does for the DNN ----------------------
+ * Replaces autograd through DNN.sequential (called from BaseAlgorithm.opt_step,
+ * base_algorithm.py:208-226).  Input dscores[B, L] = d(loss)/d(scores) up to the scalar
+ * factor the loss kernels keep separate (see tail).  Output grads[P + tail]: the flat
+ * parameter gradient (UNSCALED) followed by the step vector `tail` =
+ *   [0] loss_sum  [1] D  [2] loss2_sum  [3] D2  [4..4+2L) per-position sums
+ * copied (summed in fixed order) from the loss workspace `loss_ws`.  Per-block partial sums of
+ * squares of the P unscaled gradients are left at the head of bwd_ws (single-GPU fast path).
+ * The whole buffer grads[0 .. P+tail) is what a data-parallel caller all-reduces; it then calls
+ * ultr_grad_sumsq to refresh the partials before ultr_apply_update. */
+int ultr_dnn_backward(const ultr_dnn_desc* d, const float* params, const float* features, int64_t n_docs,
+                      const int32_t* docids, int32_t batch, int32_t list_size, const void* saved,
+                      const float* dscores, const void* loss_ws, void* bwd_ws, float* grads, void* stream);
+
+/* partial sums of squares of grads[0..P) -> head of bwd_ws; only needed after an all-reduce */
+int ultr_grad_sumsq(float* grads, int64_t n_params, int32_t list_size, void* bwd_ws, void* stream);
+
+/* ---- a4 / a7 / a8: listwise softmax cross entropy (NA, IPW) -------------------------
+ * Replaces BaseAlgorithm.softmax_loss + softmax_cross_entropy_with_logits
+ * (base_algorithm.py:18-30, 309-330) and, when ipw_table != NULL, the per-list Python loop
+ * over BasicPropensityEstimator.getPropensityForOneList (ipw_rank.py:115-128,
+ * propensity_estimator.py:22-42):  pw[b,l] = labels[l,b] > 0 ? ipw_table[min(l,n_ipw-1)] : 0.
+ * pw (explicit [B, L] weights) and ipw_table may both be NULL (NA: weights = 1).
+ * Writes dscores[b,l] = softmax(s_b)_l * S_b - w_bl   (the gradient times the global
+ * normaliser D = sum w) and per-workgroup partial sums of (loss_sum, D) into loss_ws. */
+int ultr_softmax_ce(const float* scores, const float* labels, const float* pw, const float* ipw_table,
+                    int32_t n_ipw, int32_t batch, int32_t list_size, float* dscores, void* loss_ws, void* stream);
+
+/* ---- a9: DLA dual loss ---------------------------------------------------------------
+ * Replaces DLA.train's loss section (dla.py:196-237) + DenoisingNet.forward (dla.py:33-48)
+ * + get_normalized_weights (dla.py:287-306).  prop_params = [W(L) | bias] of the
+ * DenoisingNet's Linear(L,1).  logits_to_prob: 0 softmax, 1 sigmoid (dla.py:21-22).
+ * dscores = rank-loss gradient x D_rank (the ranker_loss_weight is applied by the update);
+ * loss_ws gets (rank_loss_sum, D_rank, exam_loss_sum, D_exam) and the per-position sums of
+ * d(exam_loss)/d(propensity) x D_exam. */
+int ultr_dla_loss(const float* scores, const float* labels, const float* prop_params, int32_t logits_to_prob,
+                  int32_t batch, int32_t list_size, float* dscores, void* loss_ws, void* stream);
+
+/* ---- a10: PairDebias pairwise loss ---------------------------------------------------
+ * Replaces the 2-level Python pair loop of PairDebias.train (pairwise_debias.py:142-157)
+ * + pairwise_cross_entropy_loss (base_algorithm.py:228-248), including the reference's xB
+ * broadcast inflation; `batch_total` is the GLOBAL batch size (== batch on one GPU).
+ * loss_ws gets loss_sum and the per-position t_plus_loss / t_minus_loss sums. */
+int ultr_pairdebias_loss(const float* scores, const float* labels, const float* t_plus, const float* t_minus,
+                         int32_t batch, int32_t list_size, int32_t batch_total, float* dscores, void* loss_ws,
+                         void* stream);
+
+/* ---- a11: LambdaRank -----------------------------------------------------------------
+ * Replaces LambdaRank.train's loss section (lambda_rank.py:116-135) + dcg/compute_delta_ndcg
+ * (lambda_rank.py:247-291): per-list descending sort, pairwise delta-NDCG-weighted
+ * BCE-with-logits on sigma(s_i - s_j), batch-global natural-log IDCG (kept separate as D). */
+int ultr_lambdarank_loss(const float* scores, const float* labels, const float* t_plus, const float* t_minus,
+                         float sigma, int32_t batch, int32_t list_size, float* dscores, void* loss_ws,
+                         void* stream);
+
+/* ---- a5 (clip) + a6 (optimizer) + EM / propensity updates ----------------------------
+ * Replaces torch.nn.utils.clip_grad_norm_ + Adagrad.step / SGD.step
+ * (base_algorithm.py:223-226; ipw_rank.py:96), DLA.separate_gradient_update
+ * (dla.py:141-177: per-model clip, fresh = stateless Adagrad), and the t_plus/t_minus EM
+ * updates (pairwise_debias.py:159-163, lambda_rank.py:136-142). */
+enum ultr_algo { ULTR_ALGO_SOFTMAX = 0, ULTR_ALGO_DLA = 1, ULTR_ALGO_PAIRDEBIAS = 2, ULTR_ALGO_LAMBDARANK = 3 };
+enum ultr_opt { ULTR_OPT_ADAGRAD = 0, ULTR_OPT_SGD = 1 };
+
+typedef struct ultr_update_desc {
+  int32_t algo;            /* ultr_algo */
+  int32_t optimizer;       /* ultr_opt (grad_strategy 'ada' / 'sgd') */
+  int32_t list_size;       /* L */
+  int32_t logits_to_prob;  /* DLA only */
+  int64_t n_params;        /* P */
+  float learning_rate;
+  float max_gradient_norm; /* <= 0 disables clipping */
+  float adagrad_eps;       /* 1e-10 */
+  float ranker_loss_weight;     /* DLA */
+  float propensity_learning_rate; /* DLA */
+  float em_step_size;      /* PairDebias / LambdaRank */
+  float regulation_p;      /* PairDebias / LambdaRank */
+  float reserved;
+} ultr_update_desc;
+
+/* params/state [P] updated in place; grads = the buffer ultr_dnn_backward filled (possibly
+ * all-reduced).  aux = prop_params[L+1] (DLA) or [t_plus(L) | t_minus(L)] (PairDebias /
+ * LambdaRank), updated in place; NULL for SOFTMAX.  bwd_ws = the workspace ultr_dnn_backward (or
+ * ultr_grad_sumsq) left the sum-of-squares partials in.
+ * scalars_out[8]: [0] loss [1] ranker grad norm (pre-clip) [2] clip coef [3] D
+ *                 [4] rank_loss (DLA) [5] exam_loss (DLA) [6] propensity grad norm (DLA) [7] sum g^2 */
+int ultr_apply_update(const ultr_update_desc* u, float* params, float* state, const float* grads, float* aux,
+                      const void* bwd_ws, float* scalars_out, void* stream);
+
+/* ---- a12 + a13: validation metrics ---------------------------------------------------
+ * Replaces remove_padding_for_metric_eval (base_algorithm.py:88-116) and
+ * normalized_discounted_cumulative_gain (metrics.py:191-265, 456-495):  pads
+ * (docid == n_docs) -> -100000, labels < 0 -> label 0 / score rowmin-1e-6, stable descending
+ * sort, gains 2^l - 1, log2 discounts, topn clipped to L, mean over the batch.
+ * ndcg_out[n_topn]; order_out (may be NULL) [B, L] int32 = the descending permutation;
+ * masked_out (may be NULL) [B, L] = the masked scores.  ndcg_ws: batch*n_topn floats. */
+int ultr_ndcg(const float* scores, const float* labels, const int32_t* docids, int64_t n_docs, int32_t batch,
+              int32_t list_size, const int32_t* topn, int32_t n_topn, float* ndcg_out, int32_t* order_out,
+              float* masked_out, float* ndcg_ws, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ULTR_HIP_H */

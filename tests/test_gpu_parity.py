@@ -1,0 +1,224 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against
+  (1) the golden vectors captured from the reference, stage by stage, and
+  (2) the oracle on seeded inputs at other shapes (incl. BASELINE configs' layer shapes).
+Tolerances (fp32): scores 1e-5 abs; loss 1e-5 (relative for |loss| > 1); gradients 1e-5 rel + 1e-6*max|g| abs;
+EM state 1e-6; NDCG values 1e-6 with the identical permutation."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.hipref import HipRun, dev, load_golden  # noqa: E402
+
+ALGO = {"na": "softmax", "ipw": "softmax", "dla": "dla", "pairdebias": "pairdebias", "lambdarank": "lambdarank"}
+TRAIN_CASES = ["na_tiny", "ipw_tiny", "dla_tiny", "pairdebias_tiny", "lambdarank_tiny", "ipw_odd", "dla_odd",
+               "pairdebias_odd", "lambdarank_odd", "na_linear", "ipw_relu", "ipw_sgd", "ipw_cfg2"]
+
+
+def gtol(g):
+    return dict(rtol=1e-5, atol=1e-6 * max(1.0, float(np.abs(g).max())))
+
+
+def make_run(m, name):
+    kw = dict(learning_rate=m["lr"], max_gradient_norm=m["max_gradient_norm"])
+    if "sgd" in name:
+        kw["optimizer"] = "sgd"
+    return HipRun(m["F"], m["hidden"] or [], m["B"], m["L"], algo=ALGO[m["algo"]], act="relu" if "relu" in name else "elu", **kw)
+
+
+def gscale_and_loss(algo, tail, rw=1.0):
+    loss_sum, D, loss2, D2 = [float(x) for x in tail[:4]]
+    if algo in ("na", "ipw"):
+        return 1.0 / D, loss_sum / D
+    if algo == "dla":
+        return rw / D, loss2 / D2 + rw * loss_sum / D
+    if algo == "pairdebias":
+        return 1.0, loss_sum
+    return 1.0 / D, loss_sum / D
+
+
+@pytest.mark.parametrize("name", TRAIN_CASES)
+def test_golden_train_step(name):
+    d, m = load_golden(name)
+    run = make_run(m, name)
+    L = m["L"]
+    for t in range(m["n_steps"]):
+        p = "s%d_" % t
+        run.set_inputs(d[p + "features"], d[p + "docids"], d[p + "labels"])
+        # --- forward
+        scores = run.forward(d[p + "pre_params"])
+        np.testing.assert_allclose(scores, d[p + "scores"], atol=1e-5, rtol=0, err_msg="scores")
+        # --- loss (fed with the HIP scores)
+        aux = None
+        if m["algo"] == "dla":
+            aux = d[p + "pre_prop_params"]
+        elif m["algo"] in ("pairdebias", "lambdarank"):
+            aux = np.concatenate([d[p + "pre_t_plus"].ravel(), d[p + "pre_t_minus"].ravel()])
+        ipw = d["ipw_list"] if m["algo"] == "ipw" else None
+        ds, tail = run.loss(aux=aux, ipw_table=ipw)
+        gs, loss = gscale_and_loss(m["algo"], tail)
+        ref_loss = float(d[p + "loss"])
+        assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), ("loss", loss, ref_loss)
+        # --- backward
+        g, tail2 = run.backward()
+        np.testing.assert_allclose(tail2, tail, rtol=1e-6, atol=1e-6)
+        gref = d[p + "grads"]
+        np.testing.assert_allclose(g * gs, gref, err_msg="grads", **gtol(gref))
+        # --- update
+        state = d[p + "pre_adagrad"] if (p + "pre_adagrad") in d.files else None
+        params, state2, aux2, sc = run.update(state)
+        assert abs(sc[0] - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss))
+        assert abs(sc[1] - float(d[p + "norm"])) <= 1e-5 * max(1.0, float(d[p + "norm"]))
+        sel = np.abs(gref) > 1e-6 * max(1.0, float(np.abs(gref).max()))
+        np.testing.assert_allclose(params[sel], d[p + "post_params"][sel], atol=2e-6, rtol=1e-5, err_msg="params")
+        if m["algo"] in ("pairdebias", "lambdarank"):
+            np.testing.assert_allclose(aux2[:L], d[p + "post_t_plus"].ravel(), atol=1e-6)
+            np.testing.assert_allclose(aux2[L:], d[p + "post_t_minus"].ravel(), atol=1e-6)
+        if m["algo"] == "dla":
+            np.testing.assert_allclose(aux2, d[p + "post_prop_params"], atol=1e-6)
+            assert abs(sc[6] - float(d[p + "prop_norm"])) < 1e-6
+            assert abs(sc[4] - float(d[p + "rank_loss"])) < 1e-5 and abs(sc[5] - float(d[p + "exam_loss"])) < 1e-5
+        if state is not None and "sgd" not in name:
+            np.testing.assert_allclose(state2, d[p + "post_adagrad"], rtol=5e-4, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["valid_tiny", "valid_odd"])
+def test_golden_validation(name):
+    from ultra_pytorch_amd import engine, hip_ops
+    d, m = load_golden(name)
+    shape = hip_ops.DnnShape(m["F"], m["hidden"], "elu")
+    params = dev(d["params"])
+    for b in range(int(d["n_batches"])):
+        p = "b%d_" % b
+        docids = d[p + "docids"]
+        L, B = docids.shape
+        ev = engine.EvalEngine(shape, B, L, torch.device("cuda"), topn=m["topn"])
+        feats = d[p + "features"]
+        scores, nd = ev.run(params, dev(feats), feats.shape[0], dev(docids, torch.int32), dev(d[p + "labels"]))
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(scores.cpu().numpy(), d[p + "scores"], atol=1e-5)   # UNMASKED scores returned
+        np.testing.assert_allclose(ev.masked.cpu().numpy(), d[p + "masked_scores"], atol=1e-5)
+        np.testing.assert_array_equal(ev.order.cpu().numpy(), d[p + "argsort_desc"])  # bit-exact ordering
+        for i, n in enumerate(m["topn"]):
+            assert abs(float(nd[i]) - float(d[p + "metric_ndcg_%d" % n])) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------
+# oracle parity at other shapes (all tile paths: R=16/32, CT=1/2/4, vec/scalar, ragged edges)
+# ------------------------------------------------------------------------------------------------
+SHAPES = [
+    # F, hidden, B, L
+    (136, [256, 256], 64, 10),        # config 2 layers, smaller batch
+    (136, [512, 256, 128], 48, 20),   # config 3 layers
+    (700, [512, 256, 128], 16, 50),   # config 4 layers
+    (136, [256, 256], 900, 10),       # > 512 row blocks -> 32-row workgroups
+    (20, [64], 7, 3),
+    (33, [17, 9], 5, 4),              # nothing aligned
+    (136, [], 32, 10),                # Linear model
+]
+
+
+def synth(F, B, L, seed):
+    rng = np.random.RandomState(seed)
+    n_docs = B * L - 3 if B * L > 8 else B * L
+    feats = rng.uniform(-1, 1, size=(n_docs, F)).astype(np.float32)
+    ids = rng.permutation(B * L)
+    ids = np.where(ids >= n_docs, n_docs, ids).astype(np.int32).reshape(L, B)  # a few PAD docs
+    labels = (rng.uniform(size=(L, B)) < 0.3).astype(np.float32)
+    labels[0, :] = 1.0
+    return feats, ids, labels
+
+
+@pytest.mark.parametrize("F,hidden,B,L", SHAPES)
+def test_oracle_forward_backward(F, hidden, B, L):
+    from oracle import ultr_oracle as O
+    feats, ids, labels = synth(F, B, L, 5)
+    params = O.init_params(F, hidden, seed=3)
+    rng = np.random.RandomState(9)
+    # non-trivial LayerNorm affine parameters
+    for name, shape, off in O.param_layout(F, hidden):
+        if "layer_norm" in name:
+            n = int(np.prod(shape))
+            params[off:off + n] += rng.uniform(-0.3, 0.3, size=n).astype(np.float32)
+    run = HipRun(F, hidden, B, L)
+    run.set_inputs(feats, ids, labels)
+    scores = run.forward(params)
+    p = torch.tensor(params, requires_grad=True)
+    ref = O.ranking_scores(p, F, hidden, feats, ids)
+    np.testing.assert_allclose(scores, ref.detach().numpy(), atol=1e-5, rtol=1e-5)
+    ds = rng.normal(size=(B, L)).astype(np.float32)
+    (gref,) = torch.autograd.grad((ref * torch.tensor(ds)).sum(), p)
+    g, _ = run.backward(dscores=ds)
+    gref = gref.numpy()
+    np.testing.assert_allclose(g, gref, rtol=2e-5, atol=2e-6 * max(1.0, float(np.abs(gref).max())))
+
+
+@pytest.mark.parametrize("algo,B,L", [("softmax", 37, 10), ("softmax", 5, 100), ("dla", 33, 20), ("pairdebias", 18, 50),
+                                      ("lambdarank", 18, 50), ("lambdarank", 3, 70), ("pairdebias", 2, 130)])
+def test_oracle_losses(algo, B, L):
+    from oracle import ultr_oracle as O
+    rng = np.random.RandomState(B * 131 + L)
+    scores = rng.normal(size=(B, L)).astype(np.float32)
+    labels_LB = (rng.uniform(size=(L, B)) < 0.3).astype(np.float32)
+    if algo == "lambdarank":
+        labels_LB = rng.randint(0, 5, size=(L, B)).astype(np.float32)
+    labels_LB[0, :] = np.maximum(labels_LB[0, :], 1.0)
+    run = HipRun(8, [4], B, L, algo=algo)
+    run.set_inputs(np.zeros((1, 8), np.float32), np.zeros((L, B), np.int32), labels_LB)
+    s = torch.tensor(scores, requires_grad=True)
+    y = torch.tensor(labels_LB.T.copy())
+    tp = torch.tensor(rng.uniform(0.8, 1.2, size=L).astype(np.float32))
+    tm = torch.tensor(rng.uniform(0.8, 1.2, size=L).astype(np.float32))
+    if algo == "softmax":
+        ipw = rng.uniform(1, 10, size=40)
+        pw = O.ipw_weights(labels_LB, ipw)
+        loss = O.softmax_loss(s, y, pw)
+        ds, tail = run.loss(ipw_table=ipw, scores=scores)
+        gs, hl = 1.0 / tail[1], tail[0] / tail[1]
+    elif algo == "dla":
+        q = torch.tensor(rng.normal(scale=0.3, size=L + 1).astype(np.float32), requires_grad=True)
+        prop = O.denoising_net(q, B, L)
+        with torch.no_grad():
+            pw = O.normalized_weights(torch.softmax(prop, -1))
+            rw = O.normalized_weights(torch.softmax(s, -1))
+        rank = O.softmax_loss(s, y, pw)
+        exam = O.softmax_loss(prop, y, rw)
+        (gprop,) = torch.autograd.grad(exam, prop, retain_graph=True)
+        loss = rank
+        ds, tail = run.loss(aux=q.detach().numpy(), scores=scores)
+        gs, hl = 1.0 / tail[1], tail[0] / tail[1]
+        assert abs(tail[2] / tail[3] - float(exam)) < 1e-5
+        np.testing.assert_allclose(tail[4:4 + L] / tail[3], gprop.sum(0).numpy(), rtol=1e-4, atol=1e-6)
+    elif algo == "pairdebias":
+        loss, PL, tpl, tml = O.pairdebias_loss(s, torch.tensor(labels_LB), tp, tm)
+        ds, tail = run.loss(aux=np.concatenate([tp.numpy(), tm.numpy()]), scores=scores)
+        gs, hl = 1.0, tail[0]
+        np.testing.assert_allclose(tail[4:4 + L], tpl.detach().numpy(), rtol=2e-5, atol=1e-3)
+        np.testing.assert_allclose(tail[4 + L:4 + 2 * L], tml.detach().numpy(), rtol=2e-5, atol=1e-3)
+    else:
+        loss, PL, tpl, tml = O.lambdarank_loss(s, y, tp, tm, 1.0)
+        ds, tail = run.loss(aux=np.concatenate([tp.numpy(), tm.numpy()]), scores=scores)
+        gs, hl = 1.0 / tail[1], tail[0] / tail[1]
+        np.testing.assert_allclose(tail[4:4 + L] / tail[1], tpl.detach().numpy(), rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(tail[4 + L:4 + 2 * L] / tail[1], tml.detach().numpy(), rtol=2e-5, atol=1e-6)
+    (g,) = torch.autograd.grad(loss, s)
+    assert abs(hl - float(loss)) <= 1e-5 * max(1.0, abs(float(loss)))
+    g = g.numpy()
+    np.testing.assert_allclose(ds * gs, g, rtol=2e-5, atol=2e-6 * max(1.0, float(np.abs(g).max())))
+
+
+def test_determinism_bitwise():
+    """Same inputs twice -> bit-identical gradients and parameters (no atomics anywhere)."""
+    d, m = load_golden("ipw_cfg2")
+    outs = []
+    for _ in range(2):
+        run = make_run(m, "ipw_cfg2")
+        run.set_inputs(d["s0_features"], d["s0_docids"], d["s0_labels"])
+        run.forward(d["s0_pre_params"])
+        run.loss(ipw_table=d["ipw_list"])
+        g, _ = run.backward()
+        params, state, _, sc = run.update(d["s0_pre_adagrad"])
+        outs.append((g.copy(), params.copy(), state.copy(), sc.copy()))
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)

@@ -1,0 +1,101 @@
+"""ctypes binding of libultr_hip.so (the C ABI declared in include/ultr_hip.h).
+
+The reference-side stub shown in INTEGRATION.md is this file minus the conveniences.
+Fails loudly when the library is missing — there is no fallback path.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libultr_hip.so")
+
+ULTR_MAX_HIDDEN = 7
+ACT = {"elu": 0, "relu": 1}
+ALGO_SOFTMAX, ALGO_DLA, ALGO_PAIRDEBIAS, ALGO_LAMBDARANK = 0, 1, 2, 3
+OPT_ADAGRAD, OPT_SGD = 0, 1
+
+c_i32, c_i64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+
+class DnnDesc(ctypes.Structure):
+    _fields_ = [("feature_size", c_i32), ("n_hidden", c_i32), ("hidden", c_i32 * ULTR_MAX_HIDDEN), ("activation", c_i32)]
+
+
+class UpdateDesc(ctypes.Structure):
+    _fields_ = [("algo", c_i32), ("optimizer", c_i32), ("list_size", c_i32), ("logits_to_prob", c_i32),
+                ("n_params", c_i64), ("learning_rate", c_f32), ("max_gradient_norm", c_f32), ("adagrad_eps", c_f32),
+                ("ranker_loss_weight", c_f32), ("propensity_learning_rate", c_f32), ("em_step_size", c_f32),
+                ("regulation_p", c_f32), ("reserved", c_f32)]
+
+
+# name -> (restype, argtypes); must list EVERY symbol include/ultr_hip.h declares
+SIGNATURES = {
+    "ultr_abi_version": (c_i32, []),
+    "ultr_dnn_param_count": (c_i64, [ctypes.POINTER(DnnDesc)]),
+    "ultr_dnn_param_offsets": (c_i32, [ctypes.POINTER(DnnDesc), ctypes.POINTER(c_i64)]),
+    "ultr_dnn_saved_bytes": (c_i64, [ctypes.POINTER(DnnDesc), c_i64]),
+    "ultr_dnn_bwd_workspace_bytes": (c_i64, [ctypes.POINTER(DnnDesc), c_i64]),
+    "ultr_step_tail_floats": (c_i64, [c_i32]),
+    "ultr_loss_workspace_bytes": (c_i64, [c_i64, c_i32]),
+    "ultr_dnn_forward": (c_i32, [ctypes.POINTER(DnnDesc), c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "ultr_dnn_backward": (c_i32, [ctypes.POINTER(DnnDesc), c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp,
+                                  c_vp, c_vp]),
+    "ultr_grad_sumsq": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp]),
+    "ultr_softmax_ce": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "ultr_dla_loss": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "ultr_pairdebias_loss": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "ultr_lambdarank_loss": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "ultr_apply_update": (c_i32, [ctypes.POINTER(UpdateDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "ultr_ndcg": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, ctypes.POINTER(c_i32), c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+}
+
+_LIB = None
+
+
+def load(path=None):
+    """dlopen libultr_hip.so and type every entry point.  Raises if it is missing."""
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            "libultr_hip.so not found at %s — build it first: python -c 'import __graft_entry__ as g; g.build()' "
+            "(ultra_pytorch_amd has no CPU fallback)" % p)
+    try:  # make sure the HIP runtime the process will use is torch's (same SONAME libamdhip64.so.7)
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - symbol checks work without torch
+        pass
+    lib = ctypes.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _LIB = lib
+    return lib
+
+
+def make_desc(feature_size, hidden, activation="elu"):
+    hidden = list(hidden or [])
+    if len(hidden) > ULTR_MAX_HIDDEN:
+        raise ValueError("at most %d hidden layers are supported" % ULTR_MAX_HIDDEN)
+    if activation not in ACT:
+        raise ValueError("activation_func must be one of %s (got %r)" % (sorted(ACT), activation))
+    d = DnnDesc()
+    d.feature_size = int(feature_size)
+    d.n_hidden = len(hidden)
+    for i, h in enumerate(hidden):
+        d.hidden[i] = int(h)
+    d.activation = ACT[activation]
+    return d
+
+
+class UltrHipError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = {-1: "bad argument", -2: "unsupported shape", -3: "workspace too small"}.get(rc, "hipError_t %d" % rc)
+        raise UltrHipError("%s failed: %s" % (what, kind))

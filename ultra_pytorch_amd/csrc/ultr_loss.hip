@@ -1,0 +1,409 @@
+// ultr_loss.hip — gfx950 list-level loss kernels (reference ultra/learning_algorithm/*.py)
+//
+// One 64-lane wavefront owns one ranked list: its scores / labels are staged in LDS, list-level
+// reductions (softmax max/sum, pair sums, rank-by-counting sort) are wavefront shuffles — no atomics, no
+// cross-workgroup traffic.  A workgroup = 4 wavefronts = 4 lists and emits ONE partial "step tail"
+// [loss_sum, D, loss2_sum, D2, per-position sums (2L)] that the gradient reduction adds up in fixed order,
+// so every step is bit-reproducible.  The global normalisers (D) are NOT applied here: the kernels emit
+// d(loss)/d(scores) x D, the update kernel applies 1/D — this is what makes the data-parallel all-reduce
+// exact and saves a grid-wide barrier on one GPU.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ultr_hip.h"
+#include "ultr_device.h"
+#include "ultr_plan.h"
+
+#define LPW ULTR_LOSS_LISTS_PER_WG  // lists (= waves) per workgroup
+
+extern "C" int64_t ultr_loss_workspace_bytes(int64_t batch, int32_t list_size) {
+  if (batch <= 0 || list_size <= 0) return 0;
+  return (ultr_loss_parts(batch) * ultr_tail_len(list_size) + 4) * (int64_t)sizeof(float);
+}
+
+// sum the per-wave tails of a workgroup in fixed order and store the workgroup's partial
+__device__ __forceinline__ void store_wg_tail(const float* sm_tail /*[LPW][tail]*/, int tail, float* part) {
+  __syncthreads();
+  for (int t = threadIdx.x; t < tail; t += blockDim.x) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < LPW; ++w) s += sm_tail[w * tail + t];
+    part[t] = s;
+  }
+}
+
+__device__ __forceinline__ float softplus_pair(float x) {
+  // log(1 + exp(x)) = -log_softmax([s_i, s_j])[0] with x = s_j - s_i   (base_algorithm.py:228-248)
+  return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ------------------------------------------------------------------------------------------------
+// a4/a7/a8: softmax cross entropy with (IPW) weights          base_algorithm.py:309-330
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LPW * 64) void softmax_ce_kernel(const float* __restrict__ scores,
+                                                             const float* __restrict__ labels,
+                                                             const float* __restrict__ pw,
+                                                             const float* __restrict__ ipw, int n_ipw, int B, int L,
+                                                             float* __restrict__ dscores, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tail = (int)ultr_tail_len(L);
+  float* sm_tail = smem;                       // [LPW][tail]
+  float* sm_s = sm_tail + LPW * tail;          // [LPW][L]
+  float* sm_w = sm_s + LPW * L;                // [LPW][L]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * LPW + wave;
+  float* ms = sm_s + wave * L;
+  float* mw = sm_w + wave * L;
+  float* mt = sm_tail + wave * tail;
+  for (int t = lane; t < tail; t += 64) mt[t] = 0.f;
+  if (b < B) {
+    float mx = -INFINITY, S = 0.f;
+    for (int l = lane; l < L; l += 64) {
+      const float s = scores[(int64_t)b * L + l];
+      const float y = labels[(int64_t)l * B + b];
+      float p = 1.0f;
+      if (pw != nullptr) p = pw[(int64_t)b * L + l];
+      else if (ipw != nullptr) p = (y > 0.f) ? ipw[l < n_ipw ? l : n_ipw - 1] : 0.f;  // propensity_estimator.py:22-42
+      const float w = (y + 0.0000001f) * p;  // the reference's 1e-7 smoothing
+      ms[l] = s;
+      mw[l] = w;
+      mx = fmaxf(mx, s);
+      S += w;
+    }
+    mx = wave_max(mx);
+    S = wave_sum(S);
+    float se = 0.f;
+    for (int l = lane; l < L; l += 64) se += expf(ms[l] - mx);
+    const float lse = mx + logf(wave_sum(se));
+    float lb = 0.f;
+    for (int l = lane; l < L; l += 64) {
+      const float s = ms[l], w = mw[l];
+      lb += w * (lse - s);                                   // -w * log_softmax(s)
+      dscores[(int64_t)b * L + l] = expf(s - lse) * S - w;   // x D
+    }
+    lb = wave_sum(lb);
+    if (lane == 0) {
+      mt[0] = lb;
+      mt[1] = S;
+    }
+  }
+  store_wg_tail(sm_tail, tail, part + (int64_t)blockIdx.x * tail);
+}
+
+extern "C" int ultr_softmax_ce(const float* scores, const float* labels, const float* pw, const float* ipw_table,
+                               int32_t n_ipw, int32_t batch, int32_t list_size, float* dscores, void* loss_ws,
+                               void* stream) {
+  if (!scores || !labels || !dscores || !loss_ws || batch <= 0 || list_size <= 0 || (ipw_table && n_ipw <= 0))
+    return ULTR_E_BADARG;
+  const int tail = (int)ultr_tail_len(list_size);
+  const size_t lds = (size_t)LPW * (tail + 2 * list_size) * sizeof(float);
+  if (lds > 64 * 1024) return ULTR_E_UNSUPPORTED;
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3((unsigned)ultr_loss_parts(batch)), dim3(LPW * 64), lds, (hipStream_t)stream,
+                     scores, labels, pw, ipw_table, (int)n_ipw, (int)batch, (int)list_size, dscores, (float*)loss_ws);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// a9: DLA dual loss                                             dla.py:196-237, 24-48, 287-306
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LPW * 64) void dla_loss_kernel(const float* __restrict__ scores,
+                                                           const float* __restrict__ labels,
+                                                           const float* __restrict__ prop, int l2p, int B, int L,
+                                                           float* __restrict__ dscores, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tail = (int)ultr_tail_len(L);
+  float* sm_tail = smem;               // [LPW][tail]
+  float* sm_s = sm_tail + LPW * tail;  // [LPW][L] scores
+  float* sm_y = sm_s + LPW * L;        // [LPW][L] clicks
+  float* sm_p = sm_y + LPW * L;        // [LPW][L] propensity logits ELU(W_l + b)  (batch independent)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * LPW + wave;
+  float* ms = sm_s + wave * L;
+  float* my = sm_y + wave * L;
+  float* mp = sm_p + wave * L;
+  float* mt = sm_tail + wave * tail;
+  for (int t = lane; t < tail; t += 64) mt[t] = 0.f;
+  if (b < B) {
+    const float pbias = prop[L];
+    float mxs = -INFINITY, mxp = -INFINITY, sums = 0.f, sump = 0.f;
+    for (int l = lane; l < L; l += 64) {
+      const float s = scores[(int64_t)b * L + l];
+      const float z = prop[l] + pbias;
+      const float pl = z > 0.f ? z : (expf(z) - 1.0f);  // DenoisingNet: Linear(one-hot) -> ELU
+      ms[l] = s;
+      my[l] = labels[(int64_t)l * B + b];
+      mp[l] = pl;
+      mxs = fmaxf(mxs, s);
+      mxp = fmaxf(mxp, pl);
+      sums += s;
+      sump += pl;
+    }
+    mxs = wave_max(mxs);
+    mxp = wave_max(mxp);
+    const float means = wave_sum(sums) / (float)L, meanp = wave_sum(sump) / (float)L;
+    float ses = 0.f, sep = 0.f;
+    for (int l = lane; l < L; l += 64) {
+      ses += expf(ms[l] - mxs);
+      sep += expf(mp[l] - mxp);
+    }
+    const float lses = mxs + logf(wave_sum(ses));
+    const float lsep = mxp + logf(wave_sum(sep));
+    // logits_to_prob at position 0 (softmax, or sigmoid(x - mean), dla.py:21-22)
+    const float p0 = (l2p == 1) ? sigmoidf_(mp[0] - meanp) : expf(mp[0] - lsep);
+    const float r0 = (l2p == 1) ? sigmoidf_(ms[0] - means) : expf(ms[0] - lses);
+    float Sr = 0.f, Se = 0.f;
+    for (int l = lane; l < L; l += 64) {
+      const float pl = (l2p == 1) ? sigmoidf_(mp[l] - meanp) : expf(mp[l] - lsep);
+      const float rl = (l2p == 1) ? sigmoidf_(ms[l] - means) : expf(ms[l] - lses);
+      Sr += (my[l] + 0.0000001f) * (p0 / pl);  // propensity weights, get_normalized_weights
+      Se += (my[l] + 0.0000001f) * (r0 / rl);  // relevance weights
+    }
+    Sr = wave_sum(Sr);
+    Se = wave_sum(Se);
+    float lr = 0.f, le = 0.f;
+    for (int l = lane; l < L; l += 64) {
+      const float pl = (l2p == 1) ? sigmoidf_(mp[l] - meanp) : expf(mp[l] - lsep);
+      const float rl = (l2p == 1) ? sigmoidf_(ms[l] - means) : expf(ms[l] - lses);
+      const float wr = (my[l] + 0.0000001f) * (p0 / pl);
+      const float we = (my[l] + 0.0000001f) * (r0 / rl);
+      lr += wr * (lses - ms[l]);
+      le += we * (lsep - mp[l]);
+      dscores[(int64_t)b * L + l] = expf(ms[l] - lses) * Sr - wr;  // d rank_loss / d s  x D_rank
+      mt[ULTR_TAIL_FIXED + l] = expf(mp[l] - lsep) * Se - we;      // d exam_loss / d propensity_l  x D_exam
+    }
+    lr = wave_sum(lr);
+    le = wave_sum(le);
+    if (lane == 0) {
+      mt[0] = lr;
+      mt[1] = Sr;
+      mt[2] = le;
+      mt[3] = Se;
+    }
+  }
+  store_wg_tail(sm_tail, tail, part + (int64_t)blockIdx.x * tail);
+}
+
+extern "C" int ultr_dla_loss(const float* scores, const float* labels, const float* prop_params, int32_t logits_to_prob,
+                             int32_t batch, int32_t list_size, float* dscores, void* loss_ws, void* stream) {
+  if (!scores || !labels || !prop_params || !dscores || !loss_ws || batch <= 0 || list_size <= 0) return ULTR_E_BADARG;
+  const int tail = (int)ultr_tail_len(list_size);
+  const size_t lds = (size_t)LPW * (tail + 3 * list_size) * sizeof(float);
+  if (lds > 64 * 1024) return ULTR_E_UNSUPPORTED;
+  hipLaunchKernelGGL(dla_loss_kernel, dim3((unsigned)ultr_loss_parts(batch)), dim3(LPW * 64), lds, (hipStream_t)stream,
+                     scores, labels, prop_params, (int)logits_to_prob, (int)batch, (int)list_size, dscores,
+                     (float*)loss_ws);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// a10: PairDebias                                               pairwise_debias.py:142-157
+// ------------------------------------------------------------------------------------------------
+// Lane i owns position i and walks all j != i once, evaluating BOTH ordered pairs (i,j) and (j,i), so every
+// gradient / EM sum it owns is produced locally (the "wavefront pair-diff kernel").
+__global__ __launch_bounds__(LPW * 64) void pairdebias_kernel(const float* __restrict__ scores,
+                                                             const float* __restrict__ labels,
+                                                             const float* __restrict__ t_plus,
+                                                             const float* __restrict__ t_minus, int B, int L,
+                                                             float bscale, float* __restrict__ dscores,
+                                                             float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tail = (int)ultr_tail_len(L);
+  float* sm_tail = smem;               // [LPW][tail]
+  float* sm_s = sm_tail + LPW * tail;  // [LPW][L]
+  float* sm_c = sm_s + LPW * L;        // [LPW][L]
+  float* sm_tp = sm_c + LPW * L;       // [L]
+  float* sm_tm = sm_tp + L;            // [L]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * LPW + wave;
+  float* ms = sm_s + wave * L;
+  float* mc = sm_c + wave * L;
+  float* mt = sm_tail + wave * tail;
+  for (int t = threadIdx.x; t < L; t += blockDim.x) {
+    sm_tp[t] = t_plus[t];
+    sm_tm[t] = t_minus[t];
+  }
+  for (int t = lane; t < tail; t += 64) mt[t] = 0.f;
+  if (b < B)
+    for (int l = lane; l < L; l += 64) {
+      ms[l] = scores[(int64_t)b * L + l];
+      mc[l] = labels[(int64_t)l * B + b];
+    }
+  __syncthreads();
+  if (b < B) {
+    float lsum = 0.f;
+    for (int i = lane; i < L; i += 64) {
+      const float si = ms[i], ci = mc[i], tpi = sm_tp[i], tmi = sm_tm[i];
+      float g = 0.f, tpl = 0.f, tml = 0.f, li = 0.f;
+      for (int j = 0; j < L; ++j) {
+        if (j == i) continue;
+        const float sj = ms[j], cj = mc[j];
+        const float mij = fminf(1.0f, fmaxf(ci - cj, 0.f));  // valid_pair_mask for (i, j)
+        const float mji = fminf(1.0f, fmaxf(cj - ci, 0.f));  // and for (j, i)
+        if (mij > 0.f) {
+          const float x = sj - si;
+          const float pl = bscale * mij * softplus_pair(x);  // PL_ij contribution of this list (x B)
+          tpl += pl / sm_tm[j];                              // t_plus_loss[i]  += PL_ij / t_minus[j]
+          li += pl / tpi / sm_tm[j];                         // loss           += PL_ij / t_plus[i] / t_minus[j]
+          g -= bscale * mij * sigmoidf_(x) / tpi / sm_tm[j]; // d/ds_i
+        }
+        if (mji > 0.f) {
+          const float x = si - sj;
+          const float pl = bscale * mji * softplus_pair(x);  // PL_ji
+          tml += pl / sm_tp[j];                              // t_minus_loss[i] += PL_ji / t_plus[j]
+          g += bscale * mji * sigmoidf_(x) / sm_tp[j] / tmi; // d PL_ji / ds_i (i is the "negative" doc)
+        }
+      }
+      dscores[(int64_t)b * L + i] = g;
+      mt[ULTR_TAIL_FIXED + i] = tpl;
+      mt[ULTR_TAIL_FIXED + L + i] = tml;
+      lsum += li;
+    }
+    lsum = wave_sum(lsum);
+    if (lane == 0) {
+      mt[0] = lsum;
+      mt[1] = 1.0f;  // unused normaliser
+    }
+  }
+  store_wg_tail(sm_tail, tail, part + (int64_t)blockIdx.x * tail);
+}
+
+extern "C" int ultr_pairdebias_loss(const float* scores, const float* labels, const float* t_plus, const float* t_minus,
+                                    int32_t batch, int32_t list_size, int32_t batch_total, float* dscores, void* loss_ws,
+                                    void* stream) {
+  if (!scores || !labels || !t_plus || !t_minus || !dscores || !loss_ws || batch <= 0 || list_size <= 0 || batch_total <= 0)
+    return ULTR_E_BADARG;
+  const int tail = (int)ultr_tail_len(list_size);
+  const size_t lds = ((size_t)LPW * (tail + 2 * list_size) + 2 * list_size) * sizeof(float);
+  if (lds > 64 * 1024) return ULTR_E_UNSUPPORTED;
+  hipLaunchKernelGGL(pairdebias_kernel, dim3((unsigned)ultr_loss_parts(batch)), dim3(LPW * 64), lds, (hipStream_t)stream,
+                     scores, labels, t_plus, t_minus, (int)batch, (int)list_size, (float)batch_total, dscores,
+                     (float*)loss_ws);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// a11: LambdaRank                                               lambda_rank.py:116-135, 247-291
+// ------------------------------------------------------------------------------------------------
+// Sort = rank by counting inside the wavefront (stable: ties broken by original index), L^2 compares from
+// LDS; the same trick orders the labels for the ideal DCG.  Then the pair walk of PairDebias on the SORTED
+// list, with delta-NDCG weights and the reference's BCE-with-logits-on-a-probability quirk.
+__device__ __forceinline__ float bce_logits(float x, float t) {
+  // torch.nn.BCEWithLogitsLoss: (1 - t) * x + log(1 + exp(-x)), stable form
+  return fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+}
+
+__global__ __launch_bounds__(LPW * 64) void lambdarank_kernel(const float* __restrict__ scores,
+                                                             const float* __restrict__ labels,
+                                                             const float* __restrict__ t_plus,
+                                                             const float* __restrict__ t_minus, float sigma, int B,
+                                                             int L, float* __restrict__ dscores,
+                                                             float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tail = (int)ultr_tail_len(L);
+  float* sm_tail = smem;                // [LPW][tail]
+  float* sm_s = sm_tail + LPW * tail;   // [LPW][L] raw scores
+  float* sm_y = sm_s + LPW * L;         // [LPW][L] raw labels
+  float* sm_ps = sm_y + LPW * L;        // [LPW][L] scores sorted desc
+  float* sm_ls = sm_ps + LPW * L;       // [LPW][L] labels in score order
+  float* sm_g = sm_ls + LPW * L;        // [LPW][L] gains 2^l - 1 in score order
+  float* sm_tp = sm_g + LPW * L;        // [L]
+  float* sm_tm = sm_tp + L;             // [L]
+  int* sm_pos = reinterpret_cast<int*>(sm_tm + L);  // [LPW][L] sorted position of original index
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * LPW + wave;
+  float* ms = sm_s + wave * L;
+  float* my = sm_y + wave * L;
+  float* ps = sm_ps + wave * L;
+  float* ls = sm_ls + wave * L;
+  float* gs = sm_g + wave * L;
+  int* pos = sm_pos + wave * L;
+  float* mt = sm_tail + wave * tail;
+  for (int t = threadIdx.x; t < L; t += blockDim.x) {
+    sm_tp[t] = t_plus[t];
+    sm_tm[t] = t_minus[t];
+  }
+  for (int t = lane; t < tail; t += 64) mt[t] = 0.f;
+  if (b < B)
+    for (int l = lane; l < L; l += 64) {
+      ms[l] = scores[(int64_t)b * L + l];
+      my[l] = labels[(int64_t)l * B + b];
+    }
+  __syncthreads();
+  if (b < B) {
+    float idcg = 0.f;
+    for (int i = lane; i < L; i += 64) {
+      const float si = ms[i], yi = my[i];
+      int rs = 0, ry = 0;
+      for (int j = 0; j < L; ++j) {
+        const float sj = ms[j], yj = my[j];
+        rs += (sj > si || (sj == si && j < i)) ? 1 : 0;
+        ry += (yj > yi || (yj == yi && j < i)) ? 1 : 0;
+      }
+      pos[i] = rs;
+      ps[rs] = si;
+      ls[rs] = yi;
+      gs[rs] = exp2f(yi) - 1.0f;
+      // dcg(): sum (2^l - 1) / ln(rank + 1), rank 1-based -> ln(ry + 2)   (lambda_rank.py:262-266)
+      idcg += (exp2f(yi) - 1.0f) / logf((float)ry + 2.0f);
+    }
+    idcg = wave_sum(idcg);
+  // make the sorted arrays visible to the whole wave (LDS writes by other lanes of the same wave)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    float lsum = 0.f;
+    for (int r = lane; r < L; r += 64) {
+      const float sr = ps[r], lr_ = ls[r], gr = gs[r], tpr = sm_tp[r], tmr = sm_tm[r];
+      const float dr = 1.0f / log2f((float)r + 2.0f);
+      float g = 0.f, tpl = 0.f, tml = 0.f, li = 0.f;
+      for (int c = 0; c < L; ++c) {
+        const float sc = ps[c], lc = ls[c], gc = gs[c];
+        const float dc = 1.0f / log2f((float)c + 2.0f);
+        const float delta = fabsf(gr - gc) * fabsf(dr - dc);                // x 1/IDCG applied later
+        const float S = fminf(1.0f, fmaxf(lr_ - lc, -1.0f));
+        const float pb_rc = 0.5f * (1.0f + S), pb_cr = 0.5f * (1.0f - S);
+        const float x_rc = 1.0f / (expf(-sigma * (sr - sc)) + 1.0f);
+        const float x_cr = 1.0f / (expf(-sigma * (sc - sr)) + 1.0f);
+        const float l_rc = delta * bce_logits(x_rc, pb_rc);                 // PL[r, c] contribution
+        const float l_cr = delta * bce_logits(x_cr, pb_cr);                 // PL[c, r]
+        const float den_rc = tpr * sm_tm[c], den_cr = sm_tp[c] * tmr;
+        tpl += l_rc / sm_tm[c];   // t_plus_loss[r]  = sum_c PL[r,c] / t_minus[c]
+        tml += l_cr / sm_tp[c];   // t_minus_loss[r] = sum_c PL[c,r] / t_plus[c]
+        li += (den_rc == 0.f) ? 0.f : l_rc / den_rc;                        // _safe_div
+        // d PL[r,c]/d s_r  and  d PL[c,r]/d s_r  (x = sigmoid(sigma * diff); BCE'(x) = sigmoid(x) - target)
+        const float d_rc = delta * (sigmoidf_(x_rc) - pb_rc) * sigma * x_rc * (1.0f - x_rc);
+        const float d_cr = delta * (sigmoidf_(x_cr) - pb_cr) * sigma * x_cr * (1.0f - x_cr);
+        g += (den_rc == 0.f) ? 0.f : d_rc / den_rc;
+        g -= (den_cr == 0.f) ? 0.f : d_cr / den_cr;
+      }
+      mt[ULTR_TAIL_FIXED + r] = tpl;
+      mt[ULTR_TAIL_FIXED + L + r] = tml;
+      ms[r] = g;  // raw scores are dead after the sort: reuse as d(loss)/d(sorted score r)
+      lsum += li;
+    }
+    lsum = wave_sum(lsum);
+    if (lane == 0) {
+      mt[0] = lsum;
+      mt[1] = idcg;
+    }
+  }
+  // ms[] (now gradients by sorted position) written by lane r, read by the lane owning the original index
+  __syncthreads();
+  if (b < B)
+    for (int i = lane; i < L; i += 64) dscores[(int64_t)b * L + i] = ms[pos[i]];
+  store_wg_tail(sm_tail, tail, part + (int64_t)blockIdx.x * tail);
+}
+
+extern "C" int ultr_lambdarank_loss(const float* scores, const float* labels, const float* t_plus, const float* t_minus,
+                                    float sigma, int32_t batch, int32_t list_size, float* dscores, void* loss_ws,
+                                    void* stream) {
+  if (!scores || !labels || !t_plus || !t_minus || !dscores || !loss_ws || batch <= 0 || list_size <= 0)
+    return ULTR_E_BADARG;
+  const int tail = (int)ultr_tail_len(list_size);
+  const size_t lds = ((size_t)LPW * (tail + 6 * list_size) + 2 * list_size) * sizeof(float);
+  if (lds > 64 * 1024) return ULTR_E_UNSUPPORTED;
+  hipLaunchKernelGGL(lambdarank_kernel, dim3((unsigned)ultr_loss_parts(batch)), dim3(LPW * 64), lds, (hipStream_t)stream,
+                     scores, labels, t_plus, t_minus, sigma, (int)batch, (int)list_size, dscores, (float*)loss_ws);
+  return (int)hipGetLastError();
+}

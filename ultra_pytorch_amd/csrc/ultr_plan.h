@@ -1,0 +1,73 @@
+// ultr_plan.h — host/device shared "plan" structs for the gfx950 hot path.
+//
+// A plan is plain-old-data computed on the host from (ultr_dnn_desc, n_rows) and passed BY VALUE
+// as a kernel argument, so kernels never chase pointers for their geometry.  All offsets are in
+// floats.  Row n of the batch is document (b = n / L, l = n % L); its id is docids[l*B + b].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ULTR_MAXL 8  // Linear layers (hidden + final)
+
+// Parameter layout = the reference's DNN.sequential state_dict order (DNN.py:41-55).
+struct DnnPlan {
+  int nl;                 // Linear layers, = n_hidden + 1; layer nl-1 is the M=1 scorer
+  int act;                // 0 elu, 1 relu
+  int K[ULTR_MAXL];       // in-features of Linear_j   (K[0] = F)
+  int M[ULTR_MAXL];       // out-features of Linear_j  (M[nl-1] = 1)
+  int64_t off_lnw[ULTR_MAXL], off_lnb[ULTR_MAXL], off_w[ULTR_MAXL], off_b[ULTR_MAXL];
+  int64_t P;              // total parameters
+  int maxdim;             // max over all K_j (and M_j)
+  // saved-for-backward workspace (floats): xs[j] = input of LayerNorm_j, j >= 1; stats for all j
+  int64_t sv_x[ULTR_MAXL];     // [N, K_j]   (j >= 1)
+  int64_t sv_mean[ULTR_MAXL];  // [N]
+  int64_t sv_rstd[ULTR_MAXL];  // [N]
+  int64_t sv_total;
+};
+
+// One matrix-gradient segment (Linear_j, j < nl-1) for the wgrad kernel.
+struct WgradLayer {
+  int M, K;
+  int nmb, nkb;        // 64x64 output blocks
+  int nsplit;          // row (n) splits -> partial slabs
+  int rows_per_split;  // multiple of 16; each of the 4 waves takes rows_per_split/4
+  int blk_begin;       // first blockIdx of this layer
+  int vec;             // 1: float4 path legal (M%4==0, K%4==0, aligned bases)
+  int64_t dz_off;      // dz_j in bwd_ws  [N, M]
+  int64_t slab_off;    // slabs in bwd_ws [nsplit][M*K + M]
+};
+
+struct BwdPlan {
+  int64_t N;
+  int rblk;                 // rows per workgroup of the dgrad-chain kernel
+  int nrb;                  // number of row blocks = ceil(N / rblk)
+  int vlen;                 // floats per vector slab
+  int voff_g[ULTR_MAXL];    // dgamma_j offset inside a vector slab
+  int voff_b[ULTR_MAXL];    // dbeta_j
+  int voff_wk, voff_bk;     // final layer weight [K_last], bias [1]
+  int64_t vslab_off;        // [nrb][vlen] in bwd_ws
+  int64_t dz_off[ULTR_MAXL];// dz_j [N, M_j], j < nl-1
+  WgradLayer wl[ULTR_MAXL];
+  int wgrad_blocks;
+  int64_t sumsq_off;        // [n_red_blocks]
+  int n_red_blocks;
+  int64_t total;            // floats in bwd_ws
+};
+
+// Segment table for the deterministic slab reduction: grads[off .. off+len) =
+//   sum_{s < nparts} ws[base + s*stride + e]
+struct RedSeg {
+  int64_t off, base, stride;
+  int len, nparts;
+};
+struct RedPlan {
+  int nseg;
+  RedSeg seg[4 * ULTR_MAXL];
+};
+
+#define ULTR_TAIL_FIXED 4
+__host__ __device__ static inline int64_t ultr_tail_len(int L) { return ULTR_TAIL_FIXED + 2 * (int64_t)L; }
+
+// loss workspace: [0] int n_partials (as float bits unused) ; partials [MAXPART][tail]
+#define ULTR_LOSS_LISTS_PER_WG 4
+__host__ __device__ static inline int64_t ultr_loss_parts(int64_t B) { return (B + ULTR_LOSS_LISTS_PER_WG - 1) / ULTR_LOSS_LISTS_PER_WG; }

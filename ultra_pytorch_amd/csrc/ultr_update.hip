@@ -1,0 +1,143 @@
+// ultr_update.hip — clip + optimizer + EM / propensity updates, one launch per step.
+//
+// Replaces torch.nn.utils.clip_grad_norm_ + torch.optim.Adagrad.step / SGD.step (reference
+// base_algorithm.py:208-226), DLA.separate_gradient_update (dla.py:141-177) and the t_plus / t_minus EM
+// updates (pairwise_debias.py:159-163, lambda_rank.py:136-142).  Every workgroup recomputes the handful of
+// step scalars (global normaliser, gradient norm, clip coefficient) from the same inputs in the same order,
+// so no grid barrier and no atomics are needed and all workgroups agree bit-for-bit.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ultr_hip.h"
+#include "ultr_device.h"
+#include "ultr_plan.h"
+
+__device__ __forceinline__ float block_sum256(float v, float* sm) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sm[wave] = v;
+  __syncthreads();
+  return ((sm[0] + sm[1]) + sm[2]) + sm[3];
+}
+
+__device__ __forceinline__ float opt_step(float p, float g, float* st, int opt, bool stateless, float lr, float eps) {
+  if (opt == ULTR_OPT_SGD) return p - lr * g;
+  // torch.optim.Adagrad (lr_decay 0, weight_decay 0, initial accumulator 0): s += g*g; p -= lr * g / (sqrt(s) + eps).
+  // stateless: DLA builds fresh optimizers every step (dla.py:153-154) -> the accumulator is always g*g.
+  const float s = (stateless ? 0.f : *st) + g * g;
+  if (!stateless) *st = s;
+  return p - lr * (g / (sqrtf(s) + eps));
+}
+
+__global__ __launch_bounds__(256) void update_kernel(ultr_update_desc u, float* __restrict__ params,
+                                                     float* __restrict__ state, const float* __restrict__ grads,
+                                                     float* __restrict__ aux, const float* __restrict__ sumsq_part,
+                                                     int nsq, float* __restrict__ scalars_out) {
+  __shared__ float sm[4];
+  const int64_t P = u.n_params;
+  const int L = u.list_size;
+  const float* tail = grads + P;
+  float ss = 0.f;
+  for (int k = threadIdx.x; k < nsq; k += 256) ss += sumsq_part[k];
+  ss = block_sum256(ss, sm);
+  const float loss_sum = tail[0], D = tail[1], loss2 = tail[2], D2 = tail[3];
+  float gs = 1.0f, loss = loss_sum, rank_loss = 0.f, exam_loss = 0.f;
+  switch (u.algo) {
+    case ULTR_ALGO_SOFTMAX:  // loss = sum_b loss_b / sum w   (base_algorithm.py:330)
+      gs = 1.0f / D;
+      loss = loss_sum / D;
+      break;
+    case ULTR_ALGO_DLA:  // loss = exam_loss + ranker_loss_weight * rank_loss   (dla.py:237)
+      rank_loss = loss_sum / D;
+      exam_loss = loss2 / D2;
+      gs = u.ranker_loss_weight / D;
+      loss = exam_loss + u.ranker_loss_weight * rank_loss;
+      break;
+    case ULTR_ALGO_PAIRDEBIAS:
+      gs = 1.0f;
+      loss = loss_sum;
+      break;
+    case ULTR_ALGO_LAMBDARANK:  // gains are normalised by the batch-global IDCG (lambda_rank.py:280-282)
+      gs = 1.0f / D;
+      loss = loss_sum / D;
+      break;
+  }
+  const float norm = fabsf(gs) * sqrtf(ss);
+  const float coef = (u.max_gradient_norm > 0.f) ? fminf(1.0f, u.max_gradient_norm / (norm + 1e-6f)) : 1.0f;
+  const bool stateless = (u.algo == ULTR_ALGO_DLA);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int64_t e = (int64_t)blockIdx.x * 1024 + it * 256 + threadIdx.x;
+    if (e < P) {
+      float g = grads[e] * gs;
+      g *= coef;
+      params[e] = opt_step(params[e], g, state ? state + e : nullptr, u.optimizer, stateless || state == nullptr,
+                           u.learning_rate, u.adagrad_eps);
+    }
+  }
+  if (blockIdx.x != 0) return;
+  // ---- block 0: step scalars + the small per-position state -----------------------------------------
+  float pnorm = 0.f;
+  if (u.algo == ULTR_ALGO_DLA && aux != nullptr) {
+    // DenoisingNet backward: propensity[b,l] = ELU(W_l + bias) for every b, so
+    //   dW_l = ELU'(W_l + bias) * (1/D_exam) * sum_b d exam/d propensity[b,l],  dbias = sum_l dW_l
+    const float bias = aux[L];
+    float gsum = 0.f, gsq = 0.f;
+    for (int l = threadIdx.x; l < L; l += 256) {
+      const float z = aux[l] + bias;
+      const float g = (tail[ULTR_TAIL_FIXED + l] / D2) * (z > 0.f ? 1.0f : expf(z));
+      gsum += g;
+      gsq += g * g;
+    }
+    gsum = block_sum256(gsum, sm);
+    gsq = block_sum256(gsq, sm);
+    pnorm = sqrtf(gsq + gsum * gsum);
+    const float pc = (u.max_gradient_norm > 0.f) ? fminf(1.0f, u.max_gradient_norm / (pnorm + 1e-6f)) : 1.0f;
+    for (int l = threadIdx.x; l < L; l += 256) {
+      const float z = aux[l] + bias;
+      const float g = (tail[ULTR_TAIL_FIXED + l] / D2) * (z > 0.f ? 1.0f : expf(z)) * pc;
+      aux[l] = opt_step(aux[l], g, nullptr, u.optimizer, true, u.propensity_learning_rate, u.adagrad_eps);
+    }
+    __syncthreads();  // every thread has read the old bias
+    if (threadIdx.x == 0) aux[L] = opt_step(bias, gsum * pc, nullptr, u.optimizer, true, u.propensity_learning_rate, u.adagrad_eps);
+  } else if ((u.algo == ULTR_ALGO_PAIRDEBIAS || u.algo == ULTR_ALGO_LAMBDARANK) && aux != nullptr) {
+    // t <- (1 - a) t + a * (t_loss / t_loss[0]) ^ (1 / (p + 1));   LambdaRank divides with _safe_div
+    const bool safe = (u.algo == ULTR_ALGO_LAMBDARANK);
+    const float ex = 1.0f / (u.regulation_p + 1.0f);
+    const float a = u.em_step_size, oma = (float)(1.0 - (double)u.em_step_size);
+    const float tp0 = tail[ULTR_TAIL_FIXED], tm0 = tail[ULTR_TAIL_FIXED + L];
+    for (int l = threadIdx.x; l < 2 * L; l += 256) {
+      const float den = (l < L) ? tp0 : tm0;
+      const float num = tail[ULTR_TAIL_FIXED + l];
+      const float ratio = (safe && den == 0.f) ? 0.f : num / den;
+      const float pw = (ex == 0.5f) ? sqrtf(ratio) : powf(ratio, ex);
+      aux[l] = oma * aux[l] + a * pw;
+    }
+  }
+  if (threadIdx.x == 0 && scalars_out != nullptr) {
+    scalars_out[0] = loss;
+    scalars_out[1] = norm;
+    scalars_out[2] = coef;
+    scalars_out[3] = D;
+    scalars_out[4] = rank_loss;
+    scalars_out[5] = exam_loss;
+    scalars_out[6] = pnorm;
+    scalars_out[7] = ss;
+  }
+}
+
+extern "C" int ultr_apply_update(const ultr_update_desc* u, float* params, float* state, const float* grads, float* aux,
+                                 const void* bwd_ws, float* scalars_out, void* stream) {
+  if (!u || !params || !grads || !bwd_ws || u->n_params <= 0 || u->list_size <= 0) return ULTR_E_BADARG;
+  if (u->algo < 0 || u->algo > ULTR_ALGO_LAMBDARANK || (u->optimizer != ULTR_OPT_ADAGRAD && u->optimizer != ULTR_OPT_SGD))
+    return ULTR_E_BADARG;
+  if (u->algo != ULTR_ALGO_SOFTMAX && !aux) return ULTR_E_BADARG;
+  if (u->optimizer == ULTR_OPT_ADAGRAD && u->algo != ULTR_ALGO_DLA && !state) return ULTR_E_BADARG;
+  const int tail = (int)ultr_tail_len(u->list_size);
+  const int nsq = (int)((u->n_params + tail + 1023) / 1024);
+  const int nblk = (int)((u->n_params + 1023) / 1024);
+  hipLaunchKernelGGL(update_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *u, params, state, grads, aux,
+                     (const float*)bwd_ws, nsq, scalars_out);
+  return (int)hipGetLastError();
+}

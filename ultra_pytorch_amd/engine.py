@@ -1,0 +1,123 @@
+"""StepEngine — one training / validation step of the hot path on one GPU (rank).
+
+Owns the per-shape device workspaces (torch tensors = plumbing for HBM allocations) and
+sequences the C-ABI calls on the current HIP stream:
+
+    train:  ultr_dnn_forward -> ultr_<loss> -> ultr_dnn_backward [-> RCCL all-reduce -> ultr_grad_sumsq]
+            -> ultr_apply_update                                             (6 kernels on one GPU)
+    valid:  ultr_dnn_forward -> ultr_ndcg
+
+Nothing here synchronises with the host; the caller decides when to read `scalars`
+(the reference's `loss.item()` is the only sync, base_algorithm.py / ipw_rank.py:182).
+"""
+import torch
+
+from . import _lib, hip_ops
+
+ALGOS = {"softmax": _lib.ALGO_SOFTMAX, "dla": _lib.ALGO_DLA, "pairdebias": _lib.ALGO_PAIRDEBIAS,
+         "lambdarank": _lib.ALGO_LAMBDARANK}
+
+
+def _f32(n, device, zero=False):
+    n = max(int(n), 1)
+    return (torch.zeros if zero else torch.empty)(n, dtype=torch.float32, device=device)
+
+
+class StepEngine:
+    def __init__(self, shape, batch, list_size, device, algo="softmax", optimizer="ada", learning_rate=0.05,
+                 max_gradient_norm=5.0, ranker_loss_weight=1.0, propensity_learning_rate=None, em_step_size=0.05,
+                 regulation_p=1.0, sigma=1.0, logits_to_prob="softmax", process_group=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("ultra_pytorch_amd needs an MI355X/ROCm GPU: there is no CPU fallback")
+        self.shape, self.B, self.L, self.device = shape, int(batch), int(list_size), device
+        self.N = self.B * self.L
+        self.algo = algo
+        self.sigma = float(sigma)
+        self.l2p = 1 if logits_to_prob == "sigmoid" else 0
+        self.pg = process_group
+        self.world = 1 if process_group is None else torch.distributed.get_world_size(process_group)
+        P, tail = shape.n_params, hip_ops.tail_floats(self.L)
+        self.P, self.tail = P, tail
+        self.saved = _f32(shape.saved_bytes(self.N) // 4, device)
+        self.bwd_ws = _f32(shape.bwd_workspace_bytes(self.N) // 4, device)
+        self.loss_ws = _f32(hip_ops.loss_workspace_bytes(self.B, self.L) // 4, device, zero=True)
+        self.scores = _f32(self.N, device).view(self.B, self.L)
+        self.dscores = _f32(self.N, device).view(self.B, self.L)
+        self.grads = _f32(P + tail, device, zero=True)
+        self.scalars = _f32(8, device, zero=True)
+        u = _lib.UpdateDesc()
+        u.algo = ALGOS[algo]
+        u.optimizer = _lib.OPT_SGD if optimizer == "sgd" else _lib.OPT_ADAGRAD
+        u.list_size = self.L
+        u.logits_to_prob = self.l2p
+        u.n_params = P
+        u.learning_rate = float(learning_rate)
+        u.max_gradient_norm = float(max_gradient_norm)
+        u.adagrad_eps = 1e-10
+        u.ranker_loss_weight = float(ranker_loss_weight)
+        plr = propensity_learning_rate
+        u.propensity_learning_rate = float(learning_rate if plr is None or plr < 0 else plr)
+        u.em_step_size = float(em_step_size)
+        u.regulation_p = float(regulation_p)
+        self.udesc = u
+
+    # ---- forward only (validation / DNN.build) -------------------------------------------------
+    def forward(self, params, features, n_docs, docids, scores=None, train=False):
+        scores = self.scores if scores is None else scores
+        hip_ops.dnn_forward(self.shape, params, features, n_docs, docids, self.B, self.L, scores,
+                            self.saved if train else None)
+        return scores
+
+    # ---- loss stage ------------------------------------------------------------------------------
+    def loss(self, labels, aux=None, ipw_table=None, pw=None):
+        B, L = self.B, self.L
+        if self.algo == "softmax":
+            hip_ops.softmax_ce(self.scores, labels, B, L, self.dscores, self.loss_ws, pw=pw, ipw_table=ipw_table)
+        elif self.algo == "dla":
+            hip_ops.dla_loss(self.scores, labels, aux, self.l2p, B, L, self.dscores, self.loss_ws)
+        elif self.algo == "pairdebias":
+            hip_ops.pairdebias_loss(self.scores, labels, aux[:L], aux[L:], B, L, B * self.world, self.dscores, self.loss_ws)
+        elif self.algo == "lambdarank":
+            hip_ops.lambdarank_loss(self.scores, labels, aux[:L], aux[L:], self.sigma, B, L, self.dscores, self.loss_ws)
+        else:
+            raise ValueError(self.algo)
+
+    def backward(self, params, features, n_docs, docids):
+        hip_ops.dnn_backward(self.shape, params, features, n_docs, docids, self.B, self.L, self.saved, self.dscores,
+                             self.loss_ws, self.bwd_ws, self.grads)
+        if self.world > 1:
+            # queries shard across ranks; ONE sum all-reduce (RCCL over xGMI) of [grads | step tail]
+            torch.distributed.all_reduce(self.grads, group=self.pg)
+            hip_ops.grad_sumsq(self.grads, self.P, self.L, self.bwd_ws)
+
+    def update(self, params, state, aux=None):
+        hip_ops.apply_update(self.udesc, params, state, self.grads, aux, self.bwd_ws, self.scalars)
+
+    def train_step(self, params, state, features, n_docs, docids, labels, aux=None, ipw_table=None, pw=None):
+        """One full step; returns the device tensor of step scalars ([0] = loss)."""
+        self.forward(params, features, n_docs, docids, train=True)
+        self.loss(labels, aux=aux, ipw_table=ipw_table, pw=pw)
+        self.backward(params, features, n_docs, docids)
+        self.update(params, state, aux)
+        return self.scalars
+
+
+class EvalEngine:
+    """validation(): forward at max_candidate_num + padding mask + NDCG@topn."""
+
+    def __init__(self, shape, batch, list_size, device, topn=(1, 3, 5, 10)):
+        if not torch.cuda.is_available():
+            raise RuntimeError("ultra_pytorch_amd needs an MI355X/ROCm GPU: there is no CPU fallback")
+        self.shape, self.B, self.L, self.device = shape, int(batch), int(list_size), device
+        self.topn = [int(t) for t in topn]
+        self.scores = _f32(self.B * self.L, device).view(self.B, self.L)
+        self.masked = _f32(self.B * self.L, device).view(self.B, self.L)
+        self.order = torch.empty(self.B, self.L, dtype=torch.int32, device=device)
+        self.ndcg = _f32(len(self.topn), device)
+        self.ndcg_ws = _f32(self.B * len(self.topn), device)
+
+    def run(self, params, features, n_docs, docids, labels):
+        hip_ops.dnn_forward(self.shape, params, features, n_docs, docids, self.B, self.L, self.scores, None)
+        hip_ops.ndcg(self.scores, labels, docids, n_docs, self.B, self.L, self.topn, self.ndcg, self.ndcg_ws,
+                     order_out=self.order, masked_out=self.masked)
+        return self.scores, self.ndcg

@@ -1,0 +1,123 @@
+"""Tensor-level wrappers over the C ABI: torch supplies device memory and the stream, nothing else.
+
+Every function takes CUDA(ROCm) float32 / int32 tensors, passes raw pointers + the current
+HIP stream to libultr_hip.so and returns immediately (asynchronous w.r.t. the host).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
+        raise TypeError("%s must be a contiguous %s tensor on the GPU" % (name, dtype))
+    return t
+
+
+class DnnShape:
+    """Host-side geometry of one DNN (desc + parameter layout), mirrors DNN.__init__ (DNN.py:25-55)."""
+
+    def __init__(self, feature_size, hidden, activation="elu"):
+        self.lib = _lib.load()
+        self.feature_size = int(feature_size)
+        self.hidden = [int(h) for h in (hidden or [])]
+        self.activation = activation
+        self.desc = _lib.make_desc(feature_size, self.hidden, activation)
+        self.n_params = int(self.lib.ultr_dnn_param_count(ctypes.byref(self.desc)))
+        if self.n_params <= 0:
+            raise ValueError("bad DNN description")
+        nl = len(self.hidden) + 1
+        offs = (ctypes.c_int64 * (4 * nl))()
+        check(self.lib.ultr_dnn_param_offsets(ctypes.byref(self.desc), offs), "ultr_dnn_param_offsets")
+        self.offsets = list(offs)
+        dims, k = [], self.feature_size
+        for m in self.hidden + [1]:
+            dims.append((k, m))
+            k = m
+        self.dims = dims
+
+    def layout(self):
+        """[(state_dict key, shape, offset)] in the reference's parameter order."""
+        out = []
+        for j, (k, m) in enumerate(self.dims):
+            o = self.offsets[4 * j:4 * j + 4]
+            out += [("sequential.layer_norm%d.weight" % j, (k,), o[0]), ("sequential.layer_norm%d.bias" % j, (k,), o[1]),
+                    ("sequential.linear%d.weight" % j, (m, k), o[2]), ("sequential.linear%d.bias" % j, (m,), o[3])]
+        return out
+
+    def saved_bytes(self, n_rows):
+        return int(self.lib.ultr_dnn_saved_bytes(ctypes.byref(self.desc), n_rows))
+
+    def bwd_workspace_bytes(self, n_rows):
+        return int(self.lib.ultr_dnn_bwd_workspace_bytes(ctypes.byref(self.desc), n_rows))
+
+
+def tail_floats(L):
+    return int(_lib.load().ultr_step_tail_floats(int(L)))
+
+
+def loss_workspace_bytes(B, L):
+    return int(_lib.load().ultr_loss_workspace_bytes(int(B), int(L)))
+
+
+def dnn_forward(shape, params, features, n_docs, docids, B, L, scores, saved=None):
+    lib = shape.lib
+    _req(params, torch.float32, "params"), _req(docids, torch.int32, "docids"), _req(scores, torch.float32, "scores")
+    if n_docs > 0:
+        _req(features, torch.float32, "features")
+    check(lib.ultr_dnn_forward(ctypes.byref(shape.desc), _p(params), _p(features) if n_docs > 0 else None, int(n_docs),
+                               _p(docids), int(B), int(L), _p(scores), _p(saved), _stream()), "ultr_dnn_forward")
+
+
+def dnn_backward(shape, params, features, n_docs, docids, B, L, saved, dscores, loss_ws, bwd_ws, grads):
+    lib = shape.lib
+    check(lib.ultr_dnn_backward(ctypes.byref(shape.desc), _p(params), _p(features) if n_docs > 0 else None, int(n_docs),
+                                _p(docids), int(B), int(L), _p(saved), _p(dscores), _p(loss_ws), _p(bwd_ws), _p(grads),
+                                _stream()), "ultr_dnn_backward")
+
+
+def grad_sumsq(grads, n_params, L, bwd_ws):
+    check(_lib.load().ultr_grad_sumsq(_p(grads), int(n_params), int(L), _p(bwd_ws), _stream()), "ultr_grad_sumsq")
+
+
+def softmax_ce(scores, labels, B, L, dscores, loss_ws, pw=None, ipw_table=None):
+    n_ipw = 0 if ipw_table is None else int(ipw_table.numel())
+    check(_lib.load().ultr_softmax_ce(_p(scores), _p(labels), _p(pw), _p(ipw_table), n_ipw, int(B), int(L), _p(dscores),
+                                      _p(loss_ws), _stream()), "ultr_softmax_ce")
+
+
+def dla_loss(scores, labels, prop_params, logits_to_prob, B, L, dscores, loss_ws):
+    check(_lib.load().ultr_dla_loss(_p(scores), _p(labels), _p(prop_params), int(logits_to_prob), int(B), int(L),
+                                    _p(dscores), _p(loss_ws), _stream()), "ultr_dla_loss")
+
+
+def pairdebias_loss(scores, labels, t_plus, t_minus, B, L, batch_total, dscores, loss_ws):
+    check(_lib.load().ultr_pairdebias_loss(_p(scores), _p(labels), _p(t_plus), _p(t_minus), int(B), int(L),
+                                           int(batch_total), _p(dscores), _p(loss_ws), _stream()), "ultr_pairdebias_loss")
+
+
+def lambdarank_loss(scores, labels, t_plus, t_minus, sigma, B, L, dscores, loss_ws):
+    check(_lib.load().ultr_lambdarank_loss(_p(scores), _p(labels), _p(t_plus), _p(t_minus), float(sigma), int(B), int(L),
+                                           _p(dscores), _p(loss_ws), _stream()), "ultr_lambdarank_loss")
+
+
+def apply_update(udesc, params, state, grads, aux, bwd_ws, scalars):
+    check(_lib.load().ultr_apply_update(ctypes.byref(udesc), _p(params), _p(state), _p(grads), _p(aux), _p(bwd_ws),
+                                        _p(scalars), _stream()), "ultr_apply_update")
+
+
+def ndcg(scores, labels, docids, n_docs, B, L, topn, ndcg_out, ndcg_ws, order_out=None, masked_out=None):
+    arr = (ctypes.c_int32 * len(topn))(*[int(t) for t in topn])
+    check(_lib.load().ultr_ndcg(_p(scores), _p(labels), _p(docids), int(n_docs), int(B), int(L), arr, len(topn),
+                                _p(ndcg_out), _p(order_out), _p(masked_out), _p(ndcg_ws), _stream()), "ultr_ndcg")
