@@ -27,11 +27,11 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // activation and its derivative expressed through the activation OUTPUT a = act(z)
-//   elu  (alpha 1): a = z > 0 ? z : exp(z) - 1  (the reference's torch CPU kernel computes exp(z) - 1);
+//   elu  (alpha 1): a = z > 0 ? z : expm1(z)   (torch.s CPU ELU kernel uses expm1 - verified numerically);
 //                   act'(z) = z > 0 ? 1 : exp(z) = a + 1
 //   relu          : act'(z) = a > 0
 __device__ __forceinline__ float act_fwd(float z, int act) {
-  if (act == 0) return z > 0.0f ? z : (expf(z) - 1.0f);
+  if (act == 0) return z > 0.0f ? z : expm1f(z);
   return fmaxf(z, 0.0f);
 }
 __device__ __forceinline__ float act_grad_from_out(float a, int act) {

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(LPW * 64) void dla_loss_kernel(const float* __restr
     for (int l = lane; l < L; l += 64) {
       const float s = scores[(int64_t)b * L + l];
       const float z = prop[l] + pbias;
-      const float pl = z > 0.f ? z : (expf(z) - 1.0f);  // DenoisingNet: Linear(one-hot) -> ELU
+      const float pl = z > 0.f ? z : expm1f(z);  // DenoisingNet: Linear(one-hot) -> ELU
       ms[l] = s;
       my[l] = labels[(int64_t)l * B + b];
       mp[l] = pl;
