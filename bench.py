@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py — queries/sec of one training step of the hot path on N MI355X GPUs.
+
+Workload (BASELINE.json configs[1]): MSLR-WEB10K-shaped synthetic data — F=136 features, list_size L=10,
+B=256 queries per GPU per step, IPWrank + DNN[256,256], PBM clicks, Adagrad lr 0.05, clip 5.0.
+A "step" = model.train on one pre-built batch: gather + DNN forward -> IPW softmax-CE -> DNN backward ->
+clip + Adagrad.  Batches are resident in HBM before the timed region starts (a pool of pre-staged
+batches is cycled), parameters/optimizer state persist across steps, nothing is skipped or cached.
+N > 1: one process per GPU, queries shard across ranks (weak scaling: B per GPU fixed), ONE RCCL sum
+all-reduce of [gradients | loss normalisers] per step, then every rank applies the identical update.
+
+Prints ONE JSON line on rank 0 (see the contract in the task statement); extra keys: `roofline` (dominant
+kernel, HIP-event timed inside the timed region), `cpu_baseline` (the oracle = a torch-CPU port of the
+reference's step, timed on this box's host cores on the same workload), `kernel_us` (per-kernel average).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+# ---- the workload -------------------------------------------------------------------------------------
+F, L, B, HIDDEN = 136, 10, 256, [256, 256]
+LR, CLIP = 0.05, 5.0
+POOL = 16  # pre-staged batches per rank, cycled
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E spec peak
+KNAMES = ["dnn_fwd_kernel", "softmax_ce_kernel", "dnn_bwd_kernel", "dnn_wgrad_kernel", "grad_reduce_kernel", "update_kernel"]
+
+
+def algorithmic_work(P):
+    """Per-launch ALGORITHMIC work of each kernel at this workload.
+    flops: 2*N*sum(K_j*M_j) forward; dgrad 2*N*(sum - F*H1) (SURVEY's figure: layer-0 dgrad not counted although
+    LayerNorm_0's gamma/beta gradients need it); wgrad 2*N*sum over the hidden Linears.  bytes for the HBM-bound ones."""
+    N = B * L
+    dims, k = [], F
+    for m in HIDDEN + [1]:
+        dims.append((k, m))
+        k = m
+    s_all = sum(k * m for k, m in dims)
+    s_hidden = sum(k * m for k, m in dims[:-1])
+    return {
+        0: ("mfma", 2.0 * N * s_all),
+        1: ("hbm", 4.0 * 4 * N),  # scores, labels in; dscores out (+ weights)
+        2: ("mfma", 2.0 * N * (s_all - dims[0][0] * dims[0][1])),
+        3: ("mfma", 2.0 * N * s_hidden),
+        4: ("hbm", 4.0 * P),  # the flat gradient written once (slab re-reads are overhead, not algorithmic)
+        5: ("hbm", 4.0 * 5 * P),  # read g, read+write Adagrad sum, read+write params
+    }
+
+
+def make_pool(rng, device):
+    from ultra_pytorch_amd import synthetic
+    pool = []
+    for _ in range(POOL):
+        feats, docids, clicks = synthetic.make_batch(rng, B, L, F, clicks=True)
+        pool.append((torch.from_numpy(feats).to(device), feats.shape[0], torch.from_numpy(docids).to(device),
+                     torch.from_numpy(clicks).to(device), (feats, docids, clicks)))
+    return pool
+
+
+def cpu_baseline(pool, params0, budget_s=10.0):
+    """The oracle's IPW step (vectorised torch-CPU port of the reference's train()) on this box's host cores.
+    The thread count is chosen by a short probe (tiny GEMMs do not scale to every core of a big host, and an
+    oversubscribed baseline would flatter the GPU); `cores` reports the threads actually used."""
+    from oracle import ultr_oracle as O
+    from ultra_pytorch_amd import synthetic
+    ipw = synthetic.load_ipw()
+    ncpu = os.cpu_count() or 1
+
+    def run(nsteps, p, s, i0):
+        t = 0.0
+        for i in range(i0, i0 + nsteps):
+            feats, docids, clicks = pool[i % POOL][4]
+            t0 = time.perf_counter()
+            r = O.train_step_softmax(p, s, F, HIDDEN, feats, docids, clicks, ipw_list=ipw, lr=LR, max_norm=CLIP)
+            t += time.perf_counter() - t0
+            p, s = r["params"], r["state"]
+        return t, p, s
+
+    best, probe = None, {}
+    for th in sorted({1, 4, 8, 16, 32, 64, ncpu}):
+        if th > ncpu:
+            continue
+        torch.set_num_threads(th)
+        p, s = params0.copy(), np.zeros_like(params0)
+        _, p, s = run(2, p, s, 0)
+        t, p, s = run(5, p, s, 2)
+        probe[th] = t / 5
+        if best is None or t / 5 < probe[best]:
+            best = th
+    torch.set_num_threads(best)
+    p, s = params0.copy(), np.zeros_like(params0)
+    _, p, s = run(5, p, s, 0)
+    n, t_used = 0, 0.0
+    while t_used < budget_s or n < 20:
+        t, p, s = run(10, p, s, 5 + n)
+        n += 10
+        t_used += t
+    return {"value": B * n / t_used, "unit": "queries/sec", "cores": best, "kind": "port",
+            "sample": "%d steps of the same workload (IPWrank+DNN[256,256], F136 L10 B256) after 5 warm-up, "
+                      "oracle/ultr_oracle.train_step_softmax, torch-CPU, %d threads picked by probe %s (host has %d), "
+                      "%.2f ms/step" % (n, best, {k: round(1e3 * v, 2) for k, v in probe.items()}, ncpu, 1e3 * t_used / n)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-every-step", action="store_true", help="also read loss.item() every step (API-faithful)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+        pg = dist.group.WORLD
+
+    from ultra_pytorch_amd import _lib, engine, hip_ops, synthetic
+    from ultra_pytorch_amd.ranking_model import init_flat_params
+    lib = _lib.load()
+    shape = hip_ops.DnnShape(F, HIDDEN, "elu")
+    P = shape.n_params
+    params0 = init_flat_params(shape, seed=0).numpy()
+    params = torch.from_numpy(params0.copy()).to(device)  # identical replicas on every rank
+    state = torch.zeros_like(params)
+    ipw = torch.tensor(synthetic.load_ipw(), dtype=torch.float32, device=device)
+    pool = make_pool(np.random.RandomState(1234 + rank), device)
+    eng = engine.StepEngine(shape, B, L, device, algo="softmax", learning_rate=LR, max_gradient_norm=CLIP, process_group=pg)
+
+    def step(i):
+        f, nd, ids, y, _ = pool[i % POOL]
+        return eng.train_step(params, state, f, nd, ids, y, ipw_table=ipw)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    # ---- warm-up (untimed) + pick the dominant kernel with all timers armed ------------------------
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    tot, cnt = (ctypes.c_double * 8)(), (ctypes.c_int64 * 8)()
+    ncal = 50
+    _lib.check(lib.ultr_prof_enable(0x3F, 8 * ncal), "ultr_prof_enable")
+    for i in range(ncal):
+        step(i)
+    torch.cuda.synchronize()
+    _lib.check(lib.ultr_prof_collect(tot, cnt), "ultr_prof_collect")
+    cal_us = [1e3 * tot[k] / max(cnt[k], 1) for k in range(6)]
+    dom = int(np.argmax(cal_us))
+    # ---- the timed region: EXACTLY K steps, dominant kernel event-timed inside it -------------------
+    _lib.check(lib.ultr_prof_enable(1 << dom, args.steps + 8), "ultr_prof_enable")
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    t1 = time.perf_counter()
+    _lib.check(lib.ultr_prof_collect(tot, cnt), "ultr_prof_collect")
+    lib.ultr_prof_enable(0, 0)
+    dom_s = 1e-3 * tot[dom] / max(cnt[dom], 1)
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=device)
+    if world > 1:
+        torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    final_loss = float(eng.scalars[0].item())
+    assert np.isfinite(final_loss), "training diverged"
+
+    synced = None
+    if args.sync_every_step or world == 1:
+        n2 = min(args.steps, 500)
+        barrier()
+        t2 = time.perf_counter()
+        for i in range(n2):
+            step(i)[0].item()  # the reference's loss.item() each step
+        t3 = time.perf_counter()
+        synced = (t3 - t2) / n2
+
+    if rank == 0:
+        work = algorithmic_work(P)
+        bound, amount = work[dom]
+        if bound == "mfma":
+            achieved, peak, unit = amount / dom_s / 1e12, PEAK_FP32_MFMA_TFLOPS, "TFLOP/s"
+        else:
+            achieved, peak, unit = amount / dom_s / 1e9, PEAK_HBM_GBS, "GB/s"
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes/launch from rocprofv3 PMC passes
+        if os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get(KNAMES[dom])
+        out = {
+            "metric": "queries/sec (training step)", "value": world * B * args.steps / elapsed, "unit": "queries/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "MSLR-WEB10K synthetic (136-d, list_size=10, batch=256/GPU): IPWrank + DNN[256,256], "
+                                   "PBM clicks, Adagrad lr 0.05, clip 5.0; one step = forward+loss+backward+clip+update",
+                       "global_batch": world * B, "list_size": L, "feature_size": F, "hidden": HIDDEN,
+                       "parallelism": "dp%d" % world, "params": P},
+            "roofline": {"kernel": KNAMES[dom], "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
+                         "frac": achieved / peak, "traffic": traffic, "avg_launch_us": 1e6 * dom_s,
+                         "algorithmic_per_launch": amount},
+            "kernel_us": {KNAMES[k]: round(cal_us[k], 3) for k in range(6)},
+            "final_loss": final_loss,
+        }
+        if synced is not None:
+            out["queries_per_sec_with_loss_item_each_step"] = B * world / synced
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pool, params0)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

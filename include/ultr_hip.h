@@ -180,6 +180,14 @@ int ultr_ndcg(const float* scores, const float* labels, const int32_t* docids, i
               int32_t list_size, const int32_t* topn, int32_t n_topn, float* ndcg_out, int32_t* order_out,
               float* masked_out, float* ndcg_ws, void* stream);
 
+/* ---- measurement hooks (bench.py only; not part of the reference's interface) ----------
+ * Per-kernel HIP-event timers on the launch stream.  kernel ids: 0 forward, 1 loss, 2 backward
+ * (dgrad chain), 3 weight gradients, 4 gradient reduction, 5 update.  enable(mask, n) arms up
+ * to n samples for the kernels in mask (0 disarms); collect() synchronises the recorded events,
+ * returns per-kernel total milliseconds and launch counts in arrays of 8, and rearms. */
+int ultr_prof_enable(uint32_t kernel_mask, int32_t max_samples);
+int ultr_prof_collect(double* total_ms, int64_t* counts);
+
 #ifdef __cplusplus
 }
 #endif

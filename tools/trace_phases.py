@@ -1,0 +1,42 @@
+"""GPU box: build a -DULTR_TRACE copy of the library, run the forward kernel at the bench shape, print phase deltas."""
+import ctypes, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+src = sorted(os.path.join(ROOT, "ultra_pytorch_amd/csrc", f) for f in os.listdir(os.path.join(ROOT, "ultra_pytorch_amd/csrc")) if f.endswith(".hip"))
+out = "/tmp/libultr_trace.so"
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DULTR_TRACE"] + src + ["-o", out])
+from ultra_pytorch_amd import _lib
+lib = _lib.load(out)
+_lib._LIB = lib
+from ultra_pytorch_amd import hip_ops, engine, synthetic
+from ultra_pytorch_amd.ranking_model import init_flat_params
+F, L, B, H = 136, 10, 256, [256, 256]
+shape = hip_ops.DnnShape(F, H, "elu")
+dev = torch.device("cuda")
+p = init_flat_params(shape, 0).to(dev)
+feats, ids, y = synthetic.make_batch(np.random.RandomState(0), B, L, F)
+f, i_, y_ = torch.tensor(feats, device=dev), torch.tensor(ids, device=dev), torch.tensor(y, device=dev)
+eng = engine.StepEngine(shape, B, L, dev)
+ipw = torch.tensor(synthetic.load_ipw(), dtype=torch.float32, device=dev)
+st = torch.zeros_like(p)
+for _ in range(20):
+    eng.train_step(p, st, f, feats.shape[0], i_, y_, ipw_table=ipw)
+torch.cuda.synchronize()
+buf = (ctypes.c_ulonglong * (64 * 32))()
+lib.ultr_trace_read.argtypes = [ctypes.c_void_p]
+lib.ultr_trace_read(buf)
+a = np.array(buf[:], dtype=np.uint64).reshape(64, 32)
+names = ["start", "gather+sync", "LN0", "GEMM0", "sync", "LN1", "GEMM1", "sync", "LN2", "dot"]
+for blk in range(5):
+    t = a[blk].astype(np.int64)
+    print("wg %3d:" % (blk * 32), " ".join("%s=%d" % (names[k], t[k] - t[k - 1]) for k in range(1, 10)), " total", t[9] - t[0])
+
+bn = ["top", "GEMM/du", "sync", "colpass", "rowpass(next top)"]
+for blk in range(3):
+    t = a[blk].astype(np.int64)
+    out = []
+    for jj in range(3):
+        base = 16 + 4 * jj
+        out.append("L%d: gemm=%d sync=%d col=%d row+sync=%d" % (2 - jj, t[base + 1] - t[base], t[base + 2] - t[base + 1], t[base + 3] - t[base + 2], (t[base + 4] - t[base + 3]) if jj < 2 else 0))
+    print("bwd wg %3d:" % (blk * 32), " | ".join(out), " total", t[16 + 11] - t[16])

@@ -46,6 +46,8 @@ SIGNATURES = {
     "ultr_pairdebias_loss": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "ultr_lambdarank_loss": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "ultr_apply_update": (c_i32, [ctypes.POINTER(UpdateDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "ultr_prof_enable": (c_i32, [ctypes.c_uint32, c_i32]),
+    "ultr_prof_collect": (c_i32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
     "ultr_ndcg": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, ctypes.POINTER(c_i32), c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
 }
 

@@ -15,15 +15,31 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// Wavefront (64-lane) reductions on the DPP path: VALU cross-lane moves, no LDS round trips (hipcc lowers
+// __shfl_xor to ds_bpermute_b32, ~100+ cycles per dependent step).  quad_perm [1,0,3,2], quad_perm [2,3,0,1],
+// row_ror:4, row_ror:8 leave every lane of a 16-lane row with the row total; row_bcast:15 / row_bcast:31 chain
+// the four rows into lane 63, which is read back as a wave-uniform scalar.  Fixed order -> deterministic.
+template <int CTRL>
+__device__ __forceinline__ float dpp_or(float old, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_or<0xb1>(0.f, v);
+  v += dpp_or<0x4e>(0.f, v);
+  v += dpp_or<0x124>(0.f, v);
+  v += dpp_or<0x128>(0.f, v);
+  v += dpp_or<0x142>(0.f, v);
+  v += dpp_or<0x143>(0.f, v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_or<0xb1>(v, v));
+  v = fmaxf(v, dpp_or<0x4e>(v, v));
+  v = fmaxf(v, dpp_or<0x124>(v, v));
+  v = fmaxf(v, dpp_or<0x128>(v, v));
+  v = fmaxf(v, dpp_or<0x142>(v, v));
+  v = fmaxf(v, dpp_or<0x143>(v, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // activation and its derivative expressed through the activation OUTPUT a = act(z)
@@ -52,6 +68,54 @@ __device__ __forceinline__ float4 ld4_masked(const float* row, int c, int len, b
   if (c + 2 < len) v.z = row[c + 2];
   if (c + 3 < len) v.w = row[c + 3];
   return v;
+}
+
+// Branch-free masked row loads for the hot loops.
+// hipcc only emits COUNTED s_waitcnt vmcnt(N) (i.e. keeps a software prefetch ring in flight) when the loads are
+// not wrapped in control flow; an `if` around a load - or a select on its result, which CodeGenPrepare turns back
+// into a branch - makes every use drain vmcnt(0) (measured: prefetch depth 1 -> 8 changed nothing).  So the VEC
+// path goes through a buffer resource (SRSRC): the hardware bounds check returns 0 for an out-of-range offset,
+// and masked lanes simply present ULTR_OOB.  Descriptors are built from kernel arguments only (wave-uniform).
+// VEC == false is the generic (unaligned / ragged) path and keeps the masked scalar loads.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define ULTR_OOB 0x80000000u  // > any buffer we describe (sizes are checked < 2 GiB on the host)
+
+struct Src {
+  const float* base;
+  __amdgpu_buffer_rsrc_t rs;
+};
+__device__ __forceinline__ Src make_src(const float* base, int64_t nfloats) {
+  Src s;
+  s.base = base;
+  s.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)(nfloats * 4), 0x00020000);
+  return s;
+}
+template <bool VEC>
+__device__ __forceinline__ float4 ld4_sel(const Src& s, int64_t off, bool ok, int c, int len) {
+  if constexpr (VEC) {
+    const unsigned bo = (ok && c < len) ? (unsigned)((off + c) * 4) : ULTR_OOB;
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(s.rs, bo, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+  } else {
+    return ld4_masked(ok ? (s.base + off) : nullptr, c, len, false);
+  }
+}
+// unmasked forms for operands whose out-of-range elements only ever meet a zero on the other side of the MFMA
+// (or produce outputs that are discarded): past-the-end offsets are zeroed by the hardware bounds check
+__device__ __forceinline__ float4 buf_ld4(const Src& s, unsigned byte_off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(s.rs, byte_off, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ float buf_ld1(const Src& s, unsigned byte_off) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(s.rs, byte_off, 0, 0));
+}
+template <bool VEC>
+__device__ __forceinline__ float ld1_sel(const Src& s, int64_t idx, bool ok) {
+  if constexpr (VEC) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(s.rs, ok ? (unsigned)(idx * 4) : ULTR_OOB, 0, 0));
+  } else {
+    return ok ? s.base[idx] : 0.f;
+  }
 }
 
 __host__ __device__ __forceinline__ int round_up(int x, int m) { return (x + m - 1) / m * m; }

@@ -20,6 +20,7 @@
 #include "../../include/ultr_hip.h"
 #include "ultr_device.h"
 #include "ultr_plan.h"
+#include "ultr_prof.h"
 
 // ------------------------------------------------------------------------------------------------
 // LDS leading dimensions
@@ -38,55 +39,80 @@ __host__ __device__ static inline int bwd_ldu(int maxdim) { return round_up(maxd
 // One call = one chunk of 16*CT output columns starting at o0, for RT row tiles of 16.
 // B fragments: lane (i = l&15, q = l>>4) loads W[o0 + 16t + i][k0 + 4q .. +3] (float4 along k), which is the
 // B operand of four consecutive k-steps (any fixed permutation of k inside the contraction is legal).
-template <int RT, int CT>
+template <int RT, int CT, bool VEC>
 __device__ __forceinline__ void gemm_nt_chunk(const float* __restrict__ Xs, int ldx, int K, int K16,
-                                              const float* __restrict__ W, bool vec, const float* __restrict__ bias,
+                                              const Src& W, const float* __restrict__ bias,
                                               int M, int o0, int act, float* __restrict__ Ys, int ldy,
                                               float* __restrict__ gout, int rows_valid, int lane) {
+  // PF-deep register ring of B fragments: the step is latency-bound (weights come from L2, ~700 cycles), so
+  // every wave keeps PF*CT 16-byte loads in flight instead of one iteration's worth.
+  constexpr int PF = (CT == 4) ? 4 : 8;
   const int i = lane & 15, q = lane >> 4;
   f32x4 acc[RT][CT];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int t = 0; t < CT; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const float* wrow[CT];
+  int64_t woff[CT];
+  bool wok[CT];
 #pragma unroll
   for (int t = 0; t < CT; ++t) {
     const int o = o0 + 16 * t + i;
-    wrow[t] = (o < M) ? (W + (int64_t)o * K) : nullptr;
+    wok[t] = o < M;
+    woff[t] = (int64_t)o * K;
   }
-  float4 bc[CT], bn[CT];
+  const int nit = K16 >> 4;
+  float4 bq[PF][CT];
 #pragma unroll
-  for (int t = 0; t < CT; ++t) {
-    bc[t] = ld4_masked(wrow[t], 4 * q, K, vec);
-    bn[t] = bc[t];
-  }
-  for (int k0 = 0; k0 < K16; k0 += 16) {
-    if (k0 + 16 < K16) {
+  for (int u = 0; u < PF; ++u)
 #pragma unroll
-      for (int t = 0; t < CT; ++t) bn[t] = ld4_masked(wrow[t], k0 + 16 + 4 * q, K, vec);
+    for (int t = 0; t < CT; ++t) {
+      // VEC: no masks at all - rows o >= M fall past the described buffer (hardware returns 0), k >= K only
+      // meets the zero padding of the A tile in LDS
+      if constexpr (VEC) bq[u][t] = buf_ld4(W, (unsigned)(woff[t] + 16 * u + 4 * q) * 4u);
+      else bq[u][t] = ld4_sel<VEC>(W, woff[t], wok[t] && u < nit, 16 * u + 4 * q, K);
     }
-    float4 a[RT];
+  // A fragments are software-pipelined one step ahead as well (the ds_read_b128 -> MFMA dependency would
+  // otherwise expose the LDS latency in every step)
+  float4 a[RT], an[RT];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) a[rt] = ld4(Xs + (rt * 16 + i) * ldx + k0 + 4 * q);
+  for (int rt = 0; rt < RT; ++rt) a[rt] = ld4(Xs + (rt * 16 + i) * ldx + 4 * q);
+  for (int it0 = 0; it0 < nit; it0 += PF) {
 #pragma unroll
-    for (int t = 0; t < CT; ++t)
+    for (int u = 0; u < PF; ++u) {
+      const int it = it0 + u;
+      if (it < nit) {
+        const int k0 = it * 16;
+        const int kn = (it + 1 < nit) ? (k0 + 16) : k0;
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) acc[rt][t] = mfma16(a[rt].x, bc[t].x, acc[rt][t]);
+        for (int rt = 0; rt < RT; ++rt) an[rt] = ld4(Xs + (rt * 16 + i) * ldx + kn + 4 * q);
 #pragma unroll
-    for (int t = 0; t < CT; ++t)
+        for (int t = 0; t < CT; ++t)
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) acc[rt][t] = mfma16(a[rt].y, bc[t].y, acc[rt][t]);
+          for (int rt = 0; rt < RT; ++rt) acc[rt][t] = mfma16(a[rt].x, bq[u][t].x, acc[rt][t]);
 #pragma unroll
-    for (int t = 0; t < CT; ++t)
+        for (int t = 0; t < CT; ++t)
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) acc[rt][t] = mfma16(a[rt].z, bc[t].z, acc[rt][t]);
+          for (int rt = 0; rt < RT; ++rt) acc[rt][t] = mfma16(a[rt].y, bq[u][t].y, acc[rt][t]);
 #pragma unroll
-    for (int t = 0; t < CT; ++t)
+        for (int t = 0; t < CT; ++t)
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) acc[rt][t] = mfma16(a[rt].w, bc[t].w, acc[rt][t]);
+          for (int rt = 0; rt < RT; ++rt) acc[rt][t] = mfma16(a[rt].z, bq[u][t].z, acc[rt][t]);
 #pragma unroll
-    for (int t = 0; t < CT; ++t) bc[t] = bn[t];
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) acc[rt][t] = mfma16(a[rt].w, bq[u][t].w, acc[rt][t]);
+        if (it + PF < nit) {
+#pragma unroll
+          for (int t = 0; t < CT; ++t) {
+            if constexpr (VEC) bq[u][t] = buf_ld4(W, (unsigned)(woff[t] + k0 + 16 * PF + 4 * q) * 4u);
+            else bq[u][t] = ld4_sel<VEC>(W, woff[t], wok[t], k0 + 16 * PF + 4 * q, K);
+          }
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) a[rt] = an[rt];
+      }
+    }
   }
   // epilogue: + bias, activation; to LDS (next layer's input) and, when training, to HBM
 #pragma unroll
@@ -107,74 +133,82 @@ __device__ __forceinline__ void gemm_nt_chunk(const float* __restrict__ Xs, int 
   }
 }
 
-// "NN" form (dgrad):  DU[r, c] = sum_m DZs[r, m] * W[m, c]       W row-major [M, K]
-// One call = one chunk of 16*CT output columns starting at c0.  Lane (i, q) loads CT consecutive floats
-// W[m0 + 4s + q][c0 + CT*i .. ] for s = 0..3: the B operands of CT interleaved column tiles
-// (tile t holds columns c0 + CT*j + t), four m-steps per iteration.
-template <int RT, int CT>
-__device__ __forceinline__ void gemm_nn_chunk(const float* __restrict__ DZs, int ldz, int M, const float* __restrict__ W,
-                                              int K, bool vec, int c0, float* __restrict__ DUs, int ldu, int lane) {
+// "NN" form (dgrad):  DU[r, c] = sum_{m in [mb, me)} DZs[r, m] * W[m, c]       W row-major [M, K]
+// One call = one chunk of 64 output columns starting at c0 over a slice [mb, me) of the contraction.
+// Lane (i, q) loads the float4 W[m0 + 4s + q][c0 + 4i .. +3] for s = 0..3: the B operands of four interleaved
+// column tiles (tile t holds columns c0 + 4j + t) for four m-steps, i.e. one 16-byte load feeds 4 MFMAs per row
+// tile - the same ratio as the forward form, without keeping a transposed copy of the weights.
+template <int RT, bool VEC>
+__device__ __forceinline__ void gemm_nn4(const float* __restrict__ DZs, int ldz, const Src& W, int K,
+                                         int mb, int me, int c0, f32x4 (&acc)[RT][4], int lane) {
+  constexpr int PF = 2;  // ring depth in 16-row groups of W: 8 x 16-byte loads in flight per lane
   const int i = lane & 15, q = lane >> 4;
-  const int col = c0 + CT * i;
-  f32x4 acc[RT][CT];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-    for (int t = 0; t < CT; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int M16 = round_up(M, 16);
-  float bc[4][CT], bn[4][CT];
-  auto load_w = [&](float(&dst)[4][CT], int m0) {
+  const int col = c0 + 4 * i;
+  const int nit = (me - mb + 15) >> 4;
+  float4 bq[PF][4];
+  auto load_w = [&](float4(&dst)[4], int m0) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int m = m0 + 4 * s + q;
-      const float* row = (m < M) ? (W + (int64_t)m * K) : nullptr;
-      if constexpr (CT == 4) {
-        const float4 v = ld4_masked(row, col, K, vec);
-        dst[s][0] = v.x;
-        dst[s][1] = v.y;
-        dst[s][2] = v.z;
-        dst[s][3] = v.w;
-      } else {
-#pragma unroll
-        for (int t = 0; t < CT; ++t) dst[s][t] = (row != nullptr && col + t < K) ? row[col + t] : 0.f;
-      }
+      // VEC: rows m >= me meet a zeroed A element, rows m >= M are past the buffer, columns >= K are discarded
+      if constexpr (VEC) dst[s] = buf_ld4(W, (unsigned)(m * K + col) * 4u);
+      else dst[s] = ld4_sel<VEC>(W, (int64_t)m * K, m < me, col, K);
     }
   };
-  load_w(bc, 0);
-  for (int m0 = 0; m0 < M16; m0 += 16) {
-    if (m0 + 16 < M16) load_w(bn, m0 + 16);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int m = m0 + 4 * s + q;
-      float a[RT];
+  for (int u = 0; u < PF; ++u) {
+    if (u < nit) load_w(bq[u], mb + 16 * u);
+  }
+  for (int it0 = 0; it0 < nit; it0 += PF) {
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) a[rt] = (m < M) ? DZs[(rt * 16 + i) * ldz + m] : 0.f;
+    for (int u = 0; u < PF; ++u) {
+      const int it = it0 + u;
+      if (it < nit) {
+        const int m0 = mb + it * 16;
 #pragma unroll
-      for (int t = 0; t < CT; ++t)
+        for (int s = 0; s < 4; ++s) {
+          const int m = m0 + 4 * s + q;
+          float a[RT];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc[rt][t] = mfma16(a[rt], bc[s][t], acc[rt][t]);
-    }
-    if (m0 + 16 < M16) {
+          for (int rt = 0; rt < RT; ++rt) a[rt] = (m < me) ? DZs[(rt * 16 + i) * ldz + m] : 0.f;
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int t = 0; t < CT; ++t) bc[s][t] = bn[s][t];
+          for (int rt = 0; rt < RT; ++rt) {
+            acc[rt][0] = mfma16(a[rt], bq[u][s].x, acc[rt][0]);
+            acc[rt][1] = mfma16(a[rt], bq[u][s].y, acc[rt][1]);
+            acc[rt][2] = mfma16(a[rt], bq[u][s].z, acc[rt][2]);
+            acc[rt][3] = mfma16(a[rt], bq[u][s].w, acc[rt][3]);
+          }
+        }
+        if (it + PF < nit) load_w(bq[u], m0 + 16 * PF);
+      }
     }
   }
+}
+
+// epilogue of gemm_nn4: lane holds D_t[row = 4q + r][j = i] = DU[row][c0 + 4i + t]
+template <int RT>
+__device__ __forceinline__ void store_nn4(const f32x4 (&acc)[RT][4], float* __restrict__ DUs, int ldu, int K, int c0,
+                                          int lane, bool add) {
+  const int i = lane & 15, q = lane >> 4;
+  const int col = c0 + 4 * i;
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = rt * 16 + 4 * q + r;
-      if constexpr (CT == 4) {
-        if (col + 3 < K) {
-          st4(DUs + row * ldu + col, make_float4(acc[rt][0][r], acc[rt][1][r], acc[rt][2][r], acc[rt][3][r]));
-          continue;
+      float* dst = DUs + (rt * 16 + 4 * q + r) * ldu + col;
+      float4 v = make_float4(acc[rt][0][r], acc[rt][1][r], acc[rt][2][r], acc[rt][3][r]);
+      if (col + 3 < K) {
+        if (add) {
+          const float4 o = ld4(dst);
+          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
         }
-      }
+        st4(dst, v);
+      } else {
+        const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-      for (int t = 0; t < CT; ++t)
-        if (col + t < K) DUs[row * ldu + col + t] = acc[rt][t][r];
+        for (int t = 0; t < 4; ++t)
+          if (col + t < K) dst[t] = add ? (dst[t] + vv[t]) : vv[t];
+      }
     }
 }
 
@@ -185,10 +219,28 @@ __device__ __forceinline__ int pick_ct(int width, int nw) {
   return 1;
 }
 
+// Optional phase tracing (build with -DULTR_TRACE): wave 0 of every 32nd workgroup stamps s_memtime at phase
+// boundaries into g_ultr_trace; tools/trace_phases.py prints the deltas.  Compiled out by default.
+#ifdef ULTR_TRACE
+__device__ unsigned long long g_ultr_trace[64 * 32];
+#define TRACE_STAMP(slot)                                                                           \
+  do {                                                                                              \
+    if (threadIdx.x == 0 && (blockIdx.x & 31) == 0 && (slot) < 32 && (blockIdx.x >> 5) < 64)        \
+      g_ultr_trace[(blockIdx.x >> 5) * 32 + (slot)] = __builtin_amdgcn_s_memtime();                 \
+  } while (0)
+extern "C" int ultr_trace_read(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ultr_trace), sizeof(unsigned long long) * 64 * 32);
+}
+#else
+#define TRACE_STAMP(slot) \
+  do {                    \
+  } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // Forward
 // ------------------------------------------------------------------------------------------------
-template <int R, int NW>
+template <int R, int NW, bool VEC>
 __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float* __restrict__ params,
                                                           const float* __restrict__ features, int64_t n_docs,
                                                           const int32_t* __restrict__ docids, int B, int L,
@@ -203,12 +255,13 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t n0 = (int64_t)blockIdx.x * R;
   const int rows_valid = (int)((N - n0) < R ? (N - n0) : R);
+  TRACE_STAMP(0);
 
   // ---- a2: gather feature rows (zero row for the PAD id == n_docs and for rows past N) ----------
   {
     const int F = p.K[0];
     const int F16 = round_up(F, 16);
-    const bool vecf = (vecmask >> 31) & 1;
+    const bool vecf = VEC || ((vecmask >> 31) & 1);
     for (int r = wave; r < R; r += NW) {
       const int64_t n = n0 + r;
       const float* src = nullptr;
@@ -221,6 +274,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
     }
   }
   __syncthreads();
+  TRACE_STAMP(1);
 
   for (int j = 0; j < p.nl; ++j) {
     const int K = p.K[j], M = p.M[j];
@@ -228,42 +282,86 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
     const float* lnw = params + p.off_lnw[j];
     const float* lnb = params + p.off_lnb[j];
     // ---- LayerNorm (biased variance, eps 1e-5, affine), in place; two-pass statistics -----------
-    for (int r = wave; r < R; r += NW) {
-      float* row = X + r * ld;
-      float s = 0.f;
-      for (int c = lane; c < K; c += 64) s += row[c];
-      const float mean = wave_sum(s) / (float)K;
-      float v = 0.f;
-      for (int c = lane; c < K; c += 64) {
-        const float d = row[c] - mean;
-        v += d * d;
+    if (K <= 256) {
+      // fast path: a lane owns columns lane + 64k (k < 4); gamma/beta are fetched once per layer and the row
+      // lives in registers between the passes
+      float g[4], be[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = lane + 64 * k;
+        g[k] = (c < K) ? lnw[c] : 0.f;
+        be[k] = (c < K) ? lnb[c] : 0.f;
       }
-      const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)K + ULTR_LN_EPS);
-      for (int c = lane; c < K16; c += 64) row[c] = (c < K) ? ((row[c] - mean) * rstd * lnw[c] + lnb[c]) : 0.f;
-      if (saved != nullptr && lane == 0 && n0 + r < N) {
-        saved[p.sv_mean[j] + n0 + r] = mean;
-        saved[p.sv_rstd[j] + n0 + r] = rstd;
+      for (int r = wave; r < R; r += NW) {
+        float* row = X + r * ld;
+        float x[4];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int c = lane + 64 * k;
+          x[k] = (c < K) ? row[c] : 0.f;
+          s += x[k];
+        }
+        const float mean = wave_sum(s) / (float)K;
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int c = lane + 64 * k;
+          x[k] = (c < K) ? (x[k] - mean) : 0.f;
+          v += x[k] * x[k];
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)K + ULTR_LN_EPS);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int c = lane + 64 * k;
+          if (c < K16) row[c] = x[k] * rstd * g[k] + be[k];  // c in [K, K16): 0 * rstd * 0 + 0 = 0 (zero padding)
+        }
+        if (saved != nullptr && lane == 0 && n0 + r < N) {
+          saved[p.sv_mean[j] + n0 + r] = mean;
+          saved[p.sv_rstd[j] + n0 + r] = rstd;
+        }
+      }
+    } else {
+      for (int r = wave; r < R; r += NW) {
+        float* row = X + r * ld;
+        float s = 0.f;
+        for (int c = lane; c < K; c += 64) s += row[c];
+        const float mean = wave_sum(s) / (float)K;
+        float v = 0.f;
+        for (int c = lane; c < K; c += 64) {
+          const float d = row[c] - mean;
+          v += d * d;
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)K + ULTR_LN_EPS);
+        for (int c = lane; c < K16; c += 64) row[c] = (c < K) ? ((row[c] - mean) * rstd * lnw[c] + lnb[c]) : 0.f;
+        if (saved != nullptr && lane == 0 && n0 + r < N) {
+          saved[p.sv_mean[j] + n0 + r] = mean;
+          saved[p.sv_rstd[j] + n0 + r] = rstd;
+        }
       }
     }
     __syncthreads();
+    TRACE_STAMP(2 + 3 * j);
     const float* W = params + p.off_w[j];
     const float* bias = params + p.off_b[j];
     if (j < p.nl - 1) {
       // ---- Linear + activation on the matrix cores ------------------------------------------------
-      const bool vec = (vecmask >> j) & 1;
       float* gout = (saved != nullptr) ? (saved + p.sv_x[j + 1] + n0 * M) : nullptr;
+      const Src Wsrc = make_src(W, (int64_t)M * K);
       const int ct = pick_ct(M, NW);
       if (ct == 4) {
         for (int ch = wave; ch * 64 < M; ch += NW)
-          gemm_nt_chunk<RT, 4>(X, ld, K, K16, W, vec, bias, M, ch * 64, p.act, Y, ld, gout, rows_valid, lane);
+          gemm_nt_chunk<RT, 4, VEC>(X, ld, K, K16, Wsrc, bias, M, ch * 64, p.act, Y, ld, gout, rows_valid, lane);
       } else if (ct == 2) {
         for (int ch = wave; ch * 32 < M; ch += NW)
-          gemm_nt_chunk<RT, 2>(X, ld, K, K16, W, vec, bias, M, ch * 32, p.act, Y, ld, gout, rows_valid, lane);
+          gemm_nt_chunk<RT, 2, VEC>(X, ld, K, K16, Wsrc, bias, M, ch * 32, p.act, Y, ld, gout, rows_valid, lane);
       } else {
         for (int ch = wave; ch * 16 < M; ch += NW)
-          gemm_nt_chunk<RT, 1>(X, ld, K, K16, W, vec, bias, M, ch * 16, p.act, Y, ld, gout, rows_valid, lane);
+          gemm_nt_chunk<RT, 1, VEC>(X, ld, K, K16, Wsrc, bias, M, ch * 16, p.act, Y, ld, gout, rows_valid, lane);
       }
+      TRACE_STAMP(3 + 3 * j);
       __syncthreads();
+      TRACE_STAMP(4 + 3 * j);
       float* t = X;
       X = Y;
       Y = t;
@@ -276,6 +374,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
         s = wave_sum(s);
         if (lane == 0 && n0 + r < N) scores[n0 + r] = s + bias[0];
       }
+      TRACE_STAMP(3 + 3 * j);
     }
   }
 }
@@ -283,7 +382,13 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
 // ------------------------------------------------------------------------------------------------
 // Backward, row-local half
 // ------------------------------------------------------------------------------------------------
-template <int R, int NW>
+__device__ __forceinline__ int64_t sm_id_raw(const int32_t* __restrict__ docids, int64_t n, int B, int L, int64_t n_docs) {
+  const int b = (int)(n / L), l = (int)(n % L);
+  const int64_t d = docids[(int64_t)l * B + b];
+  return (d >= 0 && d < n_docs) ? d : -1;
+}
+
+template <int R, int NW, bool VEC>
 __global__ __launch_bounds__(NW * 64) void dnn_bwd_kernel(DnnPlan p, BwdPlan bp, const float* __restrict__ params,
                                                           const float* __restrict__ features, int64_t n_docs,
                                                           const int32_t* __restrict__ docids, int B, int L,
@@ -296,8 +401,11 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd_kernel(DnnPlan p, BwdPlan bp,
   const int64_t N = (int64_t)B * L;
   const int ldz = bwd_ldz(p.maxdim), ldu = bwd_ldu(p.maxdim);
   float* DU = smem;                    // [R][ldu]   (first: 16-byte aligned float4 stores)
-  float* DZ = DU + R * ldu;            // [R][ldz]
-  float* sm_ds = DZ + R * ldz;         // [R]
+  float* XS = DU + R * ldu;            // [R][ldu]   input of LayerNorm_j for this row block (staged once per layer)
+  float* DZ = XS + R * ldu;            // [R][ldz]
+  float* sm_g = DZ + R * ldz;          // [ldu] LayerNorm_j gamma
+  float* sm_b = sm_g + ldu;            // [ldu] LayerNorm_j beta
+  float* sm_ds = sm_b + ldu;           // [R]
   float* sm_mean2 = sm_ds + R;         // [2][R]  double-buffered by layer parity (no extra barrier)
   float* sm_rstd2 = sm_mean2 + 2 * R;  // [2][R]
   int64_t* sm_id = reinterpret_cast<int64_t*>(sm_rstd2 + 2 * R);  // [R] feature row id or -1
@@ -332,7 +440,52 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd_kernel(DnnPlan p, BwdPlan bp,
       sm_mean[tid] = (n < N) ? saved[p.sv_mean[j] + n] : 0.f;
       sm_rstd[tid] = (n < N) ? saved[p.sv_rstd[j] + n] : 0.f;
     }
-    __syncthreads();  // sm_* visible; DZ of the previous iteration complete
+    // stage x_j [R, K] (saved activations, or the gathered feature rows for j == 0) into LDS with every thread's
+    // loads in flight at once; the column / row passes below then never touch global memory for x
+    // (a per-row serial global read cost ~11k cycles per layer).  XS is free here: its last readers finished
+    // before the barrier that ended the previous layer's row pass... which is the one below for j < nl-1.
+    if (j < p.nl - 1) __syncthreads();
+    for (int c = tid; c < K; c += NT) {
+      sm_g[c] = lnw[c];
+      sm_b[c] = lnb[c];
+    }
+    {
+      const bool v4 = VEC || (((vecmask >> 31) & 1) && j == 0 && (K & 3) == 0) || (j > 0 && (K & 3) == 0);
+      if (v4) {
+        const int K4 = K >> 2;
+        for (int e = tid; e < R * K4; e += NT) {
+          const int r = e / K4, c4 = (e - r * K4) * 4;
+          const int64_t n = n0 + r;
+          const float* src = nullptr;
+          if (n < N) {
+            if (j == 0) {
+              const int64_t id = sm_id_raw(docids, n, B, L, n_docs);
+              if (id >= 0) src = features + id * K;
+            } else {
+              src = saved + p.sv_x[j] + n * K;
+            }
+          }
+          st4(XS + r * ldu + c4, src ? ld4(src + c4) : make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+      } else {
+        for (int e = tid; e < R * K; e += NT) {
+          const int r = e / K, c = e - r * K;
+          const int64_t n = n0 + r;
+          float x = 0.f;
+          if (n < N) {
+            if (j == 0) {
+              const int64_t id = sm_id_raw(docids, n, B, L, n_docs);
+              if (id >= 0) x = features[id * K + c];
+            } else {
+              x = saved[p.sv_x[j] + n * K + c];
+            }
+          }
+          XS[r * ldu + c] = x;
+        }
+      }
+    }
+    __syncthreads();  // sm_*, XS visible; DZ of the previous iteration complete
+    TRACE_STAMP(16 + 4 * (p.nl - 1 - j));
     // ---- du_j = dz_j . W_j ------------------------------------------------------------------------
     if (last) {
       for (int r = wave; r < R; r += NW) {
@@ -340,34 +493,55 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd_kernel(DnnPlan p, BwdPlan bp,
         for (int c = lane; c < K; c += 64) DU[r * ldu + c] = ds * W[c];
       }
     } else {
-      const bool vec = (vecmask >> j) & 1;
-      const int ct = pick_ct(K, NW);
-      if (ct == 4) {
-        for (int ch = wave; ch * 64 < K; ch += NW) gemm_nn_chunk<RT, 4>(DZ, ldz, M, W, K, vec, ch * 64, DU, ldu, lane);
-      } else if (ct == 2) {
-        for (int ch = wave; ch * 32 < K; ch += NW) gemm_nn_chunk<RT, 2>(DZ, ldz, M, W, K, false, ch * 32, DU, ldu, lane);
+      // 64-column chunks x slices of the contraction so that all NW waves work; slices are summed into DU
+      // in fixed order (slice 0 stores, slice r adds after a barrier) -> deterministic
+      const Src Wsrc = make_src(W, (int64_t)M * K);
+      const int nch = (K + 63) >> 6;
+      int msplit = 1;
+      while (msplit * 2 * nch <= NW) msplit *= 2;
+      if (msplit == 1) {
+        for (int ch = wave; ch < nch; ch += NW) {
+          f32x4 acc[RT][4];
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          gemm_nn4<RT, VEC>(DZ, ldz, Wsrc, K, 0, M, ch * 64, acc, lane);
+          store_nn4<RT>(acc, DU, ldu, K, ch * 64, lane, false);
+        }
       } else {
-        for (int ch = wave; ch * 16 < K; ch += NW) gemm_nn_chunk<RT, 1>(DZ, ldz, M, W, K, false, ch * 16, DU, ldu, lane);
+        const int mlen = round_up((M + msplit - 1) / msplit, 16);
+        const bool has = wave < nch * msplit;
+        const int ch = wave % nch, ms = wave / nch;
+        f32x4 acc[RT][4];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (has) {
+          const int mb = ms * mlen;
+          const int me = (mb + mlen < M) ? (mb + mlen) : M;
+          if (mb < me) gemm_nn4<RT, VEC>(DZ, ldz, Wsrc, K, mb, me, ch * 64, acc, lane);
+        }
+        for (int r = 0; r < msplit; ++r) {
+          if (has && ms == r) store_nn4<RT>(acc, DU, ldu, K, ch * 64, lane, r > 0);
+          if (r + 1 < msplit) __syncthreads();
+        }
       }
     }
+    TRACE_STAMP(17 + 4 * (p.nl - 1 - j));
     __syncthreads();
+    TRACE_STAMP(18 + 4 * (p.nl - 1 - j));
     // ---- column pass: per-row-block partial sums of the vector-parameter gradients ---------------
     //   dgamma_j[c] = sum_r du[r,c] xhat[r,c]   dbeta_j[c] = sum_r du[r,c]
     //   final layer: dW[c] = sum_r ds[r] u[r,c], db = sum_r ds[r]
     for (int c = tid; c < K; c += NT) {
       float pg = 0.f, pb = 0.f, pw = 0.f;
-      const float g = lnw[c], be = lnb[c];
+      const float g = sm_g[c], be = sm_b[c];
+#pragma unroll 4
       for (int r = 0; r < R; ++r) {
-        const int64_t n = n0 + r;
-        if (n >= N) break;
-        float x;
-        if (j == 0) {
-          const int64_t id = sm_id[r];
-          x = (id >= 0) ? features[id * K + c] : 0.f;
-        } else {
-          x = saved[p.sv_x[j] + n * K + c];
-        }
-        const float xh = (x - sm_mean[r]) * sm_rstd[r];
+        if (n0 + r >= N) break;
+        const float xh = (XS[r * ldu + c] - sm_mean[r]) * sm_rstd[r];
         const float du = DU[r * ldu + c];
         pg += du * xh;
         pb += du;
@@ -382,6 +556,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd_kernel(DnnPlan p, BwdPlan bp,
       for (int r = 0; r < R; ++r) s += sm_ds[r];
       vslab[bp.voff_bk] = s;
     }
+    TRACE_STAMP(19 + 4 * (p.nl - 1 - j));
     // ---- row pass: LayerNorm backward, then through the previous activation -> dz_{j-1} ----------
     if (j > 0) {
       float* dzg = ws + bp.dz_off[j - 1];
@@ -389,21 +564,21 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd_kernel(DnnPlan p, BwdPlan bp,
         const int64_t n = n0 + r;
         const bool valid = n < N;
         const float mean = sm_mean[r], rstd = sm_rstd[r];
-        const float* xrow = valid ? (saved + p.sv_x[j] + n * K) : nullptr;
+        const float* xrow = XS + r * ldu;
         float s1 = 0.f, s2 = 0.f;
         for (int c = lane; c < K; c += 64) {
-          const float x = valid ? xrow[c] : 0.f;
+          const float x = xrow[c];
           const float xh = (x - mean) * rstd;
-          const float gx = DU[r * ldu + c] * lnw[c];
+          const float gx = DU[r * ldu + c] * sm_g[c];
           s1 += gx;
           s2 += gx * xh;
         }
         s1 = wave_sum(s1) / (float)K;
         s2 = wave_sum(s2) / (float)K;
         for (int c = lane; c < K; c += 64) {
-          const float x = valid ? xrow[c] : 0.f;
+          const float x = xrow[c];
           const float xh = (x - mean) * rstd;
-          const float gx = DU[r * ldu + c] * lnw[c];
+          const float gx = DU[r * ldu + c] * sm_g[c];
           const float dx = rstd * (gx - s1 - xh * s2);
           const float dzv = dx * act_grad_from_out(x, p.act);
           DZ[r * ldz + c] = dzv;
@@ -421,13 +596,17 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd_kernel(DnnPlan p, BwdPlan bp,
 // split, then the four 64x64 partials are summed through LDS in fixed order and written to the split's slab.
 // Per step a lane issues two 16-byte loads (dz row piece along m, x row piece along k) feeding 16 MFMAs:
 // A[i][kk] = dz[n+kk][m0+4i+ta], B[kk][j] = u[n+kk][k0+4j+tb]  ->  D_{ta,tb}[i][j] = dW[m0+4i+ta][k0+4j+tb].
+template <bool VEC>
 __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, const float* __restrict__ params,
                                                         const float* __restrict__ features, int64_t n_docs,
                                                         const int32_t* __restrict__ docids, int B, int L,
                                                         const float* __restrict__ saved, float* __restrict__ ws,
                                                         int vecf) {
-  __shared__ __attribute__((aligned(16))) float red[4][64 * 64];
-  __shared__ float bred[4][64];
+  // ONE dynamic LDS array: [4][64*64] cross-wave reduction | [4][64] bias partials | [rows_per_split] doc ids
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float (*red)[64 * 64] = reinterpret_cast<float (*)[64 * 64]>(smem);
+  float (*bred)[64] = reinterpret_cast<float (*)[64]>(smem + 4 * 64 * 64);
+  int* sm_ids = reinterpret_cast<int*>(smem + 4 * 64 * 64 + 4 * 64);
   const int64_t N = bp.N;
   int j = 0;
   while (j + 1 < p.nl - 1 && (int)blockIdx.x >= bp.wl[j + 1].blk_begin) ++j;
@@ -441,16 +620,31 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
   const bool vec = wl.vec != 0;
-  const bool vecx = (j == 0) ? (vecf != 0) : vec;
   const int rpw = wl.rows_per_split / 4;
   const int64_t nbeg = (int64_t)split * wl.rows_per_split + (int64_t)wave * rpw;
   int64_t nend = nbeg + rpw;
   if (nend > N) nend = N;
 
-  const float* dz = ws + wl.dz_off;
-  const float* xs = (j == 0) ? nullptr : (saved + p.sv_x[j]);
-  const float* meanp = saved + p.sv_mean[j];
-  const float* rstdp = saved + p.sv_rstd[j];
+  const Src dz = make_src(ws + wl.dz_off, N * M);
+  const Src xs = (j == 0) ? make_src(features, n_docs * K) : make_src(saved + p.sv_x[j], N * K);
+  const Src meansrc = make_src(saved + p.sv_mean[j], N);
+  const Src rstdsrc = make_src(saved + p.sv_rstd[j], N);
+  const int64_t nsplit0 = (int64_t)split * wl.rows_per_split;
+  if (j == 0) {
+    // layer 0 reads feature rows through the doc ids: resolve them once into LDS so that the main loop has no
+    // dependent global load (a docid -> row chain forces vmcnt(0) and drains the prefetch ring)
+    for (int r = tid; r < wl.rows_per_split; r += 256) {
+      const int64_t n = nsplit0 + r;
+      int id = -1;
+      if (n < N) {
+        const int b = (int)(n / L), l = (int)(n % L);
+        const int64_t d = docids[(int64_t)l * B + b];
+        if (d >= 0 && d < n_docs) id = (int)d;
+      }
+      sm_ids[r] = id;
+    }
+    __syncthreads();
+  }
   const float4 gam = ld4_masked(params + p.off_lnw[j], k0 + 4 * i, K, false);
   const float4 bet = ld4_masked(params + p.off_lnb[j], k0 + 4 * i, K, false);
   const int kc = k0 + 4 * i;
@@ -464,20 +658,36 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
 
   auto load_step = [&](int64_t n, float4& a4, float4& b4) {
-    a4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    b4 = a4;
-    if (n < nend) {
-      a4 = ld4_masked(dz + n * M, m0 + 4 * i, M, vec);
-      const float* xrow;
+    const bool ok = n < nend;
+    float4 x4;
+    float mean, rstd;
+    if constexpr (VEC) {
+      // only dz must be exactly zero for rows outside this wave's slice; x / statistics of such rows are finite
+      // (other rows of the batch) or hardware-zeroed (past N), and their products meet a4 == 0.  PAD documents
+      // (id < 0) must read as the all-zero feature row -> out-of-bounds offset.
+      a4 = buf_ld4(dz, ok ? (unsigned)(n * M + m0 + 4 * i) * 4u : ULTR_OOB);
       if (j == 0) {
-        const int b = (int)(n / L), l = (int)(n % L);
-        const int64_t id = docids[(int64_t)l * B + b];
-        xrow = (id >= 0 && id < n_docs) ? (features + id * K) : nullptr;
+        const int id = ok ? sm_ids[(int)(n - nsplit0)] : -1;
+        x4 = buf_ld4(xs, id >= 0 ? (unsigned)((int64_t)id * K + kc) * 4u : ULTR_OOB);
       } else {
-        xrow = xs + n * K;
+        x4 = buf_ld4(xs, (unsigned)(n * K + kc) * 4u);
       }
-      const float4 x4 = ld4_masked(xrow, kc, K, vecx);
-      const float mean = meanp[n], rstd = rstdp[n];
+      mean = buf_ld1(meansrc, (unsigned)n * 4u);
+      rstd = buf_ld1(rstdsrc, (unsigned)n * 4u);
+      b4.x = (x4.x - mean) * rstd * gam.x + bet.x;
+      b4.y = (x4.y - mean) * rstd * gam.y + bet.y;
+      b4.z = (x4.z - mean) * rstd * gam.z + bet.z;
+      b4.w = (x4.w - mean) * rstd * gam.w + bet.w;
+    } else {
+      a4 = ld4_sel<VEC>(dz, n * M, ok, m0 + 4 * i, M);
+      if (j == 0) {
+        const int id = ok ? sm_ids[(int)(n - nsplit0)] : -1;
+        x4 = ld4_sel<VEC>(xs, (int64_t)id * K, id >= 0, kc, K);
+      } else {
+        x4 = ld4_sel<VEC>(xs, n * K, ok, kc, K);
+      }
+      mean = ld1_sel<VEC>(meansrc, n, ok);
+      rstd = ld1_sel<VEC>(rstdsrc, n, ok);
       b4.x = k_ok0 ? ((x4.x - mean) * rstd * gam.x + bet.x) : 0.f;
       b4.y = k_ok1 ? ((x4.y - mean) * rstd * gam.y + bet.y) : 0.f;
       b4.z = k_ok2 ? ((x4.z - mean) * rstd * gam.z + bet.z) : 0.f;
@@ -485,22 +695,30 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
     }
   };
 
-  float4 a_c, b_c, a_n, b_n;
-  load_step(nbeg + q, a_c, b_c);
-  for (int64_t n = nbeg; n < nend; n += 4) {
-    load_step(n + 4 + q, a_n, b_n);
-    bsum.x += a_c.x;
-    bsum.y += a_c.y;
-    bsum.z += a_c.z;
-    bsum.w += a_c.w;
-    const float av[4] = {a_c.x, a_c.y, a_c.z, a_c.w};
-    const float bv[4] = {b_c.x, b_c.y, b_c.z, b_c.w};
+  // PF-deep ring: every lane keeps 2*PF 16-byte loads in flight (the layer-0 x rows are a dependent
+  // docid -> feature-row chain, and dz / x come from HBM or a remote L2)
+  constexpr int PF = 4;
+  float4 aq[PF], bq[PF];
 #pragma unroll
-    for (int ta = 0; ta < 4; ++ta)
+  for (int u = 0; u < PF; ++u) load_step(nbeg + 4 * u + q, aq[u], bq[u]);
+  for (int64_t n = nbeg; n < nend; n += 4 * PF) {
 #pragma unroll
-      for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = mfma16(av[ta], bv[tb], acc[ta][tb]);
-    a_c = a_n;
-    b_c = b_n;
+    for (int u = 0; u < PF; ++u) {
+      if (n + 4 * u < nend) {
+        const float4 a_c = aq[u], b_c = bq[u];
+        bsum.x += a_c.x;
+        bsum.y += a_c.y;
+        bsum.z += a_c.z;
+        bsum.w += a_c.w;
+        const float av[4] = {a_c.x, a_c.y, a_c.z, a_c.w};
+        const float bv[4] = {b_c.x, b_c.y, b_c.z, b_c.w};
+#pragma unroll
+        for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+          for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = mfma16(av[ta], bv[tb], acc[ta][tb]);
+        load_step(n + 4 * (u + PF) + q, aq[u], bq[u]);
+      }
+    }
   }
   // ---- cross-wave reduction through LDS (fixed order) -------------------------------------------
   // lane holds D_{ta,tb}[row = 4q + r][col = i]  ->  block-local (m = 4*(4q+r) + ta, k = 4*i + tb)
@@ -566,49 +784,54 @@ __device__ __forceinline__ float block_sum_256(float v, float* sm) {
   return t;
 }
 
+// One workgroup = 64 consecutive gradient elements x 4 slab groups: group g adds slabs g, g+4, ... with eight
+// independent loads in flight, then the four group sums are combined in fixed order through LDS.  (A serial
+// loop over 160 slabs per thread was latency-bound at ~120 us.)
+__device__ __forceinline__ float strided_sum(const float* __restrict__ src, int64_t stride, int nparts, int grp) {
+  float part = 0.f;
+  int k = grp;
+  for (; k + 28 < nparts; k += 32) {
+    const float v0 = src[(int64_t)k * stride], v1 = src[(int64_t)(k + 4) * stride];
+    const float v2 = src[(int64_t)(k + 8) * stride], v3 = src[(int64_t)(k + 12) * stride];
+    const float v4 = src[(int64_t)(k + 16) * stride], v5 = src[(int64_t)(k + 20) * stride];
+    const float v6 = src[(int64_t)(k + 24) * stride], v7 = src[(int64_t)(k + 28) * stride];
+    part += ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7));
+  }
+  for (; k < nparts; k += 4) part += src[(int64_t)k * stride];
+  return part;
+}
+
 __global__ __launch_bounds__(256) void grad_reduce_kernel(RedPlan rp, int64_t P, int tail, const float* __restrict__ ws,
                                                           const float* __restrict__ loss_part, int n_loss_part,
                                                           float* __restrict__ grads, float* __restrict__ sumsq_part) {
-  __shared__ float sm[4];
-  float sq = 0.f;
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int64_t e = (int64_t)blockIdx.x * 1024 + it * 256 + threadIdx.x;
-    if (e < P) {
-      int s = 0;
-      while (s + 1 < rp.nseg && e >= rp.seg[s + 1].off) ++s;
-      const RedSeg sg = rp.seg[s];
-      const float* src = ws + sg.base + (e - sg.off);
-      float g = 0.f;
-      for (int k = 0; k < sg.nparts; ++k) g += src[(int64_t)k * sg.stride];
-      grads[e] = g;
-      sq += g * g;
-    } else if (e < P + tail) {
-      const int t = (int)(e - P);
-      float g = 0.f;
-      if (loss_part != nullptr)
-        for (int k = 0; k < n_loss_part; ++k) g += loss_part[(int64_t)k * tail + t];
-      grads[e] = g;
-    }
+  __shared__ float sm[4][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t e = (int64_t)blockIdx.x * 64 + lane;
+  float part = 0.f;
+  if (e < P) {
+    int s = 0;
+    while (s + 1 < rp.nseg && e >= rp.seg[s + 1].off) ++s;
+    const RedSeg sg = rp.seg[s];
+    part = strided_sum(ws + sg.base + (e - sg.off), sg.stride, sg.nparts, grp);
+  } else if (e < P + tail && loss_part != nullptr) {
+    part = strided_sum(loss_part + (e - P), tail, n_loss_part, grp);
   }
-  const float tot = block_sum_256(sq, sm);
-  if (threadIdx.x == 0) sumsq_part[blockIdx.x] = tot;
+  sm[grp][lane] = part;
+  __syncthreads();
+  if (grp == 0) {
+    const float g = ((sm[0][lane] + sm[1][lane]) + sm[2][lane]) + sm[3][lane];
+    if (e < P + tail) grads[e] = g;
+    const float sq = wave_sum(e < P ? g * g : 0.f);
+    if (lane == 0) sumsq_part[blockIdx.x] = sq;
+  }
 }
 
-__global__ __launch_bounds__(256) void grad_sumsq_kernel(int64_t P, const float* __restrict__ grads,
-                                                         float* __restrict__ sumsq_part) {
-  __shared__ float sm[4];
-  float sq = 0.f;
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int64_t e = (int64_t)blockIdx.x * 1024 + it * 256 + threadIdx.x;
-    if (e < P) {
-      const float g = grads[e];
-      sq += g * g;
-    }
-  }
-  const float tot = block_sum_256(sq, sm);
-  if (threadIdx.x == 0) sumsq_part[blockIdx.x] = tot;
+__global__ __launch_bounds__(64) void grad_sumsq_kernel(int64_t P, const float* __restrict__ grads,
+                                                        float* __restrict__ sumsq_part) {
+  const int64_t e = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const float g = (e < P) ? grads[e] : 0.f;
+  const float sq = wave_sum(g * g);
+  if (threadIdx.x == 0) sumsq_part[blockIdx.x] = sq;
 }
 
 // ================================================================================================
@@ -669,7 +892,7 @@ static int fwd_rows_per_wg(const DnnPlan& p, int64_t N) {
   return ((N + 15) / 16 > 512 && lds32 <= 160 * 1024) ? 32 : 16;
 }
 static size_t bwd_lds_bytes(const DnnPlan& p, int R) {
-  return ((size_t)R * (bwd_ldu(p.maxdim) + bwd_ldz(p.maxdim)) + 5 * (size_t)R) * sizeof(float) + (size_t)R * sizeof(int64_t);
+  return ((size_t)R * (2 * bwd_ldu(p.maxdim) + bwd_ldz(p.maxdim)) + 2 * (size_t)bwd_ldu(p.maxdim) + 5 * (size_t)R) * sizeof(float) + (size_t)R * sizeof(int64_t);
 }
 static int bwd_rows_per_wg(const DnnPlan& p, int64_t N) {
   int r = env_int("ULTR_BWD_R", 0);
@@ -693,7 +916,7 @@ bool ultr_make_bwd_plan(const DnnPlan& p, int64_t N, BwdPlan* bp) {
   int64_t off = 0;
   // sum-of-squares partials first (fixed, small)
   const int64_t tail_max = 4096;  // generous: tail is 4 + 2L floats
-  bp->n_red_blocks = (int)((p.P + tail_max + 1023) / 1024);
+  bp->n_red_blocks = (int)ultr_red_blocks(p.P, (int)tail_max);
   bp->sumsq_off = off; off += bp->n_red_blocks; off = (off + 3) & ~(int64_t)3;
   bp->vslab_off = off; off += (int64_t)bp->nrb * bp->vlen; off = (off + 3) & ~(int64_t)3;
   for (int j = 0; j < p.nl - 1; ++j) {
@@ -713,6 +936,7 @@ bool ultr_make_bwd_plan(const DnnPlan& p, int64_t N, BwdPlan* bp) {
     int64_t rps = (N + nsplit - 1) / nsplit;
     rps = (rps + 15) / 16 * 16;
     if (rps < 64) rps = 64;
+    if (rps > 4096) rps = 4096;  // the doc-id table of a split lives in LDS
     w.rows_per_split = (int)rps;
     w.nsplit = (int)((N + rps - 1) / rps);
     w.blk_begin = blk;
@@ -743,6 +967,18 @@ static void make_red_plan(const DnnPlan& p, const BwdPlan& bp, RedPlan* rp) {
     }
   }
   rp->nseg = s;
+}
+
+// true when every hot-loop load may take the aligned branch-free float4 path
+static bool all_vec(const DnnPlan& p, int vm, int64_t N, int64_t n_docs) {
+  // buffer-resource offsets are 32-bit: every described tensor must stay below 2 GiB
+  const int64_t lim = (int64_t)1 << 31;
+  if (n_docs * p.K[0] * 4 >= lim || N * p.maxdim * 4 >= lim) return false;
+  for (int j = 0; j < p.nl; ++j)
+    if (!((vm >> j) & 1)) return false;
+  for (int j = 0; j < p.nl - 1; ++j)
+    if (p.M[j] % 4 != 0) return false;
+  return (vm >> 31) & 1;
 }
 
 static int vecmask_for(const DnnPlan& p, const float* params, const float* features) {
@@ -808,17 +1044,26 @@ extern "C" int ultr_dnn_forward(const ultr_dnn_desc* d, const float* params, con
   const dim3 grid((unsigned)((N + R - 1) / R));
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipSuccess;
-#define LAUNCH_FWD(RR, NWW)                                                                                     \
-  do {                                                                                                          \
-    e = set_lds(dnn_fwd_kernel<RR, NWW>, lds);                                                                  \
-    if (e != hipSuccess) return (int)e;                                                                         \
-    hipLaunchKernelGGL((dnn_fwd_kernel<RR, NWW>), grid, dim3(NWW * 64), lds, st, p, params, features, n_docs,   \
-                       docids, (int)batch, (int)list_size, scores, (float*)saved, vm);                         \
+  UltrProfScope prof(ULTR_K_FWD, st);
+  const bool av = all_vec(p, vm, N, n_docs) && env_int("ULTR_NO_VEC", 0) == 0;
+#define LAUNCH_FWD(RR, NWW, VV)                                                                                     \
+  do {                                                                                                              \
+    e = set_lds(dnn_fwd_kernel<RR, NWW, VV>, lds);                                                                  \
+    if (e != hipSuccess) return (int)e;                                                                             \
+    hipLaunchKernelGGL((dnn_fwd_kernel<RR, NWW, VV>), grid, dim3(NWW * 64), lds, st, p, params, features, n_docs,   \
+                       docids, (int)batch, (int)list_size, scores, (float*)saved, vm);                             \
   } while (0)
-  if (R == 16 && nw == 4) LAUNCH_FWD(16, 4);
-  else if (R == 16) LAUNCH_FWD(16, 8);
-  else if (nw == 4) LAUNCH_FWD(32, 4);
-  else LAUNCH_FWD(32, 8);
+#define LAUNCH_FWD2(RR, NWW) \
+  do {                       \
+    if (av) LAUNCH_FWD(RR, NWW, true); \
+    else LAUNCH_FWD(RR, NWW, false);   \
+  } while (0)
+  if (R == 16 && nw == 4) LAUNCH_FWD2(16, 4);
+  else if (R == 16 && nw == 16) LAUNCH_FWD2(16, 16);
+  else if (R == 16) LAUNCH_FWD2(16, 8);
+  else if (nw == 4) LAUNCH_FWD2(32, 4);
+  else LAUNCH_FWD2(32, 8);
+#undef LAUNCH_FWD2
 #undef LAUNCH_FWD
   return (int)hipGetLastError();
 }
@@ -842,30 +1087,52 @@ extern "C" int ultr_dnn_backward(const ultr_dnn_desc* d, const float* params, co
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipSuccess;
   float* ws = (float*)bwd_ws;
-#define LAUNCH_BWD(RR, NWW)                                                                                        \
-  do {                                                                                                             \
-    e = set_lds(dnn_bwd_kernel<RR, NWW>, lds);                                                                     \
-    if (e != hipSuccess) return (int)e;                                                                            \
-    hipLaunchKernelGGL((dnn_bwd_kernel<RR, NWW>), dim3(bp.nrb), dim3(NWW * 64), lds, st, p, bp, params, features,  \
-                       n_docs, docids, (int)batch, (int)list_size, (const float*)saved, dscores, ws, vm);         \
+  const bool av = all_vec(p, vm, N, n_docs) && env_int("ULTR_NO_VEC", 0) == 0;
+#define LAUNCH_BWD(RR, NWW, VV)                                                                                        \
+  do {                                                                                                                 \
+    e = set_lds(dnn_bwd_kernel<RR, NWW, VV>, lds);                                                                     \
+    if (e != hipSuccess) return (int)e;                                                                                \
+    hipLaunchKernelGGL((dnn_bwd_kernel<RR, NWW, VV>), dim3(bp.nrb), dim3(NWW * 64), lds, st, p, bp, params, features,  \
+                       n_docs, docids, (int)batch, (int)list_size, (const float*)saved, dscores, ws, vm);             \
   } while (0)
-  if (bp.rblk == 16 && nw == 4) LAUNCH_BWD(16, 4);
-  else if (bp.rblk == 16) LAUNCH_BWD(16, 8);
-  else if (nw == 4) LAUNCH_BWD(32, 4);
-  else LAUNCH_BWD(32, 8);
+#define LAUNCH_BWD2(RR, NWW) \
+  do {                       \
+    if (av) LAUNCH_BWD(RR, NWW, true); \
+    else LAUNCH_BWD(RR, NWW, false);   \
+  } while (0)
+  {
+    UltrProfScope prof(ULTR_K_BWD, st);
+    if (bp.rblk == 16 && nw == 4) LAUNCH_BWD2(16, 4);
+    else if (bp.rblk == 16 && nw == 16) LAUNCH_BWD2(16, 16);
+    else if (bp.rblk == 16) LAUNCH_BWD2(16, 8);
+    else if (nw == 4) LAUNCH_BWD2(32, 4);
+    else LAUNCH_BWD2(32, 8);
+  }
+#undef LAUNCH_BWD2
 #undef LAUNCH_BWD
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   if (bp.wgrad_blocks > 0) {
-    hipLaunchKernelGGL(dnn_wgrad_kernel, dim3(bp.wgrad_blocks), dim3(256), 0, st, p, bp, params, features, n_docs, docids,
-                       (int)batch, (int)list_size, (const float*)saved, ws, (vm >> 31) & 1);
+    UltrProfScope prof(ULTR_K_WGRAD, st);
+    int maxrps = 0;
+    for (int j = 0; j < p.nl - 1; ++j) maxrps = bp.wl[j].rows_per_split > maxrps ? bp.wl[j].rows_per_split : maxrps;
+    const size_t wlds = (size_t)(4 * 64 * 64 + 4 * 64 + maxrps) * sizeof(float);
+    e = av ? set_lds(dnn_wgrad_kernel<true>, wlds) : set_lds(dnn_wgrad_kernel<false>, wlds);
+    if (e != hipSuccess) return (int)e;
+    if (av)
+      hipLaunchKernelGGL(dnn_wgrad_kernel<true>, dim3(bp.wgrad_blocks), dim3(256), wlds, st, p, bp, params, features, n_docs,
+                         docids, (int)batch, (int)list_size, (const float*)saved, ws, (vm >> 31) & 1);
+    else
+      hipLaunchKernelGGL(dnn_wgrad_kernel<false>, dim3(bp.wgrad_blocks), dim3(256), wlds, st, p, bp, params, features, n_docs,
+                         docids, (int)batch, (int)list_size, (const float*)saved, ws, (vm >> 31) & 1);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }
   RedPlan rp;
   make_red_plan(p, bp, &rp);
-  const int nblk = (int)((p.P + tail + 1023) / 1024);
+  const int nblk = (int)ultr_red_blocks(p.P, tail);
   const float* lp = (const float*)loss_ws;
+  UltrProfScope prof(ULTR_K_REDUCE, st);
   hipLaunchKernelGGL(grad_reduce_kernel, dim3(nblk), dim3(256), 0, st, rp, p.P, tail, (const float*)ws, lp,
                      (int)ultr_loss_parts(batch), grads, ws + bp.sumsq_off);
   return (int)hipGetLastError();
@@ -874,8 +1141,8 @@ extern "C" int ultr_dnn_backward(const ultr_dnn_desc* d, const float* params, co
 extern "C" int ultr_grad_sumsq(float* grads, int64_t n_params, int32_t list_size, void* bwd_ws, void* stream) {
   if (!grads || !bwd_ws || n_params <= 0) return ULTR_E_BADARG;
   const int tail = (int)ultr_tail_len(list_size);
-  const int nblk = (int)((n_params + tail + 1023) / 1024);
-  hipLaunchKernelGGL(grad_sumsq_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, n_params, (const float*)grads,
+  const int nblk = (int)ultr_red_blocks(n_params, tail);
+  hipLaunchKernelGGL(grad_sumsq_kernel, dim3(nblk), dim3(64), 0, (hipStream_t)stream, n_params, (const float*)grads,
                      (float*)bwd_ws);  // sumsq partials live at offset 0 of bwd_ws
   return (int)hipGetLastError();
 }

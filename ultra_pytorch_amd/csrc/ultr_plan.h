@@ -68,6 +68,9 @@ struct RedPlan {
 #define ULTR_TAIL_FIXED 4
 __host__ __device__ static inline int64_t ultr_tail_len(int L) { return ULTR_TAIL_FIXED + 2 * (int64_t)L; }
 
+// sum-of-squares partials: one per 64 gradient elements (grad_reduce_kernel / grad_sumsq_kernel geometry)
+__host__ __device__ static inline int64_t ultr_red_blocks(int64_t P, int tail) { return (P + tail + 63) / 64; }
+
 // loss workspace: [0] int n_partials (as float bits unused) ; partials [MAXPART][tail]
 #define ULTR_LOSS_LISTS_PER_WG 4
 __host__ __device__ static inline int64_t ultr_loss_parts(int64_t B) { return (B + ULTR_LOSS_LISTS_PER_WG - 1) / ULTR_LOSS_LISTS_PER_WG; }

@@ -1,0 +1,69 @@
+// ultr_prof.hip — HIP-event kernel timers behind ultr_prof_enable / ultr_prof_collect.
+#include "ultr_prof.h"
+
+#include <vector>
+
+#include "../../include/ultr_hip.h"
+
+uint32_t g_ultr_prof_mask = 0;
+
+namespace {
+struct Sample {
+  hipEvent_t a, b;
+  int kid;
+};
+std::vector<Sample> g_pool;
+size_t g_used = 0;
+size_t g_open[ULTR_K_COUNT];
+}  // namespace
+
+void ultr_prof_mark(int kid, int phase, hipStream_t st) {
+  if (phase == 0) {
+    if (g_used >= g_pool.size()) {
+      g_open[kid] = (size_t)-1;
+      return;
+    }
+    g_open[kid] = g_used++;
+    g_pool[g_open[kid]].kid = kid;
+    (void)hipEventRecord(g_pool[g_open[kid]].a, st);
+  } else if (g_open[kid] != (size_t)-1) {
+    (void)hipEventRecord(g_pool[g_open[kid]].b, st);
+  }
+}
+
+extern "C" int ultr_prof_enable(uint32_t kernel_mask, int32_t max_samples) {
+  g_ultr_prof_mask = 0;
+  g_used = 0;
+  if (kernel_mask == 0) return 0;
+  if (max_samples <= 0) return ULTR_E_BADARG;
+  while (g_pool.size() < (size_t)max_samples) {
+    Sample s;
+    hipError_t e = hipEventCreate(&s.a);
+    if (e != hipSuccess) return (int)e;
+    e = hipEventCreate(&s.b);
+    if (e != hipSuccess) return (int)e;
+    s.kid = -1;
+    g_pool.push_back(s);
+  }
+  g_ultr_prof_mask = kernel_mask;
+  return 0;
+}
+
+extern "C" int ultr_prof_collect(double* total_ms, int64_t* counts) {
+  if (!total_ms || !counts) return ULTR_E_BADARG;
+  for (int k = 0; k < ULTR_K_COUNT; ++k) {
+    total_ms[k] = 0.0;
+    counts[k] = 0;
+  }
+  for (size_t i = 0; i < g_used; ++i) {
+    hipError_t e = hipEventSynchronize(g_pool[i].b);
+    if (e != hipSuccess) return (int)e;
+    float ms = 0.f;
+    e = hipEventElapsedTime(&ms, g_pool[i].a, g_pool[i].b);
+    if (e != hipSuccess) return (int)e;
+    total_ms[g_pool[i].kid] += ms;
+    counts[g_pool[i].kid] += 1;
+  }
+  g_used = 0;
+  return 0;
+}

@@ -11,6 +11,7 @@
 #include "../../include/ultr_hip.h"
 #include "ultr_device.h"
 #include "ultr_plan.h"
+#include "ultr_prof.h"
 
 __device__ __forceinline__ float block_sum256(float v, float* sm) {
   v = wave_sum(v);
@@ -135,8 +136,9 @@ extern "C" int ultr_apply_update(const ultr_update_desc* u, float* params, float
   if (u->algo != ULTR_ALGO_SOFTMAX && !aux) return ULTR_E_BADARG;
   if (u->optimizer == ULTR_OPT_ADAGRAD && u->algo != ULTR_ALGO_DLA && !state) return ULTR_E_BADARG;
   const int tail = (int)ultr_tail_len(u->list_size);
-  const int nsq = (int)((u->n_params + tail + 1023) / 1024);
+  const int nsq = (int)ultr_red_blocks(u->n_params, tail);
   const int nblk = (int)((u->n_params + 1023) / 1024);
+  UltrProfScope prof(ULTR_K_UPDATE, (hipStream_t)stream);
   hipLaunchKernelGGL(update_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *u, params, state, grads, aux,
                      (const float*)bwd_ws, nsq, scalars_out);
   return (int)hipGetLastError();
