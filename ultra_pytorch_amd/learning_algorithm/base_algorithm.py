@@ -1,0 +1,133 @@
+"""BaseAlgorithm — the shared half of the `ultra.learning_algorithm` plugin contract, HIP-backed.
+
+Mirrors what main.py and the input feeds call / read on a learning-algorithm object:
+  ctor (data_set, exp_settings); train(input_feed) -> (float loss, None, dict);
+  validation(input_feed, is_online_simulation=False) -> (None, Tensor[B, max_candidate_num], dict);
+  attributes model, global_step, learning_rate, rank_list_size, max_candidate_num, feature_size,
+  letor_features_name, docid_inputs_name[], labels_name[], hparams.
+Reference: ultra/learning_algorithm/base_algorithm.py:32-333.
+
+The hot path — gather + DNN forward, the loss, DNN backward, clip, optimizer, NDCG — runs in libultr_hip.so
+(engine.StepEngine / EvalEngine).  This file only marshals the feed (host numpy -> pinned -> HBM) and keeps the
+reference's bookkeeping.  There is no CPU path: constructing an algorithm without a GPU raises.
+"""
+import numpy as np
+import torch
+
+from .. import engine
+from ..utils import find_class
+from ..utils import metrics as metrics_mod
+
+
+class BaseAlgorithm(object):
+    PADDING_SCORE = -100000  # base_algorithm.py:36
+    ENGINE_ALGO = "softmax"
+
+    # ---- construction ------------------------------------------------------------------------------
+    def _setup(self, data_set, exp_settings):
+        if not torch.cuda.is_available():
+            raise RuntimeError("ultra_pytorch_amd.learning_algorithm needs an MI355X/ROCm GPU (no CPU fallback)")
+        self.cuda = torch.device("cuda", torch.cuda.current_device())
+        self.is_cuda_avail = True
+        self.train_summary, self.eval_summary = {}, {}
+        self.exp_settings = exp_settings
+        if "selection_bias_cutoff" in exp_settings:
+            self.rank_list_size = int(exp_settings["selection_bias_cutoff"])
+        self.max_candidate_num = int(exp_settings["max_candidate_num"])
+        self.feature_size = int(data_set.feature_size)
+        self.letor_features_name = "letor_features"
+        self.letor_features = None
+        self.docid_inputs_name = ["docid_input{0}".format(i) for i in range(self.max_candidate_num)]
+        self.labels_name = ["label{0}".format(i) for i in range(self.max_candidate_num)]
+        self.docid_inputs, self.labels = [], []
+        self.global_step = 0
+        self.model = self.create_model(self.feature_size).to(self.cuda)
+        self.learning_rate = float(self.hparams.learning_rate)
+        self.state_sum = torch.zeros_like(self.model.flat_params)  # Adagrad accumulator (initial value 0)
+        self._train_engines, self._eval_engines, self._stage = {}, {}, {}
+        self.process_group = exp_settings.get("process_group", None)  # data parallel: one rank per GPU
+
+    def create_model(self, feature_size):
+        """base_algorithm.py:156-167: the ranking model is a plugin too."""
+        model = find_class(self.exp_settings["ranking_model"])(self.exp_settings["ranking_model_hparams"], feature_size)
+        if not hasattr(model, "flat_params") or not hasattr(model, "shape"):
+            raise TypeError("ranking_model %r is not a HIP-backed model; use ultra_pytorch_amd.ranking_model.DNN / .Linear"
+                            % self.exp_settings["ranking_model"])
+        return model
+
+    # ---- feed marshalling (a1: base_algorithm.py:169-186) -------------------------------------------
+    def _pinned(self, key, shape, dtype):
+        t = self._stage.get(key)
+        n = int(np.prod(shape))
+        if t is None or t.numel() < n or t.dtype != dtype:
+            t = torch.empty(max(n, 1), dtype=dtype).pin_memory()
+            self._stage[key] = t
+        return t[:n].view(*shape)
+
+    def _upload(self, key, array, dtype):
+        host = self._pinned(key, array.shape, dtype)
+        host.copy_(torch.from_numpy(np.ascontiguousarray(array)))  # casts (f64 features -> f32, f32 ids -> i32)
+        return host.to(self.cuda, non_blocking=True)
+
+    def create_input_feed(self, input_feed, list_size):
+        """numpy feed -> device tensors: features [n_docs,F] f32, docids [L,B] i32, labels [L,B] f32."""
+        feats = np.asarray(input_feed[self.letor_features_name])
+        if feats.ndim != 2:
+            feats = feats.reshape(0, self.feature_size)
+        self.n_docs = int(feats.shape[0])
+        ids = np.stack([np.asarray(input_feed[self.docid_inputs_name[l]]) for l in range(list_size)])
+        lab = np.stack([np.asarray(input_feed[self.labels_name[l]]) for l in range(list_size)])
+        self.batch_size = int(ids.shape[1])
+        self.letor_features = self._upload("features", feats, torch.float32) if self.n_docs > 0 else None
+        self.docid_inputs = self._upload("docids", ids, torch.int32)
+        self.labels_LB = self._upload("labels", lab, torch.float32)
+        return lab
+
+    # ---- engines -------------------------------------------------------------------------------------
+    def _engine_kwargs(self):
+        return {}
+
+    def _train_engine(self, B, L):
+        key = (B, L)
+        if key not in self._train_engines:
+            kw = dict(learning_rate=self.learning_rate, max_gradient_norm=float(self.hparams.max_gradient_norm),
+                      optimizer="sgd" if self.hparams.grad_strategy == "sgd" else "ada",
+                      process_group=self.process_group)
+            kw.update(self._engine_kwargs())
+            self._train_engines[key] = engine.StepEngine(self.model.shape, B, L, self.cuda, algo=self.ENGINE_ALGO, **kw)
+        return self._train_engines[key]
+
+    def _check_hparams(self):
+        if float(getattr(self.hparams, "l2_loss", 0.0)) > 0:
+            raise NotImplementedError("l2_loss > 0: in the reference this also silently disables gradient clipping "
+                                      "(ipw_rank.py:154-159); only l2_loss = 0 is supported")
+        lf = getattr(self.hparams, "loss_func", "softmax_loss")
+        if lf in ("sigmoid_loss", "pairwise_loss"):
+            raise NotImplementedError("loss_func=%r raises in the reference too (base_algorithm.py:267,307)" % lf)
+
+    # ---- validation (a12/a13: e.g. ipw_rank.py:184-211) ----------------------------------------------
+    def validation(self, input_feed, is_online_simulation=False):
+        self.model.eval()
+        L = self.max_candidate_num
+        labels_host = self.create_input_feed(input_feed, L)
+        B = self.batch_size
+        topn = [int(t) for t in self.exp_settings["metrics_topn"]]
+        key = (B, L, tuple(topn))
+        if key not in self._eval_engines:
+            self._eval_engines[key] = engine.EvalEngine(self.model.shape, B, L, self.cuda, topn=topn)
+        ev = self._eval_engines[key]
+        scores, ndcg = ev.run(self.model.flat_params, self.letor_features, self.n_docs, self.docid_inputs, self.labels_LB)
+        self.output = scores.clone()  # the UNMASKED scores are what callers get (base_algorithm.py / main.py:266)
+        if not is_online_simulation:
+            masked = None
+            for metric in self.exp_settings["metrics"]:
+                if metric == metrics_mod.RankingMetricKey.NDCG:
+                    values = ndcg.cpu()
+                else:
+                    if masked is None:
+                        masked = ev.masked.cpu()
+                        lab_BL = torch.from_numpy(np.ascontiguousarray(labels_host.T.astype(np.float32)))
+                    values = metrics_mod.make_ranking_metric_fn(metric, topn)(lab_BL, masked, None)
+                for n, v in zip(topn, values):
+                    self.eval_summary["%s_%d" % (metric, n)] = float(v)
+        return None, self.output, self.eval_summary
