@@ -120,6 +120,11 @@ def main():
     ap.add_argument("--sync-every-step", action="store_true", help="also read loss.item() every step (API-faithful)")
     args = ap.parse_args()
 
+    # stdout must carry exactly ONE line (the JSON): RCCL / HIP print banners to fd 1 on init, so everything goes
+    # to stderr until the result is ready
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -129,12 +134,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    pg = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
-        pg = dist.group.WORLD
+    from ultra_pytorch_amd import parallel
+    _, _, _, pg = parallel.init_process_group_from_env(backend="nccl")
 
     from ultra_pytorch_amd import _lib, engine, hip_ops, synthetic
     from ultra_pytorch_amd.ranking_model import init_flat_params
@@ -154,7 +155,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if pg is not None:
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
@@ -183,7 +184,7 @@ def main():
     lib.ultr_prof_enable(0, 0)
     dom_s = 1e-3 * tot[dom] / max(cnt[dom], 1)
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=device)
-    if world > 1:
+    if pg is not None:
         torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(elapsed.item())
     final_loss = float(eng.scalars[0].item())
@@ -228,8 +229,10 @@ def main():
             out["queries_per_sec_with_loss_item_each_step"] = B * world / synced
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pool, params0)
-        print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+    if pg is not None:
         torch.distributed.destroy_process_group()
 
 

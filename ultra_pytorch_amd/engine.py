@@ -85,7 +85,7 @@ class StepEngine:
     def backward(self, params, features, n_docs, docids):
         hip_ops.dnn_backward(self.shape, params, features, n_docs, docids, self.B, self.L, self.saved, self.dscores,
                              self.loss_ws, self.bwd_ws, self.grads)
-        if self.world > 1:
+        if self.pg is not None:
             # queries shard across ranks; ONE sum all-reduce (RCCL over xGMI) of [grads | step tail]
             torch.distributed.all_reduce(self.grads, group=self.pg)
             hip_ops.grad_sumsq(self.grads, self.P, self.L, self.bwd_ws)
