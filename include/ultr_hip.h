@@ -77,9 +77,16 @@ int64_t ultr_loss_workspace_bytes(int64_t batch, int32_t list_size);
  * then [LayerNorm -> Linear -> act] x k -> LayerNorm -> Linear(.,1), scores as [B, L].
  * saved == NULL: inference (validation) forward; otherwise activations and LayerNorm
  * statistics are kept for ultr_dnn_backward. */
-int ultr_dnn_forward(const ultr_dnn_desc* d, const float* params, const float* features, int64_t n_docs,
-                     const int32_t* docids, int32_t batch, int32_t list_size, float* scores, void* saved,
-                     void* stream);
+int ultr_dnn_forward(const ultr_dnn_desc* d, const float* params, const float* wt, const float* features,
+                     int64_t n_docs, const int32_t* docids, int32_t batch, int32_t list_size, float* scores,
+                     void* saved, void* stream);
+
+/* k-major copy of the hidden Linear weights (WT_j = W_j^T): lets the forward stream MFMA B-fragments as
+ * 256-byte contiguous pieces.  `wt` has ultr_dnn_wt_floats(d) floats; build it once after the parameters
+ * were written from outside (load_state_dict / init), ultr_apply_update keeps it current afterwards.
+ * Passing wt == NULL to ultr_dnn_forward selects the (slower) generic path that reads W directly. */
+int64_t ultr_dnn_wt_floats(const ultr_dnn_desc* d);
+int ultr_dnn_build_wt(const ultr_dnn_desc* d, const float* params, float* wt, void* stream);
 
 /* ---- a5 (backward half): what loss.backward() does for the DNN ----------------------
  * Replaces autograd through DNN.sequential (called from BaseAlgorithm.opt_step,
@@ -162,12 +169,47 @@ typedef struct ultr_update_desc {
 
 /* params/state [P] updated in place; grads = the buffer ultr_dnn_backward filled (possibly
  * all-reduced).  aux = prop_params[L+1] (DLA) or [t_plus(L) | t_minus(L)] (PairDebias /
- * LambdaRank), updated in place; NULL for SOFTMAX.  bwd_ws = the workspace ultr_dnn_backward (or
+ * LambdaRank), updated in place; NULL for SOFTMAX.  d + wt (both may be NULL): keep the k-major weight copy
+ * in sync with the updated parameters.  bwd_ws = the workspace ultr_dnn_backward (or
  * ultr_grad_sumsq) left the sum-of-squares partials in.
  * scalars_out[8]: [0] loss [1] ranker grad norm (pre-clip) [2] clip coef [3] D
  *                 [4] rank_loss (DLA) [5] exam_loss (DLA) [6] propensity grad norm (DLA) [7] sum g^2 */
-int ultr_apply_update(const ultr_update_desc* u, float* params, float* state, const float* grads, float* aux,
-                      const void* bwd_ws, float* scalars_out, void* stream);
+int ultr_apply_update(const ultr_update_desc* u, const ultr_dnn_desc* d, float* params, float* wt, float* state,
+                      const float* grads, float* aux, const void* bwd_ws, float* scalars_out, void* stream);
+
+/* ---- one call per training step -----------------------------------------------------------
+ * ultr_dnn_forward -> ultr_<loss by upd->algo> -> ultr_dnn_backward -> ultr_apply_update, enqueued by ONE host
+ * call (what `model.train(input_feed)` does between marshalling the feed and `loss.item()`).  A data-parallel
+ * caller sets skip_update, all-reduces `grads`, then calls ultr_grad_sumsq + ultr_apply_update itself.
+ * aux: prop_params (DLA) or [t_plus | t_minus] (PairDebias / LambdaRank) or NULL. */
+typedef struct ultr_step_args {
+  const ultr_dnn_desc* desc;
+  const ultr_update_desc* upd;
+  float* params;
+  float* wt;
+  float* state;
+  float* aux;
+  const float* features;
+  const int32_t* docids;
+  const float* labels;
+  const float* pw;
+  const float* ipw_table;
+  float* scores;
+  float* dscores;
+  void* saved;
+  void* loss_ws;
+  void* bwd_ws;
+  float* grads;
+  float* scalars;
+  int64_t n_docs;
+  int32_t n_ipw;
+  int32_t batch;
+  int32_t list_size;
+  int32_t batch_total; /* PairDebias: global batch (0 = batch) */
+  int32_t skip_update;
+  float sigma;         /* LambdaRank */
+} ultr_step_args;
+int ultr_train_step(const ultr_step_args* a, void* stream);
 
 /* ---- a12 + a13: validation metrics ---------------------------------------------------
  * Replaces remove_padding_for_metric_eval (base_algorithm.py:88-116) and

@@ -28,6 +28,14 @@ class UpdateDesc(ctypes.Structure):
                 ("regulation_p", c_f32), ("reserved", c_f32)]
 
 
+class StepArgs(ctypes.Structure):
+    _fields_ = [("desc", ctypes.POINTER(DnnDesc)), ("upd", ctypes.POINTER(UpdateDesc)), ("params", c_vp), ("wt", c_vp),
+                ("state", c_vp), ("aux", c_vp), ("features", c_vp), ("docids", c_vp), ("labels", c_vp), ("pw", c_vp),
+                ("ipw_table", c_vp), ("scores", c_vp), ("dscores", c_vp), ("saved", c_vp), ("loss_ws", c_vp),
+                ("bwd_ws", c_vp), ("grads", c_vp), ("scalars", c_vp), ("n_docs", c_i64), ("n_ipw", c_i32),
+                ("batch", c_i32), ("list_size", c_i32), ("batch_total", c_i32), ("skip_update", c_i32), ("sigma", c_f32)]
+
+
 # name -> (restype, argtypes); must list EVERY symbol include/ultr_hip.h declares
 SIGNATURES = {
     "ultr_abi_version": (c_i32, []),
@@ -37,7 +45,9 @@ SIGNATURES = {
     "ultr_dnn_bwd_workspace_bytes": (c_i64, [ctypes.POINTER(DnnDesc), c_i64]),
     "ultr_step_tail_floats": (c_i64, [c_i32]),
     "ultr_loss_workspace_bytes": (c_i64, [c_i64, c_i32]),
-    "ultr_dnn_forward": (c_i32, [ctypes.POINTER(DnnDesc), c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "ultr_dnn_forward": (c_i32, [ctypes.POINTER(DnnDesc), c_vp, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "ultr_dnn_wt_floats": (c_i64, [ctypes.POINTER(DnnDesc)]),
+    "ultr_dnn_build_wt": (c_i32, [ctypes.POINTER(DnnDesc), c_vp, c_vp, c_vp]),
     "ultr_dnn_backward": (c_i32, [ctypes.POINTER(DnnDesc), c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp,
                                   c_vp, c_vp]),
     "ultr_grad_sumsq": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp]),
@@ -45,7 +55,9 @@ SIGNATURES = {
     "ultr_dla_loss": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "ultr_pairdebias_loss": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "ultr_lambdarank_loss": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_vp, c_vp, c_vp]),
-    "ultr_apply_update": (c_i32, [ctypes.POINTER(UpdateDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "ultr_apply_update": (c_i32, [ctypes.POINTER(UpdateDesc), ctypes.POINTER(DnnDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                  c_vp, c_vp]),
+    "ultr_train_step": (c_i32, [ctypes.POINTER(StepArgs), c_vp]),
     "ultr_prof_enable": (c_i32, [ctypes.c_uint32, c_i32]),
     "ultr_prof_collect": (c_i32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
     "ultr_ndcg": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, ctypes.POINTER(c_i32), c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),

@@ -25,10 +25,11 @@
 // ------------------------------------------------------------------------------------------------
 // LDS leading dimensions
 // ------------------------------------------------------------------------------------------------
-// forward buffers: float4 A-fragment reads -> ld % 4 == 0 and (ld/4) odd
-__host__ __device__ static inline int fwd_ld(int maxdim) { return round_up(maxdim, 16) + 4; }
-// backward dz buffer: scalar A-fragment reads [i][m0+q] -> ld == 2 (mod 32) is conflict-free
-__host__ __device__ static inline int bwd_ldz(int maxdim) { return round_up(maxdim, 32) + 2; }
+// forward buffers: float4 epilogue stores / float4 A reads of the generic path -> ld % 4 == 0; rows padded so that
+// the pipelined GEMM may read (masked) up to 31 columns past K
+__host__ __device__ static inline int fwd_ld(int maxdim) { return round_up(maxdim, 32) + 36; }
+// backward dz buffer: float4 A-fragment reads, rows zero-padded to a multiple of 32 (see gemm_nn4)
+__host__ __device__ static inline int bwd_ldz(int maxdim) { return round_up(maxdim, 32) + 36; }
 // backward du buffer: float4 epilogue stores -> ld % 4 == 0
 __host__ __device__ static inline int bwd_ldu(int maxdim) { return round_up(maxdim, 16) + 4; }
 
@@ -139,50 +140,133 @@ __device__ __forceinline__ void gemm_nt_chunk(const float* __restrict__ Xs, int 
 // column tiles (tile t holds columns c0 + 4j + t) for four m-steps, i.e. one 16-byte load feeds 4 MFMAs per row
 // tile - the same ratio as the forward form, without keeping a transposed copy of the weights.
 template <int RT, bool VEC>
-__device__ __forceinline__ void gemm_nn4(const float* __restrict__ DZs, int ldz, const Src& W, int K,
+__device__ __forceinline__ void gemm_nn4(const float* __restrict__ As, int lda, const Src& W, int K,
                                          int mb, int me, int c0, f32x4 (&acc)[RT][4], int lane) {
-  constexpr int PF = 2;  // ring depth in 16-row groups of W: 8 x 16-byte loads in flight per lane
   const int i = lane & 15, q = lane >> 4;
   const int col = c0 + 4 * i;
-  const int nit = (me - mb + 15) >> 4;
-  float4 bq[PF][4];
-  auto load_w = [&](float4(&dst)[4], int m0) {
+  if constexpr (VEC) {
+    // Straight-line software pipeline, 32 rows of W (two 16-row groups) per trip, no control flow and no masks:
+    //  * the slice [mb, me) starts on a multiple of 32; the A tile in LDS is ZERO beyond the real contraction
+    //    length up to the next multiple of 32, so a ragged tail contributes nothing;
+    //  * lane (i, q) owns contraction indices m0 + 4q .. 4q+3 of a group: A is ONE ds_read_b128, B four 16-byte
+    //    rows W[m0 + 4q + s][c0 + 4i ..] (256 B contiguous per 16 lanes);
+    //  * the next trip's B rows are issued at the TOP of the trip into their own registers (reloading in place
+    //    would have to wait for the MFMAs that read them - hipcc then sinks every load to the end of the body and
+    //    drains vmcnt(0) at the top); past the slice they are fetched with the out-of-bounds offset (no traffic).
+    const int npair = (me - mb + 31) >> 5;
+    const unsigned rs = (unsigned)K * 4u;  // bytes per row of W
+    unsigned o0 = ((unsigned)(mb + 4 * q) * (unsigned)K + (unsigned)col) * 4u;
+    const float* ap = As + i * lda + mb + 4 * q;
+    int m0 = mb;
+    // one trip: prefetch the NEXT 32 rows into (nx0, nx1), consume (cu0, cu1).  The caller alternates the two
+    // register sets, so there are no register copies and no in-place reloads.
+    auto trip = [&](float4(&cu0)[4], float4(&cu1)[4], float4(&nx0)[4], float4(&nx1)[4]) {
+      const unsigned on = o0 + 32u * rs;
+      const bool more0 = m0 + 32 < me, more1 = m0 + 48 < me;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int m = m0 + 4 * s + q;
-      // VEC: rows m >= me meet a zeroed A element, rows m >= M are past the buffer, columns >= K are discarded
-      if constexpr (VEC) dst[s] = buf_ld4(W, (unsigned)(m * K + col) * 4u);
-      else dst[s] = ld4_sel<VEC>(W, (int64_t)m * K, m < me, col, K);
-    }
-  };
+      for (int s = 0; s < 4; ++s) {
+        nx0[s] = buf_ld4(W, more0 ? (on + (unsigned)s * rs) : ULTR_OOB);
+        nx1[s] = buf_ld4(W, more1 ? (on + (unsigned)(16 + s) * rs) : ULTR_OOB);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch at the top of the trip
+      float4 a0[RT], a1[RT];
 #pragma unroll
-  for (int u = 0; u < PF; ++u) {
-    if (u < nit) load_w(bq[u], mb + 16 * u);
-  }
-  for (int it0 = 0; it0 < nit; it0 += PF) {
+      for (int rt = 0; rt < RT; ++rt) {
+        a0[rt] = ld4(ap + rt * 16 * lda);
+        a1[rt] = ld4(ap + rt * 16 * lda + 16);
+      }
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      const int it = it0 + u;
-      if (it < nit) {
-        const int m0 = mb + it * 16;
+      for (int rt = 0; rt < RT; ++rt) {
+        const float av[4] = {a0[rt].x, a0[rt].y, a0[rt].z, a0[rt].w};
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const int m = m0 + 4 * s + q;
-          float a[RT];
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt) a[rt] = (m < me) ? DZs[(rt * 16 + i) * ldz + m] : 0.f;
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt) {
-            acc[rt][0] = mfma16(a[rt], bq[u][s].x, acc[rt][0]);
-            acc[rt][1] = mfma16(a[rt], bq[u][s].y, acc[rt][1]);
-            acc[rt][2] = mfma16(a[rt], bq[u][s].z, acc[rt][2]);
-            acc[rt][3] = mfma16(a[rt], bq[u][s].w, acc[rt][3]);
-          }
+          acc[rt][0] = mfma16(av[s], cu0[s].x, acc[rt][0]);
+          acc[rt][1] = mfma16(av[s], cu0[s].y, acc[rt][1]);
+          acc[rt][2] = mfma16(av[s], cu0[s].z, acc[rt][2]);
+          acc[rt][3] = mfma16(av[s], cu0[s].w, acc[rt][3]);
         }
-        if (it + PF < nit) load_w(bq[u], m0 + 16 * PF);
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const float av[4] = {a1[rt].x, a1[rt].y, a1[rt].z, a1[rt].w};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          acc[rt][0] = mfma16(av[s], cu1[s].x, acc[rt][0]);
+          acc[rt][1] = mfma16(av[s], cu1[s].y, acc[rt][1]);
+          acc[rt][2] = mfma16(av[s], cu1[s].z, acc[rt][2]);
+          acc[rt][3] = mfma16(av[s], cu1[s].w, acc[rt][3]);
+        }
+      }
+      o0 = on;
+      ap += 32;
+      m0 += 32;
+    };
+    float4 p0[4], p1[4], r0[4], r1[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      p0[s] = buf_ld4(W, o0 + (unsigned)s * rs);
+      p1[s] = buf_ld4(W, (mb + 16 < me) ? (o0 + (unsigned)(16 + s) * rs) : ULTR_OOB);
+    }
+    int pr = 0;
+    for (; pr + 1 < npair; pr += 2) {
+      trip(p0, p1, r0, r1);
+      trip(r0, r1, p0, p1);
+    }
+    if (pr < npair) trip(p0, p1, r0, r1);
+  } else {
+    // generic path (unaligned / ragged shapes): masked scalar loads, no pipelining
+    for (int m0 = mb; m0 < me; m0 += 4) {
+      const int m = m0 + q;
+      const float4 b = ld4_sel<false>(W, (int64_t)m * K, m < me, col, K);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const float a = (m < me) ? As[(rt * 16 + i) * lda + m] : 0.f;
+        acc[rt][0] = mfma16(a, b.x, acc[rt][0]);
+        acc[rt][1] = mfma16(a, b.y, acc[rt][1]);
+        acc[rt][2] = mfma16(a, b.z, acc[rt][2]);
+        acc[rt][3] = mfma16(a, b.w, acc[rt][3]);
       }
     }
   }
+}
+
+// forward epilogue of the last contraction slice: (+ partial sums of earlier slices) + bias, activation; to LDS
+// (next layer's input) and, when training, to HBM — 16-byte stores, the lane owns 4 consecutive output columns
+template <int RT>
+__device__ __forceinline__ void finish_fwd_nn4(const f32x4 (&acc)[RT][4], float* __restrict__ Ys, int ldy, int M, int c0,
+                                               int lane, bool add, const float* __restrict__ bias, int act,
+                                               float* __restrict__ gout, int rows_valid, bool vec) {
+  const int i = lane & 15, q = lane >> 4;
+  const int col = c0 + 4 * i;
+  if (col >= M) return;
+  float bv[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) bv[t] = (col + t < M) ? bias[col + t] : 0.f;
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = rt * 16 + 4 * q + r;
+      float* dst = Ys + row * ldy + col;
+      float v[4] = {acc[rt][0][r], acc[rt][1][r], acc[rt][2][r], acc[rt][3][r]};
+      if (add) {
+        const float4 o = ld4(dst);  // LDS rows are padded to a multiple of 4: a full float4 is always in range
+        v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v[t] = act_fwd(v[t] + bv[t], act);
+      st4(dst, make_float4(v[0], v[1], v[2], v[3]));
+      if (gout != nullptr && row < rows_valid) {
+        float* g = gout + (int64_t)row * M + col;
+        if (vec && col + 3 < M) {
+          st4(g, make_float4(v[0], v[1], v[2], v[3]));
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (col + t < M) g[t] = v[t];
+        }
+      }
+    }
 }
 
 // epilogue of gemm_nn4: lane holds D_t[row = 4q + r][j = i] = DU[row][c0 + 4i + t]
@@ -245,7 +329,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
                                                           const float* __restrict__ features, int64_t n_docs,
                                                           const int32_t* __restrict__ docids, int B, int L,
                                                           float* __restrict__ scores, float* __restrict__ saved,
-                                                          int vecmask) {
+                                                          const float* __restrict__ wt, int vecmask) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int RT = R / 16;
   const int64_t N = (int64_t)B * L;
@@ -278,7 +362,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
 
   for (int j = 0; j < p.nl; ++j) {
     const int K = p.K[j], M = p.M[j];
-    const int K16 = round_up(K, 16);
+    const int K16 = round_up(K, 32);  // zero-padded width of the A tile (multiple of 32, see gemm_nn4)
     const float* lnw = params + p.off_lnw[j];
     const float* lnb = params + p.off_lnb[j];
     // ---- LayerNorm (biased variance, eps 1e-5, affine), in place; two-pass statistics -----------
@@ -347,17 +431,69 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
     if (j < p.nl - 1) {
       // ---- Linear + activation on the matrix cores ------------------------------------------------
       float* gout = (saved != nullptr) ? (saved + p.sv_x[j + 1] + n0 * M) : nullptr;
-      const Src Wsrc = make_src(W, (int64_t)M * K);
-      const int ct = pick_ct(M, NW);
-      if (ct == 4) {
-        for (int ch = wave; ch * 64 < M; ch += NW)
-          gemm_nt_chunk<RT, 4, VEC>(X, ld, K, K16, Wsrc, bias, M, ch * 64, p.act, Y, ld, gout, rows_valid, lane);
-      } else if (ct == 2) {
-        for (int ch = wave; ch * 32 < M; ch += NW)
-          gemm_nt_chunk<RT, 2, VEC>(X, ld, K, K16, Wsrc, bias, M, ch * 32, p.act, Y, ld, gout, rows_valid, lane);
+      if constexpr (VEC) {
+        // Y = act(X . W^T + b) on the k-major weight copy: 64-column chunks x slices of the contraction over the
+        // NW waves; slice 0 stores its partial tile in Y, later slices add in fixed order, the last one finishes
+        const Src Wt = make_src(wt + p.wt_off[j], (int64_t)K * M);
+        const int nch = (M + 63) >> 6;
+        int ksplit = 1;
+        while (ksplit * 2 * nch <= NW) ksplit *= 2;
+        if (ksplit == 1) {
+          for (int ch = wave; ch < nch; ch += NW) {
+            f32x4 acc[RT][4];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+              for (int t = 0; t < 4; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            gemm_nn4<RT, true>(X, ld, Wt, M, 0, K, ch * 64, acc, lane);
+            finish_fwd_nn4<RT>(acc, Y, ld, M, ch * 64, lane, false, bias, p.act, gout, rows_valid, true);
+          }
+        } else {
+          const int klen = round_up((K + ksplit - 1) / ksplit, 32);
+          const bool has = wave < nch * ksplit;
+          const int ch = wave % nch, ks = wave / nch;
+          f32x4 acc[RT][4];
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (has) {
+            const int kb = ks * klen;
+            const int ke = (kb + klen < K) ? (kb + klen) : K;
+            if (kb < ke) gemm_nn4<RT, true>(X, ld, Wt, M, kb, ke, ch * 64, acc, lane);
+          }
+          // raw partial tiles are summed into Y slice by slice (fixed order), then ALL threads apply bias +
+          // activation (the expm1f-heavy epilogue would otherwise run on the last slice's waves only)
+          for (int r = 0; r < ksplit; ++r) {
+            if (has && ks == r) store_nn4<RT>(acc, Y, ld, M, ch * 64, lane, r > 0);
+            __syncthreads();
+          }
+          const int M4 = M >> 2;  // VEC path: M % 4 == 0
+          for (int e = tid; e < R * M4; e += NW * 64) {
+            const int row = e / M4, c4 = (e - row * M4) * 4;
+            float4 v = ld4(Y + row * ld + c4);
+            const float4 b4 = ld4(bias + c4);
+            v.x = act_fwd(v.x + b4.x, p.act);
+            v.y = act_fwd(v.y + b4.y, p.act);
+            v.z = act_fwd(v.z + b4.z, p.act);
+            v.w = act_fwd(v.w + b4.w, p.act);
+            st4(Y + row * ld + c4, v);
+            if (gout != nullptr && row < rows_valid) st4(gout + (int64_t)row * M + c4, v);
+          }
+        }
       } else {
-        for (int ch = wave; ch * 16 < M; ch += NW)
-          gemm_nt_chunk<RT, 1, VEC>(X, ld, K, K16, Wsrc, bias, M, ch * 16, p.act, Y, ld, gout, rows_valid, lane);
+        const Src Wsrc = make_src(W, (int64_t)M * K);
+        const int ct = pick_ct(M, NW);
+        if (ct == 4) {
+          for (int ch = wave; ch * 64 < M; ch += NW)
+            gemm_nt_chunk<RT, 4, false>(X, ld, K, K16, Wsrc, bias, M, ch * 64, p.act, Y, ld, gout, rows_valid, lane);
+        } else if (ct == 2) {
+          for (int ch = wave; ch * 32 < M; ch += NW)
+            gemm_nt_chunk<RT, 2, false>(X, ld, K, K16, Wsrc, bias, M, ch * 32, p.act, Y, ld, gout, rows_valid, lane);
+        } else {
+          for (int ch = wave; ch * 16 < M; ch += NW)
+            gemm_nt_chunk<RT, 1, false>(X, ld, K, K16, Wsrc, bias, M, ch * 16, p.act, Y, ld, gout, rows_valid, lane);
+        }
       }
       TRACE_STAMP(3 + 3 * j);
       __syncthreads();
@@ -510,7 +646,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd_kernel(DnnPlan p, BwdPlan bp,
           store_nn4<RT>(acc, DU, ldu, K, ch * 64, lane, false);
         }
       } else {
-        const int mlen = round_up((M + msplit - 1) / msplit, 16);
+        const int mlen = round_up((M + msplit - 1) / msplit, 32);
         const bool has = wave < nch * msplit;
         const int ch = wave % nch, ms = wave / nch;
         f32x4 acc[RT][4];
@@ -584,10 +720,29 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd_kernel(DnnPlan p, BwdPlan bp,
           DZ[r * ldz + c] = dzv;
           if (valid) dzg[n * K + c] = dzv;
         }
+        for (int c = K + lane; c < round_up(K, 32); c += 64) DZ[r * ldz + c] = 0.f;  // zero pad (gemm_nn4 reads it)
       }
     }
   }
 }
+
+// One workgroup = 64 consecutive gradient elements x 4 slab groups: group g adds slabs g, g+4, ... with eight
+// independent loads in flight, then the four group sums are combined in fixed order through LDS.  (A serial
+// loop over 160 slabs per thread was latency-bound at ~120 us.)
+__device__ __forceinline__ float strided_sum(const float* __restrict__ src, int64_t stride, int nparts, int grp) {
+  float part = 0.f;
+  int k = grp;
+  for (; k + 28 < nparts; k += 32) {
+    const float v0 = src[(int64_t)k * stride], v1 = src[(int64_t)(k + 4) * stride];
+    const float v2 = src[(int64_t)(k + 8) * stride], v3 = src[(int64_t)(k + 12) * stride];
+    const float v4 = src[(int64_t)(k + 16) * stride], v5 = src[(int64_t)(k + 20) * stride];
+    const float v6 = src[(int64_t)(k + 24) * stride], v7 = src[(int64_t)(k + 28) * stride];
+    part += ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7));
+  }
+  for (; k < nparts; k += 4) part += src[(int64_t)k * stride];
+  return part;
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // Weight gradients of the hidden Linears: dW_j[m,k] = sum_n dz_j[n,m] u_j[n,k],  db_j[m] = sum_n dz_j[n,m]
@@ -608,6 +763,18 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
   float (*bred)[64] = reinterpret_cast<float (*)[64]>(smem + 4 * 64 * 64);
   int* sm_ids = reinterpret_cast<int*>(smem + 4 * 64 * 64 + 4 * 64);
   const int64_t N = bp.N;
+  if ((int)blockIdx.x >= bp.wgrad_blocks) {
+    // spare workgroups: fold the nrb per-row-block vector slabs (LayerNorm gamma/beta, scorer) into ONE slab while
+    // the matrix blocks run, so that the reduction kernel's critical path is not a 160-deep serial sum
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int e = ((int)blockIdx.x - bp.wgrad_blocks) * 64 + lane;
+    const float part = (e < bp.vlen) ? strided_sum(ws + bp.vslab_off + e, bp.vlen, bp.nrb, grp) : 0.f;
+    smem[grp * 64 + lane] = part;
+    __syncthreads();
+    if (grp == 0 && e < bp.vlen)
+      ws[bp.vred_off + e] = ((smem[lane] + smem[64 + lane]) + smem[128 + lane]) + smem[192 + lane];
+    return;
+  }
   int j = 0;
   while (j + 1 < p.nl - 1 && (int)blockIdx.x >= bp.wl[j + 1].blk_begin) ++j;
   const WgradLayer wl = bp.wl[j];
@@ -784,23 +951,6 @@ __device__ __forceinline__ float block_sum_256(float v, float* sm) {
   return t;
 }
 
-// One workgroup = 64 consecutive gradient elements x 4 slab groups: group g adds slabs g, g+4, ... with eight
-// independent loads in flight, then the four group sums are combined in fixed order through LDS.  (A serial
-// loop over 160 slabs per thread was latency-bound at ~120 us.)
-__device__ __forceinline__ float strided_sum(const float* __restrict__ src, int64_t stride, int nparts, int grp) {
-  float part = 0.f;
-  int k = grp;
-  for (; k + 28 < nparts; k += 32) {
-    const float v0 = src[(int64_t)k * stride], v1 = src[(int64_t)(k + 4) * stride];
-    const float v2 = src[(int64_t)(k + 8) * stride], v3 = src[(int64_t)(k + 12) * stride];
-    const float v4 = src[(int64_t)(k + 16) * stride], v5 = src[(int64_t)(k + 20) * stride];
-    const float v6 = src[(int64_t)(k + 24) * stride], v7 = src[(int64_t)(k + 28) * stride];
-    part += ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7));
-  }
-  for (; k < nparts; k += 4) part += src[(int64_t)k * stride];
-  return part;
-}
-
 __global__ __launch_bounds__(256) void grad_reduce_kernel(RedPlan rp, int64_t P, int tail, const float* __restrict__ ws,
                                                           const float* __restrict__ loss_part, int n_loss_part,
                                                           float* __restrict__ grads, float* __restrict__ sumsq_part) {
@@ -871,6 +1021,13 @@ bool ultr_make_dnn_plan(const ultr_dnn_desc* d, int64_t N, DnnPlan* p) {
     k = m;
   }
   p->P = off;
+  int64_t wt = 0;
+  for (int j = 0; j < p->nl - 1; ++j) {
+    p->wt_off[j] = wt;
+    wt += (int64_t)p->K[j] * p->M[j];
+    wt = (wt + 3) & ~(int64_t)3;
+  }
+  p->wt_total = wt;
   int64_t sv = 0;
   for (int j = 1; j < p->nl; ++j) {
     p->sv_x[j] = sv;
@@ -919,6 +1076,8 @@ bool ultr_make_bwd_plan(const DnnPlan& p, int64_t N, BwdPlan* bp) {
   bp->n_red_blocks = (int)ultr_red_blocks(p.P, (int)tail_max);
   bp->sumsq_off = off; off += bp->n_red_blocks; off = (off + 3) & ~(int64_t)3;
   bp->vslab_off = off; off += (int64_t)bp->nrb * bp->vlen; off = (off + 3) & ~(int64_t)3;
+  bp->vred_off = off; off += bp->vlen; off = (off + 3) & ~(int64_t)3;
+  bp->vred_blocks = (bp->vlen + 63) / 64;
   for (int j = 0; j < p.nl - 1; ++j) {
     bp->dz_off[j] = off; off += N * p.M[j]; off = (off + 3) & ~(int64_t)3;
   }
@@ -954,11 +1113,11 @@ static void make_red_plan(const DnnPlan& p, const BwdPlan& bp, RedPlan* rp) {
   int s = 0;
   for (int j = 0; j < p.nl; ++j) {
     const bool last = (j == p.nl - 1);
-    rp->seg[s++] = RedSeg{p.off_lnw[j], bp.vslab_off + bp.voff_g[j], bp.vlen, p.K[j], bp.nrb};
-    rp->seg[s++] = RedSeg{p.off_lnb[j], bp.vslab_off + bp.voff_b[j], bp.vlen, p.K[j], bp.nrb};
+    rp->seg[s++] = RedSeg{p.off_lnw[j], bp.vred_off + bp.voff_g[j], 0, p.K[j], 1};
+    rp->seg[s++] = RedSeg{p.off_lnb[j], bp.vred_off + bp.voff_b[j], 0, p.K[j], 1};
     if (last) {
-      rp->seg[s++] = RedSeg{p.off_w[j], bp.vslab_off + bp.voff_wk, bp.vlen, p.K[j], bp.nrb};
-      rp->seg[s++] = RedSeg{p.off_b[j], bp.vslab_off + bp.voff_bk, bp.vlen, 1, bp.nrb};
+      rp->seg[s++] = RedSeg{p.off_w[j], bp.vred_off + bp.voff_wk, 0, p.K[j], 1};
+      rp->seg[s++] = RedSeg{p.off_b[j], bp.vred_off + bp.voff_bk, 0, 1, 1};
     } else {
       const WgradLayer& w = bp.wl[j];
       const int64_t stride = (int64_t)w.M * w.K + w.M;
@@ -1022,15 +1181,47 @@ extern "C" int64_t ultr_dnn_bwd_workspace_bytes(const ultr_dnn_desc* d, int64_t 
 }
 extern "C" int64_t ultr_step_tail_floats(int32_t list_size) { return ultr_tail_len(list_size); }
 
+extern "C" int64_t ultr_dnn_wt_floats(const ultr_dnn_desc* d) {
+  DnnPlan p;
+  if (!ultr_make_dnn_plan(d, 0, &p)) return 0;
+  return p.wt_total > 0 ? p.wt_total : 4;
+}
+
+// WT_j[k, m] = W_j[m, k] for every hidden Linear (coalesced reads, strided writes; ~100k elements)
+__global__ __launch_bounds__(256) void wt_build_kernel(DnnPlan p, const float* __restrict__ params, float* __restrict__ wt) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t base = 0;
+  for (int j = 0; j < p.nl - 1; ++j) {
+    const int64_t n = (int64_t)p.M[j] * p.K[j];
+    if (e >= base && e < base + n) {
+      const int64_t r = e - base;
+      const int m = (int)(r / p.K[j]), k = (int)(r % p.K[j]);
+      wt[p.wt_off[j] + (int64_t)k * p.M[j] + m] = params[p.off_w[j] + r];
+      return;
+    }
+    base += n;
+  }
+}
+
+extern "C" int ultr_dnn_build_wt(const ultr_dnn_desc* d, const float* params, float* wt, void* stream) {
+  DnnPlan p;
+  if (!params || !wt || !ultr_make_dnn_plan(d, 0, &p)) return ULTR_E_BADARG;
+  int64_t n = 0;
+  for (int j = 0; j < p.nl - 1; ++j) n += (int64_t)p.M[j] * p.K[j];
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(wt_build_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, params, wt);
+  return (int)hipGetLastError();
+}
+
 template <typename KernelT>
 static hipError_t set_lds(KernelT k, size_t bytes) {
   if (bytes <= 64 * 1024) return hipSuccess;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-extern "C" int ultr_dnn_forward(const ultr_dnn_desc* d, const float* params, const float* features, int64_t n_docs,
-                                const int32_t* docids, int32_t batch, int32_t list_size, float* scores, void* saved,
-                                void* stream) {
+extern "C" int ultr_dnn_forward(const ultr_dnn_desc* d, const float* params, const float* wt, const float* features,
+                                int64_t n_docs, const int32_t* docids, int32_t batch, int32_t list_size, float* scores,
+                                void* saved, void* stream) {
   if (!params || !docids || !scores || batch <= 0 || list_size <= 0 || n_docs < 0 || (n_docs > 0 && !features))
     return ULTR_E_BADARG;
   const int64_t N = (int64_t)batch * list_size;
@@ -1045,13 +1236,15 @@ extern "C" int ultr_dnn_forward(const ultr_dnn_desc* d, const float* params, con
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipSuccess;
   UltrProfScope prof(ULTR_K_FWD, st);
-  const bool av = all_vec(p, vm, N, n_docs) && env_int("ULTR_NO_VEC", 0) == 0;
+  // the fast path needs the k-major weight copy (ultr_dnn_build_wt / kept current by ultr_apply_update)
+  const bool av = all_vec(p, vm, N, n_docs) && env_int("ULTR_NO_VEC", 0) == 0 && (wt != nullptr || p.nl == 1) &&
+                  ((uintptr_t)wt & 15) == 0;
 #define LAUNCH_FWD(RR, NWW, VV)                                                                                     \
   do {                                                                                                              \
     e = set_lds(dnn_fwd_kernel<RR, NWW, VV>, lds);                                                                  \
     if (e != hipSuccess) return (int)e;                                                                             \
     hipLaunchKernelGGL((dnn_fwd_kernel<RR, NWW, VV>), grid, dim3(NWW * 64), lds, st, p, params, features, n_docs,   \
-                       docids, (int)batch, (int)list_size, scores, (float*)saved, vm);                             \
+                       docids, (int)batch, (int)list_size, scores, (float*)saved, wt, vm);                         \
   } while (0)
 #define LAUNCH_FWD2(RR, NWW) \
   do {                       \
@@ -1112,7 +1305,7 @@ extern "C" int ultr_dnn_backward(const ultr_dnn_desc* d, const float* params, co
 #undef LAUNCH_BWD
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
-  if (bp.wgrad_blocks > 0) {
+  {
     UltrProfScope prof(ULTR_K_WGRAD, st);
     int maxrps = 0;
     for (int j = 0; j < p.nl - 1; ++j) maxrps = bp.wl[j].rows_per_split > maxrps ? bp.wl[j].rows_per_split : maxrps;
@@ -1120,10 +1313,10 @@ extern "C" int ultr_dnn_backward(const ultr_dnn_desc* d, const float* params, co
     e = av ? set_lds(dnn_wgrad_kernel<true>, wlds) : set_lds(dnn_wgrad_kernel<false>, wlds);
     if (e != hipSuccess) return (int)e;
     if (av)
-      hipLaunchKernelGGL(dnn_wgrad_kernel<true>, dim3(bp.wgrad_blocks), dim3(256), wlds, st, p, bp, params, features, n_docs,
+      hipLaunchKernelGGL(dnn_wgrad_kernel<true>, dim3(bp.wgrad_blocks + bp.vred_blocks), dim3(256), wlds, st, p, bp, params, features, n_docs,
                          docids, (int)batch, (int)list_size, (const float*)saved, ws, (vm >> 31) & 1);
     else
-      hipLaunchKernelGGL(dnn_wgrad_kernel<false>, dim3(bp.wgrad_blocks), dim3(256), wlds, st, p, bp, params, features, n_docs,
+      hipLaunchKernelGGL(dnn_wgrad_kernel<false>, dim3(bp.wgrad_blocks + bp.vred_blocks), dim3(256), wlds, st, p, bp, params, features, n_docs,
                          docids, (int)batch, (int)list_size, (const float*)saved, ws, (vm >> 31) & 1);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;

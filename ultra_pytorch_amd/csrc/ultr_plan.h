@@ -17,6 +17,11 @@ struct DnnPlan {
   int M[ULTR_MAXL];       // out-features of Linear_j  (M[nl-1] = 1)
   int64_t off_lnw[ULTR_MAXL], off_lnb[ULTR_MAXL], off_w[ULTR_MAXL], off_b[ULTR_MAXL];
   int64_t P;              // total parameters
+  // k-major copy of the hidden Linear weights (WT_j = W_j^T, [K_j, M_j] row-major), j < nl-1: the forward's MFMA
+  // B-fragments are then 256-byte contiguous per 16 lanes (W_j itself gives 16 rows x 64 B per load instruction,
+  // which the texture addresser processes ~4x slower); maintained by the update kernel
+  int64_t wt_off[ULTR_MAXL];
+  int64_t wt_total;
   int maxdim;             // max over all K_j (and M_j)
   // saved-for-backward workspace (floats): xs[j] = input of LayerNorm_j, j >= 1; stats for all j
   int64_t sv_x[ULTR_MAXL];     // [N, K_j]   (j >= 1)
@@ -46,6 +51,8 @@ struct BwdPlan {
   int voff_b[ULTR_MAXL];    // dbeta_j
   int voff_wk, voff_bk;     // final layer weight [K_last], bias [1]
   int64_t vslab_off;        // [nrb][vlen] in bwd_ws
+  int64_t vred_off;         // [vlen]: the vector slabs pre-reduced (by spare workgroups of the wgrad launch)
+  int vred_blocks;          // ceil(vlen / 64)
   int64_t dz_off[ULTR_MAXL];// dz_j [N, M_j], j < nl-1
   WgradLayer wl[ULTR_MAXL];
   int wgrad_blocks;
@@ -64,6 +71,9 @@ struct RedPlan {
   int nseg;
   RedSeg seg[4 * ULTR_MAXL];
 };
+
+struct ultr_dnn_desc;
+bool ultr_make_dnn_plan(const ultr_dnn_desc* d, int64_t N, DnnPlan* p);  // ultr_dnn.hip
 
 #define ULTR_TAIL_FIXED 4
 __host__ __device__ static inline int64_t ultr_tail_len(int L) { return ULTR_TAIL_FIXED + 2 * (int64_t)L; }

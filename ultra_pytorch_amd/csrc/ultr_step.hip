@@ -1,0 +1,39 @@
+// ultr_step.hip — one host call per training step: forward -> loss -> backward -> (update).
+// Exists to keep the HOST out of the critical path: at ~100 us of GPU work per step, four separate FFI calls from
+// Python (argument marshalling + launches) cost more than a third of that.  No new device code here.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ultr_hip.h"
+
+extern "C" int ultr_train_step(const ultr_step_args* a, void* stream) {
+  if (!a || !a->desc || !a->upd) return ULTR_E_BADARG;
+  int rc = ultr_dnn_forward(a->desc, a->params, a->wt, a->features, a->n_docs, a->docids, a->batch, a->list_size,
+                            a->scores, a->saved, stream);
+  if (rc) return rc;
+  switch (a->upd->algo) {
+    case ULTR_ALGO_SOFTMAX:
+      rc = ultr_softmax_ce(a->scores, a->labels, a->pw, a->ipw_table, a->n_ipw, a->batch, a->list_size, a->dscores,
+                           a->loss_ws, stream);
+      break;
+    case ULTR_ALGO_DLA:
+      rc = ultr_dla_loss(a->scores, a->labels, a->aux, a->upd->logits_to_prob, a->batch, a->list_size, a->dscores,
+                         a->loss_ws, stream);
+      break;
+    case ULTR_ALGO_PAIRDEBIAS:
+      rc = ultr_pairdebias_loss(a->scores, a->labels, a->aux, a->aux ? a->aux + a->list_size : nullptr, a->batch,
+                                a->list_size, a->batch_total > 0 ? a->batch_total : a->batch, a->dscores, a->loss_ws, stream);
+      break;
+    case ULTR_ALGO_LAMBDARANK:
+      rc = ultr_lambdarank_loss(a->scores, a->labels, a->aux, a->aux ? a->aux + a->list_size : nullptr, a->sigma, a->batch,
+                                a->list_size, a->dscores, a->loss_ws, stream);
+      break;
+    default:
+      return ULTR_E_BADARG;
+  }
+  if (rc) return rc;
+  rc = ultr_dnn_backward(a->desc, a->params, a->features, a->n_docs, a->docids, a->batch, a->list_size, a->saved,
+                         a->dscores, a->loss_ws, a->bwd_ws, a->grads, stream);
+  if (rc || a->skip_update) return rc;
+  return ultr_apply_update(a->upd, a->desc, a->params, a->wt, a->state, a->grads, a->aux, a->bwd_ws, a->scalars, stream);
+}

@@ -7,6 +7,7 @@
 // so no grid barrier and no atomics are needed and all workgroups agree bit-for-bit.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "../../include/ultr_hip.h"
 #include "ultr_device.h"
@@ -31,15 +32,17 @@ __device__ __forceinline__ float opt_step(float p, float g, float* st, int opt, 
   return p - lr * (g / (sqrtf(s) + eps));
 }
 
-__global__ __launch_bounds__(256) void update_kernel(ultr_update_desc u, float* __restrict__ params,
+__global__ __launch_bounds__(256) void update_kernel(ultr_update_desc u, DnnPlan dp, float* __restrict__ params,
                                                      float* __restrict__ state, const float* __restrict__ grads,
-                                                     float* __restrict__ aux, const float* __restrict__ sumsq_part,
-                                                     int nsq, float* __restrict__ scalars_out) {
+                                                     float* __restrict__ aux, float* __restrict__ wt,
+                                                     const float* __restrict__ sumsq_part, int nsq,
+                                                     float* __restrict__ scalars_out) {
   __shared__ float sm[4];
   const int64_t P = u.n_params;
   const int L = u.list_size;
   const float* tail = grads + P;
   float ss = 0.f;
+#pragma unroll 8
   for (int k = threadIdx.x; k < nsq; k += 256) ss += sumsq_part[k];
   ss = block_sum256(ss, sm);
   const float loss_sum = tail[0], D = tail[1], loss2 = tail[2], D2 = tail[3];
@@ -67,14 +70,30 @@ __global__ __launch_bounds__(256) void update_kernel(ultr_update_desc u, float* 
   const float norm = fabsf(gs) * sqrtf(ss);
   const float coef = (u.max_gradient_norm > 0.f) ? fminf(1.0f, u.max_gradient_norm / (norm + 1e-6f)) : 1.0f;
   const bool stateless = (u.algo == ULTR_ALGO_DLA);
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int64_t e = (int64_t)blockIdx.x * 1024 + it * 256 + threadIdx.x;
+  {
+    // one element per thread: every load of the kernel is in flight at once (the step is latency-bound)
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e < P) {
       float g = grads[e] * gs;
       g *= coef;
-      params[e] = opt_step(params[e], g, state ? state + e : nullptr, u.optimizer, stateless || state == nullptr,
-                           u.learning_rate, u.adagrad_eps);
+      const float pn = opt_step(params[e], g, state ? state + e : nullptr, u.optimizer, stateless || state == nullptr,
+                                u.learning_rate, u.adagrad_eps);
+      params[e] = pn;
+      if (wt != nullptr) {
+        // keep the k-major copy of the hidden Linear weights current: WT_j[k, m] = W_j[m, k]
+        for (int j = 0; j < dp.nl - 1; ++j) {
+          const int r = (int)(e - dp.off_w[j]);
+          const int K = dp.K[j], M = dp.M[j];
+          if (e >= dp.off_w[j] && r < M * K) {
+            int m = (int)((float)r * (1.0f / (float)K));  // r / K without the integer divide; fix the +-1
+            int k = r - m * K;
+            if (k < 0) { --m; k += K; }
+            if (k >= K) { ++m; k -= K; }
+            wt[dp.wt_off[j] + (int64_t)k * M + m] = pn;
+            break;
+          }
+        }
+      }
     }
   }
   if (blockIdx.x != 0) return;
@@ -128,18 +147,23 @@ __global__ __launch_bounds__(256) void update_kernel(ultr_update_desc u, float* 
   }
 }
 
-extern "C" int ultr_apply_update(const ultr_update_desc* u, float* params, float* state, const float* grads, float* aux,
-                                 const void* bwd_ws, float* scalars_out, void* stream) {
+extern "C" int ultr_apply_update(const ultr_update_desc* u, const ultr_dnn_desc* d, float* params, float* wt, float* state,
+                                 const float* grads, float* aux, const void* bwd_ws, float* scalars_out, void* stream) {
   if (!u || !params || !grads || !bwd_ws || u->n_params <= 0 || u->list_size <= 0) return ULTR_E_BADARG;
+  DnnPlan dp;
+  memset(&dp, 0, sizeof(dp));
+  if (wt != nullptr) {
+    if (!ultr_make_dnn_plan(d, 0, &dp) || dp.P != u->n_params) return ULTR_E_BADARG;
+  }
   if (u->algo < 0 || u->algo > ULTR_ALGO_LAMBDARANK || (u->optimizer != ULTR_OPT_ADAGRAD && u->optimizer != ULTR_OPT_SGD))
     return ULTR_E_BADARG;
   if (u->algo != ULTR_ALGO_SOFTMAX && !aux) return ULTR_E_BADARG;
   if (u->optimizer == ULTR_OPT_ADAGRAD && u->algo != ULTR_ALGO_DLA && !state) return ULTR_E_BADARG;
   const int tail = (int)ultr_tail_len(u->list_size);
   const int nsq = (int)ultr_red_blocks(u->n_params, tail);
-  const int nblk = (int)((u->n_params + 1023) / 1024);
+  const int nblk = (int)((u->n_params + 255) / 256);
   UltrProfScope prof(ULTR_K_UPDATE, (hipStream_t)stream);
-  hipLaunchKernelGGL(update_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *u, params, state, grads, aux,
+  hipLaunchKernelGGL(update_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *u, dp, params, state, grads, aux, wt,
                      (const float*)bwd_ws, nsq, scalars_out);
   return (int)hipGetLastError();
 }

@@ -10,6 +10,8 @@ sequences the C-ABI calls on the current HIP stream:
 Nothing here synchronises with the host; the caller decides when to read `scalars`
 (the reference's `loss.item()` is the only sync, base_algorithm.py / ipw_rank.py:182).
 """
+import ctypes
+
 import torch
 
 from . import _lib, hip_ops
@@ -60,6 +62,7 @@ class StepEngine:
         u.em_step_size = float(em_step_size)
         u.regulation_p = float(regulation_p)
         self.udesc = u
+        self._args = None
 
     # ---- forward only (validation / DNN.build) -------------------------------------------------
     def forward(self, params, features, n_docs, docids, scores=None, train=False):
@@ -91,14 +94,37 @@ class StepEngine:
             hip_ops.grad_sumsq(self.grads, self.P, self.L, self.bwd_ws)
 
     def update(self, params, state, aux=None):
-        hip_ops.apply_update(self.udesc, params, state, self.grads, aux, self.bwd_ws, self.scalars)
+        hip_ops.apply_update(self.shape, self.udesc, params, state, self.grads, aux, self.bwd_ws, self.scalars)
 
     def train_step(self, params, state, features, n_docs, docids, labels, aux=None, ipw_table=None, pw=None):
-        """One full step; returns the device tensor of step scalars ([0] = loss)."""
-        self.forward(params, features, n_docs, docids, train=True)
-        self.loss(labels, aux=aux, ipw_table=ipw_table, pw=pw)
-        self.backward(params, features, n_docs, docids)
-        self.update(params, state, aux)
+        """One full step through ONE C call (ultr_train_step); returns the device tensor of step scalars ([0] = loss)."""
+        a = self._args
+        if a is None:
+            a = self._args = _lib.StepArgs()
+            a.desc = ctypes.pointer(self.shape.desc)
+            a.upd = ctypes.pointer(self.udesc)
+            a.scores, a.dscores = self.scores.data_ptr(), self.dscores.data_ptr()
+            a.saved, a.loss_ws, a.bwd_ws = self.saved.data_ptr(), self.loss_ws.data_ptr(), self.bwd_ws.data_ptr()
+            a.grads, a.scalars = self.grads.data_ptr(), self.scalars.data_ptr()
+            a.batch, a.list_size, a.batch_total = self.B, self.L, self.B * self.world
+            a.sigma = self.sigma
+            a.skip_update = 1 if self.pg is not None else 0
+            self._fn = self.shape.lib.ultr_train_step
+        a.params = params.data_ptr()
+        a.wt = hip_ops.weight_copy(self.shape).get(params).data_ptr()
+        a.state = state.data_ptr() if state is not None else None
+        a.aux = aux.data_ptr() if aux is not None else None
+        a.features = features.data_ptr() if n_docs > 0 else None
+        a.n_docs = n_docs
+        a.docids, a.labels = docids.data_ptr(), labels.data_ptr()
+        a.pw = pw.data_ptr() if pw is not None else None
+        a.ipw_table = ipw_table.data_ptr() if ipw_table is not None else None
+        a.n_ipw = int(ipw_table.numel()) if ipw_table is not None else 0
+        _lib.check(self._fn(ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ultr_train_step")
+        if self.pg is not None:
+            torch.distributed.all_reduce(self.grads, group=self.pg)
+            hip_ops.grad_sumsq(self.grads, self.P, self.L, self.bwd_ws)
+            self.update(params, state, aux)
         return self.scalars
 
 

@@ -4,6 +4,7 @@ Every function takes CUDA(ROCm) float32 / int32 tensors, passes raw pointers + t
 HIP stream to libultr_hip.so and returns immediately (asynchronous w.r.t. the host).
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -71,13 +72,45 @@ def loss_workspace_bytes(B, L):
     return int(_lib.load().ultr_loss_workspace_bytes(int(B), int(L)))
 
 
-def dnn_forward(shape, params, features, n_docs, docids, B, L, scores, saved=None):
+class WeightCopy:
+    """The k-major copy of the hidden Linear weights the fast forward reads (ultr_dnn_build_wt).  Rebuilt whenever
+    torch reports an in-place modification of `params` (load_state_dict, .copy_, init); ultr_apply_update keeps it
+    current on its own (it writes through raw pointers, which does not bump the tensor version)."""
+
+    def __init__(self, shape):
+        self.shape = shape
+        self.n = int(shape.lib.ultr_dnn_wt_floats(ctypes.byref(shape.desc)))
+        self.wt, self.key, self.ref = None, None, None
+
+    def get(self, params):
+        # identity of the tensor OBJECT (weakref: a freed tensor's address and version 0 can both be reused)
+        key = (params.data_ptr(), params._version)
+        same = self.ref is not None and self.ref() is params and key == self.key
+        if self.wt is None or self.wt.device != params.device:
+            self.wt = torch.empty(self.n, dtype=torch.float32, device=params.device)
+            same = False
+        if not same:
+            check(self.shape.lib.ultr_dnn_build_wt(ctypes.byref(self.shape.desc), _p(params), _p(self.wt), _stream()),
+                  "ultr_dnn_build_wt")
+            self.key, self.ref = key, weakref.ref(params)
+        return self.wt
+
+
+def weight_copy(shape):
+    if getattr(shape, "_wcopy", None) is None:
+        shape._wcopy = WeightCopy(shape)
+    return shape._wcopy
+
+
+def dnn_forward(shape, params, features, n_docs, docids, B, L, scores, saved=None, wt=None):
     lib = shape.lib
     _req(params, torch.float32, "params"), _req(docids, torch.int32, "docids"), _req(scores, torch.float32, "scores")
     if n_docs > 0:
         _req(features, torch.float32, "features")
-    check(lib.ultr_dnn_forward(ctypes.byref(shape.desc), _p(params), _p(features) if n_docs > 0 else None, int(n_docs),
-                               _p(docids), int(B), int(L), _p(scores), _p(saved), _stream()), "ultr_dnn_forward")
+    if wt is None:
+        wt = weight_copy(shape).get(params)
+    check(lib.ultr_dnn_forward(ctypes.byref(shape.desc), _p(params), _p(wt), _p(features) if n_docs > 0 else None,
+                               int(n_docs), _p(docids), int(B), int(L), _p(scores), _p(saved), _stream()), "ultr_dnn_forward")
 
 
 def dnn_backward(shape, params, features, n_docs, docids, B, L, saved, dscores, loss_ws, bwd_ws, grads):
@@ -112,9 +145,10 @@ def lambdarank_loss(scores, labels, t_plus, t_minus, sigma, B, L, dscores, loss_
                                            _p(dscores), _p(loss_ws), _stream()), "ultr_lambdarank_loss")
 
 
-def apply_update(udesc, params, state, grads, aux, bwd_ws, scalars):
-    check(_lib.load().ultr_apply_update(ctypes.byref(udesc), _p(params), _p(state), _p(grads), _p(aux), _p(bwd_ws),
-                                        _p(scalars), _stream()), "ultr_apply_update")
+def apply_update(shape, udesc, params, state, grads, aux, bwd_ws, scalars):
+    wt = weight_copy(shape).get(params)  # the update kernel writes the new weights into both layouts
+    check(shape.lib.ultr_apply_update(ctypes.byref(udesc), ctypes.byref(shape.desc), _p(params), _p(wt), _p(state), _p(grads),
+                                      _p(aux), _p(bwd_ws), _p(scalars), _stream()), "ultr_apply_update")
 
 
 def ndcg(scores, labels, docids, n_docs, B, L, topn, ndcg_out, ndcg_ws, order_out=None, masked_out=None):
