@@ -102,6 +102,14 @@ int ultr_dnn_backward(const ultr_dnn_desc* d, const float* params, const float* 
                       const int32_t* docids, int32_t batch, int32_t list_size, const void* saved,
                       const float* dscores, const void* loss_ws, void* bwd_ws, float* grads, void* stream);
 
+/* Same, with the NA / IPW loss (ultr_softmax_ce) FUSED into the backward kernel's prologue: takes the scores
+ * and the feed's labels instead of dscores.  dscores_out may be NULL.  Identical results to
+ * ultr_softmax_ce + ultr_dnn_backward (tests/test_gpu_parity.py::test_fused_softmax_backward). */
+int ultr_dnn_backward_softmax(const ultr_dnn_desc* d, const float* params, const float* features, int64_t n_docs,
+                              const int32_t* docids, int32_t batch, int32_t list_size, const void* saved,
+                              const float* scores, const float* labels, const float* pw, const float* ipw_table,
+                              int32_t n_ipw, float* dscores_out, void* loss_ws, void* bwd_ws, float* grads, void* stream);
+
 /* partial sums of squares of grads[0..P) -> head of bwd_ws; only needed after an all-reduce */
 int ultr_grad_sumsq(float* grads, int64_t n_params, int32_t list_size, void* bwd_ws, void* stream);
 

@@ -239,3 +239,29 @@ def test_determinism_bitwise():
         outs.append((g.copy(), params.copy(), state.copy(), sc.copy()))
     for a, b in zip(outs[0], outs[1]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["ipw_tiny", "na_tiny", "ipw_cfg2", "ipw_odd"])
+def test_fused_softmax_backward(name):
+    """ultr_dnn_backward_softmax (loss fused into the backward prologue) == ultr_softmax_ce + ultr_dnn_backward:
+    identical dscores and gradients (bitwise), loss / normaliser sums equal up to summation order."""
+    from ultra_pytorch_amd import hip_ops
+    d, m = load_golden(name)
+    run = make_run(m, name)
+    run.set_inputs(d["s0_features"], d["s0_docids"], d["s0_labels"])
+    run.forward(d["s0_pre_params"])
+    ipw = d["ipw_list"] if m["algo"] == "ipw" else None
+    ds_ref, tail_ref = run.loss(ipw_table=ipw)
+    g_ref, _ = run.backward()
+    eng = run.eng
+    eng.dscores.zero_()
+    eng.grads.zero_()
+    hip_ops.dnn_backward_softmax(run.shape, run.params, run.features, run.n_docs, run.docids, run.B, run.L, eng.saved, eng.scores,
+                                 run.labels, eng.loss_ws, eng.bwd_ws, eng.grads, ipw_table=run.ipw, dscores_out=eng.dscores)
+    torch.cuda.synchronize()
+    assert np.array_equal(eng.dscores.cpu().numpy(), ds_ref)
+    g = eng.grads.cpu().numpy()
+    P = run.shape.n_params
+    assert np.array_equal(g[:P], g_ref)
+    np.testing.assert_allclose(g[P:P + 2], tail_ref[:2], rtol=1e-6)
+    assert np.all(g[P + 2:] == 0)

@@ -40,3 +40,7 @@ for blk in range(3):
         base = 16 + 4 * jj
         out.append("L%d: gemm=%d sync=%d col=%d row+sync=%d" % (2 - jj, t[base + 1] - t[base], t[base + 2] - t[base + 1], t[base + 3] - t[base + 2], (t[base + 4] - t[base + 3]) if jj < 2 else 0))
     print("bwd wg %3d:" % (blk * 32), " | ".join(out), " total", t[16 + 11] - t[16])
+
+for blk in range(0, 13, 3):
+    t = a[blk].astype(np.int64)
+    print("wgrad wg %3d: ids+sync=%d mainloop=%d ldswrite+sync=%d reduce+store=%d total=%d" % (blk * 32, t[9] - t[8], t[10] - t[9], t[11] - t[10], t[12] - t[11], t[12] - t[8]))

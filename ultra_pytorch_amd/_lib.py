@@ -50,6 +50,8 @@ SIGNATURES = {
     "ultr_dnn_build_wt": (c_i32, [ctypes.POINTER(DnnDesc), c_vp, c_vp, c_vp]),
     "ultr_dnn_backward": (c_i32, [ctypes.POINTER(DnnDesc), c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp,
                                   c_vp, c_vp]),
+    "ultr_dnn_backward_softmax": (c_i32, [ctypes.POINTER(DnnDesc), c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp,
+                                          c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "ultr_grad_sumsq": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp]),
     "ultr_softmax_ce": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "ultr_dla_loss": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),

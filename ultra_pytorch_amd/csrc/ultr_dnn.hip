@@ -17,6 +17,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "../../include/ultr_hip.h"
 #include "ultr_device.h"
 #include "ultr_plan.h"
@@ -518,6 +520,17 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
 // ------------------------------------------------------------------------------------------------
 // Backward, row-local half
 // ------------------------------------------------------------------------------------------------
+// inputs of the fused NA / IPW loss (scores == nullptr: dscores come from a separate loss kernel)
+struct FusedSoftmax {
+  const float* scores;   // [B, L]
+  const float* labels;   // [L, B]
+  const float* pw;       // [B, L] or nullptr
+  const float* ipw;      // [n_ipw] or nullptr
+  int n_ipw;
+  float* dscores_out;    // [B, L] or nullptr
+  float* loss_part;      // [nrb][tail]
+};
+
 __device__ __forceinline__ int64_t sm_id_raw(const int32_t* __restrict__ docids, int64_t n, int B, int L, int64_t n_docs) {
   const int b = (int)(n / L), l = (int)(n % L);
   const int64_t d = docids[(int64_t)l * B + b];
@@ -530,7 +543,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd_kernel(DnnPlan p, BwdPlan bp,
                                                           const int32_t* __restrict__ docids, int B, int L,
                                                           const float* __restrict__ saved,
                                                           const float* __restrict__ dscores, float* __restrict__ ws,
-                                                          int vecmask) {
+                                                          int vecmask, FusedSoftmax fl) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int RT = R / 16;
   constexpr int NT = NW * 64;
@@ -554,13 +567,69 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd_kernel(DnnPlan p, BwdPlan bp,
     float ds = 0.f;
     int64_t id = -1;
     if (n < N) {
-      ds = dscores[n];
+      if (fl.scores == nullptr) ds = dscores[n];
       const int b = (int)(n / L), l = (int)(n % L);
       const int64_t d = docids[(int64_t)l * B + b];
       if (d >= 0 && d < n_docs) id = d;
     }
     sm_ds[tid] = ds;
     sm_id[tid] = id;
+  }
+  if (fl.scores != nullptr) {
+    // ---- fused listwise softmax cross entropy (NA / IPW): this row block touches at most R/L + 2 lists; one
+    // wavefront recomputes each of them (L scores from L2) instead of a separate launch + dependent kernel boundary.
+    // A list's loss / normaliser partial is emitted by the block that owns the list's FIRST row, exactly once.
+    __syncthreads();  // sm_ds zero-initialised above
+    float* sm_lt = DU;  // [NW][2] scratch (DU is not live yet)
+    if (lane < 2) sm_lt[wave * 2 + lane] = 0.f;
+    const int64_t nlast = (n0 + R < N ? n0 + R : N) - 1;
+    const int b_lo = (int)(n0 / L), b_hi = (int)(nlast / L);
+    for (int b = b_lo + wave; b <= b_hi; b += NW) {
+      float mx = -INFINITY, S = 0.f;
+      for (int l = lane; l < L; l += 64) {
+        const float sc = fl.scores[(int64_t)b * L + l];
+        const float y = fl.labels[(int64_t)l * B + b];
+        float pwt = 1.0f;
+        if (fl.pw != nullptr) pwt = fl.pw[(int64_t)b * L + l];
+        else if (fl.ipw != nullptr) pwt = (y > 0.f) ? fl.ipw[l < fl.n_ipw ? l : fl.n_ipw - 1] : 0.f;
+        mx = fmaxf(mx, sc);
+        S += (y + 0.0000001f) * pwt;
+      }
+      mx = wave_max(mx);
+      S = wave_sum(S);
+      float se = 0.f;
+      for (int l = lane; l < L; l += 64) se += expf(fl.scores[(int64_t)b * L + l] - mx);
+      const float lse = mx + logf(wave_sum(se));
+      float lb = 0.f;
+      for (int l = lane; l < L; l += 64) {
+        const float sc = fl.scores[(int64_t)b * L + l];
+        const float y = fl.labels[(int64_t)l * B + b];
+        float pwt = 1.0f;
+        if (fl.pw != nullptr) pwt = fl.pw[(int64_t)b * L + l];
+        else if (fl.ipw != nullptr) pwt = (y > 0.f) ? fl.ipw[l < fl.n_ipw ? l : fl.n_ipw - 1] : 0.f;
+        const float w = (y + 0.0000001f) * pwt;
+        const float ds = expf(sc - lse) * S - w;
+        lb += w * (lse - sc);
+        const int64_t n = (int64_t)b * L + l;
+        if (n >= n0 && n <= nlast) {
+          sm_ds[n - n0] = ds;
+          if (fl.dscores_out != nullptr) fl.dscores_out[n] = ds;
+        }
+      }
+      lb = wave_sum(lb);
+      if (lane == 0 && (int64_t)b * L >= n0) {
+        sm_lt[wave * 2 + 0] += lb;
+        sm_lt[wave * 2 + 1] += S;
+      }
+    }
+    __syncthreads();
+    const int tail = (int)ultr_tail_len(L);
+    for (int t = tid; t < tail; t += NT) {
+      float v = 0.f;
+      if (t < 2)
+        for (int w = 0; w < NW; ++w) v += sm_lt[w * 2 + t];
+      fl.loss_part[(int64_t)blockIdx.x * tail + t] = v;
+    }
   }
 
   for (int j = p.nl - 1; j >= 0; --j) {
@@ -775,6 +844,7 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
       ws[bp.vred_off + e] = ((smem[lane] + smem[64 + lane]) + smem[128 + lane]) + smem[192 + lane];
     return;
   }
+  TRACE_STAMP(8);
   int j = 0;
   while (j + 1 < p.nl - 1 && (int)blockIdx.x >= bp.wl[j + 1].blk_begin) ++j;
   const WgradLayer wl = bp.wl[j];
@@ -812,6 +882,7 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
     }
     __syncthreads();
   }
+  TRACE_STAMP(9);
   const float4 gam = ld4_masked(params + p.off_lnw[j], k0 + 4 * i, K, false);
   const float4 bet = ld4_masked(params + p.off_lnb[j], k0 + 4 * i, K, false);
   const int kc = k0 + 4 * i;
@@ -824,16 +895,19 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
     for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  auto load_step = [&](int64_t n, float4& a4, float4& b4) {
+  // Raw operands are kept in the prefetch ring and the LayerNorm transform is applied when a step is CONSUMED:
+  // transforming at load time would make every load's first use immediate and drain the ring (measured: ~2.7k
+  // cycles per 16-MFMA step, one exposed memory latency each).
+  auto mainloop = [&](auto layer0_tag) {
+  constexpr bool LAYER0 = decltype(layer0_tag)::value;
+  auto load_step = [&](int64_t n, float4& a4, float4& x4, float& mean, float& rstd) {
     const bool ok = n < nend;
-    float4 x4;
-    float mean, rstd;
     if constexpr (VEC) {
       // only dz must be exactly zero for rows outside this wave's slice; x / statistics of such rows are finite
       // (other rows of the batch) or hardware-zeroed (past N), and their products meet a4 == 0.  PAD documents
       // (id < 0) must read as the all-zero feature row -> out-of-bounds offset.
       a4 = buf_ld4(dz, ok ? (unsigned)(n * M + m0 + 4 * i) * 4u : ULTR_OOB);
-      if (j == 0) {
+      if constexpr (LAYER0) {
         const int id = ok ? sm_ids[(int)(n - nsplit0)] : -1;
         x4 = buf_ld4(xs, id >= 0 ? (unsigned)((int64_t)id * K + kc) * 4u : ULTR_OOB);
       } else {
@@ -841,13 +915,9 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
       }
       mean = buf_ld1(meansrc, (unsigned)n * 4u);
       rstd = buf_ld1(rstdsrc, (unsigned)n * 4u);
-      b4.x = (x4.x - mean) * rstd * gam.x + bet.x;
-      b4.y = (x4.y - mean) * rstd * gam.y + bet.y;
-      b4.z = (x4.z - mean) * rstd * gam.z + bet.z;
-      b4.w = (x4.w - mean) * rstd * gam.w + bet.w;
     } else {
       a4 = ld4_sel<VEC>(dz, n * M, ok, m0 + 4 * i, M);
-      if (j == 0) {
+      if constexpr (LAYER0) {
         const int id = ok ? sm_ids[(int)(n - nsplit0)] : -1;
         x4 = ld4_sel<VEC>(xs, (int64_t)id * K, id >= 0, kc, K);
       } else {
@@ -855,38 +925,60 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
       }
       mean = ld1_sel<VEC>(meansrc, n, ok);
       rstd = ld1_sel<VEC>(rstdsrc, n, ok);
-      b4.x = k_ok0 ? ((x4.x - mean) * rstd * gam.x + bet.x) : 0.f;
-      b4.y = k_ok1 ? ((x4.y - mean) * rstd * gam.y + bet.y) : 0.f;
-      b4.z = k_ok2 ? ((x4.z - mean) * rstd * gam.z + bet.z) : 0.f;
-      b4.w = k_ok3 ? ((x4.w - mean) * rstd * gam.w + bet.w) : 0.f;
     }
   };
 
-  // PF-deep ring: every lane keeps 2*PF 16-byte loads in flight (the layer-0 x rows are a dependent
-  // docid -> feature-row chain, and dz / x come from HBM or a remote L2)
-  constexpr int PF = 4;
-  float4 aq[PF], bq[PF];
+  // Straight-line software pipeline (same shape as gemm_nn4): a trip consumes TWO steps (8 rows, 32 MFMAs) from one
+  // register set while the next trip's operands are already in flight into the other; no control flow in the
+  // steady state.  Steps past the wave's slice load dz through the out-of-bounds offset (zeros): wasted MFMAs, no
+  // wrong sums - the host rounds rows_per_split to a multiple of 32 so that there are none in the common case.
+  struct StepRegs {
+    float4 a, x;
+    float mean, rstd;
+  };
+  constexpr int SPT = 2;  // steps per trip: 8 rows, 32 MFMAs (4 was measured no faster)
+  int64_t nn = nbeg;
+  auto trip = [&](StepRegs(&cu)[SPT], StepRegs(&nx)[SPT]) {
 #pragma unroll
-  for (int u = 0; u < PF; ++u) load_step(nbeg + 4 * u + q, aq[u], bq[u]);
-  for (int64_t n = nbeg; n < nend; n += 4 * PF) {
+    for (int u = 0; u < SPT; ++u) load_step(nn + 4 * SPT + 4 * u + q, nx[u].a, nx[u].x, nx[u].mean, nx[u].rstd);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      if (n + 4 * u < nend) {
-        const float4 a_c = aq[u], b_c = bq[u];
-        bsum.x += a_c.x;
-        bsum.y += a_c.y;
-        bsum.z += a_c.z;
-        bsum.w += a_c.w;
-        const float av[4] = {a_c.x, a_c.y, a_c.z, a_c.w};
-        const float bv[4] = {b_c.x, b_c.y, b_c.z, b_c.w};
+    for (int u = 0; u < SPT; ++u) {
+      const float4 a_c = cu[u].a, x_c = cu[u].x;
+      const float mean = cu[u].mean, rstd = cu[u].rstd;
+      bsum.x += a_c.x;
+      bsum.y += a_c.y;
+      bsum.z += a_c.z;
+      bsum.w += a_c.w;
+      const float av[4] = {a_c.x, a_c.y, a_c.z, a_c.w};
+      float bv[4];
+      bv[0] = (VEC || k_ok0) ? ((x_c.x - mean) * rstd * gam.x + bet.x) : 0.f;
+      bv[1] = (VEC || k_ok1) ? ((x_c.y - mean) * rstd * gam.y + bet.y) : 0.f;
+      bv[2] = (VEC || k_ok2) ? ((x_c.z - mean) * rstd * gam.z + bet.z) : 0.f;
+      bv[3] = (VEC || k_ok3) ? ((x_c.w - mean) * rstd * gam.w + bet.w) : 0.f;
 #pragma unroll
-        for (int ta = 0; ta < 4; ++ta)
+      for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
-          for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = mfma16(av[ta], bv[tb], acc[ta][tb]);
-        load_step(n + 4 * (u + PF) + q, aq[u], bq[u]);
-      }
+        for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = mfma16(av[ta], bv[tb], acc[ta][tb]);
     }
+    nn += 4 * SPT;
+  };
+  StepRegs ra[SPT], rb[SPT];
+#pragma unroll
+  for (int u = 0; u < SPT; ++u) load_step(nbeg + 4 * u + q, ra[u].a, ra[u].x, ra[u].mean, ra[u].rstd);
+  const int ntrip = (int)((nend - nbeg + 4 * SPT - 1) / (4 * SPT));
+  int t = 0;
+  for (; t + 1 < ntrip; t += 2) {
+    trip(ra, rb);
+    trip(rb, ra);
   }
+  if (t < ntrip) trip(ra, rb);
+  };  // mainloop
+  // the layer-0 variant (doc ids -> feature rows through LDS) and the plain variant are separate straight-line
+  // loops: a branch on j inside the loop would put the loads in control flow and drain vmcnt(0) every step
+  if (j == 0) mainloop(std::true_type{});
+  else mainloop(std::false_type{});
+  TRACE_STAMP(10);
   // ---- cross-wave reduction through LDS (fixed order) -------------------------------------------
   // lane holds D_{ta,tb}[row = 4q + r][col = i]  ->  block-local (m = 4*(4q+r) + ta, k = 4*i + tb)
 #pragma unroll
@@ -909,6 +1001,7 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
     }
   }
   __syncthreads();
+  TRACE_STAMP(11);
   float* slab = ws + wl.slab_off + (int64_t)split * ((int64_t)M * K + M);
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
@@ -936,6 +1029,7 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
   }
   if (kb == 0 && tid < 64 && m0 + tid < M)
     slab[(int64_t)M * K + m0 + tid] = ((bred[0][tid] + bred[1][tid]) + bred[2][tid]) + bred[3][tid];
+  TRACE_STAMP(12);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1093,7 +1187,7 @@ bool ultr_make_bwd_plan(const DnnPlan& p, int64_t N, BwdPlan* bp) {
     int nsplit = tiles > 0 ? (target + tiles - 1) / tiles : 1;
     if (nsplit < 1) nsplit = 1;
     int64_t rps = (N + nsplit - 1) / nsplit;
-    rps = (rps + 15) / 16 * 16;
+    rps = (rps + 31) / 32 * 32;  // 8 rows per wave-trip
     if (rps < 64) rps = 64;
     if (rps > 4096) rps = 4096;  // the doc-id table of a split lives in LDS
     w.rows_per_split = (int)rps;
@@ -1261,11 +1355,11 @@ extern "C" int ultr_dnn_forward(const ultr_dnn_desc* d, const float* params, con
   return (int)hipGetLastError();
 }
 
-extern "C" int ultr_dnn_backward(const ultr_dnn_desc* d, const float* params, const float* features, int64_t n_docs,
-                                 const int32_t* docids, int32_t batch, int32_t list_size, const void* saved,
-                                 const float* dscores, const void* loss_ws, void* bwd_ws, float* grads, void* stream) {
-  if (!params || !docids || !saved || !dscores || !bwd_ws || !grads || batch <= 0 || list_size <= 0 || n_docs < 0 ||
-      (n_docs > 0 && !features))
+static int backward_impl(const ultr_dnn_desc* d, const float* params, const float* features, int64_t n_docs,
+                         const int32_t* docids, int32_t batch, int32_t list_size, const void* saved, const float* dscores,
+                         const void* loss_ws, void* bwd_ws, float* grads, void* stream, FusedSoftmax fl) {
+  if (!params || !docids || !saved || (!dscores && !fl.scores) || !bwd_ws || !grads || batch <= 0 || list_size <= 0 ||
+      n_docs < 0 || (n_docs > 0 && !features))
     return ULTR_E_BADARG;
   const int64_t N = (int64_t)batch * list_size;
   DnnPlan p;
@@ -1286,7 +1380,7 @@ extern "C" int ultr_dnn_backward(const ultr_dnn_desc* d, const float* params, co
     e = set_lds(dnn_bwd_kernel<RR, NWW, VV>, lds);                                                                     \
     if (e != hipSuccess) return (int)e;                                                                                \
     hipLaunchKernelGGL((dnn_bwd_kernel<RR, NWW, VV>), dim3(bp.nrb), dim3(NWW * 64), lds, st, p, bp, params, features,  \
-                       n_docs, docids, (int)batch, (int)list_size, (const float*)saved, dscores, ws, vm);             \
+                       n_docs, docids, (int)batch, (int)list_size, (const float*)saved, dscores, ws, vm, fl);         \
   } while (0)
 #define LAUNCH_BWD2(RR, NWW) \
   do {                       \
@@ -1327,8 +1421,25 @@ extern "C" int ultr_dnn_backward(const ultr_dnn_desc* d, const float* params, co
   const float* lp = (const float*)loss_ws;
   UltrProfScope prof(ULTR_K_REDUCE, st);
   hipLaunchKernelGGL(grad_reduce_kernel, dim3(nblk), dim3(256), 0, st, rp, p.P, tail, (const float*)ws, lp,
-                     (int)ultr_loss_parts(batch), grads, ws + bp.sumsq_off);
+                     fl.scores ? bp.nrb : (int)ultr_loss_parts(batch), grads, ws + bp.sumsq_off);
   return (int)hipGetLastError();
+}
+
+extern "C" int ultr_dnn_backward(const ultr_dnn_desc* d, const float* params, const float* features, int64_t n_docs,
+                                 const int32_t* docids, int32_t batch, int32_t list_size, const void* saved,
+                                 const float* dscores, const void* loss_ws, void* bwd_ws, float* grads, void* stream) {
+  FusedSoftmax fl = {nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
+  return backward_impl(d, params, features, n_docs, docids, batch, list_size, saved, dscores, loss_ws, bwd_ws, grads, stream, fl);
+}
+
+extern "C" int ultr_dnn_backward_softmax(const ultr_dnn_desc* d, const float* params, const float* features, int64_t n_docs,
+                                         const int32_t* docids, int32_t batch, int32_t list_size, const void* saved,
+                                         const float* scores, const float* labels, const float* pw, const float* ipw_table,
+                                         int32_t n_ipw, float* dscores_out, void* loss_ws, void* bwd_ws, float* grads,
+                                         void* stream) {
+  if (!scores || !labels || !loss_ws || (ipw_table && n_ipw <= 0)) return ULTR_E_BADARG;
+  FusedSoftmax fl = {scores, labels, pw, ipw_table, (int)n_ipw, dscores_out, (float*)loss_ws};
+  return backward_impl(d, params, features, n_docs, docids, batch, list_size, saved, nullptr, loss_ws, bwd_ws, grads, stream, fl);
 }
 
 extern "C" int ultr_grad_sumsq(float* grads, int64_t n_params, int32_t list_size, void* bwd_ws, void* stream) {

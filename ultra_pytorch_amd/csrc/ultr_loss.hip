@@ -19,7 +19,10 @@
 
 extern "C" int64_t ultr_loss_workspace_bytes(int64_t batch, int32_t list_size) {
   if (batch <= 0 || list_size <= 0) return 0;
-  return (ultr_loss_parts(batch) * ultr_tail_len(list_size) + 4) * (int64_t)sizeof(float);
+  // one tail partial per 4 lists (stand-alone loss kernels) or per 16-row block (loss fused into the backward)
+  const int64_t parts_fused = (batch * (int64_t)list_size + 15) / 16;
+  const int64_t parts = ultr_loss_parts(batch) > parts_fused ? ultr_loss_parts(batch) : parts_fused;
+  return (parts * ultr_tail_len(list_size) + 4) * (int64_t)sizeof(float);
 }
 
 // sum the per-wave tails of a workgroup in fixed order and store the workgroup's partial

@@ -11,11 +11,16 @@ extern "C" int ultr_train_step(const ultr_step_args* a, void* stream) {
   int rc = ultr_dnn_forward(a->desc, a->params, a->wt, a->features, a->n_docs, a->docids, a->batch, a->list_size,
                             a->scores, a->saved, stream);
   if (rc) return rc;
+  if (a->upd->algo == ULTR_ALGO_SOFTMAX) {
+    // NA / IPW: the loss is fused into the backward kernel's prologue (one launch and one dependent kernel
+    // boundary fewer); ultr_softmax_ce stays available as the stand-alone stage
+    rc = ultr_dnn_backward_softmax(a->desc, a->params, a->features, a->n_docs, a->docids, a->batch, a->list_size, a->saved,
+                                   a->scores, a->labels, a->pw, a->ipw_table, a->n_ipw, a->dscores, a->loss_ws, a->bwd_ws,
+                                   a->grads, stream);
+    if (rc || a->skip_update) return rc;
+    return ultr_apply_update(a->upd, a->desc, a->params, a->wt, a->state, a->grads, a->aux, a->bwd_ws, a->scalars, stream);
+  }
   switch (a->upd->algo) {
-    case ULTR_ALGO_SOFTMAX:
-      rc = ultr_softmax_ce(a->scores, a->labels, a->pw, a->ipw_table, a->n_ipw, a->batch, a->list_size, a->dscores,
-                           a->loss_ws, stream);
-      break;
     case ULTR_ALGO_DLA:
       rc = ultr_dla_loss(a->scores, a->labels, a->aux, a->upd->logits_to_prob, a->batch, a->list_size, a->dscores,
                          a->loss_ws, stream);

@@ -120,6 +120,15 @@ def dnn_backward(shape, params, features, n_docs, docids, B, L, saved, dscores, 
                                 _stream()), "ultr_dnn_backward")
 
 
+def dnn_backward_softmax(shape, params, features, n_docs, docids, B, L, saved, scores, labels, loss_ws, bwd_ws, grads,
+                         pw=None, ipw_table=None, dscores_out=None):
+    n_ipw = 0 if ipw_table is None else int(ipw_table.numel())
+    check(shape.lib.ultr_dnn_backward_softmax(ctypes.byref(shape.desc), _p(params), _p(features) if n_docs > 0 else None,
+                                              int(n_docs), _p(docids), int(B), int(L), _p(saved), _p(scores), _p(labels), _p(pw),
+                                              _p(ipw_table), n_ipw, _p(dscores_out), _p(loss_ws), _p(bwd_ws), _p(grads),
+                                              _stream()), "ultr_dnn_backward_softmax")
+
+
 def grad_sumsq(grads, n_params, L, bwd_ws):
     check(_lib.load().ultr_grad_sumsq(_p(grads), int(n_params), int(L), _p(bwd_ws), _stream()), "ultr_grad_sumsq")
 
