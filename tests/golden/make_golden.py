@@ -335,7 +335,52 @@ def run_valid_case(ultra, name, F, Lmax, B, hidden, seed, list_lens, n_queries=2
     print("wrote", name)
 
 
+def run_feed_case(ultra, name, seed=0):
+    """input_feed dicts the reference's feeds build from the toy ULTRA dataset (tests/data of the reference, copied
+    as DATA to tests/golden/ultra_toy_data) with random.seed(seed), plus what its loader parsed."""
+    data_dir = os.path.join(HERE, "ultra_toy_data") + "/"
+    out = {}
+    sets = {}
+    for prefix in ("train", "valid"):
+        ds = quiet(ultra.utils.read_data, data_dir, prefix, None, None)
+        sets[prefix] = ds
+        out[prefix + "_qids"] = np.asarray(ds.qids)
+        out[prefix + "_lens"] = np.asarray(ds.initial_list_lengths, dtype=np.int32)
+        out[prefix + "_rank_list_size"] = np.int32(ds.rank_list_size)
+        out[prefix + "_n_features_rows"] = np.int32(len(ds.features))
+        out[prefix + "_feature_sum"] = np.float64(np.asarray(ds.features, dtype=np.float64).sum())
+        out[prefix + "_lists"] = np.asarray([x + [-7] * (16 - len(x)) for x in ds.initial_list], dtype=np.int32)
+        out[prefix + "_labels"] = np.asarray([x + [-7.0] * (16 - len(x)) for x in ds.labels], dtype=np.float32)
+    max_cand = max(sets["train"].rank_list_size, sets["valid"].rank_list_size)
+    exp = {"learning_algorithm": ALGOS["ipw"], "learning_algorithm_hparams": "", "ranking_model": "ultra.ranking_model.DNN",
+           "ranking_model_hparams": "hidden_layer_sizes=[8]", "max_candidate_num": max_cand,
+           "selection_bias_cutoff": min(10, max_cand), "metrics": ["ndcg"], "metrics_topn": [1, 3]}
+    for ds in sets.values():
+        ds.pad(max_cand)
+    algo = quiet(ultra.utils.find_class(exp["learning_algorithm"]), sets["train"], exp)
+    L = exp["selection_bias_cutoff"]
+    random.seed(seed)
+    feed = quiet(ultra.utils.find_class("ultra.input_layer.ClickSimulationFeed"), algo, 6, "")
+    for t in range(2):
+        f, info = feed.get_batch(sets["train"], check_validation=True)
+        fe, ids, lab = feed_arrays(algo, f, L)
+        out["click%d_features" % t], out["click%d_docids" % t], out["click%d_labels" % t] = fe, ids, lab
+        out["click%d_idxs" % t] = np.asarray(info["rank_list_idxs"], dtype=np.int32)
+    dfeed = quiet(ultra.utils.find_class("ultra.input_layer.DirectLabelFeed"), algo, 4, "")
+    f, info = dfeed.get_next_batch(0, sets["valid"], check_validation=False)
+    fe, ids, lab = feed_arrays(algo, f, max_cand)
+    out["direct_features"], out["direct_docids"], out["direct_labels"] = fe, ids, lab
+    random.seed(seed + 1)
+    f, info = dfeed.get_batch(sets["train"], check_validation=True)
+    fe, ids, lab = feed_arrays(algo, f, max_cand)
+    out["directrand_features"], out["directrand_docids"], out["directrand_labels"] = fe, ids, lab
+    out["meta"] = json.dumps({"name": name, "seed": seed, "max_candidate_num": int(max_cand), "L": int(L), "F": int(sets["train"].feature_size)})
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name)
+
+
 CASES = {
+    "feeds_toy": lambda u: run_feed_case(u, "feeds_toy"),
     # tiny, two teacher-forced steps each
     "na_tiny": lambda u: run_train_case(u, "na_tiny", "na", 136, 10, 8, [32, 16], 2, 11),
     "ipw_tiny": lambda u: run_train_case(u, "ipw_tiny", "ipw", 136, 10, 8, [32, 16], 2, 12),
