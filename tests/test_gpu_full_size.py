@@ -1,0 +1,158 @@
+"""BASELINE.json configs at FULL size on the GPU: one training step of each against the oracle, plus
+size-independent properties (shard-sum linearity = the data-parallel identity, shift invariance, zero row sums,
+batch-permutation invariance, bitwise determinism)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.hipref import HipRun  # noqa: E402
+
+CONFIGS = {
+    # name: (F, hidden, B, L, algo, lr)
+    "cfg2_ipw": (136, [256, 256], 256, 10, "softmax", 0.05),
+    "cfg3_dla": (136, [512, 256, 128], 512, 20, "dla", 0.05),
+    "cfg4_pairdebias": (700, [512, 256, 128], 256, 50, "pairdebias", 0.005),
+    "cfg4_lambdarank": (700, [512, 256, 128], 256, 50, "lambdarank", 0.05),
+}
+
+
+def make_inputs(F, B, L, algo, seed=0):
+    from ultra_pytorch_amd import synthetic
+    rng = np.random.RandomState(seed)
+    feats, ids, clicks = synthetic.make_batch(rng, B, L, F, clicks=(algo != "lambdarank"))
+    return feats, ids, clicks
+
+
+def run_oracle(name, params, feats, ids, y, aux):
+    from oracle import ultr_oracle as O
+    from ultra_pytorch_amd import synthetic
+    F, hidden, B, L, algo, lr = CONFIGS[name]
+    z = np.zeros_like(params)
+    if algo == "softmax":
+        return O.train_step_softmax(params, z, F, hidden, feats, ids, y, ipw_list=synthetic.load_ipw(), lr=lr)
+    if algo == "dla":
+        return O.dla_step(params, aux, F, hidden, feats, ids, y, lr=lr)
+    if algo == "pairdebias":
+        return O.pairdebias_step(params, z, aux[:L], aux[L:], F, hidden, feats, ids, y, lr=lr)
+    return O.lambdarank_step(params, z, aux[:L], aux[L:], F, hidden, feats, ids, y, lr=lr)
+
+
+def run_hip(name, params, feats, ids, y, aux, B=None):
+    from ultra_pytorch_amd import synthetic
+    F, hidden, B0, L, algo, lr = CONFIGS[name]
+    B = B or B0
+    run = HipRun(F, hidden, B, L, algo=algo, learning_rate=lr)
+    run.set_inputs(feats, ids, y)
+    scores = run.forward(params)
+    ds, tail = run.loss(aux=aux, ipw_table=synthetic.load_ipw() if algo == "softmax" else None)
+    g, tail2 = run.backward()
+    return run, scores, ds, g, tail2
+
+
+def aux_for(name, rng):
+    F, hidden, B, L, algo, lr = CONFIGS[name]
+    if algo == "dla":
+        return rng.normal(scale=0.2, size=L + 1).astype(np.float32)
+    if algo in ("pairdebias", "lambdarank"):
+        return rng.uniform(0.8, 1.2, size=2 * L).astype(np.float32)
+    return None
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_full_size_step_matches_oracle(name):
+    from oracle import ultr_oracle as O
+    F, hidden, B, L, algo, lr = CONFIGS[name]
+    rng = np.random.RandomState(7)
+    feats, ids, y = make_inputs(F, B, L, algo)
+    params = O.init_params(F, hidden, seed=2)
+    aux = aux_for(name, rng)
+    ref = run_oracle(name, params, feats, ids, y, aux)
+    run, scores, ds, g, tail = run_hip(name, params, feats, ids, y, aux)
+    np.testing.assert_allclose(scores, ref["scores"], atol=2e-5)
+    state = None if algo == "dla" else np.zeros_like(params)
+    new_params, _, aux2, sc = run.update(state)
+    assert abs(sc[0] - ref["loss"]) <= 2e-5 * max(1.0, abs(ref["loss"]))
+    gs = {"softmax": 1.0 / tail[1], "dla": 1.0 / tail[1], "pairdebias": 1.0, "lambdarank": 1.0 / tail[1]}[algo]
+    gref = ref["grads"]
+    np.testing.assert_allclose(g * gs, gref, rtol=1e-4, atol=1e-5 * float(np.abs(gref).max()))
+    assert abs(sc[1] - ref["norm"]) <= 1e-4 * ref["norm"]
+    if algo in ("pairdebias", "lambdarank"):
+        np.testing.assert_allclose(aux2[:L], ref["t_plus"].ravel(), atol=2e-6)
+        np.testing.assert_allclose(aux2[L:], ref["t_minus"].ravel(), atol=2e-6)
+    if algo == "dla":
+        np.testing.assert_allclose(aux2, ref["prop_params"], atol=2e-6)
+
+
+@pytest.mark.parametrize("name", ["cfg2_ipw", "cfg4_pairdebias"])
+def test_shard_sum_equals_full_batch(name):
+    """The data-parallel identity at full size: [unscaled grads | tail] of the two half batches add up to the
+    full batch's (a checksum of checksums: every kernel and every partial-sum path contributes)."""
+    from oracle import ultr_oracle as O
+    from ultra_pytorch_amd import parallel
+    F, hidden, B, L, algo, lr = CONFIGS[name]
+    rng = np.random.RandomState(3)
+    feats, ids, y = make_inputs(F, B, L, algo, seed=5)
+    params = O.init_params(F, hidden, seed=4)
+    aux = aux_for(name, rng)
+    _, _, _, g_full, t_full = run_hip(name, params, feats, ids, y, aux)
+    names_d, names_l = ["d%d" % l for l in range(L)], ["y%d" % l for l in range(L)]
+    feed = {"f": feats}
+    for l in range(L):
+        feed[names_d[l]], feed[names_l[l]] = ids[l].astype(np.float32), y[l]
+    acc_g, acc_t = 0.0, 0.0
+    for r in range(2):
+        loc = parallel.shard_input_feed(feed, "f", names_d, names_l, L, r, 2)
+        lids = np.stack([loc[n] for n in names_d]).astype(np.int32)
+        ly = np.stack([loc[n] for n in names_l]).astype(np.float32)
+        run = HipRun(F, hidden, B // 2, L, algo=algo)
+        run.eng.world = 2  # PairDebias' xB factor uses the GLOBAL batch
+        run.set_inputs(loc["f"], lids, ly)
+        run.forward(params)
+        from ultra_pytorch_amd import synthetic
+        run.loss(aux=aux, ipw_table=synthetic.load_ipw() if algo == "softmax" else None)
+        g, t = run.backward()
+        acc_g, acc_t = acc_g + g.astype(np.float64), acc_t + t.astype(np.float64)
+    np.testing.assert_allclose(acc_g, g_full, rtol=2e-4, atol=2e-5 * float(np.abs(g_full).max()))
+    np.testing.assert_allclose(acc_t[:2], t_full[:2], rtol=1e-5)
+
+
+def test_softmax_properties_full_size():
+    from oracle import ultr_oracle as O
+    from ultra_pytorch_amd import synthetic
+    F, hidden, B, L, algo, lr = CONFIGS["cfg2_ipw"]
+    feats, ids, y = make_inputs(F, B, L, algo, seed=9)
+    run = HipRun(F, hidden, B, L, algo="softmax")
+    run.set_inputs(feats, ids, y)
+    rng = np.random.RandomState(1)
+    scores = rng.normal(size=(B, L)).astype(np.float32)
+    ipw = synthetic.load_ipw()
+    ds, tail = run.loss(ipw_table=ipw, scores=scores)
+    # gradient of a softmax cross entropy sums to zero over every list
+    assert np.abs(ds.sum(1)).max() < 1e-4 * np.abs(ds).max()
+    # shift invariance: adding a per-list constant changes neither loss nor gradient
+    ds2, tail2 = run.loss(ipw_table=ipw, scores=scores + rng.normal(size=(B, 1)).astype(np.float32))
+    np.testing.assert_allclose(ds2, ds, atol=2e-5 * np.abs(ds).max())
+    assert abs(tail2[0] - tail[0]) < 1e-4 * abs(tail[0]) and tail2[1] == tail[1]
+    # unclicked lists' documents get weight 0: D equals the host-side sum of IPW-weighted clicks
+    table = np.asarray([ipw[min(l, len(ipw) - 1)] for l in range(L)])
+    D = ((y + 1e-7) * np.where(y > 0, table[:, None], 0.0)).sum()
+    assert abs(tail[1] - D) < 1e-4 * D
+
+
+def test_batch_permutation_invariance_and_determinism():
+    from oracle import ultr_oracle as O
+    F, hidden, B, L, algo, lr = CONFIGS["cfg3_dla"]
+    rng = np.random.RandomState(11)
+    feats, ids, y = make_inputs(F, B, L, algo, seed=2)
+    params = O.init_params(F, hidden, seed=6)
+    aux = aux_for("cfg3_dla", rng)
+    _, s1, _, g1, t1 = run_hip("cfg3_dla", params, feats, ids, y, aux)
+    _, s1b, _, g1b, t1b = run_hip("cfg3_dla", params, feats, ids, y, aux)
+    assert np.array_equal(g1, g1b) and np.array_equal(s1, s1b) and np.array_equal(t1, t1b)  # bitwise reruns
+    perm = rng.permutation(B)
+    _, s2, _, g2, t2 = run_hip("cfg3_dla", params, feats, ids[:, perm], y[:, perm], aux)
+    np.testing.assert_array_equal(s2, s1[perm])  # scores are per-document: exact
+    np.testing.assert_allclose(g2, g1, rtol=2e-4, atol=2e-5 * float(np.abs(g1).max()))
+    np.testing.assert_allclose(t2[:4], t1[:4], rtol=1e-5)
