@@ -87,7 +87,9 @@ def test_train_matches_golden(name):
 
 @pytest.mark.parametrize("name", ["valid_tiny", "valid_odd"])
 def test_validation_matches_golden(name):
+    from ultra_pytorch_amd.utils import metrics
     d, m = load_golden(name)
+    metrics.RankingMetricKey.MAX_LABEL = m["max_label"]  # global set by the data loader (data_utils.py:96), as in the reference
     m2 = dict(m, algo="ipw")
     algo = build(m2, extra={"selection_bias_cutoff": min(10, m["L"])})
     load_flat(algo.model, d["params"])

@@ -1,0 +1,40 @@
+"""GPU box: time one training step of every BASELINE config (not bench lines)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from ultra_pytorch_amd import engine, hip_ops, synthetic
+from ultra_pytorch_amd.ranking_model import init_flat_params
+CONFIGS = {"cfg2 IPW F136 L10 B256 [256,256]": (136, [256, 256], 256, 10, "softmax", 0.05),
+           "cfg3 DLA F136 L20 B512 [512,256,128]": (136, [512, 256, 128], 512, 20, "dla", 0.05),
+           "cfg4 PairDebias F700 L50 B256 [512,256,128]": (700, [512, 256, 128], 256, 50, "pairdebias", 0.005),
+           "cfg4 LambdaRank F700 L50 B256 [512,256,128]": (700, [512, 256, 128], 256, 50, "lambdarank", 0.05),
+           "cfg2x4 IPW F136 L10 B1024 [256,256]": (136, [256, 256], 1024, 10, "softmax", 0.05)}
+dev = torch.device("cuda")
+for name, (F, hidden, B, L, algo, lr) in CONFIGS.items():
+    shape = hip_ops.DnnShape(F, hidden, "elu")
+    eng = engine.StepEngine(shape, B, L, dev, algo=algo, learning_rate=lr)
+    p = init_flat_params(shape, 0).to(dev)
+    st = None if algo == "dla" else torch.zeros_like(p)
+    rng = np.random.RandomState(0)
+    pool = []
+    for _ in range(4):
+        f, i, y = synthetic.make_batch(rng, B, L, F, clicks=(algo != "lambdarank"))
+        pool.append((torch.tensor(f, device=dev), f.shape[0], torch.tensor(i, device=dev), torch.tensor(y, device=dev)))
+    aux = None
+    if algo == "dla":
+        aux = torch.zeros(L + 1, device=dev)
+    elif algo != "softmax":
+        aux = torch.ones(2 * L, device=dev)
+    ipw = torch.tensor(synthetic.load_ipw(), dtype=torch.float32, device=dev) if algo == "softmax" else None
+    def step(k):
+        f, nd, i, y = pool[k % 4]
+        return eng.train_step(p, st, f, nd, i, y, aux=aux, ipw_table=ipw)
+    for k in range(30): step(k)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    n = 300
+    for k in range(n): step(k)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+    dims = [(F, hidden[0])] + list(zip(hidden[:-1], hidden[1:])) + [(hidden[-1], 1)]
+    S = sum(a * b for a, b in dims)
+    flops = B * L * (6 * S - 2 * F * hidden[0])
+    print("%-46s %8.1f us/step %10.0f q/s  %6.2f TFLOP/s (%.1f%% of fp32 MFMA peak)  loss %.4f" % (name, dt * 1e6, B / dt, flops / dt / 1e12, 100 * flops / dt / 157.3e12, float(eng.scalars[0])))

@@ -338,10 +338,29 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
   const int ld = fwd_ld(p.maxdim);
   float* X = smem;
   float* Y = smem + R * ld;
+  float* PV = smem + 2 * R * ld;  // every vector parameter of the model, staged once (see below)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t n0 = (int64_t)blockIdx.x * R;
   const int rows_valid = (int)((N - n0) < R ? (N - n0) : R);
   TRACE_STAMP(0);
+
+  // LayerNorm gamma/beta, biases and the scorer's weight row go to LDS up front, overlapped with the feature
+  // gather: each later phase would otherwise start with an exposed ~1-2k-cycle global load of a few hundred floats.
+  // layout per layer j: gamma[K_j] | beta[K_j] | bias[M_j]; then the last layer's weight row [K_last]
+  {
+    int off = 0;
+    for (int j = 0; j < p.nl; ++j) {
+      const int K = p.K[j], M = p.M[j];
+      for (int c = tid; c < K; c += NW * 64) {
+        PV[off + c] = params[p.off_lnw[j] + c];
+        PV[off + K + c] = params[p.off_lnb[j] + c];
+      }
+      for (int c = tid; c < M; c += NW * 64) PV[off + 2 * K + c] = params[p.off_b[j] + c];
+      off += 2 * K + M;
+    }
+    const int Kl = p.K[p.nl - 1];
+    for (int c = tid; c < Kl; c += NW * 64) PV[off + c] = params[p.off_w[p.nl - 1] + c];
+  }
 
   // ---- a2: gather feature rows (zero row for the PAD id == n_docs and for rows past N) ----------
   {
@@ -362,11 +381,14 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
   __syncthreads();
   TRACE_STAMP(1);
 
+  int pv_off = 0;
   for (int j = 0; j < p.nl; ++j) {
     const int K = p.K[j], M = p.M[j];
     const int K16 = round_up(K, 32);  // zero-padded width of the A tile (multiple of 32, see gemm_nn4)
-    const float* lnw = params + p.off_lnw[j];
-    const float* lnb = params + p.off_lnb[j];
+    const float* lnw = PV + pv_off;
+    const float* lnb = PV + pv_off + K;
+    const float* bias = PV + pv_off + 2 * K;
+    pv_off += 2 * K + M;
     // ---- LayerNorm (biased variance, eps 1e-5, affine), in place; two-pass statistics -----------
     if (K <= 256) {
       // fast path: a lane owns columns lane + 64k (k < 4); gamma/beta are fetched once per layer and the row
@@ -429,7 +451,6 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
     __syncthreads();
     TRACE_STAMP(2 + 3 * j);
     const float* W = params + p.off_w[j];
-    const float* bias = params + p.off_b[j];
     if (j < p.nl - 1) {
       // ---- Linear + activation on the matrix cores ------------------------------------------------
       float* gout = (saved != nullptr) ? (saved + p.sv_x[j + 1] + n0 * M) : nullptr;
@@ -508,7 +529,8 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
       for (int r = wave; r < R; r += NW) {
         const float* row = X + r * ld;
         float s = 0.f;
-        for (int c = lane; c < K; c += 64) s += row[c] * W[c];
+        const float* wl = PV + pv_off;  // the scorer's weight row
+        for (int c = lane; c < K; c += 64) s += row[c] * wl[c];
         s = wave_sum(s);
         if (lane == 0 && n0 + r < N) scores[n0 + r] = s + bias[0];
       }
@@ -1136,10 +1158,16 @@ bool ultr_make_dnn_plan(const ultr_dnn_desc* d, int64_t N, DnnPlan* p) {
   return true;
 }
 
+static size_t fwd_pv_floats(const DnnPlan& p) {
+  size_t n = 0;
+  for (int j = 0; j < p.nl; ++j) n += 2 * (size_t)p.K[j] + (size_t)p.M[j];
+  return (n + p.K[p.nl - 1] + 3) & ~(size_t)3;
+}
+static size_t fwd_lds_bytes(const DnnPlan& p, int R) { return ((size_t)2 * R * fwd_ld(p.maxdim) + fwd_pv_floats(p)) * sizeof(float); }
 static int fwd_rows_per_wg(const DnnPlan& p, int64_t N) {
   int r = env_int("ULTR_FWD_R", 0);
   if (r == 16 || r == 32) return r;
-  const size_t lds32 = (size_t)2 * 32 * fwd_ld(p.maxdim) * sizeof(float);
+  const size_t lds32 = fwd_lds_bytes(p, 32);
   return ((N + 15) / 16 > 512 && lds32 <= 160 * 1024) ? 32 : 16;
 }
 static size_t bwd_lds_bytes(const DnnPlan& p, int R) {
@@ -1322,7 +1350,7 @@ extern "C" int ultr_dnn_forward(const ultr_dnn_desc* d, const float* params, con
   DnnPlan p;
   if (!ultr_make_dnn_plan(d, N, &p)) return ULTR_E_BADARG;
   const int R = fwd_rows_per_wg(p, N);
-  const size_t lds = (size_t)2 * R * fwd_ld(p.maxdim) * sizeof(float);
+  const size_t lds = fwd_lds_bytes(p, R);
   if (lds > 160 * 1024) return ULTR_E_UNSUPPORTED;
   const int nw = env_int("ULTR_FWD_NW", 8);
   const int vm = vecmask_for(p, params, features);

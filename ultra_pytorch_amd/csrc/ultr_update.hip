@@ -41,6 +41,12 @@ __global__ __launch_bounds__(256) void update_kernel(ultr_update_desc u, DnnPlan
   const int64_t P = u.n_params;
   const int L = u.list_size;
   const float* tail = grads + P;
+  // this thread's element: issue its loads BEFORE the norm reduction so that the two memory round trips overlap
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = e < P;
+  const float g_raw = live ? grads[e] : 0.f;
+  const float p_old = live ? params[e] : 0.f;
+  const float s_old = (live && state != nullptr) ? state[e] : 0.f;
   float ss = 0.f;
 #pragma unroll 8
   for (int k = threadIdx.x; k < nsq; k += 256) ss += sumsq_part[k];
@@ -72,13 +78,13 @@ __global__ __launch_bounds__(256) void update_kernel(ultr_update_desc u, DnnPlan
   const bool stateless = (u.algo == ULTR_ALGO_DLA);
   {
     // one element per thread: every load of the kernel is in flight at once (the step is latency-bound)
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e < P) {
-      float g = grads[e] * gs;
+    if (live) {
+      float g = g_raw * gs;
       g *= coef;
-      const float pn = opt_step(params[e], g, state ? state + e : nullptr, u.optimizer, stateless || state == nullptr,
-                                u.learning_rate, u.adagrad_eps);
+      float s_new = s_old;
+      const float pn = opt_step(p_old, g, &s_new, u.optimizer, stateless || state == nullptr, u.learning_rate, u.adagrad_eps);
       params[e] = pn;
+      if (state != nullptr && !stateless && u.optimizer != ULTR_OPT_SGD) state[e] = s_new;
       if (wt != nullptr) {
         // keep the k-major copy of the hidden Linear weights current: WT_j[k, m] = W_j[m, k]
         for (int j = 0; j < dp.nl - 1; ++j) {
