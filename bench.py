@@ -200,6 +200,40 @@ def main():
         t3 = time.perf_counter()
         synced = (t3 - t2) / n2
 
+    e2e = None
+    if world == 1:
+        # end-to-end variant (the reference's own step_time definition, main.py:153-156: get_batch + train): the
+        # dataset is resident in HBM and clicks are simulated on the device (ultr_click_batch)
+        nq = 20000
+        rng = np.random.RandomState(99)
+        rfeat = torch.from_numpy(rng.uniform(-1, 1, size=(nq * L, F)).astype(np.float32)).to(device)
+        rlists = torch.arange(nq * L, dtype=torch.int32, device=device).view(nq, L).contiguous()
+        rel = rng.randint(0, 5, size=(nq, L)).astype(np.float32)
+        rel[:, 0] = np.maximum(rel[:, 0], 1)
+        rlab = torch.from_numpy(rel).to(device)
+        exam_np, cp_np = synthetic.load_pbm()
+        exam = torch.tensor(exam_np, dtype=torch.float32, device=device)
+        cprob = torch.tensor(cp_np, dtype=torch.float32, device=device)
+        dids = torch.empty(L, B, dtype=torch.int32, device=device)
+        dclk = torch.empty(L, B, dtype=torch.float32, device=device)
+        vp = lambda t: ctypes.c_void_p(t.data_ptr())
+
+        def e2e_step(i):
+            _lib.check(lib.ultr_click_batch(vp(rlists), vp(rlab), nq, L, nq * L, vp(exam), int(exam.numel()), vp(cprob),
+                                            int(cprob.numel()), 1234, i, B, L, 100, vp(dids), vp(dclk), None,
+                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ultr_click_batch")
+            return eng.train_step(params, state, rfeat, nq * L, dids, dclk, ipw_table=ipw)
+
+        for i in range(50):
+            e2e_step(i)
+        barrier()
+        n3 = min(args.steps, 1000)
+        t4 = time.perf_counter()
+        for i in range(n3):
+            e2e_step(50 + i)
+        barrier()
+        e2e = B * n3 / (time.perf_counter() - t4)
+
     if rank == 0:
         work = algorithmic_work(P)
         bound, amount = work[dom]
@@ -227,6 +261,8 @@ def main():
         }
         if synced is not None:
             out["queries_per_sec_with_loss_item_each_step"] = B * world / synced
+        if e2e is not None:
+            out["end_to_end_queries_per_sec_device_feed"] = e2e  # batch construction (click simulation) + train step
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pool, params0)
         sys.stdout.flush()

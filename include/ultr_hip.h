@@ -230,6 +230,19 @@ int ultr_ndcg(const float* scores, const float* labels, const int32_t* docids, i
               int32_t list_size, const int32_t* topn, int32_t n_topn, float* ndcg_out, int32_t* order_out,
               float* masked_out, float* ndcg_ws, void* stream);
 
+/* ---- next row: device-side click simulation + batch assembly -------------------
+ * Counterpart of ClickSimulationFeed.get_batch (click_simulation_feed.py:70-174) + PositionBiasedModel
+ * (click_models.py:68-110) for a dataset RESIDENT in HBM: lists [n_queries, lmax] int32 (doc index, -1 = pad),
+ * labels [n_queries, lmax] relevance.  Draws `batch` queries uniformly, samples PBM clicks
+ * (exam_prob[min(l, n_exam-1)] * click_prob[min(label, n_rel-1)]), redraws lists without a click (up to
+ * max_tries), and writes docids [L, B] (global doc ids, PAD = n_docs) + clicks [L, B] ready for ultr_train_step
+ * with features = the resident matrix.  query_idx (may be NULL) [B] = the sampled queries.  Counter-based RNG:
+ * the batch is a pure function of (seed, step).  Parity with the Python feed is distributional. */
+int ultr_click_batch(const int32_t* lists, const float* labels, int64_t n_queries, int32_t lmax, int64_t n_docs,
+                     const float* exam_prob, int32_t n_exam, const float* click_prob, int32_t n_rel, uint64_t seed,
+                     uint64_t step, int32_t batch, int32_t list_size, int32_t max_tries, int32_t* docids, float* clicks,
+                     int32_t* query_idx, void* stream);
+
 /* ---- measurement hooks (bench.py only; not part of the reference's interface) ----------
  * Per-kernel HIP-event timers on the launch stream.  kernel ids: 0 forward, 1 loss, 2 backward
  * (dgrad chain), 3 weight gradients, 4 gradient reduction, 5 update.  enable(mask, n) arms up

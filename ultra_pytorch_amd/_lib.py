@@ -60,6 +60,8 @@ SIGNATURES = {
     "ultr_apply_update": (c_i32, [ctypes.POINTER(UpdateDesc), ctypes.POINTER(DnnDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                   c_vp, c_vp]),
     "ultr_train_step": (c_i32, [ctypes.POINTER(StepArgs), c_vp]),
+    "ultr_click_batch": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_i32, ctypes.c_uint64, ctypes.c_uint64,
+                                 c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "ultr_prof_enable": (c_i32, [ctypes.c_uint32, c_i32]),
     "ultr_prof_collect": (c_i32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
     "ultr_ndcg": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, ctypes.POINTER(c_i32), c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),

@@ -1,0 +1,100 @@
+// ultr_feed.hip — device-side click simulation + batch assembly (a "next" row).
+//
+// The reference builds every training batch in pure Python (ClickSimulationFeed.get_batch,
+// click_simulation_feed.py:101-174: ~15 ms at config 2, 100x longer than the GPU step).  With the whole dataset
+// resident in HBM (features [n_docs, F], initial lists [n_queries, Lmax] padded with -1, labels), a batch is just
+// B x L document ids and clicks: this kernel draws them on the device and the step kernels gather the feature rows
+// straight from the resident matrix (global doc ids; PAD id = n_docs).
+//
+// Per batch slot (one wavefront): pick a query uniformly, sample position-biased clicks
+//   click_l ~ Bernoulli(exam_prob[min(l, n_exam-1)] * click_prob[min(label_l, n_rel-1)])      (click_models.py:68-110)
+// and, as the reference feed does with check_validation, redraw the whole list while it has no click.
+// Randomness: a counter-based generator (Philox-4x32-10 keyed by (seed, step); counter = slot, attempt, position), so a
+// batch is a pure function of (seed, step) - reproducible and independent of launch geometry.  It is NOT the
+// Python Mersenne-Twister stream: parity with the reference feed is distributional (tests/test_gpu_feed.py).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ultr_hip.h"
+#include "ultr_device.h"
+
+struct Philox {
+  uint32_t k0, k1;
+  __device__ __forceinline__ void round(uint32_t (&c)[4], uint32_t ka, uint32_t kb) const {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ ka, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ kb;
+    c[1] = (uint32_t)p1;
+    c[3] = (uint32_t)p0;
+    c[0] = n0;
+    c[2] = n2;
+  }
+  __device__ __forceinline__ void operator()(uint32_t (&c)[4]) const {
+    uint32_t ka = k0, kb = k1;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      round(c, ka, kb);
+      ka += 0x9E3779B9u;
+      kb += 0xBB67AE85u;
+    }
+  }
+};
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }  // [0, 1)
+
+__global__ __launch_bounds__(256) void click_batch_kernel(const int32_t* __restrict__ lists, const float* __restrict__ rel,
+                                                          int64_t n_queries, int Lmax, int64_t n_docs,
+                                                          const float* __restrict__ exam, int n_exam,
+                                                          const float* __restrict__ cprob, int n_rel, uint64_t seed,
+                                                          uint64_t step, int B, int L, int max_tries,
+                                                          int32_t* __restrict__ docids, float* __restrict__ clicks,
+                                                          int32_t* __restrict__ qidx) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  Philox rng{(uint32_t)seed ^ (uint32_t)(step * 0x9E3779B97F4A7C15ull >> 32), (uint32_t)(seed >> 32) ^ (uint32_t)step};
+  int64_t q = 0;
+  for (int attempt = 0; attempt < max_tries; ++attempt) {
+    uint32_t c[4] = {(uint32_t)b, (uint32_t)attempt, 0xFFFFFFFFu, 0x51ED270Bu};
+    rng(c);
+    q = (int64_t)((double)u01(c[0]) * (double)n_queries);  // uniform query pick (click_simulation_feed.py:126)
+    if (q >= n_queries) q = n_queries - 1;
+    float any = 0.f;
+    for (int l0 = 0; l0 < L; l0 += 64) {
+      const int l = l0 + lane;
+      float ck = 0.f;
+      int32_t id = (int32_t)n_docs;
+      if (l < L) {
+        const int32_t d = (l < Lmax) ? lists[q * Lmax + l] : -1;
+        // a PAD position counts as a label-0 document and CAN be clicked, exactly as in the reference feed
+        // (click_simulation_feed.py:74-81 builds the label list with 0 for pads and samples every position)
+        float y = 0.f;
+        if (d >= 0) {
+          id = d;
+          y = rel[q * Lmax + l];
+        }
+        const int lab = y > 0.f ? (int)y : 0;
+        uint32_t r[4] = {(uint32_t)b, (uint32_t)attempt, (uint32_t)(l >> 2), 0x2545F491u};
+        rng(r);
+        const float p = exam[l < n_exam ? l : n_exam - 1] * cprob[lab < n_rel ? lab : n_rel - 1];
+        ck = (u01(r[l & 3]) < p) ? 1.f : 0.f;
+        docids[(int64_t)l * B + b] = id;
+        clicks[(int64_t)l * B + b] = ck;
+      }
+      any += ck;
+    }
+    if (wave_sum(any) > 0.f) break;  // lists without a click are rejected (click_simulation_feed.py:89-91)
+  }
+  if (lane == 0 && qidx != nullptr) qidx[b] = (int32_t)q;
+}
+
+extern "C" int ultr_click_batch(const int32_t* lists, const float* labels, int64_t n_queries, int32_t lmax, int64_t n_docs,
+                                const float* exam_prob, int32_t n_exam, const float* click_prob, int32_t n_rel,
+                                uint64_t seed, uint64_t step, int32_t batch, int32_t list_size, int32_t max_tries,
+                                int32_t* docids, float* clicks, int32_t* query_idx, void* stream) {
+  if (!lists || !labels || !exam_prob || !click_prob || !docids || !clicks || n_queries <= 0 || lmax <= 0 || batch <= 0 ||
+      list_size <= 0 || n_exam <= 0 || n_rel <= 0 || max_tries <= 0 || n_docs < 0 || n_docs >= ((int64_t)1 << 31))
+    return ULTR_E_BADARG;
+  hipLaunchKernelGGL(click_batch_kernel, dim3((batch + 3) / 4), dim3(256), 0, (hipStream_t)stream, lists, labels, n_queries,
+                     (int)lmax, n_docs, exam_prob, (int)n_exam, click_prob, (int)n_rel, seed, step, (int)batch,
+                     (int)list_size, (int)max_tries, docids, clicks, query_idx);
+  return (int)hipGetLastError();
+}

@@ -3,3 +3,4 @@
 from .base_input_feed import BaseInputFeed  # noqa: F401
 from .click_simulation_feed import ClickSimulationFeed  # noqa: F401
 from .direct_label_feed import DirectLabelFeed  # noqa: F401
+from .device_click_feed import DeviceClickFeed, ResidentDataset  # noqa: F401

@@ -70,7 +70,14 @@ class BaseAlgorithm(object):
         return host.to(self.cuda, non_blocking=True)
 
     def create_input_feed(self, input_feed, list_size):
-        """numpy feed -> device tensors: features [n_docs,F] f32, docids [L,B] i32, labels [L,B] f32."""
+        """numpy feed -> device tensors: features [n_docs,F] f32, docids [L,B] i32, labels [L,B] f32.
+        A feed from input_layer.DeviceClickFeed already holds device tensors (resident dataset): nothing to move."""
+        if input_feed.get("device_feed", False):
+            self.n_docs, self.batch_size = int(input_feed["n_docs"]), int(input_feed["batch_size"])
+            self.letor_features = input_feed["features"]
+            self.docid_inputs = input_feed["docids"][:list_size]
+            self.labels_LB = input_feed["labels"][:list_size]
+            return None
         feats = np.asarray(input_feed[self.letor_features_name])
         if feats.ndim != 2:
             feats = feats.reshape(0, self.feature_size)

@@ -38,12 +38,13 @@ class IPWrank(BaseAlgorithm):
         self.global_step += 1
         self.model.train()
         L = self.rank_list_size
-        clicks = self.create_input_feed(input_feed, L)  # [L, B] host
-        table = np.asarray([self.IPW_list[l] if l < len(self.IPW_list) else self.IPW_list[-1] for l in range(L)])
-        pw = np.where(clicks > 0, table[:, None], 0.0)
-        for l in range(L):
-            input_feed["propensity_weights{0}".format(l)] = pw[l].tolist()
-        self.propensity_weights = pw.T
+        clicks = self.create_input_feed(input_feed, L)  # [L, B] host (None for a device feed)
+        if clicks is not None:
+            table = np.asarray([self.IPW_list[l] if l < len(self.IPW_list) else self.IPW_list[-1] for l in range(L)])
+            pw = np.where(clicks > 0, table[:, None], 0.0)
+            for l in range(L):
+                input_feed["propensity_weights{0}".format(l)] = pw[l].tolist()
+            self.propensity_weights = pw.T
         eng = self._train_engine(self.batch_size, L)
         sc = eng.train_step(self.model.flat_params, self.state_sum, self.letor_features, self.n_docs, self.docid_inputs,
                             self.labels_LB, ipw_table=self.ipw_table)
