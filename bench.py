@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures (profiling passes)")
     ap.add_argument("--sync-every-step", action="store_true", help="also read loss.item() every step (API-faithful)")
     args = ap.parse_args()
 
@@ -191,7 +192,7 @@ def main():
     assert np.isfinite(final_loss), "training diverged"
 
     synced = None
-    if args.sync_every_step or world == 1:
+    if args.sync_every_step or (world == 1 and not args.no_extras):
         n2 = min(args.steps, 500)
         barrier()
         t2 = time.perf_counter()
@@ -201,7 +202,7 @@ def main():
         synced = (t3 - t2) / n2
 
     e2e = None
-    if world == 1:
+    if world == 1 and not args.no_extras:
         # end-to-end variant (the reference's own step_time definition, main.py:153-156: get_batch + train): the
         # dataset is resident in HBM and clicks are simulated on the device (ultr_click_batch)
         nq = 20000

@@ -29,12 +29,34 @@ __global__ __launch_bounds__(NW * 64) void ub_kernel(const float* __restrict__ W
       for (int t = 0; t < 4; ++t) acc[0][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (has) {
         const int kb = ks * klen, ke = (kb + klen < Kc) ? (kb + klen) : Kc;
-        if (kb < ke) gemm_nn4<1, true>(X, ld, Wt, Mo, kb, ke, ch * 64, acc, lane);
+        if (kb < ke) gemm_nn<1, 4, true>(X, ld, Wt, Mo, kb, ke, ch * 64, acc, lane);
       }
       for (int r = 0; r < ksplit; ++r) {
-        if (has && ks == r) store_nn4<1>(acc, Y, ld, Mo, ch * 64, lane, r > 0);
+        if (has && ks == r) store_nn<1, 4>(acc, Y, ld, Mo, ch * 64, lane, r > 0);
         __syncthreads();
       }
+    } else if (VARIANT == 3) {
+      // 32-column chunks, whole contraction per wave, depth-1 pipeline (gemm_nn)
+      for (int chn = wave; chn * 32 < Mo; chn += NW) {
+        f32x4 acc[1][2];
+        for (int t = 0; t < 2; ++t) acc[0][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        gemm_nn<1, 2, true>(X, ld, Wt, Mo, 0, Kc, chn * 32, acc, lane);
+        store_nn<1, 2>(acc, Y, ld, Mo, chn * 32, lane, false);
+      }
+      __syncthreads();
+    } else if (VARIANT == 4 || VARIANT == 5 || VARIANT == 6 || VARIANT == 7 || VARIANT == 8 || VARIANT == 9 || VARIANT == 10) {
+      // GemmPipe depth 4; 5: next repetition's first trips issued before the epilogue + barrier; 6: rotated trip order
+      GemmPipe<1, 2, 4, (VARIANT == 9) ? 2 : (VARIANT == 10) ? 3 : (VARIANT >= 7) ? 1 : 0> pipe;
+      const int rot = (VARIANT == 6) ? (int)blockIdx.x : 0;
+      if ((VARIANT != 5 && VARIANT != 8) || rep == 0) pipe.begin(Wt, Mo, 0, Kc, wave * 32, wave * 32 < Mo, rot, lane);
+      for (int chn = wave; chn * 32 < Mo; chn += NW) {
+        f32x4 acc[1][2];
+        for (int t = 0; t < 2; ++t) acc[0][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        pipe.run(X, ld, Wt, 0, Kc, rot, acc, lane);
+        if (VARIANT == 5 || VARIANT == 8) pipe.begin(Wt, Mo, 0, Kc, wave * 32, wave * 32 < Mo, rot, lane);
+        store_nn<1, 2>(acc, Y, ld, Mo, chn * 32, lane, false);
+      }
+      lds_barrier();
     } else if (VARIANT == 2) {
       // NT form on W [Mo][Kc] (16 rows x 64 B per load instruction), CT = Mo / (16*NW) col tiles per wave
       const int K16 = round_up(Kc, 16);
@@ -51,9 +73,10 @@ __global__ __launch_bounds__(NW * 64) void ub_kernel(const float* __restrict__ W
   if (tid < 16) out[blockIdx.x * 16 + tid] = Y[tid * ld + tid];
 }
 
+static int g_G = 160;
 template <int V, int NW>
 void run(const char* name, const float* dW, int Kc, int Mo, float* dout, unsigned long long* dcyc) {
-  const int G = 160, reps = 200;
+  const int G = g_G, reps = 200;
   const size_t lds = (size_t)2 * 16 * fwd_ld(Kc > Mo ? Kc : Mo) * sizeof(float);
   hipFuncSetAttribute(reinterpret_cast<const void*>(ub_kernel<V, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -76,6 +99,7 @@ void run(const char* name, const float* dW, int Kc, int Mo, float* dout, unsigne
 
 int main(int argc, char** argv) {
   const int only = argc > 1 ? atoi(argv[1]) : -1;
+  if (argc > 2) g_G = atoi(argv[2]);
   const int KM = 256 * 256;
   std::vector<float> h(KM);
   for (int i = 0; i < KM; ++i) h[i] = 0.001f * (float)(i % 101);
@@ -87,6 +111,19 @@ int main(int argc, char** argv) {
   if (only < 0 || only == 2) run<1, 4>("nn4 nosplit NW=4", dW, 256, 256, dout, dcyc);
   if (only < 0 || only == 3) run<2, 8>("nt CT=2 NW=8", dW, 256, 256, dout, dcyc);
   if (only < 0 || only == 4) run<2, 16>("nt CT=1 NW=16", dW, 256, 256, dout, dcyc);
+  if (only < 0 || only == 10) run<3, 8>("nn CT=2 nosplit depth1 NW=8", dW, 256, 256, dout, dcyc);
+  if (only < 0 || only == 11) run<4, 8>("pipe CT=2 D=4 NW=8", dW, 256, 256, dout, dcyc);
+  if (only < 0 || only == 12) run<5, 8>("pipe CT=2 D=4 cross-phase NW=8", dW, 256, 256, dout, dcyc);
+  if (only < 0 || only == 17) run<7, 8>("pipe CT=2 D=4 interleaved NW=8", dW, 256, 256, dout, dcyc);
+  if (only < 0 || only == 18) run<8, 8>("pipe CT=2 D=4 interleaved cross-phase", dW, 256, 256, dout, dcyc);
+  if (only < 0 || only == 19) run<7, 8>("pipe CT=2 D=4 interleaved NW=8", dW, 136, 256, dout, dcyc);
+  if (only < 0 || only == 20) run<8, 8>("pipe CT=2 D=4 interleaved cross-phase", dW, 136, 256, dout, dcyc);
+  if (only < 0 || only == 21) run<9, 8>("pipe CT=2 D=4 NO LOADS", dW, 256, 256, dout, dcyc);
+  if (only < 0 || only == 22) run<10, 8>("pipe CT=2 D=4 NO MFMA", dW, 256, 256, dout, dcyc);
+  if (only < 0 || only == 15) run<6, 8>("pipe CT=2 D=4 rotated NW=8", dW, 256, 256, dout, dcyc);
+  if (only < 0 || only == 16) run<6, 8>("pipe CT=2 D=4 rotated NW=8", dW, 136, 256, dout, dcyc);
+  if (only < 0 || only == 13) run<3, 8>("nn CT=2 nosplit depth1 NW=8", dW, 136, 256, dout, dcyc);
+  if (only < 0 || only == 14) run<5, 8>("pipe CT=2 D=4 cross-phase NW=8", dW, 136, 256, dout, dcyc);
   if (only < 0 || only == 5) run<0, 8>("nn4 ksplit NW=8", dW, 136, 256, dout, dcyc);
   if (only < 0 || only == 6) run<2, 8>("nt CT=2 NW=8", dW, 136, 256, dout, dcyc);
   return 0;

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence for bench.py's workload on the GPU box (run through gpurun from the repo root):
+#   pass 1: --kernel-trace --stats            -> per-kernel durations
+#   pass 2: --pmc FETCH_SIZE  --kernel-trace  -> HBM read  KiB per dispatch   (one counter per pass, no other domains)
+#   pass 3: --pmc WRITE_SIZE  --kernel-trace  -> HBM write KiB per dispatch
+# Every pass is wrapped in `timeout`; tools/summarize_profiles.py turns gpurun_out/prof_<tag>/ into profiles/.
+TAG=${1:-r01}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/prof_$TAG
+rm -rf "$OUT"; mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+CMD="python $REPO/bench.py --steps 500 --warmup 50 --no-cpu-baseline --no-extras"
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- $CMD > "$OUT/stats.log" 2>&1
+echo "stats rc=$?"
+timeout 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -o f -- $CMD > "$OUT/fetch.log" 2>&1
+echo "fetch rc=$?"
+timeout 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -o w -- $CMD > "$OUT/write.log" 2>&1
+echo "write rc=$?"
+find "$OUT" -name "*.csv" | head -20

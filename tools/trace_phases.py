@@ -32,6 +32,9 @@ for blk in range(5):
     t = a[blk].astype(np.int64)
     print("wg %3d:" % (blk * 32), " ".join("%s=%d" % (names[k], t[k] - t[k - 1]) for k in range(1, 10)), " total", t[9] - t[0])
 
+for blk in range(3):
+    t = a[blk].astype(np.int64)
+    print("fwd LN1 detail wg %3d: postGEMMbarrier->LNstart=%d loads+mean=%d var=%d write=%d ->barrier=%d" % (blk * 32, t[28] - t[4], t[29] - t[28], t[30] - t[29], t[31] - t[30], t[5] - t[31]))
 bn = ["top", "GEMM/du", "sync", "colpass", "rowpass(next top)"]
 for blk in range(3):
     t = a[blk].astype(np.int64)

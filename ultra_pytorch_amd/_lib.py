@@ -75,7 +75,7 @@ def load(path=None):
     global _LIB
     if _LIB is not None and path is None:
         return _LIB
-    p = path or LIB_PATH
+    p = path or os.environ.get("ULTR_HIP_LIB") or LIB_PATH  # ULTR_HIP_LIB: experiment builds (tools/ab_build.sh)
     if not os.path.exists(p):
         raise RuntimeError(
             "libultr_hip.so not found at %s — build it first: python -c 'import __graft_entry__ as g; g.build()' "

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define ULTR_LN_EPS 1e-5f       // nn.LayerNorm default eps (reference DNN.py:46)
 #define ULTR_PAD_SCORE -100000.0f  // BaseAlgorithm.PADDING_SCORE (base_algorithm.py:36)
@@ -31,6 +32,25 @@ __device__ __forceinline__ float wave_sum(float v) {
   v += dpp_or<0x142>(0.f, v);
   v += dpp_or<0x143>(0.f, v);
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// N independent sums at once: the six dependent DPP steps of the N chains interleave (a single chain leaves the
+// VALU idle for most of each step's latency)
+template <int N>
+__device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] += dpp_or<0xb1>(0.f, v[k]);
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] += dpp_or<0x4e>(0.f, v[k]);
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] += dpp_or<0x124>(0.f, v[k]);
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] += dpp_or<0x128>(0.f, v[k]);
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] += dpp_or<0x142>(0.f, v[k]);
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] += dpp_or<0x143>(0.f, v[k]);
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[k]), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
   v = fmaxf(v, dpp_or<0xb1>(v, v));
@@ -78,6 +98,7 @@ __device__ __forceinline__ float4 ld4_masked(const float* row, int c, int len, b
 // and masked lanes simply present ULTR_OOB.  Descriptors are built from kernel arguments only (wave-uniform).
 // VEC == false is the generic (unaligned / ragged) path and keeps the masked scalar loads.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define ULTR_OOB 0x80000000u  // > any buffer we describe (sizes are checked < 2 GiB on the host)
 
 struct Src {
@@ -109,6 +130,26 @@ __device__ __forceinline__ float4 buf_ld4(const Src& s, unsigned byte_off) {
 __device__ __forceinline__ float buf_ld1(const Src& s, unsigned byte_off) {
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(s.rs, byte_off, 0, 0));
 }
+// Agent-scope coherent accesses (cache policy sc1): a store is written through to the device coherence point and a
+// load is served from it, so two workgroups on different XCDs (each XCD has its own L2) can hand data over inside ONE
+// launch without the L2-wide writeback + invalidate of a device-scope fence (measured: __threadfence() in every
+// workgroup of the wgrad kernel took it from 16 us to 89 us).
+#define ULTR_SC1 0x10
+__device__ __forceinline__ void coh_st4(const Src& s, unsigned byte_off, float4 v) {
+  const u32x4 d = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(d, s.rs, byte_off, 0, ULTR_SC1);
+}
+__device__ __forceinline__ void coh_st1(const Src& s, unsigned byte_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), s.rs, byte_off, 0, ULTR_SC1);
+}
+__device__ __forceinline__ float4 coh_ld4(const Src& s, unsigned byte_off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(s.rs, byte_off, 0, ULTR_SC1);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ float coh_ld1(const Src& s, unsigned byte_off) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(s.rs, byte_off, 0, ULTR_SC1));
+}
+
 template <bool VEC>
 __device__ __forceinline__ float ld1_sel(const Src& s, int64_t idx, bool ok) {
   if constexpr (VEC) {
@@ -117,5 +158,11 @@ __device__ __forceinline__ float ld1_sel(const Src& s, int64_t idx, bool ok) {
     return ok ? s.base[idx] : 0.f;
   }
 }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence + s_barrier and hipcc
+// implements the fence as s_waitcnt vmcnt(0) lgkmcnt(0): every global store of an epilogue and every prefetched
+// global load would be drained at each phase boundary.  The kernels here never communicate through global memory
+// inside a launch, so waiting for the LDS queue is sufficient.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __host__ __device__ __forceinline__ int round_up(int x, int m) { return (x + m - 1) / m * m; }

@@ -30,7 +30,7 @@
 // forward buffers: float4 epilogue stores / float4 A reads of the generic path -> ld % 4 == 0; rows padded so that
 // the pipelined GEMM may read (masked) up to 31 columns past K
 __host__ __device__ static inline int fwd_ld(int maxdim) { return round_up(maxdim, 32) + 36; }
-// backward dz buffer: float4 A-fragment reads, rows zero-padded to a multiple of 32 (see gemm_nn4)
+// backward dz buffer: float4 A-fragment reads, rows zero-padded to a multiple of 32 (see gemm_nn)
 __host__ __device__ static inline int bwd_ldz(int maxdim) { return round_up(maxdim, 32) + 36; }
 // backward du buffer: float4 epilogue stores -> ld % 4 == 0
 __host__ __device__ static inline int bwd_ldu(int maxdim) { return round_up(maxdim, 16) + 4; }
@@ -141,17 +141,32 @@ __device__ __forceinline__ void gemm_nt_chunk(const float* __restrict__ Xs, int 
 // Lane (i, q) loads the float4 W[m0 + 4s + q][c0 + 4i .. +3] for s = 0..3: the B operands of four interleaved
 // column tiles (tile t holds columns c0 + 4j + t) for four m-steps, i.e. one 16-byte load feeds 4 MFMAs per row
 // tile - the same ratio as the forward form, without keeping a transposed copy of the weights.
-template <int RT, bool VEC>
-__device__ __forceinline__ void gemm_nn4(const float* __restrict__ As, int lda, const Src& W, int K,
-                                         int mb, int me, int c0, f32x4 (&acc)[RT][4], int lane) {
+template <int CT> struct BVec;
+template <> struct BVec<4> { typedef f32x4 type; };
+template <> struct BVec<2> { typedef f32x2 type; };
+template <int CT>
+__device__ __forceinline__ typename BVec<CT>::type buf_ldv(const Src& s, unsigned byte_off) {
+  if constexpr (CT == 4) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(s.rs, byte_off, 0, 0);
+    return (f32x4){__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+  } else {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(s.rs, byte_off, 0, 0);
+    return (f32x2){__uint_as_float(v.x), __uint_as_float(v.y)};
+  }
+}
+
+template <int RT, int CT, bool VEC>
+__device__ __forceinline__ void gemm_nn(const float* __restrict__ As, int lda, const Src& W, int K,
+                                        int mb, int me, int c0, f32x4 (&acc)[RT][CT], int lane) {
+  typedef typename BVec<CT>::type bvec;
   const int i = lane & 15, q = lane >> 4;
-  const int col = c0 + 4 * i;
+  const int col = c0 + CT * i;
   if constexpr (VEC) {
     // Straight-line software pipeline, 32 rows of W (two 16-row groups) per trip, no control flow and no masks:
     //  * the slice [mb, me) starts on a multiple of 32; the A tile in LDS is ZERO beyond the real contraction
     //    length up to the next multiple of 32, so a ragged tail contributes nothing;
-    //  * lane (i, q) owns contraction indices m0 + 4q .. 4q+3 of a group: A is ONE ds_read_b128, B four 16-byte
-    //    rows W[m0 + 4q + s][c0 + 4i ..] (256 B contiguous per 16 lanes);
+    //  * lane (i, q) owns contraction indices m0 + 4q .. 4q+3 of a group: A is ONE ds_read_b128, B four 4*CT-byte
+    //    rows W[m0 + 4q + s][c0 + CT*i ..] (64*CT B contiguous per 16 lanes);
     //  * the next trip's B rows are issued at the TOP of the trip into their own registers (reloading in place
     //    would have to wait for the MFMAs that read them - hipcc then sinks every load to the end of the body and
     //    drains vmcnt(0) at the top); past the slice they are fetched with the out-of-bounds offset (no traffic).
@@ -162,13 +177,13 @@ __device__ __forceinline__ void gemm_nn4(const float* __restrict__ As, int lda, 
     int m0 = mb;
     // one trip: prefetch the NEXT 32 rows into (nx0, nx1), consume (cu0, cu1).  The caller alternates the two
     // register sets, so there are no register copies and no in-place reloads.
-    auto trip = [&](float4(&cu0)[4], float4(&cu1)[4], float4(&nx0)[4], float4(&nx1)[4]) {
+    auto trip = [&](bvec(&cu0)[4], bvec(&cu1)[4], bvec(&nx0)[4], bvec(&nx1)[4]) {
       const unsigned on = o0 + 32u * rs;
       const bool more0 = m0 + 32 < me, more1 = m0 + 48 < me;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        nx0[s] = buf_ld4(W, more0 ? (on + (unsigned)s * rs) : ULTR_OOB);
-        nx1[s] = buf_ld4(W, more1 ? (on + (unsigned)(16 + s) * rs) : ULTR_OOB);
+        nx0[s] = buf_ldv<CT>(W, more0 ? (on + (unsigned)s * rs) : ULTR_OOB);
+        nx1[s] = buf_ldv<CT>(W, more1 ? (on + (unsigned)(16 + s) * rs) : ULTR_OOB);
       }
       __builtin_amdgcn_sched_barrier(0);  // keep the prefetch at the top of the trip
       float4 a0[RT], a1[RT];
@@ -181,33 +196,27 @@ __device__ __forceinline__ void gemm_nn4(const float* __restrict__ As, int lda, 
       for (int rt = 0; rt < RT; ++rt) {
         const float av[4] = {a0[rt].x, a0[rt].y, a0[rt].z, a0[rt].w};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          acc[rt][0] = mfma16(av[s], cu0[s].x, acc[rt][0]);
-          acc[rt][1] = mfma16(av[s], cu0[s].y, acc[rt][1]);
-          acc[rt][2] = mfma16(av[s], cu0[s].z, acc[rt][2]);
-          acc[rt][3] = mfma16(av[s], cu0[s].w, acc[rt][3]);
-        }
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int t = 0; t < CT; ++t) acc[rt][t] = mfma16(av[s], cu0[s][t], acc[rt][t]);
       }
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         const float av[4] = {a1[rt].x, a1[rt].y, a1[rt].z, a1[rt].w};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          acc[rt][0] = mfma16(av[s], cu1[s].x, acc[rt][0]);
-          acc[rt][1] = mfma16(av[s], cu1[s].y, acc[rt][1]);
-          acc[rt][2] = mfma16(av[s], cu1[s].z, acc[rt][2]);
-          acc[rt][3] = mfma16(av[s], cu1[s].w, acc[rt][3]);
-        }
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int t = 0; t < CT; ++t) acc[rt][t] = mfma16(av[s], cu1[s][t], acc[rt][t]);
       }
       o0 = on;
       ap += 32;
       m0 += 32;
     };
-    float4 p0[4], p1[4], r0[4], r1[4];
+    bvec p0[4], p1[4], r0[4], r1[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      p0[s] = buf_ld4(W, o0 + (unsigned)s * rs);
-      p1[s] = buf_ld4(W, (mb + 16 < me) ? (o0 + (unsigned)(16 + s) * rs) : ULTR_OOB);
+      p0[s] = buf_ldv<CT>(W, o0 + (unsigned)s * rs);
+      p1[s] = buf_ldv<CT>(W, (mb + 16 < me) ? (o0 + (unsigned)(16 + s) * rs) : ULTR_OOB);
     }
     int pr = 0;
     for (; pr + 1 < npair; pr += 2) {
@@ -216,83 +225,239 @@ __device__ __forceinline__ void gemm_nn4(const float* __restrict__ As, int lda, 
     }
     if (pr < npair) trip(p0, p1, r0, r1);
   } else {
+    static_assert(VEC || CT == 4, "generic path is 4-wide");
     // generic path (unaligned / ragged shapes): masked scalar loads, no pipelining
     for (int m0 = mb; m0 < me; m0 += 4) {
       const int m = m0 + q;
       const float4 b = ld4_sel<false>(W, (int64_t)m * K, m < me, col, K);
+      const float bv[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         const float a = (m < me) ? As[(rt * 16 + i) * lda + m] : 0.f;
-        acc[rt][0] = mfma16(a, b.x, acc[rt][0]);
-        acc[rt][1] = mfma16(a, b.y, acc[rt][1]);
-        acc[rt][2] = mfma16(a, b.z, acc[rt][2]);
-        acc[rt][3] = mfma16(a, b.w, acc[rt][3]);
+#pragma unroll
+        for (int t = 0; t < CT; ++t) acc[rt][t] = mfma16(a, bv[t], acc[rt][t]);
       }
     }
   }
 }
 
-// forward epilogue of the last contraction slice: (+ partial sums of earlier slices) + bias, activation; to LDS
-// (next layer's input) and, when training, to HBM — 16-byte stores, the lane owns 4 consecutive output columns
-template <int RT>
-__device__ __forceinline__ void finish_fwd_nn4(const f32x4 (&acc)[RT][4], float* __restrict__ Ys, int ldy, int M, int c0,
-                                               int lane, bool add, const float* __restrict__ bias, int act,
-                                               float* __restrict__ gout, int rows_valid, bool vec) {
-  const int i = lane & 15, q = lane >> 4;
-  const int col = c0 + 4 * i;
-  if (col >= M) return;
-  float bv[4];
+// The same contraction as gemm_nn<.., true>, split into an ISSUE half and a CONSUME half so that a wave can put the
+// first D-1 trips of its W panel in flight BEFORE the phase that produces the A tile (LayerNorm, the elementwise
+// backward passes) and keep D-1 trips in flight while it computes: with 16-row tiles a trip is only 16*CT MFMAs
+// (0.5-1k cycles per wave), less than one L2/HBM round trip, so a depth-1 pipeline exposes the latency every trip.
+// One slot = one trip = 32 rows of W = 8 loads of 4*CT bytes per lane.  Slots are indexed by compile-time constants
+// only (fully unrolled), there is no control flow around any load (out-of-range trips fetch the out-of-bounds
+// offset: zeros, no traffic), so hipcc keeps counted s_waitcnt vmcnt(N) throughout.
+template <int RT, int CT, int D, int SCHED = 1>
+struct GemmPipe {
+  typedef typename BVec<CT>::type bvec;
+  bvec b[D][8];
+  unsigned of, of0;  // this lane's byte offset of the next trip to fetch / of the slice's first trip
+  unsigned rs;       // bytes per row of W
+  int mf, mb, me;    // contraction index of the next trip to fetch / slice bounds
+  int left;          // trips still to fetch
+
+  template <int S>
+  __device__ __forceinline__ void fetch(const Src& W) {
+    const bool ok0 = left > 0, ok1 = left > 0 && mf + 16 < me;
 #pragma unroll
-  for (int t = 0; t < 4; ++t) bv[t] = (col + t < M) ? bias[col + t] : 0.f;
+    for (int s = 0; s < 4; ++s) {
+      if constexpr (SCHED == 2) {  // experiment: no global loads
+        b[S][s] = (bvec)(1.0f);
+        b[S][4 + s] = (bvec)(1.0f);
+      } else {
+        b[S][s] = buf_ldv<CT>(W, ok0 ? (of + (unsigned)s * rs) : ULTR_OOB);
+        b[S][4 + s] = buf_ldv<CT>(W, ok1 ? (of + (unsigned)(16 + s) * rs) : ULTR_OOB);
+      }
+    }
+    --left;
+    mf += 32;
+    of += 32u * rs;
+    if (mf >= me) {  // wrap: trips are visited in rotated order (see begin)
+      mf = mb;
+      of = of0;
+    }
+  }
+  // slice [mb_, me_) of the contraction (mb_ a multiple of 32), output columns c0 .. c0 + 16*CT; !valid => no
+  // traffic.  rot rotates the ORDER in which the slice's 32-row trips are visited (trip (rot + t) mod n): workgroups
+  // that stream the same W in lockstep would otherwise all hit the same few L2 channels at the same moment.
+  __device__ __forceinline__ void begin(const Src& W, int ldw, int mb_, int me_, int c0, bool valid, int rot, int lane) {
+    const int i = lane & 15, q = lane >> 4;
+    const int n = (me_ - mb_ + 31) >> 5;
+    rs = (unsigned)ldw * 4u;
+    of0 = ((unsigned)(mb_ + 4 * q) * (unsigned)ldw + (unsigned)(c0 + CT * i)) * 4u;
+    mb = mb_;
+    me = me_;
+    left = valid ? n : 0;
+    const int r0 = n > 0 ? rot % n : 0;
+    mf = mb_ + 32 * r0;
+    of = of0 + (unsigned)(32 * r0) * rs;
+    if constexpr (D > 1) fetch<0>(W);
+    if constexpr (D > 2) fetch<1>(W);
+    if constexpr (D > 3) fetch<2>(W);
+    if constexpr (D > 4) fetch<3>(W);
+    if constexpr (D > 5) fetch<4>(W);
+    if constexpr (D > 6) fetch<5>(W);
+    if constexpr (D > 7) fetch<6>(W);
+    static_assert(D >= 2 && D <= 8, "pipeline depth");
+  }
+  // Instruction mix of one trip: 8 W loads (for a later trip), 2*RT LDS reads, 8*RT*CT MFMAs.
+  //   SCHED 0: all loads first (a burst: every wave of the CU queues on the one texture-address unit while the
+  //            matrix cores idle, then all waves compute while the memory pipe idles);
+  //   SCHED 1: one load after every RT*CT MFMAs, so address generation runs in the shadow of the MFMAs.
+  __device__ __forceinline__ void sched_top() {
+    if constexpr (SCHED == 0) __builtin_amdgcn_sched_barrier(0);
+  }
+  __device__ __forceinline__ void sched_mix() {
+    if constexpr (SCHED == 1) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * RT, 0);  // DS reads (the A fragments)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, RT * CT, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // VMEM read
+      }
+    }
+  }
+  template <int S>
+  __device__ __forceinline__ void consume(const float* __restrict__ ap, int lda, f32x4 (&acc)[RT][CT]) {
+    float4 a0[RT], a1[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      a0[rt] = ld4(ap + rt * 16 * lda);
+      a1[rt] = ld4(ap + rt * 16 * lda + 16);
+    }
+    if constexpr (SCHED == 3) {  // experiment: no MFMA
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int t = 0; t < CT; ++t) acc[0][t][s & 3] += b[S][s][t] * a0[0].x;
+      return;
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const float av[4] = {a0[rt].x, a0[rt].y, a0[rt].z, a0[rt].w};
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < CT; ++t) acc[rt][t] = mfma16(av[s], b[S][s][t], acc[rt][t]);
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const float av[4] = {a1[rt].x, a1[rt].y, a1[rt].z, a1[rt].w};
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < CT; ++t) acc[rt][t] = mfma16(av[s], b[S][4 + s][t], acc[rt][t]);
+    }
+  }
+  // consume the slice begun with begin() (same mb_, me_, rot): As = A tile in LDS, zero beyond the real contraction
+  // length up to a multiple of 32
+  __device__ __forceinline__ void run(const float* __restrict__ As, int lda, const Src& W, int mb_, int me_, int rot,
+                                      f32x4 (&acc)[RT][CT], int lane) {
+    const int i = lane & 15, q = lane >> 4;
+    const int n = (me_ - mb_ + 31) >> 5;
+    const float* a_lo = As + i * lda + mb_ + 4 * q;
+    const float* a_hi = a_lo + 32 * n;
+    const float* ap = a_lo + 32 * (n > 0 ? rot % n : 0);
+    auto adv = [&]() {
+      ap += 32;
+      if (ap == a_hi) ap = a_lo;
+    };
+    auto step = [&](auto uc) {
+      constexpr int U = decltype(uc)::value;
+      fetch<(U + D - 1) % D>(W);
+      sched_top();
+      consume<U>(ap, lda, acc);
+      sched_mix();
+      adv();
+    };
+    int t = 0;
+    for (; t + D <= n; t += D) {
+      step(std::integral_constant<int, 0>());
+      step(std::integral_constant<int, 1>());
+      if constexpr (D > 2) step(std::integral_constant<int, 2>());
+      if constexpr (D > 3) step(std::integral_constant<int, 3>());
+      if constexpr (D > 4) step(std::integral_constant<int, 4>());
+      if constexpr (D > 5) step(std::integral_constant<int, 5>());
+      if constexpr (D > 6) step(std::integral_constant<int, 6>());
+      if constexpr (D > 7) step(std::integral_constant<int, 7>());
+    }
+    // tail (< D trips, already in flight): consume only
+    if (t < n) { consume<0>(ap, lda, acc); adv(); }
+    if constexpr (D > 2) if (t + 1 < n) { consume<1>(ap, lda, acc); adv(); }
+    if constexpr (D > 3) if (t + 2 < n) { consume<2>(ap, lda, acc); adv(); }
+    if constexpr (D > 4) if (t + 3 < n) { consume<3>(ap, lda, acc); adv(); }
+    if constexpr (D > 5) if (t + 4 < n) { consume<4>(ap, lda, acc); adv(); }
+    if constexpr (D > 6) if (t + 5 < n) { consume<5>(ap, lda, acc); adv(); }
+    if constexpr (D > 7) if (t + 6 < n) { consume<6>(ap, lda, acc); adv(); }
+  }
+};
+
+// forward epilogue of the last contraction slice: (+ partial sums of earlier slices) + bias, activation; to LDS
+// (next layer's input) and, when training, to HBM — 4*CT-byte stores, the lane owns CT consecutive output columns
+template <int RT, int CT>
+__device__ __forceinline__ void finish_fwd_nn(const f32x4 (&acc)[RT][CT], float* __restrict__ Ys, int ldy, int M, int c0,
+                                              int lane, const float* __restrict__ bias, int act,
+                                              float* __restrict__ gout, int rows_valid) {
+  // VEC path only: M % 4 == 0, so a lane's CT columns are all inside or all outside
+  const int i = lane & 15, q = lane >> 4;
+  const int col = c0 + CT * i;
+  if (col >= M) return;
+  float bv[CT];
+#pragma unroll
+  for (int t = 0; t < CT; ++t) bv[t] = bias[col + t];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = rt * 16 + 4 * q + r;
       float* dst = Ys + row * ldy + col;
-      float v[4] = {acc[rt][0][r], acc[rt][1][r], acc[rt][2][r], acc[rt][3][r]};
-      if (add) {
-        const float4 o = ld4(dst);  // LDS rows are padded to a multiple of 4: a full float4 is always in range
-        v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
-      }
+      float v[CT];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) v[t] = act_fwd(v[t] + bv[t], act);
-      st4(dst, make_float4(v[0], v[1], v[2], v[3]));
+      for (int t = 0; t < CT; ++t) v[t] = act_fwd(acc[rt][t][r] + bv[t], act);
+      if constexpr (CT == 4) st4(dst, make_float4(v[0], v[1], v[2], v[3]));
+      else *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
       if (gout != nullptr && row < rows_valid) {
         float* g = gout + (int64_t)row * M + col;
-        if (vec && col + 3 < M) {
-          st4(g, make_float4(v[0], v[1], v[2], v[3]));
-        } else {
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            if (col + t < M) g[t] = v[t];
-        }
+        if constexpr (CT == 4) st4(g, make_float4(v[0], v[1], v[2], v[3]));
+        else *reinterpret_cast<float2*>(g) = make_float2(v[0], v[1]);
       }
     }
 }
 
-// epilogue of gemm_nn4: lane holds D_t[row = 4q + r][j = i] = DU[row][c0 + 4i + t]
-template <int RT>
-__device__ __forceinline__ void store_nn4(const f32x4 (&acc)[RT][4], float* __restrict__ DUs, int ldu, int K, int c0,
-                                          int lane, bool add) {
+// epilogue of gemm_nn: lane holds D_t[row = 4q + r][j = i] = DU[row][c0 + CT*i + t]
+template <int RT, int CT>
+__device__ __forceinline__ void store_nn(const f32x4 (&acc)[RT][CT], float* __restrict__ DUs, int ldu, int K, int c0,
+                                         int lane, bool add) {
   const int i = lane & 15, q = lane >> 4;
-  const int col = c0 + 4 * i;
+  const int col = c0 + CT * i;
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float* dst = DUs + (rt * 16 + 4 * q + r) * ldu + col;
-      float4 v = make_float4(acc[rt][0][r], acc[rt][1][r], acc[rt][2][r], acc[rt][3][r]);
-      if (col + 3 < K) {
-        if (add) {
-          const float4 o = ld4(dst);
-          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-        }
-        st4(dst, v);
-      } else {
-        const float vv[4] = {v.x, v.y, v.z, v.w};
+      float vv[CT];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < CT; ++t) vv[t] = acc[rt][t][r];
+      if (col + CT - 1 < K) {
+        if constexpr (CT == 4) {
+          float4 v = make_float4(vv[0], vv[1], vv[2], vv[3]);
+          if (add) {
+            const float4 o = ld4(dst);
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+          }
+          st4(dst, v);
+        } else {
+          float2 v = make_float2(vv[0], vv[1]);
+          if (add) {
+            const float2 o = *reinterpret_cast<const float2*>(dst);
+            v.x += o.x; v.y += o.y;
+          }
+          *reinterpret_cast<float2*>(dst) = v;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
           if (col + t < K) dst[t] = add ? (dst[t] + vv[t]) : vv[t];
       }
     }
@@ -326,6 +491,10 @@ extern "C" int ultr_trace_read(unsigned long long* host_out) {
 // ------------------------------------------------------------------------------------------------
 // Forward
 // ------------------------------------------------------------------------------------------------
+// prefetch depth (trips of 32 W rows) of the forward GEMM pipeline
+#ifndef FWD_D
+#define FWD_D 2
+#endif
 template <int R, int NW, bool VEC>
 __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float* __restrict__ params,
                                                           const float* __restrict__ features, int64_t n_docs,
@@ -347,7 +516,52 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
   // LayerNorm gamma/beta, biases and the scorer's weight row go to LDS up front, overlapped with the feature
   // gather: each later phase would otherwise start with an exposed ~1-2k-cycle global load of a few hundred floats.
   // layout per layer j: gamma[K_j] | beta[K_j] | bias[M_j]; then the last layer's weight row [K_last]
-  {
+  bool staged = false;
+  if constexpr (VEC) {
+    constexpr int NT = NW * 64, RPW = R / NW, PVR = 3, FCH = 4;
+    if (wt != nullptr && p.pv_total <= PVR * NT * 4 && p.K[0] <= FCH * 256) {
+      // Fast prologue, ONE exposed round trip + the dependent gather instead of three serial ones: the ids go
+      // first, then the packed vector-parameter image (contiguous 16-byte loads, kept current by the update
+      // kernel), then - as soon as the ids are back - every feature row of the wave; only then anything is
+      // written to LDS.  No control flow around the loads (out-of-range chunks present the OOB offset).
+      const int F = p.K[0];
+      const int64_t nme = n0 + wave + NW * (lane < RPW ? lane : 0);
+      const bool idok = lane < RPW && nme < N;
+      const int bb = (int)((uint32_t)(idok ? nme : 0) / (uint32_t)L), ll = (int)((uint32_t)(idok ? nme : 0) % (uint32_t)L);
+      const int myid_raw = docids[(int64_t)ll * B + bb];
+      const Src pvs = make_src(wt + p.wt_pv_off, p.pv_total);
+      float4 pvr[PVR];
+#pragma unroll
+      for (int u = 0; u < PVR; ++u) pvr[u] = buf_ld4(pvs, (unsigned)(tid + u * NT) * 16u);
+      const int myid = (idok && myid_raw >= 0 && myid_raw < n_docs) ? myid_raw : -1;
+      const Src fs = make_src(features, n_docs * F);
+      float4 fr[RPW][FCH];
+#pragma unroll
+      for (int k = 0; k < RPW; ++k) {
+        const int id = __builtin_amdgcn_readlane(myid, k);
+#pragma unroll
+        for (int u = 0; u < FCH; ++u) {
+          const int c = lane * 4 + 256 * u;
+          fr[k][u] = buf_ld4(fs, (id >= 0 && c < F) ? (unsigned)(((int64_t)id * F + c) * 4) : ULTR_OOB);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < PVR; ++u) {
+        const int o = (tid + u * NT) * 4;
+        if (o < p.pv_total) st4(PV + o, pvr[u]);
+      }
+      const int F16 = round_up(F, 16);
+#pragma unroll
+      for (int k = 0; k < RPW; ++k)
+#pragma unroll
+        for (int u = 0; u < FCH; ++u) {
+          const int c = lane * 4 + 256 * u;
+          if (c < F16) st4(X + (wave + NW * k) * ld + c, fr[k][u]);
+        }
+      staged = true;
+    }
+  }
+  if (!staged) {
     int off = 0;
     for (int j = 0; j < p.nl; ++j) {
       const int K = p.K[j], M = p.M[j];
@@ -360,10 +574,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
     }
     const int Kl = p.K[p.nl - 1];
     for (int c = tid; c < Kl; c += NW * 64) PV[off + c] = params[p.off_w[p.nl - 1] + c];
-  }
-
-  // ---- a2: gather feature rows (zero row for the PAD id == n_docs and for rows past N) ----------
-  {
+    // ---- a2: gather feature rows (zero row for the PAD id == n_docs and for rows past N) ----------
     const int F = p.K[0];
     const int F16 = round_up(F, 16);
     const bool vecf = VEC || ((vecmask >> 31) & 1);
@@ -378,57 +589,121 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
       for (int c = lane * 4; c < F16; c += 256) st4(X + r * ld + c, ld4_masked(src, c, F, vecf));
     }
   }
-  __syncthreads();
+  lds_barrier();
   TRACE_STAMP(1);
 
   int pv_off = 0;
   for (int j = 0; j < p.nl; ++j) {
     const int K = p.K[j], M = p.M[j];
-    const int K16 = round_up(K, 32);  // zero-padded width of the A tile (multiple of 32, see gemm_nn4)
+    const int K16 = round_up(K, 32);  // zero-padded width of the A tile (multiple of 32, see gemm_nn)
     const float* lnw = PV + pv_off;
     const float* lnb = PV + pv_off + K;
     const float* bias = PV + pv_off + 2 * K;
     pv_off += 2 * K + M;
+    // ---- plan of this layer's GEMM -----------------------------------------------------------------------
+    // 32-column chunks.  Enough chunks for every wave: a wave takes chunks wave, wave + NW, .. over the whole
+    // contraction.  Fewer: chunks x ksplit slices of the contraction, partial tiles summed in fixed order.
+    int ksplit = 1, kb = 0, ke = K, c0 = wave * 32;
+    bool has = false;
+    const int nch = (M + 31) >> 5;
+    Src Wt = make_src(wt, 0);
+    GemmPipe<RT, 2, FWD_D, 0> pipe;
+    if constexpr (VEC) {
+      if (j < p.nl - 1) {
+        Wt = make_src(wt + p.wt_off[j], (int64_t)K * M);
+        while (ksplit * 2 * nch <= NW) ksplit *= 2;
+        if (ksplit > 1) {
+          const int klen = round_up((K + ksplit - 1) / ksplit, 32);
+          c0 = (wave % nch) * 32;
+          kb = (wave / nch) * klen;
+          ke = (kb + klen < K) ? (kb + klen) : K;
+          has = wave < nch * ksplit && kb < ke;
+        } else {
+          has = c0 < M;
+        }
+      }
+    }
     // ---- LayerNorm (biased variance, eps 1e-5, affine), in place; two-pass statistics -----------
+    bool scored = false;
     if (K <= 256) {
-      // fast path: a lane owns columns lane + 64k (k < 4); gamma/beta are fetched once per layer and the row
-      // lives in registers between the passes
+      // fast path: a lane owns columns lane + 64k (k < 4); gamma/beta are fetched once per layer, the wave's
+      // rows live in registers between the passes and their reductions are interleaved.  The scorer (last
+      // layer, M = 1) is folded in:  score = rstd * sum_c (x_c - mean) gamma_c w_c + sum_c beta_c w_c + b
+      constexpr int RPW = (R + NW - 1) / NW;
+      const bool last = (j == p.nl - 1);
+      const float* wl = PV + pv_off;  // the scorer's weight row (valid when last)
       float g[4], be[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int c = lane + 64 * k;
         g[k] = (c < K) ? lnw[c] : 0.f;
         be[k] = (c < K) ? lnb[c] : 0.f;
-      }
-      for (int r = wave; r < R; r += NW) {
-        float* row = X + r * ld;
-        float x[4];
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int c = lane + 64 * k;
-          x[k] = (c < K) ? row[c] : 0.f;
-          s += x[k];
-        }
-        const float mean = wave_sum(s) / (float)K;
-        float v = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int c = lane + 64 * k;
-          x[k] = (c < K) ? (x[k] - mean) : 0.f;
-          v += x[k] * x[k];
-        }
-        const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)K + ULTR_LN_EPS);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int c = lane + 64 * k;
-          if (c < K16) row[c] = x[k] * rstd * g[k] + be[k];  // c in [K, K16): 0 * rstd * 0 + 0 = 0 (zero padding)
-        }
-        if (saved != nullptr && lane == 0 && n0 + r < N) {
-          saved[p.sv_mean[j] + n0 + r] = mean;
-          saved[p.sv_rstd[j] + n0 + r] = rstd;
+        if (last) {
+          const float w = (c < K) ? wl[c] : 0.f;
+          g[k] *= w;
+          be[k] *= w;
         }
       }
+      if (j == 1) TRACE_STAMP(28);
+      float x[RPW][4], s[RPW];
+#pragma unroll
+      for (int q = 0; q < RPW; ++q) {
+        const int r = wave + NW * q;
+        const float* row = X + (r < R ? r : 0) * ld;
+        s[q] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int c = lane + 64 * k;
+          x[q][k] = (c < K) ? row[c] : 0.f;
+          s[q] += x[q][k];
+        }
+      }
+      wave_sum_n<RPW>(s);
+      if (j == 1) TRACE_STAMP(29);
+      float v[RPW], t[RPW + 1];
+#pragma unroll
+      for (int q = 0; q < RPW; ++q) {
+        s[q] /= (float)K;  // mean
+        v[q] = 0.f;
+        t[q] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int c = lane + 64 * k;
+          x[q][k] = (c < K) ? (x[q][k] - s[q]) : 0.f;
+          v[q] += x[q][k] * x[q][k];
+          t[q] += x[q][k] * g[k];
+        }
+      }
+      wave_sum_n<RPW>(v);
+      if (j == 1) TRACE_STAMP(30);
+      if (last) {
+        t[RPW] = (be[0] + be[1]) + (be[2] + be[3]);
+        wave_sum_n<RPW + 1>(t);
+      }
+#pragma unroll
+      for (int q = 0; q < RPW; ++q) {
+        const int r = wave + NW * q;
+        if (r < R) {
+          const float rstd = 1.0f / sqrtf(v[q] / (float)K + ULTR_LN_EPS);
+          if (!last) {
+            float* row = X + r * ld;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int c = lane + 64 * k;
+              if (c < K16) row[c] = x[q][k] * rstd * g[k] + be[k];  // c in [K, K16): 0 * rstd * 0 + 0 = 0 (zero padding)
+            }
+          }
+          if (lane == 0 && n0 + r < N) {
+            if (saved != nullptr) {
+              saved[p.sv_mean[j] + n0 + r] = s[q];
+              saved[p.sv_rstd[j] + n0 + r] = rstd;
+            }
+            if (last) scores[n0 + r] = rstd * t[q] + t[RPW] + bias[0];
+          }
+        }
+      }
+      scored = last;
+      if (j == 1) TRACE_STAMP(31);
     } else {
       for (int r = wave; r < R; r += NW) {
         float* row = X + r * ld;
@@ -448,48 +723,40 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     TRACE_STAMP(2 + 3 * j);
     const float* W = params + p.off_w[j];
     if (j < p.nl - 1) {
       // ---- Linear + activation on the matrix cores ------------------------------------------------
       float* gout = (saved != nullptr) ? (saved + p.sv_x[j + 1] + n0 * M) : nullptr;
       if constexpr (VEC) {
-        // Y = act(X . W^T + b) on the k-major weight copy: 64-column chunks x slices of the contraction over the
-        // NW waves; slice 0 stores its partial tile in Y, later slices add in fixed order, the last one finishes
-        const Src Wt = make_src(wt + p.wt_off[j], (int64_t)K * M);
-        const int nch = (M + 63) >> 6;
-        int ksplit = 1;
-        while (ksplit * 2 * nch <= NW) ksplit *= 2;
+        // Y = act(X . W^T + b) on the k-major weight copy.  (Issuing the first trips before the LayerNorm was
+        // measured SLOWER: hipcc then drains vmcnt(0) inside the LayerNorm / epilogue code, see DESIGN.md.)
+        pipe.begin(Wt, M, kb, ke, c0, has, 0, lane);
         if (ksplit == 1) {
-          for (int ch = wave; ch < nch; ch += NW) {
-            f32x4 acc[RT][4];
+          for (int cc = c0; cc < M; cc += NW * 32) {
+            f32x4 acc[RT][2];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-              for (int t = 0; t < 4; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            gemm_nn4<RT, true>(X, ld, Wt, M, 0, K, ch * 64, acc, lane);
-            finish_fwd_nn4<RT>(acc, Y, ld, M, ch * 64, lane, false, bias, p.act, gout, rows_valid, true);
+              for (int t = 0; t < 2; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            pipe.run(X, ld, Wt, 0, K, 0, acc, lane);
+            if (cc + NW * 32 < M) pipe.begin(Wt, M, 0, K, cc + NW * 32, true, 0, lane);
+            finish_fwd_nn<RT, 2>(acc, Y, ld, M, cc, lane, bias, p.act, gout, rows_valid);
           }
         } else {
-          const int klen = round_up((K + ksplit - 1) / ksplit, 32);
-          const bool has = wave < nch * ksplit;
-          const int ch = wave % nch, ks = wave / nch;
-          f32x4 acc[RT][4];
+          f32x4 acc[RT][2];
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (has) {
-            const int kb = ks * klen;
-            const int ke = (kb + klen < K) ? (kb + klen) : K;
-            if (kb < ke) gemm_nn4<RT, true>(X, ld, Wt, M, kb, ke, ch * 64, acc, lane);
-          }
+            for (int t = 0; t < 2; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (has) pipe.run(X, ld, Wt, kb, ke, 0, acc, lane);
           // raw partial tiles are summed into Y slice by slice (fixed order), then ALL threads apply bias +
           // activation (the expm1f-heavy epilogue would otherwise run on the last slice's waves only)
+          const int ks = wave / nch;
           for (int r = 0; r < ksplit; ++r) {
-            if (has && ks == r) store_nn4<RT>(acc, Y, ld, M, ch * 64, lane, r > 0);
-            __syncthreads();
+            if (wave < nch * ksplit && ks == r) store_nn<RT, 2>(acc, Y, ld, M, c0, lane, r > 0);
+            lds_barrier();
           }
           const int M4 = M >> 2;  // VEC path: M % 4 == 0
           for (int e = tid; e < R * M4; e += NW * 64) {
@@ -519,13 +786,14 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
         }
       }
       TRACE_STAMP(3 + 3 * j);
-      __syncthreads();
+      lds_barrier();
       TRACE_STAMP(4 + 3 * j);
       float* t = X;
       X = Y;
       Y = t;
     } else {
       // ---- final Linear(K, 1): a dot product per row, wave-shuffle reduction ---------------------
+      if (!scored)
       for (int r = wave; r < R; r += NW) {
         const float* row = X + r * ld;
         float s = 0.f;
@@ -601,7 +869,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd_kernel(DnnPlan p, BwdPlan bp,
     // ---- fused listwise softmax cross entropy (NA / IPW): this row block touches at most R/L + 2 lists; one
     // wavefront recomputes each of them (L scores from L2) instead of a separate launch + dependent kernel boundary.
     // A list's loss / normaliser partial is emitted by the block that owns the list's FIRST row, exactly once.
-    __syncthreads();  // sm_ds zero-initialised above
+    lds_barrier();  // sm_ds zero-initialised above
     float* sm_lt = DU;  // [NW][2] scratch (DU is not live yet)
     if (lane < 2) sm_lt[wave * 2 + lane] = 0.f;
     const int64_t nlast = (n0 + R < N ? n0 + R : N) - 1;
@@ -644,7 +912,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd_kernel(DnnPlan p, BwdPlan bp,
         sm_lt[wave * 2 + 1] += S;
       }
     }
-    __syncthreads();
+    lds_barrier();
     const int tail = (int)ultr_tail_len(L);
     for (int t = tid; t < tail; t += NT) {
       float v = 0.f;
@@ -671,7 +939,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd_kernel(DnnPlan p, BwdPlan bp,
     // loads in flight at once; the column / row passes below then never touch global memory for x
     // (a per-row serial global read cost ~11k cycles per layer).  XS is free here: its last readers finished
     // before the barrier that ended the previous layer's row pass... which is the one below for j < nl-1.
-    if (j < p.nl - 1) __syncthreads();
+    if (j < p.nl - 1) lds_barrier();
     for (int c = tid; c < K; c += NT) {
       sm_g[c] = lnw[c];
       sm_b[c] = lnb[c];
@@ -711,7 +979,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd_kernel(DnnPlan p, BwdPlan bp,
         }
       }
     }
-    __syncthreads();  // sm_*, XS visible; DZ of the previous iteration complete
+    lds_barrier();  // sm_*, XS visible; DZ of the previous iteration complete
     TRACE_STAMP(16 + 4 * (p.nl - 1 - j));
     // ---- du_j = dz_j . W_j ------------------------------------------------------------------------
     if (last) {
@@ -726,15 +994,32 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd_kernel(DnnPlan p, BwdPlan bp,
       const int nch = (K + 63) >> 6;
       int msplit = 1;
       while (msplit * 2 * nch <= NW) msplit *= 2;
-      if (msplit == 1) {
+      bool done = false;
+      if constexpr (VEC) {
+        if (msplit > 1 && ((K + 31) >> 5) >= NW) {
+          // 32-column chunks give every wave a whole contraction: no partial-tile rounds
+          for (int ch = wave; ch * 32 < K; ch += NW) {
+            f32x4 acc[RT][2];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+              for (int t = 0; t < 2; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            gemm_nn<RT, 2, true>(DZ, ldz, Wsrc, K, 0, M, ch * 32, acc, lane);
+            store_nn<RT, 2>(acc, DU, ldu, K, ch * 32, lane, false);
+          }
+          done = true;
+        }
+      }
+      if (done) {
+      } else if (msplit == 1) {
         for (int ch = wave; ch < nch; ch += NW) {
           f32x4 acc[RT][4];
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          gemm_nn4<RT, VEC>(DZ, ldz, Wsrc, K, 0, M, ch * 64, acc, lane);
-          store_nn4<RT>(acc, DU, ldu, K, ch * 64, lane, false);
+          gemm_nn<RT, 4, VEC>(DZ, ldz, Wsrc, K, 0, M, ch * 64, acc, lane);
+          store_nn<RT, 4>(acc, DU, ldu, K, ch * 64, lane, false);
         }
       } else {
         const int mlen = round_up((M + msplit - 1) / msplit, 32);
@@ -748,16 +1033,16 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd_kernel(DnnPlan p, BwdPlan bp,
         if (has) {
           const int mb = ms * mlen;
           const int me = (mb + mlen < M) ? (mb + mlen) : M;
-          if (mb < me) gemm_nn4<RT, VEC>(DZ, ldz, Wsrc, K, mb, me, ch * 64, acc, lane);
+          if (mb < me) gemm_nn<RT, 4, VEC>(DZ, ldz, Wsrc, K, mb, me, ch * 64, acc, lane);
         }
         for (int r = 0; r < msplit; ++r) {
-          if (has && ms == r) store_nn4<RT>(acc, DU, ldu, K, ch * 64, lane, r > 0);
-          if (r + 1 < msplit) __syncthreads();
+          if (has && ms == r) store_nn<RT, 4>(acc, DU, ldu, K, ch * 64, lane, r > 0);
+          if (r + 1 < msplit) lds_barrier();
         }
       }
     }
     TRACE_STAMP(17 + 4 * (p.nl - 1 - j));
-    __syncthreads();
+    lds_barrier();
     TRACE_STAMP(18 + 4 * (p.nl - 1 - j));
     // ---- column pass: per-row-block partial sums of the vector-parameter gradients ---------------
     //   dgamma_j[c] = sum_r du[r,c] xhat[r,c]   dbeta_j[c] = sum_r du[r,c]
@@ -811,7 +1096,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd_kernel(DnnPlan p, BwdPlan bp,
           DZ[r * ldz + c] = dzv;
           if (valid) dzg[n * K + c] = dzv;
         }
-        for (int c = K + lane; c < round_up(K, 32); c += 64) DZ[r * ldz + c] = 0.f;  // zero pad (gemm_nn4 reads it)
+        for (int c = K + lane; c < round_up(K, 32); c += 64) DZ[r * ldz + c] = 0.f;  // zero pad (gemm_nn reads it)
       }
     }
   }
@@ -861,7 +1146,7 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
     const int e = ((int)blockIdx.x - bp.wgrad_blocks) * 64 + lane;
     const float part = (e < bp.vlen) ? strided_sum(ws + bp.vslab_off + e, bp.vlen, bp.nrb, grp) : 0.f;
     smem[grp * 64 + lane] = part;
-    __syncthreads();
+    lds_barrier();
     if (grp == 0 && e < bp.vlen)
       ws[bp.vred_off + e] = ((smem[lane] + smem[64 + lane]) + smem[128 + lane]) + smem[192 + lane];
     return;
@@ -902,7 +1187,7 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
       }
       sm_ids[r] = id;
     }
-    __syncthreads();
+    lds_barrier();
   }
   TRACE_STAMP(9);
   const float4 gam = ld4_masked(params + p.off_lnw[j], k0 + 4 * i, K, false);
@@ -950,7 +1235,7 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
     }
   };
 
-  // Straight-line software pipeline (same shape as gemm_nn4): a trip consumes TWO steps (8 rows, 32 MFMAs) from one
+  // Straight-line software pipeline (same shape as gemm_nn): a trip consumes TWO steps (8 rows, 32 MFMAs) from one
   // register set while the next trip's operands are already in flight into the other; no control flow in the
   // steady state.  Steps past the wave's slice load dz through the out-of-bounds offset (zeros): wasted MFMAs, no
   // wrong sums - the host rounds rows_per_split to a multiple of 32 so that there are none in the common case.
@@ -1022,7 +1307,7 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
       bred[wave][4 * i + 3] = s.w;
     }
   }
-  __syncthreads();
+  lds_barrier();
   TRACE_STAMP(11);
   float* slab = ws + wl.slab_off + (int64_t)split * ((int64_t)M * K + M);
 #pragma unroll
@@ -1143,7 +1428,16 @@ bool ultr_make_dnn_plan(const ultr_dnn_desc* d, int64_t N, DnnPlan* p) {
     wt += (int64_t)p->K[j] * p->M[j];
     wt = (wt + 3) & ~(int64_t)3;
   }
-  p->wt_total = wt;
+  p->wt_pv_off = wt;
+  int pv = 0;
+  for (int j = 0; j < p->nl; ++j) {
+    p->pv_off[j] = pv;
+    pv += 2 * p->K[j] + p->M[j];
+  }
+  p->pv_wlast = pv;
+  pv += p->K[p->nl - 1];
+  p->pv_total = (pv + 3) & ~3;
+  p->wt_total = wt + p->pv_total;
   int64_t sv = 0;
   for (int j = 1; j < p->nl; ++j) {
     p->sv_x[j] = sv;
@@ -1158,11 +1452,7 @@ bool ultr_make_dnn_plan(const ultr_dnn_desc* d, int64_t N, DnnPlan* p) {
   return true;
 }
 
-static size_t fwd_pv_floats(const DnnPlan& p) {
-  size_t n = 0;
-  for (int j = 0; j < p.nl; ++j) n += 2 * (size_t)p.K[j] + (size_t)p.M[j];
-  return (n + p.K[p.nl - 1] + 3) & ~(size_t)3;
-}
+static size_t fwd_pv_floats(const DnnPlan& p) { return (size_t)p.pv_total; }
 static size_t fwd_lds_bytes(const DnnPlan& p, int R) { return ((size_t)2 * R * fwd_ld(p.maxdim) + fwd_pv_floats(p)) * sizeof(float); }
 static int fwd_rows_per_wg(const DnnPlan& p, int64_t N) {
   int r = env_int("ULTR_FWD_R", 0);
@@ -1230,6 +1520,7 @@ bool ultr_make_bwd_plan(const DnnPlan& p, int64_t N, BwdPlan* bp) {
   bp->total = off;
   return true;
 }
+
 
 static void make_red_plan(const DnnPlan& p, const BwdPlan& bp, RedPlan* rp) {
   int s = 0;
@@ -1309,28 +1600,33 @@ extern "C" int64_t ultr_dnn_wt_floats(const ultr_dnn_desc* d) {
   return p.wt_total > 0 ? p.wt_total : 4;
 }
 
-// WT_j[k, m] = W_j[m, k] for every hidden Linear (coalesced reads, strided writes; ~100k elements)
+// WT_j[k, m] = W_j[m, k] for every hidden Linear (coalesced reads, strided writes; ~100k elements) + the PV image
 __global__ __launch_bounds__(256) void wt_build_kernel(DnnPlan p, const float* __restrict__ params, float* __restrict__ wt) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  int64_t base = 0;
+  if (e >= p.P) {
+    const int64_t idx = p.pv_wlast + p.K[p.nl - 1] + (e - p.P);  // zero the image's padding (< 4 floats)
+    if (idx < p.pv_total) wt[p.wt_pv_off + idx] = 0.f;
+    return;
+  }
+  const int pv = ultr_pv_index(p, e);
+  if (pv >= 0) {
+    wt[p.wt_pv_off + pv] = params[e];
+    return;
+  }
   for (int j = 0; j < p.nl - 1; ++j) {
-    const int64_t n = (int64_t)p.M[j] * p.K[j];
-    if (e >= base && e < base + n) {
-      const int64_t r = e - base;
+    const int64_t r = e - p.off_w[j];
+    if (r >= 0 && r < (int64_t)p.M[j] * p.K[j]) {
       const int m = (int)(r / p.K[j]), k = (int)(r % p.K[j]);
-      wt[p.wt_off[j] + (int64_t)k * p.M[j] + m] = params[p.off_w[j] + r];
+      wt[p.wt_off[j] + (int64_t)k * p.M[j] + m] = params[e];
       return;
     }
-    base += n;
   }
 }
 
 extern "C" int ultr_dnn_build_wt(const ultr_dnn_desc* d, const float* params, float* wt, void* stream) {
   DnnPlan p;
   if (!params || !wt || !ultr_make_dnn_plan(d, 0, &p)) return ULTR_E_BADARG;
-  int64_t n = 0;
-  for (int j = 0; j < p.nl - 1; ++j) n += (int64_t)p.M[j] * p.K[j];
-  if (n == 0) return 0;
+  const int64_t n = p.P + 4;
   hipLaunchKernelGGL(wt_build_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, params, wt);
   return (int)hipGetLastError();
 }

@@ -21,7 +21,14 @@ struct DnnPlan {
   // B-fragments are then 256-byte contiguous per 16 lanes (W_j itself gives 16 rows x 64 B per load instruction,
   // which the texture addresser processes ~4x slower); maintained by the update kernel
   int64_t wt_off[ULTR_MAXL];
-  int64_t wt_total;
+  // ... followed, in the same buffer, by the "PV image": every vector parameter packed in the order the forward
+  // kernel keeps them in LDS - per layer gamma[K_j] | beta[K_j] | bias[M_j], then the scorer's weight row
+  // [K_last] - so a workgroup stages all of them with a handful of contiguous 16-byte loads
+  int64_t wt_pv_off;
+  int pv_off[ULTR_MAXL];  // offset of layer j's gamma inside the image
+  int pv_wlast;           // offset of the scorer's weight row
+  int pv_total;           // floats, padded to a multiple of 4
+  int64_t wt_total;       // weights + image
   int maxdim;             // max over all K_j (and M_j)
   // saved-for-backward workspace (floats): xs[j] = input of LayerNorm_j, j >= 1; stats for all j
   int64_t sv_x[ULTR_MAXL];     // [N, K_j]   (j >= 1)
@@ -29,6 +36,18 @@ struct DnnPlan {
   int64_t sv_rstd[ULTR_MAXL];  // [N]
   int64_t sv_total;
 };
+
+// position of parameter e inside the PV image (DnnPlan::pv_*), or -1 when e is a hidden Linear weight
+__host__ __device__ inline int ultr_pv_index(const DnnPlan& p, int64_t e) {
+  for (int j = 0; j < p.nl; ++j) {
+    const int K = p.K[j], M = p.M[j];
+    if (e >= p.off_lnw[j] && e < p.off_lnw[j] + 2 * (int64_t)K) return p.pv_off[j] + (int)(e - p.off_lnw[j]);  // gamma | beta
+    if (e >= p.off_b[j] && e < p.off_b[j] + M) return p.pv_off[j] + 2 * K + (int)(e - p.off_b[j]);
+  }
+  const int64_t w = p.off_w[p.nl - 1];
+  if (e >= w && e < w + p.K[p.nl - 1]) return p.pv_wlast + (int)(e - w);
+  return -1;
+}
 
 // One matrix-gradient segment (Linear_j, j < nl-1) for the wgrad kernel.
 struct WgradLayer {

@@ -86,7 +86,9 @@ __global__ __launch_bounds__(256) void update_kernel(ultr_update_desc u, DnnPlan
       params[e] = pn;
       if (state != nullptr && !stateless && u.optimizer != ULTR_OPT_SGD) state[e] = s_new;
       if (wt != nullptr) {
-        // keep the k-major copy of the hidden Linear weights current: WT_j[k, m] = W_j[m, k]
+        // keep the k-major copy of the hidden Linear weights current: WT_j[k, m] = W_j[m, k]; every other
+        // parameter goes to the packed vector-parameter image behind it (DnnPlan::wt_pv_off)
+        bool hidden_w = false;
         for (int j = 0; j < dp.nl - 1; ++j) {
           const int r = (int)(e - dp.off_w[j]);
           const int K = dp.K[j], M = dp.M[j];
@@ -96,8 +98,13 @@ __global__ __launch_bounds__(256) void update_kernel(ultr_update_desc u, DnnPlan
             if (k < 0) { --m; k += K; }
             if (k >= K) { ++m; k -= K; }
             wt[dp.wt_off[j] + (int64_t)k * M + m] = pn;
+            hidden_w = true;
             break;
           }
+        }
+        if (!hidden_w) {
+          const int pv = ultr_pv_index(dp, e);
+          if (pv >= 0) wt[dp.wt_pv_off + pv] = pn;
         }
       }
     }
