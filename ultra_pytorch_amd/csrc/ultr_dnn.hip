@@ -1102,6 +1102,394 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd_kernel(DnnPlan p, BwdPlan bp,
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward, row-local half - fast variant (aligned shapes, every K_j <= 256*XC, LDS budget permitting)
+// ------------------------------------------------------------------------------------------------
+// Same math and outputs as dnn_bwd_kernel; what changes is the schedule:
+//  * a wave OWNS rows wave, wave+NW, .. of the block for everything row-local (staging, LayerNorm backward), so the
+//    next layer's x tile / statistics / gamma, beta are PREFETCHED into registers right after the GEMM barrier and
+//    committed to LDS after the row pass - their latency hides behind the pass instead of heading the next phase;
+//  * the kernel's first loads (doc ids, fused-loss inputs, top layer's tile) are issued back to back before anything
+//    waits (the old prologue paid four dependent round trips);
+//  * the column sums (dgamma, dbeta, scorer dW) are accumulated inside the row pass - per-wave partials in LDS,
+//    folded in fixed wave order after the next barrier - instead of a separate pass that re-read XS and DU and
+//    recomputed xhat;
+//  * 16-byte LDS accesses, the wave's rows interleaved (one set of wave reductions for all of them);
+//  * the scorer layer needs no DU tile: du = ds * w is formed on the fly.
+// floats of column partials per wave: dgamma | dbeta (| scorer dW for the top layer), each round_up(K_j, 4) long
+__host__ __device__ static inline int bwd2_cp_stride(const DnnPlan& p) {
+  int cpw = 0;
+  for (int j = 0; j < p.nl; ++j) {
+    const int v = (j == p.nl - 1 ? 3 : 2) * round_up(p.K[j], 4);
+    cpw = v > cpw ? v : cpw;
+  }
+  return cpw;
+}
+__host__ __device__ static inline size_t bwd2_lds_floats(const DnnPlan& p, int R, int NW) {
+  const size_t ldu = bwd_ldu(p.maxdim), ldz = bwd_ldz(p.maxdim);
+  return (size_t)R * (2 * ldu + ldz) + 5 * ldu + (size_t)NW * bwd2_cp_stride(p) + 5 * (size_t)R + 2 * (size_t)NW + 8;
+}
+
+template <int R, int NW, int XC>
+__global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp, const float* __restrict__ params,
+                                                           const float* __restrict__ features, int64_t n_docs,
+                                                           const int32_t* __restrict__ docids, int B, int L,
+                                                           const float* __restrict__ saved,
+                                                           const float* __restrict__ dscores, float* __restrict__ ws,
+                                                           FusedSoftmax fl) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int RT = R / 16, NT = NW * 64, RPW = R / NW;
+  static_assert(R % NW == 0, "a wave owns whole rows");
+  const int64_t N = (int64_t)B * L;
+  const int ldz = bwd_ldz(p.maxdim), ldu = bwd_ldu(p.maxdim);
+  float* DU = smem;                    // [R][ldu]
+  float* XS = DU + R * ldu;            // [R][ldu]  input of LayerNorm_j (rows written and read by their owner wave only)
+  float* DZ = XS + R * ldu;            // [R][ldz]
+  float* sm_g2 = DZ + R * ldz;         // [2][ldu]  gamma_j, double-buffered by layer parity
+  float* sm_b2 = sm_g2 + 2 * ldu;      // [2][ldu]  beta_j
+  float* sm_wl = sm_b2 + 2 * ldu;      // [ldu]     the scorer's weight row
+  const int cpw = bwd2_cp_stride(p);
+  float* CP = sm_wl + ldu;             // [NW][cpw] per-wave column partials (dgamma | dbeta | scorer dW)
+  float* sm_ds = CP + NW * cpw;        // [R]
+  float* sm_mean2 = sm_ds + R;         // [2][R]
+  float* sm_rstd2 = sm_mean2 + 2 * R;  // [2][R]
+  float* sm_lt = sm_rstd2 + 2 * R;     // [NW][2] loss / normaliser partials of the fused loss
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t n0 = (int64_t)blockIdx.x * R;
+  float* vslab = ws + bp.vslab_off + (int64_t)blockIdx.x * bp.vlen;
+  const Src savedsrc = make_src(saved, p.sv_total);
+  const Src featsrc = make_src(features, n_docs * p.K[0]);
+  const Src parsrc = make_src(params, p.P);
+  const bool fused = fl.scores != nullptr;
+  const int top = p.nl - 1;
+
+  // ---- every first-round load of the kernel, back to back ------------------------------------------------------
+  const int64_t nme = n0 + wave + NW * (lane < RPW ? lane : 0);  // lane k < RPW speaks for the wave's k-th row
+  const bool rowok = lane < RPW && nme < N;
+  const uint32_t nme32 = rowok ? (uint32_t)nme : 0u;
+  const int id_raw = docids[(int64_t)(nme32 % (uint32_t)L) * B + (nme32 / (uint32_t)L)];
+  float ds_in = 0.f;
+  if (tid < R && !fused && n0 + tid < N) ds_in = dscores[n0 + tid];
+  // fused loss, first list of this wave (lists b_lo + wave + NW*i); one element per lane when L <= 64
+  const int64_t nlast = (n0 + R < N ? n0 + R : N) - 1;
+  const int b_lo = (int)(n0 / L), b_hi = (int)(nlast / L);
+  const bool l64 = L <= 64;
+  const int b0 = b_lo + wave;
+  const bool lact0 = fused && l64 && b0 <= b_hi && lane < L;
+  float sc0 = 0.f, y0 = 0.f, pw0 = 1.0f;
+  if (lact0) {
+    sc0 = fl.scores[(int64_t)b0 * L + lane];
+    y0 = fl.labels[(int64_t)lane * B + b0];
+    if (fl.pw != nullptr) pw0 = fl.pw[(int64_t)b0 * L + lane];
+    else if (fl.ipw != nullptr) pw0 = fl.ipw[lane < fl.n_ipw ? lane : fl.n_ipw - 1];
+  }
+  const int myid = (rowok && id_raw >= 0 && id_raw < n_docs) ? id_raw : -1;
+
+  struct Stage {
+    float4 x[RPW][XC];
+    float4 g, b;
+    float mean, rstd;
+  };
+  auto stage_issue = [&](int j, Stage& s) {
+    const int K = p.K[j];
+    const Src& xsrc = (j == 0) ? featsrc : savedsrc;
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+      const int64_t n = n0 + wave + NW * k;
+      const int id = __builtin_amdgcn_readlane(myid, k);
+      const bool ok = (j == 0) ? (id >= 0) : (n < N);
+      const int64_t base = (j == 0) ? (int64_t)id * K : (p.sv_x[j] + n * K);
+#pragma unroll
+      for (int u = 0; u < XC; ++u) {
+        const int c = 4 * lane + 256 * u;
+        s.x[k][u] = buf_ld4(xsrc, (ok && c < K) ? (unsigned)((base + c) * 4) : ULTR_OOB);
+      }
+    }
+    s.g = buf_ld4(parsrc, (4 * tid < K) ? (unsigned)((p.off_lnw[j] + 4 * tid) * 4) : ULTR_OOB);
+    s.b = buf_ld4(parsrc, (4 * tid < K) ? (unsigned)((p.off_lnb[j] + 4 * tid) * 4) : ULTR_OOB);
+    s.mean = buf_ld1(savedsrc, rowok ? (unsigned)((p.sv_mean[j] + nme) * 4) : ULTR_OOB);
+    s.rstd = buf_ld1(savedsrc, rowok ? (unsigned)((p.sv_rstd[j] + nme) * 4) : ULTR_OOB);
+  };
+  auto stage_commit = [&](int j, const Stage& s) {
+    const int K = p.K[j], par = j & 1;
+#pragma unroll
+    for (int k = 0; k < RPW; ++k)
+#pragma unroll
+      for (int u = 0; u < XC; ++u) {
+        const int c = 4 * lane + 256 * u;
+        if (c < K) st4(XS + (wave + NW * k) * ldu + c, s.x[k][u]);
+      }
+    if (4 * tid < K) {
+      st4(sm_g2 + par * ldu + 4 * tid, s.g);
+      st4(sm_b2 + par * ldu + 4 * tid, s.b);
+    }
+    if (lane < RPW) {
+      sm_mean2[par * R + wave + NW * lane] = s.mean;
+      sm_rstd2[par * R + wave + NW * lane] = s.rstd;
+    }
+  };
+
+  Stage st;
+  stage_issue(top, st);
+  const float4 wl4 = buf_ld4(parsrc, (4 * tid < p.K[top]) ? (unsigned)((p.off_w[top] + 4 * tid) * 4) : ULTR_OOB);
+
+  if (tid < R) sm_ds[tid] = ds_in;
+  if (lane < 2) sm_lt[wave * 2 + lane] = 0.f;
+  if (fused) {
+    // ---- fused listwise softmax cross entropy (NA / IPW): this row block touches at most R/L + 2 lists; a
+    // wavefront recomputes each of them.  A list's loss / normaliser partial is emitted by the block that owns the
+    // list's FIRST row, exactly once.
+    lds_barrier();  // sm_ds / sm_lt initialised
+    if (l64) {
+      for (int b = b0; b <= b_hi; b += NW) {
+        const bool act = lane < L;
+        float sc = sc0, y = y0, pwt = pw0;
+        if (b != b0 && act) {
+          sc = fl.scores[(int64_t)b * L + lane];
+          y = fl.labels[(int64_t)lane * B + b];
+          pwt = 1.0f;
+          if (fl.pw != nullptr) pwt = fl.pw[(int64_t)b * L + lane];
+          else if (fl.ipw != nullptr) pwt = fl.ipw[lane < fl.n_ipw ? lane : fl.n_ipw - 1];
+        }
+        if (fl.pw == nullptr && fl.ipw != nullptr && !(y > 0.f)) pwt = 0.f;
+        const float w = act ? (y + 0.0000001f) * pwt : 0.f;
+        const float mx = wave_max(act ? sc : -INFINITY);
+        const float S = wave_sum(w);
+        const float lse = mx + logf(wave_sum(act ? expf(sc - mx) : 0.f));
+        const float dsv = expf(sc - lse) * S - w;
+        const float lb = wave_sum(act ? w * (lse - sc) : 0.f);
+        const int64_t n = (int64_t)b * L + lane;
+        if (act && n >= n0 && n <= nlast) {
+          sm_ds[n - n0] = dsv;
+          if (fl.dscores_out != nullptr) fl.dscores_out[n] = dsv;
+        }
+        if (lane == 0 && (int64_t)b * L >= n0) {
+          sm_lt[wave * 2 + 0] += lb;
+          sm_lt[wave * 2 + 1] += S;
+        }
+      }
+    } else {
+      for (int b = b_lo + wave; b <= b_hi; b += NW) {
+        float mx = -INFINITY, S = 0.f;
+        for (int l = lane; l < L; l += 64) {
+          const float sc = fl.scores[(int64_t)b * L + l];
+          const float y = fl.labels[(int64_t)l * B + b];
+          float pwt = 1.0f;
+          if (fl.pw != nullptr) pwt = fl.pw[(int64_t)b * L + l];
+          else if (fl.ipw != nullptr) pwt = (y > 0.f) ? fl.ipw[l < fl.n_ipw ? l : fl.n_ipw - 1] : 0.f;
+          mx = fmaxf(mx, sc);
+          S += (y + 0.0000001f) * pwt;
+        }
+        mx = wave_max(mx);
+        S = wave_sum(S);
+        float se = 0.f;
+        for (int l = lane; l < L; l += 64) se += expf(fl.scores[(int64_t)b * L + l] - mx);
+        const float lse = mx + logf(wave_sum(se));
+        float lb = 0.f;
+        for (int l = lane; l < L; l += 64) {
+          const float sc = fl.scores[(int64_t)b * L + l];
+          const float y = fl.labels[(int64_t)l * B + b];
+          float pwt = 1.0f;
+          if (fl.pw != nullptr) pwt = fl.pw[(int64_t)b * L + l];
+          else if (fl.ipw != nullptr) pwt = (y > 0.f) ? fl.ipw[l < fl.n_ipw ? l : fl.n_ipw - 1] : 0.f;
+          const float w = (y + 0.0000001f) * pwt;
+          const float dsv = expf(sc - lse) * S - w;
+          lb += w * (lse - sc);
+          const int64_t n = (int64_t)b * L + l;
+          if (n >= n0 && n <= nlast) {
+            sm_ds[n - n0] = dsv;
+            if (fl.dscores_out != nullptr) fl.dscores_out[n] = dsv;
+          }
+        }
+        lb = wave_sum(lb);
+        if (lane == 0 && (int64_t)b * L >= n0) {
+          sm_lt[wave * 2 + 0] += lb;
+          sm_lt[wave * 2 + 1] += S;
+        }
+      }
+    }
+  }
+  stage_commit(top, st);
+  if (4 * tid < p.K[top]) st4(sm_wl + 4 * tid, wl4);
+  lds_barrier();
+  if (fused) {
+    const int tail = (int)ultr_tail_len(L);
+    for (int t = tid; t < tail; t += NT) {
+      float v = 0.f;
+      if (t < 2)
+        for (int w = 0; w < NW; ++w) v += sm_lt[w * 2 + t];
+      fl.loss_part[(int64_t)blockIdx.x * tail + t] = v;
+    }
+  }
+  TRACE_STAMP(16);
+
+  // column sums of layer jj: fold the per-wave partials in wave order
+  auto finalize = [&](int jj) {
+    const int K = p.K[jj], K4 = round_up(K, 4);
+    const bool lastl = (jj == top);
+    for (int c = tid; c < K; c += NT) {
+      float pg = 0.f, pb = 0.f, pw = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        pg += CP[w * cpw + c];
+        pb += CP[w * cpw + K4 + c];
+        if (lastl) pw += CP[w * cpw + 2 * K4 + c];
+      }
+      vslab[bp.voff_g[jj] + c] = pg;
+      vslab[bp.voff_b[jj] + c] = pb;
+      if (lastl) vslab[bp.voff_wk + c] = pw;
+    }
+    if (lastl && tid == 0) {
+      float sds = 0.f;
+      for (int r = 0; r < R; ++r) sds += sm_ds[r];
+      vslab[bp.voff_bk] = sds;
+    }
+  };
+
+  for (int j = top; j >= 0; --j) {
+    const int K = p.K[j], M = p.M[j];
+    const bool last = (j == top);
+    const int par = j & 1;
+    if (!last) {
+      finalize(j + 1);
+      // ---- du_j = dz_j . W_j  (32-column chunks when every wave gets one; else 64-column chunks x slices of the
+      // contraction, summed into DU in fixed order)
+      const Src Wsrc = make_src(params + p.off_w[j], (int64_t)M * K);
+      const int nch = (K + 63) >> 6;
+      int msplit = 1;
+      while (msplit * 2 * nch <= NW) msplit *= 2;
+      if (msplit > 1 && ((K + 31) >> 5) >= NW) {
+        for (int ch = wave; ch * 32 < K; ch += NW) {
+          f32x4 acc[RT][2];
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          gemm_nn<RT, 2, true>(DZ, ldz, Wsrc, K, 0, M, ch * 32, acc, lane);
+          store_nn<RT, 2>(acc, DU, ldu, K, ch * 32, lane, false);
+        }
+      } else if (msplit == 1) {
+        for (int ch = wave; ch < nch; ch += NW) {
+          f32x4 acc[RT][4];
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          gemm_nn<RT, 4, true>(DZ, ldz, Wsrc, K, 0, M, ch * 64, acc, lane);
+          store_nn<RT, 4>(acc, DU, ldu, K, ch * 64, lane, false);
+        }
+      } else {
+        const int mlen = round_up((M + msplit - 1) / msplit, 32);
+        const bool has = wave < nch * msplit;
+        const int ch = wave % nch, ms = wave / nch;
+        f32x4 acc[RT][4];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (has) {
+          const int mb = ms * mlen;
+          const int me = (mb + mlen < M) ? (mb + mlen) : M;
+          if (mb < me) gemm_nn<RT, 4, true>(DZ, ldz, Wsrc, K, mb, me, ch * 64, acc, lane);
+        }
+        for (int r = 0; r < msplit; ++r) {
+          if (has && ms == r) store_nn<RT, 4>(acc, DU, ldu, K, ch * 64, lane, r > 0);
+          if (r + 1 < msplit) lds_barrier();
+        }
+      }
+      TRACE_STAMP(17 + 4 * (top - j));
+      lds_barrier();
+    }
+    TRACE_STAMP(18 + 4 * (top - j));
+    if (j > 0) stage_issue(j - 1, st);
+    // ---- row pass: LayerNorm backward + activation' -> dz_{j-1}; column partials on the side ------------------
+    {
+      const float* gs = sm_g2 + par * ldu;
+      const float* bs = sm_b2 + par * ldu;
+      float mean[RPW], rstd[RPW], dsr[RPW];
+#pragma unroll
+      for (int k = 0; k < RPW; ++k) {
+        const int r = wave + NW * k;
+        mean[k] = sm_mean2[par * R + r];
+        rstd[k] = sm_rstd2[par * R + r];
+        dsr[k] = sm_ds[r];
+      }
+      float4 xk[RPW][XC], gxk[RPW][XC];
+      float red[2 * RPW];
+#pragma unroll
+      for (int k = 0; k < 2 * RPW; ++k) red[k] = 0.f;
+#pragma unroll
+      for (int u = 0; u < XC; ++u) {
+        const int c = 4 * lane + 256 * u;
+        const bool act = c < K;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 g4 = act ? ld4(gs + c) : z4;
+        const float4 be4 = (act && last) ? ld4(bs + c) : z4;
+        const float4 w4 = (act && last) ? ld4(sm_wl + c) : z4;
+        float4 pg = z4, pb = z4, pw = z4;
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+          const int r = wave + NW * k;
+          const float4 x4 = act ? ld4(XS + r * ldu + c) : z4;
+          float4 du4;
+          if (last) du4 = make_float4(dsr[k] * w4.x, dsr[k] * w4.y, dsr[k] * w4.z, dsr[k] * w4.w);
+          else du4 = act ? ld4(DU + r * ldu + c) : z4;
+          const float4 xh = make_float4((x4.x - mean[k]) * rstd[k], (x4.y - mean[k]) * rstd[k],
+                                        (x4.z - mean[k]) * rstd[k], (x4.w - mean[k]) * rstd[k]);
+          const float4 gx = make_float4(du4.x * g4.x, du4.y * g4.y, du4.z * g4.z, du4.w * g4.w);
+          red[k] += (gx.x + gx.y) + (gx.z + gx.w);
+          red[RPW + k] += (gx.x * xh.x + gx.y * xh.y) + (gx.z * xh.z + gx.w * xh.w);
+          if (act) {  // padded lanes would add (0 - mean) * rstd garbage
+            pg.x += du4.x * xh.x; pg.y += du4.y * xh.y; pg.z += du4.z * xh.z; pg.w += du4.w * xh.w;
+            pb.x += du4.x; pb.y += du4.y; pb.z += du4.z; pb.w += du4.w;
+            if (last) {
+              pw.x += dsr[k] * (g4.x * xh.x + be4.x); pw.y += dsr[k] * (g4.y * xh.y + be4.y);
+              pw.z += dsr[k] * (g4.z * xh.z + be4.z); pw.w += dsr[k] * (g4.w * xh.w + be4.w);
+            }
+          }
+          xk[k][u] = x4;
+          gxk[k][u] = gx;
+        }
+        if (act) {
+          const int K4 = round_up(K, 4);
+          st4(CP + wave * cpw + c, pg);
+          st4(CP + wave * cpw + K4 + c, pb);
+          if (last) st4(CP + wave * cpw + 2 * K4 + c, pw);
+        }
+      }
+      if (j > 0) {
+        wave_sum_n<2 * RPW>(red);
+        float* dzg = ws + bp.dz_off[j - 1];
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+          const int r = wave + NW * k;
+          const int64_t n = n0 + r;
+          const float s1 = red[k] / (float)K, s2 = red[RPW + k] / (float)K;
+#pragma unroll
+          for (int u = 0; u < XC; ++u) {
+            const int c = 4 * lane + 256 * u;
+            if (c < K) {
+              const float4 x4 = xk[k][u], gx = gxk[k][u];
+              float4 dz;
+              dz.x = rstd[k] * (gx.x - s1 - (x4.x - mean[k]) * rstd[k] * s2) * act_grad_from_out(x4.x, p.act);
+              dz.y = rstd[k] * (gx.y - s1 - (x4.y - mean[k]) * rstd[k] * s2) * act_grad_from_out(x4.y, p.act);
+              dz.z = rstd[k] * (gx.z - s1 - (x4.z - mean[k]) * rstd[k] * s2) * act_grad_from_out(x4.z, p.act);
+              dz.w = rstd[k] * (gx.w - s1 - (x4.w - mean[k]) * rstd[k] * s2) * act_grad_from_out(x4.w, p.act);
+              st4(DZ + r * ldz + c, dz);
+              if (n < N) st4(dzg + n * K + c, dz);
+            }
+          }
+          for (int c = K + lane; c < round_up(K, 32); c += 64) DZ[r * ldz + c] = 0.f;  // zero pad (gemm_nn reads it)
+        }
+      }
+    }
+    TRACE_STAMP(19 + 4 * (top - j));
+    if (j > 0) stage_commit(j - 1, st);
+    lds_barrier();
+  }
+  finalize(0);
+}
+
 // One workgroup = 64 consecutive gradient elements x 4 slab groups: group g adds slabs g, g+4, ... with eight
 // independent loads in flight, then the four group sums are combined in fixed order through LDS.  (A serial
 // loop over 160 slabs per thread was latency-bound at ~120 us.)
@@ -1711,7 +2099,25 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
     if (av) LAUNCH_BWD(RR, NWW, true); \
     else LAUNCH_BWD(RR, NWW, false);   \
   } while (0)
-  {
+  // fast variant: aligned shapes, K_j <= 512, 8 waves, LDS budget (see dnn_bwd2_kernel)
+  const size_t lds2 = bwd2_lds_floats(p, bp.rblk, 8) * sizeof(float);
+  const bool v2 = av && nw == 8 && p.maxdim <= 512 && lds2 <= 160 * 1024 && p.sv_total * 4 < ((int64_t)1 << 31) &&
+                  p.P * 4 < ((int64_t)1 << 31) && env_int("ULTR_BWD_V1", 0) == 0;
+#define LAUNCH_BWDV2(RR, XX)                                                                                           \
+  do {                                                                                                                 \
+    e = set_lds(dnn_bwd2_kernel<RR, 8, XX>, lds2);                                                                     \
+    if (e != hipSuccess) return (int)e;                                                                                \
+    hipLaunchKernelGGL((dnn_bwd2_kernel<RR, 8, XX>), dim3(bp.nrb), dim3(512), lds2, st, p, bp, params, features,       \
+                       n_docs, docids, (int)batch, (int)list_size, (const float*)saved, dscores, ws, fl);              \
+  } while (0)
+  if (v2) {
+    UltrProfScope prof(ULTR_K_BWD, st);
+    const int xc = p.maxdim <= 256 ? 1 : 2;
+    if (bp.rblk == 16 && xc == 1) LAUNCH_BWDV2(16, 1);
+    else if (bp.rblk == 16) LAUNCH_BWDV2(16, 2);
+    else if (xc == 1) LAUNCH_BWDV2(32, 1);
+    else LAUNCH_BWDV2(32, 2);
+  } else {
     UltrProfScope prof(ULTR_K_BWD, st);
     if (bp.rblk == 16 && nw == 4) LAUNCH_BWD2(16, 4);
     else if (bp.rblk == 16 && nw == 16) LAUNCH_BWD2(16, 16);
@@ -1720,6 +2126,7 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
     else LAUNCH_BWD2(32, 8);
   }
 #undef LAUNCH_BWD2
+#undef LAUNCH_BWDV2
 #undef LAUNCH_BWD
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
