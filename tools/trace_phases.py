@@ -35,15 +35,15 @@ for blk in range(5):
 for blk in range(3):
     t = a[blk].astype(np.int64)
     print("fwd LN1 detail wg %3d: postGEMMbarrier->LNstart=%d loads+mean=%d var=%d write=%d ->barrier=%d" % (blk * 32, t[28] - t[4], t[29] - t[28], t[30] - t[29], t[31] - t[30], t[5] - t[31]))
-bn = ["top", "GEMM/du", "sync", "colpass", "rowpass(next top)"]
+# fast backward kernel (dnn_bwd2_kernel): 15 start, 14 softmax done, 16 prologue done; per layer jj = top - j:
+# 17+4jj GEMM done, 18+4jj barrier passed (18 for the top layer = right after 16), 19+4jj row pass done
 for blk in range(3):
     t = a[blk].astype(np.int64)
-    out = []
-    for jj in range(3):
-        base = 16 + 4 * jj
-        out.append("L%d: gemm=%d sync=%d col=%d row+sync=%d" % (2 - jj, t[base + 1] - t[base], t[base + 2] - t[base + 1], t[base + 3] - t[base + 2], (t[base + 4] - t[base + 3]) if jj < 2 else 0))
-    print("bwd wg %3d:" % (blk * 32), " | ".join(out), " total", t[16 + 11] - t[16])
-
+    out = ["loads+softmax=%d commit+sync=%d" % (t[14] - t[15], t[16] - t[14])]
+    out.append("L2: rowcol=%d commit+sync+finalize+gemm=%d" % (t[19] - t[18], t[21] - t[19]))
+    out.append("L1: sync=%d rowcol=%d | next gemm(incl commit,sync,finalize)=%d" % (t[22] - t[21], t[23] - t[22], t[25] - t[23]))
+    out.append("L0: sync=%d rowcol=%d" % (t[26] - t[25], t[27] - t[26]))
+    print("bwd2 wg %3d:" % (blk * 32), " | ".join(out), " total(15->27)", t[27] - t[15])
 for blk in range(0, 13, 3):
     t = a[blk].astype(np.int64)
     print("wgrad wg %3d: ids+sync=%d mainloop=%d ldswrite+sync=%d reduce+store=%d total=%d" % (blk * 32, t[9] - t[8], t[10] - t[9], t[11] - t[10], t[12] - t[11], t[12] - t[8]))

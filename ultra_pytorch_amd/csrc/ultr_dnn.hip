@@ -508,7 +508,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
   float* X = smem;
   float* Y = smem + R * ld;
   float* PV = smem + 2 * R * ld;  // every vector parameter of the model, staged once (see below)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave: SGPR
   const int64_t n0 = (int64_t)blockIdx.x * R;
   const int rows_valid = (int)((N - n0) < R ? (N - n0) : R);
   TRACE_STAMP(0);
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
     // ---- plan of this layer's GEMM -----------------------------------------------------------------------
     // 32-column chunks.  Enough chunks for every wave: a wave takes chunks wave, wave + NW, .. over the whole
     // contraction.  Fewer: chunks x ksplit slices of the contraction, partial tiles summed in fixed order.
-    int ksplit = 1, kb = 0, ke = K, c0 = wave * 32;
+    int ksplit = 1, kb = 0, ke = K, c0 = wave * 32, kslice = 0;
     bool has = false;
     const int nch = (M + 31) >> 5;
     Src Wt = make_src(wt, 0);
@@ -611,11 +611,20 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
     if constexpr (VEC) {
       if (j < p.nl - 1) {
         Wt = make_src(wt + p.wt_off[j], (int64_t)K * M);
-        while (ksplit * 2 * nch <= NW) ksplit *= 2;
+        int klen = K;
+        if constexpr (NW == 8) {
+          ksplit = p.fwd_ksplit[j];
+          klen = p.fwd_klen[j];
+        } else {
+          while (ksplit * 2 * nch <= NW) ksplit *= 2;
+          klen = round_up((K + ksplit - 1) / ksplit, 32);
+        }
         if (ksplit > 1) {
-          const int klen = round_up((K + ksplit - 1) / ksplit, 32);
-          c0 = (wave % nch) * 32;
-          kb = (wave / nch) * klen;
+          int wq = 0, wr = wave;  // wave / nch, wave % nch on scalars
+          while (wr >= nch) { wr -= nch; ++wq; }
+          c0 = wr * 32;
+          kslice = wq;
+          kb = wq * klen;
           ke = (kb + klen < K) ? (kb + klen) : K;
           has = wave < nch * ksplit && kb < ke;
         } else {
@@ -753,7 +762,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
           if (has) pipe.run(X, ld, Wt, kb, ke, 0, acc, lane);
           // raw partial tiles are summed into Y slice by slice (fixed order), then ALL threads apply bias +
           // activation (the expm1f-heavy epilogue would otherwise run on the last slice's waves only)
-          const int ks = wave / nch;
+          const int ks = kslice;
           for (int r = 0; r < ksplit; ++r) {
             if (wave < nch * ksplit && ks == r) store_nn<RT, 2>(acc, Y, ld, M, c0, lane, r > 0);
             lds_barrier();
@@ -848,7 +857,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd_kernel(DnnPlan p, BwdPlan bp,
   float* sm_mean2 = sm_ds + R;         // [2][R]  double-buffered by layer parity (no extra barrier)
   float* sm_rstd2 = sm_mean2 + 2 * R;  // [2][R]
   int64_t* sm_id = reinterpret_cast<int64_t*>(sm_rstd2 + 2 * R);  // [R] feature row id or -1
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave: SGPR
   const int64_t n0 = (int64_t)blockIdx.x * R;
   float* vslab = ws + bp.vslab_off + (int64_t)blockIdx.x * bp.vlen;
 
@@ -1154,7 +1163,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
   float* sm_mean2 = sm_ds + R;         // [2][R]
   float* sm_rstd2 = sm_mean2 + 2 * R;  // [2][R]
   float* sm_lt = sm_rstd2 + 2 * R;     // [NW][2] loss / normaliser partials of the fused loss
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave: SGPR
   const int64_t n0 = (int64_t)blockIdx.x * R;
   float* vslab = ws + bp.vslab_off + (int64_t)blockIdx.x * bp.vlen;
   const Src savedsrc = make_src(saved, p.sv_total);
@@ -1162,6 +1171,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
   const Src parsrc = make_src(params, p.P);
   const bool fused = fl.scores != nullptr;
   const int top = p.nl - 1;
+  TRACE_STAMP(15);
 
   // ---- every first-round load of the kernel, back to back ------------------------------------------------------
   const int64_t nme = n0 + wave + NW * (lane < RPW ? lane : 0);  // lane k < RPW speaks for the wave's k-th row
@@ -1309,6 +1319,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
       }
     }
   }
+  TRACE_STAMP(14);
   stage_commit(top, st);
   if (4 * tid < p.K[top]) st4(sm_wl + 4 * tid, wl4);
   lds_barrier();
@@ -1355,10 +1366,9 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
       // ---- du_j = dz_j . W_j  (32-column chunks when every wave gets one; else 64-column chunks x slices of the
       // contraction, summed into DU in fixed order)
       const Src Wsrc = make_src(params + p.off_w[j], (int64_t)M * K);
-      const int nch = (K + 63) >> 6;
-      int msplit = 1;
-      while (msplit * 2 * nch <= NW) msplit *= 2;
-      if (msplit > 1 && ((K + 31) >> 5) >= NW) {
+      static_assert(NW == 8, "the precomputed split is for 8 waves");
+      const int nch = p.bwd_nch[j], msplit = p.bwd_msplit[j], mode = p.bwd_mode[j];
+      if (mode == 1) {
         for (int ch = wave; ch * 32 < K; ch += NW) {
           f32x4 acc[RT][2];
 #pragma unroll
@@ -1368,7 +1378,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
           gemm_nn<RT, 2, true>(DZ, ldz, Wsrc, K, 0, M, ch * 32, acc, lane);
           store_nn<RT, 2>(acc, DU, ldu, K, ch * 32, lane, false);
         }
-      } else if (msplit == 1) {
+      } else if (mode == 2) {
         for (int ch = wave; ch < nch; ch += NW) {
           f32x4 acc[RT][4];
 #pragma unroll
@@ -1379,9 +1389,10 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
           store_nn<RT, 4>(acc, DU, ldu, K, ch * 64, lane, false);
         }
       } else {
-        const int mlen = round_up((M + msplit - 1) / msplit, 32);
+        const int mlen = p.bwd_mlen[j];
         const bool has = wave < nch * msplit;
-        const int ch = wave % nch, ms = wave / nch;
+        int ms = 0, ch = wave;  // wave / nch, wave % nch on scalars
+        while (ch >= nch) { ch -= nch; ++ms; }
         f32x4 acc[RT][4];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -1515,6 +1526,9 @@ __device__ __forceinline__ float strided_sum(const float* __restrict__ src, int6
 // split, then the four 64x64 partials are summed through LDS in fixed order and written to the split's slab.
 // Per step a lane issues two 16-byte loads (dz row piece along m, x row piece along k) feeding 16 MFMAs:
 // A[i][kk] = dz[n+kk][m0+4i+ta], B[kk][j] = u[n+kk][k0+4j+tb]  ->  D_{ta,tb}[i][j] = dW[m0+4i+ta][k0+4j+tb].
+#ifndef WG_D
+#define WG_D 2  // register sets of the wgrad operand ring (3 was measured no faster)
+#endif
 template <bool VEC>
 __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, const float* __restrict__ params,
                                                         const float* __restrict__ features, int64_t n_docs,
@@ -1549,7 +1563,7 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
   const int mb = tile / wl.nkb, kb = tile % wl.nkb;
   const int M = wl.M, K = wl.K;
   const int m0 = mb * 64, k0 = kb * 64;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave: SGPR
   const int i = lane & 15, q = lane >> 4;
   const bool vec = wl.vec != 0;
   const int rpw = wl.rows_per_split / 4;
@@ -1633,9 +1647,11 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
   };
   constexpr int SPT = 2;  // steps per trip: 8 rows, 32 MFMAs (4 was measured no faster)
   int64_t nn = nbeg;
+  // consume `cu` (trip t) while the operands of trip t + WG_D - 1 go in flight into `nx`
   auto trip = [&](StepRegs(&cu)[SPT], StepRegs(&nx)[SPT]) {
 #pragma unroll
-    for (int u = 0; u < SPT; ++u) load_step(nn + 4 * SPT + 4 * u + q, nx[u].a, nx[u].x, nx[u].mean, nx[u].rstd);
+    for (int u = 0; u < SPT; ++u)
+      load_step(nn + 4 * SPT * (WG_D - 1) + 4 * u + q, nx[u].a, nx[u].x, nx[u].mean, nx[u].rstd);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < SPT; ++u) {
@@ -1658,16 +1674,32 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
     }
     nn += 4 * SPT;
   };
+  const int ntrip = (int)((nend - nbeg + 4 * SPT - 1) / (4 * SPT));
   StepRegs ra[SPT], rb[SPT];
 #pragma unroll
   for (int u = 0; u < SPT; ++u) load_step(nbeg + 4 * u + q, ra[u].a, ra[u].x, ra[u].mean, ra[u].rstd);
-  const int ntrip = (int)((nend - nbeg + 4 * SPT - 1) / (4 * SPT));
-  int t = 0;
-  for (; t + 1 < ntrip; t += 2) {
-    trip(ra, rb);
-    trip(rb, ra);
+  if constexpr (WG_D == 2) {
+    int t = 0;
+    for (; t + 1 < ntrip; t += 2) {
+      trip(ra, rb);
+      trip(rb, ra);
+    }
+    if (t < ntrip) trip(ra, rb);
+  } else {
+    // three register sets: operands are requested two trips (64 MFMAs per wave) before they are consumed - the
+    // dz / x rows were written by the previous launches, mostly on other XCDs, and come from beyond the local L2
+    StepRegs rc[SPT];
+#pragma unroll
+    for (int u = 0; u < SPT; ++u) load_step(nbeg + 4 * SPT + 4 * u + q, rb[u].a, rb[u].x, rb[u].mean, rb[u].rstd);
+    int t = 0;
+    for (; t + 2 < ntrip; t += 3) {
+      trip(ra, rc);
+      trip(rb, ra);
+      trip(rc, rb);
+    }
+    if (t < ntrip) trip(ra, rc);
+    if (t + 1 < ntrip) trip(rb, ra);
   }
-  if (t < ntrip) trip(ra, rb);
   };  // mainloop
   // the layer-0 variant (doc ids -> feature rows through LDS) and the plain variant are separate straight-line
   // loops: a branch on j inside the loop would put the loads in control flow and drain vmcnt(0) every step
@@ -1810,6 +1842,27 @@ bool ultr_make_dnn_plan(const ultr_dnn_desc* d, int64_t N, DnnPlan* p) {
     k = m;
   }
   p->P = off;
+  const int NWP = 8;  // waves of the fast kernels
+  for (int j = 0; j < p->nl - 1; ++j) {
+    const int K = p->K[j], M = p->M[j];
+    {
+      const int nch = (M + 31) >> 5;
+      int ks = 1;
+      while (ks * 2 * nch <= NWP) ks *= 2;
+      p->fwd_nch[j] = nch;
+      p->fwd_ksplit[j] = ks;
+      p->fwd_klen[j] = (ks > 1) ? round_up((K + ks - 1) / ks, 32) : K;
+    }
+    {
+      const int nch = (K + 63) >> 6;
+      int ms = 1;
+      while (ms * 2 * nch <= NWP) ms *= 2;
+      p->bwd_nch[j] = nch;
+      p->bwd_msplit[j] = ms;
+      p->bwd_mlen[j] = round_up((M + ms - 1) / ms, 32);
+      p->bwd_mode[j] = (ms > 1 && ((K + 31) >> 5) >= NWP) ? 1 : (ms == 1 ? 2 : 3);
+    }
+  }
   int64_t wt = 0;
   for (int j = 0; j < p->nl - 1; ++j) {
     p->wt_off[j] = wt;

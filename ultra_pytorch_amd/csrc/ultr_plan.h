@@ -30,6 +30,12 @@ struct DnnPlan {
   int pv_total;           // floats, padded to a multiple of 4
   int64_t wt_total;       // weights + image
   int maxdim;             // max over all K_j (and M_j)
+  // GEMM work split of the fast kernels (8 waves), precomputed: integer divisions in the kernel cost ~1k cycles per
+  // layer.  Forward Y_j = X.W_j^T: 32-column chunks of M_j; fwd_ksplit > 1 = chunks x slices of the contraction.
+  // Backward du_j = dz_j.W_j: bwd_mode 1 = 32-column chunks of K_j, 2 = 64-column chunks, 3 = 64-column chunks x
+  // bwd_msplit slices of the contraction M_j (slice length bwd_mlen).
+  int fwd_ksplit[ULTR_MAXL], fwd_klen[ULTR_MAXL], fwd_nch[ULTR_MAXL];
+  int bwd_mode[ULTR_MAXL], bwd_msplit[ULTR_MAXL], bwd_mlen[ULTR_MAXL], bwd_nch[ULTR_MAXL];
   // saved-for-backward workspace (floats): xs[j] = input of LayerNorm_j, j >= 1; stats for all j
   int64_t sv_x[ULTR_MAXL];     // [N, K_j]   (j >= 1)
   int64_t sv_mean[ULTR_MAXL];  // [N]
