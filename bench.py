@@ -174,7 +174,11 @@ def main():
     cal_us = [1e3 * tot[k] / max(cnt[k], 1) for k in range(6)]
     dom = int(np.argmax(cal_us))
     # ---- the timed region: EXACTLY K steps, dominant kernel event-timed inside it -------------------
-    _lib.check(lib.ultr_prof_enable(1 << dom, args.steps + 8), "ultr_prof_enable")
+    # every kernel of the step is timed inside the timed region on every 8th step, by the start/stop timestamps of its
+    # own dispatch packet (what rocprofv3 --kernel-trace reports; timing ONE kernel only would add the wait for its
+    # predecessor's tail to its start stamp)
+    _lib.check(lib.ultr_prof_set_stride(8), "ultr_prof_set_stride")
+    _lib.check(lib.ultr_prof_enable(0x3F, 6 * (args.steps // 8 + 2)), "ultr_prof_enable")
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -184,6 +188,9 @@ def main():
     _lib.check(lib.ultr_prof_collect(tot, cnt), "ultr_prof_collect")
     lib.ultr_prof_enable(0, 0)
     dom_s = 1e-3 * tot[dom] / max(cnt[dom], 1)
+    dom_samples = int(cnt[dom])
+    timed_us = [1e3 * tot[k] / max(cnt[k], 1) for k in range(6)]
+    lib.ultr_prof_set_stride(1)
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=device)
     if pg is not None:
         torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
@@ -256,8 +263,9 @@ def main():
                        "parallelism": "dp%d" % world, "params": P},
             "roofline": {"kernel": KNAMES[dom], "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": traffic, "avg_launch_us": 1e6 * dom_s,
+                         "launches_timed": dom_samples,
                          "algorithmic_per_launch": amount},
-            "kernel_us": {KNAMES[k]: round(cal_us[k], 3) for k in range(6)},
+            "kernel_us": {KNAMES[k]: round(timed_us[k], 3) for k in range(6)},
             "final_loss": final_loss,
         }
         if synced is not None:

@@ -244,11 +244,14 @@ int ultr_click_batch(const int32_t* lists, const float* labels, int64_t n_querie
                      int32_t* query_idx, void* stream);
 
 /* ---- measurement hooks (bench.py only; not part of the reference's interface) ----------
- * Per-kernel HIP-event timers on the launch stream.  kernel ids: 0 forward, 1 loss, 2 backward
- * (dgrad chain), 3 weight gradients, 4 gradient reduction, 5 update.  enable(mask, n) arms up
- * to n samples for the kernels in mask (0 disarms); collect() synchronises the recorded events,
- * returns per-kernel total milliseconds and launch counts in arrays of 8, and rearms. */
+ * Per-kernel timers: an armed kernel is launched with a start and a stop event taken from its OWN dispatch
+ * packet (hipExtLaunchKernelGGL), i.e. the duration rocprofv3 --kernel-trace reports, without marker packets
+ * on the stream.  kernel ids: 0 forward, 1 loss, 2 backward (dgrad chain), 3 weight gradients, 4 gradient
+ * reduction, 5 update.  enable(mask, n) arms up to n samples for the kernels in mask (0 disarms);
+ * set_stride(k) times only every k-th launch of an armed kernel; collect() synchronises the recorded events,
+ * returns per-kernel total milliseconds and sample counts in arrays of 8, and rearms. */
 int ultr_prof_enable(uint32_t kernel_mask, int32_t max_samples);
+int ultr_prof_set_stride(int32_t every_nth_launch);
 int ultr_prof_collect(double* total_ms, int64_t* counts);
 
 #ifdef __cplusplus

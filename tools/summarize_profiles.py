@@ -11,9 +11,13 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 OURS = ["dnn_fwd_kernel", "softmax_ce_kernel", "dnn_bwd_kernel", "dnn_wgrad_kernel", "grad_reduce_kernel",
         "update_kernel", "grad_sumsq_kernel", "click_batch_kernel"]
+ALIAS = {"dnn_bwd2_kernel": "dnn_bwd_kernel"}  # the fast row-local backward kernel reports under bench.py's slot name
 
 
 def short(name):
+    for k, v in ALIAS.items():
+        if k in name:
+            return v
     for k in OURS:
         if k in name:
             return k

@@ -63,6 +63,7 @@ SIGNATURES = {
     "ultr_click_batch": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_i32, ctypes.c_uint64, ctypes.c_uint64,
                                  c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "ultr_prof_enable": (c_i32, [ctypes.c_uint32, c_i32]),
+    "ultr_prof_set_stride": (c_i32, [c_i32]),
     "ultr_prof_collect": (c_i32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
     "ultr_ndcg": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, ctypes.POINTER(c_i32), c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
 }

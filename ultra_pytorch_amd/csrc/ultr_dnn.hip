@@ -2102,7 +2102,7 @@ extern "C" int ultr_dnn_forward(const ultr_dnn_desc* d, const float* params, con
   do {                                                                                                              \
     e = set_lds(dnn_fwd_kernel<RR, NWW, VV>, lds);                                                                  \
     if (e != hipSuccess) return (int)e;                                                                             \
-    hipLaunchKernelGGL((dnn_fwd_kernel<RR, NWW, VV>), grid, dim3(NWW * 64), lds, st, p, params, features, n_docs,   \
+    ULTR_LAUNCH(prof, (dnn_fwd_kernel<RR, NWW, VV>), grid, dim3(NWW * 64), lds, st, p, params, features, n_docs,    \
                        docids, (int)batch, (int)list_size, scores, (float*)saved, wt, vm);                         \
   } while (0)
 #define LAUNCH_FWD2(RR, NWW) \
@@ -2144,7 +2144,7 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
   do {                                                                                                                 \
     e = set_lds(dnn_bwd_kernel<RR, NWW, VV>, lds);                                                                     \
     if (e != hipSuccess) return (int)e;                                                                                \
-    hipLaunchKernelGGL((dnn_bwd_kernel<RR, NWW, VV>), dim3(bp.nrb), dim3(NWW * 64), lds, st, p, bp, params, features,  \
+    ULTR_LAUNCH(prof, (dnn_bwd_kernel<RR, NWW, VV>), dim3(bp.nrb), dim3(NWW * 64), lds, st, p, bp, params, features,   \
                        n_docs, docids, (int)batch, (int)list_size, (const float*)saved, dscores, ws, vm, fl);         \
   } while (0)
 #define LAUNCH_BWD2(RR, NWW) \
@@ -2160,7 +2160,7 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
   do {                                                                                                                 \
     e = set_lds(dnn_bwd2_kernel<RR, 8, XX>, lds2);                                                                     \
     if (e != hipSuccess) return (int)e;                                                                                \
-    hipLaunchKernelGGL((dnn_bwd2_kernel<RR, 8, XX>), dim3(bp.nrb), dim3(512), lds2, st, p, bp, params, features,       \
+    ULTR_LAUNCH(prof, (dnn_bwd2_kernel<RR, 8, XX>), dim3(bp.nrb), dim3(512), lds2, st, p, bp, params, features,        \
                        n_docs, docids, (int)batch, (int)list_size, (const float*)saved, dscores, ws, fl);              \
   } while (0)
   if (v2) {
@@ -2191,10 +2191,10 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
     e = av ? set_lds(dnn_wgrad_kernel<true>, wlds) : set_lds(dnn_wgrad_kernel<false>, wlds);
     if (e != hipSuccess) return (int)e;
     if (av)
-      hipLaunchKernelGGL(dnn_wgrad_kernel<true>, dim3(bp.wgrad_blocks + bp.vred_blocks), dim3(256), wlds, st, p, bp, params, features, n_docs,
+      ULTR_LAUNCH(prof, dnn_wgrad_kernel<true>, dim3(bp.wgrad_blocks + bp.vred_blocks), dim3(256), wlds, st, p, bp, params, features, n_docs,
                          docids, (int)batch, (int)list_size, (const float*)saved, ws, (vm >> 31) & 1);
     else
-      hipLaunchKernelGGL(dnn_wgrad_kernel<false>, dim3(bp.wgrad_blocks + bp.vred_blocks), dim3(256), wlds, st, p, bp, params, features, n_docs,
+      ULTR_LAUNCH(prof, dnn_wgrad_kernel<false>, dim3(bp.wgrad_blocks + bp.vred_blocks), dim3(256), wlds, st, p, bp, params, features, n_docs,
                          docids, (int)batch, (int)list_size, (const float*)saved, ws, (vm >> 31) & 1);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
@@ -2204,7 +2204,7 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
   const int nblk = (int)ultr_red_blocks(p.P, tail);
   const float* lp = (const float*)loss_ws;
   UltrProfScope prof(ULTR_K_REDUCE, st);
-  hipLaunchKernelGGL(grad_reduce_kernel, dim3(nblk), dim3(256), 0, st, rp, p.P, tail, (const float*)ws, lp,
+  ULTR_LAUNCH(prof, grad_reduce_kernel, dim3(nblk), dim3(256), 0, st, rp, p.P, tail, (const float*)ws, lp,
                      fl.scores ? bp.nrb : (int)ultr_loss_parts(batch), grads, ws + bp.sumsq_off);
   return (int)hipGetLastError();
 }

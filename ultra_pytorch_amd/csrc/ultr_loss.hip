@@ -104,7 +104,7 @@ extern "C" int ultr_softmax_ce(const float* scores, const float* labels, const f
   const size_t lds = (size_t)LPW * (tail + 2 * list_size) * sizeof(float);
   if (lds > 64 * 1024) return ULTR_E_UNSUPPORTED;
   UltrProfScope prof(ULTR_K_LOSS, (hipStream_t)stream);
-  hipLaunchKernelGGL(softmax_ce_kernel, dim3((unsigned)ultr_loss_parts(batch)), dim3(LPW * 64), lds, (hipStream_t)stream,
+  ULTR_LAUNCH(prof, softmax_ce_kernel, dim3((unsigned)ultr_loss_parts(batch)), dim3(LPW * 64), lds, (hipStream_t)stream,
                      scores, labels, pw, ipw_table, (int)n_ipw, (int)batch, (int)list_size, dscores, (float*)loss_ws);
   return (int)hipGetLastError();
 }
@@ -196,7 +196,7 @@ extern "C" int ultr_dla_loss(const float* scores, const float* labels, const flo
   const size_t lds = (size_t)LPW * (tail + 3 * list_size) * sizeof(float);
   if (lds > 64 * 1024) return ULTR_E_UNSUPPORTED;
   UltrProfScope prof(ULTR_K_LOSS, (hipStream_t)stream);
-  hipLaunchKernelGGL(dla_loss_kernel, dim3((unsigned)ultr_loss_parts(batch)), dim3(LPW * 64), lds, (hipStream_t)stream,
+  ULTR_LAUNCH(prof, dla_loss_kernel, dim3((unsigned)ultr_loss_parts(batch)), dim3(LPW * 64), lds, (hipStream_t)stream,
                      scores, labels, prop_params, (int)logits_to_prob, (int)batch, (int)list_size, dscores,
                      (float*)loss_ws);
   return (int)hipGetLastError();
@@ -283,7 +283,7 @@ extern "C" int ultr_pairdebias_loss(const float* scores, const float* labels, co
   const size_t lds = ((size_t)LPW * (tail + 2 * list_size) + 2 * list_size) * sizeof(float);
   if (lds > 64 * 1024) return ULTR_E_UNSUPPORTED;
   UltrProfScope prof(ULTR_K_LOSS, (hipStream_t)stream);
-  hipLaunchKernelGGL(pairdebias_kernel, dim3((unsigned)ultr_loss_parts(batch)), dim3(LPW * 64), lds, (hipStream_t)stream,
+  ULTR_LAUNCH(prof, pairdebias_kernel, dim3((unsigned)ultr_loss_parts(batch)), dim3(LPW * 64), lds, (hipStream_t)stream,
                      scores, labels, t_plus, t_minus, (int)batch, (int)list_size, (float)batch_total, dscores,
                      (float*)loss_ws);
   return (int)hipGetLastError();
@@ -411,7 +411,7 @@ extern "C" int ultr_lambdarank_loss(const float* scores, const float* labels, co
   const size_t lds = ((size_t)LPW * (tail + 6 * list_size) + 2 * list_size) * sizeof(float);
   if (lds > 64 * 1024) return ULTR_E_UNSUPPORTED;
   UltrProfScope prof(ULTR_K_LOSS, (hipStream_t)stream);
-  hipLaunchKernelGGL(lambdarank_kernel, dim3((unsigned)ultr_loss_parts(batch)), dim3(LPW * 64), lds, (hipStream_t)stream,
+  ULTR_LAUNCH(prof, lambdarank_kernel, dim3((unsigned)ultr_loss_parts(batch)), dim3(LPW * 64), lds, (hipStream_t)stream,
                      scores, labels, t_plus, t_minus, sigma, (int)batch, (int)list_size, dscores, (float*)loss_ws);
   return (int)hipGetLastError();
 }

@@ -1,7 +1,11 @@
-// ultr_prof.h — optional per-kernel HIP-event timing (used by bench.py for the roofline line).
-// Disabled by default: the launch sites pay one predictable branch.
+// ultr_prof.h — optional per-kernel timing (used by bench.py for the roofline line).
+// Disabled by default: the launch sites pay one predictable branch.  When armed for a kernel id, that kernel is
+// launched through hipExtLaunchKernelGGL with a start and a stop event: the two timestamps are taken from the
+// kernel's OWN dispatch packet (what rocprofv3 --kernel-trace reports), not from extra marker packets around it.
+// (hipEventRecord brackets were measured at ~5 us per pair on the stream - more than the small kernels they timed.)
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 enum UltrKernelId {
@@ -10,16 +14,21 @@ enum UltrKernelId {
 };
 
 extern uint32_t g_ultr_prof_mask;
-void ultr_prof_mark(int kid, int phase, hipStream_t st);  // phase 0 = before launch, 1 = after
+// reserves a sample (start/stop event pair) for kernel `kid`; false when the pool is exhausted or the sampling
+// stride skips this launch
+bool ultr_prof_take(int kid, hipEvent_t* a, hipEvent_t* b);
 
 struct UltrProfScope {
-  int kid;
-  hipStream_t st;
+  hipEvent_t a, b;
   bool on;
-  UltrProfScope(int k, hipStream_t s) : kid(k), st(s), on((g_ultr_prof_mask >> k) & 1u) {
-    if (on) ultr_prof_mark(kid, 0, st);
-  }
-  ~UltrProfScope() {
-    if (on) ultr_prof_mark(kid, 1, st);
+  UltrProfScope(int k, hipStream_t) : a(nullptr), b(nullptr), on(false) {
+    if ((g_ultr_prof_mask >> k) & 1u) on = ultr_prof_take(k, &a, &b);
   }
 };
+
+// launch KERNEL (parenthesise template-ids) under the scope PS: timed when armed, a plain launch otherwise
+#define ULTR_LAUNCH(PS, KERNEL, GRID, BLOCK, LDS, ST, ...)                                                   \
+  do {                                                                                                       \
+    if ((PS).on) hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, (uint32_t)(LDS), ST, (PS).a, (PS).b, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, ST, __VA_ARGS__);                                      \
+  } while (0)

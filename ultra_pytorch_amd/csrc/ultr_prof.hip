@@ -14,26 +14,24 @@ struct Sample {
 };
 std::vector<Sample> g_pool;
 size_t g_used = 0;
-size_t g_open[ULTR_K_COUNT];
+uint64_t g_calls[ULTR_K_COUNT];
+int g_stride = 1;
 }  // namespace
 
-void ultr_prof_mark(int kid, int phase, hipStream_t st) {
-  if (phase == 0) {
-    if (g_used >= g_pool.size()) {
-      g_open[kid] = (size_t)-1;
-      return;
-    }
-    g_open[kid] = g_used++;
-    g_pool[g_open[kid]].kid = kid;
-    (void)hipEventRecord(g_pool[g_open[kid]].a, st);
-  } else if (g_open[kid] != (size_t)-1) {
-    (void)hipEventRecord(g_pool[g_open[kid]].b, st);
-  }
+bool ultr_prof_take(int kid, hipEvent_t* a, hipEvent_t* b) {
+  if (g_stride > 1 && (g_calls[kid]++ % (uint64_t)g_stride) != 0) return false;
+  if (g_used >= g_pool.size()) return false;
+  Sample& s = g_pool[g_used++];
+  s.kid = kid;
+  *a = s.a;
+  *b = s.b;
+  return true;
 }
 
 extern "C" int ultr_prof_enable(uint32_t kernel_mask, int32_t max_samples) {
   g_ultr_prof_mask = 0;
   g_used = 0;
+  for (int k = 0; k < ULTR_K_COUNT; ++k) g_calls[k] = 0;
   if (kernel_mask == 0) return 0;
   if (max_samples <= 0) return ULTR_E_BADARG;
   while (g_pool.size() < (size_t)max_samples) {
@@ -46,6 +44,13 @@ extern "C" int ultr_prof_enable(uint32_t kernel_mask, int32_t max_samples) {
     g_pool.push_back(s);
   }
   g_ultr_prof_mask = kernel_mask;
+  return 0;
+}
+
+// time only every n-th launch of an armed kernel (n >= 1): keeps the instrumentation out of the measured throughput
+extern "C" int ultr_prof_set_stride(int32_t n) {
+  if (n < 1) return ULTR_E_BADARG;
+  g_stride = n;
   return 0;
 }
 

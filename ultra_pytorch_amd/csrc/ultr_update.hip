@@ -176,7 +176,7 @@ extern "C" int ultr_apply_update(const ultr_update_desc* u, const ultr_dnn_desc*
   const int nsq = (int)ultr_red_blocks(u->n_params, tail);
   const int nblk = (int)((u->n_params + 255) / 256);
   UltrProfScope prof(ULTR_K_UPDATE, (hipStream_t)stream);
-  hipLaunchKernelGGL(update_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *u, dp, params, state, grads, aux, wt,
+  ULTR_LAUNCH(prof, update_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *u, dp, params, state, grads, aux, wt,
                      (const float*)bwd_ws, nsq, scalars_out);
   return (int)hipGetLastError();
 }
