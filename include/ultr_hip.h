@@ -151,12 +151,22 @@ int ultr_lambdarank_loss(const float* scores, const float* labels, const float* 
                          float sigma, int32_t batch, int32_t list_size, float* dscores, void* loss_ws,
                          void* stream);
 
+/* ---- next row 8f.3: RegressionEM -----------------------------------------------------
+ * Replaces RegressionEM.train's estimation + loss section (regression_EM.py:128-151, get_bernoulli_sample
+ * :20-34): gamma = sigmoid(s); posteriors with the propensity [L]; pseudo-labels ceil(p_r1 - u) with u from
+ * `uniforms` [B, L] (teacher-forced) or, when NULL, Philox keyed by (seed, step); BCE-with-logits, mean over
+ * B*L (the count is left in the tail as D).  loss_ws also gets the per-position sums of the M-step
+ * (regression_EM.py:180-183), applied by ultr_apply_update (aux = propensity).  pseudo_labels_out may be NULL. */
+int ultr_regem_loss(const float* scores, const float* labels, const float* propensity, const float* uniforms,
+                    uint64_t seed, uint64_t step, int32_t batch, int32_t list_size, float* dscores,
+                    float* pseudo_labels_out, void* loss_ws, void* stream);
+
 /* ---- a5 (clip) + a6 (optimizer) + EM / propensity updates ----------------------------
  * Replaces torch.nn.utils.clip_grad_norm_ + Adagrad.step / SGD.step
  * (base_algorithm.py:223-226; ipw_rank.py:96), DLA.separate_gradient_update
  * (dla.py:141-177: per-model clip, fresh = stateless Adagrad), and the t_plus/t_minus EM
  * updates (pairwise_debias.py:159-163, lambda_rank.py:136-142). */
-enum ultr_algo { ULTR_ALGO_SOFTMAX = 0, ULTR_ALGO_DLA = 1, ULTR_ALGO_PAIRDEBIAS = 2, ULTR_ALGO_LAMBDARANK = 3 };
+enum ultr_algo { ULTR_ALGO_SOFTMAX = 0, ULTR_ALGO_DLA = 1, ULTR_ALGO_PAIRDEBIAS = 2, ULTR_ALGO_LAMBDARANK = 3, ULTR_ALGO_REGEM = 4 };
 enum ultr_opt { ULTR_OPT_ADAGRAD = 0, ULTR_OPT_SGD = 1 };
 
 typedef struct ultr_update_desc {
@@ -189,7 +199,7 @@ int ultr_apply_update(const ultr_update_desc* u, const ultr_dnn_desc* d, float* 
  * ultr_dnn_forward -> ultr_<loss by upd->algo> -> ultr_dnn_backward -> ultr_apply_update, enqueued by ONE host
  * call (what `model.train(input_feed)` does between marshalling the feed and `loss.item()`).  A data-parallel
  * caller sets skip_update, all-reduces `grads`, then calls ultr_grad_sumsq + ultr_apply_update itself.
- * aux: prop_params (DLA) or [t_plus | t_minus] (PairDebias / LambdaRank) or NULL. */
+ * aux: prop_params (DLA) or [t_plus | t_minus] (PairDebias / LambdaRank) or propensity [L] (RegressionEM) or NULL. */
 typedef struct ultr_step_args {
   const ultr_dnn_desc* desc;
   const ultr_update_desc* upd;
@@ -216,6 +226,9 @@ typedef struct ultr_step_args {
   int32_t batch_total; /* PairDebias: global batch (0 = batch) */
   int32_t skip_update;
   float sigma;         /* LambdaRank */
+  const float* uniforms; /* RegressionEM: [B, L] uniforms of the Bernoulli draw, or NULL = Philox(rng_seed, rng_step) */
+  uint64_t rng_seed;
+  uint64_t rng_step;
 } ultr_step_args;
 int ultr_train_step(const ultr_step_args* a, void* stream);
 

@@ -410,6 +410,44 @@ def lambdarank_step(params, state_sum, t_plus, t_minus, F_, hidden, features, do
 
 
 # --------------------------------------------------------------------------------------
+# next row 8f.3: RegressionEM  (regression_EM.py:108-193)
+# --------------------------------------------------------------------------------------
+def regression_em_estimation(scores: torch.Tensor, labels: torch.Tensor, propensity: torch.Tensor):
+    """E-step (regression_EM.py:130-145): gamma = sigmoid(s + sigmoid_prob_b) with sigmoid_prob_b == 0 (a plain tensor,
+    never trained: :102-104); posteriors of (examined, not relevant) and (not examined, relevant) given no click;
+    p_r1 = c + (1 - c) * P(e=0, r=1 | c=0)."""
+    gamma = torch.sigmoid(scores)
+    den = 1 - propensity * gamma
+    p_e1_r0_c0 = propensity * (1 - gamma) / den
+    p_e0_r1_c0 = (1 - propensity) * gamma / den
+    p_r1 = labels + (1 - labels) * p_e0_r1_c0
+    return p_e1_r0_c0, p_r1
+
+
+def regression_em_step(params, state_sum, propensity, uniforms, F_, hidden, features, docids, labels_LB, lr=0.05,
+                       max_norm=5.0, em_step=0.05, strategy="ada", act="elu"):
+    """One RegressionEM.train step with the Bernoulli uniforms INJECTED (the reference draws them from an unseeded
+    torch.rand: get_bernoulli_sample, regression_EM.py:20-34, sample = ceil(p - u)).  Loss = BCEWithLogits(scores,
+    pseudo-labels), mean over all B*L elements (:149-151); persistent Adagrad + global-norm clip (:165-176); M-step
+    propensity <- (1-a) propensity + a * mean_b(c + (1-c) P(e=1, r=0 | c=0)) with the PRE-update scores (:180-183)."""
+    p = torch.as_tensor(params, dtype=torch.float32).clone().requires_grad_(True)
+    prop = torch.as_tensor(propensity, dtype=torch.float32).reshape(1, -1)
+    u = torch.as_tensor(uniforms, dtype=torch.float32)
+    scores = ranking_scores(p, F_, hidden, features, docids, act)
+    labels = torch.from_numpy(np.ascontiguousarray(np.transpose(labels_LB))).float()
+    with torch.no_grad():
+        p_e1_r0_c0, p_r1 = regression_em_estimation(scores.detach(), labels, prop)
+        ranker_labels = torch.ceil(p_r1 - u)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(scores, ranker_labels)
+    (g,) = torch.autograd.grad(loss, p)
+    with torch.no_grad():
+        prop2 = (1 - em_step) * prop + em_step * torch.mean(labels + (1 - labels) * p_e1_r0_c0, dim=0, keepdim=True)
+        p2, s2, n, _ = apply_update(p.detach(), g, torch.as_tensor(state_sum, dtype=torch.float32), lr, max_norm, strategy)
+    return dict(loss=float(loss.detach()), scores=scores.detach().numpy(), grads=g.numpy(), norm=float(n), params=p2.numpy(),
+                state=s2.numpy(), propensity=prop2.numpy(), ranker_labels=ranker_labels.numpy())
+
+
+# --------------------------------------------------------------------------------------
 # a12/a13: validation  (base_algorithm.py:88-116; metrics.py:156-336, 456-495)
 # --------------------------------------------------------------------------------------
 def mask_padding(scores: torch.Tensor, docids_LB: np.ndarray, n_docs: int) -> torch.Tensor:

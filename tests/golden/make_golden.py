@@ -198,6 +198,7 @@ ALGOS = {
     "dla": "ultra.learning_algorithm.DLA",
     "pairdebias": "ultra.learning_algorithm.PairDebias",
     "lambdarank": "ultra.learning_algorithm.LambdaRank",
+    "regem": "ultra.learning_algorithm.RegressionEM",
 }
 
 
@@ -240,15 +241,38 @@ def run_train_case(ultra, name, algo_key, F, L, B, hidden, n_steps, seed, n_quer
         input_feed, _ = feed.get_batch(ds, check_validation=True)
         feats, docids, labels = feed_arrays(algo, input_feed, L)
         pre = {"params": flat_params(algo.model)}
-        if algo_key in ("na", "ipw", "pairdebias", "lambdarank"):
+        if algo_key in ("na", "ipw", "pairdebias", "lambdarank", "regem"):
             pre["adagrad"] = adagrad_state(algo.optimizer_func, algo.model)
+        if algo_key == "regem":
+            pre["propensity"] = algo.propensity.detach().cpu().numpy().copy()
         if algo_key in ("pairdebias", "lambdarank"):
             pre["t_plus"] = algo.t_plus.detach().cpu().numpy().copy()
             pre["t_minus"] = algo.t_minus.detach().cpu().numpy().copy()
         if algo_key == "dla":
             pre["prop_params"] = flat_params(algo.propensity_model)
-        loss, _, _ = quiet(algo.train, input_feed)
+        drawn = []
+        if algo_key == "regem":
+            # RegressionEM draws its Bernoulli pseudo-labels from an unseeded torch.rand (regression_EM.py:30-33):
+            # record the uniforms so that the restatement / the kernel can be teacher-forced with the same draw
+            orig_rand = torch.rand
+
+            def rec_rand(*a, **k):
+                u = orig_rand(*a, **k)
+                drawn.append(u.detach().cpu().numpy().copy())
+                return u
+
+            torch.rand = rec_rand
+        try:
+            loss, _, _ = quiet(algo.train, input_feed)
+        finally:
+            if algo_key == "regem":
+                torch.rand = orig_rand
         p = "s%d_" % t
+        if algo_key == "regem":
+            assert len(drawn) == 1
+            out[p + "uniforms"] = drawn[0].astype(np.float32)  # [B, L]
+            out[p + "ranker_labels"] = algo.ranker_labels.detach().cpu().numpy().astype(np.float32)
+            out[p + "post_propensity"] = algo.propensity.detach().cpu().numpy().copy()
         out[p + "features"] = feats
         out[p + "docids"] = docids
         out[p + "labels"] = labels
@@ -392,6 +416,9 @@ CASES = {
     "dla_odd": lambda u: run_train_case(u, "dla_odd", "dla", 13, 7, 9, [19, 6, 3], 2, 17, n_queries=32),
     "pairdebias_odd": lambda u: run_train_case(u, "pairdebias_odd", "pairdebias", 13, 7, 9, [19, 6, 3], 2, 18, n_queries=32),
     "lambdarank_odd": lambda u: run_train_case(u, "lambdarank_odd", "lambdarank", 13, 7, 9, [19, 6, 3], 2, 19, n_queries=32),
+    # next row 8f.3: RegressionEM (uniforms of the Bernoulli draw recorded)
+    "regem_tiny": lambda u: run_train_case(u, "regem_tiny", "regem", 136, 10, 8, [32, 16], 2, 23),
+    "regem_odd": lambda u: run_train_case(u, "regem_odd", "regem", 13, 7, 9, [19, 6, 3], 2, 24, n_queries=32),
     # k = 0 (the Linear ranking model: LayerNorm -> Linear(F,1))
     "na_linear": lambda u: run_train_case(u, "na_linear", "na", 136, 10, 8, None, 2, 20,
                                           model_cls="ultra.ranking_model.Linear"),

@@ -43,13 +43,17 @@ class HipRun:
         torch.cuda.synchronize()
         return self.eng.scores.cpu().numpy()
 
-    def loss(self, aux=None, ipw_table=None, pw=None, scores=None):
+    def loss(self, aux=None, ipw_table=None, pw=None, scores=None, uniforms=None):
         if scores is not None:
             self.eng.scores.copy_(dev(scores, torch.float32).view(self.B, self.L))
         self.aux = None if aux is None else dev(aux, torch.float32)
         self.ipw = None if ipw_table is None else dev(np.asarray(ipw_table, np.float32))
         self.pw = None if pw is None else dev(pw, torch.float32)
-        self.eng.loss(self.labels, aux=self.aux, ipw_table=self.ipw, pw=self.pw)
+        kw = {}
+        if uniforms is not None:
+            self.uniforms = dev(uniforms, torch.float32)
+            kw["uniforms"] = self.uniforms
+        self.eng.loss(self.labels, aux=self.aux, ipw_table=self.ipw, pw=self.pw, **kw)
         torch.cuda.synchronize()
         tail = self.eng.tail
         parts = self.eng.loss_ws[: ((self.B + 3) // 4) * tail].view(-1, tail).cpu().numpy()

@@ -11,9 +11,10 @@ pytestmark = pytest.mark.gpu
 
 from tests.hipref import HipRun, dev, load_golden  # noqa: E402
 
-ALGO = {"na": "softmax", "ipw": "softmax", "dla": "dla", "pairdebias": "pairdebias", "lambdarank": "lambdarank"}
+ALGO = {"na": "softmax", "ipw": "softmax", "dla": "dla", "pairdebias": "pairdebias", "lambdarank": "lambdarank",
+        "regem": "regem"}
 TRAIN_CASES = ["na_tiny", "ipw_tiny", "dla_tiny", "pairdebias_tiny", "lambdarank_tiny", "ipw_odd", "dla_odd",
-               "pairdebias_odd", "lambdarank_odd", "na_linear", "ipw_relu", "ipw_sgd", "ipw_cfg2"]
+               "pairdebias_odd", "lambdarank_odd", "na_linear", "ipw_relu", "ipw_sgd", "ipw_cfg2", "regem_tiny", "regem_odd"]
 
 
 def gtol(g, name=""):
@@ -61,8 +62,15 @@ def test_golden_train_step(name):
             aux = d[p + "pre_prop_params"]
         elif m["algo"] in ("pairdebias", "lambdarank"):
             aux = np.concatenate([d[p + "pre_t_plus"].ravel(), d[p + "pre_t_minus"].ravel()])
+        elif m["algo"] == "regem":
+            aux = d[p + "pre_propensity"].ravel()
         ipw = d["ipw_list"] if m["algo"] == "ipw" else None
-        ds, tail = run.loss(aux=aux, ipw_table=ipw)
+        # RegressionEM: teacher-forced with the uniforms the reference drew
+        ds, tail = run.loss(aux=aux, ipw_table=ipw, uniforms=d[p + "uniforms"] if m["algo"] == "regem" else None)
+        if m["algo"] == "regem":
+            # the pseudo-labels are the only discrete quantity: dscores x D = sigmoid(s) - y  =>  y = sigmoid(s) - ds
+            y = 1.0 / (1.0 + np.exp(-scores.astype(np.float64))) - ds
+            np.testing.assert_allclose(y, d[p + "ranker_labels"], atol=1e-5)
         gs, loss = gscale_and_loss(m["algo"], tail)
         ref_loss = float(d[p + "loss"])
         assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), ("loss", loss, ref_loss)
@@ -81,6 +89,8 @@ def test_golden_train_step(name):
         if m["algo"] in ("pairdebias", "lambdarank"):
             np.testing.assert_allclose(aux2[:L], d[p + "post_t_plus"].ravel(), atol=1e-6)
             np.testing.assert_allclose(aux2[L:], d[p + "post_t_minus"].ravel(), atol=1e-6)
+        if m["algo"] == "regem":
+            np.testing.assert_allclose(aux2, d[p + "post_propensity"].ravel(), atol=1e-6)
         if m["algo"] == "dla":
             np.testing.assert_allclose(aux2, d[p + "post_prop_params"], atol=1e-6)
             assert abs(sc[6] - float(d[p + "prop_norm"])) < 1e-6

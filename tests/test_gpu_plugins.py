@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 
 from tests.hipref import load_golden  # noqa: E402
 
-CLS = {"na": "NavieAlgorithm", "ipw": "IPWrank", "dla": "DLA", "pairdebias": "PairDebias", "lambdarank": "LambdaRank"}
+CLS = {"na": "NavieAlgorithm", "ipw": "IPWrank", "dla": "DLA", "pairdebias": "PairDebias", "lambdarank": "LambdaRank",
+       "regem": "RegressionEM"}
 
 
 class DataSet:
@@ -51,7 +52,8 @@ def load_flat(model, flat):
     model.load_state_dict(sd)
 
 
-@pytest.mark.parametrize("name", ["na_tiny", "ipw_tiny", "dla_tiny", "pairdebias_tiny", "lambdarank_tiny", "na_linear", "ipw_cfg2"])
+@pytest.mark.parametrize("name", ["na_tiny", "ipw_tiny", "dla_tiny", "pairdebias_tiny", "lambdarank_tiny", "na_linear", "ipw_cfg2",
+                                  "regem_tiny"])
 def test_train_matches_golden(name):
     d, m = load_golden(name)
     algo = build(m, model_cls="Linear" if m["model"] == "Linear" else "DNN")
@@ -66,6 +68,9 @@ def test_train_matches_golden(name):
             algo.propensity_model.flat_params.copy_(torch.from_numpy(d[p + "pre_prop_params"]))
         if m["algo"] in ("pairdebias", "lambdarank"):
             algo.t_state.copy_(torch.from_numpy(np.concatenate([d[p + "pre_t_plus"].ravel(), d[p + "pre_t_minus"].ravel()])))
+        if m["algo"] == "regem":
+            algo.propensity_state.copy_(torch.from_numpy(d[p + "pre_propensity"].ravel()))
+            algo.uniforms = torch.from_numpy(d[p + "uniforms"]).cuda()  # the reference's recorded Bernoulli draw
         feed = make_feed(algo, d[p + "features"], d[p + "docids"], d[p + "labels"])
         loss, out, summary = algo.train(feed)
         ref = float(d[p + "loss"])
@@ -78,6 +83,8 @@ def test_train_matches_golden(name):
         if m["algo"] in ("pairdebias", "lambdarank"):
             np.testing.assert_allclose(algo.t_plus.cpu().numpy(), d[p + "post_t_plus"], atol=1e-6)
             np.testing.assert_allclose(algo.t_minus.cpu().numpy(), d[p + "post_t_minus"], atol=1e-6)
+        if m["algo"] == "regem":
+            np.testing.assert_allclose(algo.propensity.cpu().numpy(), d[p + "post_propensity"], atol=1e-6)
         if m["algo"] == "dla":
             np.testing.assert_allclose(algo.propensity_model.flat_params.cpu().numpy(), d[p + "post_prop_params"], atol=1e-6)
         if m["algo"] == "ipw":
@@ -127,3 +134,27 @@ def test_unsupported_options_raise():
         build(dict(m, algo_hparams="l2_loss=0.1"))
     with pytest.raises(NotImplementedError):
         build(dict(m, algo_hparams="loss_func=sigmoid_loss"))
+
+
+def test_regression_em_device_rng():
+    """Without injected uniforms the Bernoulli draw comes from the device Philox stream: pseudo-label rate must match
+    the posterior mean, the draw must be reproducible for a fixed (seed, step) and differ between steps."""
+    from ultra_pytorch_amd import hip_ops
+    B, L = 512, 10
+    rng = np.random.RandomState(0)
+    scores = torch.from_numpy(rng.normal(size=(B, L)).astype(np.float32)).cuda()
+    labels = torch.from_numpy((rng.uniform(size=(L, B)) < 0.2).astype(np.float32)).cuda()
+    prop = torch.full((L,), 0.9, device="cuda")
+    ds = torch.empty(B, L, device="cuda")
+    ws = torch.zeros(hip_ops.loss_workspace_bytes(B, L) // 4, device="cuda")
+    ys = []
+    for step in (0, 0, 1):
+        y = torch.empty(B, L, device="cuda")
+        hip_ops.regem_loss(scores, labels, prop, B, L, ds, ws, seed=7, step=step, pseudo_out=y)
+        ys.append(y.cpu().numpy())
+    assert np.array_equal(ys[0], ys[1]) and not np.array_equal(ys[0], ys[2])
+    gamma = 1.0 / (1.0 + np.exp(-scores.cpu().numpy().astype(np.float64)))
+    c = labels.cpu().numpy().T
+    p_r1 = c + (1 - c) * (0.1 * gamma / (1 - 0.9 * gamma))
+    assert set(np.unique(ys[0])) <= {0.0, 1.0}
+    assert abs(ys[0].mean() - p_r1.mean()) < 4 * np.sqrt(0.25 / (B * L))

@@ -80,6 +80,21 @@ def test_pairwise_em(name):
         np.testing.assert_allclose(r["state"], d[p + "post_adagrad"], rtol=5e-4, atol=1e-12)
 
 
+@pytest.mark.parametrize("name", ["regem_tiny", "regem_odd"])
+def test_regression_em(name):
+    """teacher-forced with the uniforms the reference drew (recorded by make_golden.py)."""
+    d, m = load(name)
+    for t in range(m["n_steps"]):
+        p = "s%d_" % t
+        r = O.regression_em_step(d[p + "pre_params"], d[p + "pre_adagrad"], d[p + "pre_propensity"], d[p + "uniforms"],
+                                 m["F"], m["hidden"], d[p + "features"], d[p + "docids"], d[p + "labels"], lr=m["lr"],
+                                 max_norm=m["max_gradient_norm"])
+        np.testing.assert_array_equal(r["ranker_labels"], d[p + "ranker_labels"])
+        check_common(d, m, t, r)
+        np.testing.assert_allclose(r["propensity"], d[p + "post_propensity"], atol=1e-6)
+        np.testing.assert_allclose(r["state"], d[p + "post_adagrad"], rtol=5e-4, atol=1e-12)
+
+
 @pytest.mark.parametrize("name", ["valid_tiny", "valid_odd"])
 def test_validation(name):
     d, m = load(name)

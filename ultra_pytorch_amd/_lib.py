@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libultr_hip.so")
 
 ULTR_MAX_HIDDEN = 7
 ACT = {"elu": 0, "relu": 1}
-ALGO_SOFTMAX, ALGO_DLA, ALGO_PAIRDEBIAS, ALGO_LAMBDARANK = 0, 1, 2, 3
+ALGO_SOFTMAX, ALGO_DLA, ALGO_PAIRDEBIAS, ALGO_LAMBDARANK, ALGO_REGEM = 0, 1, 2, 3, 4
 OPT_ADAGRAD, OPT_SGD = 0, 1
 
 c_i32, c_i64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
@@ -33,7 +33,8 @@ class StepArgs(ctypes.Structure):
                 ("state", c_vp), ("aux", c_vp), ("features", c_vp), ("docids", c_vp), ("labels", c_vp), ("pw", c_vp),
                 ("ipw_table", c_vp), ("scores", c_vp), ("dscores", c_vp), ("saved", c_vp), ("loss_ws", c_vp),
                 ("bwd_ws", c_vp), ("grads", c_vp), ("scalars", c_vp), ("n_docs", c_i64), ("n_ipw", c_i32),
-                ("batch", c_i32), ("list_size", c_i32), ("batch_total", c_i32), ("skip_update", c_i32), ("sigma", c_f32)]
+                ("batch", c_i32), ("list_size", c_i32), ("batch_total", c_i32), ("skip_update", c_i32), ("sigma", c_f32),
+                ("uniforms", c_vp), ("rng_seed", ctypes.c_uint64), ("rng_step", ctypes.c_uint64)]
 
 
 # name -> (restype, argtypes); must list EVERY symbol include/ultr_hip.h declares
@@ -57,6 +58,7 @@ SIGNATURES = {
     "ultr_dla_loss": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "ultr_pairdebias_loss": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "ultr_lambdarank_loss": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "ultr_regem_loss": (c_i32, [c_vp, c_vp, c_vp, c_vp, ctypes.c_uint64, ctypes.c_uint64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "ultr_apply_update": (c_i32, [ctypes.POINTER(UpdateDesc), ctypes.POINTER(DnnDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                   c_vp, c_vp]),
     "ultr_train_step": (c_i32, [ctypes.POINTER(StepArgs), c_vp]),

@@ -18,28 +18,6 @@
 #include "../../include/ultr_hip.h"
 #include "ultr_device.h"
 
-struct Philox {
-  uint32_t k0, k1;
-  __device__ __forceinline__ void round(uint32_t (&c)[4], uint32_t ka, uint32_t kb) const {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ ka, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ kb;
-    c[1] = (uint32_t)p1;
-    c[3] = (uint32_t)p0;
-    c[0] = n0;
-    c[2] = n2;
-  }
-  __device__ __forceinline__ void operator()(uint32_t (&c)[4]) const {
-    uint32_t ka = k0, kb = k1;
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-      round(c, ka, kb);
-      ka += 0x9E3779B9u;
-      kb += 0xBB67AE85u;
-    }
-  }
-};
-__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }  // [0, 1)
-
 __global__ __launch_bounds__(256) void click_batch_kernel(const int32_t* __restrict__ lists, const float* __restrict__ rel,
                                                           int64_t n_queries, int Lmax, int64_t n_docs,
                                                           const float* __restrict__ exam, int n_exam,

@@ -109,6 +109,77 @@ extern "C" int ultr_softmax_ce(const float* scores, const float* labels, const f
   return (int)hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// next row 8f.3: RegressionEM                                         regression_EM.py:108-193
+// ------------------------------------------------------------------------------------------------
+// E-step posteriors from the CURRENT scores and propensity, Bernoulli pseudo-labels y = ceil(p_r1 - u), loss =
+// BCEWithLogits(s, y) averaged over all B*L elements (D = element count in the tail, applied by the update kernel),
+// per-position sums of c + (1 - c) P(e=1, r=0 | c=0) for the M-step.  u comes from `uniforms` (teacher-forced
+// parity with the reference's recorded torch.rand draw) or, when NULL, from Philox keyed by (seed, step).
+__global__ __launch_bounds__(LPW * 64) void regem_kernel(const float* __restrict__ scores, const float* __restrict__ labels,
+                                                        const float* __restrict__ propensity,
+                                                        const float* __restrict__ uniforms, uint64_t seed, uint64_t step,
+                                                        int B, int L, float* __restrict__ dscores,
+                                                        float* __restrict__ pseudo, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tail = (int)ultr_tail_len(L);
+  float* sm_tail = smem;  // [LPW][tail]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * LPW + wave;
+  float* mt = sm_tail + wave * tail;
+  for (int t = lane; t < tail; t += 64) mt[t] = 0.f;
+  if (b < B) {
+    const Philox rng{(uint32_t)seed ^ (uint32_t)(step * 0x9E3779B97F4A7C15ull >> 32), (uint32_t)(seed >> 32) ^ (uint32_t)step};
+    float lsum = 0.f, cnt = 0.f;
+    for (int l = lane; l < L; l += 64) {
+      const float s = scores[(int64_t)b * L + l];
+      const float c = labels[(int64_t)l * B + b];
+      const float pr = propensity[l];
+      const float gamma = sigmoidf_(s);
+      const float den = 1.0f - pr * gamma;
+      const float p_e1_r0_c0 = pr * (1.0f - gamma) / den;
+      const float p_e0_r1_c0 = (1.0f - pr) * gamma / den;
+      const float p_r1 = c + (1.0f - c) * p_e0_r1_c0;
+      float u;
+      if (uniforms != nullptr) {
+        u = uniforms[(int64_t)b * L + l];
+      } else {
+        uint32_t ctr[4] = {(uint32_t)b, (uint32_t)l, 0x5245454Du, 0x1u};
+        rng(ctr);
+        u = u01(ctr[0]);
+      }
+      const float y = ceilf(p_r1 - u);  // get_bernoulli_sample (regression_EM.py:20-34)
+      lsum += fmaxf(s, 0.f) - s * y + log1pf(expf(-fabsf(s)));  // BCEWithLogits element
+      cnt += 1.0f;
+      dscores[(int64_t)b * L + l] = gamma - y;  // x D
+      if (pseudo != nullptr) pseudo[(int64_t)b * L + l] = y;
+      mt[ULTR_TAIL_FIXED + l] = c + (1.0f - c) * p_e1_r0_c0;
+    }
+    lsum = wave_sum(lsum);
+    cnt = wave_sum(cnt);
+    if (lane == 0) {
+      mt[0] = lsum;
+      mt[1] = cnt;
+    }
+  }
+  store_wg_tail(sm_tail, tail, part + (int64_t)blockIdx.x * tail);
+}
+
+extern "C" int ultr_regem_loss(const float* scores, const float* labels, const float* propensity, const float* uniforms,
+                               uint64_t seed, uint64_t step, int32_t batch, int32_t list_size, float* dscores,
+                               float* pseudo_labels_out, void* loss_ws, void* stream) {
+  if (!scores || !labels || !propensity || !dscores || !loss_ws || batch <= 0 || list_size <= 0) return ULTR_E_BADARG;
+  const int tail = (int)ultr_tail_len(list_size);
+  const size_t lds = (size_t)LPW * tail * sizeof(float);
+  if (lds > 64 * 1024) return ULTR_E_UNSUPPORTED;
+  UltrProfScope prof(ULTR_K_LOSS, (hipStream_t)stream);
+  ULTR_LAUNCH(prof, regem_kernel, dim3((unsigned)ultr_loss_parts(batch)), dim3(LPW * 64), lds, (hipStream_t)stream, scores,
+              labels, propensity, uniforms, seed, step, (int)batch, (int)list_size, dscores, pseudo_labels_out,
+              (float*)loss_ws);
+  return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // a9: DLA dual loss                                             dla.py:196-237, 24-48, 287-306
 // ------------------------------------------------------------------------------------------------

@@ -33,6 +33,10 @@ extern "C" int ultr_train_step(const ultr_step_args* a, void* stream) {
       rc = ultr_lambdarank_loss(a->scores, a->labels, a->aux, a->aux ? a->aux + a->list_size : nullptr, a->sigma, a->batch,
                                 a->list_size, a->dscores, a->loss_ws, stream);
       break;
+    case ULTR_ALGO_REGEM:
+      rc = ultr_regem_loss(a->scores, a->labels, a->aux, a->uniforms, a->rng_seed, a->rng_step, a->batch, a->list_size,
+                           a->dscores, nullptr, a->loss_ws, stream);
+      break;
     default:
       return ULTR_E_BADARG;
   }

@@ -72,6 +72,10 @@ __global__ __launch_bounds__(256) void update_kernel(ultr_update_desc u, DnnPlan
       gs = 1.0f / D;
       loss = loss_sum / D;
       break;
+    case ULTR_ALGO_REGEM:  // BCEWithLogits, mean over the D = B*L elements (regression_EM.py:149-151)
+      gs = 1.0f / D;
+      loss = loss_sum / D;
+      break;
   }
   const float norm = fabsf(gs) * sqrtf(ss);
   const float coef = (u.max_gradient_norm > 0.f) ? fminf(1.0f, u.max_gradient_norm / (norm + 1e-6f)) : 1.0f;
@@ -147,6 +151,11 @@ __global__ __launch_bounds__(256) void update_kernel(ultr_update_desc u, DnnPlan
       const float pw = (ex == 0.5f) ? sqrtf(ratio) : powf(ratio, ex);
       aux[l] = oma * aux[l] + a * pw;
     }
+  } else if (u.algo == ULTR_ALGO_REGEM && aux != nullptr) {
+    // M-step: propensity <- (1 - a) propensity + a * mean_b(c + (1 - c) P(e=1, r=0 | c=0))   (regression_EM.py:180-183)
+    const float a = u.em_step_size, oma = (float)(1.0 - (double)u.em_step_size);
+    const float nb = D / (float)L;  // lists in the (global) batch
+    for (int l = threadIdx.x; l < L; l += 256) aux[l] = oma * aux[l] + a * (tail[ULTR_TAIL_FIXED + l] / nb);
   }
   if (threadIdx.x == 0 && scalars_out != nullptr) {
     scalars_out[0] = loss;
@@ -168,7 +177,7 @@ extern "C" int ultr_apply_update(const ultr_update_desc* u, const ultr_dnn_desc*
   if (wt != nullptr) {
     if (!ultr_make_dnn_plan(d, 0, &dp) || dp.P != u->n_params) return ULTR_E_BADARG;
   }
-  if (u->algo < 0 || u->algo > ULTR_ALGO_LAMBDARANK || (u->optimizer != ULTR_OPT_ADAGRAD && u->optimizer != ULTR_OPT_SGD))
+  if (u->algo < 0 || u->algo > ULTR_ALGO_REGEM || (u->optimizer != ULTR_OPT_ADAGRAD && u->optimizer != ULTR_OPT_SGD))
     return ULTR_E_BADARG;
   if (u->algo != ULTR_ALGO_SOFTMAX && !aux) return ULTR_E_BADARG;
   if (u->optimizer == ULTR_OPT_ADAGRAD && u->algo != ULTR_ALGO_DLA && !state) return ULTR_E_BADARG;

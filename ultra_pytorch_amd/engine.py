@@ -17,7 +17,7 @@ import torch
 from . import _lib, hip_ops
 
 ALGOS = {"softmax": _lib.ALGO_SOFTMAX, "dla": _lib.ALGO_DLA, "pairdebias": _lib.ALGO_PAIRDEBIAS,
-         "lambdarank": _lib.ALGO_LAMBDARANK}
+         "lambdarank": _lib.ALGO_LAMBDARANK, "regem": _lib.ALGO_REGEM}
 
 
 def _f32(n, device, zero=False):
@@ -28,13 +28,14 @@ def _f32(n, device, zero=False):
 class StepEngine:
     def __init__(self, shape, batch, list_size, device, algo="softmax", optimizer="ada", learning_rate=0.05,
                  max_gradient_norm=5.0, ranker_loss_weight=1.0, propensity_learning_rate=None, em_step_size=0.05,
-                 regulation_p=1.0, sigma=1.0, logits_to_prob="softmax", process_group=None):
+                 regulation_p=1.0, sigma=1.0, logits_to_prob="softmax", process_group=None, rng_seed=0):
         if not torch.cuda.is_available():
             raise RuntimeError("ultra_pytorch_amd needs an MI355X/ROCm GPU: there is no CPU fallback")
         self.shape, self.B, self.L, self.device = shape, int(batch), int(list_size), device
         self.N = self.B * self.L
         self.algo = algo
         self.sigma = float(sigma)
+        self.rng_seed, self.rng_step = int(rng_seed), 0  # RegressionEM's Bernoulli draw when no uniforms are injected
         self.l2p = 1 if logits_to_prob == "sigmoid" else 0
         self.pg = process_group
         self.world = 1 if process_group is None else torch.distributed.get_world_size(process_group)
@@ -72,7 +73,7 @@ class StepEngine:
         return scores
 
     # ---- loss stage ------------------------------------------------------------------------------
-    def loss(self, labels, aux=None, ipw_table=None, pw=None):
+    def loss(self, labels, aux=None, ipw_table=None, pw=None, uniforms=None):
         B, L = self.B, self.L
         if self.algo == "softmax":
             hip_ops.softmax_ce(self.scores, labels, B, L, self.dscores, self.loss_ws, pw=pw, ipw_table=ipw_table)
@@ -82,6 +83,10 @@ class StepEngine:
             hip_ops.pairdebias_loss(self.scores, labels, aux[:L], aux[L:], B, L, B * self.world, self.dscores, self.loss_ws)
         elif self.algo == "lambdarank":
             hip_ops.lambdarank_loss(self.scores, labels, aux[:L], aux[L:], self.sigma, B, L, self.dscores, self.loss_ws)
+        elif self.algo == "regem":
+            hip_ops.regem_loss(self.scores, labels, aux, B, L, self.dscores, self.loss_ws, uniforms=uniforms,
+                               seed=self.rng_seed, step=self.rng_step)
+            self.rng_step += 1
         else:
             raise ValueError(self.algo)
 
@@ -96,7 +101,8 @@ class StepEngine:
     def update(self, params, state, aux=None):
         hip_ops.apply_update(self.shape, self.udesc, params, state, self.grads, aux, self.bwd_ws, self.scalars)
 
-    def train_step(self, params, state, features, n_docs, docids, labels, aux=None, ipw_table=None, pw=None):
+    def train_step(self, params, state, features, n_docs, docids, labels, aux=None, ipw_table=None, pw=None,
+                   uniforms=None):
         """One full step through ONE C call (ultr_train_step); returns the device tensor of step scalars ([0] = loss)."""
         a = self._args
         if a is None:
@@ -120,6 +126,10 @@ class StepEngine:
         a.pw = pw.data_ptr() if pw is not None else None
         a.ipw_table = ipw_table.data_ptr() if ipw_table is not None else None
         a.n_ipw = int(ipw_table.numel()) if ipw_table is not None else 0
+        if self.algo == "regem":
+            a.uniforms = uniforms.data_ptr() if uniforms is not None else None
+            a.rng_seed, a.rng_step = self.rng_seed, self.rng_step
+            self.rng_step += 1
         _lib.check(self._fn(ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ultr_train_step")
         if self.pg is not None:
             torch.distributed.all_reduce(self.grads, group=self.pg)

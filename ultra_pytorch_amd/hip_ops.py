@@ -154,6 +154,12 @@ def lambdarank_loss(scores, labels, t_plus, t_minus, sigma, B, L, dscores, loss_
                                            _p(dscores), _p(loss_ws), _stream()), "ultr_lambdarank_loss")
 
 
+def regem_loss(scores, labels, propensity, B, L, dscores, loss_ws, uniforms=None, seed=0, step=0, pseudo_out=None):
+    """RegressionEM estimation + BCE loss; uniforms [B, L] teacher-forces the Bernoulli draw."""
+    check(_lib.load().ultr_regem_loss(_p(scores), _p(labels), _p(propensity), _p(uniforms), int(seed), int(step), int(B),
+                                      int(L), _p(dscores), _p(pseudo_out), _p(loss_ws), _stream()), "ultr_regem_loss")
+
+
 def apply_update(shape, udesc, params, state, grads, aux, bwd_ws, scalars):
     wt = weight_copy(shape).get(params)  # the update kernel writes the new weights into both layouts
     check(shape.lib.ultr_apply_update(ctypes.byref(udesc), ctypes.byref(shape.desc), _p(params), _p(wt), _p(state), _p(grads),

@@ -7,3 +7,4 @@ from .ipw_rank import IPWrank  # noqa: F401
 from .dla import DLA, DenoisingNet  # noqa: F401
 from .pairwise_debias import PairDebias  # noqa: F401
 from .lambda_rank import LambdaRank  # noqa: F401
+from .regression_EM import RegressionEM  # noqa: F401
