@@ -165,6 +165,33 @@ __device__ __forceinline__ float ld1_sel(const Src& s, int64_t idx, bool ok) {
 // inside a launch, so waiting for the LDS queue is sufficient.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Canonical order of every cross-workgroup partial sum (slabs, loss partials): part k belongs to group k & 3; a group
+// adds its parts in chunks of 8, ((v0+v1)+(v2+v3))+((v4+v5)+(v6+v7)) with missing parts = 0, chunks accumulate in
+// order; total = ((S0+S1)+S2)+S3.  strided_sum = ONE group (4 cooperating threads + an LDS combine), full_sum = all four
+// groups by one thread with 32 loads in flight: both produce the same bits.
+__device__ __forceinline__ float strided_sum(const float* __restrict__ src, int64_t stride, int nparts, int grp) {
+  float part = 0.f;
+  for (int k = grp; k < nparts; k += 32) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (k + 4 * i < nparts) ? src[(int64_t)(k + 4 * i) * stride] : 0.f;
+    part += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  }
+  return part;
+}
+__device__ __forceinline__ float full_sum(const float* __restrict__ src, int64_t stride, int nparts) {
+  float S[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < nparts; k0 += 32) {
+    float v[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] = (k0 + i < nparts) ? src[(int64_t)(k0 + i) * stride] : 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      S[g] += ((v[g] + v[g + 4]) + (v[g + 8] + v[g + 12])) + ((v[g + 16] + v[g + 20]) + (v[g + 24] + v[g + 28]));
+  }
+  return ((S[0] + S[1]) + S[2]) + S[3];
+}
+
 // Counter-based generator (Philox-4x32-10): a draw is a pure function of (key, counter) - no state, no ordering
 struct Philox {
   uint32_t k0, k1;

@@ -1501,24 +1501,6 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
   finalize(0);
 }
 
-// One workgroup = 64 consecutive gradient elements x 4 slab groups: group g adds slabs g, g+4, ... with eight
-// independent loads in flight, then the four group sums are combined in fixed order through LDS.  (A serial
-// loop over 160 slabs per thread was latency-bound at ~120 us.)
-__device__ __forceinline__ float strided_sum(const float* __restrict__ src, int64_t stride, int nparts, int grp) {
-  float part = 0.f;
-  int k = grp;
-  for (; k + 28 < nparts; k += 32) {
-    const float v0 = src[(int64_t)k * stride], v1 = src[(int64_t)(k + 4) * stride];
-    const float v2 = src[(int64_t)(k + 8) * stride], v3 = src[(int64_t)(k + 12) * stride];
-    const float v4 = src[(int64_t)(k + 16) * stride], v5 = src[(int64_t)(k + 20) * stride];
-    const float v6 = src[(int64_t)(k + 24) * stride], v7 = src[(int64_t)(k + 28) * stride];
-    part += ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7));
-  }
-  for (; k < nparts; k += 4) part += src[(int64_t)k * stride];
-  return part;
-}
-
-
 // ------------------------------------------------------------------------------------------------
 // Weight gradients of the hidden Linears: dW_j[m,k] = sum_n dz_j[n,m] u_j[n,k],  db_j[m] = sum_n dz_j[n,m]
 // ------------------------------------------------------------------------------------------------
@@ -1534,14 +1516,15 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
                                                         const float* __restrict__ features, int64_t n_docs,
                                                         const int32_t* __restrict__ docids, int B, int L,
                                                         const float* __restrict__ saved, float* __restrict__ ws,
-                                                        int vecf) {
+                                                        int vecf, float* __restrict__ grads,
+                                                        const float* __restrict__ loss_part, int n_loss_part, int tail) {
   // ONE dynamic LDS array: [4][64*64] cross-wave reduction | [4][64] bias partials | [rows_per_split] doc ids
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float (*red)[64 * 64] = reinterpret_cast<float (*)[64 * 64]>(smem);
   float (*bred)[64] = reinterpret_cast<float (*)[64]>(smem + 4 * 64 * 64);
   int* sm_ids = reinterpret_cast<int*>(smem + 4 * 64 * 64 + 4 * 64);
   const int64_t N = bp.N;
-  if ((int)blockIdx.x >= bp.wgrad_blocks) {
+  if ((int)blockIdx.x >= bp.wgrad_blocks && (int)blockIdx.x < bp.wgrad_blocks + bp.vred_blocks) {
     // spare workgroups: fold the nrb per-row-block vector slabs (LayerNorm gamma/beta, scorer) into ONE slab while
     // the matrix blocks run, so that the reduction kernel's critical path is not a 160-deep serial sum
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -1551,6 +1534,20 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
     lds_barrier();
     if (grp == 0 && e < bp.vlen)
       ws[bp.vred_off + e] = ((smem[lane] + smem[64 + lane]) + smem[128 + lane]) + smem[192 + lane];
+    return;
+  }
+  if ((int)blockIdx.x == bp.wgrad_blocks + bp.vred_blocks) {
+    // last spare workgroup: fold the loss partials into the step tail grads[P ..] (so the kernels after this one read
+    // it with plain loads; the reduction launch then only folds gradient slabs)
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    for (int t0 = 0; t0 < tail; t0 += 64) {
+      const int t = t0 + lane;
+      smem[grp * 64 + lane] = (t < tail && loss_part != nullptr) ? strided_sum(loss_part + t, tail, n_loss_part, grp) : 0.f;
+      lds_barrier();
+      if (grp == 0 && t < tail && loss_part != nullptr)
+        grads[p.P + t] = ((smem[lane] + smem[64 + lane]) + smem[128 + lane]) + smem[192 + lane];
+      lds_barrier();
+    }
     return;
   }
   TRACE_STAMP(8);
@@ -1784,14 +1781,12 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(RedPlan rp, int64_t P,
     while (s + 1 < rp.nseg && e >= rp.seg[s + 1].off) ++s;
     const RedSeg sg = rp.seg[s];
     part = strided_sum(ws + sg.base + (e - sg.off), sg.stride, sg.nparts, grp);
-  } else if (e < P + tail && loss_part != nullptr) {
-    part = strided_sum(loss_part + (e - P), tail, n_loss_part, grp);
-  }
+  }  // the step tail grads[P ..] was written by the wgrad launch's last spare workgroup
   sm[grp][lane] = part;
   __syncthreads();
   if (grp == 0) {
     const float g = ((sm[0][lane] + sm[1][lane]) + sm[2][lane]) + sm[3][lane];
-    if (e < P + tail) grads[e] = g;
+    if (e < P) grads[e] = g;
     const float sq = wave_sum(e < P ? g * g : 0.f);
     if (lane == 0) sumsq_part[blockIdx.x] = sq;
   }
@@ -1963,7 +1958,7 @@ bool ultr_make_bwd_plan(const DnnPlan& p, int64_t N, BwdPlan* bp) {
 }
 
 
-static void make_red_plan(const DnnPlan& p, const BwdPlan& bp, RedPlan* rp) {
+void ultr_make_red_plan(const DnnPlan& p, const BwdPlan& bp, RedPlan* rp) {
   int s = 0;
   for (int j = 0; j < p.nl; ++j) {
     const bool last = (j == p.nl - 1);
@@ -2185,22 +2180,24 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
   if (e != hipSuccess) return (int)e;
   {
     UltrProfScope prof(ULTR_K_WGRAD, st);
+    const float* lp = (const float*)loss_ws;
+    const int nlp = fl.scores ? bp.nrb : (int)ultr_loss_parts(batch);
     int maxrps = 0;
     for (int j = 0; j < p.nl - 1; ++j) maxrps = bp.wl[j].rows_per_split > maxrps ? bp.wl[j].rows_per_split : maxrps;
     const size_t wlds = (size_t)(4 * 64 * 64 + 4 * 64 + maxrps) * sizeof(float);
     e = av ? set_lds(dnn_wgrad_kernel<true>, wlds) : set_lds(dnn_wgrad_kernel<false>, wlds);
     if (e != hipSuccess) return (int)e;
     if (av)
-      ULTR_LAUNCH(prof, dnn_wgrad_kernel<true>, dim3(bp.wgrad_blocks + bp.vred_blocks), dim3(256), wlds, st, p, bp, params, features, n_docs,
-                         docids, (int)batch, (int)list_size, (const float*)saved, ws, (vm >> 31) & 1);
+      ULTR_LAUNCH(prof, dnn_wgrad_kernel<true>, dim3(bp.wgrad_blocks + bp.vred_blocks + 1), dim3(256), wlds, st, p, bp, params, features, n_docs,
+                         docids, (int)batch, (int)list_size, (const float*)saved, ws, (vm >> 31) & 1, grads, lp, nlp, tail);
     else
-      ULTR_LAUNCH(prof, dnn_wgrad_kernel<false>, dim3(bp.wgrad_blocks + bp.vred_blocks), dim3(256), wlds, st, p, bp, params, features, n_docs,
-                         docids, (int)batch, (int)list_size, (const float*)saved, ws, (vm >> 31) & 1);
+      ULTR_LAUNCH(prof, dnn_wgrad_kernel<false>, dim3(bp.wgrad_blocks + bp.vred_blocks + 1), dim3(256), wlds, st, p, bp, params, features, n_docs,
+                         docids, (int)batch, (int)list_size, (const float*)saved, ws, (vm >> 31) & 1, grads, lp, nlp, tail);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }
   RedPlan rp;
-  make_red_plan(p, bp, &rp);
+  ultr_make_red_plan(p, bp, &rp);
   const int nblk = (int)ultr_red_blocks(p.P, tail);
   const float* lp = (const float*)loss_ws;
   UltrProfScope prof(ULTR_K_REDUCE, st);

@@ -99,6 +99,8 @@ struct RedPlan {
 
 struct ultr_dnn_desc;
 bool ultr_make_dnn_plan(const ultr_dnn_desc* d, int64_t N, DnnPlan* p);  // ultr_dnn.hip
+bool ultr_make_bwd_plan(const DnnPlan& p, int64_t N, BwdPlan* bp);         // ultr_dnn.hip
+void ultr_make_red_plan(const DnnPlan& p, const BwdPlan& bp, RedPlan* rp); // ultr_dnn.hip
 
 #define ULTR_TAIL_FIXED 4
 __host__ __device__ static inline int64_t ultr_tail_len(int L) { return ULTR_TAIL_FIXED + 2 * (int64_t)L; }

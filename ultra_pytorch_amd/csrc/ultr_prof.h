@@ -14,15 +14,17 @@ enum UltrKernelId {
 };
 
 extern uint32_t g_ultr_prof_mask;
-// reserves a sample (start/stop event pair) for kernel `kid`; false when the pool is exhausted or the sampling
-// stride skips this launch
+extern bool g_ultr_prof_live;  // false on the steps the sampling stride skips
+// called once at the top of ultr_train_step: decides whether THIS step is timed (every stride-th step while armed)
+void ultr_prof_tick();
+// reserves a sample (start/stop event pair) for kernel `kid`; false when the pool is exhausted
 bool ultr_prof_take(int kid, hipEvent_t* a, hipEvent_t* b);
 
 struct UltrProfScope {
   hipEvent_t a, b;
   bool on;
   UltrProfScope(int k, hipStream_t) : a(nullptr), b(nullptr), on(false) {
-    if ((g_ultr_prof_mask >> k) & 1u) on = ultr_prof_take(k, &a, &b);
+    if (g_ultr_prof_live && ((g_ultr_prof_mask >> k) & 1u)) on = ultr_prof_take(k, &a, &b);
   }
 };
 

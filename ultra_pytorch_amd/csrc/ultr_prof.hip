@@ -6,6 +6,7 @@
 #include "../../include/ultr_hip.h"
 
 uint32_t g_ultr_prof_mask = 0;
+bool g_ultr_prof_live = false;
 
 namespace {
 struct Sample {
@@ -14,12 +15,16 @@ struct Sample {
 };
 std::vector<Sample> g_pool;
 size_t g_used = 0;
-uint64_t g_calls[ULTR_K_COUNT];
+uint64_t g_ticks = 0;
 int g_stride = 1;
 }  // namespace
 
+void ultr_prof_tick() {
+  if (g_ultr_prof_mask == 0) return;
+  g_ultr_prof_live = (g_ticks++ % (uint64_t)g_stride) == 0;
+}
+
 bool ultr_prof_take(int kid, hipEvent_t* a, hipEvent_t* b) {
-  if (g_stride > 1 && (g_calls[kid]++ % (uint64_t)g_stride) != 0) return false;
   if (g_used >= g_pool.size()) return false;
   Sample& s = g_pool[g_used++];
   s.kid = kid;
@@ -31,7 +36,8 @@ bool ultr_prof_take(int kid, hipEvent_t* a, hipEvent_t* b) {
 extern "C" int ultr_prof_enable(uint32_t kernel_mask, int32_t max_samples) {
   g_ultr_prof_mask = 0;
   g_used = 0;
-  for (int k = 0; k < ULTR_K_COUNT; ++k) g_calls[k] = 0;
+  g_ticks = 0;
+  g_ultr_prof_live = false;
   if (kernel_mask == 0) return 0;
   if (max_samples <= 0) return ULTR_E_BADARG;
   while (g_pool.size() < (size_t)max_samples) {
@@ -44,6 +50,7 @@ extern "C" int ultr_prof_enable(uint32_t kernel_mask, int32_t max_samples) {
     g_pool.push_back(s);
   }
   g_ultr_prof_mask = kernel_mask;
+  g_ultr_prof_live = true;  // stand-alone stage calls are always timed; ultr_train_step applies the stride
   return 0;
 }
 

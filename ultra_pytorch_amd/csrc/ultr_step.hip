@@ -5,9 +5,11 @@
 #include <stdint.h>
 
 #include "../../include/ultr_hip.h"
+#include "ultr_prof.h"
 
 extern "C" int ultr_train_step(const ultr_step_args* a, void* stream) {
   if (!a || !a->desc || !a->upd) return ULTR_E_BADARG;
+  ultr_prof_tick();
   int rc = ultr_dnn_forward(a->desc, a->params, a->wt, a->features, a->n_docs, a->docids, a->batch, a->list_size,
                             a->scores, a->saved, stream);
   if (rc) return rc;

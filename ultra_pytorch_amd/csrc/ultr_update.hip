@@ -32,25 +32,16 @@ __device__ __forceinline__ float opt_step(float p, float g, float* st, int opt, 
   return p - lr * (g / (sqrtf(s) + eps));
 }
 
-__global__ __launch_bounds__(256) void update_kernel(ultr_update_desc u, DnnPlan dp, float* __restrict__ params,
-                                                     float* __restrict__ state, const float* __restrict__ grads,
-                                                     float* __restrict__ aux, float* __restrict__ wt,
-                                                     const float* __restrict__ sumsq_part, int nsq,
-                                                     float* __restrict__ scalars_out) {
-  __shared__ float sm[4];
+// Everything after the gradient and the sum of squares are known: step scalars, clip, optimizer, k-major copy /
+// image, and (block 0) the per-position state.  EPT elements per thread: e_k = blockIdx*256*EPT + k*256 + tid.
+template <int EPT>
+__device__ __forceinline__ void update_body(const ultr_update_desc& u, const DnnPlan& dp, float* __restrict__ params,
+                                            float* __restrict__ state, const float* __restrict__ tail,
+                                            float* __restrict__ aux, float* __restrict__ wt, float ss,
+                                            const float (&g_raw_a)[EPT], const float (&p_old_a)[EPT],
+                                            const float (&s_old_a)[EPT], float* sm, float* __restrict__ scalars_out) {
   const int64_t P = u.n_params;
   const int L = u.list_size;
-  const float* tail = grads + P;
-  // this thread's element: issue its loads BEFORE the norm reduction so that the two memory round trips overlap
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const bool live = e < P;
-  const float g_raw = live ? grads[e] : 0.f;
-  const float p_old = live ? params[e] : 0.f;
-  const float s_old = (live && state != nullptr) ? state[e] : 0.f;
-  float ss = 0.f;
-#pragma unroll 8
-  for (int k = threadIdx.x; k < nsq; k += 256) ss += sumsq_part[k];
-  ss = block_sum256(ss, sm);
   const float loss_sum = tail[0], D = tail[1], loss2 = tail[2], D2 = tail[3];
   float gs = 1.0f, loss = loss_sum, rank_loss = 0.f, exam_loss = 0.f;
   switch (u.algo) {
@@ -80,9 +71,11 @@ __global__ __launch_bounds__(256) void update_kernel(ultr_update_desc u, DnnPlan
   const float norm = fabsf(gs) * sqrtf(ss);
   const float coef = (u.max_gradient_norm > 0.f) ? fminf(1.0f, u.max_gradient_norm / (norm + 1e-6f)) : 1.0f;
   const bool stateless = (u.algo == ULTR_ALGO_DLA);
-  {
-    // one element per thread: every load of the kernel is in flight at once (the step is latency-bound)
-    if (live) {
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int64_t e = ((int64_t)blockIdx.x * EPT + k) * 256 + threadIdx.x;
+    const float g_raw = g_raw_a[k], p_old = p_old_a[k], s_old = s_old_a[k];
+    if (e < P) {
       float g = g_raw * gs;
       g *= coef;
       float s_new = s_old;
@@ -98,10 +91,10 @@ __global__ __launch_bounds__(256) void update_kernel(ultr_update_desc u, DnnPlan
           const int K = dp.K[j], M = dp.M[j];
           if (e >= dp.off_w[j] && r < M * K) {
             int m = (int)((float)r * (1.0f / (float)K));  // r / K without the integer divide; fix the +-1
-            int k = r - m * K;
-            if (k < 0) { --m; k += K; }
-            if (k >= K) { ++m; k -= K; }
-            wt[dp.wt_off[j] + (int64_t)k * M + m] = pn;
+            int kk = r - m * K;
+            if (kk < 0) { --m; kk += K; }
+            if (kk >= K) { ++m; kk -= K; }
+            wt[dp.wt_off[j] + (int64_t)kk * M + m] = pn;
             hidden_w = true;
             break;
           }
@@ -167,6 +160,26 @@ __global__ __launch_bounds__(256) void update_kernel(ultr_update_desc u, DnnPlan
     scalars_out[6] = pnorm;
     scalars_out[7] = ss;
   }
+}
+
+__global__ __launch_bounds__(256) void update_kernel(ultr_update_desc u, DnnPlan dp, float* __restrict__ params,
+                                                     float* __restrict__ state, const float* __restrict__ grads,
+                                                     float* __restrict__ aux, float* __restrict__ wt,
+                                                     const float* __restrict__ sumsq_part, int nsq,
+                                                     float* __restrict__ scalars_out) {
+  __shared__ float sm[4];
+  const int64_t P = u.n_params;
+  // this thread's element: issue its loads BEFORE the norm reduction so that the two memory round trips overlap
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = e < P;
+  const float g_raw[1] = {live ? grads[e] : 0.f};
+  const float p_old[1] = {live ? params[e] : 0.f};
+  const float s_old[1] = {(live && state != nullptr) ? state[e] : 0.f};
+  float ss = 0.f;
+#pragma unroll 8
+  for (int k = threadIdx.x; k < nsq; k += 256) ss += sumsq_part[k];
+  ss = block_sum256(ss, sm);
+  update_body<1>(u, dp, params, state, grads + P, aux, wt, ss, g_raw, p_old, s_old, sm, scalars_out);
 }
 
 extern "C" int ultr_apply_update(const ultr_update_desc* u, const ultr_dnn_desc* d, float* params, float* wt, float* state,
