@@ -66,8 +66,25 @@ __device__ __forceinline__ float wave_max(float v) {
 //   elu  (alpha 1): a = z > 0 ? z : expm1(z)   (torch.s CPU ELU kernel uses expm1 - verified numerically);
 //                   act'(z) = z > 0 ? 1 : exp(z) = a + 1
 //   relu          : act'(z) = a > 0
+// expm1 for z <= 0 in ~14 VALU instructions, both sides evaluated (no divergence): near zero the degree-8 Taylor
+// polynomial (|z| <= 0.35: truncation 0.35^8/9! relative = 4e-10), elsewhere exp(z) - 1 where the subtraction is
+// benign (|result| >= 0.29) and v_exp_f32's ~1 ulp is far inside the parity bar.  OCML's expm1f is ~3x the
+// instructions; at 4 cycles of SIMD time per wave64 VALU instruction the ELU epilogue was ~1k cycles per layer.
+__device__ __forceinline__ float expm1_neg(float z) {
+  float p = 2.4801587e-5f;          // 1/8!
+  p = fmaf(p, z, 1.9841270e-4f);    // 1/7!
+  p = fmaf(p, z, 1.3888889e-3f);    // 1/6!
+  p = fmaf(p, z, 8.3333333e-3f);    // 1/5!
+  p = fmaf(p, z, 4.1666667e-2f);    // 1/4!
+  p = fmaf(p, z, 1.6666667e-1f);    // 1/3!
+  p = fmaf(p, z, 0.5f);
+  p = fmaf(p, z, 1.0f);
+  p *= z;
+  const float e = __expf(z) - 1.0f;
+  return z > -0.35f ? p : e;
+}
 __device__ __forceinline__ float act_fwd(float z, int act) {
-  if (act == 0) return z > 0.0f ? z : expm1f(z);
+  if (act == 0) return z > 0.0f ? z : expm1_neg(z);
   return fmaxf(z, 0.0f);
 }
 __device__ __forceinline__ float act_grad_from_out(float a, int act) {
@@ -157,6 +174,14 @@ __device__ __forceinline__ float ld1_sel(const Src& s, int64_t idx, bool ok) {
   } else {
     return ok ? s.base[idx] : 0.f;
   }
+}
+
+// 1/sqrt(x): v_rsq_f32 (1 ulp) + one Newton step.  The IEEE sequence 1.0f / sqrtf(x) costs ~45 VALU instructions per
+// value (two v_div_* fix-up chains); a wave64 VALU instruction occupies its SIMD for 4 cycles, so in the latency-bound
+// LayerNorm phases instruction count is time.
+__device__ __forceinline__ float rsqrt_nr(float x) {
+  const float y = __builtin_amdgcn_rsqf(x);
+  return y * (1.5f - 0.5f * x * y * y);
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence + s_barrier and hipcc

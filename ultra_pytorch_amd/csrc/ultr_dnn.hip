@@ -640,6 +640,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
       // layer, M = 1) is folded in:  score = rstd * sum_c (x_c - mean) gamma_c w_c + sum_c beta_c w_c + b
       constexpr int RPW = (R + NW - 1) / NW;
       const bool last = (j == p.nl - 1);
+      const float invK = 1.0f / (float)K;
       const float* wl = PV + pv_off;  // the scorer's weight row (valid when last)
       float g[4], be[4];
 #pragma unroll
@@ -672,7 +673,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
       float v[RPW], t[RPW + 1];
 #pragma unroll
       for (int q = 0; q < RPW; ++q) {
-        s[q] /= (float)K;  // mean
+        s[q] *= invK;  // mean
         v[q] = 0.f;
         t[q] = 0.f;
 #pragma unroll
@@ -693,7 +694,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
       for (int q = 0; q < RPW; ++q) {
         const int r = wave + NW * q;
         if (r < R) {
-          const float rstd = 1.0f / sqrtf(v[q] / (float)K + ULTR_LN_EPS);
+          const float rstd = rsqrt_nr(v[q] * invK + ULTR_LN_EPS);
           if (!last) {
             float* row = X + r * ld;
 #pragma unroll
@@ -1417,6 +1418,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
     {
       const float* gs = sm_g2 + par * ldu;
       const float* bs = sm_b2 + par * ldu;
+      const float invK = 1.0f / (float)K;
       float mean[RPW], rstd[RPW], dsr[RPW];
 #pragma unroll
       for (int k = 0; k < RPW; ++k) {
@@ -1475,7 +1477,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
         for (int k = 0; k < RPW; ++k) {
           const int r = wave + NW * k;
           const int64_t n = n0 + r;
-          const float s1 = red[k] / (float)K, s2 = red[RPW + k] / (float)K;
+          const float s1 = red[k] * invK, s2 = red[RPW + k] * invK;
 #pragma unroll
           for (int u = 0; u < XC; ++u) {
             const int c = 4 * lane + 256 * u;
@@ -1855,7 +1857,9 @@ bool ultr_make_dnn_plan(const ultr_dnn_desc* d, int64_t N, DnnPlan* p) {
       p->bwd_nch[j] = nch;
       p->bwd_msplit[j] = ms;
       p->bwd_mlen[j] = round_up((M + ms - 1) / ms, 32);
-      p->bwd_mode[j] = (ms > 1 && ((K + 31) >> 5) >= NWP) ? 1 : (ms == 1 ? 2 : 3);
+      // 32-column chunks over the whole contraction as soon as they occupy more than half of the waves: no partial-
+      // tile rounds, and for a ragged width (136 = 4 x 32 + 8) far fewer wasted columns than 64-column chunks
+      p->bwd_mode[j] = (ms > 1 && 2 * ((K + 31) >> 5) > NWP) ? 1 : (ms == 1 ? 2 : 3);
     }
   }
   int64_t wt = 0;
