@@ -594,7 +594,8 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
 
   int pv_off = 0;
   for (int j = 0; j < p.nl; ++j) {
-    const int K = p.K[j], M = p.M[j];
+    const DnnPlan::FwdLayer lay = p.fl[j];  // one 64-byte scalar load for everything about this layer
+    const int K = lay.K, M = lay.M;
     const int K16 = round_up(K, 32);  // zero-padded width of the A tile (multiple of 32, see gemm_nn)
     const float* lnw = PV + pv_off;
     const float* lnb = PV + pv_off + K;
@@ -610,11 +611,11 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
     GemmPipe<RT, 2, FWD_D, 0> pipe;
     if constexpr (VEC) {
       if (j < p.nl - 1) {
-        Wt = make_src(wt + p.wt_off[j], (int64_t)K * M);
+        Wt = make_src(wt + lay.wt_off, (int64_t)K * M);
         int klen = K;
         if constexpr (NW == 8) {
-          ksplit = p.fwd_ksplit[j];
-          klen = p.fwd_klen[j];
+          ksplit = lay.ksplit;
+          klen = lay.klen;
         } else {
           while (ksplit * 2 * nch <= NW) ksplit *= 2;
           klen = round_up((K + ksplit - 1) / ksplit, 32);
@@ -705,8 +706,8 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
           }
           if (lane == 0 && n0 + r < N) {
             if (saved != nullptr) {
-              saved[p.sv_mean[j] + n0 + r] = s[q];
-              saved[p.sv_rstd[j] + n0 + r] = rstd;
+              saved[lay.sv_mean + n0 + r] = s[q];
+              saved[lay.sv_rstd + n0 + r] = rstd;
             }
             if (last) scores[n0 + r] = rstd * t[q] + t[RPW] + bias[0];
           }
@@ -728,17 +729,17 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
         const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)K + ULTR_LN_EPS);
         for (int c = lane; c < K16; c += 64) row[c] = (c < K) ? ((row[c] - mean) * rstd * lnw[c] + lnb[c]) : 0.f;
         if (saved != nullptr && lane == 0 && n0 + r < N) {
-          saved[p.sv_mean[j] + n0 + r] = mean;
-          saved[p.sv_rstd[j] + n0 + r] = rstd;
+          saved[lay.sv_mean + n0 + r] = mean;
+          saved[lay.sv_rstd + n0 + r] = rstd;
         }
       }
     }
     lds_barrier();
     TRACE_STAMP(2 + 3 * j);
-    const float* W = params + p.off_w[j];
+    const float* W = params + lay.off_w;
     if (j < p.nl - 1) {
       // ---- Linear + activation on the matrix cores ------------------------------------------------
-      float* gout = (saved != nullptr) ? (saved + p.sv_x[j + 1] + n0 * M) : nullptr;
+      float* gout = (saved != nullptr) ? (saved + lay.sv_x_next + n0 * M) : nullptr;
       if constexpr (VEC) {
         // Y = act(X . W^T + b) on the k-major weight copy.  (Issuing the first trips before the LayerNorm was
         // measured SLOWER: hipcc then drains vmcnt(0) inside the LayerNorm / epilogue code, see DESIGN.md.)
@@ -1889,6 +1890,14 @@ bool ultr_make_dnn_plan(const ultr_dnn_desc* d, int64_t N, DnnPlan* p) {
     p->sv_rstd[j] = sv; sv += N;
   }
   p->sv_total = sv;
+  for (int j = 0; j < p->nl; ++j) {
+    DnnPlan::FwdLayer& l = p->fl[j];
+    l.K = p->K[j]; l.M = p->M[j];
+    l.ksplit = p->fwd_ksplit[j]; l.klen = p->fwd_klen[j]; l.nch = (p->M[j] + 31) >> 5; l.pad = 0;
+    l.wt_off = p->wt_off[j]; l.sv_mean = p->sv_mean[j]; l.sv_rstd = p->sv_rstd[j];
+    l.sv_x_next = (j + 1 < p->nl) ? p->sv_x[j + 1] : 0;
+    l.off_w = p->off_w[j];
+  }
   return true;
 }
 

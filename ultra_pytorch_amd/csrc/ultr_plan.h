@@ -35,6 +35,13 @@ struct DnnPlan {
   // Backward du_j = dz_j.W_j: bwd_mode 1 = 32-column chunks of K_j, 2 = 64-column chunks, 3 = 64-column chunks x
   // bwd_msplit slices of the contraction M_j (slice length bwd_mlen).
   int fwd_ksplit[ULTR_MAXL], fwd_klen[ULTR_MAXL], fwd_nch[ULTR_MAXL];
+  // everything the forward kernel needs about layer j, in ONE 64-byte record: `const FwdLayer l = p.fl[j]` is a single
+  // s_load_dwordx16 at the top of the layer (scattered p.X[j] reads were a dependent scalar load + wait each, ~1k
+  // cycles per layer in the latency-bound phases)
+  struct FwdLayer {
+    int K, M, ksplit, klen, nch, pad;
+    int64_t wt_off, sv_mean, sv_rstd, sv_x_next, off_w;
+  } fl[ULTR_MAXL];
   int bwd_mode[ULTR_MAXL], bwd_msplit[ULTR_MAXL], bwd_mlen[ULTR_MAXL], bwd_nch[ULTR_MAXL];
   // saved-for-backward workspace (floats): xs[j] = input of LayerNorm_j, j >= 1; stats for all j
   int64_t sv_x[ULTR_MAXL];     // [N, K_j]   (j >= 1)
