@@ -33,7 +33,10 @@ LR, CLIP = 0.05, 5.0
 POOL = 16  # pre-staged batches per rank, cycled
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E spec peak
-KNAMES = ["dnn_fwd_kernel", "softmax_ce_kernel", "dnn_bwd_kernel", "dnn_wgrad_kernel", "grad_reduce_kernel", "update_kernel"]
+# profiling slots of the library (ultr_prof.h); slot 7 = forward + loss + backward fused in one launch (small batches)
+KNAMES = ["dnn_fwd_kernel", "softmax_ce_kernel", "dnn_bwd_kernel", "dnn_wgrad_kernel", "grad_reduce_kernel", "update_kernel",
+          "ndcg_list_kernel", "dnn_fb_kernel"]
+KSLOTS = [0, 1, 2, 3, 4, 5, 7]
 
 
 def algorithmic_work(P):
@@ -54,6 +57,7 @@ def algorithmic_work(P):
         3: ("mfma", 2.0 * N * s_hidden),
         4: ("hbm", 4.0 * P),  # the flat gradient written once (slab re-reads are overhead, not algorithmic)
         5: ("hbm", 4.0 * 5 * P),  # read g, read+write Adagrad sum, read+write params
+        7: ("mfma", 2.0 * N * s_all + 2.0 * N * (s_all - dims[0][0] * dims[0][1])),  # forward + dgrad in one launch
     }
 
 
@@ -166,19 +170,19 @@ def main():
     barrier()
     tot, cnt = (ctypes.c_double * 8)(), (ctypes.c_int64 * 8)()
     ncal = 50
-    _lib.check(lib.ultr_prof_enable(0x3F, 8 * ncal), "ultr_prof_enable")
+    _lib.check(lib.ultr_prof_enable(0xBF, 8 * ncal), "ultr_prof_enable")
     for i in range(ncal):
         step(i)
     torch.cuda.synchronize()
     _lib.check(lib.ultr_prof_collect(tot, cnt), "ultr_prof_collect")
-    cal_us = [1e3 * tot[k] / max(cnt[k], 1) for k in range(6)]
+    cal_us = [1e3 * tot[k] / max(cnt[k], 1) for k in range(8)]
     dom = int(np.argmax(cal_us))
     # ---- the timed region: EXACTLY K steps, dominant kernel event-timed inside it -------------------
     # every kernel of the step is timed inside the timed region on every 8th step, by the start/stop timestamps of its
     # own dispatch packet (what rocprofv3 --kernel-trace reports; timing ONE kernel only would add the wait for its
     # predecessor's tail to its start stamp)
     _lib.check(lib.ultr_prof_set_stride(8), "ultr_prof_set_stride")
-    _lib.check(lib.ultr_prof_enable(0x3F, 6 * (args.steps // 8 + 2)), "ultr_prof_enable")
+    _lib.check(lib.ultr_prof_enable(0xBF, 7 * (args.steps // 8 + 2)), "ultr_prof_enable")
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -189,7 +193,7 @@ def main():
     lib.ultr_prof_enable(0, 0)
     dom_s = 1e-3 * tot[dom] / max(cnt[dom], 1)
     dom_samples = int(cnt[dom])
-    timed_us = [1e3 * tot[k] / max(cnt[k], 1) for k in range(6)]
+    timed_us = [1e3 * tot[k] / max(cnt[k], 1) for k in range(8)]
     lib.ultr_prof_set_stride(1)
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=device)
     if pg is not None:
@@ -265,7 +269,7 @@ def main():
                          "frac": achieved / peak, "traffic": traffic, "avg_launch_us": 1e6 * dom_s,
                          "launches_timed": dom_samples,
                          "algorithmic_per_launch": amount},
-            "kernel_us": {KNAMES[k]: round(timed_us[k], 3) for k in range(6)},
+            "kernel_us": {KNAMES[k]: round(timed_us[k], 3) for k in KSLOTS if cnt[k] > 0},
             "final_loss": final_loss,
         }
         if synced is not None:

@@ -275,3 +275,38 @@ def test_fused_softmax_backward(name):
     assert np.array_equal(g[:P], g_ref)
     np.testing.assert_allclose(g[P:P + 2], tail_ref[:2], rtol=1e-6)
     assert np.all(g[P + 2:] == 0)
+
+
+@pytest.mark.parametrize("B,L,F,hidden", [(256, 10, 136, [256, 256]), (37, 7, 24, [16, 8]), (64, 16, 136, [512, 256, 128]),
+                                          (50, 5, 136, [32, 16]), (9, 1, 8, [8])])
+def test_fused_forward_backward_step(B, L, F, hidden, monkeypatch):
+    """ultr_train_step picks ONE fused forward+loss+backward launch for small NA/IPW batches (list_size <= 16): it must
+    produce what the separate kernels produce (scores, loss, gradient, updated parameters) - and what the oracle says."""
+    from oracle import ultr_oracle as O
+    from ultra_pytorch_amd import engine, hip_ops, synthetic
+    from ultra_pytorch_amd.ranking_model import init_flat_params
+    shape = hip_ops.DnnShape(F, hidden, "elu")
+    rng = np.random.RandomState(5)
+    feats, ids, y = synthetic.make_batch(rng, B, L, F)
+    ipw = np.asarray(synthetic.load_ipw(), np.float32)
+    p0 = init_flat_params(shape, seed=3).numpy()
+    out = {}
+    for mode in ("fused", "separate"):
+        monkeypatch.setenv("ULTR_NO_FUSED_FB", "0" if mode == "fused" else "1")
+        eng = engine.StepEngine(shape, B, L, torch.device("cuda"), algo="softmax", learning_rate=0.05, max_gradient_norm=5.0)
+        params, state = dev(p0.copy()), dev(np.zeros_like(p0))
+        sc = eng.train_step(params, state, dev(feats), feats.shape[0], dev(ids, torch.int32), dev(y), ipw_table=dev(ipw))
+        torch.cuda.synchronize()
+        out[mode] = dict(scores=eng.scores.cpu().numpy().copy(), grads=eng.grads.cpu().numpy().copy(),
+                         params=params.cpu().numpy().copy(), scalars=sc.cpu().numpy().copy())
+    f, s = out["fused"], out["separate"]
+    np.testing.assert_allclose(f["scores"], s["scores"], atol=2e-6, rtol=1e-6)
+    gmax = float(np.abs(s["grads"][: shape.n_params]).max())
+    np.testing.assert_allclose(f["grads"], s["grads"], rtol=1e-5, atol=1e-6 * max(1.0, gmax))
+    np.testing.assert_allclose(f["scalars"][:4], s["scalars"][:4], rtol=1e-5, atol=1e-6)
+    r = O.train_step_softmax(p0, np.zeros_like(p0), F, hidden, feats, ids, y, ipw_list=ipw, lr=0.05, max_norm=5.0)
+    np.testing.assert_allclose(f["scores"], r["scores"], atol=1e-5)
+    assert abs(float(f["scalars"][0]) - r["loss"]) <= 1e-5 * max(1.0, abs(r["loss"]))
+    gs = 1.0 / float(f["scalars"][3])
+    np.testing.assert_allclose(f["grads"][: shape.n_params] * gs, r["grads"], rtol=1e-5,
+                               atol=1e-6 * max(1.0, float(np.abs(r["grads"]).max())))

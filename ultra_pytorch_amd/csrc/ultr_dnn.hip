@@ -1505,6 +1505,451 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
 }
 
 // ------------------------------------------------------------------------------------------------
+// Forward + NA/IPW loss + row-local backward in ONE launch (small batches: the latency regime)
+// ------------------------------------------------------------------------------------------------
+// A workgroup owns LPB = 16 / L WHOLE lists (RB = LPB * L rows of its 16-row MFMA tile), so the listwise loss is
+// local to it and the three stages chain inside one kernel: every activation tile x_j stays in LDS from the forward
+// to the backward (the copies in `saved` are still written - the weight-gradient kernel reads them), the backward
+// needs no prologue of its own (ids, scores, labels, tiles, statistics, gamma/beta are all on chip already), and one
+// launch + one dependent kernel boundary disappear.  Same arithmetic as dnn_fwd_kernel + dnn_bwd2_kernel (shared
+// building blocks), same outputs: scores, saved, dz_j, vector slabs, loss partials (one per workgroup).
+// Chosen only when the batch has at most ~2 workgroups per CU: with B >= 1024 the unfused kernels fill their 16-row
+// tiles completely (here RB/16 of a tile is live) and win on throughput.
+__host__ __device__ static inline size_t fb_lds_floats(const DnnPlan& p) {
+  const size_t ld = fwd_ld(p.maxdim), ldu = bwd_ldu(p.maxdim);
+  return (size_t)16 * ld * (p.nl + 1) + 16 * ldu + (size_t)8 * bwd2_cp_stride(p) + (size_t)p.pv_total + 2 * 16 * (size_t)p.nl +
+         2 * 16 + 2 * 8 + 8;
+}
+
+template <int XC>
+__global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, const float* __restrict__ params,
+                                                     const float* __restrict__ wt, const float* __restrict__ features,
+                                                     int64_t n_docs, const int32_t* __restrict__ docids, int B, int L,
+                                                     int LPB, float* __restrict__ scores, float* __restrict__ saved,
+                                                     float* __restrict__ ws, FusedSoftmax fl) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int R = 16, NW = 8, RT = 1, NT = NW * 64, RPW = R / NW;
+  const int64_t N = (int64_t)B * L;
+  const int ld = fwd_ld(p.maxdim), ldu = bwd_ldu(p.maxdim), ldz = ld;
+  const int cpw = bwd2_cp_stride(p);
+  float* XSall = smem;                          // [nl][16][ld]   x_j = input of LayerNorm_j, j = 0..nl-1
+  float* UZ = XSall + (size_t)p.nl * R * ld;    // [16][ld]       forward: LayerNorm output (A tile); backward: dz (A tile)
+  float* DU = UZ + R * ld;                      // [16][ldu]
+  float* CP = DU + R * ldu;                     // [NW][cpw]
+  float* PV = CP + NW * cpw;                    // [pv_total]     every vector parameter (the packed image)
+  float* sm_mean = PV + p.pv_total;             // [nl][16]
+  float* sm_rstd = sm_mean + p.nl * R;          // [nl][16]
+  float* sm_s = sm_rstd + p.nl * R;             // [16] scores
+  float* sm_ds = sm_s + R;                      // [16]
+  float* sm_lt = sm_ds + R;                     // [NW][2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int RB = LPB * L;                       // live rows of this block
+  const int64_t n0 = (int64_t)blockIdx.x * RB;
+  const int b_first = blockIdx.x * LPB;
+  const int rows_valid = (int)((N - n0) < RB ? (N - n0) : RB);
+  float* vslab = ws + bp.vslab_off + (int64_t)blockIdx.x * bp.vlen;
+  const int top = p.nl - 1;
+  TRACE_STAMP(0);
+
+  // ---- prologue: ids, loss inputs of this wave's list, parameter image, feature rows - all issued back to back -----
+  {
+    constexpr int PVR = 3, FCH = XC;
+    const int F = p.K[0];
+    const int rme = wave + NW * (lane < RPW ? lane : 0);
+    const bool idok = lane < RPW && rme < rows_valid;
+    const uint32_t nme = idok ? (uint32_t)(n0 + rme) : 0u;
+    const int myid_raw = docids[(int64_t)(nme % (uint32_t)L) * B + (nme / (uint32_t)L)];
+    const Src pvs = make_src(wt + p.wt_pv_off, p.pv_total);
+    float4 pvr[PVR];
+#pragma unroll
+    for (int u = 0; u < PVR; ++u) pvr[u] = buf_ld4(pvs, (unsigned)(tid + u * NT) * 16u);
+    const int myid = (idok && myid_raw >= 0 && myid_raw < n_docs) ? myid_raw : -1;
+    const Src fs = make_src(features, n_docs * F);
+    float4 fr[RPW][FCH];
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+      const int id = __builtin_amdgcn_readlane(myid, k);
+#pragma unroll
+      for (int u = 0; u < FCH; ++u) {
+        const int c = lane * 4 + 256 * u;
+        fr[k][u] = buf_ld4(fs, (id >= 0 && c < F) ? (unsigned)(((int64_t)id * F + c) * 4) : ULTR_OOB);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PVR; ++u) {
+      const int o = (tid + u * NT) * 4;
+      if (o < p.pv_total) st4(PV + o, pvr[u]);
+    }
+#pragma unroll
+    for (int k = 0; k < RPW; ++k)
+#pragma unroll
+      for (int u = 0; u < FCH; ++u) {
+        const int c = lane * 4 + 256 * u;
+        if (c < F) st4(XSall + (wave + NW * k) * ld + c, fr[k][u]);
+      }
+    if (tid < R) sm_ds[tid] = 0.f;
+    if (lane < 2) sm_lt[wave * 2 + lane] = 0.f;
+  }
+  // loss inputs of the wave's first list (lane = position), in flight during the whole forward
+  const int li0 = wave;  // list index inside the block handled by this wave (then + NW)
+  const bool lact0 = li0 < LPB && b_first + li0 < B && lane < L;
+  float y0 = 0.f, pw0 = 1.0f;
+  if (lact0) {
+    const int b = b_first + li0;
+    y0 = fl.labels[(int64_t)lane * B + b];
+    if (fl.pw != nullptr) pw0 = fl.pw[(int64_t)b * L + lane];
+    else if (fl.ipw != nullptr) pw0 = fl.ipw[lane < fl.n_ipw ? lane : fl.n_ipw - 1];
+  }
+  lds_barrier();
+  TRACE_STAMP(1);
+
+  // =================================== forward ===================================
+  for (int j = 0; j < p.nl; ++j) {
+    const DnnPlan::FwdLayer lay = p.fl[j];
+    const int K = lay.K, M = lay.M;
+    const int K32 = round_up(K, 32);
+    const bool last = (j == top);
+    const float* XS = XSall + (size_t)j * R * ld;
+    const float* gs = PV + p.pv_off[j];
+    const float* bs = gs + K;
+    const float* bias = bs + K;
+    const float* wlp = PV + p.pv_wlast;
+    const float invK = 1.0f / (float)K;
+    // ---- LayerNorm_j: XS_j -> UZ (zero-padded to a multiple of 32 columns); the scorer folded into the last one ----
+    {
+      float4 x[RPW][XC], g4[XC], b4[XC];
+      float s[RPW];
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < XC; ++u) {
+        const int c = 4 * lane + 256 * u;
+        g4[u] = (c < K) ? ld4(gs + c) : z4;
+        b4[u] = (c < K) ? ld4(bs + c) : z4;
+        if (last) {
+          const float4 w4 = (c < K) ? ld4(wlp + c) : z4;
+          g4[u].x *= w4.x; g4[u].y *= w4.y; g4[u].z *= w4.z; g4[u].w *= w4.w;
+          b4[u].x *= w4.x; b4[u].y *= w4.y; b4[u].z *= w4.z; b4[u].w *= w4.w;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < RPW; ++q) {
+        const int r = wave + NW * q;
+        s[q] = 0.f;
+#pragma unroll
+        for (int u = 0; u < XC; ++u) {
+          const int c = 4 * lane + 256 * u;
+          x[q][u] = (c < K) ? ld4(XS + r * ld + c) : z4;
+          s[q] += (x[q][u].x + x[q][u].y) + (x[q][u].z + x[q][u].w);
+        }
+      }
+      wave_sum_n<RPW>(s);
+      float v[RPW], t[RPW + 1];
+#pragma unroll
+      for (int q = 0; q < RPW; ++q) {
+        s[q] *= invK;
+        v[q] = 0.f;
+        t[q] = 0.f;
+#pragma unroll
+        for (int u = 0; u < XC; ++u) {
+          const int c = 4 * lane + 256 * u;
+          float4& xx = x[q][u];
+          if (c < K) {
+            xx.x -= s[q]; xx.y -= s[q]; xx.z -= s[q]; xx.w -= s[q];
+          }
+          v[q] += (xx.x * xx.x + xx.y * xx.y) + (xx.z * xx.z + xx.w * xx.w);
+          t[q] += (xx.x * g4[u].x + xx.y * g4[u].y) + (xx.z * g4[u].z + xx.w * g4[u].w);
+        }
+      }
+      wave_sum_n<RPW>(v);
+      if (last) {
+        t[RPW] = 0.f;
+#pragma unroll
+        for (int u = 0; u < XC; ++u) t[RPW] += (b4[u].x + b4[u].y) + (b4[u].z + b4[u].w);
+        wave_sum_n<RPW + 1>(t);
+      }
+#pragma unroll
+      for (int q = 0; q < RPW; ++q) {
+        const int r = wave + NW * q;
+        const float rstd = rsqrt_nr(v[q] * invK + ULTR_LN_EPS);
+        if (!last) {
+#pragma unroll
+          for (int u = 0; u < XC; ++u) {
+            const int c = 4 * lane + 256 * u;
+            if (c < K32) {
+              const float4 xx = x[q][u];
+              st4(UZ + r * ld + c, make_float4(xx.x * rstd * g4[u].x + b4[u].x, xx.y * rstd * g4[u].y + b4[u].y,
+                                               xx.z * rstd * g4[u].z + b4[u].z, xx.w * rstd * g4[u].w + b4[u].w));
+            }
+          }
+        }
+        if (lane == 0) {
+          const bool valid = r < rows_valid;
+          sm_mean[j * R + r] = valid ? s[q] : 0.f;
+          sm_rstd[j * R + r] = valid ? rstd : 0.f;
+          if (valid) {
+            saved[lay.sv_mean + n0 + r] = s[q];
+            saved[lay.sv_rstd + n0 + r] = rstd;
+          }
+          if (last) {
+            const float sc = rstd * t[q] + t[RPW] + bias[0];
+            sm_s[r] = sc;
+            if (valid) scores[n0 + r] = sc;
+          }
+        }
+      }
+    }
+    lds_barrier();
+    TRACE_STAMP(2 + 2 * j);
+    if (!last) {
+      // ---- Linear_j + activation: UZ . WT_j -> XS_{j+1} (LDS) and saved x_{j+1} (HBM, for the weight gradients) ----
+      float* Y = XSall + (size_t)(j + 1) * R * ld;
+      float* gout = saved + lay.sv_x_next + n0 * M;
+      const Src Wt = make_src(wt + lay.wt_off, (int64_t)K * M);
+      const int nch = lay.nch, ksplit = lay.ksplit, klen = lay.klen;
+      GemmPipe<RT, 2, FWD_D, 0> pipe;
+      if (ksplit == 1) {
+        const int c0 = wave * 32;
+        pipe.begin(Wt, M, 0, K, c0, c0 < M, 0, lane);
+        for (int cc = c0; cc < M; cc += NW * 32) {
+          f32x4 acc[RT][2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) acc[0][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          pipe.run(UZ, ld, Wt, 0, K, 0, acc, lane);
+          if (cc + NW * 32 < M) pipe.begin(Wt, M, 0, K, cc + NW * 32, true, 0, lane);
+          finish_fwd_nn<RT, 2>(acc, Y, ld, M, cc, lane, bias, p.act, gout, rows_valid);
+        }
+      } else {
+        int wq = 0, wr = wave;
+        while (wr >= nch) { wr -= nch; ++wq; }
+        const int c0 = wr * 32, kb = wq * klen;
+        const int ke = (kb + klen < K) ? (kb + klen) : K;
+        const bool has = wave < nch * ksplit && kb < ke;
+        pipe.begin(Wt, M, kb, ke, c0, has, 0, lane);
+        f32x4 acc[RT][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[0][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (has) pipe.run(UZ, ld, Wt, kb, ke, 0, acc, lane);
+        for (int r = 0; r < ksplit; ++r) {
+          if (wave < nch * ksplit && wq == r) store_nn<RT, 2>(acc, Y, ld, M, c0, lane, r > 0);
+          lds_barrier();
+        }
+        const int M4 = M >> 2;
+        for (int e = tid; e < R * M4; e += NT) {
+          const int row = e / M4, c4 = (e - row * M4) * 4;
+          float4 vv = ld4(Y + row * ld + c4);
+          const float4 bb = ld4(bias + c4);
+          vv.x = act_fwd(vv.x + bb.x, p.act);
+          vv.y = act_fwd(vv.y + bb.y, p.act);
+          vv.z = act_fwd(vv.z + bb.z, p.act);
+          vv.w = act_fwd(vv.w + bb.w, p.act);
+          st4(Y + row * ld + c4, vv);
+          if (row < rows_valid) st4(gout + (int64_t)row * M + c4, vv);
+        }
+      }
+      lds_barrier();
+      TRACE_STAMP(3 + 2 * j);
+    }
+  }
+
+  // =================================== listwise softmax cross entropy ===================================
+  for (int li = li0; li < LPB; li += NW) {
+    const int b = b_first + li;
+    if (b >= B) break;
+    const bool act = lane < L;
+    float y = y0, pwt = pw0;
+    if (li != li0 && act) {
+      y = fl.labels[(int64_t)lane * B + b];
+      pwt = 1.0f;
+      if (fl.pw != nullptr) pwt = fl.pw[(int64_t)b * L + lane];
+      else if (fl.ipw != nullptr) pwt = fl.ipw[lane < fl.n_ipw ? lane : fl.n_ipw - 1];
+    }
+    if (fl.pw == nullptr && fl.ipw != nullptr && !(y > 0.f)) pwt = 0.f;
+    const int r = li * L + lane;
+    const float sc = act ? sm_s[r] : 0.f;
+    const float w = act ? (y + 0.0000001f) * pwt : 0.f;
+    const float mx = wave_max(act ? sc : -INFINITY);
+    const float S = wave_sum(w);
+    const float lse = mx + logf(wave_sum(act ? expf(sc - mx) : 0.f));
+    const float dsv = expf(sc - lse) * S - w;
+    const float lb = wave_sum(act ? w * (lse - sc) : 0.f);
+    if (act) {
+      sm_ds[r] = dsv;
+      if (fl.dscores_out != nullptr) fl.dscores_out[n0 + r] = dsv;
+    }
+    if (lane == 0) {
+      sm_lt[wave * 2 + 0] += lb;
+      sm_lt[wave * 2 + 1] += S;
+    }
+  }
+  lds_barrier();
+  {
+    const int tail = (int)ultr_tail_len(L);
+    for (int t = tid; t < tail; t += NT) {
+      float v = 0.f;
+      if (t < 2)
+        for (int w = 0; w < NW; ++w) v += sm_lt[w * 2 + t];
+      fl.loss_part[(int64_t)blockIdx.x * tail + t] = v;
+    }
+  }
+  TRACE_STAMP(16);
+
+  // =================================== backward (as dnn_bwd2_kernel, tiles already on chip) ===================================
+  auto finalize = [&](int jj) {
+    const int K = p.K[jj], K4 = round_up(K, 4);
+    const bool lastl = (jj == top);
+    for (int c = tid; c < K; c += NT) {
+      float pg = 0.f, pb = 0.f, pw = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        pg += CP[w * cpw + c];
+        pb += CP[w * cpw + K4 + c];
+        if (lastl) pw += CP[w * cpw + 2 * K4 + c];
+      }
+      vslab[bp.voff_g[jj] + c] = pg;
+      vslab[bp.voff_b[jj] + c] = pb;
+      if (lastl) vslab[bp.voff_wk + c] = pw;
+    }
+    if (lastl && tid == 0) {
+      float sds = 0.f;
+      for (int r = 0; r < R; ++r) sds += sm_ds[r];
+      vslab[bp.voff_bk] = sds;
+    }
+  };
+  float* DZ = UZ;
+  for (int j = top; j >= 0; --j) {
+    const int K = p.K[j], M = p.M[j];
+    const bool last = (j == top);
+    if (!last) {
+      finalize(j + 1);
+      const Src Wsrc = make_src(params + p.off_w[j], (int64_t)M * K);
+      const int nch = p.bwd_nch[j], msplit = p.bwd_msplit[j], mode = p.bwd_mode[j];
+      if (mode == 1) {
+        for (int ch = wave; ch * 32 < K; ch += NW) {
+          f32x4 acc[RT][2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) acc[0][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          gemm_nn<RT, 2, true>(DZ, ldz, Wsrc, K, 0, M, ch * 32, acc, lane);
+          store_nn<RT, 2>(acc, DU, ldu, K, ch * 32, lane, false);
+        }
+      } else if (mode == 2) {
+        for (int ch = wave; ch < nch; ch += NW) {
+          f32x4 acc[RT][4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[0][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          gemm_nn<RT, 4, true>(DZ, ldz, Wsrc, K, 0, M, ch * 64, acc, lane);
+          store_nn<RT, 4>(acc, DU, ldu, K, ch * 64, lane, false);
+        }
+      } else {
+        const int mlen = p.bwd_mlen[j];
+        const bool has = wave < nch * msplit;
+        int ms = 0, ch = wave;
+        while (ch >= nch) { ch -= nch; ++ms; }
+        f32x4 acc[RT][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[0][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (has) {
+          const int mb = ms * mlen;
+          const int me = (mb + mlen < M) ? (mb + mlen) : M;
+          if (mb < me) gemm_nn<RT, 4, true>(DZ, ldz, Wsrc, K, mb, me, ch * 64, acc, lane);
+        }
+        for (int r = 0; r < msplit; ++r) {
+          if (has && ms == r) store_nn<RT, 4>(acc, DU, ldu, K, ch * 64, lane, r > 0);
+          if (r + 1 < msplit) lds_barrier();
+        }
+      }
+      TRACE_STAMP(17 + 4 * (top - j));
+      lds_barrier();
+    }
+    TRACE_STAMP(18 + 4 * (top - j));
+    {
+      const float* XS = XSall + (size_t)j * R * ld;
+      const float* gs = PV + p.pv_off[j];
+      const float* bs = gs + K;
+      const float* wlp = PV + p.pv_wlast;
+      const float invK = 1.0f / (float)K;
+      float mean[RPW], rstd[RPW], dsr[RPW];
+#pragma unroll
+      for (int k = 0; k < RPW; ++k) {
+        const int r = wave + NW * k;
+        mean[k] = sm_mean[j * R + r];
+        rstd[k] = sm_rstd[j * R + r];
+        dsr[k] = sm_ds[r];
+      }
+      float4 xk[RPW][XC], gxk[RPW][XC];
+      float red[2 * RPW];
+#pragma unroll
+      for (int k = 0; k < 2 * RPW; ++k) red[k] = 0.f;
+#pragma unroll
+      for (int u = 0; u < XC; ++u) {
+        const int c = 4 * lane + 256 * u;
+        const bool act = c < K;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 g4 = act ? ld4(gs + c) : z4;
+        const float4 be4 = (act && last) ? ld4(bs + c) : z4;
+        const float4 w4 = (act && last) ? ld4(wlp + c) : z4;
+        float4 pg = z4, pb = z4, pw = z4;
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+          const int r = wave + NW * k;
+          const float4 x4 = act ? ld4(XS + r * ld + c) : z4;
+          float4 du4;
+          if (last) du4 = make_float4(dsr[k] * w4.x, dsr[k] * w4.y, dsr[k] * w4.z, dsr[k] * w4.w);
+          else du4 = act ? ld4(DU + r * ldu + c) : z4;
+          const float4 xh = make_float4((x4.x - mean[k]) * rstd[k], (x4.y - mean[k]) * rstd[k],
+                                        (x4.z - mean[k]) * rstd[k], (x4.w - mean[k]) * rstd[k]);
+          const float4 gx = make_float4(du4.x * g4.x, du4.y * g4.y, du4.z * g4.z, du4.w * g4.w);
+          red[k] += (gx.x + gx.y) + (gx.z + gx.w);
+          red[RPW + k] += (gx.x * xh.x + gx.y * xh.y) + (gx.z * xh.z + gx.w * xh.w);
+          if (act) {
+            pg.x += du4.x * xh.x; pg.y += du4.y * xh.y; pg.z += du4.z * xh.z; pg.w += du4.w * xh.w;
+            pb.x += du4.x; pb.y += du4.y; pb.z += du4.z; pb.w += du4.w;
+            if (last) {
+              pw.x += dsr[k] * (g4.x * xh.x + be4.x); pw.y += dsr[k] * (g4.y * xh.y + be4.y);
+              pw.z += dsr[k] * (g4.z * xh.z + be4.z); pw.w += dsr[k] * (g4.w * xh.w + be4.w);
+            }
+          }
+          xk[k][u] = x4;
+          gxk[k][u] = gx;
+        }
+        if (act) {
+          const int K4 = round_up(K, 4);
+          st4(CP + wave * cpw + c, pg);
+          st4(CP + wave * cpw + K4 + c, pb);
+          if (last) st4(CP + wave * cpw + 2 * K4 + c, pw);
+        }
+      }
+      if (j > 0) {
+        wave_sum_n<2 * RPW>(red);
+        float* dzg = ws + bp.dz_off[j - 1];
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+          const int r = wave + NW * k;
+          const float s1 = red[k] * invK, s2 = red[RPW + k] * invK;
+#pragma unroll
+          for (int u = 0; u < XC; ++u) {
+            const int c = 4 * lane + 256 * u;
+            if (c < K) {
+              const float4 x4 = xk[k][u], gx = gxk[k][u];
+              float4 dz;
+              dz.x = rstd[k] * (gx.x - s1 - (x4.x - mean[k]) * rstd[k] * s2) * act_grad_from_out(x4.x, p.act);
+              dz.y = rstd[k] * (gx.y - s1 - (x4.y - mean[k]) * rstd[k] * s2) * act_grad_from_out(x4.y, p.act);
+              dz.z = rstd[k] * (gx.z - s1 - (x4.z - mean[k]) * rstd[k] * s2) * act_grad_from_out(x4.z, p.act);
+              dz.w = rstd[k] * (gx.w - s1 - (x4.w - mean[k]) * rstd[k] * s2) * act_grad_from_out(x4.w, p.act);
+              st4(DZ + r * ldz + c, dz);
+              if (r < rows_valid) st4(dzg + (n0 + r) * K + c, dz);
+            }
+          }
+          for (int c = K + lane; c < round_up(K, 32); c += 64) DZ[r * ldz + c] = 0.f;
+        }
+      }
+    }
+    TRACE_STAMP(19 + 4 * (top - j));
+    lds_barrier();
+  }
+  finalize(0);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Weight gradients of the hidden Linears: dW_j[m,k] = sum_n dz_j[n,m] u_j[n,k],  db_j[m] = sum_n dz_j[n,m]
 // ------------------------------------------------------------------------------------------------
 // Workgroup = 4 waves on ONE 64x64 output block; each wave contracts a different quarter of the block's row
@@ -1936,7 +2381,9 @@ bool ultr_make_bwd_plan(const DnnPlan& p, int64_t N, BwdPlan* bp) {
   const int64_t tail_max = 4096;  // generous: tail is 4 + 2L floats
   bp->n_red_blocks = (int)ultr_red_blocks(p.P, (int)tail_max);
   bp->sumsq_off = off; off += bp->n_red_blocks; off = (off + 3) & ~(int64_t)3;
-  bp->vslab_off = off; off += (int64_t)bp->nrb * bp->vlen; off = (off + 3) & ~(int64_t)3;
+  // sized for the finest row blocking any kernel uses (the fused forward+backward kernel owns >= 9 live rows per block)
+  const int64_t nrb_alloc = (N + 8) / 9 + 1 > bp->nrb ? (N + 8) / 9 + 1 : bp->nrb;
+  bp->vslab_off = off; off += nrb_alloc * bp->vlen; off = (off + 3) & ~(int64_t)3;
   bp->vred_off = off; off += bp->vlen; off = (off + 3) & ~(int64_t)3;
   bp->vred_blocks = (bp->vlen + 63) / 64;
   for (int j = 0; j < p.nl - 1; ++j) {
@@ -2130,7 +2577,9 @@ extern "C" int ultr_dnn_forward(const ultr_dnn_desc* d, const float* params, con
 
 static int backward_impl(const ultr_dnn_desc* d, const float* params, const float* features, int64_t n_docs,
                          const int32_t* docids, int32_t batch, int32_t list_size, const void* saved, const float* dscores,
-                         const void* loss_ws, void* bwd_ws, float* grads, void* stream, FusedSoftmax fl) {
+                         const void* loss_ws, void* bwd_ws, float* grads, void* stream, FusedSoftmax fl,
+                         int fused_rb = 0 /* > 0: the fused forward+backward kernel ran with this many rows per block;
+                                             only the weight gradients and the reduction remain */) {
   if (!params || !docids || !saved || (!dscores && !fl.scores) || !bwd_ws || !grads || batch <= 0 || list_size <= 0 ||
       n_docs < 0 || (n_docs > 0 && !features))
     return ULTR_E_BADARG;
@@ -2138,6 +2587,7 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
   DnnPlan p;
   BwdPlan bp;
   if (!ultr_make_dnn_plan(d, N, &p) || !ultr_make_bwd_plan(p, N, &bp)) return ULTR_E_BADARG;
+  if (fused_rb > 0) bp.nrb = (int)((N + fused_rb - 1) / fused_rb);  // vector slabs / loss partials: one per fused block
   const int tail = (int)ultr_tail_len(list_size);
   if (tail > 4096) return ULTR_E_UNSUPPORTED;
   const size_t lds = bwd_lds_bytes(p, bp.rblk);
@@ -2171,7 +2621,9 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
     ULTR_LAUNCH(prof, (dnn_bwd2_kernel<RR, 8, XX>), dim3(bp.nrb), dim3(512), lds2, st, p, bp, params, features,        \
                        n_docs, docids, (int)batch, (int)list_size, (const float*)saved, dscores, ws, fl);              \
   } while (0)
-  if (v2) {
+  if (fused_rb > 0) {
+    // the row-local half already ran inside dnn_fb_kernel
+  } else if (v2) {
     UltrProfScope prof(ULTR_K_BWD, st);
     const int xc = p.maxdim <= 256 ? 1 : 2;
     if (bp.rblk == 16 && xc == 1) LAUNCH_BWDV2(16, 1);
@@ -2234,6 +2686,65 @@ extern "C" int ultr_dnn_backward_softmax(const ultr_dnn_desc* d, const float* pa
   if (!scores || !labels || !loss_ws || (ipw_table && n_ipw <= 0)) return ULTR_E_BADARG;
   FusedSoftmax fl = {scores, labels, pw, ipw_table, (int)n_ipw, dscores_out, (float*)loss_ws};
   return backward_impl(d, params, features, n_docs, docids, batch, list_size, saved, nullptr, loss_ws, bwd_ws, grads, stream, fl);
+}
+
+// internal (ultr_train_step): forward + NA/IPW loss + backward for a small batch through dnn_fb_kernel, then the weight
+// gradients + reduction.  Returns ULTR_E_UNSUPPORTED when the shape does not qualify - the caller then issues the
+// separate forward / backward calls.
+int ultr_fused_step_softmax(const ultr_dnn_desc* d, const float* params, const float* wt, const float* features, int64_t n_docs,
+                            const int32_t* docids, int32_t batch, int32_t list_size, float* scores, void* saved,
+                            const float* labels, const float* pw, const float* ipw_table, int32_t n_ipw, float* dscores_out,
+                            void* loss_ws, void* bwd_ws, float* grads, void* stream) {
+  if (!params || !wt || !docids || !scores || !saved || !labels || !loss_ws || !bwd_ws || !grads || batch <= 0 ||
+      list_size <= 0 || n_docs < 0 || (n_docs > 0 && !features) || (ipw_table && n_ipw <= 0))
+    return ULTR_E_BADARG;
+  if (env_int("ULTR_NO_FUSED_FB", 0) != 0) return ULTR_E_UNSUPPORTED;
+  const int L = list_size;
+  if (L > 16) return ULTR_E_UNSUPPORTED;
+  const int64_t N = (int64_t)batch * L;
+  DnnPlan p;
+  BwdPlan bp;
+  if (!ultr_make_dnn_plan(d, N, &p) || !ultr_make_bwd_plan(p, N, &bp)) return ULTR_E_BADARG;
+  const int lpb = 16 / L, rb = lpb * L;
+  const int64_t nblk = (batch + lpb - 1) / lpb;
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      cus = 256;
+  }
+  const int vm = vecmask_for(p, params, features);
+  const size_t lds = fb_lds_floats(p) * sizeof(float);
+  const bool ok = all_vec(p, vm, N, n_docs) && env_int("ULTR_NO_VEC", 0) == 0 && ((uintptr_t)wt & 15) == 0 &&
+                  p.nl >= 2 && p.maxdim <= 512 && p.pv_total <= 3 * 512 * 4 && lds <= 160 * 1024 &&
+                  nblk <= 2 * (int64_t)cus &&                              // latency regime only
+                  nblk <= (N + 8) / 9 + 1 &&                               // vector-slab allocation (>= 9 live rows / block)
+                  p.sv_total * 4 < ((int64_t)1 << 31) && p.P * 4 < ((int64_t)1 << 31);
+  if (!ok) return ULTR_E_UNSUPPORTED;
+  bp.nrb = (int)nblk;
+  hipStream_t st = (hipStream_t)stream;
+  FusedSoftmax fl = {nullptr, labels, pw, ipw_table, (int)n_ipw, dscores_out, (float*)loss_ws};
+  float* ws = (float*)bwd_ws;
+  hipError_t e;
+  {
+    UltrProfScope prof(ULTR_K_FUSED, st);
+    if (p.maxdim <= 256) {
+      e = set_lds(dnn_fb_kernel<1>, lds);
+      if (e != hipSuccess) return (int)e;
+      ULTR_LAUNCH(prof, dnn_fb_kernel<1>, dim3((unsigned)nblk), dim3(512), lds, st, p, bp, params, wt, features, n_docs, docids,
+                  (int)batch, L, lpb, scores, (float*)saved, ws, fl);
+    } else {
+      e = set_lds(dnn_fb_kernel<2>, lds);
+      if (e != hipSuccess) return (int)e;
+      ULTR_LAUNCH(prof, dnn_fb_kernel<2>, dim3((unsigned)nblk), dim3(512), lds, st, p, bp, params, wt, features, n_docs, docids,
+                  (int)batch, L, lpb, scores, (float*)saved, ws, fl);
+    }
+  }
+  e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  fl.scores = scores;  // marks "loss partials come one per row block" for the reduction
+  return backward_impl(d, params, features, n_docs, docids, batch, list_size, saved, nullptr, loss_ws, bwd_ws, grads, stream, fl,
+                       rb);
 }
 
 extern "C" int ultr_grad_sumsq(float* grads, int64_t n_params, int32_t list_size, void* bwd_ws, void* stream) {

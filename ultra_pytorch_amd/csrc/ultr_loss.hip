@@ -20,7 +20,9 @@
 extern "C" int64_t ultr_loss_workspace_bytes(int64_t batch, int32_t list_size) {
   if (batch <= 0 || list_size <= 0) return 0;
   // one tail partial per 4 lists (stand-alone loss kernels) or per 16-row block (loss fused into the backward)
-  const int64_t parts_fused = (batch * (int64_t)list_size + 15) / 16;
+  // or per workgroup of the fused forward+backward kernel (at most one per list)
+  int64_t parts_fused = (batch * (int64_t)list_size + 15) / 16;
+  if (batch > parts_fused) parts_fused = batch;
   const int64_t parts = ultr_loss_parts(batch) > parts_fused ? ultr_loss_parts(batch) : parts_fused;
   return (parts * ultr_tail_len(list_size) + 4) * (int64_t)sizeof(float);
 }

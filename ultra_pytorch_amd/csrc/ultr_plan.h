@@ -109,6 +109,13 @@ bool ultr_make_dnn_plan(const ultr_dnn_desc* d, int64_t N, DnnPlan* p);  // ultr
 bool ultr_make_bwd_plan(const DnnPlan& p, int64_t N, BwdPlan* bp);         // ultr_dnn.hip
 void ultr_make_red_plan(const DnnPlan& p, const BwdPlan& bp, RedPlan* rp); // ultr_dnn.hip
 
+// library-internal: the small-batch NA/IPW step as one fused forward+loss+backward launch (+ weight gradients +
+// reduction); ULTR_E_UNSUPPORTED = shape does not qualify, use the separate calls
+int ultr_fused_step_softmax(const ultr_dnn_desc* d, const float* params, const float* wt, const float* features, int64_t n_docs,
+                            const int32_t* docids, int32_t batch, int32_t list_size, float* scores, void* saved,
+                            const float* labels, const float* pw, const float* ipw_table, int32_t n_ipw, float* dscores_out,
+                            void* loss_ws, void* bwd_ws, float* grads, void* stream);
+
 #define ULTR_TAIL_FIXED 4
 __host__ __device__ static inline int64_t ultr_tail_len(int L) { return ULTR_TAIL_FIXED + 2 * (int64_t)L; }
 

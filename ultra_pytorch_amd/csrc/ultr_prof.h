@@ -10,7 +10,9 @@
 
 enum UltrKernelId {
   ULTR_K_FWD = 0, ULTR_K_LOSS = 1, ULTR_K_BWD = 2, ULTR_K_WGRAD = 3, ULTR_K_REDUCE = 4, ULTR_K_UPDATE = 5,
-  ULTR_K_NDCG = 6, ULTR_K_COUNT = 8
+  ULTR_K_NDCG = 6,
+  ULTR_K_FUSED = 7,  // forward + loss + backward in one launch (small batches)
+  ULTR_K_COUNT = 8
 };
 
 extern uint32_t g_ultr_prof_mask;

@@ -5,12 +5,25 @@
 #include <stdint.h>
 
 #include "../../include/ultr_hip.h"
+#include "ultr_plan.h"
 #include "ultr_prof.h"
 
 extern "C" int ultr_train_step(const ultr_step_args* a, void* stream) {
   if (!a || !a->desc || !a->upd) return ULTR_E_BADARG;
   ultr_prof_tick();
-  int rc = ultr_dnn_forward(a->desc, a->params, a->wt, a->features, a->n_docs, a->docids, a->batch, a->list_size,
+  int rc;
+  if (a->upd->algo == ULTR_ALGO_SOFTMAX) {
+    // small batches (NA / IPW): forward + loss + backward as ONE launch when the shape qualifies
+    rc = ultr_fused_step_softmax(a->desc, a->params, a->wt, a->features, a->n_docs, a->docids, a->batch, a->list_size,
+                                 a->scores, a->saved, a->labels, a->pw, a->ipw_table, a->n_ipw, a->dscores, a->loss_ws,
+                                 a->bwd_ws, a->grads, stream);
+    if (rc == 0) {
+      if (a->skip_update) return 0;
+      return ultr_apply_update(a->upd, a->desc, a->params, a->wt, a->state, a->grads, a->aux, a->bwd_ws, a->scalars, stream);
+    }
+    if (rc != ULTR_E_UNSUPPORTED) return rc;
+  }
+  rc = ultr_dnn_forward(a->desc, a->params, a->wt, a->features, a->n_docs, a->docids, a->batch, a->list_size,
                             a->scores, a->saved, stream);
   if (rc) return rc;
   if (a->upd->algo == ULTR_ALGO_SOFTMAX) {
