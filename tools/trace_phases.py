@@ -27,6 +27,16 @@ buf = (ctypes.c_ulonglong * (64 * 32))()
 lib.ultr_trace_read.argtypes = [ctypes.c_void_p]
 lib.ultr_trace_read(buf)
 a = np.array(buf[:], dtype=np.uint64).reshape(64, 32)
+# fused forward+loss+backward kernel (dnn_fb_kernel): 0 start, 1 prologue done, 2+2j LayerNorm_j done, 3+2j GEMM_j done,
+# 16 loss done, then the backward stamps of dnn_bwd2_kernel (18+4jj row pass start, 19+4jj row pass done, 17+4jj GEMM done)
+if os.environ.get("ULTR_NO_FUSED_FB", "0") != "1":
+    for blk in range(3):
+        t = a[blk].astype(np.int64)
+        print("fused wg %3d: prologue=%d LN0=%d GEMM0=%d LN1=%d GEMM1=%d LN2+score=%d loss=%d | rowcol2=%d fin+GEMM1'=%d sync=%d rowcol1=%d "
+              "fin+GEMM0'=%d sync=%d rowcol0=%d  total(0->27)=%d" % (blk * 32, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4],
+                                                               t[6] - t[5], t[16] - t[6], t[19] - t[18], t[21] - t[19], t[22] - t[21],
+                                                               t[23] - t[22], t[25] - t[23], t[26] - t[25], t[27] - t[26], t[27] - t[0]))
+    sys.exit(0)
 names = ["start", "gather+sync", "LN0", "GEMM0", "sync", "LN1", "GEMM1", "sync", "LN2", "dot"]
 for blk in range(5):
     t = a[blk].astype(np.int64)
