@@ -277,9 +277,9 @@ def test_fused_softmax_backward(name):
     assert np.all(g[P + 2:] == 0)
 
 
-@pytest.mark.parametrize("B,L,F,hidden", [(256, 10, 136, [256, 256]), (37, 7, 24, [16, 8]), (64, 16, 136, [512, 256, 128]),
-                                          (50, 5, 136, [32, 16]), (9, 1, 8, [8])])
-def test_fused_forward_backward_step(B, L, F, hidden, monkeypatch):
+@pytest.mark.parametrize("B,L,F,hidden,n_pad", [(256, 10, 136, [256, 256], 0), (37, 7, 24, [16, 8], 2), (64, 16, 136, [512, 256, 128], 0),
+                                                (50, 5, 136, [32, 16], 1), (9, 1, 8, [8], 0), (33, 12, 260, [264, 12], 3)])
+def test_fused_forward_backward_step(B, L, F, hidden, n_pad, monkeypatch):
     """ultr_train_step picks ONE fused forward+loss+backward launch for small NA/IPW batches (list_size <= 16): it must
     produce what the separate kernels produce (scores, loss, gradient, updated parameters) - and what the oracle says."""
     from oracle import ultr_oracle as O
@@ -287,7 +287,7 @@ def test_fused_forward_backward_step(B, L, F, hidden, monkeypatch):
     from ultra_pytorch_amd.ranking_model import init_flat_params
     shape = hip_ops.DnnShape(F, hidden, "elu")
     rng = np.random.RandomState(5)
-    feats, ids, y = synthetic.make_batch(rng, B, L, F)
+    feats, ids, y = synthetic.make_batch(rng, B, L, F, n_pad=n_pad)  # PAD documents (id == n_docs) at the list tails
     ipw = np.asarray(synthetic.load_ipw(), np.float32)
     p0 = init_flat_params(shape, seed=3).numpy()
     out = {}

@@ -37,4 +37,16 @@ for name, (F, hidden, B, L, algo, lr) in CONFIGS.items():
     dims = [(F, hidden[0])] + list(zip(hidden[:-1], hidden[1:])) + [(hidden[-1], 1)]
     S = sum(a * b for a, b in dims)
     flops = B * L * (6 * S - 2 * F * hidden[0])
-    print("%-46s %8.1f us/step %10.0f q/s  %6.2f TFLOP/s (%.1f%% of fp32 MFMA peak)  loss %.4f" % (name, dt * 1e6, B / dt, flops / dt / 1e12, 100 * flops / dt / 157.3e12, float(eng.scalars[0])))
+    import ctypes
+    from ultra_pytorch_amd import _lib
+    lib = _lib.load()
+    tot, cnt = (ctypes.c_double * 8)(), (ctypes.c_int64 * 8)()
+    lib.ultr_prof_set_stride(1)
+    lib.ultr_prof_enable(0xBF, 8 * 40)
+    for k in range(40): step(k)
+    torch.cuda.synchronize()
+    lib.ultr_prof_collect(tot, cnt)
+    lib.ultr_prof_enable(0, 0)
+    kn = ["fwd", "loss", "bwd", "wgrad", "reduce", "update", "ndcg", "fused"]
+    kus = {kn[k]: round(1e3 * tot[k] / cnt[k], 1) for k in range(8) if cnt[k] > 0}
+    print("%-46s %8.1f us/step %10.0f q/s  %6.2f TFLOP/s (%.1f%% of fp32 MFMA peak)  loss %.4f" % (name, dt * 1e6, B / dt, flops / dt / 1e12, 100 * flops / dt / 157.3e12, float(eng.scalars[0])), kus)

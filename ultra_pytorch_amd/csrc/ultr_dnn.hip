@@ -2351,8 +2351,10 @@ static size_t fwd_lds_bytes(const DnnPlan& p, int R) { return ((size_t)2 * R * f
 static int fwd_rows_per_wg(const DnnPlan& p, int64_t N) {
   int r = env_int("ULTR_FWD_R", 0);
   if (r == 16 || r == 32) return r;
-  const size_t lds32 = fwd_lds_bytes(p, 32);
-  return ((N + 15) / 16 > 512 && lds32 <= 160 * 1024) ? 32 : 16;
+  // 16-row tiles everywhere: 32-row tiles halve the W stream per row, but their LDS footprint leaves one workgroup per CU and
+  // the grid quantises badly (measured at cfg3 / B=1024: 114 -> 100 us and 57 -> 43 us with 16 rows); ULTR_FWD_R=32 forces them
+  (void)N;
+  return 16;
 }
 static size_t bwd_lds_bytes(const DnnPlan& p, int R) {
   return ((size_t)R * (2 * bwd_ldu(p.maxdim) + bwd_ldz(p.maxdim)) + 2 * (size_t)bwd_ldu(p.maxdim) + 5 * (size_t)R) * sizeof(float) + (size_t)R * sizeof(int64_t);
