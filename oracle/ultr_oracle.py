@@ -227,7 +227,9 @@ def clip_coef(total_norm: float, max_norm: float) -> float:
 
 
 def grad_norm(g: torch.Tensor) -> torch.Tensor:
-    return torch.linalg.vector_norm(g, 2)
+    """clip_grad_norm_ takes the norm of the per-tensor norms (short fp32 sums, accurate to ~1e-7); a flat fp32
+    vector_norm over 250k elements is off by 1e-5 (measured on the SetRank fixture), so accumulate in fp64."""
+    return torch.linalg.vector_norm(g.double(), 2).float()
 
 
 def adagrad_update(p: torch.Tensor, g: torch.Tensor, state_sum: torch.Tensor, lr: float, eps: float = 1e-10):
@@ -445,6 +447,92 @@ def regression_em_step(params, state_sum, propensity, uniforms, F_, hidden, feat
         p2, s2, n, _ = apply_update(p.detach(), g, torch.as_tensor(state_sum, dtype=torch.float32), lr, max_norm, strategy)
     return dict(loss=float(loss.detach()), scores=scores.detach().numpy(), grads=g.numpy(), norm=float(n), params=p2.numpy(),
                 state=s2.numpy(), propensity=prop2.numpy(), ranker_labels=ranker_labels.numpy())
+
+
+# --------------------------------------------------------------------------------------
+# next row 8f.1: the SetRank ranking model  (ranking_model/SetRank.py:23-255)
+# --------------------------------------------------------------------------------------
+def setrank_layout(feature_size: int, d_model: int, num_layers: int, dff: int) -> List[Tuple[str, Tuple[int, ...], int]]:
+    """Flat parameter layout = SetRank.state_dict() order: Encoder.__init__ registers input_layer_norm, input_embedding,
+    output_layer, then enc_layers (SetRank.py:130-141); an EncoderLayer registers mha.dense, ffn, layernorm1, layernorm2
+    (:95-103)."""
+    out, off = [], 0
+
+    def add(name, shape):
+        nonlocal off
+        out.append((name, tuple(shape), off))
+        off += int(np.prod(shape))
+
+    e = "Encoder_layer."
+    add(e + "input_layer_norm.weight", (feature_size,))
+    add(e + "input_layer_norm.bias", (feature_size,))
+    add(e + "input_embedding.0.weight", (dff, feature_size))
+    add(e + "input_embedding.0.bias", (dff,))
+    add(e + "input_embedding.2.weight", (d_model, dff))
+    add(e + "input_embedding.2.bias", (d_model,))
+    add(e + "output_layer.0.weight", (dff, d_model))
+    add(e + "output_layer.0.bias", (dff,))
+    add(e + "output_layer.2.weight", (1, dff))
+    add(e + "output_layer.2.bias", (1,))
+    for i in range(num_layers):
+        l = e + "enc_layers.encoder%d." % i
+        add(l + "mha.dense.weight", (d_model, d_model))
+        add(l + "mha.dense.bias", (d_model,))
+        add(l + "ffn.0.weight", (dff, d_model))
+        add(l + "ffn.0.bias", (dff,))
+        add(l + "ffn.2.weight", (d_model, dff))
+        add(l + "ffn.2.bias", (d_model,))
+        add(l + "layernorm1.weight", (d_model,))
+        add(l + "layernorm1.bias", (d_model,))
+        add(l + "layernorm2.weight", (d_model,))
+        add(l + "layernorm2.bias", (d_model,))
+    return out
+
+
+def setrank_forward(params: torch.Tensor, feature_size: int, d_model: int, num_heads: int, num_layers: int, dff: int,
+                    features: np.ndarray, docids: np.ndarray) -> torch.Tensor:
+    """SetRank.build + Encoder.forward (SetRank.py:143-156, 229-255) -> scores [B, L].  No Q/K/V projections (the
+    heads are slices of x itself, :57-66), no mask, dropout rate 0.0 (default hparam) = identity, LayerNorm eps 1e-6,
+    softmax(q k^T / sqrt(depth)) v per head (:159-195), then mha.dense; post-LN residual blocks (:105-117)."""
+    P = {n: params[o:o + int(np.prod(sh))].reshape(sh) for n, sh, o in setrank_layout(feature_size, d_model, num_layers, dff)}
+    e = "Encoder_layer."
+    x = gather_rows(features, docids)  # [L, B, F] rows by (position, query)
+    L, B = docids.shape
+    x = x.reshape(L, B, feature_size).permute(1, 0, 2).float()  # [B, L, F]
+    x = torch.nn.functional.layer_norm(x, (feature_size,), P[e + "input_layer_norm.weight"], P[e + "input_layer_norm.bias"], 1e-6)
+    x = torch.relu(x @ P[e + "input_embedding.0.weight"].T + P[e + "input_embedding.0.bias"])
+    x = x @ P[e + "input_embedding.2.weight"].T + P[e + "input_embedding.2.bias"]
+    depth = d_model // num_heads
+    for i in range(num_layers):
+        l = e + "enc_layers.encoder%d." % i
+        q = x.reshape(B, L, num_heads, depth).permute(0, 2, 1, 3)  # [B, H, L, depth]
+        logits = (q @ q.transpose(-1, -2)) / torch.sqrt(torch.tensor(float(depth)))
+        att = torch.softmax(logits, dim=-1) @ q
+        att = att.permute(0, 2, 1, 3).reshape(B, L, d_model)
+        att = att @ P[l + "mha.dense.weight"].T + P[l + "mha.dense.bias"]
+        out1 = torch.nn.functional.layer_norm(x + att, (d_model,), P[l + "layernorm1.weight"], P[l + "layernorm1.bias"], 1e-6)
+        f = torch.relu(out1 @ P[l + "ffn.0.weight"].T + P[l + "ffn.0.bias"])
+        f = f @ P[l + "ffn.2.weight"].T + P[l + "ffn.2.bias"]
+        x = torch.nn.functional.layer_norm(out1 + f, (d_model,), P[l + "layernorm2.weight"], P[l + "layernorm2.bias"], 1e-6)
+    o = torch.relu(x @ P[e + "output_layer.0.weight"].T + P[e + "output_layer.0.bias"])
+    o = o @ P[e + "output_layer.2.weight"].T + P[e + "output_layer.2.bias"]
+    return o[..., 0]  # [B, L]
+
+
+def train_step_setrank_softmax(params, state_sum, cfg, features, docids, labels_LB, ipw_list=None, lr=0.05, max_norm=5.0,
+                               strategy="ada"):
+    """NavieAlgorithm / IPWrank.train with ranking_model = SetRank: same loss, clip and optimizer as a7 / a8.
+    cfg = (feature_size, d_model, num_heads, num_layers, dff)."""
+    p = torch.as_tensor(params, dtype=torch.float32).clone().requires_grad_(True)
+    scores = setrank_forward(p, *cfg, features, docids)
+    labels = torch.from_numpy(np.ascontiguousarray(np.transpose(labels_LB))).float()
+    pw = ipw_weights(labels_LB, ipw_list) if ipw_list is not None else None
+    loss = softmax_loss(scores, labels, pw)
+    (g,) = torch.autograd.grad(loss, p)
+    with torch.no_grad():
+        p2, s2, n, _ = apply_update(p.detach(), g, torch.as_tensor(state_sum, dtype=torch.float32), lr, max_norm, strategy)
+    return dict(loss=float(loss.detach()), scores=scores.detach().numpy(), grads=g.numpy(), norm=float(n), params=p2.numpy(),
+                state=s2.numpy())
 
 
 # --------------------------------------------------------------------------------------

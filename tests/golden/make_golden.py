@@ -419,6 +419,16 @@ CASES = {
     # next row 8f.3: RegressionEM (uniforms of the Bernoulli draw recorded)
     "regem_tiny": lambda u: run_train_case(u, "regem_tiny", "regem", 136, 10, 8, [32, 16], 2, 23),
     "regem_odd": lambda u: run_train_case(u, "regem_odd", "regem", 13, 7, 9, [19, 6, 3], 2, 24, n_queries=32),
+    # next row 8f.1: the SetRank ranking model (addressed as ultra.ranking_model.SetRank.SetRank) under IPW / NA
+    "setrank_tiny": lambda u: run_train_case(u, "setrank_tiny", "ipw", 24, 10, 8, None, 2, 41,
+                                             model_cls="ultra.ranking_model.SetRank.SetRank",
+                                             model_extra="d_model=32,num_heads=4,num_layers=2,diff=16"),
+    "setrank_odd": lambda u: run_train_case(u, "setrank_odd", "na", 13, 7, 5, None, 2, 42, n_queries=16,
+                                            model_cls="ultra.ranking_model.SetRank.SetRank",
+                                            model_extra="d_model=24,num_heads=3,num_layers=1,diff=12"),
+    # config-5 layer shapes (F220, L100, d_model 256, 8 heads, 2 layers, dff 64) at B = 2
+    "setrank_cfg5_b2": lambda u: run_train_case(u, "setrank_cfg5_b2", "ipw", 220, 100, 2, None, 1, 43, n_queries=4,
+                                                model_cls="ultra.ranking_model.SetRank.SetRank", model_extra=""),
     # k = 0 (the Linear ranking model: LayerNorm -> Linear(F,1))
     "na_linear": lambda u: run_train_case(u, "na_linear", "na", 136, 10, 8, None, 2, 20,
                                           model_cls="ultra.ranking_model.Linear"),

@@ -95,6 +95,25 @@ def test_regression_em(name):
         np.testing.assert_allclose(r["state"], d[p + "post_adagrad"], rtol=5e-4, atol=1e-12)
 
 
+@pytest.mark.parametrize("name", ["setrank_tiny", "setrank_odd", "setrank_cfg5_b2"])
+def test_setrank(name):
+    """the SetRank ranking model under NA / IPW, against the reference's own forward/backward."""
+    d, m = load(name)
+    shapes = dict(zip(m["param_keys"], m["param_shapes"]))
+    dff, F = shapes["Encoder_layer.input_embedding.0.weight"]
+    d_model = shapes["Encoder_layer.input_embedding.2.weight"][0]
+    n_layers = sum(1 for k in m["param_keys"] if k.endswith("mha.dense.weight"))
+    heads = {"setrank_tiny": 4, "setrank_odd": 3, "setrank_cfg5_b2": 8}[name]
+    assert [n for n, _, _ in O.setrank_layout(F, d_model, n_layers, dff)] == m["param_keys"]
+    cfg = (F, d_model, heads, n_layers, dff)
+    for t in range(m["n_steps"]):
+        p = "s%d_" % t
+        r = O.train_step_setrank_softmax(d[p + "pre_params"], d[p + "pre_adagrad"], cfg, d[p + "features"], d[p + "docids"],
+                                         d[p + "labels"], ipw_list=d["ipw_list"] if m["algo"] == "ipw" else None, lr=m["lr"],
+                                         max_norm=m["max_gradient_norm"])
+        check_common(d, m, t, r)
+
+
 @pytest.mark.parametrize("name", ["valid_tiny", "valid_odd"])
 def test_validation(name):
     d, m = load(name)
