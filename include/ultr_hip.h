@@ -161,6 +161,30 @@ int ultr_regem_loss(const float* scores, const float* labels, const float* prope
                     uint64_t seed, uint64_t step, int32_t batch, int32_t list_size, float* dscores,
                     float* pseudo_labels_out, void* loss_ws, void* stream);
 
+/* ---- next row 8f.1: the SetRank ranking model --------------------------------------------
+ * Replaces SetRank.build / Encoder.forward (ranking_model/SetRank.py:143-156, 229-255) and its autograd
+ * backward: input LayerNorm (eps 1e-6) -> FFN(F -> dff -> d_model) -> num_layers x [multi-head self-attention
+ * WITHOUT projections (heads = slices of x) -> dense -> residual + LayerNorm -> FFN -> residual + LayerNorm]
+ * -> FFN(d_model -> dff -> 1).  fp32; plain Linear layers through rocBLAS sgemm, everything else hand-written.
+ * params: flat vector in SetRank.state_dict() order (Encoder_layer.input_layer_norm, input_embedding.{0,2},
+ * output_layer.{0,2}, then per encoder: mha.dense, ffn.{0,2}, layernorm1, layernorm2).
+ * forward: scores [B, L]; `saved` (ultr_setrank_saved_bytes) receives every activation the backward needs and is
+ * required for validation too (it doubles as scratch).  list_size <= 256.
+ * backward: dscores [B, L] from any ultr_*_loss kernel (x D convention), loss_ws/n_loss_parts = that kernel's
+ * partials; writes grads [P + step tail]; follow with ultr_grad_sumsq + ultr_apply_update(wt = NULL).
+ * list_size <= 120 (two [L, L] matrices per (list, head) live in LDS). */
+typedef struct ultr_setrank_desc {
+  int32_t feature_size, d_model, num_heads, num_layers, dff;
+} ultr_setrank_desc;
+int64_t ultr_setrank_param_count(const ultr_setrank_desc* c);
+int64_t ultr_setrank_saved_bytes(const ultr_setrank_desc* c, int64_t n_rows);
+int64_t ultr_setrank_workspace_bytes(const ultr_setrank_desc* c, int64_t n_rows);
+int ultr_setrank_forward(const ultr_setrank_desc* c, const float* params, const float* features, int64_t n_docs,
+                         const int32_t* docids, int32_t batch, int32_t list_size, float* scores, void* saved, void* stream);
+int ultr_setrank_backward(const ultr_setrank_desc* c, const float* params, int32_t batch, int32_t list_size, const void* saved,
+                          const float* dscores, const void* loss_ws, int32_t n_loss_parts, void* workspace, float* grads,
+                          void* stream);
+
 /* ---- a5 (clip) + a6 (optimizer) + EM / propensity updates ----------------------------
  * Replaces torch.nn.utils.clip_grad_norm_ + Adagrad.step / SGD.step
  * (base_algorithm.py:223-226; ipw_rank.py:96), DLA.separate_gradient_update

@@ -1,0 +1,114 @@
+"""SURVEY 8f.1 - the SetRank ranking model on the HIP path (ultr_setrank_forward / ultr_setrank_backward), against the
+golden vectors captured from the reference (IPW / NA + ultra.ranking_model.SetRank.SetRank) and against the oracle at
+other shapes.  Same tolerances as the DNN path: scores 1e-5, loss 1e-5, gradients 1e-5 rel + 1e-6*max|g|."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.hipref import dev, load_golden  # noqa: E402
+
+HEADS = {"setrank_tiny": 4, "setrank_odd": 3, "setrank_cfg5_b2": 8}
+
+
+def cfg_of(m, name):
+    shapes = dict(zip(m["param_keys"], m["param_shapes"]))
+    dff, F = shapes["Encoder_layer.input_embedding.0.weight"]
+    d_model = shapes["Encoder_layer.input_embedding.2.weight"][0]
+    n_layers = sum(1 for k in m["param_keys"] if k.endswith("mha.dense.weight"))
+    return F, d_model, HEADS[name], n_layers, dff
+
+
+def run_step(shape, B, L, algo_kw, params, state, feats, ids, labels, ipw):
+    from ultra_pytorch_amd import engine
+    eng = engine.SetRankStepEngine(shape, B, L, torch.device("cuda"), algo="softmax", **algo_kw)
+    p, s = dev(params.copy()), dev(state.copy())
+    f = dev(np.asarray(feats, np.float32))
+    i, y = dev(ids, torch.int32), dev(labels, torch.float32)
+    eng.forward(p, f, f.shape[0], i, train=True)
+    torch.cuda.synchronize()
+    scores = eng.scores.cpu().numpy().copy()
+    eng.loss(y, ipw_table=None if ipw is None else dev(np.asarray(ipw, np.float32)))
+    eng.backward(p, f, f.shape[0], i)
+    torch.cuda.synchronize()
+    g = eng.grads.cpu().numpy().copy()
+    eng.update(p, s)
+    torch.cuda.synchronize()
+    return scores, g, p.cpu().numpy(), s.cpu().numpy(), eng.scalars.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", ["setrank_tiny", "setrank_odd", "setrank_cfg5_b2"])
+def test_setrank_golden(name):
+    from ultra_pytorch_amd import hip_ops
+    d, m = load_golden(name)
+    F, dm, H, nl, dff = cfg_of(m, name)
+    shape = hip_ops.SetRankShape(F, dm, H, nl, dff)
+    assert [n for n, _, _ in shape.layout()] == m["param_keys"]
+    assert [list(s) for _, s, _ in shape.layout()] == m["param_shapes"]
+    B, L = m["B"], m["L"]
+    for t in range(m["n_steps"]):
+        p = "s%d_" % t
+        scores, g, params, state, sc = run_step(shape, B, L, dict(learning_rate=m["lr"], max_gradient_norm=m["max_gradient_norm"]),
+                                                d[p + "pre_params"], d[p + "pre_adagrad"], d[p + "features"], d[p + "docids"],
+                                                d[p + "labels"], d["ipw_list"] if m["algo"] == "ipw" else None)
+        np.testing.assert_allclose(scores, d[p + "scores"], atol=1e-5, rtol=0, err_msg="scores")
+        ref_loss = float(d[p + "loss"])
+        assert abs(sc[0] - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (sc[0], ref_loss)
+        gref = d[p + "grads"]
+        gs = 1.0 / float(sc[3])
+        np.testing.assert_allclose(g[: shape.n_params] * gs, gref, rtol=1e-5, atol=2e-6 * max(1.0, float(np.abs(gref).max())),
+                                   err_msg="grads")
+        assert abs(sc[1] - float(d[p + "norm"])) <= 1e-5 * max(1.0, float(d[p + "norm"]))
+        sel = np.abs(gref) > 1e-6 * max(1.0, float(np.abs(gref).max()))
+        np.testing.assert_allclose(params[sel], d[p + "post_params"][sel], atol=5e-6, rtol=1e-5, err_msg="params")
+
+
+@pytest.mark.parametrize("B,L,F,dm,H,nl,dff", [(16, 10, 136, 64, 4, 2, 32), (3, 37, 20, 48, 6, 1, 20), (5, 100, 220, 256, 8, 2, 64)])
+def test_setrank_oracle(B, L, F, dm, H, nl, dff):
+    from oracle import ultr_oracle as O
+    from ultra_pytorch_amd import hip_ops, synthetic
+    from ultra_pytorch_amd.ranking_model.SetRank import init_setrank_params
+    shape = hip_ops.SetRankShape(F, dm, H, nl, dff)
+    rng = np.random.RandomState(11)
+    feats, ids, y = synthetic.make_batch(rng, B, L, F, n_pad=2 if L > 8 else 0)
+    ipw = np.asarray(synthetic.load_ipw(), np.float32)
+    p0 = init_setrank_params(shape, seed=9).numpy()
+    scores, g, params, state, sc = run_step(shape, B, L, dict(learning_rate=0.05, max_gradient_norm=5.0), p0, np.zeros_like(p0),
+                                            feats, ids, y, ipw)
+    r = O.train_step_setrank_softmax(p0, np.zeros_like(p0), (F, dm, H, nl, dff), feats, ids, y, ipw_list=ipw, lr=0.05, max_norm=5.0)
+    np.testing.assert_allclose(scores, r["scores"], atol=1e-5)
+    assert abs(float(sc[0]) - r["loss"]) <= 1e-5 * max(1.0, abs(r["loss"]))
+    gs = 1.0 / float(sc[3])
+    np.testing.assert_allclose(g[: shape.n_params] * gs, r["grads"], rtol=1e-5, atol=2e-6 * max(1.0, float(np.abs(r["grads"]).max())))
+
+
+def test_setrank_plugin_train_and_validation():
+    """Class-path plug-in exactly as the reference's settings JSON would name it; train() against the golden step,
+    validation() returns [B, max_candidate_num] scores + metrics; state_dict keys interchange."""
+    from ultra_pytorch_amd.utils import find_class
+    from tests.test_gpu_plugins import DataSet, load_flat, make_feed
+    d, m = load_golden("setrank_tiny")
+    exp = {"learning_algorithm": "ultra_pytorch_amd.learning_algorithm.IPWrank", "learning_algorithm_hparams": "",
+           "ranking_model": "ultra_pytorch_amd.ranking_model.SetRank.SetRank",
+           "ranking_model_hparams": "d_model=32,num_heads=4,num_layers=2,diff=16",
+           "max_candidate_num": m["L"], "selection_bias_cutoff": m["L"], "metrics": ["ndcg", "err"], "metrics_topn": [1, 3, 5, 10]}
+    algo = find_class(exp["learning_algorithm"])(DataSet(m["F"]), exp)
+    assert list(algo.model.state_dict().keys()) == m["param_keys"]
+    for t in range(m["n_steps"]):
+        p = "s%d_" % t
+        load_flat(algo.model, d[p + "pre_params"])
+        algo.state_sum.copy_(torch.from_numpy(d[p + "pre_adagrad"]))
+        feed = make_feed(algo, d[p + "features"], d[p + "docids"], d[p + "labels"])
+        loss, out, _ = algo.train(feed)
+        ref = float(d[p + "loss"])
+        assert out is None and abs(loss - ref) <= 1e-5 * max(1.0, abs(ref))
+        g = d[p + "grads"]
+        sel = np.abs(g) > 1e-6 * max(1.0, float(np.abs(g).max()))
+        np.testing.assert_allclose(algo.model.flat_params.cpu().numpy()[sel], d[p + "post_params"][sel], atol=5e-6, rtol=1e-5)
+    _, scores, summary = algo.validation(make_feed(algo, d["s0_features"], d["s0_docids"], d["s0_labels"]))
+    assert tuple(scores.shape) == (m["B"], m["L"]) and "ndcg_10" in summary and 0.0 <= summary["ndcg_10"] <= 1.0
+    outs = algo.model.build([torch.from_numpy(d["s0_features"][d["s0_docids"][l]]) for l in range(m["L"])])
+    assert len(outs) == m["L"] and tuple(outs[0].shape) == (m["B"], 1)

@@ -28,6 +28,10 @@ class UpdateDesc(ctypes.Structure):
                 ("regulation_p", c_f32), ("reserved", c_f32)]
 
 
+class SetRankDesc(ctypes.Structure):
+    _fields_ = [("feature_size", c_i32), ("d_model", c_i32), ("num_heads", c_i32), ("num_layers", c_i32), ("dff", c_i32)]
+
+
 class StepArgs(ctypes.Structure):
     _fields_ = [("desc", ctypes.POINTER(DnnDesc)), ("upd", ctypes.POINTER(UpdateDesc)), ("params", c_vp), ("wt", c_vp),
                 ("state", c_vp), ("aux", c_vp), ("features", c_vp), ("docids", c_vp), ("labels", c_vp), ("pw", c_vp),
@@ -59,6 +63,12 @@ SIGNATURES = {
     "ultr_pairdebias_loss": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "ultr_lambdarank_loss": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "ultr_regem_loss": (c_i32, [c_vp, c_vp, c_vp, c_vp, ctypes.c_uint64, ctypes.c_uint64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "ultr_setrank_param_count": (c_i64, [ctypes.POINTER(SetRankDesc)]),
+    "ultr_setrank_saved_bytes": (c_i64, [ctypes.POINTER(SetRankDesc), c_i64]),
+    "ultr_setrank_workspace_bytes": (c_i64, [ctypes.POINTER(SetRankDesc), c_i64]),
+    "ultr_setrank_forward": (c_i32, [ctypes.POINTER(SetRankDesc), c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "ultr_setrank_backward": (c_i32, [ctypes.POINTER(SetRankDesc), c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp,
+                                      c_vp]),
     "ultr_apply_update": (c_i32, [ctypes.POINTER(UpdateDesc), ctypes.POINTER(DnnDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                   c_vp, c_vp]),
     "ultr_train_step": (c_i32, [ctypes.POINTER(StepArgs), c_vp]),

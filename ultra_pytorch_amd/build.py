@@ -13,6 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libultr_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc"]
+LIBS = ["-L/opt/rocm/lib", "-lrocblas"]  # plain GEMMs of the SetRank model (ultr_setrank.hip)
 
 
 def _hipcc():
@@ -47,7 +48,7 @@ def build_library(force=False, verbose=True):
             return LIB
         raise RuntimeError("hipcc not found and %s does not exist" % LIB)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = [cc] + FLAGS + sources() + ["-o", LIB]
+    cmd = [cc] + FLAGS + sources() + LIBS + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -1,0 +1,550 @@
+// ultr_setrank.hip — the SetRank ranking model (reference ultra/ranking_model/SetRank.py:23-255),
+// forward and backward, fp32.  First correct path of this "next" row:
+//   * the token-local Linear layers are PLAIN GEMMs and go to rocBLAS (sgemm, atomics off -> deterministic);
+//   * everything that is not a plain GEMM is hand-written here: feature gather + LayerNorm, bias / ReLU epilogues,
+//     residual + LayerNorm (forward and backward with the gamma/beta column sums), bias-gradient column sums, and
+//     the per-(list, head) self-attention WITHOUT Q/K/V projections (the heads are slices of x itself,
+//     SetRank.py:57-66) forward and backward, deterministic (no atomics: the key/value-side sums are a second pass
+//     over LDS-resident P and dS matrices).
+// Token n = b*L + l (list-major), all activations row-major [T, width].  Parameters: ONE flat vector in the
+// reference's state_dict order (ultr_setrank_param_offsets).  fp16 MFMA attention (BASELINE config 5) is the next
+// step; fp32 keeps the 1e-5 parity bar of the rest of the path.
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/ultr_hip.h"
+#include "ultr_device.h"
+#include "ultr_plan.h"
+
+#define SR_EPS 1e-6f  // nn.LayerNorm(eps=1e-6) everywhere in SetRank.py (:100-101, :134)
+#define SR_ROWS 4     // rows per workgroup (= waves) of the row-wise kernels
+#define SR_CS_ROWS 128  // rows per partial of the column-sum kernels
+
+namespace {
+
+struct SrLayer {  // offsets (floats) into the flat parameter vector
+  int64_t wd, bd, wf1, bf1, wf2, bf2, g1, b1, g2, b2;
+};
+struct SrPlan {
+  int F, d, H, nl, dff, dh;
+  int64_t T;
+  int64_t g_in, b_in, w1, b1, w2, b2, wo1, bo1, wo2, bo2;
+  SrLayer lay[8];
+  int64_t P;
+  // saved activations (floats)
+  int64_t sv_xg, sv_mean_in, sv_rstd_in, sv_xn0, sv_h0, sv_oh;
+  int64_t sv_x[9];  // x_0 .. x_nl  [T, d]
+  int64_t sv_A[8], sv_s1[8], sv_m1[8], sv_r1[8], sv_out1[8], sv_f[8], sv_s2[8], sv_m2[8], sv_r2[8];
+  int64_t sv_total;
+  // workspace (floats)
+  int maxw;
+  int64_t ws_g[3];   // three [T, maxw] gradient buffers
+  int64_t ws_part;   // [n_cs][2 * maxw] column-sum partials
+  int n_cs;
+  int64_t ws_total;
+};
+
+bool make_plan(const ultr_setrank_desc* c, int64_t T, SrPlan* p) {
+  if (!c || c->feature_size <= 0 || c->d_model <= 0 || c->num_heads <= 0 || c->num_layers <= 0 || c->num_layers > 8 ||
+      c->dff <= 0 || c->d_model % c->num_heads != 0)
+    return false;
+  memset(p, 0, sizeof(*p));
+  p->F = c->feature_size; p->d = c->d_model; p->H = c->num_heads; p->nl = c->num_layers; p->dff = c->dff;
+  p->dh = p->d / p->H;
+  p->T = T;
+  const int64_t F = p->F, d = p->d, dff = p->dff;
+  int64_t o = 0;
+  p->g_in = o; o += F;  p->b_in = o; o += F;
+  p->w1 = o; o += dff * F;  p->b1 = o; o += dff;
+  p->w2 = o; o += d * dff;  p->b2 = o; o += d;
+  p->wo1 = o; o += dff * d; p->bo1 = o; o += dff;
+  p->wo2 = o; o += dff;     p->bo2 = o; o += 1;
+  for (int l = 0; l < p->nl; ++l) {
+    SrLayer& y = p->lay[l];
+    y.wd = o; o += d * d;    y.bd = o; o += d;
+    y.wf1 = o; o += dff * d; y.bf1 = o; o += dff;
+    y.wf2 = o; o += d * dff; y.bf2 = o; o += d;
+    y.g1 = o; o += d; y.b1 = o; o += d;
+    y.g2 = o; o += d; y.b2 = o; o += d;
+  }
+  p->P = o;
+  int64_t s = 0;
+  auto take = [&](int64_t n) { const int64_t at = s; s += (n + 3) & ~(int64_t)3; return at; };
+  p->sv_xg = take(T * F); p->sv_mean_in = take(T); p->sv_rstd_in = take(T); p->sv_xn0 = take(T * F);
+  p->sv_h0 = take(T * dff);
+  for (int l = 0; l <= p->nl; ++l) p->sv_x[l] = take(T * d);
+  for (int l = 0; l < p->nl; ++l) {
+    p->sv_A[l] = take(T * d); p->sv_s1[l] = take(T * d); p->sv_m1[l] = take(T); p->sv_r1[l] = take(T);
+    p->sv_out1[l] = take(T * d); p->sv_f[l] = take(T * dff);
+    p->sv_s2[l] = take(T * d); p->sv_m2[l] = take(T); p->sv_r2[l] = take(T);
+  }
+  p->sv_oh = take(T * dff);
+  p->sv_total = s;
+  p->maxw = (int)(F > d ? F : d);
+  if (dff > p->maxw) p->maxw = (int)dff;
+  int64_t w = 0;
+  for (int k = 0; k < 3; ++k) { p->ws_g[k] = w; w += (T * p->maxw + 3) & ~(int64_t)3; }
+  p->n_cs = (int)((T + SR_CS_ROWS - 1) / SR_CS_ROWS);
+  p->ws_part = w; w += (int64_t)p->n_cs * 2 * p->maxw;
+  // sum-of-squares partials for ultr_apply_update live at offset 0 of a SEPARATE region at the end (ultr_grad_sumsq
+  // writes them at the start of the pointer it is given)
+  p->ws_total = w;
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// row-wise kernels: one wavefront per row, SR_ROWS rows per workgroup
+// ---------------------------------------------------------------------------------------------------------
+// y = LayerNorm(a [+ b]) * gamma + beta; optionally stores the pre-norm sum and the statistics.
+// a_gather: a is the feature matrix and rows are gathered through the doc ids (PAD -> zero row).
+__global__ __launch_bounds__(SR_ROWS * 64) void sr_ln_fwd_kernel(const float* a, const float* b /* may alias y */,
+                                                                const int32_t* __restrict__ docids, int64_t n_docs, int B,
+                                                                int L, int64_t T, int W, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ sum_out,
+                                                                float* y, float* __restrict__ mean_out,
+                                                                float* __restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t n = (int64_t)blockIdx.x * SR_ROWS + wave;
+  if (n >= T) return;
+  const float* ra = a + n * W;
+  if (docids != nullptr) {
+    const int bb = (int)(n / L), ll = (int)(n % L);
+    const int id = docids[(int64_t)ll * B + bb];
+    ra = (id >= 0 && id < n_docs) ? a + (int64_t)id * W : nullptr;
+  }
+  float s = 0.f;
+  for (int c = lane; c < W; c += 64) {
+    float v = ra ? ra[c] : 0.f;
+    if (b != nullptr) v += b[n * W + c];
+    if (sum_out != nullptr) sum_out[n * W + c] = v;
+    s += v;
+  }
+  const float mean = wave_sum(s) / (float)W;
+  float q = 0.f;
+  for (int c = lane; c < W; c += 64) {
+    float v = ra ? ra[c] : 0.f;
+    if (b != nullptr) v += b[n * W + c];
+    const float dlt = v - mean;
+    q += dlt * dlt;
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)W + SR_EPS);
+  for (int c = lane; c < W; c += 64) {
+    float v = ra ? ra[c] : 0.f;
+    if (b != nullptr) v += b[n * W + c];
+    y[n * W + c] = (v - mean) * rstd * gamma[c] + beta[c];
+  }
+  if (lane == 0) {
+    if (mean_out) mean_out[n] = mean;
+    if (rstd_out) rstd_out[n] = rstd;
+  }
+}
+
+// LayerNorm backward per row: ds = rstd * (g - mean(g) - xh * mean(g * xh)), g = dy * gamma, xh = (s - mean) * rstd.
+// ds_out may be NULL (only the parameter gradients are wanted); accumulate: ds_out += instead of =.
+__global__ __launch_bounds__(SR_ROWS * 64) void sr_ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ s,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ gamma, int64_t T, int W,
+                                                                float* __restrict__ ds_out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t n = (int64_t)blockIdx.x * SR_ROWS + wave;
+  if (n >= T || ds_out == nullptr) return;
+  const float m = mean[n], r = rstd[n];
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = lane; c < W; c += 64) {
+    const float g = dy[n * W + c] * gamma[c];
+    const float xh = (s[n * W + c] - m) * r;
+    s1 += g;
+    s2 += g * xh;
+  }
+  s1 = wave_sum(s1) / (float)W;
+  s2 = wave_sum(s2) / (float)W;
+  for (int c = lane; c < W; c += 64) {
+    const float g = dy[n * W + c] * gamma[c];
+    const float xh = (s[n * W + c] - m) * r;
+    ds_out[n * W + c] = r * (g - s1 - xh * s2);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// element-wise epilogues
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sr_bias_act_kernel(float* __restrict__ y, const float* __restrict__ bias, int64_t T, int W,
+                                                          int relu) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= T * W) return;
+  float v = y[e] + bias[e % W];
+  if (relu) v = fmaxf(v, 0.f);
+  y[e] = v;
+}
+// dy *= (act > 0)
+__global__ __launch_bounds__(256) void sr_relu_mask_kernel(float* __restrict__ dy, const float* __restrict__ act, int64_t n) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < n && !(act[e] > 0.f)) dy[e] = 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// column sums (bias gradients, LayerNorm gamma/beta gradients): partials per SR_CS_ROWS rows, then a fixed-order fold
+// ---------------------------------------------------------------------------------------------------------
+// part[blk][c]      = sum_r a[r][c]                       (mode 0)
+// part[blk][c]      = sum_r dy[r][c] * xh[r][c]           (mode 1: gamma gradient; xh from s, mean, rstd)
+__global__ __launch_bounds__(256) void sr_colsum_kernel(const float* __restrict__ a, const float* __restrict__ s,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        int64_t T, int W, int mode, float* __restrict__ part) {
+  const int64_t r0 = (int64_t)blockIdx.x * SR_CS_ROWS;
+  const int64_t r1 = (r0 + SR_CS_ROWS < T) ? r0 + SR_CS_ROWS : T;
+  for (int c = threadIdx.x; c < W; c += 256) {
+    float acc = 0.f;
+    for (int64_t r = r0; r < r1; ++r) {
+      float v = a[r * W + c];
+      if (mode == 1) v *= (s[r * W + c] - mean[r]) * rstd[r];
+      acc += v;
+    }
+    part[(int64_t)blockIdx.x * W + c] = acc;
+  }
+}
+// dst[c] = sum over nparts partials (canonical order)
+__global__ __launch_bounds__(256) void sr_fold_kernel(const float* __restrict__ part, int64_t stride, int nparts, int len,
+                                                      float* __restrict__ dst) {
+  __shared__ float sm[4][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  sm[grp][lane] = (c < len) ? strided_sum(part + c, stride, nparts, grp) : 0.f;
+  __syncthreads();
+  if (grp == 0 && c < len) dst[c] = ((sm[0][lane] + sm[1][lane]) + sm[2][lane]) + sm[3][lane];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// self-attention over one list, one head per workgroup (no projections: q = k = v = x[:, head slice])
+// ---------------------------------------------------------------------------------------------------------
+#define SR_KPL 4  // keys per lane: lists up to 256 documents
+
+// A[i, :] = softmax_j(x_i . x_j / sqrt(dh)) @ x        (SetRank.py:159-195, mask = None)
+__global__ __launch_bounds__(256) void sr_attn_fwd_kernel(const float* __restrict__ x, int L, int d, int dh, float* __restrict__ A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int ldx = dh + 1;
+  float* xs = smem;                 // [L][dh + 1]
+  float* ps = xs + L * ldx;         // [4 waves][L] probabilities of the wave's current query row
+  const int b = blockIdx.x, h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* xb = x + (int64_t)b * L * d + h * dh;
+  for (int e = tid; e < L * dh; e += 256) {
+    const int r = e / dh, c = e - r * dh;
+    xs[r * ldx + c] = xb[(int64_t)r * d + c];
+  }
+  __syncthreads();
+  const float scale = 1.0f / sqrtf((float)dh);
+  float* pw = ps + wave * L;
+  for (int i = wave; i < L; i += 4) {
+    float sc[SR_KPL];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < SR_KPL; ++k) {
+      const int j = lane + 64 * k;
+      float acc = 0.f;
+      if (j < L)
+        for (int c = 0; c < dh; ++c) acc += xs[i * ldx + c] * xs[j * ldx + c];
+      sc[k] = (j < L) ? acc * scale : -INFINITY;
+      mx = fmaxf(mx, sc[k]);
+    }
+    mx = wave_max(mx);
+    float se = 0.f;
+#pragma unroll
+    for (int k = 0; k < SR_KPL; ++k) {
+      const int j = lane + 64 * k;
+      sc[k] = (j < L) ? expf(sc[k] - mx) : 0.f;
+      se += sc[k];
+    }
+    se = wave_sum(se);
+#pragma unroll
+    for (int k = 0; k < SR_KPL; ++k) {
+      const int j = lane + 64 * k;
+      if (j < L) pw[j] = sc[k] / se;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // lane c < dh: A[i][c] = sum_j p_j x_j[c]
+    for (int c = lane; c < dh; c += 64) {
+      float acc = 0.f;
+      for (int j = 0; j < L; ++j) acc += pw[j] * xs[j * ldx + c];
+      A[((int64_t)b * L + i) * d + h * dh + c] = acc;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// dx[:, head slice] += dq + dk + dv   with  P recomputed from x,  dP = dA x^T,  dS = P o (dP - rowsum(P o dP)),
+//   dq_i = scale * sum_j dS_ij x_j,  dk_j = scale * sum_i dS_ij x_i,  dv_j = sum_i P_ij dA_i      (L <= 120)
+__global__ __launch_bounds__(256) void sr_attn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dA, int L, int d,
+                                                          int dh, float* __restrict__ dx) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int ldx = dh + 1;
+  float* xs = smem;                 // [L][dh + 1]
+  float* das = xs + L * ldx;        // [L][dh + 1]
+  float* Pm = das + L * ldx;        // [L][L]
+  float* Sm = Pm + L * L;           // [L][L]  dS
+  const int b = blockIdx.x, h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t base = (int64_t)b * L * d + h * dh;
+  for (int e = tid; e < L * dh; e += 256) {
+    const int r = e / dh, c = e - r * dh;
+    xs[r * ldx + c] = x[base + (int64_t)r * d + c];
+    das[r * ldx + c] = dA[base + (int64_t)r * d + c];
+  }
+  __syncthreads();
+  const float scale = 1.0f / sqrtf((float)dh);
+  // pass 1: rows of P and dS (one wave per query row), dq
+  for (int i = wave; i < L; i += 4) {
+    float sc[2], dp[2];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int j = lane + 64 * k;
+      float acc = 0.f, accp = 0.f;
+      if (j < L)
+        for (int c = 0; c < dh; ++c) {
+          acc += xs[i * ldx + c] * xs[j * ldx + c];
+          accp += das[i * ldx + c] * xs[j * ldx + c];
+        }
+      sc[k] = (j < L) ? acc * scale : -INFINITY;
+      dp[k] = accp;
+      mx = fmaxf(mx, sc[k]);
+    }
+    mx = wave_max(mx);
+    float se = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int j = lane + 64 * k;
+      sc[k] = (j < L) ? expf(sc[k] - mx) : 0.f;
+      se += sc[k];
+    }
+    se = wave_sum(se);
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      sc[k] /= se;  // p_ij
+      t += sc[k] * dp[k];
+    }
+    t = wave_sum(t);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int j = lane + 64 * k;
+      if (j < L) {
+        Pm[i * L + j] = sc[k];
+        Sm[i * L + j] = sc[k] * (dp[k] - t);
+      }
+    }
+  }
+  __syncthreads();
+  // pass 2: one thread per (token r, channel c): dq (row r of dS), dk and dv (column r of dS / P)
+  for (int e = tid; e < L * dh; e += 256) {
+    const int r = e / dh, c = e - r * dh;
+    float dq = 0.f, dk = 0.f, dv = 0.f;
+    for (int j = 0; j < L; ++j) {
+      dq += Sm[r * L + j] * xs[j * ldx + c];
+      dk += Sm[j * L + r] * xs[j * ldx + c];
+      dv += Pm[j * L + r] * das[j * ldx + c];
+    }
+    dx[base + (int64_t)r * d + c] += scale * (dq + dk) + dv;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+rocblas_handle g_handle = nullptr;
+
+int blas_setup(hipStream_t st) {
+  if (g_handle == nullptr) {
+    if (rocblas_create_handle(&g_handle) != rocblas_status_success) return ULTR_E_UNSUPPORTED;
+    rocblas_set_atomics_mode(g_handle, rocblas_atomics_not_allowed);
+    rocblas_set_pointer_mode(g_handle, rocblas_pointer_mode_host);
+  }
+  return rocblas_set_stream(g_handle, st) == rocblas_status_success ? 0 : ULTR_E_UNSUPPORTED;
+}
+// row-major  Y[T, M] (+)= X[T, K] . W[M, K]^T
+int gemm_xwT(const float* X, const float* W, float* Y, int64_t T, int K, int M, float beta) {
+  const float alpha = 1.0f;
+  return rocblas_sgemm(g_handle, rocblas_operation_transpose, rocblas_operation_none, M, (int)T, K, &alpha, W, K, X, K, &beta, Y,
+                       M) == rocblas_status_success ? 0 : ULTR_E_UNSUPPORTED;
+}
+// row-major  dX[T, K] (+)= dY[T, M] . W[M, K]
+int gemm_dyw(const float* dY, const float* W, float* dX, int64_t T, int K, int M, float beta) {
+  const float alpha = 1.0f;
+  return rocblas_sgemm(g_handle, rocblas_operation_none, rocblas_operation_none, K, (int)T, M, &alpha, W, K, dY, M, &beta, dX,
+                       K) == rocblas_status_success ? 0 : ULTR_E_UNSUPPORTED;
+}
+// row-major  dW[M, K] = dY[T, M]^T . X[T, K]
+int gemm_dyTx(const float* dY, const float* X, float* dW, int64_t T, int K, int M) {
+  const float alpha = 1.0f, beta = 0.0f;
+  return rocblas_sgemm(g_handle, rocblas_operation_none, rocblas_operation_transpose, K, M, (int)T, &alpha, X, K, dY, M, &beta, dW,
+                       K) == rocblas_status_success ? 0 : ULTR_E_UNSUPPORTED;
+}
+
+#define SR_CHECK(call)        \
+  do {                        \
+    const int rc_ = (call);   \
+    if (rc_ != 0) return rc_; \
+  } while (0)
+
+void bias_act(float* y, const float* bias, int64_t T, int W, int relu, hipStream_t st) {
+  const int64_t n = T * W;
+  hipLaunchKernelGGL(sr_bias_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, bias, T, W, relu);
+}
+void relu_mask(float* dy, const float* act, int64_t n, hipStream_t st) {
+  hipLaunchKernelGGL(sr_relu_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dy, act, n);
+}
+// dst[0..W) = column sums of a (mode 0) or of a o xhat (mode 1)
+void colsum(const SrPlan& p, const float* a, const float* s, const float* mean, const float* rstd, int W, int mode, float* ws,
+            float* dst, hipStream_t st) {
+  float* part = ws + p.ws_part;
+  hipLaunchKernelGGL(sr_colsum_kernel, dim3(p.n_cs), dim3(256), 0, st, a, s, mean, rstd, p.T, W, mode, part);
+  hipLaunchKernelGGL(sr_fold_kernel, dim3((W + 63) / 64), dim3(256), 0, st, (const float*)part, (int64_t)W, p.n_cs, W, dst);
+}
+
+}  // namespace
+
+extern "C" int64_t ultr_setrank_param_count(const ultr_setrank_desc* c) {
+  SrPlan p;
+  return make_plan(c, 0, &p) ? p.P : 0;
+}
+extern "C" int64_t ultr_setrank_saved_bytes(const ultr_setrank_desc* c, int64_t n_rows) {
+  SrPlan p;
+  return (n_rows >= 0 && make_plan(c, n_rows, &p)) ? (p.sv_total + 4) * (int64_t)sizeof(float) : 0;
+}
+extern "C" int64_t ultr_setrank_workspace_bytes(const ultr_setrank_desc* c, int64_t n_rows) {
+  SrPlan p;
+  return (n_rows >= 0 && make_plan(c, n_rows, &p)) ? (p.ws_total + 4) * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int ultr_setrank_forward(const ultr_setrank_desc* c, const float* params, const float* features, int64_t n_docs,
+                                    const int32_t* docids, int32_t batch, int32_t list_size, float* scores, void* saved,
+                                    void* stream) {
+  if (!params || !docids || !scores || !saved || batch <= 0 || list_size <= 0 || n_docs < 0 || (n_docs > 0 && !features))
+    return ULTR_E_BADARG;
+  const int64_t T = (int64_t)batch * list_size;
+  SrPlan p;
+  if (!make_plan(c, T, &p)) return ULTR_E_BADARG;
+  const int L = list_size;
+  if (L > 64 * SR_KPL) return ULTR_E_UNSUPPORTED;
+  if (T > 0x7fffffff / 4) return ULTR_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  SR_CHECK(blas_setup(st));
+  float* sv = (float*)saved;
+  const unsigned rblk = (unsigned)((T + SR_ROWS - 1) / SR_ROWS);
+  const int F = p.F, d = p.d, dff = p.dff;
+  // input LayerNorm on the gathered rows, then the embedding FFN (SetRank.py:134-135, 146)
+  hipLaunchKernelGGL(sr_ln_fwd_kernel, dim3(rblk), dim3(SR_ROWS * 64), 0, st, features, (const float*)nullptr, docids, n_docs,
+                     (int)batch, L, T, F, params + p.g_in, params + p.b_in, sv + p.sv_xg, sv + p.sv_xn0, sv + p.sv_mean_in,
+                     sv + p.sv_rstd_in);
+  SR_CHECK(gemm_xwT(sv + p.sv_xn0, params + p.w1, sv + p.sv_h0, T, F, dff, 0.f));
+  bias_act(sv + p.sv_h0, params + p.b1, T, dff, 1, st);
+  SR_CHECK(gemm_xwT(sv + p.sv_h0, params + p.w2, sv + p.sv_x[0], T, dff, d, 0.f));
+  bias_act(sv + p.sv_x[0], params + p.b2, T, d, 0, st);
+  const size_t lds_att = ((size_t)L * (p.dh + 1) + 4 * (size_t)L) * sizeof(float);
+  if (lds_att > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sr_attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_att) != hipSuccess)
+      return ULTR_E_UNSUPPORTED;
+  }
+  for (int l = 0; l < p.nl; ++l) {
+    const SrLayer& y = p.lay[l];
+    const float* x = sv + p.sv_x[l];
+    hipLaunchKernelGGL(sr_attn_fwd_kernel, dim3(batch, p.H), dim3(256), lds_att, st, x, L, d, p.dh, sv + p.sv_A[l]);
+    // o = A Wd^T + bd lands in out1's buffer, then out1 = LN1(x + o) in place (s1 keeps the pre-norm sum)
+    SR_CHECK(gemm_xwT(sv + p.sv_A[l], params + y.wd, sv + p.sv_out1[l], T, d, d, 0.f));
+    bias_act(sv + p.sv_out1[l], params + y.bd, T, d, 0, st);
+    hipLaunchKernelGGL(sr_ln_fwd_kernel, dim3(rblk), dim3(SR_ROWS * 64), 0, st, x, (const float*)(sv + p.sv_out1[l]),
+                       (const int32_t*)nullptr, (int64_t)0, (int)batch, L, T, d, params + y.g1, params + y.b1, sv + p.sv_s1[l],
+                       sv + p.sv_out1[l], sv + p.sv_m1[l], sv + p.sv_r1[l]);
+    SR_CHECK(gemm_xwT(sv + p.sv_out1[l], params + y.wf1, sv + p.sv_f[l], T, d, dff, 0.f));
+    bias_act(sv + p.sv_f[l], params + y.bf1, T, dff, 1, st);
+    SR_CHECK(gemm_xwT(sv + p.sv_f[l], params + y.wf2, sv + p.sv_x[l + 1], T, dff, d, 0.f));
+    bias_act(sv + p.sv_x[l + 1], params + y.bf2, T, d, 0, st);
+    hipLaunchKernelGGL(sr_ln_fwd_kernel, dim3(rblk), dim3(SR_ROWS * 64), 0, st, (const float*)(sv + p.sv_out1[l]),
+                       (const float*)(sv + p.sv_x[l + 1]), (const int32_t*)nullptr, (int64_t)0, (int)batch, L, T, d, params + y.g2,
+                       params + y.b2, sv + p.sv_s2[l], sv + p.sv_x[l + 1], sv + p.sv_m2[l], sv + p.sv_r2[l]);
+  }
+  // output FFN (SetRank.py:136, 153)
+  SR_CHECK(gemm_xwT(sv + p.sv_x[p.nl], params + p.wo1, sv + p.sv_oh, T, d, dff, 0.f));
+  bias_act(sv + p.sv_oh, params + p.bo1, T, dff, 1, st);
+  SR_CHECK(gemm_xwT(sv + p.sv_oh, params + p.wo2, scores, T, dff, 1, 0.f));
+  bias_act(scores, params + p.bo2, T, 1, 0, st);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ultr_setrank_backward(const ultr_setrank_desc* c, const float* params, int32_t batch, int32_t list_size,
+                                     const void* saved, const float* dscores, const void* loss_ws, int32_t n_loss_parts, void* ws_,
+                                     float* grads, void* stream) {
+  if (!params || !saved || !dscores || !ws_ || !grads || batch <= 0 || list_size <= 0) return ULTR_E_BADARG;
+  const int64_t T = (int64_t)batch * list_size;
+  SrPlan p;
+  if (!make_plan(c, T, &p)) return ULTR_E_BADARG;
+  const int L = list_size;
+  if (L > 120) return ULTR_E_UNSUPPORTED;  // the attention backward keeps two [L, L] matrices in LDS
+  hipStream_t st = (hipStream_t)stream;
+  SR_CHECK(blas_setup(st));
+  const float* sv = (const float*)saved;
+  float* ws = (float*)ws_;
+  float* G0 = ws + p.ws_g[0];
+  float* G1 = ws + p.ws_g[1];
+  float* G2 = ws + p.ws_g[2];
+  const unsigned rblk = (unsigned)((T + SR_ROWS - 1) / SR_ROWS);
+  const int F = p.F, d = p.d, dff = p.dff;
+  const size_t lds_att = ((size_t)2 * L * (p.dh + 1) + 2 * (size_t)L * L) * sizeof(float);
+  if (lds_att > 160 * 1024) return ULTR_E_UNSUPPORTED;
+  if (lds_att > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(sr_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lds_att) != hipSuccess)
+    return ULTR_E_UNSUPPORTED;
+  // ---- output FFN:  s = oh wo2^T + bo2,  oh = relu(x_nl Wo1^T + bo1) ----------------------------------------------
+  SR_CHECK(gemm_dyTx(dscores, sv + p.sv_oh, grads + p.wo2, T, dff, 1));
+  colsum(p, dscores, nullptr, nullptr, nullptr, 1, 0, ws, grads + p.bo2, st);
+  SR_CHECK(gemm_dyw(dscores, params + p.wo2, G1, T, dff, 1, 0.f));           // G1 = d oh  [T, dff]
+  relu_mask(G1, sv + p.sv_oh, T * dff, st);
+  SR_CHECK(gemm_dyTx(G1, sv + p.sv_x[p.nl], grads + p.wo1, T, d, dff));
+  colsum(p, G1, nullptr, nullptr, nullptr, dff, 0, ws, grads + p.bo1, st);
+  SR_CHECK(gemm_dyw(G1, params + p.wo1, G0, T, d, dff, 0.f));                // G0 = d x_nl  [T, d]
+  for (int l = p.nl - 1; l >= 0; --l) {
+    const SrLayer& y = p.lay[l];
+    // x_{l+1} = LN2(s2),  s2 = out1 + ffn
+    colsum(p, G0, sv + p.sv_s2[l], sv + p.sv_m2[l], sv + p.sv_r2[l], d, 1, ws, grads + y.g2, st);
+    colsum(p, G0, nullptr, nullptr, nullptr, d, 0, ws, grads + y.b2, st);
+    hipLaunchKernelGGL(sr_ln_bwd_kernel, dim3(rblk), dim3(SR_ROWS * 64), 0, st, (const float*)G0, sv + p.sv_s2[l], sv + p.sv_m2[l],
+                       sv + p.sv_r2[l], params + y.g2, T, d, G2);            // G2 = d s2 = d out1 (residual) = d ffn
+    SR_CHECK(gemm_dyTx(G2, sv + p.sv_f[l], grads + y.wf2, T, dff, d));
+    colsum(p, G2, nullptr, nullptr, nullptr, d, 0, ws, grads + y.bf2, st);
+    SR_CHECK(gemm_dyw(G2, params + y.wf2, G1, T, dff, d, 0.f));              // G1 = d f  [T, dff]
+    relu_mask(G1, sv + p.sv_f[l], T * dff, st);
+    SR_CHECK(gemm_dyTx(G1, sv + p.sv_out1[l], grads + y.wf1, T, d, dff));
+    colsum(p, G1, nullptr, nullptr, nullptr, dff, 0, ws, grads + y.bf1, st);
+    SR_CHECK(gemm_dyw(G1, params + y.wf1, G2, T, d, dff, 1.0f));             // G2 = d out1 (both paths)
+    // out1 = LN1(s1),  s1 = x_l + o
+    colsum(p, G2, sv + p.sv_s1[l], sv + p.sv_m1[l], sv + p.sv_r1[l], d, 1, ws, grads + y.g1, st);
+    colsum(p, G2, nullptr, nullptr, nullptr, d, 0, ws, grads + y.b1, st);
+    hipLaunchKernelGGL(sr_ln_bwd_kernel, dim3(rblk), dim3(SR_ROWS * 64), 0, st, (const float*)G2, sv + p.sv_s1[l], sv + p.sv_m1[l],
+                       sv + p.sv_r1[l], params + y.g1, T, d, G0);            // G0 = d s1 = d x_l (residual) = d o
+    SR_CHECK(gemm_dyTx(G0, sv + p.sv_A[l], grads + y.wd, T, d, d));
+    colsum(p, G0, nullptr, nullptr, nullptr, d, 0, ws, grads + y.bd, st);
+    SR_CHECK(gemm_dyw(G0, params + y.wd, G1, T, d, d, 0.f));                 // G1 = d A  [T, d]
+    hipLaunchKernelGGL(sr_attn_bwd_kernel, dim3(batch, p.H), dim3(256), lds_att, st, sv + p.sv_x[l], (const float*)G1, L, d, p.dh,
+                       G0);                                                  // G0 += attention path -> d x_l
+  }
+  // ---- embedding FFN and the input LayerNorm's parameters -------------------------------------------------------------
+  SR_CHECK(gemm_dyTx(G0, sv + p.sv_h0, grads + p.w2, T, dff, d));
+  colsum(p, G0, nullptr, nullptr, nullptr, d, 0, ws, grads + p.b2, st);
+  SR_CHECK(gemm_dyw(G0, params + p.w2, G1, T, dff, d, 0.f));
+  relu_mask(G1, sv + p.sv_h0, T * dff, st);
+  SR_CHECK(gemm_dyTx(G1, sv + p.sv_xn0, grads + p.w1, T, F, dff));
+  colsum(p, G1, nullptr, nullptr, nullptr, dff, 0, ws, grads + p.b1, st);
+  SR_CHECK(gemm_dyw(G1, params + p.w1, G2, T, F, dff, 0.f));                 // G2 = d xn0  [T, F]
+  colsum(p, G2, sv + p.sv_xg, sv + p.sv_mean_in, sv + p.sv_rstd_in, F, 1, ws, grads + p.g_in, st);
+  colsum(p, G2, nullptr, nullptr, nullptr, F, 0, ws, grads + p.b_in, st);
+  // ---- step tail: fold the loss partials behind the gradient ----------------------------------------------------------
+  if (loss_ws != nullptr && n_loss_parts > 0) {
+    const int tail = (int)ultr_tail_len(list_size);
+    hipLaunchKernelGGL(sr_fold_kernel, dim3((tail + 63) / 64), dim3(256), 0, st, (const float*)loss_ws, (int64_t)tail, (int)n_loss_parts,
+                       tail, grads + p.P);
+  }
+  return (int)hipGetLastError();
+}

@@ -41,8 +41,7 @@ class StepEngine:
         self.world = 1 if process_group is None else torch.distributed.get_world_size(process_group)
         P, tail = shape.n_params, hip_ops.tail_floats(self.L)
         self.P, self.tail = P, tail
-        self.saved = _f32(shape.saved_bytes(self.N) // 4, device)
-        self.bwd_ws = _f32(shape.bwd_workspace_bytes(self.N) // 4, device)
+        self._alloc(shape, device)
         self.loss_ws = _f32(hip_ops.loss_workspace_bytes(self.B, self.L) // 4, device, zero=True)
         self.scores = _f32(self.N, device).view(self.B, self.L)
         self.dscores = _f32(self.N, device).view(self.B, self.L)
@@ -64,6 +63,10 @@ class StepEngine:
         u.regulation_p = float(regulation_p)
         self.udesc = u
         self._args = None
+
+    def _alloc(self, shape, device):
+        self.saved = _f32(shape.saved_bytes(self.N) // 4, device)
+        self.bwd_ws = _f32(shape.bwd_workspace_bytes(self.N) // 4, device)
 
     # ---- forward only (validation / DNN.build) -------------------------------------------------
     def forward(self, params, features, n_docs, docids, scores=None, train=False):
@@ -154,6 +157,65 @@ class EvalEngine:
 
     def run(self, params, features, n_docs, docids, labels):
         hip_ops.dnn_forward(self.shape, params, features, n_docs, docids, self.B, self.L, self.scores, None)
+        hip_ops.ndcg(self.scores, labels, docids, n_docs, self.B, self.L, self.topn, self.ndcg, self.ndcg_ws,
+                     order_out=self.order, masked_out=self.masked)
+        return self.scores, self.ndcg
+
+
+class SetRankStepEngine(StepEngine):
+    """The same step for the SetRank ranking model: ultr_setrank_forward -> ultr_<loss> ->
+    ultr_setrank_backward -> [all-reduce] -> ultr_grad_sumsq -> ultr_apply_update.  Stage calls instead of ONE C call:
+    at SetRank's size (hundreds of microseconds to milliseconds per step) the host is not on the critical path."""
+
+    def __init__(self, shape, batch, list_size, device, **kw):
+        self._sr_shape = shape
+        super().__init__(shape, batch, list_size, device, **kw)
+
+    def _alloc(self, shape, device):
+        self.saved = _f32(shape.saved_bytes(self.N) // 4, device)
+        self.sr_ws = _f32(shape.workspace_bytes(self.N) // 4, device)
+        # sum-of-squares partials of ultr_grad_sumsq / ultr_apply_update
+        self.bwd_ws = _f32((self.P + self.tail + 63) // 64 + self.P // 4096 + 16, device)
+
+    def forward(self, params, features, n_docs, docids, scores=None, train=False):
+        scores = self.scores if scores is None else scores
+        hip_ops.setrank_forward(self.shape, params, features, n_docs, docids, self.B, self.L, scores, self.saved)
+        return scores
+
+    def backward(self, params, features, n_docs, docids):
+        hip_ops.setrank_backward(self.shape, params, self.B, self.L, self.saved, self.dscores, self.loss_ws, (self.B + 3) // 4,
+                                 self.sr_ws, self.grads)
+        if self.pg is not None:
+            torch.distributed.all_reduce(self.grads, group=self.pg)
+        hip_ops.grad_sumsq(self.grads, self.P, self.L, self.bwd_ws)
+
+    def update(self, params, state, aux=None):
+        check = _lib.check
+        check(self.shape.lib.ultr_apply_update(ctypes.byref(self.udesc), None, ctypes.c_void_p(params.data_ptr()), None,
+                                               ctypes.c_void_p(state.data_ptr()) if state is not None else None,
+                                               ctypes.c_void_p(self.grads.data_ptr()),
+                                               ctypes.c_void_p(aux.data_ptr()) if aux is not None else None,
+                                               ctypes.c_void_p(self.bwd_ws.data_ptr()), ctypes.c_void_p(self.scalars.data_ptr()),
+                                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ultr_apply_update")
+
+    def train_step(self, params, state, features, n_docs, docids, labels, aux=None, ipw_table=None, pw=None, uniforms=None):
+        self.forward(params, features, n_docs, docids, train=True)
+        if self.algo == "regem":
+            self.loss(labels, aux=aux, uniforms=uniforms)
+        else:
+            self.loss(labels, aux=aux, ipw_table=ipw_table, pw=pw)
+        self.backward(params, features, n_docs, docids)
+        self.update(params, state, aux)
+        return self.scalars
+
+
+class SetRankEvalEngine(EvalEngine):
+    def __init__(self, shape, batch, list_size, device, topn=(1, 3, 5, 10)):
+        super().__init__(shape, batch, list_size, device, topn=topn)
+        self.saved = _f32(shape.saved_bytes(self.B * self.L) // 4, device)
+
+    def run(self, params, features, n_docs, docids, labels):
+        hip_ops.setrank_forward(self.shape, params, features, n_docs, docids, self.B, self.L, self.scores, self.saved)
         hip_ops.ndcg(self.scores, labels, docids, n_docs, self.B, self.L, self.topn, self.ndcg, self.ndcg_ws,
                      order_out=self.order, masked_out=self.masked)
         return self.scores, self.ndcg

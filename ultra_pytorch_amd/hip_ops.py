@@ -64,6 +64,64 @@ class DnnShape:
         return int(self.lib.ultr_dnn_bwd_workspace_bytes(ctypes.byref(self.desc), n_rows))
 
 
+class SetRankShape:
+    """Host-side geometry of one SetRank model: descriptor + flat parameter layout in the reference's
+    state_dict order (SetRank.py:95-103, 130-141)."""
+
+    def __init__(self, feature_size, d_model=256, num_heads=8, num_layers=2, dff=64):
+        self.lib = _lib.load()
+        self.feature_size, self.d_model, self.num_heads = int(feature_size), int(d_model), int(num_heads)
+        self.num_layers, self.dff = int(num_layers), int(dff)
+        self.desc = _lib.SetRankDesc(self.feature_size, self.d_model, self.num_heads, self.num_layers, self.dff)
+        self.n_params = int(self.lib.ultr_setrank_param_count(ctypes.byref(self.desc)))
+        if self.n_params <= 0:
+            raise ValueError("bad SetRank description (d_model must be a multiple of num_heads, 1..8 layers)")
+
+    def layout(self):
+        F, d, dff = self.feature_size, self.d_model, self.dff
+        out, off = [], 0
+
+        def add(name, shape):
+            nonlocal off
+            out.append((name, tuple(shape), off))
+            n = 1
+            for v in shape:
+                n *= v
+            off += n
+
+        e = "Encoder_layer."
+        add(e + "input_layer_norm.weight", (F,)); add(e + "input_layer_norm.bias", (F,))
+        add(e + "input_embedding.0.weight", (dff, F)); add(e + "input_embedding.0.bias", (dff,))
+        add(e + "input_embedding.2.weight", (d, dff)); add(e + "input_embedding.2.bias", (d,))
+        add(e + "output_layer.0.weight", (dff, d)); add(e + "output_layer.0.bias", (dff,))
+        add(e + "output_layer.2.weight", (1, dff)); add(e + "output_layer.2.bias", (1,))
+        for i in range(self.num_layers):
+            l = e + "enc_layers.encoder%d." % i
+            add(l + "mha.dense.weight", (d, d)); add(l + "mha.dense.bias", (d,))
+            add(l + "ffn.0.weight", (dff, d)); add(l + "ffn.0.bias", (dff,))
+            add(l + "ffn.2.weight", (d, dff)); add(l + "ffn.2.bias", (d,))
+            add(l + "layernorm1.weight", (d,)); add(l + "layernorm1.bias", (d,))
+            add(l + "layernorm2.weight", (d,)); add(l + "layernorm2.bias", (d,))
+        assert off == self.n_params
+        return out
+
+    def saved_bytes(self, n_rows):
+        return int(self.lib.ultr_setrank_saved_bytes(ctypes.byref(self.desc), n_rows))
+
+    def workspace_bytes(self, n_rows):
+        return int(self.lib.ultr_setrank_workspace_bytes(ctypes.byref(self.desc), n_rows))
+
+
+def setrank_forward(shape, params, features, n_docs, docids, B, L, scores, saved):
+    check(shape.lib.ultr_setrank_forward(ctypes.byref(shape.desc), _p(params), _p(features), int(n_docs), _p(docids), int(B),
+                                         int(L), _p(scores), _p(saved), _stream()), "ultr_setrank_forward")
+
+
+def setrank_backward(shape, params, B, L, saved, dscores, loss_ws, n_loss_parts, ws, grads):
+    check(shape.lib.ultr_setrank_backward(ctypes.byref(shape.desc), _p(params), int(B), int(L), _p(saved), _p(dscores), _p(loss_ws),
+                                          int(n_loss_parts), _p(ws), _p(grads), _stream()), "ultr_setrank_backward")
+
+
 def tail_floats(L):
     return int(_lib.load().ultr_step_tail_floats(int(L)))
 

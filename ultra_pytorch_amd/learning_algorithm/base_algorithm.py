@@ -101,7 +101,8 @@ class BaseAlgorithm(object):
                       optimizer="sgd" if self.hparams.grad_strategy == "sgd" else "ada",
                       process_group=self.process_group)
             kw.update(self._engine_kwargs())
-            self._train_engines[key] = engine.StepEngine(self.model.shape, B, L, self.cuda, algo=self.ENGINE_ALGO, **kw)
+            cls = getattr(self.model, "step_engine_cls", engine.StepEngine)  # the ranking model picks its engine
+            self._train_engines[key] = cls(self.model.shape, B, L, self.cuda, algo=self.ENGINE_ALGO, **kw)
         return self._train_engines[key]
 
     def _check_hparams(self):
@@ -121,7 +122,8 @@ class BaseAlgorithm(object):
         topn = [int(t) for t in self.exp_settings["metrics_topn"]]
         key = (B, L, tuple(topn))
         if key not in self._eval_engines:
-            self._eval_engines[key] = engine.EvalEngine(self.model.shape, B, L, self.cuda, topn=topn)
+            cls = getattr(self.model, "eval_engine_cls", engine.EvalEngine)
+            self._eval_engines[key] = cls(self.model.shape, B, L, self.cuda, topn=topn)
         ev = self._eval_engines[key]
         scores, ndcg = ev.run(self.model.flat_params, self.letor_features, self.n_docs, self.docid_inputs, self.labels_LB)
         self.output = scores.clone()  # the UNMASKED scores are what callers get (base_algorithm.py / main.py:266)
