@@ -50,3 +50,26 @@ for name, (F, hidden, B, L, algo, lr) in CONFIGS.items():
     kn = ["fwd", "loss", "bwd", "wgrad", "reduce", "update", "ndcg", "fused"]
     kus = {kn[k]: round(1e3 * tot[k] / cnt[k], 1) for k in range(8) if cnt[k] > 0}
     print("%-46s %8.1f us/step %10.0f q/s  %6.2f TFLOP/s (%.1f%% of fp32 MFMA peak)  loss %.4f" % (name, dt * 1e6, B / dt, flops / dt / 1e12, 100 * flops / dt / 157.3e12, float(eng.scalars[0])), kus)
+
+
+# ---- config 5: SetRank, F220 L100 B1024, d_model 256, 8 heads x 32, 2 layers, dff 64, IPW ---------------------
+from ultra_pytorch_amd.ranking_model.SetRank import init_setrank_params
+for name, (F, B, L) in {"cfg5 IPW+SetRank F220 L100 B1024 d256 h8 l2 dff64": (220, 1024, 100),
+                        "cfg5/4 IPW+SetRank F220 L100 B256": (220, 256, 100)}.items():
+    shape = hip_ops.SetRankShape(F, 256, 8, 2, 64)
+    eng = engine.SetRankStepEngine(shape, B, L, dev, algo="softmax", learning_rate=0.05)
+    p = init_setrank_params(shape, 0).to(dev)
+    st = torch.zeros_like(p)
+    rng = np.random.RandomState(0)
+    f, i, y = synthetic.make_batch(rng, B, L, F)
+    f, nd, i, y = torch.tensor(f, device=dev), f.shape[0], torch.tensor(i, device=dev), torch.tensor(y, device=dev)
+    ipw = torch.tensor(synthetic.load_ipw(), dtype=torch.float32, device=dev)
+    for k in range(3): eng.train_step(p, st, f, nd, i, y, ipw_table=ipw)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    n = 10
+    for k in range(n): eng.train_step(p, st, f, nd, i, y, ipw_table=ipw)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+    # per token MACs: input FFN + 2 x (attention 2*L*d + dense d*d + FFN 2*d*dff) + output FFN; x3 for fwd+bwd
+    mac = F * 64 + 64 * 256 + 2 * (2 * L * 256 + 256 * 256 + 2 * 256 * 64) + 256 * 64 + 64
+    flops = 3 * 2.0 * mac * B * L
+    print("%-52s %9.1f us/step %9.0f q/s  %6.2f TFLOP/s  loss %.4f" % (name, dt * 1e6, B / dt, flops / dt / 1e12, float(eng.scalars[0])))

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <rocblas/rocblas.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/ultr_hip.h"
@@ -350,6 +351,168 @@ __global__ __launch_bounds__(256) void sr_attn_bwd_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// the same attention on the matrix cores (fp32 v_mfma_f32_16x16x4_f32): list_size <= 112, head depth 16 / 32 / 64
+// ---------------------------------------------------------------------------------------------------------
+// One workgroup (4 waves) per (list, head).  x_h [Lp, DH] (Lp = L rounded up to 16, zero rows past L) and the [Lp, Lp]
+// score / probability matrix live in LDS; 16x16 output tiles are dealt to the waves.  A lane group q = lane >> 4 owns
+// a CONTIGUOUS quarter of the contraction (any fixed permutation of k is legal in a dot product), so the A operand
+// is read as float4 from a row-major LDS tile.
+template <int DH>
+__global__ __launch_bounds__(256) void sr_attn_fwd_mfma_kernel(const float* __restrict__ x, int L, int d, float* __restrict__ A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int KQ = DH / 4, LDX = DH + 4, NC = DH / 16;
+  const int Lp = round_up(L, 16), NTL = Lp / 16, LDP = Lp + 4, KP = Lp / 4;
+  float* xs = smem;             // [Lp][LDX]
+  float* Ps = xs + Lp * LDX;    // [Lp][LDP]
+  const int b = blockIdx.x, h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+  const float* xb = x + (int64_t)b * L * d + h * DH;
+  for (int e = tid; e < Lp * (DH / 4); e += 256) {
+    const int r = e / (DH / 4), c4 = (e - r * (DH / 4)) * 4;
+    st4(xs + r * LDX + c4, r < L ? ld4(xb + (int64_t)r * d + c4) : make_float4(0.f, 0.f, 0.f, 0.f));
+  }
+  __syncthreads();
+  const float scale = 1.0f / sqrtf((float)DH);
+  for (int t = wave; t < NTL * NTL; t += 4) {
+    const int ti = t / NTL, tj = t - ti * NTL;
+    const float* ar = xs + (ti * 16 + i) * LDX + q * KQ;
+    const float* br = xs + (tj * 16 + i) * LDX + q * KQ;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < KQ; kk += 4) {
+      const float4 a4 = ld4(ar + kk), b4 = ld4(br + kk);
+      acc = mfma16(a4.x, b4.x, acc);
+      acc = mfma16(a4.y, b4.y, acc);
+      acc = mfma16(a4.z, b4.z, acc);
+      acc = mfma16(a4.w, b4.w, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ps[(ti * 16 + 4 * q + r) * LDP + tj * 16 + i] = acc[r] * scale;
+  }
+  __syncthreads();
+  for (int row = wave; row < Lp; row += 4) {
+    float* pr = Ps + row * LDP;
+    const float s0 = (lane < L) ? pr[lane] : -INFINITY, s1 = (lane + 64 < L) ? pr[lane + 64] : -INFINITY;
+    const float mx = wave_max(fmaxf(s0, s1));
+    const float e0 = (lane < L) ? expf(s0 - mx) : 0.f, e1 = (lane + 64 < L) ? expf(s1 - mx) : 0.f;
+    const float inv = (row < L) ? 1.0f / wave_sum(e0 + e1) : 0.f;
+    if (lane < Lp) pr[lane] = e0 * inv;
+    if (lane + 64 < Lp) pr[lane + 64] = e1 * inv;
+  }
+  __syncthreads();
+  for (int t = wave; t < NTL * NC; t += 4) {
+    const int ti = t / NC, tc = t - ti * NC;
+    const float* pr = Ps + (ti * 16 + i) * LDP + q * KP;
+    const float* vr = xs + (q * KP) * LDX + tc * 16 + i;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int kk = 0; kk < KP; kk += 4) {
+      const float4 p4 = ld4(pr + kk);
+      acc = mfma16(p4.x, vr[(kk + 0) * LDX], acc);
+      acc = mfma16(p4.y, vr[(kk + 1) * LDX], acc);
+      acc = mfma16(p4.z, vr[(kk + 2) * LDX], acc);
+      acc = mfma16(p4.w, vr[(kk + 3) * LDX], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = ti * 16 + 4 * q + r;
+      if (row < L) A[((int64_t)b * L + row) * d + h * DH + tc * 16 + i] = acc[r];
+    }
+  }
+}
+
+// backward: P and dP = dA x^T tiles in one sweep, dS = scale * P o (dP - rowsum(P o dP)) per row, then ONE accumulator
+// per output tile for  dq + dk + dv = dS x + dS^T x + P^T dA.
+template <int DH>
+__global__ __launch_bounds__(256) void sr_attn_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dA, int L,
+                                                               int d, float* __restrict__ dx) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int KQ = DH / 4, LDX = DH + 4, NC = DH / 16;
+  const int Lp = round_up(L, 16), NTL = Lp / 16, LDP = Lp + 4, KP = Lp / 4;
+  float* xs = smem;               // [Lp][LDX]
+  float* das = xs + Lp * LDX;     // [Lp][LDX]
+  float* Ps = das + Lp * LDX;     // [Lp][LDP]
+  float* Ds = Ps + Lp * LDP;      // [Lp][LDP]  dP, then dS (pre-scaled)
+  const int b = blockIdx.x, h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+  const int64_t base = (int64_t)b * L * d + h * DH;
+  for (int e = tid; e < Lp * (DH / 4); e += 256) {
+    const int r = e / (DH / 4), c4 = (e - r * (DH / 4)) * 4;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    st4(xs + r * LDX + c4, r < L ? ld4(x + base + (int64_t)r * d + c4) : z4);
+    st4(das + r * LDX + c4, r < L ? ld4(dA + base + (int64_t)r * d + c4) : z4);
+  }
+  __syncthreads();
+  const float scale = 1.0f / sqrtf((float)DH);
+  for (int t = wave; t < NTL * NTL; t += 4) {
+    const int ti = t / NTL, tj = t - ti * NTL;
+    const float* ar = xs + (ti * 16 + i) * LDX + q * KQ;
+    const float* gr = das + (ti * 16 + i) * LDX + q * KQ;
+    const float* br = xs + (tj * 16 + i) * LDX + q * KQ;
+    f32x4 accs = {0.f, 0.f, 0.f, 0.f}, accd = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < KQ; kk += 4) {
+      const float4 a4 = ld4(ar + kk), g4 = ld4(gr + kk), b4 = ld4(br + kk);
+      accs = mfma16(a4.x, b4.x, accs); accd = mfma16(g4.x, b4.x, accd);
+      accs = mfma16(a4.y, b4.y, accs); accd = mfma16(g4.y, b4.y, accd);
+      accs = mfma16(a4.z, b4.z, accs); accd = mfma16(g4.z, b4.z, accd);
+      accs = mfma16(a4.w, b4.w, accs); accd = mfma16(g4.w, b4.w, accd);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      Ps[(ti * 16 + 4 * q + r) * LDP + tj * 16 + i] = accs[r] * scale;
+      Ds[(ti * 16 + 4 * q + r) * LDP + tj * 16 + i] = accd[r];
+    }
+  }
+  __syncthreads();
+  for (int row = wave; row < Lp; row += 4) {
+    float* pr = Ps + row * LDP;
+    float* dr = Ds + row * LDP;
+    const float s0 = (lane < L) ? pr[lane] : -INFINITY, s1 = (lane + 64 < L) ? pr[lane + 64] : -INFINITY;
+    const float mx = wave_max(fmaxf(s0, s1));
+    const float e0 = (lane < L) ? expf(s0 - mx) : 0.f, e1 = (lane + 64 < L) ? expf(s1 - mx) : 0.f;
+    const float inv = (row < L) ? 1.0f / wave_sum(e0 + e1) : 0.f;
+    const float p0 = e0 * inv, p1 = e1 * inv;
+    const float d0 = (lane < L) ? dr[lane] : 0.f, d1 = (lane + 64 < L) ? dr[lane + 64] : 0.f;
+    const float tt = wave_sum(p0 * d0 + p1 * d1);
+    if (lane < Lp) {
+      pr[lane] = p0;
+      dr[lane] = scale * p0 * (d0 - tt);
+    }
+    if (lane + 64 < Lp) {
+      pr[lane + 64] = p1;
+      dr[lane + 64] = scale * p1 * (d1 - tt);
+    }
+  }
+  __syncthreads();
+  for (int t = wave; t < NTL * NC; t += 4) {
+    const int ti = t / NC, tc = t - ti * NC;
+    const int k0 = q * KP;
+    const float* dsrow = Ds + (ti * 16 + i) * LDP + k0;   // dS[row][k]      (float4 along k)
+    const float* dscol = Ds + k0 * LDP + ti * 16 + i;     // dS[k][row]
+    const float* pcol = Ps + k0 * LDP + ti * 16 + i;      // P[k][row]
+    const float* xr = xs + k0 * LDX + tc * 16 + i;        // x[k][col]
+    const float* gr = das + k0 * LDX + tc * 16 + i;       // dA[k][col]
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int kk = 0; kk < KP; kk += 4) {
+      const float4 s4 = ld4(dsrow + kk);
+      const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float xv = xr[(kk + u) * LDX];
+        acc = mfma16(sv[u], xv, acc);                          // dq: dS[row][k] x[k][col]
+        acc = mfma16(dscol[(kk + u) * LDP], xv, acc);          // dk: dS[k][row] x[k][col]
+        acc = mfma16(pcol[(kk + u) * LDP], gr[(kk + u) * LDX], acc);  // dv: P[k][row] dA[k][col]
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = ti * 16 + 4 * q + r;
+      if (row < L) dx[base + (int64_t)row * d + tc * 16 + i] += acc[r];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
 rocblas_handle g_handle = nullptr;
@@ -386,6 +549,54 @@ int gemm_dyTx(const float* dY, const float* X, float* dW, int64_t T, int K, int 
     const int rc_ = (call);   \
     if (rc_ != 0) return rc_; \
   } while (0)
+
+// matrix-core attention: list_size <= 112 (two [Lp, Lp] fp32 matrices + two [Lp, dh] tiles in 160 KB of LDS for the
+// backward), head depth 16 / 32 / 64, 16-byte aligned head slices; ULTR_SR_SCALAR_ATTN=1 forces the scalar kernels
+bool attn_mfma_ok(const SrPlan& p, int L) {
+  const char* v = getenv("ULTR_SR_SCALAR_ATTN");
+  if (v != nullptr && v[0] == '1') return false;
+  return L <= 112 && (p.dh == 16 || p.dh == 32 || p.dh == 64) && p.d % 4 == 0;
+}
+template <typename K>
+int set_dyn_lds(K kernel, size_t bytes) {
+  if (bytes > 160 * 1024) return ULTR_E_UNSUPPORTED;
+  if (bytes > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+    return ULTR_E_UNSUPPORTED;
+  return 0;
+}
+int attn_fwd_mfma(const SrPlan& p, const float* x, int batch, int L, float* A, hipStream_t st) {
+  const int Lp = round_up(L, 16);
+  const size_t lds = ((size_t)Lp * (p.dh + 4) + (size_t)Lp * (Lp + 4)) * sizeof(float);
+  const dim3 grid(batch, p.H);
+  if (p.dh == 16) {
+    SR_CHECK(set_dyn_lds(sr_attn_fwd_mfma_kernel<16>, lds));
+    hipLaunchKernelGGL(sr_attn_fwd_mfma_kernel<16>, grid, dim3(256), lds, st, x, L, p.d, A);
+  } else if (p.dh == 32) {
+    SR_CHECK(set_dyn_lds(sr_attn_fwd_mfma_kernel<32>, lds));
+    hipLaunchKernelGGL(sr_attn_fwd_mfma_kernel<32>, grid, dim3(256), lds, st, x, L, p.d, A);
+  } else {
+    SR_CHECK(set_dyn_lds(sr_attn_fwd_mfma_kernel<64>, lds));
+    hipLaunchKernelGGL(sr_attn_fwd_mfma_kernel<64>, grid, dim3(256), lds, st, x, L, p.d, A);
+  }
+  return 0;
+}
+int attn_bwd_mfma(const SrPlan& p, const float* x, const float* dA, int batch, int L, float* dx, hipStream_t st) {
+  const int Lp = round_up(L, 16);
+  const size_t lds = ((size_t)2 * Lp * (p.dh + 4) + (size_t)2 * Lp * (Lp + 4)) * sizeof(float);
+  const dim3 grid(batch, p.H);
+  if (p.dh == 16) {
+    SR_CHECK(set_dyn_lds(sr_attn_bwd_mfma_kernel<16>, lds));
+    hipLaunchKernelGGL(sr_attn_bwd_mfma_kernel<16>, grid, dim3(256), lds, st, x, dA, L, p.d, dx);
+  } else if (p.dh == 32) {
+    SR_CHECK(set_dyn_lds(sr_attn_bwd_mfma_kernel<32>, lds));
+    hipLaunchKernelGGL(sr_attn_bwd_mfma_kernel<32>, grid, dim3(256), lds, st, x, dA, L, p.d, dx);
+  } else {
+    SR_CHECK(set_dyn_lds(sr_attn_bwd_mfma_kernel<64>, lds));
+    hipLaunchKernelGGL(sr_attn_bwd_mfma_kernel<64>, grid, dim3(256), lds, st, x, dA, L, p.d, dx);
+  }
+  return 0;
+}
 
 void bias_act(float* y, const float* bias, int64_t T, int W, int relu, hipStream_t st) {
   const int64_t n = T * W;
@@ -447,10 +658,12 @@ extern "C" int ultr_setrank_forward(const ultr_setrank_desc* c, const float* par
                             (int)lds_att) != hipSuccess)
       return ULTR_E_UNSUPPORTED;
   }
+  const bool mfma_att = attn_mfma_ok(p, L);
   for (int l = 0; l < p.nl; ++l) {
     const SrLayer& y = p.lay[l];
     const float* x = sv + p.sv_x[l];
-    hipLaunchKernelGGL(sr_attn_fwd_kernel, dim3(batch, p.H), dim3(256), lds_att, st, x, L, d, p.dh, sv + p.sv_A[l]);
+    if (mfma_att) SR_CHECK(attn_fwd_mfma(p, x, batch, L, sv + p.sv_A[l], st));
+    else hipLaunchKernelGGL(sr_attn_fwd_kernel, dim3(batch, p.H), dim3(256), lds_att, st, x, L, d, p.dh, sv + p.sv_A[l]);
     // o = A Wd^T + bd lands in out1's buffer, then out1 = LN1(x + o) in place (s1 keeps the pre-norm sum)
     SR_CHECK(gemm_xwT(sv + p.sv_A[l], params + y.wd, sv + p.sv_out1[l], T, d, d, 0.f));
     bias_act(sv + p.sv_out1[l], params + y.bd, T, d, 0, st);
@@ -527,8 +740,9 @@ extern "C" int ultr_setrank_backward(const ultr_setrank_desc* c, const float* pa
     SR_CHECK(gemm_dyTx(G0, sv + p.sv_A[l], grads + y.wd, T, d, d));
     colsum(p, G0, nullptr, nullptr, nullptr, d, 0, ws, grads + y.bd, st);
     SR_CHECK(gemm_dyw(G0, params + y.wd, G1, T, d, d, 0.f));                 // G1 = d A  [T, d]
-    hipLaunchKernelGGL(sr_attn_bwd_kernel, dim3(batch, p.H), dim3(256), lds_att, st, sv + p.sv_x[l], (const float*)G1, L, d, p.dh,
-                       G0);                                                  // G0 += attention path -> d x_l
+    if (attn_mfma_ok(p, L)) SR_CHECK(attn_bwd_mfma(p, sv + p.sv_x[l], G1, batch, L, G0, st));   // G0 += attention path -> d x_l
+    else hipLaunchKernelGGL(sr_attn_bwd_kernel, dim3(batch, p.H), dim3(256), lds_att, st, sv + p.sv_x[l], (const float*)G1, L, d,
+                            p.dh, G0);
   }
   // ---- embedding FFN and the input LayerNorm's parameters -------------------------------------------------------------
   SR_CHECK(gemm_dyTx(G0, sv + p.sv_h0, grads + p.w2, T, dff, d));
