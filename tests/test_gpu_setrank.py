@@ -66,7 +66,8 @@ def test_setrank_golden(name):
         np.testing.assert_allclose(params[sel], d[p + "post_params"][sel], atol=5e-6, rtol=1e-5, err_msg="params")
 
 
-@pytest.mark.parametrize("B,L,F,dm,H,nl,dff", [(16, 10, 136, 64, 4, 2, 32), (3, 37, 20, 48, 6, 1, 20), (5, 100, 220, 256, 8, 2, 64)])
+@pytest.mark.parametrize("B,L,F,dm,H,nl,dff", [(16, 10, 136, 64, 4, 2, 32), (3, 37, 20, 48, 6, 1, 20), (5, 100, 220, 256, 8, 2, 64),
+                                               (64, 100, 24, 64, 4, 1, 16), (256, 10, 136, 32, 2, 2, 16)])  # split weight gradients
 def test_setrank_oracle(B, L, F, dm, H, nl, dff):
     from oracle import ultr_oracle as O
     from ultra_pytorch_amd import hip_ops, synthetic

@@ -44,6 +44,9 @@ struct SrPlan {
   int64_t ws_g[3];   // three [T, maxw] gradient buffers
   int64_t ws_part;   // [n_cs][2 * maxw] column-sum partials
   int n_cs;
+  int64_t ws_wg;     // [wg_split][max M*K] partial weight gradients (split over lists: rocBLAS would run a
+                     // [M, K] = dY^T X product with T = 100k contraction rows on a handful of workgroups)
+  int wg_split;      // chunks of whole lists, divides the batch
   int64_t ws_total;
 };
 
@@ -91,6 +94,14 @@ bool make_plan(const ultr_setrank_desc* c, int64_t T, SrPlan* p) {
   p->ws_part = w; w += (int64_t)p->n_cs * 2 * p->maxw;
   // sum-of-squares partials for ultr_apply_update live at offset 0 of a SEPARATE region at the end (ultr_grad_sumsq
   // writes them at the start of the pointer it is given)
+  // weight-gradient split: the largest divisor of T that leaves chunks of >= 512 rows, at most 128 chunks
+  p->wg_split = 1;
+  for (int sdiv = 2; sdiv <= 128 && T / sdiv >= 512; ++sdiv)
+    if (T % sdiv == 0) p->wg_split = sdiv;
+  int64_t maxmk = dff * F;
+  if (d * dff > maxmk) maxmk = d * dff;
+  if (d * d > maxmk) maxmk = d * d;
+  p->ws_wg = w; w += (int64_t)p->wg_split * maxmk;
   p->ws_total = w;
   return true;
 }
@@ -114,6 +125,40 @@ __global__ __launch_bounds__(SR_ROWS * 64) void sr_ln_fwd_kernel(const float* a,
     const int bb = (int)(n / L), ll = (int)(n % L);
     const int id = docids[(int64_t)ll * B + bb];
     ra = (id >= 0 && id < n_docs) ? a + (int64_t)id * W : nullptr;
+  }
+  if (W <= 64 * 16) {
+    // the row lives in registers between the passes (one read of a and b)
+    float v[16];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int c = lane + 64 * k;
+      v[k] = 0.f;
+      if (c < W) {
+        v[k] = ra ? ra[c] : 0.f;
+        if (b != nullptr) v[k] += b[n * W + c];
+        if (sum_out != nullptr) sum_out[n * W + c] = v[k];
+      }
+      s += v[k];
+    }
+    const float mean = wave_sum(s) / (float)W;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float dlt = (lane + 64 * k < W) ? v[k] - mean : 0.f;
+      q += dlt * dlt;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)W + SR_EPS);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int c = lane + 64 * k;
+      if (c < W) y[n * W + c] = (v[k] - mean) * rstd * gamma[c] + beta[c];
+    }
+    if (lane == 0) {
+      if (mean_out) mean_out[n] = mean;
+      if (rstd_out) rstd_out[n] = rstd;
+    }
+    return;
   }
   float s = 0.f;
   for (int c = lane; c < W; c += 64) {
@@ -203,6 +248,23 @@ __global__ __launch_bounds__(256) void sr_colsum_kernel(const float* __restrict_
       acc += v;
     }
     part[(int64_t)blockIdx.x * W + c] = acc;
+  }
+}
+// LayerNorm parameter gradients in ONE pass over dy: part[blk][c] = sum_r dy xhat, part[blk][W + c] = sum_r dy
+__global__ __launch_bounds__(256) void sr_colsum_ln_kernel(const float* __restrict__ dy, const float* __restrict__ s,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           int64_t T, int W, float* __restrict__ part) {
+  const int64_t r0 = (int64_t)blockIdx.x * SR_CS_ROWS;
+  const int64_t r1 = (r0 + SR_CS_ROWS < T) ? r0 + SR_CS_ROWS : T;
+  for (int c = threadIdx.x; c < W; c += 256) {
+    float ag = 0.f, ab = 0.f;
+    for (int64_t r = r0; r < r1; ++r) {
+      const float g = dy[r * W + c];
+      ag += g * ((s[r * W + c] - mean[r]) * rstd[r]);
+      ab += g;
+    }
+    part[(int64_t)blockIdx.x * 2 * W + c] = ag;
+    part[(int64_t)blockIdx.x * 2 * W + W + c] = ab;
   }
 }
 // dst[c] = sum over nparts partials (canonical order)
@@ -537,11 +599,22 @@ int gemm_dyw(const float* dY, const float* W, float* dX, int64_t T, int K, int M
   return rocblas_sgemm(g_handle, rocblas_operation_none, rocblas_operation_none, K, (int)T, M, &alpha, W, K, dY, M, &beta, dX,
                        K) == rocblas_status_success ? 0 : ULTR_E_UNSUPPORTED;
 }
-// row-major  dW[M, K] = dY[T, M]^T . X[T, K]
-int gemm_dyTx(const float* dY, const float* X, float* dW, int64_t T, int K, int M) {
+// row-major  dW[M, K] = dY[T, M]^T . X[T, K]: `split` equal row chunks as ONE strided-batched sgemm into partials,
+// folded in canonical order (split == 1: straight into dW)
+int gemm_dyTx(const SrPlan& p, const float* dY, const float* X, float* dW, int64_t T, int K, int M, float* ws, hipStream_t st) {
   const float alpha = 1.0f, beta = 0.0f;
-  return rocblas_sgemm(g_handle, rocblas_operation_none, rocblas_operation_transpose, K, M, (int)T, &alpha, X, K, dY, M, &beta, dW,
-                       K) == rocblas_status_success ? 0 : ULTR_E_UNSUPPORTED;
+  const int S = p.wg_split;
+  if (S <= 1 || (int64_t)M * K < 64)
+    return rocblas_sgemm(g_handle, rocblas_operation_none, rocblas_operation_transpose, K, M, (int)T, &alpha, X, K, dY, M, &beta,
+                         dW, K) == rocblas_status_success ? 0 : ULTR_E_UNSUPPORTED;
+  const int64_t rows = T / S;
+  float* part = ws + p.ws_wg;
+  if (rocblas_sgemm_strided_batched(g_handle, rocblas_operation_none, rocblas_operation_transpose, K, M, (int)rows, &alpha, X, K,
+                                    rows * K, dY, M, rows * M, &beta, part, K, (int64_t)M * K, S) != rocblas_status_success)
+    return ULTR_E_UNSUPPORTED;
+  const int len = M * K;
+  hipLaunchKernelGGL(sr_fold_kernel, dim3((len + 63) / 64), dim3(256), 0, st, (const float*)part, (int64_t)len, S, len, dW);
+  return 0;
 }
 
 #define SR_CHECK(call)        \
@@ -611,6 +684,14 @@ void colsum(const SrPlan& p, const float* a, const float* s, const float* mean, 
   float* part = ws + p.ws_part;
   hipLaunchKernelGGL(sr_colsum_kernel, dim3(p.n_cs), dim3(256), 0, st, a, s, mean, rstd, p.T, W, mode, part);
   hipLaunchKernelGGL(sr_fold_kernel, dim3((W + 63) / 64), dim3(256), 0, st, (const float*)part, (int64_t)W, p.n_cs, W, dst);
+}
+
+// dst[0..W) = d gamma, dst[W..2W) = d beta (adjacent in the flat layout: <ln>.weight then <ln>.bias)
+void colsum_ln(const SrPlan& p, const float* dy, const float* s, const float* mean, const float* rstd, int W, float* ws, float* dst,
+               hipStream_t st) {
+  float* part = ws + p.ws_part;
+  hipLaunchKernelGGL(sr_colsum_ln_kernel, dim3(p.n_cs), dim3(256), 0, st, dy, s, mean, rstd, p.T, W, part);
+  hipLaunchKernelGGL(sr_fold_kernel, dim3((2 * W + 63) / 64), dim3(256), 0, st, (const float*)part, (int64_t)2 * W, p.n_cs, 2 * W, dst);
 }
 
 }  // namespace
@@ -711,33 +792,31 @@ extern "C" int ultr_setrank_backward(const ultr_setrank_desc* c, const float* pa
                           (int)lds_att) != hipSuccess)
     return ULTR_E_UNSUPPORTED;
   // ---- output FFN:  s = oh wo2^T + bo2,  oh = relu(x_nl Wo1^T + bo1) ----------------------------------------------
-  SR_CHECK(gemm_dyTx(dscores, sv + p.sv_oh, grads + p.wo2, T, dff, 1));
+  SR_CHECK(gemm_dyTx(p, dscores, sv + p.sv_oh, grads + p.wo2, T, dff, 1, ws, st));
   colsum(p, dscores, nullptr, nullptr, nullptr, 1, 0, ws, grads + p.bo2, st);
   SR_CHECK(gemm_dyw(dscores, params + p.wo2, G1, T, dff, 1, 0.f));           // G1 = d oh  [T, dff]
   relu_mask(G1, sv + p.sv_oh, T * dff, st);
-  SR_CHECK(gemm_dyTx(G1, sv + p.sv_x[p.nl], grads + p.wo1, T, d, dff));
+  SR_CHECK(gemm_dyTx(p, G1, sv + p.sv_x[p.nl], grads + p.wo1, T, d, dff, ws, st));
   colsum(p, G1, nullptr, nullptr, nullptr, dff, 0, ws, grads + p.bo1, st);
   SR_CHECK(gemm_dyw(G1, params + p.wo1, G0, T, d, dff, 0.f));                // G0 = d x_nl  [T, d]
   for (int l = p.nl - 1; l >= 0; --l) {
     const SrLayer& y = p.lay[l];
     // x_{l+1} = LN2(s2),  s2 = out1 + ffn
-    colsum(p, G0, sv + p.sv_s2[l], sv + p.sv_m2[l], sv + p.sv_r2[l], d, 1, ws, grads + y.g2, st);
-    colsum(p, G0, nullptr, nullptr, nullptr, d, 0, ws, grads + y.b2, st);
+    colsum_ln(p, G0, sv + p.sv_s2[l], sv + p.sv_m2[l], sv + p.sv_r2[l], d, ws, grads + y.g2, st);  // g2 | b2
     hipLaunchKernelGGL(sr_ln_bwd_kernel, dim3(rblk), dim3(SR_ROWS * 64), 0, st, (const float*)G0, sv + p.sv_s2[l], sv + p.sv_m2[l],
                        sv + p.sv_r2[l], params + y.g2, T, d, G2);            // G2 = d s2 = d out1 (residual) = d ffn
-    SR_CHECK(gemm_dyTx(G2, sv + p.sv_f[l], grads + y.wf2, T, dff, d));
+    SR_CHECK(gemm_dyTx(p, G2, sv + p.sv_f[l], grads + y.wf2, T, dff, d, ws, st));
     colsum(p, G2, nullptr, nullptr, nullptr, d, 0, ws, grads + y.bf2, st);
     SR_CHECK(gemm_dyw(G2, params + y.wf2, G1, T, dff, d, 0.f));              // G1 = d f  [T, dff]
     relu_mask(G1, sv + p.sv_f[l], T * dff, st);
-    SR_CHECK(gemm_dyTx(G1, sv + p.sv_out1[l], grads + y.wf1, T, d, dff));
+    SR_CHECK(gemm_dyTx(p, G1, sv + p.sv_out1[l], grads + y.wf1, T, d, dff, ws, st));
     colsum(p, G1, nullptr, nullptr, nullptr, dff, 0, ws, grads + y.bf1, st);
     SR_CHECK(gemm_dyw(G1, params + y.wf1, G2, T, d, dff, 1.0f));             // G2 = d out1 (both paths)
     // out1 = LN1(s1),  s1 = x_l + o
-    colsum(p, G2, sv + p.sv_s1[l], sv + p.sv_m1[l], sv + p.sv_r1[l], d, 1, ws, grads + y.g1, st);
-    colsum(p, G2, nullptr, nullptr, nullptr, d, 0, ws, grads + y.b1, st);
+    colsum_ln(p, G2, sv + p.sv_s1[l], sv + p.sv_m1[l], sv + p.sv_r1[l], d, ws, grads + y.g1, st);  // g1 | b1
     hipLaunchKernelGGL(sr_ln_bwd_kernel, dim3(rblk), dim3(SR_ROWS * 64), 0, st, (const float*)G2, sv + p.sv_s1[l], sv + p.sv_m1[l],
                        sv + p.sv_r1[l], params + y.g1, T, d, G0);            // G0 = d s1 = d x_l (residual) = d o
-    SR_CHECK(gemm_dyTx(G0, sv + p.sv_A[l], grads + y.wd, T, d, d));
+    SR_CHECK(gemm_dyTx(p, G0, sv + p.sv_A[l], grads + y.wd, T, d, d, ws, st));
     colsum(p, G0, nullptr, nullptr, nullptr, d, 0, ws, grads + y.bd, st);
     SR_CHECK(gemm_dyw(G0, params + y.wd, G1, T, d, d, 0.f));                 // G1 = d A  [T, d]
     if (attn_mfma_ok(p, L)) SR_CHECK(attn_bwd_mfma(p, sv + p.sv_x[l], G1, batch, L, G0, st));   // G0 += attention path -> d x_l
@@ -745,15 +824,14 @@ extern "C" int ultr_setrank_backward(const ultr_setrank_desc* c, const float* pa
                             p.dh, G0);
   }
   // ---- embedding FFN and the input LayerNorm's parameters -------------------------------------------------------------
-  SR_CHECK(gemm_dyTx(G0, sv + p.sv_h0, grads + p.w2, T, dff, d));
+  SR_CHECK(gemm_dyTx(p, G0, sv + p.sv_h0, grads + p.w2, T, dff, d, ws, st));
   colsum(p, G0, nullptr, nullptr, nullptr, d, 0, ws, grads + p.b2, st);
   SR_CHECK(gemm_dyw(G0, params + p.w2, G1, T, dff, d, 0.f));
   relu_mask(G1, sv + p.sv_h0, T * dff, st);
-  SR_CHECK(gemm_dyTx(G1, sv + p.sv_xn0, grads + p.w1, T, F, dff));
+  SR_CHECK(gemm_dyTx(p, G1, sv + p.sv_xn0, grads + p.w1, T, F, dff, ws, st));
   colsum(p, G1, nullptr, nullptr, nullptr, dff, 0, ws, grads + p.b1, st);
   SR_CHECK(gemm_dyw(G1, params + p.w1, G2, T, F, dff, 0.f));                 // G2 = d xn0  [T, F]
-  colsum(p, G2, sv + p.sv_xg, sv + p.sv_mean_in, sv + p.sv_rstd_in, F, 1, ws, grads + p.g_in, st);
-  colsum(p, G2, nullptr, nullptr, nullptr, F, 0, ws, grads + p.b_in, st);
+  colsum_ln(p, G2, sv + p.sv_xg, sv + p.sv_mean_in, sv + p.sv_rstd_in, F, ws, grads + p.g_in, st);  // g_in | b_in
   // ---- step tail: fold the loss partials behind the gradient ----------------------------------------------------------
   if (loss_ws != nullptr && n_loss_parts > 0) {
     const int tail = (int)ultr_tail_len(list_size);
