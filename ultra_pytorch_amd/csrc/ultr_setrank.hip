@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void sr_attn_fwd_mfma_kernel(const float* __re
 // backward: P and dP = dA x^T tiles in one sweep, dS = scale * P o (dP - rowsum(P o dP)) per row, then ONE accumulator
 // per output tile for  dq + dk + dv = dS x + dS^T x + P^T dA.
 template <int DH>
-__global__ __launch_bounds__(256) void sr_attn_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dA, int L,
+__global__ __launch_bounds__(512) void sr_attn_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dA, int L,
                                                                int d, float* __restrict__ dx) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int KQ = DH / 4, LDX = DH + 4, NC = DH / 16;
@@ -497,7 +497,8 @@ __global__ __launch_bounds__(256) void sr_attn_bwd_mfma_kernel(const float* __re
   const int b = blockIdx.x, h = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
   const int64_t base = (int64_t)b * L * d + h * DH;
-  for (int e = tid; e < Lp * (DH / 4); e += 256) {
+  constexpr int NWB = 8;  // waves: one workgroup per CU (136 KB of LDS at L = 100), so two waves per SIMD hide the LDS latency
+  for (int e = tid; e < Lp * (DH / 4); e += NWB * 64) {
     const int r = e / (DH / 4), c4 = (e - r * (DH / 4)) * 4;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     st4(xs + r * LDX + c4, r < L ? ld4(x + base + (int64_t)r * d + c4) : z4);
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(256) void sr_attn_bwd_mfma_kernel(const float* __re
   }
   __syncthreads();
   const float scale = 1.0f / sqrtf((float)DH);
-  for (int t = wave; t < NTL * NTL; t += 4) {
+  for (int t = wave; t < NTL * NTL; t += NWB) {
     const int ti = t / NTL, tj = t - ti * NTL;
     const float* ar = xs + (ti * 16 + i) * LDX + q * KQ;
     const float* gr = das + (ti * 16 + i) * LDX + q * KQ;
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(256) void sr_attn_bwd_mfma_kernel(const float* __re
     }
   }
   __syncthreads();
-  for (int row = wave; row < Lp; row += 4) {
+  for (int row = wave; row < Lp; row += NWB) {
     float* pr = Ps + row * LDP;
     float* dr = Ds + row * LDP;
     const float s0 = (lane < L) ? pr[lane] : -INFINITY, s1 = (lane + 64 < L) ? pr[lane + 64] : -INFINITY;
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(256) void sr_attn_bwd_mfma_kernel(const float* __re
     }
   }
   __syncthreads();
-  for (int t = wave; t < NTL * NC; t += 4) {
+  for (int t = wave; t < NTL * NC; t += NWB) {
     const int ti = t / NC, tc = t - ti * NC;
     const int k0 = q * KP;
     const float* dsrow = Ds + (ti * 16 + i) * LDP + k0;   // dS[row][k]      (float4 along k)
@@ -554,22 +555,22 @@ __global__ __launch_bounds__(256) void sr_attn_bwd_mfma_kernel(const float* __re
     const float* pcol = Ps + k0 * LDP + ti * 16 + i;      // P[k][row]
     const float* xr = xs + k0 * LDX + tc * 16 + i;        // x[k][col]
     const float* gr = das + k0 * LDX + tc * 16 + i;       // dA[k][col]
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 aq = {0.f, 0.f, 0.f, 0.f}, ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};  // three independent chains
     for (int kk = 0; kk < KP; kk += 4) {
       const float4 s4 = ld4(dsrow + kk);
       const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const float xv = xr[(kk + u) * LDX];
-        acc = mfma16(sv[u], xv, acc);                          // dq: dS[row][k] x[k][col]
-        acc = mfma16(dscol[(kk + u) * LDP], xv, acc);          // dk: dS[k][row] x[k][col]
-        acc = mfma16(pcol[(kk + u) * LDP], gr[(kk + u) * LDX], acc);  // dv: P[k][row] dA[k][col]
+        aq = mfma16(sv[u], xv, aq);                                  // dq: dS[row][k] x[k][col]
+        ak = mfma16(dscol[(kk + u) * LDP], xv, ak);                  // dk: dS[k][row] x[k][col]
+        av = mfma16(pcol[(kk + u) * LDP], gr[(kk + u) * LDX], av);   // dv: P[k][row] dA[k][col]
       }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = ti * 16 + 4 * q + r;
-      if (row < L) dx[base + (int64_t)row * d + tc * 16 + i] += acc[r];
+      if (row < L) dx[base + (int64_t)row * d + tc * 16 + i] += (aq[r] + ak[r]) + av[r];
     }
   }
 }
@@ -660,13 +661,13 @@ int attn_bwd_mfma(const SrPlan& p, const float* x, const float* dA, int batch, i
   const dim3 grid(batch, p.H);
   if (p.dh == 16) {
     SR_CHECK(set_dyn_lds(sr_attn_bwd_mfma_kernel<16>, lds));
-    hipLaunchKernelGGL(sr_attn_bwd_mfma_kernel<16>, grid, dim3(256), lds, st, x, dA, L, p.d, dx);
+    hipLaunchKernelGGL(sr_attn_bwd_mfma_kernel<16>, grid, dim3(512), lds, st, x, dA, L, p.d, dx);
   } else if (p.dh == 32) {
     SR_CHECK(set_dyn_lds(sr_attn_bwd_mfma_kernel<32>, lds));
-    hipLaunchKernelGGL(sr_attn_bwd_mfma_kernel<32>, grid, dim3(256), lds, st, x, dA, L, p.d, dx);
+    hipLaunchKernelGGL(sr_attn_bwd_mfma_kernel<32>, grid, dim3(512), lds, st, x, dA, L, p.d, dx);
   } else {
     SR_CHECK(set_dyn_lds(sr_attn_bwd_mfma_kernel<64>, lds));
-    hipLaunchKernelGGL(sr_attn_bwd_mfma_kernel<64>, grid, dim3(256), lds, st, x, dA, L, p.d, dx);
+    hipLaunchKernelGGL(sr_attn_bwd_mfma_kernel<64>, grid, dim3(512), lds, st, x, dA, L, p.d, dx);
   }
   return 0;
 }
