@@ -20,10 +20,9 @@ from ..utils.hparams import HParams
 
 def init_setrank_params(shape, seed=None):
     """nn.LayerNorm / nn.Linear default initialisation in the flat layout (parity tests load golden weights)."""
-    g = torch.Generator()
-    if seed is None:
-        g.seed()
-    else:
+    g = None  # seed None: the global torch RNG, like nn.Linear's own initialisation (torch.manual_seed controls it)
+    if seed is not None:
+        g = torch.Generator()
         g.manual_seed(int(seed))
     flat = torch.empty(shape.n_params, dtype=torch.float32)
     pending_bound = None

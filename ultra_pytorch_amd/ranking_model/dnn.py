@@ -21,10 +21,9 @@ def init_flat_params(shape, seed=None):
     """nn.LayerNorm / nn.Linear default initialisation (what DNN.__init__ gets, DNN.py:44-52: gamma 1, beta 0,
     weight and bias U(-1/sqrt(fan_in), 1/sqrt(fan_in))) written into the flat layout.  Parity tests never rely
     on it (they load golden weights)."""
-    g = torch.Generator()
-    if seed is None:
-        g.seed()
-    else:
+    g = None  # seed None: the global torch RNG, like nn.Linear's own initialisation (torch.manual_seed controls it)
+    if seed is not None:
+        g = torch.Generator()
         g.manual_seed(int(seed))
     flat = torch.empty(shape.n_params, dtype=torch.float32)
     for j, (k, m) in enumerate(shape.dims):
