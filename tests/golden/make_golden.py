@@ -426,6 +426,10 @@ CASES = {
     "setrank_odd": lambda u: run_train_case(u, "setrank_odd", "na", 13, 7, 5, None, 2, 42, n_queries=16,
                                             model_cls="ultra.ranking_model.SetRank.SetRank",
                                             model_extra="d_model=24,num_heads=3,num_layers=1,diff=12"),
+    # the reference's own SetRank example pairs it with DLA (example/offline_setting/dla_exp_settings_setrank.json)
+    "setrank_dla_tiny": lambda u: run_train_case(u, "setrank_dla_tiny", "dla", 24, 10, 8, None, 2, 44,
+                                                 model_cls="ultra.ranking_model.SetRank.SetRank",
+                                                 model_extra="d_model=32,num_heads=2,num_layers=1,diff=16"),
     # config-5 layer shapes (F220, L100, d_model 256, 8 heads, 2 layers, dff 64) at B = 2
     "setrank_cfg5_b2": lambda u: run_train_case(u, "setrank_cfg5_b2", "ipw", 220, 100, 2, None, 1, 43, n_queries=4,
                                                 model_cls="ultra.ranking_model.SetRank.SetRank", model_extra=""),

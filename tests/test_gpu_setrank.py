@@ -113,3 +113,33 @@ def test_setrank_plugin_train_and_validation():
     assert tuple(scores.shape) == (m["B"], m["L"]) and "ndcg_10" in summary and 0.0 <= summary["ndcg_10"] <= 1.0
     outs = algo.model.build([torch.from_numpy(d["s0_features"][d["s0_docids"][l]]) for l in range(m["L"])])
     assert len(outs) == m["L"] and tuple(outs[0].shape) == (m["B"], 1)
+
+
+def test_setrank_with_dla_plugin():
+    """DLA + SetRank (the pairing of the reference's own SetRank example settings): ranker = SetRank, DenoisingNet as usual;
+    teacher-forced golden steps through the plugin classes."""
+    from ultra_pytorch_amd.utils import find_class
+    from tests.test_gpu_plugins import DataSet, load_flat, make_feed
+    d, m = load_golden("setrank_dla_tiny")
+    exp = {"learning_algorithm": "ultra_pytorch_amd.learning_algorithm.DLA", "learning_algorithm_hparams": "",
+           "ranking_model": "ultra_pytorch_amd.ranking_model.SetRank.SetRank",
+           "ranking_model_hparams": "d_model=32,num_heads=2,num_layers=1,diff=16",
+           "max_candidate_num": m["L"], "selection_bias_cutoff": m["L"], "metrics": ["ndcg"], "metrics_topn": [1, 3, 5, 10]}
+    algo = find_class(exp["learning_algorithm"])(DataSet(m["F"]), exp)
+    assert list(algo.model.state_dict().keys()) == m["param_keys"]
+    for t in range(m["n_steps"]):
+        p = "s%d_" % t
+        load_flat(algo.model, d[p + "pre_params"])
+        algo.propensity_model.flat_params.copy_(torch.from_numpy(d[p + "pre_prop_params"]))
+        loss, out, _ = algo.train(make_feed(algo, d[p + "features"], d[p + "docids"], d[p + "labels"]))
+        ref = float(d[p + "loss"])
+        assert abs(loss - ref) <= 1e-5 * max(1.0, abs(ref))
+        assert abs(algo.rank_loss - float(d[p + "rank_loss"])) < 1e-5 and abs(algo.exam_loss - float(d[p + "exam_loss"])) < 1e-5
+        g = d[p + "grads"]
+        sel = np.abs(g) > 1e-6 * max(1.0, float(np.abs(g).max()))
+        np.testing.assert_allclose(algo.model.flat_params.cpu().numpy()[sel], d[p + "post_params"][sel], atol=5e-6, rtol=1e-5)
+        # DLA's stateless Adagrad moves a parameter by lr * g / (|g| + 1e-10): sign-like, so elements whose gradient is
+        # ~0 (here the bias: the position gradients cancel to 2.7e-7) are ill-conditioned and skipped, as for the ranker
+        pg = d[p + "prop_grads"]
+        psel = np.abs(pg) > 1e-5 * float(np.abs(pg).max())
+        np.testing.assert_allclose(algo.propensity_model.flat_params.cpu().numpy()[psel], d[p + "post_prop_params"][psel], atol=1e-6)
