@@ -1513,8 +1513,9 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
 // needs no prologue of its own (ids, scores, labels, tiles, statistics, gamma/beta are all on chip already), and one
 // launch + one dependent kernel boundary disappear.  Same arithmetic as dnn_fwd_kernel + dnn_bwd2_kernel (shared
 // building blocks), same outputs: scores, saved, dz_j, vector slabs, loss partials (one per workgroup).
-// Chosen only when the batch has at most ~2 workgroups per CU: with B >= 1024 the unfused kernels fill their 16-row
-// tiles completely (here RB/16 of a tile is live) and win on throughput.
+// Chosen only when the grid is at most ONE workgroup per CU (measured, tools/fused_threshold.py: B = 256 lists of 10 -> 62 vs
+// 68 us per step; B = 288 -> 94 vs 70 us, a second round of long workgroups); larger batches use the separate kernels,
+// whose 16-row tiles are completely live.
 __host__ __device__ static inline size_t fb_lds_floats(const DnnPlan& p) {
   const size_t ld = fwd_ld(p.maxdim), ldu = bwd_ldu(p.maxdim);
   return (size_t)16 * ld * (p.nl + 1) + 16 * ldu + (size_t)8 * bwd2_cp_stride(p) + (size_t)p.pv_total + 2 * 16 * (size_t)p.nl +
@@ -2719,7 +2720,8 @@ int ultr_fused_step_softmax(const ultr_dnn_desc* d, const float* params, const f
   const size_t lds = fb_lds_floats(p) * sizeof(float);
   const bool ok = all_vec(p, vm, N, n_docs) && env_int("ULTR_NO_VEC", 0) == 0 && ((uintptr_t)wt & 15) == 0 &&
                   p.nl >= 2 && p.maxdim <= 512 && p.pv_total <= 3 * 512 * 4 && lds <= 160 * 1024 &&
-                  nblk <= 2 * (int64_t)cus &&                              // latency regime only
+                  nblk <= (int64_t)env_int("ULTR_FB_MAX_WG_PER_CU", 1) * cus &&  // one round of workgroups (tools/fused_threshold.py:
+                                                                          // B=256 62 vs 68 us, B=288 94 vs 70 us)
                   nblk <= (N + 8) / 9 + 1 &&                               // vector-slab allocation (>= 9 live rows / block)
                   p.sv_total * 4 < ((int64_t)1 << 31) && p.P * 4 < ((int64_t)1 << 31);
   if (!ok) return ULTR_E_UNSUPPORTED;
