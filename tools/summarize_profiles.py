@@ -67,4 +67,22 @@ with open(os.path.join(ROOT, "profiles", tag + "_hbm_traffic.md"), "w") as fh:
     for k in OURS:
         if k in traffic:
             fh.write("| %s | %.2f | %.1f | %.1f | %d |\n" % (k, avg_us.get(k, float("nan")), fetch.get(k, 0), write.get(k, 0), traffic[k]))
+# matrix-core occupancy (optional 4th pass): SQ_VALU_MFMA_BUSY_CYCLES sums, over all SIMDs, the cycles an MFMA occupies its pipe
+# (32 per v_mfma_f32_16x16x4_f32); GRBM_GUI_ACTIVE = GPU-busy cycles of the dispatch SUMMED over the 8 XCDs (checked: 8 x the
+# kernel duration in shader cycles).  util = busy / (active / 8 * 1024 SIMDs).
+mf = glob.glob(os.path.join(src, "mfma/**/*counter_collection.csv"), recursive=True)
+if mf:
+    busy = counter("mfma/**/*counter_collection.csv", "SQ_VALU_MFMA_BUSY_CYCLES")
+    act = counter("mfma/**/*counter_collection.csv", "GRBM_GUI_ACTIVE")
+    with open(os.path.join(ROOT, "profiles", tag + "_mfma_util.md"), "w") as fh:
+        fh.write("# %s - matrix-core occupancy per launch (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE, own pass)\n\n" % tag)
+        fh.write("`busy` = MFMA pipe cycles summed over the 1024 SIMDs (32 per v_mfma_f32_16x16x4_f32; for dnn_fb_kernel exactly\n"
+                 "256 workgroups x 3328 MFMAs x 32), `active` = GRBM_GUI_ACTIVE of the dispatch, which sums the 8 XCDs (and includes the\n"
+                 "counter-collection overhead); utilisation = busy / (active / 8 x 1024).  100 %% = the 157.3 TFLOP/s fp32 MFMA peak.\n"
+                 "The figure counts ISSUED MFMAs: padding rows of the 16-row tiles (10 of 16 live at list_size 10) and the layer-0\n"
+                 "dgrad are in it but not in bench.py's algorithmic flops.\n\n")
+        fh.write("| kernel | MFMA busy cycles | GPU active cycles (8 XCDs) | matrix-core utilisation |\n|---|---|---|---|\n")
+        for k in OURS:
+            if k in busy and act.get(k, 0) > 0:
+                fh.write("| %s | %.0f | %.0f | %.1f %% |\n" % (k, busy[k], act[k], 100.0 * busy[k] / (act[k] / 8.0 * 1024.0)))
 print(json.dumps({"avg_us": avg_us, "traffic": traffic}, indent=1))
