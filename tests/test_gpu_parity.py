@@ -310,3 +310,27 @@ def test_fused_forward_backward_step(B, L, F, hidden, n_pad, monkeypatch):
     gs = 1.0 / float(f["scalars"][3])
     np.testing.assert_allclose(f["grads"][: shape.n_params] * gs, r["grads"], rtol=1e-5,
                                atol=1e-6 * max(1.0, float(np.abs(r["grads"]).max())))
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_ipw_table_saturates_at_last_entry(fused, monkeypatch):
+    """SURVEY Appendix A.4 on the device: positions past the end of the IPW table reuse its LAST entry, unclicked
+    documents weigh 0 - in the stand-alone loss / separate kernels and in the fused forward+loss+backward kernel."""
+    from oracle import ultr_oracle as O
+    from ultra_pytorch_amd import engine, hip_ops, synthetic
+    from ultra_pytorch_amd.ranking_model import init_flat_params
+    monkeypatch.setenv("ULTR_NO_FUSED_FB", "0" if fused else "1")
+    B, L, F, hidden = 12, 10, 16, [8]
+    shape = hip_ops.DnnShape(F, hidden, "elu")
+    feats, ids, y = synthetic.make_batch(np.random.RandomState(3), B, L, F)
+    ipw = np.asarray([1.0, 2.5, 7.0], np.float32)  # 3 entries for 10 positions
+    p0 = init_flat_params(shape, seed=4).numpy()
+    eng = engine.StepEngine(shape, B, L, torch.device("cuda"), algo="softmax")
+    params, state = dev(p0.copy()), dev(np.zeros_like(p0))
+    sc = eng.train_step(params, state, dev(feats), feats.shape[0], dev(ids, torch.int32), dev(y), ipw_table=dev(ipw))
+    torch.cuda.synchronize()
+    r = O.train_step_softmax(p0, np.zeros_like(p0), F, hidden, feats, ids, y, ipw_list=ipw, lr=0.05, max_norm=5.0)
+    assert abs(float(sc[0]) - r["loss"]) <= 1e-5 * max(1.0, abs(r["loss"]))
+    gs = 1.0 / float(sc[3])
+    np.testing.assert_allclose(eng.grads.cpu().numpy()[: shape.n_params] * gs, r["grads"], rtol=1e-5,
+                               atol=1e-6 * max(1.0, float(np.abs(r["grads"]).max())))
