@@ -1359,7 +1359,8 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
     }
   };
 
-  for (int j = top; j >= 0; --j) {
+  const int jlow = bp.l0g ? 1 : 0;  // layer-0 shortcut: du_0 is never formed (BwdPlan::l0g)
+  for (int j = top; j >= jlow; --j) {
     const int K = p.K[j], M = p.M[j];
     const bool last = (j == top);
     const int par = j & 1;
@@ -1414,7 +1415,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
       lds_barrier();
     }
     TRACE_STAMP(18 + 4 * (top - j));
-    if (j > 0) stage_issue(j - 1, st);
+    if (j > jlow) stage_issue(j - 1, st);
     // ---- row pass: LayerNorm backward + activation' -> dz_{j-1}; column partials on the side ------------------
     {
       const float* gs = sm_g2 + par * ldu;
@@ -1498,10 +1499,10 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
       }
     }
     TRACE_STAMP(19 + 4 * (top - j));
-    if (j > 0) stage_commit(j - 1, st);
+    if (j > jlow) stage_commit(j - 1, st);
     lds_barrier();
   }
-  finalize(0);
+  finalize(jlow);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1817,7 +1818,8 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
     }
   };
   float* DZ = UZ;
-  for (int j = top; j >= 0; --j) {
+  const int jlow = bp.l0g ? 1 : 0;  // layer-0 shortcut: du_0 is never formed (BwdPlan::l0g)
+  for (int j = top; j >= jlow; --j) {
     const int K = p.K[j], M = p.M[j];
     const bool last = (j == top);
     if (!last) {
@@ -1947,7 +1949,7 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
     TRACE_STAMP(19 + 4 * (top - j));
     lds_barrier();
   }
-  finalize(0);
+  finalize(jlow);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2038,8 +2040,9 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
     lds_barrier();
   }
   TRACE_STAMP(9);
-  const float4 gam = ld4_masked(params + p.off_lnw[j], k0 + 4 * i, K, false);
-  const float4 bet = ld4_masked(params + p.off_lnb[j], k0 + 4 * i, K, false);
+  const bool l0g = (j == 0) && bp.l0g != 0;  // layer-0 shortcut: contract with xhat, apply gamma/beta in the epilogue
+  const float4 gam = l0g ? make_float4(1.f, 1.f, 1.f, 1.f) : ld4_masked(params + p.off_lnw[j], k0 + 4 * i, K, false);
+  const float4 bet = l0g ? make_float4(0.f, 0.f, 0.f, 0.f) : ld4_masked(params + p.off_lnb[j], k0 + 4 * i, K, false);
   const int kc = k0 + 4 * i;
   const bool k_ok0 = kc < K, k_ok1 = kc + 1 < K, k_ok2 = kc + 2 < K, k_ok3 = kc + 3 < K;
 
@@ -2176,6 +2179,7 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
   lds_barrier();
   TRACE_STAMP(11);
   float* slab = ws + wl.slab_off + (int64_t)split * ((int64_t)M * K + M);
+  float4 l0pg = make_float4(0.f, 0.f, 0.f, 0.f), l0pb = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int e = tid + 256 * it;  // float4 index inside the 64x64 block
@@ -2188,6 +2192,15 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
     s.z = ((v0.z + v1.z) + v2.z) + v3.z;
     s.w = ((v0.w + v1.w) + v2.w) + v3.w;
     const int m = m0 + ml, k = k0 + k4;
+    if (l0g && m < M && k < K) {
+      // G -> dW_0 = gamma o G + S_m * beta;  partial column sums of W_0 o G and W_0 * S_m for d gamma_0 / d beta_0
+      const float Sm = ((bred[0][ml] + bred[1][ml]) + bred[2][ml]) + bred[3][ml];
+      const float4 g4 = ld4_masked(params + p.off_lnw[0], k, K, vec), b4 = ld4_masked(params + p.off_lnb[0], k, K, vec);
+      const float4 w4 = ld4_masked(params + p.off_w[0] + (int64_t)m * K, k, K, vec);
+      l0pg.x += w4.x * s.x; l0pg.y += w4.y * s.y; l0pg.z += w4.z * s.z; l0pg.w += w4.w * s.w;
+      l0pb.x += w4.x * Sm; l0pb.y += w4.y * Sm; l0pb.z += w4.z * Sm; l0pb.w += w4.w * Sm;
+      s.x = g4.x * s.x + b4.x * Sm; s.y = g4.y * s.y + b4.y * Sm; s.z = g4.z * s.z + b4.z * Sm; s.w = g4.w * s.w + b4.w * Sm;
+    }
     if (m < M && k < K) {
       float* dst = slab + (int64_t)m * K + k;
       if (vec && k + 3 < K) {
@@ -2202,6 +2215,24 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
   }
   if (kb == 0 && tid < 64 && m0 + tid < M)
     slab[(int64_t)M * K + m0 + tid] = ((bred[0][tid] + bred[1][tid]) + bred[2][tid]) + bred[3][tid];
+  if (l0g) {
+    // fold the 16 row groups (tid >> 4) of this block in fixed order: 64 columns x {d gamma_0, d beta_0} partials
+    lds_barrier();  // everyone is done reading `red`
+    float* pgs = &red[0][0];         // [16][64]
+    float* pbs = pgs + 16 * 64;      // [16][64]
+    const int grp16 = tid >> 4, c4 = (tid & 15) * 4;
+    st4(pgs + grp16 * 64 + c4, l0pg);
+    st4(pbs + grp16 * 64 + c4, l0pb);
+    lds_barrier();
+    if (tid < 128) {
+      const int which = tid >> 6, c = tid & 63;
+      const float* src = which ? pbs : pgs;
+      float a = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) a += src[g * 64 + c];
+      if (k0 + c < K) ws[bp.l0part_off + ((int64_t)(mb * wl.nsplit + split) * 2 + which) * K + k0 + c] = a;
+    }
+  }
   TRACE_STAMP(12);
 }
 
@@ -2416,6 +2447,9 @@ bool ultr_make_bwd_plan(const DnnPlan& p, int64_t N, BwdPlan* bp) {
     w.slab_off = off; off += (int64_t)w.nsplit * ((int64_t)w.M * w.K + w.M); off = (off + 3) & ~(int64_t)3;
   }
   bp->wgrad_blocks = blk;
+  bp->l0g = 0;
+  bp->l0part_off = off;
+  if (p.nl >= 2) off += ((int64_t)bp->wl[0].nmb * bp->wl[0].nsplit * 2 * p.K[0] + 3) & ~(int64_t)3;
   bp->total = off;
   return true;
 }
@@ -2425,8 +2459,14 @@ void ultr_make_red_plan(const DnnPlan& p, const BwdPlan& bp, RedPlan* rp) {
   int s = 0;
   for (int j = 0; j < p.nl; ++j) {
     const bool last = (j == p.nl - 1);
-    rp->seg[s++] = RedSeg{p.off_lnw[j], bp.vred_off + bp.voff_g[j], 0, p.K[j], 1};
-    rp->seg[s++] = RedSeg{p.off_lnb[j], bp.vred_off + bp.voff_b[j], 0, p.K[j], 1};
+    if (j == 0 && bp.l0g) {
+      const int np0 = bp.wl[0].nmb * bp.wl[0].nsplit;
+      rp->seg[s++] = RedSeg{p.off_lnw[0], bp.l0part_off, 2 * (int64_t)p.K[0], p.K[0], np0};
+      rp->seg[s++] = RedSeg{p.off_lnb[0], bp.l0part_off + p.K[0], 2 * (int64_t)p.K[0], p.K[0], np0};
+    } else {
+      rp->seg[s++] = RedSeg{p.off_lnw[j], bp.vred_off + bp.voff_g[j], 0, p.K[j], 1};
+      rp->seg[s++] = RedSeg{p.off_lnb[j], bp.vred_off + bp.voff_b[j], 0, p.K[j], 1};
+    }
     if (last) {
       rp->seg[s++] = RedSeg{p.off_w[j], bp.vred_off + bp.voff_wk, 0, p.K[j], 1};
       rp->seg[s++] = RedSeg{p.off_b[j], bp.vred_off + bp.voff_bk, 0, 1, 1};
@@ -2591,6 +2631,7 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
   BwdPlan bp;
   if (!ultr_make_dnn_plan(d, N, &p) || !ultr_make_bwd_plan(p, N, &bp)) return ULTR_E_BADARG;
   if (fused_rb > 0) bp.nrb = (int)((N + fused_rb - 1) / fused_rb);  // vector slabs / loss partials: one per fused block
+  const bool l0g_ok = p.nl >= 2 && env_int("ULTR_NO_L0G", 0) == 0;
   const int tail = (int)ultr_tail_len(list_size);
   if (tail > 4096) return ULTR_E_UNSUPPORTED;
   const size_t lds = bwd_lds_bytes(p, bp.rblk);
@@ -2624,6 +2665,7 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
     ULTR_LAUNCH(prof, (dnn_bwd2_kernel<RR, 8, XX>), dim3(bp.nrb), dim3(512), lds2, st, p, bp, params, features,        \
                        n_docs, docids, (int)batch, (int)list_size, (const float*)saved, dscores, ws, fl);              \
   } while (0)
+  bp.l0g = ((fused_rb > 0 || v2) && l0g_ok) ? 1 : 0;  // the fast kernels skip du_0; the wgrad launch makes up for it
   if (fused_rb > 0) {
     // the row-local half already ran inside dnn_fb_kernel
   } else if (v2) {
@@ -2726,6 +2768,7 @@ int ultr_fused_step_softmax(const ultr_dnn_desc* d, const float* params, const f
                   p.sv_total * 4 < ((int64_t)1 << 31) && p.P * 4 < ((int64_t)1 << 31);
   if (!ok) return ULTR_E_UNSUPPORTED;
   bp.nrb = (int)nblk;
+  bp.l0g = (p.nl >= 2 && env_int("ULTR_NO_L0G", 0) == 0) ? 1 : 0;  // must match backward_impl's choice
   hipStream_t st = (hipStream_t)stream;
   FusedSoftmax fl = {nullptr, labels, pw, ipw_table, (int)n_ipw, dscores_out, (float*)loss_ws};
   float* ws = (float*)bwd_ws;

@@ -88,6 +88,12 @@ struct BwdPlan {
   int64_t dz_off[ULTR_MAXL];// dz_j [N, M_j], j < nl-1
   WgradLayer wl[ULTR_MAXL];
   int wgrad_blocks;
+  // Layer-0 shortcut of the fast backward kernels: the dgrad du_0 = dz_0 . W_0 exists only to feed LayerNorm_0's gamma/beta
+  // gradients.  Instead the wgrad launch contracts dz_0 with the NORMALISED input xhat_0 (G = dz_0^T xhat_0, S = sum_r dz_0) and
+  // its epilogue emits  dW_0 = gamma o G + S (x) beta  (exact algebra, no division) plus partial column sums of
+  // d gamma_0 = sum_m W_0[m,:] o G[m,:]  and  d beta_0 = sum_m W_0[m,:] S[m]  per (row block of W_0, row split).
+  int l0g;                  // 1: shortcut active (set by the launcher together with the kernel that skips du_0)
+  int64_t l0part_off;       // [nmb_0 * nsplit_0][2][K_0]
   int64_t sumsq_off;        // [n_red_blocks]
   int n_red_blocks;
   int64_t total;            // floats in bwd_ws
