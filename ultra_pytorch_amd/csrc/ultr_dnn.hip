@@ -933,7 +933,8 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd_kernel(DnnPlan p, BwdPlan bp,
     }
   }
 
-  for (int j = p.nl - 1; j >= 0; --j) {
+  const int jlow = bp.l0g ? 1 : 0;  // layer-0 shortcut: du_0 is never formed (BwdPlan::l0g)
+  for (int j = p.nl - 1; j >= jlow; --j) {
     const int K = p.K[j], M = p.M[j];
     const bool last = (j == p.nl - 1);
     const float* lnw = params + p.off_lnw[j];
@@ -2665,7 +2666,7 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
     ULTR_LAUNCH(prof, (dnn_bwd2_kernel<RR, 8, XX>), dim3(bp.nrb), dim3(512), lds2, st, p, bp, params, features,        \
                        n_docs, docids, (int)batch, (int)list_size, (const float*)saved, dscores, ws, fl);              \
   } while (0)
-  bp.l0g = ((fused_rb > 0 || v2) && l0g_ok) ? 1 : 0;  // the fast kernels skip du_0; the wgrad launch makes up for it
+  bp.l0g = l0g_ok ? 1 : 0;  // every backward kernel skips du_0; the wgrad launch makes up for it
   if (fused_rb > 0) {
     // the row-local half already ran inside dnn_fb_kernel
   } else if (v2) {
