@@ -2368,6 +2368,31 @@ bool ultr_make_dnn_plan(const ultr_dnn_desc* d, int64_t N, DnnPlan* p) {
     p->sv_rstd[j] = sv; sv += N;
   }
   p->sv_total = sv;
+  {  // update-kernel work map
+    int t = 0;
+    for (int j = 0; j < p->nl - 1; ++j) {
+      p->upd_tile_begin[j] = t;
+      p->upd_ntk[j] = (p->K[j] + 15) / 16;
+      t += ((p->M[j] + 15) / 16) * p->upd_ntk[j];
+    }
+    p->upd_tile_begin[p->nl - 1] = t;
+    int n = 0, v = 0;
+    auto seg = [&](int64_t o, int len, int pvpos) {
+      p->vs_off[n] = o; p->vs_len[n] = len; p->vs_pv[n] = pvpos; p->vs_begin[n] = v;
+      v += len; ++n;
+    };
+    for (int j = 0; j < p->nl; ++j) {
+      seg(p->off_lnw[j], 2 * p->K[j], p->pv_off[j]);  // gamma | beta are adjacent in both layouts
+      if (j < p->nl - 1) {
+        seg(p->off_b[j], p->M[j], p->pv_off[j] + 2 * p->K[j]);
+      } else {
+        seg(p->off_w[j], p->K[j], p->pv_wlast);
+        seg(p->off_b[j], 1, p->pv_off[j] + 2 * p->K[j]);
+      }
+    }
+    p->n_vs = n;
+    p->vs_begin[n] = v;
+  }
   for (int j = 0; j < p->nl; ++j) {
     DnnPlan::FwdLayer& l = p->fl[j];
     l.K = p->K[j]; l.M = p->M[j];

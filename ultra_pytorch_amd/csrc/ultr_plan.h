@@ -30,6 +30,14 @@ struct DnnPlan {
   int pv_total;           // floats, padded to a multiple of 4
   int64_t wt_total;       // weights + image
   int maxdim;             // max over all K_j (and M_j)
+  // work map of the update kernel when it maintains the copies above: 16x16 tiles over every hidden W_j (a tile is
+  // read row-major and written k-major through an LDS transpose: 64-byte segments both ways instead of a 4-byte
+  // scatter), then the vector parameters as segments (parameter offset, length, position in the image)
+  int upd_tile_begin[ULTR_MAXL + 1];  // first tile of layer j (prefix sums), j < nl-1
+  int upd_ntk[ULTR_MAXL];             // tiles along k of layer j
+  int n_vs;
+  int64_t vs_off[2 * ULTR_MAXL + 2];
+  int vs_len[2 * ULTR_MAXL + 2], vs_pv[2 * ULTR_MAXL + 2], vs_begin[2 * ULTR_MAXL + 3];
   // GEMM work split of the fast kernels (8 waves), precomputed: integer divisions in the kernel cost ~1k cycles per
   // layer.  Forward Y_j = X.W_j^T: 32-column chunks of M_j; fwd_ksplit > 1 = chunks x slices of the contraction.
   // Backward du_j = dz_j.W_j: bwd_mode 1 = 32-column chunks of K_j, 2 = 64-column chunks, 3 = 64-column chunks x

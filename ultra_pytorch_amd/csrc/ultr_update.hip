@@ -33,13 +33,15 @@ __device__ __forceinline__ float opt_step(float p, float g, float* st, int opt, 
 }
 
 // Everything after the gradient and the sum of squares are known: step scalars, clip, optimizer, k-major copy /
-// image, and (block 0) the per-position state.  EPT elements per thread: e_k = blockIdx*256*EPT + k*256 + tid.
+// image, and (block 0) the per-position state.  EPT elements per thread, indices e_a (-1 = none); the new parameter
+// values come back in p_new_a for the caller's k-major / image writes.
 template <int EPT>
 __device__ __forceinline__ void update_body(const ultr_update_desc& u, const DnnPlan& dp, float* __restrict__ params,
                                             float* __restrict__ state, const float* __restrict__ tail,
-                                            float* __restrict__ aux, float* __restrict__ wt, float ss,
+                                            float* __restrict__ aux, float ss, const int64_t (&e_a)[EPT],
                                             const float (&g_raw_a)[EPT], const float (&p_old_a)[EPT],
-                                            const float (&s_old_a)[EPT], float* sm, float* __restrict__ scalars_out) {
+                                            const float (&s_old_a)[EPT], float (&p_new_a)[EPT], float* sm,
+                                            float* __restrict__ scalars_out) {
   const int64_t P = u.n_params;
   const int L = u.list_size;
   const float loss_sum = tail[0], D = tail[1], loss2 = tail[2], D2 = tail[3];
@@ -73,37 +75,17 @@ __device__ __forceinline__ void update_body(const ultr_update_desc& u, const Dnn
   const bool stateless = (u.algo == ULTR_ALGO_DLA);
 #pragma unroll
   for (int k = 0; k < EPT; ++k) {
-    const int64_t e = ((int64_t)blockIdx.x * EPT + k) * 256 + threadIdx.x;
+    const int64_t e = e_a[k];  // -1: no element
     const float g_raw = g_raw_a[k], p_old = p_old_a[k], s_old = s_old_a[k];
-    if (e < P) {
+    p_new_a[k] = 0.f;
+    if (e >= 0 && e < P) {
       float g = g_raw * gs;
       g *= coef;
       float s_new = s_old;
       const float pn = opt_step(p_old, g, &s_new, u.optimizer, stateless || state == nullptr, u.learning_rate, u.adagrad_eps);
       params[e] = pn;
       if (state != nullptr && !stateless && u.optimizer != ULTR_OPT_SGD) state[e] = s_new;
-      if (wt != nullptr) {
-        // keep the k-major copy of the hidden Linear weights current: WT_j[k, m] = W_j[m, k]; every other
-        // parameter goes to the packed vector-parameter image behind it (DnnPlan::wt_pv_off)
-        bool hidden_w = false;
-        for (int j = 0; j < dp.nl - 1; ++j) {
-          const int r = (int)(e - dp.off_w[j]);
-          const int K = dp.K[j], M = dp.M[j];
-          if (e >= dp.off_w[j] && r < M * K) {
-            int m = (int)((float)r * (1.0f / (float)K));  // r / K without the integer divide; fix the +-1
-            int kk = r - m * K;
-            if (kk < 0) { --m; kk += K; }
-            if (kk >= K) { ++m; kk -= K; }
-            wt[dp.wt_off[j] + (int64_t)kk * M + m] = pn;
-            hidden_w = true;
-            break;
-          }
-        }
-        if (!hidden_w) {
-          const int pv = ultr_pv_index(dp, e);
-          if (pv >= 0) wt[dp.wt_pv_off + pv] = pn;
-        }
-      }
+      p_new_a[k] = pn;
     }
   }
   if (blockIdx.x != 0) return;
@@ -164,14 +146,15 @@ __device__ __forceinline__ void update_body(const ultr_update_desc& u, const Dnn
 
 __global__ __launch_bounds__(256) void update_kernel(ultr_update_desc u, DnnPlan dp, float* __restrict__ params,
                                                      float* __restrict__ state, const float* __restrict__ grads,
-                                                     float* __restrict__ aux, float* __restrict__ wt,
-                                                     const float* __restrict__ sumsq_part, int nsq,
+                                                     float* __restrict__ aux, const float* __restrict__ sumsq_part, int nsq,
                                                      float* __restrict__ scalars_out) {
+  // flat variant (no k-major copy to maintain): one element per thread, loads issued BEFORE the norm reduction so
+  // that the two memory round trips overlap
   __shared__ float sm[4];
   const int64_t P = u.n_params;
-  // this thread's element: issue its loads BEFORE the norm reduction so that the two memory round trips overlap
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool live = e < P;
+  const int64_t ea[1] = {live ? e : -1};
   const float g_raw[1] = {live ? grads[e] : 0.f};
   const float p_old[1] = {live ? params[e] : 0.f};
   const float s_old[1] = {(live && state != nullptr) ? state[e] : 0.f};
@@ -179,7 +162,68 @@ __global__ __launch_bounds__(256) void update_kernel(ultr_update_desc u, DnnPlan
 #pragma unroll 8
   for (int k = threadIdx.x; k < nsq; k += 256) ss += sumsq_part[k];
   ss = block_sum256(ss, sm);
-  update_body<1>(u, dp, params, state, grads + P, aux, wt, ss, g_raw, p_old, s_old, sm, scalars_out);
+  float pn[1];
+  update_body<1>(u, dp, params, state, grads + P, aux, ss, ea, g_raw, p_old, s_old, pn, sm, scalars_out);
+}
+
+// Variant that keeps the k-major weight copy and the vector-parameter image current (DnnPlan::wt_*).  Workgroups
+// [0, n_tiles): one 16x16 tile of a hidden W_j - thread (r, c) updates W_j[m0 + r][k0 + c] (64-byte row segments) and
+// the tile goes out transposed through LDS as WT_j[k0 + r][m0 + c] (64-byte segments again; a per-element scatter wrote
+// 4 bytes per 64-byte sector: 3.5 MB of write traffic for 0.4 MB of data and ~1 us of the kernel).  The remaining
+// workgroups walk the vector parameters segment by segment and write the image.
+__global__ __launch_bounds__(256) void update_tiled_kernel(ultr_update_desc u, DnnPlan dp, float* __restrict__ params,
+                                                           float* __restrict__ state, const float* __restrict__ grads,
+                                                           float* __restrict__ aux, float* __restrict__ wt,
+                                                           const float* __restrict__ sumsq_part, int nsq,
+                                                           float* __restrict__ scalars_out) {
+  __shared__ float sm[4];
+  __shared__ float tile[16][17];
+  const int64_t P = u.n_params;
+  const int n_tiles = dp.upd_tile_begin[dp.nl - 1];
+  const int tid = threadIdx.x, r = tid >> 4, c = tid & 15;
+  int64_t ea[1] = {-1};
+  int j = 0, m0 = 0, k0 = 0, pvpos = -1;
+  const bool is_tile = (int)blockIdx.x < n_tiles;
+  if (is_tile) {
+    while (j + 1 < dp.nl - 1 && (int)blockIdx.x >= dp.upd_tile_begin[j + 1]) ++j;
+    const int t = (int)blockIdx.x - dp.upd_tile_begin[j];
+    const int tm = t / dp.upd_ntk[j];
+    m0 = tm * 16;
+    k0 = (t - tm * dp.upd_ntk[j]) * 16;
+    if (m0 + r < dp.M[j] && k0 + c < dp.K[j]) ea[0] = dp.off_w[j] + (int64_t)(m0 + r) * dp.K[j] + k0 + c;
+  } else {
+    const int v = ((int)blockIdx.x - n_tiles) * 256 + tid;
+    if (v < dp.vs_begin[dp.n_vs]) {
+      int sg = 0;
+      while (sg + 1 < dp.n_vs && v >= dp.vs_begin[sg + 1]) ++sg;
+      ea[0] = dp.vs_off[sg] + (v - dp.vs_begin[sg]);
+      pvpos = dp.vs_pv[sg] + (v - dp.vs_begin[sg]);
+    }
+  }
+  const int64_t e = ea[0];
+  const bool live = e >= 0;
+  const float g_raw[1] = {live ? grads[e] : 0.f};
+  const float p_old[1] = {live ? params[e] : 0.f};
+  const float s_old[1] = {(live && state != nullptr) ? state[e] : 0.f};
+  float ss = 0.f;
+#pragma unroll 8
+  for (int k = tid; k < nsq; k += 256) ss += sumsq_part[k];
+  ss = block_sum256(ss, sm);
+  float pn[1];
+  // block 0's extra duties (EM / propensity updates, step scalars) run inside update_body and need all 256 threads
+  if (blockIdx.x != 0) {
+    update_body<1>(u, dp, params, state, grads + P, aux, ss, ea, g_raw, p_old, s_old, pn, sm, nullptr);
+  } else {
+    update_body<1>(u, dp, params, state, grads + P, aux, ss, ea, g_raw, p_old, s_old, pn, sm, scalars_out);
+  }
+  if (is_tile) {
+    tile[r][c] = pn[0];
+    __syncthreads();
+    const int k = k0 + r, m = m0 + c;  // transposed ownership
+    if (k < dp.K[j] && m < dp.M[j]) wt[dp.wt_off[j] + (int64_t)k * dp.M[j] + m] = tile[c][r];
+  } else if (pvpos >= 0) {
+    wt[dp.wt_pv_off + pvpos] = pn[0];
+  }
 }
 
 extern "C" int ultr_apply_update(const ultr_update_desc* u, const ultr_dnn_desc* d, float* params, float* wt, float* state,
@@ -196,9 +240,15 @@ extern "C" int ultr_apply_update(const ultr_update_desc* u, const ultr_dnn_desc*
   if (u->optimizer == ULTR_OPT_ADAGRAD && u->algo != ULTR_ALGO_DLA && !state) return ULTR_E_BADARG;
   const int tail = (int)ultr_tail_len(u->list_size);
   const int nsq = (int)ultr_red_blocks(u->n_params, tail);
-  const int nblk = (int)((u->n_params + 255) / 256);
   UltrProfScope prof(ULTR_K_UPDATE, (hipStream_t)stream);
-  ULTR_LAUNCH(prof, update_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *u, dp, params, state, grads, aux, wt,
-                     (const float*)bwd_ws, nsq, scalars_out);
+  if (wt != nullptr) {
+    const int nblk = dp.upd_tile_begin[dp.nl - 1] + (dp.vs_begin[dp.n_vs] + 255) / 256;
+    ULTR_LAUNCH(prof, update_tiled_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *u, dp, params, state, grads, aux, wt,
+                (const float*)bwd_ws, nsq, scalars_out);
+  } else {
+    const int nblk = (int)((u->n_params + 255) / 256);
+    ULTR_LAUNCH(prof, update_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *u, dp, params, state, grads, aux,
+                (const float*)bwd_ws, nsq, scalars_out);
+  }
   return (int)hipGetLastError();
 }
