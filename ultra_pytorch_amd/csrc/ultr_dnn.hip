@@ -1675,13 +1675,19 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
         const int r = wave + NW * q;
         const float rstd = rsqrt_nr(v[q] * invK + ULTR_LN_EPS);
         if (!last) {
+          // the weight gradients' operand goes to HBM from here: u_j, or xhat_0 for the layer-0 shortcut
+          float* wop = saved + p.sv_x[j] + (n0 + r) * K;
+          const bool xhat_only = (j == 0) && bp.l0g != 0;
 #pragma unroll
           for (int u = 0; u < XC; ++u) {
             const int c = 4 * lane + 256 * u;
             if (c < K32) {
               const float4 xx = x[q][u];
-              st4(UZ + r * ld + c, make_float4(xx.x * rstd * g4[u].x + b4[u].x, xx.y * rstd * g4[u].y + b4[u].y,
-                                               xx.z * rstd * g4[u].z + b4[u].z, xx.w * rstd * g4[u].w + b4[u].w));
+              const float4 xh = make_float4(xx.x * rstd, xx.y * rstd, xx.z * rstd, xx.w * rstd);
+              const float4 uu = make_float4(xh.x * g4[u].x + b4[u].x, xh.y * g4[u].y + b4[u].y, xh.z * g4[u].z + b4[u].z,
+                                            xh.w * g4[u].w + b4[u].w);
+              st4(UZ + r * ld + c, uu);
+              if (c < K && r < rows_valid) st4(wop + c, xhat_only ? xh : uu);
             }
           }
         }
@@ -1706,7 +1712,7 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
     if (!last) {
       // ---- Linear_j + activation: UZ . WT_j -> XS_{j+1} (LDS) and saved x_{j+1} (HBM, for the weight gradients) ----
       float* Y = XSall + (size_t)(j + 1) * R * ld;
-      float* gout = saved + lay.sv_x_next + n0 * M;
+      float* gout = nullptr;  // x_{j+1} stays on chip; `saved` gets the wgrad operand in the next LayerNorm
       const Src Wt = make_src(wt + lay.wt_off, (int64_t)K * M);
       const int nch = lay.nch, ksplit = lay.ksplit, klen = lay.klen;
       GemmPipe<RT, 2, FWD_D, 0> pipe;
@@ -1746,7 +1752,6 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
           vv.z = act_fwd(vv.z + bb.z, p.act);
           vv.w = act_fwd(vv.w + bb.w, p.act);
           st4(Y + row * ld + c4, vv);
-          if (row < rows_valid) st4(gout + (int64_t)row * M + c4, vv);
         }
       }
       lds_barrier();
@@ -2021,11 +2026,12 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
   if (nend > N) nend = N;
 
   const Src dz = make_src(ws + wl.dz_off, N * M);
-  const Src xs = (j == 0) ? make_src(features, n_docs * K) : make_src(saved + p.sv_x[j], N * K);
+  const bool prenorm = bp.wg_prenorm != 0;  // `saved` holds the ready-made operand (also for layer 0: no ids, no gather)
+  const Src xs = (j == 0 && !prenorm) ? make_src(features, n_docs * K) : make_src(saved + p.sv_x[j], N * K);
   const Src meansrc = make_src(saved + p.sv_mean[j], N);
   const Src rstdsrc = make_src(saved + p.sv_rstd[j], N);
   const int64_t nsplit0 = (int64_t)split * wl.rows_per_split;
-  if (j == 0) {
+  if (j == 0 && !prenorm) {
     // layer 0 reads feature rows through the doc ids: resolve them once into LDS so that the main loop has no
     // dependent global load (a docid -> row chain forces vmcnt(0) and drains the prefetch ring)
     for (int r = tid; r < wl.rows_per_split; r += 256) {
@@ -2057,8 +2063,9 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
   // Raw operands are kept in the prefetch ring and the LayerNorm transform is applied when a step is CONSUMED:
   // transforming at load time would make every load's first use immediate and drain the ring (measured: ~2.7k
   // cycles per 16-MFMA step, one exposed memory latency each).
-  auto mainloop = [&](auto layer0_tag) {
+  auto mainloop = [&](auto layer0_tag, auto prenorm_tag) {
   constexpr bool LAYER0 = decltype(layer0_tag)::value;
+  constexpr bool PRENORM = decltype(prenorm_tag)::value;  // operand ready-made in `saved`: two loads per step, no transform
   auto load_step = [&](int64_t n, float4& a4, float4& x4, float& mean, float& rstd) {
     const bool ok = n < nend;
     if constexpr (VEC) {
@@ -2072,8 +2079,13 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
       } else {
         x4 = buf_ld4(xs, (unsigned)(n * K + kc) * 4u);
       }
-      mean = buf_ld1(meansrc, (unsigned)n * 4u);
-      rstd = buf_ld1(rstdsrc, (unsigned)n * 4u);
+      if constexpr (PRENORM) {
+        mean = 0.f;
+        rstd = 1.f;
+      } else {
+        mean = buf_ld1(meansrc, (unsigned)n * 4u);
+        rstd = buf_ld1(rstdsrc, (unsigned)n * 4u);
+      }
     } else {
       a4 = ld4_sel<VEC>(dz, n * M, ok, m0 + 4 * i, M);
       if constexpr (LAYER0) {
@@ -2113,10 +2125,14 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
       bsum.w += a_c.w;
       const float av[4] = {a_c.x, a_c.y, a_c.z, a_c.w};
       float bv[4];
-      bv[0] = (VEC || k_ok0) ? ((x_c.x - mean) * rstd * gam.x + bet.x) : 0.f;
-      bv[1] = (VEC || k_ok1) ? ((x_c.y - mean) * rstd * gam.y + bet.y) : 0.f;
-      bv[2] = (VEC || k_ok2) ? ((x_c.z - mean) * rstd * gam.z + bet.z) : 0.f;
-      bv[3] = (VEC || k_ok3) ? ((x_c.w - mean) * rstd * gam.w + bet.w) : 0.f;
+      if constexpr (PRENORM) {
+        bv[0] = x_c.x; bv[1] = x_c.y; bv[2] = x_c.z; bv[3] = x_c.w;
+      } else {
+        bv[0] = (VEC || k_ok0) ? ((x_c.x - mean) * rstd * gam.x + bet.x) : 0.f;
+        bv[1] = (VEC || k_ok1) ? ((x_c.y - mean) * rstd * gam.y + bet.y) : 0.f;
+        bv[2] = (VEC || k_ok2) ? ((x_c.z - mean) * rstd * gam.z + bet.z) : 0.f;
+        bv[3] = (VEC || k_ok3) ? ((x_c.w - mean) * rstd * gam.w + bet.w) : 0.f;
+      }
 #pragma unroll
       for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
@@ -2153,8 +2169,14 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
   };  // mainloop
   // the layer-0 variant (doc ids -> feature rows through LDS) and the plain variant are separate straight-line
   // loops: a branch on j inside the loop would put the loads in control flow and drain vmcnt(0) every step
-  if (j == 0) mainloop(std::true_type{});
-  else mainloop(std::false_type{});
+  if constexpr (VEC) {
+    if (prenorm) mainloop(std::false_type{}, std::true_type{});
+    else if (j == 0) mainloop(std::true_type{}, std::false_type{});
+    else mainloop(std::false_type{}, std::false_type{});
+  } else {
+    if (j == 0) mainloop(std::true_type{}, std::false_type{});
+    else mainloop(std::false_type{}, std::false_type{});
+  }
   TRACE_STAMP(10);
   // ---- cross-wave reduction through LDS (fixed order) -------------------------------------------
   // lane holds D_{ta,tb}[row = 4q + r][col = i]  ->  block-local (m = 4*(4q+r) + ta, k = 4*i + tb)
@@ -2363,6 +2385,9 @@ bool ultr_make_dnn_plan(const ultr_dnn_desc* d, int64_t N, DnnPlan* p) {
     sv += N * p->K[j];
     sv = (sv + 3) & ~(int64_t)3;
   }
+  p->sv_x[0] = sv;  // normalised layer-0 input for the weight gradients (fused kernel, BwdPlan::wg_prenorm)
+  sv += N * p->K[0];
+  sv = (sv + 3) & ~(int64_t)3;
   for (int j = 0; j < p->nl; ++j) {
     p->sv_mean[j] = sv; sv += N;
     p->sv_rstd[j] = sv; sv += N;
@@ -2692,6 +2717,7 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
                        n_docs, docids, (int)batch, (int)list_size, (const float*)saved, dscores, ws, fl);              \
   } while (0)
   bp.l0g = l0g_ok ? 1 : 0;  // every backward kernel skips du_0; the wgrad launch makes up for it
+  bp.wg_prenorm = (fused_rb > 0) ? 1 : 0;  // the fused kernel left the ready-made wgrad operands in `saved`
   if (fused_rb > 0) {
     // the row-local half already ran inside dnn_fb_kernel
   } else if (v2) {
@@ -2795,6 +2821,7 @@ int ultr_fused_step_softmax(const ultr_dnn_desc* d, const float* params, const f
   if (!ok) return ULTR_E_UNSUPPORTED;
   bp.nrb = (int)nblk;
   bp.l0g = (p.nl >= 2 && env_int("ULTR_NO_L0G", 0) == 0) ? 1 : 0;  // must match backward_impl's choice
+  bp.wg_prenorm = 1;
   hipStream_t st = (hipStream_t)stream;
   FusedSoftmax fl = {nullptr, labels, pw, ipw_table, (int)n_ipw, dscores_out, (float*)loss_ws};
   float* ws = (float*)bwd_ws;

@@ -52,7 +52,7 @@ struct DnnPlan {
   } fl[ULTR_MAXL];
   int bwd_mode[ULTR_MAXL], bwd_msplit[ULTR_MAXL], bwd_mlen[ULTR_MAXL], bwd_nch[ULTR_MAXL];
   // saved-for-backward workspace (floats): xs[j] = input of LayerNorm_j, j >= 1; stats for all j
-  int64_t sv_x[ULTR_MAXL];     // [N, K_j]   (j >= 1)
+  int64_t sv_x[ULTR_MAXL];     // [N, K_j]   (j >= 1: activations; j = 0: only written in wg_prenorm mode)
   int64_t sv_mean[ULTR_MAXL];  // [N]
   int64_t sv_rstd[ULTR_MAXL];  // [N]
   int64_t sv_total;
@@ -101,6 +101,10 @@ struct BwdPlan {
   // its epilogue emits  dW_0 = gamma o G + S (x) beta  (exact algebra, no division) plus partial column sums of
   // d gamma_0 = sum_m W_0[m,:] o G[m,:]  and  d beta_0 = sum_m W_0[m,:] S[m]  per (row block of W_0, row split).
   int l0g;                  // 1: shortcut active (set by the launcher together with the kernel that skips du_0)
+  // 1: `saved` holds what the wgrad launch contracts with, ready-made (the fused forward+backward kernel keeps x_j on chip, so
+  // its copies in `saved` serve the weight gradients only): u_j = LayerNorm_j output for j >= 1, xhat_0 (l0g) or u_0 for j = 0.
+  // The wgrad loop then issues two loads per 16 MFMAs instead of four and applies no transform.
+  int wg_prenorm;
   int64_t l0part_off;       // [nmb_0 * nsplit_0][2][K_0]
   int64_t sumsq_off;        // [n_red_blocks]
   int n_red_blocks;
