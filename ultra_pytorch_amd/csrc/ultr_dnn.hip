@@ -2050,6 +2050,21 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
   const bool l0g = (j == 0) && bp.l0g != 0;  // layer-0 shortcut: contract with xhat, apply gamma/beta in the epilogue
   const float4 gam = l0g ? make_float4(1.f, 1.f, 1.f, 1.f) : ld4_masked(params + p.off_lnw[j], k0 + 4 * i, K, false);
   const float4 bet = l0g ? make_float4(0.f, 0.f, 0.f, 0.f) : ld4_masked(params + p.off_lnb[j], k0 + 4 * i, K, false);
+  // layer-0 shortcut: the epilogue's operands (this thread's four W_0 pieces, gamma_0, beta_0) are requested NOW and ride
+  // through the main loop in registers - fetched in the epilogue they added ~4k cycles of exposed latency to its tail
+  float4 l0w[4], l0g4 = make_float4(0.f, 0.f, 0.f, 0.f), l0b4 = l0g4;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) l0w[it] = l0g4;
+  if (l0g) {
+    const int kq = k0 + (tid & 15) * 4;
+    l0g4 = ld4_masked(params + p.off_lnw[0], kq, K, wl.vec != 0);
+    l0b4 = ld4_masked(params + p.off_lnb[0], kq, K, wl.vec != 0);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int m = m0 + ((tid + 256 * it) >> 4);
+      if (m < M) l0w[it] = ld4_masked(params + p.off_w[0] + (int64_t)m * K, kq, K, wl.vec != 0);
+    }
+  }
   const int kc = k0 + 4 * i;
   const bool k_ok0 = kc < K, k_ok1 = kc + 1 < K, k_ok2 = kc + 2 < K, k_ok3 = kc + 3 < K;
 
@@ -2218,8 +2233,7 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
     if (l0g && m < M && k < K) {
       // G -> dW_0 = gamma o G + S_m * beta;  partial column sums of W_0 o G and W_0 * S_m for d gamma_0 / d beta_0
       const float Sm = ((bred[0][ml] + bred[1][ml]) + bred[2][ml]) + bred[3][ml];
-      const float4 g4 = ld4_masked(params + p.off_lnw[0], k, K, vec), b4 = ld4_masked(params + p.off_lnb[0], k, K, vec);
-      const float4 w4 = ld4_masked(params + p.off_w[0] + (int64_t)m * K, k, K, vec);
+      const float4 g4 = l0g4, b4 = l0b4, w4 = l0w[it];
       l0pg.x += w4.x * s.x; l0pg.y += w4.y * s.y; l0pg.z += w4.z * s.z; l0pg.w += w4.w * s.w;
       l0pb.x += w4.x * Sm; l0pb.y += w4.y * Sm; l0pb.z += w4.z * Sm; l0pb.w += w4.w * Sm;
       s.x = g4.x * s.x + b4.x * Sm; s.y = g4.y * s.y + b4.y * Sm; s.z = g4.z * s.z + b4.z * Sm; s.w = g4.w * s.w + b4.w * Sm;
