@@ -2491,7 +2491,10 @@ bool ultr_make_bwd_plan(const DnnPlan& p, int64_t N, BwdPlan* bp) {
   // wgrad geometry
   int tiles = 0;
   for (int j = 0; j < p.nl - 1; ++j) tiles += ((p.M[j] + 63) / 64) * ((p.K[j] + 63) / 64);
-  const int target = env_int("ULTR_WGRAD_WGS", 384);
+  // workgroups over all hidden Linears: about one per CU for a small batch (every workgroup is a chain of latencies and a
+  // second one on the CU only slows both), about two per CU otherwise - measured (tools/sweep_wgrad.sh, bench_configs.py):
+  // N = 2560 rows: 224 -> 12.3 us, 392 -> 12.7, 448 -> 13.0;  N = 10240: 224 -> 36, 392 -> 33, 448 -> 30 us
+  const int target = env_int("ULTR_WGRAD_WGS", N < 4096 ? 224 : 448);
   int blk = 0;
   for (int j = 0; j < p.nl - 1; ++j) {
     WgradLayer& w = bp->wl[j];
