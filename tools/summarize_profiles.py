@@ -11,7 +11,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 OURS = ["dnn_fwd_kernel", "softmax_ce_kernel", "dnn_bwd_kernel", "dnn_wgrad_kernel", "grad_reduce_kernel",
         "update_kernel", "grad_sumsq_kernel", "click_batch_kernel", "dnn_fb_kernel"]
-ALIAS = {"dnn_bwd2_kernel": "dnn_bwd_kernel"}  # the fast row-local backward kernel reports under bench.py's slot name
+ALIAS = {"dnn_bwd2_kernel": "dnn_bwd_kernel", "update_tiled_kernel": "update_kernel"}  # the fast row-local backward kernel reports under bench.py's slot name
 
 
 def short(name):
