@@ -7,7 +7,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from tests.hipref import HipRun  # noqa: E402
+from tests.hipref import HipRun, dev  # noqa: E402
 
 CONFIGS = {
     # name: (F, hidden, B, L, algo, lr)
@@ -156,3 +156,51 @@ def test_batch_permutation_invariance_and_determinism():
     np.testing.assert_array_equal(s2, s1[perm])  # scores are per-document: exact
     np.testing.assert_allclose(g2, g1, rtol=2e-4, atol=2e-5 * float(np.abs(g1).max()))
     np.testing.assert_allclose(t2[:4], t1[:4], rtol=1e-5)
+
+
+@pytest.mark.parametrize("algo", ["ipw", "dla"])
+def test_multi_step_trajectory_and_ndcg_parity(algo):
+    """BASELINE metric, second half: NDCG@10 parity.  40 training steps on the SAME batch sequence from the SAME
+    initialisation, once on the HIP path and once with the oracle; trajectories are not compared bit-wise (fp32 order
+    noise compounds) but they must stay close: for IPW the loss within 2e-3 relative after 40 steps, NDCG@10 of the
+    two final models on a held-out batch within 0.005 and identical top-10 orderings for at least 90% of the lists."""
+    from oracle import ultr_oracle as O
+    from ultra_pytorch_amd import engine, hip_ops, synthetic
+    from ultra_pytorch_amd.ranking_model import init_flat_params
+    F, hidden, B, L, steps = 136, [64, 32], 64, 10, 40
+    shape = hip_ops.DnnShape(F, hidden, "elu")
+    rng = np.random.RandomState(21)
+    batches = [synthetic.make_batch(rng, B, L, F) for _ in range(steps)]
+    vf, vi, vy = synthetic.make_batch(rng, 256, L, F, clicks=False)  # held-out, true labels
+    ipw = np.asarray(synthetic.load_ipw(), np.float32)
+    p0 = init_flat_params(shape, seed=5).numpy()
+    # ---- HIP
+    eng = engine.StepEngine(shape, B, L, torch.device("cuda"), algo="softmax" if algo == "ipw" else "dla")
+    p = dev(p0.copy())
+    st = dev(np.zeros_like(p0)) if algo == "ipw" else None
+    aux = None if algo == "ipw" else dev(np.zeros(L + 1, np.float32))
+    for f, i, y in batches:
+        sc = eng.train_step(p, st, dev(f), f.shape[0], dev(i, torch.int32), dev(y), aux=aux,
+                            ipw_table=dev(ipw) if algo == "ipw" else None)
+    torch.cuda.synchronize()
+    hip_loss, hip_params = float(sc[0]), p.cpu().numpy()
+    # ---- oracle
+    po, so, pp = p0.copy(), np.zeros_like(p0), np.zeros(L + 1, np.float32)
+    for f, i, y in batches:
+        if algo == "ipw":
+            r = O.train_step_softmax(po, so, F, hidden, f, i, y, ipw_list=ipw, lr=0.05, max_norm=5.0)
+            po, so = r["params"], r["state"]
+        else:
+            r = O.dla_step(po, pp, F, hidden, f, i, y, lr=0.05, max_norm=5.0)
+            po, pp = r["params"], r["prop_params"]
+    # DLA's optimizer is sign-like (stateless Adagrad: every parameter moves by +-lr whatever |g| is, SURVEY A.5), so a
+    # rounding-level sign flip of one tiny gradient sends the two runs apart: only a statistical band is meaningful there
+    # (the reference itself differs by 0.04-0.15 in the scores at step 3 between 1 and 8 CPU threads, BASELINE.md)
+    ltol, ntol = (2e-3, 0.005) if algo == "ipw" else (5e-2, 0.03)
+    assert abs(hip_loss - r["loss"]) <= ltol * max(1.0, abs(r["loss"])), (hip_loss, r["loss"])
+    vh = O.validation(hip_params, F, hidden, vf, vi, vy, topn=(10,))
+    vo = O.validation(po, F, hidden, vf, vi, vy, topn=(10,))
+    assert abs(float(vh["ndcg"][0]) - float(vo["ndcg"][0])) <= ntol, (vh["ndcg"], vo["ndcg"])
+    if algo == "ipw":
+        same = (vh["argsort"][:, :10] == vo["argsort"][:, :10]).all(axis=1).mean()
+        assert same >= 0.9, same
