@@ -1966,7 +1966,7 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
 // Per step a lane issues two 16-byte loads (dz row piece along m, x row piece along k) feeding 16 MFMAs:
 // A[i][kk] = dz[n+kk][m0+4i+ta], B[kk][j] = u[n+kk][k0+4j+tb]  ->  D_{ta,tb}[i][j] = dW[m0+4i+ta][k0+4j+tb].
 #ifndef WG_D
-#define WG_D 2  // register sets of the wgrad operand ring (3 was measured no faster)
+#define WG_D 3  // register sets of the wgrad operand ring (operands requested two trips ahead; pays with one workgroup per CU)
 #endif
 template <bool VEC>
 __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, const float* __restrict__ params,
