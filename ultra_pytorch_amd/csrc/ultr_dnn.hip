@@ -27,11 +27,18 @@
 // ------------------------------------------------------------------------------------------------
 // LDS leading dimensions
 // ------------------------------------------------------------------------------------------------
+// Row stride of the LDS tiles that feed MFMA A-fragments: a multiple of 32 columns (zero padding read by the pipelined GEMM)
+// plus ULTR_LD_PAD floats.  The 16 lanes of a float4 A read sit in 16 different rows: conflict-free when (stride / 4) is odd,
+// i.e. stride = 4 (mod 8).  4 is the smallest such pad; it keeps a 512-wide forward tile pair + parameter image under 80 KB
+// (two workgroups per CU at BASELINE config 3).
+#ifndef ULTR_LD_PAD
+#define ULTR_LD_PAD 4
+#endif
 // forward buffers: float4 epilogue stores / float4 A reads of the generic path -> ld % 4 == 0; rows padded so that
 // the pipelined GEMM may read (masked) up to 31 columns past K
-__host__ __device__ static inline int fwd_ld(int maxdim) { return round_up(maxdim, 32) + 36; }
+__host__ __device__ static inline int fwd_ld(int maxdim) { return round_up(maxdim, 32) + ULTR_LD_PAD; }
 // backward dz buffer: float4 A-fragment reads, rows zero-padded to a multiple of 32 (see gemm_nn)
-__host__ __device__ static inline int bwd_ldz(int maxdim) { return round_up(maxdim, 32) + 36; }
+__host__ __device__ static inline int bwd_ldz(int maxdim) { return round_up(maxdim, 32) + ULTR_LD_PAD; }
 // backward du buffer: float4 epilogue stores -> ld % 4 == 0
 __host__ __device__ static inline int bwd_ldu(int maxdim) { return round_up(maxdim, 16) + 4; }
 
