@@ -76,11 +76,13 @@ if mf:
     act = counter("mfma/**/*counter_collection.csv", "GRBM_GUI_ACTIVE")
     with open(os.path.join(ROOT, "profiles", tag + "_mfma_util.md"), "w") as fh:
         fh.write("# %s - matrix-core occupancy per launch (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE, own pass)\n\n" % tag)
-        fh.write("`busy` = MFMA pipe cycles summed over the 1024 SIMDs (32 per v_mfma_f32_16x16x4_f32; for dnn_fb_kernel exactly\n"
-                 "256 workgroups x 3328 MFMAs x 32), `active` = GRBM_GUI_ACTIVE of the dispatch, which sums the 8 XCDs (and includes the\n"
-                 "counter-collection overhead); utilisation = busy / (active / 8 x 1024).  100 %% = the 157.3 TFLOP/s fp32 MFMA peak.\n"
-                 "The figure counts ISSUED MFMAs: padding rows of the 16-row tiles (10 of 16 live at list_size 10) and the layer-0\n"
-                 "dgrad are in it but not in bench.py's algorithmic flops.\n\n")
+        fb = busy.get("dnn_fb_kernel", 0.0)
+        fh.write("`busy` = MFMA pipe cycles summed over the 1024 SIMDs (32 per v_mfma_f32_16x16x4_f32%s),\n"
+                 "`active` = GRBM_GUI_ACTIVE of the dispatch, which sums the 8 XCDs (and includes the counter-collection overhead);\n"
+                 "utilisation = busy / (active / 8 x 1024).  100 %% = the 157.3 TFLOP/s fp32 MFMA peak.\n"
+                 "The figure counts ISSUED MFMAs: the padding rows of the 16-row tiles (10 of 16 live at list_size 10) are in it but\n"
+                 "not in bench.py's algorithmic flops.\n\n"
+                 % ("; dnn_fb_kernel: %.0f MFMAs per workgroup x 256 workgroups" % (fb / 32.0 / 256.0) if fb else ""))
         fh.write("| kernel | MFMA busy cycles | GPU active cycles (8 XCDs) | matrix-core utilisation |\n|---|---|---|---|\n")
         for k in OURS:
             if k in busy and act.get(k, 0) > 0:
