@@ -413,164 +413,246 @@ __global__ __launch_bounds__(256) void sr_attn_bwd_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// the same attention on the matrix cores (fp32 v_mfma_f32_16x16x4_f32): list_size <= 112, head depth 16 / 32 / 64
+// the same attention on the matrix cores (fp32 v_mfma_f32_16x16x4_f32): list_size <= 128, head depth 16 / 32 / 64
 // ---------------------------------------------------------------------------------------------------------
-// One workgroup (4 waves) per (list, head).  x_h [Lp, DH] (Lp = L rounded up to 16, zero rows past L) and the [Lp, Lp]
-// score / probability matrix live in LDS; 16x16 output tiles are dealt to the waves.  A lane group q = lane >> 4 owns
-// a CONTIGUOUS quarter of the contraction (any fixed permutation of k is legal in a dot product), so the A operand
-// is read as float4 from a row-major LDS tile.
+// One workgroup per (list, head), one WAVE per block of 16 tokens; the only LDS is the head slice x_h [Lp, DH]
+// (Lp = L rounded up to 16, zero rows past L).  The [L, L] score matrix never exists in memory:
+//  * SetRank has no Q/K/V projections, so S = x x^T is symmetric.  The wave computes the TRANSPOSED tiles
+//    D[key][query] = x[key tile] . x[query block]^T: in the MFMA result layout lane (i, q) then holds, for ITS query i,
+//    the scores of keys {16 t + 4 q + r}: the whole softmax row sits in 4 lanes (in-register max / sum + two
+//    cross-lane steps), and the probabilities are ALREADY the A operand of P.V (any fixed permutation of the
+//    contraction index is legal as long as the B operand follows it: B reads V[key(q, t, r)][c] from LDS).
+//  * A lane group q = lane >> 4 owns a contiguous quarter of the head depth in the S contraction (float4 LDS reads).
+constexpr int SR_MAXT = 8;  // 16-token blocks per list (list_size <= 128)
+
+__device__ __forceinline__ float quad_max(float v) {  // over the 4 lanes {i, i+16, i+32, i+48}
+  v = fmaxf(v, __shfl_xor(v, 16));
+  return fmaxf(v, __shfl_xor(v, 32));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __shfl_xor(v, 16);
+  return v + __shfl_xor(v, 32);
+}
+
+// stage the head slice(s) into LDS, zero rows past L
+template <int DH, bool WITH_DA>
+__device__ __forceinline__ void sr_stage_head(const float* __restrict__ x, const float* __restrict__ dA, int64_t base, int L, int Lp,
+                                              int d, float* xs, float* das, int tid, int nthr) {
+  constexpr int LDX = DH + 4;
+  for (int e = tid; e < Lp * (DH / 4); e += nthr) {
+    const int r = e / (DH / 4), c4 = (e - r * (DH / 4)) * 4;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    st4(xs + r * LDX + c4, r < L ? ld4(x + base + (int64_t)r * d + c4) : z4);
+    if (WITH_DA) st4(das + r * LDX + c4, r < L ? ld4(dA + base + (int64_t)r * d + c4) : z4);
+  }
+}
+
+// tile  D[row = 16 ta + (4 q + r)][col = block of bf] = sum_k  a[16 ta + i][k] * bf[i][k]   (a from LDS, bf = fragments)
 template <int DH>
-__global__ __launch_bounds__(256) void sr_attn_fwd_mfma_kernel(const float* __restrict__ x, int L, int d, float* __restrict__ A) {
+__device__ __forceinline__ f32x4 sr_tile_nt(const float* arow, const float4 (&bf)[DH / 16]) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int f = 0; f < DH / 16; ++f) {
+    const float4 a4 = ld4(arow + 4 * f);
+    acc = mfma16(a4.x, bf[f].x, acc);
+    acc = mfma16(a4.y, bf[f].y, acc);
+    acc = mfma16(a4.z, bf[f].z, acc);
+    acc = mfma16(a4.w, bf[f].w, acc);
+  }
+  return acc;
+}
+
+template <int DH>
+__global__ __launch_bounds__(SR_MAXT * 64) void sr_attn_fwd_mfma_kernel(const float* __restrict__ x, int L, int d,
+                                                                       float* __restrict__ A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int KQ = DH / 4, LDX = DH + 4, NC = DH / 16;
-  const int Lp = round_up(L, 16), NTL = Lp / 16, LDP = Lp + 4, KP = Lp / 4;
-  float* xs = smem;             // [Lp][LDX]
-  float* Ps = xs + Lp * LDX;    // [Lp][LDP]
+  constexpr int KQ = DH / 4, LDX = DH + 4, NC = DH / 16, NF = DH / 16;
+  const int Lp = round_up(L, 16), NTL = Lp / 16;
+  float* xs = smem;  // [Lp][LDX]
   const int b = blockIdx.x, h = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
-  const float* xb = x + (int64_t)b * L * d + h * DH;
-  for (int e = tid; e < Lp * (DH / 4); e += 256) {
-    const int r = e / (DH / 4), c4 = (e - r * (DH / 4)) * 4;
-    st4(xs + r * LDX + c4, r < L ? ld4(xb + (int64_t)r * d + c4) : make_float4(0.f, 0.f, 0.f, 0.f));
-  }
+  const int64_t base = (int64_t)b * L * d + h * DH;
+  sr_stage_head<DH, false>(x, nullptr, base, L, Lp, d, xs, nullptr, tid, NTL * 64);
   __syncthreads();
   const float scale = 1.0f / sqrtf((float)DH);
-  for (int t = wave; t < NTL * NTL; t += 4) {
-    const int ti = t / NTL, tj = t - ti * NTL;
-    const float* ar = xs + (ti * 16 + i) * LDX + q * KQ;
-    const float* br = xs + (tj * 16 + i) * LDX + q * KQ;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float4 bq[NF];  // this wave's query block
 #pragma unroll
-    for (int kk = 0; kk < KQ; kk += 4) {
-      const float4 a4 = ld4(ar + kk), b4 = ld4(br + kk);
-      acc = mfma16(a4.x, b4.x, acc);
-      acc = mfma16(a4.y, b4.y, acc);
-      acc = mfma16(a4.z, b4.z, acc);
-      acc = mfma16(a4.w, b4.w, acc);
-    }
+  for (int f = 0; f < NF; ++f) bq[f] = ld4(xs + (wave * 16 + i) * LDX + q * KQ + 4 * f);
+  f32x4 pr[SR_MAXT];  // pr[t][r]: key 16 t + 4 q + r, query = this lane's i
+  float mx = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Ps[(ti * 16 + 4 * q + r) * LDP + tj * 16 + i] = acc[r] * scale;
-  }
-  __syncthreads();
-  for (int row = wave; row < Lp; row += 4) {
-    float* pr = Ps + row * LDP;
-    const float s0 = (lane < L) ? pr[lane] : -INFINITY, s1 = (lane + 64 < L) ? pr[lane + 64] : -INFINITY;
-    const float mx = wave_max(fmaxf(s0, s1));
-    const float e0 = (lane < L) ? expf(s0 - mx) : 0.f, e1 = (lane + 64 < L) ? expf(s1 - mx) : 0.f;
-    const float inv = (row < L) ? 1.0f / wave_sum(e0 + e1) : 0.f;
-    if (lane < Lp) pr[lane] = e0 * inv;
-    if (lane + 64 < Lp) pr[lane + 64] = e1 * inv;
-  }
-  __syncthreads();
-  for (int t = wave; t < NTL * NC; t += 4) {
-    const int ti = t / NC, tc = t - ti * NC;
-    const float* pr = Ps + (ti * 16 + i) * LDP + q * KP;
-    const float* vr = xs + (q * KP) * LDX + tc * 16 + i;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int kk = 0; kk < KP; kk += 4) {
-      const float4 p4 = ld4(pr + kk);
-      acc = mfma16(p4.x, vr[(kk + 0) * LDX], acc);
-      acc = mfma16(p4.y, vr[(kk + 1) * LDX], acc);
-      acc = mfma16(p4.z, vr[(kk + 2) * LDX], acc);
-      acc = mfma16(p4.w, vr[(kk + 3) * LDX], acc);
+  for (int t = 0; t < SR_MAXT; ++t) {
+    if (t < NTL) {
+      pr[t] = sr_tile_nt<DH>(xs + (t * 16 + i) * LDX + q * KQ, bq);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pr[t][r] = (t * 16 + 4 * q + r < L) ? pr[t][r] * scale : -INFINITY;
+        mx = fmaxf(mx, pr[t][r]);
+      }
     }
+  }
+  mx = quad_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < SR_MAXT; ++t) {
+    if (t < NTL) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pr[t][r] = expf(pr[t][r] - mx);  // exp(-inf) = 0 for the padding keys
+        sum += pr[t][r];
+      }
+    }
+  }
+  const float inv = 1.0f / quad_sum(sum);
+  f32x4 o[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) o[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < SR_MAXT; ++t) {
+    if (t < NTL) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = pr[t][r] * inv;
+        const float* vr = xs + (t * 16 + 4 * q + r) * LDX + i;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) o[c] = mfma16(pv, vr[c * 16], o[c]);
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = ti * 16 + 4 * q + r;
-      if (row < L) A[((int64_t)b * L + row) * d + h * DH + tc * 16 + i] = acc[r];
+      const int row = wave * 16 + 4 * q + r;
+      if (row < L) A[base + (int64_t)row * d + c * 16 + i] = o[c][r];
     }
   }
 }
 
-// backward: P and dP = dA x^T tiles in one sweep, dS = scale * P o (dP - rowsum(P o dP)) per row, then ONE accumulator
-// per output tile for  dq + dk + dv = dS x + dS^T x + P^T dA.
+// backward.  With P and dP = dA x^T,  dS = scale * P o (dP - rowsum(P o dP)),  dx += dS x + dS^T x + P^T dA.
+// A wave owns a block of 16 tokens twice over:
+//  (A) as QUERIES it works on transposed tiles exactly like the forward (softmax row, rowsum and dS in registers),
+//      accumulates dq = dS x, and leaves the three row statistics (max, 1 / sum, rowsum) in LDS;
+//  (B) as KEYS it needs the COLUMNS of dS and P: it recomputes the plain tiles D[query][key] (bitwise the same
+//      products in the same order as the transposed tile the other wave used), rebuilds P and dS from the saved
+//      statistics - lane (i, q) now holds, for ITS key i, the queries {16 t + 4 q + r}, the A operand of
+//      dk = dS^T x and dv = P^T dA.
+// 40% more MFMAs than materialising P and dS, but no [L, L] matrices in LDS: 32 KB instead of 136 KB per workgroup,
+// one barrier, several workgroups per CU.  All three products land in the same accumulator tile.
 template <int DH>
-__global__ __launch_bounds__(512) void sr_attn_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dA, int L,
-                                                               int d, float* __restrict__ dx) {
+__global__ __launch_bounds__(SR_MAXT * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void sr_attn_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dA,
+                                                                       int L, int d, float* __restrict__ dx) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int KQ = DH / 4, LDX = DH + 4, NC = DH / 16;
-  const int Lp = round_up(L, 16), NTL = Lp / 16, LDP = Lp + 4, KP = Lp / 4;
-  float* xs = smem;               // [Lp][LDX]
-  float* das = xs + Lp * LDX;     // [Lp][LDX]
-  float* Ps = das + Lp * LDX;     // [Lp][LDP]
-  float* Ds = Ps + Lp * LDP;      // [Lp][LDP]  dP, then dS (pre-scaled)
+  constexpr int KQ = DH / 4, LDX = DH + 4, NC = DH / 16, NF = DH / 16;
+  const int Lp = round_up(L, 16), NTL = Lp / 16;
+  float* xs = smem;              // [Lp][LDX]
+  float* das = xs + Lp * LDX;    // [Lp][LDX]
+  float* st_mx = das + Lp * LDX; // [Lp] row max | [Lp] 1 / row sum | [Lp] rowsum(P o dP)
+  float* st_inv = st_mx + Lp;
+  float* st_t = st_inv + Lp;
   const int b = blockIdx.x, h = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
   const int64_t base = (int64_t)b * L * d + h * DH;
-  constexpr int NWB = 8;  // waves: one workgroup per CU (136 KB of LDS at L = 100), so two waves per SIMD hide the LDS latency
-  for (int e = tid; e < Lp * (DH / 4); e += NWB * 64) {
-    const int r = e / (DH / 4), c4 = (e - r * (DH / 4)) * 4;
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    st4(xs + r * LDX + c4, r < L ? ld4(x + base + (int64_t)r * d + c4) : z4);
-    st4(das + r * LDX + c4, r < L ? ld4(dA + base + (int64_t)r * d + c4) : z4);
-  }
+  sr_stage_head<DH, true>(x, dA, base, L, Lp, d, xs, das, tid, NTL * 64);
   __syncthreads();
   const float scale = 1.0f / sqrtf((float)DH);
-  for (int t = wave; t < NTL * NTL; t += NWB) {
-    const int ti = t / NTL, tj = t - ti * NTL;
-    const float* ar = xs + (ti * 16 + i) * LDX + q * KQ;
-    const float* gr = das + (ti * 16 + i) * LDX + q * KQ;
-    const float* br = xs + (tj * 16 + i) * LDX + q * KQ;
-    f32x4 accs = {0.f, 0.f, 0.f, 0.f}, accd = {0.f, 0.f, 0.f, 0.f};
+  float4 bx[NF], bg[NF];  // this wave's block: x rows and dA rows
 #pragma unroll
-    for (int kk = 0; kk < KQ; kk += 4) {
-      const float4 a4 = ld4(ar + kk), g4 = ld4(gr + kk), b4 = ld4(br + kk);
-      accs = mfma16(a4.x, b4.x, accs); accd = mfma16(g4.x, b4.x, accd);
-      accs = mfma16(a4.y, b4.y, accs); accd = mfma16(g4.y, b4.y, accd);
-      accs = mfma16(a4.z, b4.z, accs); accd = mfma16(g4.z, b4.z, accd);
-      accs = mfma16(a4.w, b4.w, accs); accd = mfma16(g4.w, b4.w, accd);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      Ps[(ti * 16 + 4 * q + r) * LDP + tj * 16 + i] = accs[r] * scale;
-      Ds[(ti * 16 + 4 * q + r) * LDP + tj * 16 + i] = accd[r];
-    }
+  for (int f = 0; f < NF; ++f) {
+    bx[f] = ld4(xs + (wave * 16 + i) * LDX + q * KQ + 4 * f);
+    bg[f] = ld4(das + (wave * 16 + i) * LDX + q * KQ + 4 * f);
   }
-  __syncthreads();
-  for (int row = wave; row < Lp; row += NWB) {
-    float* pr = Ps + row * LDP;
-    float* dr = Ds + row * LDP;
-    const float s0 = (lane < L) ? pr[lane] : -INFINITY, s1 = (lane + 64 < L) ? pr[lane + 64] : -INFINITY;
-    const float mx = wave_max(fmaxf(s0, s1));
-    const float e0 = (lane < L) ? expf(s0 - mx) : 0.f, e1 = (lane + 64 < L) ? expf(s1 - mx) : 0.f;
-    const float inv = (row < L) ? 1.0f / wave_sum(e0 + e1) : 0.f;
-    const float p0 = e0 * inv, p1 = e1 * inv;
-    const float d0 = (lane < L) ? dr[lane] : 0.f, d1 = (lane + 64 < L) ? dr[lane + 64] : 0.f;
-    const float tt = wave_sum(p0 * d0 + p1 * d1);
-    if (lane < Lp) {
-      pr[lane] = p0;
-      dr[lane] = scale * p0 * (d0 - tt);
-    }
-    if (lane + 64 < Lp) {
-      pr[lane + 64] = p1;
-      dr[lane + 64] = scale * p1 * (d1 - tt);
-    }
-  }
-  __syncthreads();
-  for (int t = wave; t < NTL * NC; t += NWB) {
-    const int ti = t / NC, tc = t - ti * NC;
-    const int k0 = q * KP;
-    const float* dsrow = Ds + (ti * 16 + i) * LDP + k0;   // dS[row][k]      (float4 along k)
-    const float* dscol = Ds + k0 * LDP + ti * 16 + i;     // dS[k][row]
-    const float* pcol = Ps + k0 * LDP + ti * 16 + i;      // P[k][row]
-    const float* xr = xs + k0 * LDX + tc * 16 + i;        // x[k][col]
-    const float* gr = das + k0 * LDX + tc * 16 + i;       // dA[k][col]
-    f32x4 aq = {0.f, 0.f, 0.f, 0.f}, ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};  // three independent chains
-    for (int kk = 0; kk < KP; kk += 4) {
-      const float4 s4 = ld4(dsrow + kk);
-      const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
+  f32x4 acc[NC];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float xv = xr[(kk + u) * LDX];
-        aq = mfma16(sv[u], xv, aq);                                  // dq: dS[row][k] x[k][col]
-        ak = mfma16(dscol[(kk + u) * LDP], xv, ak);                  // dk: dS[k][row] x[k][col]
-        av = mfma16(pcol[(kk + u) * LDP], gr[(kk + u) * LDX], av);   // dv: P[k][row] dA[k][col]
+  for (int c = 0; c < NC; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  {  // ---- (A) the block as queries
+    f32x4 pr[SR_MAXT], dp[SR_MAXT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < SR_MAXT; ++t) {
+      if (t < NTL) {
+        const float* arow = xs + (t * 16 + i) * LDX + q * KQ;
+        pr[t] = sr_tile_nt<DH>(arow, bx);   // S^T[key][query]
+        dp[t] = sr_tile_nt<DH>(arow, bg);   // dP^T[key][query] = x[key] . dA[query]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pr[t][r] = (t * 16 + 4 * q + r < L) ? pr[t][r] * scale : -INFINITY;
+          mx = fmaxf(mx, pr[t][r]);
+        }
       }
     }
+    mx = quad_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < SR_MAXT; ++t) {
+      if (t < NTL) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pr[t][r] = expf(pr[t][r] - mx);
+          sum += pr[t][r];
+        }
+      }
+    }
+    const float inv = 1.0f / quad_sum(sum);
+    float tt = 0.f;
+#pragma unroll
+    for (int t = 0; t < SR_MAXT; ++t) {
+      if (t < NTL) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pr[t][r] *= inv;
+          tt += pr[t][r] * dp[t][r];
+        }
+      }
+    }
+    tt = quad_sum(tt);
+    if (q == 0) {
+      st_mx[wave * 16 + i] = mx;
+      st_inv[wave * 16 + i] = inv;
+      st_t[wave * 16 + i] = tt;
+    }
+#pragma unroll
+    for (int t = 0; t < SR_MAXT; ++t) {
+      if (t < NTL) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float ds = scale * pr[t][r] * (dp[t][r] - tt);
+          const float* xr = xs + (t * 16 + 4 * q + r) * LDX + i;
+#pragma unroll
+          for (int c = 0; c < NC; ++c) acc[c] = mfma16(ds, xr[c * 16], acc[c]);   // dq
+        }
+      }
+    }
+  }
+  __syncthreads();
+  {  // ---- (B) the block as keys
+#pragma unroll
+    for (int t = 0; t < SR_MAXT; ++t) {
+      if (t < NTL) {
+        const f32x4 s = sr_tile_nt<DH>(xs + (t * 16 + i) * LDX + q * KQ, bx);    // S[query][key]
+        const f32x4 g = sr_tile_nt<DH>(das + (t * 16 + i) * LDX + q * KQ, bx);   // dP[query][key] = dA[query] . x[key]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qr = t * 16 + 4 * q + r;   // the query of this register
+          const float pv = (qr < L) ? expf(s[r] * scale - st_mx[qr]) * st_inv[qr] : 0.f;
+          const float ds = scale * pv * (g[r] - st_t[qr]);
+          const float* xr = xs + qr * LDX + i;
+          const float* gr = das + qr * LDX + i;
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            acc[c] = mfma16(ds, xr[c * 16], acc[c]);   // dk
+            acc[c] = mfma16(pv, gr[c * 16], acc[c]);   // dv
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = ti * 16 + 4 * q + r;
-      if (row < L) dx[base + (int64_t)row * d + tc * 16 + i] += (aq[r] + ak[r]) + av[r];
+      const int row = wave * 16 + 4 * q + r;
+      if (row < L) dx[base + (int64_t)row * d + c * 16 + i] += acc[c][r];
     }
   }
 }
@@ -624,12 +706,12 @@ int gemm_dyTx(const SrPlan& p, const float* dY, const float* X, float* dW, int64
     if (rc_ != 0) return rc_; \
   } while (0)
 
-// matrix-core attention: list_size <= 112 (two [Lp, Lp] fp32 matrices + two [Lp, dh] tiles in 160 KB of LDS for the
-// backward), head depth 16 / 32 / 64, 16-byte aligned head slices; ULTR_SR_SCALAR_ATTN=1 forces the scalar kernels
+// matrix-core attention: list_size <= 128 (one wave per 16-token block), head depth 16 / 32 / 64, 16-byte aligned head
+// slices; ULTR_SR_SCALAR_ATTN=1 forces the scalar kernels
 bool attn_mfma_ok(const SrPlan& p, int L) {
   const char* v = getenv("ULTR_SR_SCALAR_ATTN");
   if (v != nullptr && v[0] == '1') return false;
-  return L <= 112 && (p.dh == 16 || p.dh == 32 || p.dh == 64) && p.d % 4 == 0;
+  return L <= 16 * SR_MAXT && (p.dh == 16 || p.dh == 32 || p.dh == 64) && p.d % 4 == 0;
 }
 template <typename K>
 int set_dyn_lds(K kernel, size_t bytes) {
@@ -641,33 +723,26 @@ int set_dyn_lds(K kernel, size_t bytes) {
 }
 int attn_fwd_mfma(const SrPlan& p, const float* x, int batch, int L, float* A, hipStream_t st) {
   const int Lp = round_up(L, 16);
-  const size_t lds = ((size_t)Lp * (p.dh + 4) + (size_t)Lp * (Lp + 4)) * sizeof(float);
-  const dim3 grid(batch, p.H);
-  if (p.dh == 16) {
-    SR_CHECK(set_dyn_lds(sr_attn_fwd_mfma_kernel<16>, lds));
-    hipLaunchKernelGGL(sr_attn_fwd_mfma_kernel<16>, grid, dim3(256), lds, st, x, L, p.d, A);
-  } else if (p.dh == 32) {
-    SR_CHECK(set_dyn_lds(sr_attn_fwd_mfma_kernel<32>, lds));
-    hipLaunchKernelGGL(sr_attn_fwd_mfma_kernel<32>, grid, dim3(256), lds, st, x, L, p.d, A);
-  } else {
-    SR_CHECK(set_dyn_lds(sr_attn_fwd_mfma_kernel<64>, lds));
-    hipLaunchKernelGGL(sr_attn_fwd_mfma_kernel<64>, grid, dim3(256), lds, st, x, L, p.d, A);
-  }
+  const size_t lds = (size_t)Lp * (p.dh + 4) * sizeof(float);
+  const dim3 grid(batch, p.H), block(Lp * 4);  // one wave per 16 tokens
+  if (p.dh == 16) hipLaunchKernelGGL(sr_attn_fwd_mfma_kernel<16>, grid, block, lds, st, x, L, p.d, A);
+  else if (p.dh == 32) hipLaunchKernelGGL(sr_attn_fwd_mfma_kernel<32>, grid, block, lds, st, x, L, p.d, A);
+  else hipLaunchKernelGGL(sr_attn_fwd_mfma_kernel<64>, grid, block, lds, st, x, L, p.d, A);
   return 0;
 }
 int attn_bwd_mfma(const SrPlan& p, const float* x, const float* dA, int batch, int L, float* dx, hipStream_t st) {
   const int Lp = round_up(L, 16);
-  const size_t lds = ((size_t)2 * Lp * (p.dh + 4) + (size_t)2 * Lp * (Lp + 4)) * sizeof(float);
-  const dim3 grid(batch, p.H);
+  const size_t lds = ((size_t)2 * Lp * (p.dh + 4) + 3 * (size_t)Lp) * sizeof(float);
+  const dim3 grid(batch, p.H), block(Lp * 4);
   if (p.dh == 16) {
     SR_CHECK(set_dyn_lds(sr_attn_bwd_mfma_kernel<16>, lds));
-    hipLaunchKernelGGL(sr_attn_bwd_mfma_kernel<16>, grid, dim3(512), lds, st, x, dA, L, p.d, dx);
+    hipLaunchKernelGGL(sr_attn_bwd_mfma_kernel<16>, grid, block, lds, st, x, dA, L, p.d, dx);
   } else if (p.dh == 32) {
     SR_CHECK(set_dyn_lds(sr_attn_bwd_mfma_kernel<32>, lds));
-    hipLaunchKernelGGL(sr_attn_bwd_mfma_kernel<32>, grid, dim3(512), lds, st, x, dA, L, p.d, dx);
+    hipLaunchKernelGGL(sr_attn_bwd_mfma_kernel<32>, grid, block, lds, st, x, dA, L, p.d, dx);
   } else {
     SR_CHECK(set_dyn_lds(sr_attn_bwd_mfma_kernel<64>, lds));
-    hipLaunchKernelGGL(sr_attn_bwd_mfma_kernel<64>, grid, dim3(512), lds, st, x, dA, L, p.d, dx);
+    hipLaunchKernelGGL(sr_attn_bwd_mfma_kernel<64>, grid, block, lds, st, x, dA, L, p.d, dx);
   }
   return 0;
 }
@@ -776,7 +851,7 @@ extern "C" int ultr_setrank_backward(const ultr_setrank_desc* c, const float* pa
   SrPlan p;
   if (!make_plan(c, T, &p)) return ULTR_E_BADARG;
   const int L = list_size;
-  if (L > 120) return ULTR_E_UNSUPPORTED;  // the attention backward keeps two [L, L] matrices in LDS
+  if (!attn_mfma_ok(p, L) && L > 120) return ULTR_E_UNSUPPORTED;  // the scalar attention backward keeps two [L, L] matrices in LDS
   hipStream_t st = (hipStream_t)stream;
   SR_CHECK(blas_setup(st));
   const float* sv = (const float*)saved;
