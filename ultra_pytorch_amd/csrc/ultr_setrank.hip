@@ -434,6 +434,16 @@ __device__ __forceinline__ float quad_sum(float v) {
   return v + __shfl_xor(v, 32);
 }
 
+// exp(x) for x <= 0 in 7 instructions: two-constant range reduction, v_exp_f32 on [-0.5, 0.5], v_ldexp (about 1 ulp).
+// Arguments below -87 are clamped (the result is ~1e-38 instead of a denormal or 0).
+__device__ __forceinline__ float exp_nonpos(float x) {
+  x = fmaxf(x, -87.0f);
+  const float n = __builtin_rintf(x * 1.44269504088896341f);
+  float r = fmaf(x, 1.44269504088896341f, -n);
+  r = fmaf(x, 1.92596299112661746e-8f, r);
+  return ldexpf(__builtin_amdgcn_exp2f(r), (int)n);
+}
+
 // stage the head slice(s) into LDS, zero rows past L
 template <int DH, bool WITH_DA>
 __device__ __forceinline__ void sr_stage_head(const float* __restrict__ x, const float* __restrict__ dA, int64_t base, int L, int Lp,
@@ -486,8 +496,8 @@ __global__ __launch_bounds__(SR_MAXT * 64) void sr_attn_fwd_mfma_kernel(const fl
       pr[t] = sr_tile_nt<DH>(xs + (t * 16 + i) * LDX + q * KQ, bq);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        pr[t][r] = (t * 16 + 4 * q + r < L) ? pr[t][r] * scale : -INFINITY;
-        mx = fmaxf(mx, pr[t][r]);
+        pr[t][r] *= scale;
+        mx = fmaxf(mx, pr[t][r]);  // padding keys score 0 <= the diagonal |x_i|^2: they never raise the maximum
       }
     }
   }
@@ -497,10 +507,13 @@ __global__ __launch_bounds__(SR_MAXT * 64) void sr_attn_fwd_mfma_kernel(const fl
   for (int t = 0; t < SR_MAXT; ++t) {
     if (t < NTL) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        pr[t][r] = expf(pr[t][r] - mx);  // exp(-inf) = 0 for the padding keys
-        sum += pr[t][r];
+      for (int r = 0; r < 4; ++r) pr[t][r] = exp_nonpos(pr[t][r] - mx);
+      if (t == NTL - 1) {  // only the last block can hold padding keys
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pr[t][r] = (t * 16 + 4 * q + r < L) ? pr[t][r] : 0.f;
       }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sum += pr[t][r];
     }
   }
   const float inv = 1.0f / quad_sum(sum);
@@ -576,7 +589,7 @@ __global__ __launch_bounds__(SR_MAXT * 64) __attribute__((amdgpu_waves_per_eu(4,
         dp[t] = sr_tile_nt<DH>(arow, bg);   // dP^T[key][query] = x[key] . dA[query]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          pr[t][r] = (t * 16 + 4 * q + r < L) ? pr[t][r] * scale : -INFINITY;
+          pr[t][r] *= scale;
           mx = fmaxf(mx, pr[t][r]);
         }
       }
@@ -587,10 +600,13 @@ __global__ __launch_bounds__(SR_MAXT * 64) __attribute__((amdgpu_waves_per_eu(4,
     for (int t = 0; t < SR_MAXT; ++t) {
       if (t < NTL) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          pr[t][r] = expf(pr[t][r] - mx);
-          sum += pr[t][r];
+        for (int r = 0; r < 4; ++r) pr[t][r] = exp_nonpos(pr[t][r] - mx);
+        if (t == NTL - 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pr[t][r] = (t * 16 + 4 * q + r < L) ? pr[t][r] : 0.f;
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum += pr[t][r];
       }
     }
     const float inv = 1.0f / quad_sum(sum);
@@ -631,11 +647,14 @@ __global__ __launch_bounds__(SR_MAXT * 64) __attribute__((amdgpu_waves_per_eu(4,
       if (t < NTL) {
         const f32x4 s = sr_tile_nt<DH>(xs + (t * 16 + i) * LDX + q * KQ, bx);    // S[query][key]
         const f32x4 g = sr_tile_nt<DH>(das + (t * 16 + i) * LDX + q * KQ, bx);   // dP[query][key] = dA[query] . x[key]
+        const float4 m4 = ld4(st_mx + t * 16 + 4 * q), i4 = ld4(st_inv + t * 16 + 4 * q), t4 = ld4(st_t + t * 16 + 4 * q);
+        const float mq[4] = {m4.x, m4.y, m4.z, m4.w}, iq[4] = {i4.x, i4.y, i4.z, i4.w}, tq[4] = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int qr = t * 16 + 4 * q + r;   // the query of this register
-          const float pv = (qr < L) ? expf(s[r] * scale - st_mx[qr]) * st_inv[qr] : 0.f;
-          const float ds = scale * pv * (g[r] - st_t[qr]);
+          float pv = exp_nonpos(s[r] * scale - mq[r]) * iq[r];
+          if (t == NTL - 1) pv = (qr < L) ? pv : 0.f;   // padding queries
+          const float ds = scale * pv * (g[r] - tq[r]);
           const float* xr = xs + qr * LDX + i;
           const float* gr = das + qr * LDX + i;
 #pragma unroll
