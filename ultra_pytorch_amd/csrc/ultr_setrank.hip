@@ -42,7 +42,7 @@ struct SrPlan {
   // workspace (floats)
   int maxw;
   int64_t ws_g[3];   // three [T, maxw] gradient buffers
-  int64_t ws_part;   // [n_cs][2 * maxw] column-sum partials
+  int64_t ws_part;   // [n_cs][3 * maxw] column-sum partials
   int n_cs;
   int64_t ws_wg;     // [wg_split][max M*K] partial weight gradients (split over lists: rocBLAS would run a
                      // [M, K] = dY^T X product with T = 100k contraction rows on a handful of workgroups)
@@ -91,7 +91,7 @@ bool make_plan(const ultr_setrank_desc* c, int64_t T, SrPlan* p) {
   int64_t w = 0;
   for (int k = 0; k < 3; ++k) { p->ws_g[k] = w; w += (T * p->maxw + 3) & ~(int64_t)3; }
   p->n_cs = (int)((T + SR_CS_ROWS - 1) / SR_CS_ROWS);
-  p->ws_part = w; w += (int64_t)p->n_cs * 2 * p->maxw;
+  p->ws_part = w; w += (int64_t)p->n_cs * 3 * p->maxw;
   // sum-of-squares partials for ultr_apply_update live at offset 0 of a SEPARATE region at the end (ultr_grad_sumsq
   // writes them at the start of the pointer it is given)
   // weight-gradient split: the largest divisor of T that leaves chunks of >= 512 rows, at most 128 chunks
@@ -109,9 +109,11 @@ bool make_plan(const ultr_setrank_desc* c, int64_t T, SrPlan* p) {
 // ---------------------------------------------------------------------------------------------------------
 // row-wise kernels: one wavefront per row, SR_ROWS rows per workgroup
 // ---------------------------------------------------------------------------------------------------------
-// y = LayerNorm(a [+ b]) * gamma + beta; optionally stores the pre-norm sum and the statistics.
+// y = LayerNorm(a [+ (b [+ bias])]) * gamma + beta; optionally stores the pre-norm sum and the statistics.
+// (b + bias is the preceding Linear's output: its bias add rides along instead of costing a pass of its own.)
 // a_gather: a is the feature matrix and rows are gathered through the doc ids (PAD -> zero row).
 __global__ __launch_bounds__(SR_ROWS * 64) void sr_ln_fwd_kernel(const float* a, const float* b /* may alias y */,
+                                                                const float* __restrict__ bias /* added to b, may be NULL */,
                                                                 const int32_t* __restrict__ docids, int64_t n_docs, int B,
                                                                 int L, int64_t T, int W, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, float* __restrict__ sum_out,
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(SR_ROWS * 64) void sr_ln_fwd_kernel(const float* a,
       v[k] = 0.f;
       if (c < W) {
         v[k] = ra ? ra[c] : 0.f;
-        if (b != nullptr) v[k] += b[n * W + c];
+        if (b != nullptr) v[k] += (bias != nullptr) ? b[n * W + c] + bias[c] : b[n * W + c];
         if (sum_out != nullptr) sum_out[n * W + c] = v[k];
       }
       s += v[k];
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(SR_ROWS * 64) void sr_ln_fwd_kernel(const float* a,
   float s = 0.f;
   for (int c = lane; c < W; c += 64) {
     float v = ra ? ra[c] : 0.f;
-    if (b != nullptr) v += b[n * W + c];
+    if (b != nullptr) v += (bias != nullptr) ? b[n * W + c] + bias[c] : b[n * W + c];
     if (sum_out != nullptr) sum_out[n * W + c] = v;
     s += v;
   }
@@ -171,14 +173,14 @@ __global__ __launch_bounds__(SR_ROWS * 64) void sr_ln_fwd_kernel(const float* a,
   float q = 0.f;
   for (int c = lane; c < W; c += 64) {
     float v = ra ? ra[c] : 0.f;
-    if (b != nullptr) v += b[n * W + c];
+    if (b != nullptr) v += (bias != nullptr) ? b[n * W + c] + bias[c] : b[n * W + c];
     const float dlt = v - mean;
     q += dlt * dlt;
   }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)W + SR_EPS);
   for (int c = lane; c < W; c += 64) {
     float v = ra ? ra[c] : 0.f;
-    if (b != nullptr) v += b[n * W + c];
+    if (b != nullptr) v += (bias != nullptr) ? b[n * W + c] + bias[c] : b[n * W + c];
     y[n * W + c] = (v - mean) * rstd * gamma[c] + beta[c];
   }
   if (lane == 0) {
@@ -211,6 +213,70 @@ __global__ __launch_bounds__(SR_ROWS * 64) void sr_ln_bwd_kernel(const float* __
     const float xh = (s[n * W + c] - m) * r;
     ds_out[n * W + c] = r * (g - s1 - xh * s2);
   }
+}
+
+// LayerNorm backward AND every column sum that hangs off it, one pass over dy and s:
+//   ds = the row gradient above;  part[blk][0:W] = sum_r dy xhat (dgamma),  [W:2W] = sum_r dy (dbeta),
+//   [2W:3W] = sum_r ds (the bias gradient of the Linear that produced s).
+// A workgroup owns SR_CS_ROWS rows, a wave every 4th of them (row in registers, KMAX columns per lane); the four
+// waves' column partials are folded in fixed order through LDS.
+template <int KMAX>
+__global__ __launch_bounds__(256) void sr_ln_bwd_cs_kernel(const float* __restrict__ dy, const float* __restrict__ s,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, int64_t T, int W,
+                                                           float* __restrict__ ds_out, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [4 waves][3][W]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * SR_CS_ROWS;
+  const int64_t r1 = (r0 + SR_CS_ROWS < T) ? r0 + SR_CS_ROWS : T;
+  float gm[KMAX], ag[KMAX], ab[KMAX], ad[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    const int c = lane + 64 * k;
+    gm[k] = (c < W) ? gamma[c] : 0.f;
+    ag[k] = ab[k] = ad[k] = 0.f;
+  }
+  const float invw = 1.0f / (float)W;
+  for (int64_t n = r0 + wave; n < r1; n += 4) {
+    const float m = mean[n], r = rstd[n];
+    float g[KMAX], xh[KMAX];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      const int c = lane + 64 * k;
+      const float d = (c < W) ? dy[n * W + c] : 0.f;
+      xh[k] = (c < W) ? (s[n * W + c] - m) * r : 0.f;
+      g[k] = d * gm[k];
+      s1 += g[k];
+      s2 += g[k] * xh[k];
+      ag[k] += d * xh[k];
+      ab[k] += d;
+    }
+    s1 = wave_sum(s1) * invw;
+    s2 = wave_sum(s2) * invw;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      const int c = lane + 64 * k;
+      const float v = r * (g[k] - s1 - xh[k] * s2);
+      if (c < W) {
+        ds_out[n * W + c] = v;
+        ad[k] += v;
+      }
+    }
+  }
+  float* mine = smem + (size_t)wave * 3 * W;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    const int c = lane + 64 * k;
+    if (c < W) {
+      mine[c] = ag[k];
+      mine[W + c] = ab[k];
+      mine[2 * W + c] = ad[k];
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 3 * W; e += 256)
+    part[(int64_t)blockIdx.x * 3 * W + e] = ((smem[e] + smem[3 * W + e]) + smem[6 * W + e]) + smem[9 * W + e];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -782,6 +848,18 @@ void colsum(const SrPlan& p, const float* a, const float* s, const float* mean, 
 }
 
 // dst[0..W) = d gamma, dst[W..2W) = d beta (adjacent in the flat layout: <ln>.weight then <ln>.bias)
+// dx = LayerNorm backward of dy; dst_gb = dgamma | dbeta; dst_bias = column sums of dx.  W <= 1024.
+int ln_bwd_cs(const SrPlan& p, const float* dy, const float* s, const float* mean, const float* rstd, const float* gamma, int W,
+              float* dx, float* ws, float* dst_gb, float* dst_bias, hipStream_t st) {
+  float* part = ws + p.ws_part;
+  const size_t lds = (size_t)4 * 3 * W * sizeof(float);
+  if (W <= 256) hipLaunchKernelGGL(sr_ln_bwd_cs_kernel<4>, dim3(p.n_cs), dim3(256), lds, st, dy, s, mean, rstd, gamma, p.T, W, dx, part);
+  else hipLaunchKernelGGL(sr_ln_bwd_cs_kernel<16>, dim3(p.n_cs), dim3(256), lds, st, dy, s, mean, rstd, gamma, p.T, W, dx, part);
+  hipLaunchKernelGGL(sr_fold_kernel, dim3((2 * W + 63) / 64), dim3(256), 0, st, (const float*)part, (int64_t)3 * W, p.n_cs, 2 * W, dst_gb);
+  hipLaunchKernelGGL(sr_fold_kernel, dim3((W + 63) / 64), dim3(256), 0, st, (const float*)(part + 2 * W), (int64_t)3 * W, p.n_cs, W,
+                     dst_bias);
+  return 0;
+}
 void colsum_ln(const SrPlan& p, const float* dy, const float* s, const float* mean, const float* rstd, int W, float* ws, float* dst,
                hipStream_t st) {
   float* part = ws + p.ws_part;
@@ -821,7 +899,7 @@ extern "C" int ultr_setrank_forward(const ultr_setrank_desc* c, const float* par
   const unsigned rblk = (unsigned)((T + SR_ROWS - 1) / SR_ROWS);
   const int F = p.F, d = p.d, dff = p.dff;
   // input LayerNorm on the gathered rows, then the embedding FFN (SetRank.py:134-135, 146)
-  hipLaunchKernelGGL(sr_ln_fwd_kernel, dim3(rblk), dim3(SR_ROWS * 64), 0, st, features, (const float*)nullptr, docids, n_docs,
+  hipLaunchKernelGGL(sr_ln_fwd_kernel, dim3(rblk), dim3(SR_ROWS * 64), 0, st, features, (const float*)nullptr, (const float*)nullptr, docids, n_docs,
                      (int)batch, L, T, F, params + p.g_in, params + p.b_in, sv + p.sv_xg, sv + p.sv_xn0, sv + p.sv_mean_in,
                      sv + p.sv_rstd_in);
   SR_CHECK(gemm_xwT(sv + p.sv_xn0, params + p.w1, sv + p.sv_h0, T, F, dff, 0.f));
@@ -840,18 +918,16 @@ extern "C" int ultr_setrank_forward(const ultr_setrank_desc* c, const float* par
     const float* x = sv + p.sv_x[l];
     if (mfma_att) SR_CHECK(attn_fwd_mfma(p, x, batch, L, sv + p.sv_A[l], st));
     else hipLaunchKernelGGL(sr_attn_fwd_kernel, dim3(batch, p.H), dim3(256), lds_att, st, x, L, d, p.dh, sv + p.sv_A[l]);
-    // o = A Wd^T + bd lands in out1's buffer, then out1 = LN1(x + o) in place (s1 keeps the pre-norm sum)
+    // A Wd^T lands in out1's buffer, then out1 = LN1(x + (A Wd^T + bd)) in place (s1 keeps the pre-norm sum)
     SR_CHECK(gemm_xwT(sv + p.sv_A[l], params + y.wd, sv + p.sv_out1[l], T, d, d, 0.f));
-    bias_act(sv + p.sv_out1[l], params + y.bd, T, d, 0, st);
-    hipLaunchKernelGGL(sr_ln_fwd_kernel, dim3(rblk), dim3(SR_ROWS * 64), 0, st, x, (const float*)(sv + p.sv_out1[l]),
+    hipLaunchKernelGGL(sr_ln_fwd_kernel, dim3(rblk), dim3(SR_ROWS * 64), 0, st, x, (const float*)(sv + p.sv_out1[l]), params + y.bd,
                        (const int32_t*)nullptr, (int64_t)0, (int)batch, L, T, d, params + y.g1, params + y.b1, sv + p.sv_s1[l],
                        sv + p.sv_out1[l], sv + p.sv_m1[l], sv + p.sv_r1[l]);
     SR_CHECK(gemm_xwT(sv + p.sv_out1[l], params + y.wf1, sv + p.sv_f[l], T, d, dff, 0.f));
     bias_act(sv + p.sv_f[l], params + y.bf1, T, dff, 1, st);
     SR_CHECK(gemm_xwT(sv + p.sv_f[l], params + y.wf2, sv + p.sv_x[l + 1], T, dff, d, 0.f));
-    bias_act(sv + p.sv_x[l + 1], params + y.bf2, T, d, 0, st);
     hipLaunchKernelGGL(sr_ln_fwd_kernel, dim3(rblk), dim3(SR_ROWS * 64), 0, st, (const float*)(sv + p.sv_out1[l]),
-                       (const float*)(sv + p.sv_x[l + 1]), (const int32_t*)nullptr, (int64_t)0, (int)batch, L, T, d, params + y.g2,
+                       (const float*)(sv + p.sv_x[l + 1]), params + y.bf2, (const int32_t*)nullptr, (int64_t)0, (int)batch, L, T, d, params + y.g2,
                        params + y.b2, sv + p.sv_s2[l], sv + p.sv_x[l + 1], sv + p.sv_m2[l], sv + p.sv_r2[l]);
   }
   // output FFN (SetRank.py:136, 153)
@@ -897,22 +973,32 @@ extern "C" int ultr_setrank_backward(const ultr_setrank_desc* c, const float* pa
   for (int l = p.nl - 1; l >= 0; --l) {
     const SrLayer& y = p.lay[l];
     // x_{l+1} = LN2(s2),  s2 = out1 + ffn
-    colsum_ln(p, G0, sv + p.sv_s2[l], sv + p.sv_m2[l], sv + p.sv_r2[l], d, ws, grads + y.g2, st);  // g2 | b2
-    hipLaunchKernelGGL(sr_ln_bwd_kernel, dim3(rblk), dim3(SR_ROWS * 64), 0, st, (const float*)G0, sv + p.sv_s2[l], sv + p.sv_m2[l],
-                       sv + p.sv_r2[l], params + y.g2, T, d, G2);            // G2 = d s2 = d out1 (residual) = d ffn
+    if (d <= 1024) {  // g2 | b2, G2 = d s2 = d out1 (residual) = d ffn, bf2: one pass
+      SR_CHECK(ln_bwd_cs(p, G0, sv + p.sv_s2[l], sv + p.sv_m2[l], sv + p.sv_r2[l], params + y.g2, d, G2, ws, grads + y.g2,
+                         grads + y.bf2, st));
+    } else {
+      colsum_ln(p, G0, sv + p.sv_s2[l], sv + p.sv_m2[l], sv + p.sv_r2[l], d, ws, grads + y.g2, st);
+      hipLaunchKernelGGL(sr_ln_bwd_kernel, dim3(rblk), dim3(SR_ROWS * 64), 0, st, (const float*)G0, sv + p.sv_s2[l], sv + p.sv_m2[l],
+                         sv + p.sv_r2[l], params + y.g2, T, d, G2);
+      colsum(p, G2, nullptr, nullptr, nullptr, d, 0, ws, grads + y.bf2, st);
+    }
     SR_CHECK(gemm_dyTx(p, G2, sv + p.sv_f[l], grads + y.wf2, T, dff, d, ws, st));
-    colsum(p, G2, nullptr, nullptr, nullptr, d, 0, ws, grads + y.bf2, st);
     SR_CHECK(gemm_dyw(G2, params + y.wf2, G1, T, dff, d, 0.f));              // G1 = d f  [T, dff]
     relu_mask(G1, sv + p.sv_f[l], T * dff, st);
     SR_CHECK(gemm_dyTx(p, G1, sv + p.sv_out1[l], grads + y.wf1, T, d, dff, ws, st));
     colsum(p, G1, nullptr, nullptr, nullptr, dff, 0, ws, grads + y.bf1, st);
     SR_CHECK(gemm_dyw(G1, params + y.wf1, G2, T, d, dff, 1.0f));             // G2 = d out1 (both paths)
     // out1 = LN1(s1),  s1 = x_l + o
-    colsum_ln(p, G2, sv + p.sv_s1[l], sv + p.sv_m1[l], sv + p.sv_r1[l], d, ws, grads + y.g1, st);  // g1 | b1
-    hipLaunchKernelGGL(sr_ln_bwd_kernel, dim3(rblk), dim3(SR_ROWS * 64), 0, st, (const float*)G2, sv + p.sv_s1[l], sv + p.sv_m1[l],
-                       sv + p.sv_r1[l], params + y.g1, T, d, G0);            // G0 = d s1 = d x_l (residual) = d o
+    if (d <= 1024) {  // g1 | b1, G0 = d s1 = d x_l (residual) = d o, bd
+      SR_CHECK(ln_bwd_cs(p, G2, sv + p.sv_s1[l], sv + p.sv_m1[l], sv + p.sv_r1[l], params + y.g1, d, G0, ws, grads + y.g1,
+                         grads + y.bd, st));
+    } else {
+      colsum_ln(p, G2, sv + p.sv_s1[l], sv + p.sv_m1[l], sv + p.sv_r1[l], d, ws, grads + y.g1, st);
+      hipLaunchKernelGGL(sr_ln_bwd_kernel, dim3(rblk), dim3(SR_ROWS * 64), 0, st, (const float*)G2, sv + p.sv_s1[l], sv + p.sv_m1[l],
+                         sv + p.sv_r1[l], params + y.g1, T, d, G0);
+      colsum(p, G0, nullptr, nullptr, nullptr, d, 0, ws, grads + y.bd, st);
+    }
     SR_CHECK(gemm_dyTx(p, G0, sv + p.sv_A[l], grads + y.wd, T, d, d, ws, st));
-    colsum(p, G0, nullptr, nullptr, nullptr, d, 0, ws, grads + y.bd, st);
     SR_CHECK(gemm_dyw(G0, params + y.wd, G1, T, d, d, 0.f));                 // G1 = d A  [T, d]
     if (attn_mfma_ok(p, L)) SR_CHECK(attn_bwd_mfma(p, sv + p.sv_x[l], G1, batch, L, G0, st));   // G0 += attention path -> d x_l
     else hipLaunchKernelGGL(sr_attn_bwd_kernel, dim3(batch, p.H), dim3(256), lds_att, st, sv + p.sv_x[l], (const float*)G1, L, d,
