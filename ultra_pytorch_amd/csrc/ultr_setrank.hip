@@ -50,6 +50,19 @@ struct SrPlan {
   int64_t ws_total;
 };
 
+// row chunks of sr_wgrad_kernel for an [M, K] gradient: about two workgroups per CU, chunks of a multiple of 32 rows
+// (4 waves x 8 rows per trip), at most 128 of them
+int wgrad_chunks(int64_t T, int M, int K, int* rows_per_chunk) {
+  const int tiles = ((M + 63) / 64) * ((K + 63) / 64);
+  int S = (512 + tiles - 1) / tiles;
+  if (S > 128) S = 128;
+  int64_t rps = (T + S - 1) / S;
+  rps = (rps + 31) / 32 * 32;
+  if (rps < 32) rps = 32;
+  *rows_per_chunk = (int)rps;
+  return (int)((T + rps - 1) / rps);
+}
+
 bool make_plan(const ultr_setrank_desc* c, int64_t T, SrPlan* p) {
   if (!c || c->feature_size <= 0 || c->d_model <= 0 || c->num_heads <= 0 || c->num_layers <= 0 || c->num_layers > 8 ||
       c->dff <= 0 || c->d_model % c->num_heads != 0)
@@ -101,7 +114,14 @@ bool make_plan(const ultr_setrank_desc* c, int64_t T, SrPlan* p) {
   int64_t maxmk = dff * F;
   if (d * dff > maxmk) maxmk = d * dff;
   if (d * d > maxmk) maxmk = d * d;
-  p->ws_wg = w; w += (int64_t)p->wg_split * maxmk;
+  int64_t wg_floats = (int64_t)p->wg_split * maxmk;  // rocBLAS path (unaligned shapes)
+  const int shapes[4][2] = {{(int)dff, (int)F}, {(int)d, (int)dff}, {(int)d, (int)d}, {(int)dff, (int)d}};  // [M, K]
+  for (int k = 0; k < 4; ++k) {
+    int rps = 0;
+    const int64_t need = (int64_t)wgrad_chunks(T, shapes[k][0], shapes[k][1], &rps) * ((int64_t)shapes[k][0] * shapes[k][1] + shapes[k][0]);
+    if (need > wg_floats) wg_floats = need;
+  }
+  p->ws_wg = w; w += wg_floats;
   p->ws_total = w;
   return true;
 }
@@ -743,6 +763,120 @@ __global__ __launch_bounds__(SR_MAXT * 64) __attribute__((amdgpu_waves_per_eu(4,
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// weight gradients of the plain Linears:  dW[M, K] = dY[T, M]^T X[T, K],  db[M] = column sums of dY
+// ---------------------------------------------------------------------------------------------------------
+// T is ~100k rows and the outputs are small (at most d x d), so the contraction is split over row chunks:
+// workgroup = (64 x 64 output block, chunk); its four waves take a quarter of the chunk each, stream the two
+// operand rows straight from global memory into MFMA fragments (lane (i, q): row 4 step + q, float4 at column 4 i -
+// the four floats feed the four 16-wide sub-tiles, i.e. the block's columns are dealt round-robin to the
+// sub-tiles, which the store undoes), 16 accumulator tiles per wave, a three-deep register ring of operands,
+// then a fixed-order LDS reduction over the waves and one slab [M*K + M] per chunk; sr_fold_kernel sums the slabs.
+// (rocBLAS ran these as strided-batched 32x32 macro-tiles at ~43 TFLOP/s; same design as dnn_wgrad_kernel.)
+constexpr int SRW_SPT = 2;  // steps (of 4 rows) per trip
+__global__ __launch_bounds__(256) void sr_wgrad_kernel(const float* __restrict__ dY, const float* __restrict__ X, int64_t T, int M,
+                                                       int K, int nkb, int nsplit, int rps, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float (*red)[64 * 64] = reinterpret_cast<float (*)[64 * 64]>(smem);
+  float (*bred)[64] = reinterpret_cast<float (*)[64]>(smem + 4 * 64 * 64);
+  const int split = blockIdx.x % nsplit, tile = blockIdx.x / nsplit;
+  const int mb = tile / nkb, kb = tile - mb * nkb;
+  const int m0 = mb * 64, k0 = kb * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, q = lane >> 4;
+  const int64_t n0 = (int64_t)split * rps;
+  const int rows_here = (int)((n0 + rps < T) ? rps : T - n0);
+  const int rpw = rps / 4;
+  const int rbeg = wave * rpw;
+  const int rend = (rbeg + rpw < rows_here) ? rbeg + rpw : rows_here;
+  // descriptors cover exactly this chunk: a masked lane presents ULTR_OOB and reads 0
+  const Src ys = make_src(dY + n0 * M, (int64_t)rows_here * M);
+  const Src xs = make_src(X + n0 * K, (int64_t)rows_here * K);
+  const unsigned mc = (unsigned)(m0 + 4 * i) * 4u, kc = (unsigned)(k0 + 4 * i) * 4u;
+  const unsigned mstride = (unsigned)M * 4u, kstride = (unsigned)K * 4u;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  struct StepRegs {
+    float4 a, x;
+  };
+  // only dY must be exactly zero for rows outside the wave's slice; X rows there are other rows of the chunk (finite)
+  auto load_step = [&](int r, StepRegs& sr) {
+    sr.a = buf_ld4(ys, (r < rend) ? (unsigned)r * mstride + mc : ULTR_OOB);
+    sr.x = buf_ld4(xs, (unsigned)r * kstride + kc);
+  };
+  int rr = rbeg;
+  auto trip = [&](StepRegs(&cu)[SRW_SPT], StepRegs(&nx)[SRW_SPT]) {
+#pragma unroll
+    for (int u = 0; u < SRW_SPT; ++u) load_step(rr + 4 * SRW_SPT * 2 + 4 * u + q, nx[u]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < SRW_SPT; ++u) {
+      const float4 a_c = cu[u].a, x_c = cu[u].x;
+      bsum.x += a_c.x;
+      bsum.y += a_c.y;
+      bsum.z += a_c.z;
+      bsum.w += a_c.w;
+      const float av[4] = {a_c.x, a_c.y, a_c.z, a_c.w};
+      const float bv[4] = {x_c.x, x_c.y, x_c.z, x_c.w};
+#pragma unroll
+      for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = mfma16(av[ta], bv[tb], acc[ta][tb]);
+    }
+    rr += 4 * SRW_SPT;
+  };
+  const int ntrip = (rend - rbeg + 4 * SRW_SPT - 1) / (4 * SRW_SPT);
+  StepRegs ra[SRW_SPT], rb[SRW_SPT], rc[SRW_SPT];
+#pragma unroll
+  for (int u = 0; u < SRW_SPT; ++u) {
+    load_step(rbeg + 4 * u + q, ra[u]);
+    load_step(rbeg + 4 * SRW_SPT + 4 * u + q, rb[u]);
+  }
+  int t = 0;
+  for (; t + 2 < ntrip; t += 3) {
+    trip(ra, rc);
+    trip(rb, ra);
+    trip(rc, rb);
+  }
+  if (t < ntrip) trip(ra, rc);
+  if (t + 1 < ntrip) trip(rb, ra);
+  // lane holds D_{ta,tb}[row = 4q + r][col = i]  ->  block-local (m = 4 (4q + r) + ta, k = 4 i + tb)
+#pragma unroll
+  for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ml = 4 * (4 * q + r) + ta;
+      st4(&red[wave][ml * 64 + 4 * i], make_float4(acc[ta][0][r], acc[ta][1][r], acc[ta][2][r], acc[ta][3][r]));
+    }
+  {
+    float4 sb = bsum;  // the 4 row groups q sit in lanes i, i+16, i+32, i+48
+    sb.x = quad_sum(sb.x); sb.y = quad_sum(sb.y); sb.z = quad_sum(sb.z); sb.w = quad_sum(sb.w);
+    if (q == 0) st4(&bred[wave][4 * i], sb);
+  }
+  __syncthreads();
+  float* slab = part + (int64_t)split * ((int64_t)M * K + M);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int e = tid + 256 * it;  // float4 index inside the 64x64 block
+    const int ml = e >> 4, k4 = (e & 15) * 4;
+    const float4 v0 = ld4(&red[0][ml * 64 + k4]), v1 = ld4(&red[1][ml * 64 + k4]);
+    const float4 v2 = ld4(&red[2][ml * 64 + k4]), v3 = ld4(&red[3][ml * 64 + k4]);
+    float4 o;
+    o.x = ((v0.x + v1.x) + v2.x) + v3.x;
+    o.y = ((v0.y + v1.y) + v2.y) + v3.y;
+    o.z = ((v0.z + v1.z) + v2.z) + v3.z;
+    o.w = ((v0.w + v1.w) + v2.w) + v3.w;
+    const int m = m0 + ml, k = k0 + k4;
+    if (m < M && k < K) st4(slab + (int64_t)m * K + k, o);  // K % 4 == 0
+  }
+  if (kb == 0 && tid < 64 && m0 + tid < M)
+    slab[(int64_t)M * K + m0 + tid] = ((bred[0][tid] + bred[1][tid]) + bred[2][tid]) + bred[3][tid];
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
 rocblas_handle g_handle = nullptr;
@@ -782,6 +916,40 @@ int gemm_dyTx(const SrPlan& p, const float* dY, const float* X, float* dW, int64
     return ULTR_E_UNSUPPORTED;
   const int len = M * K;
   hipLaunchKernelGGL(sr_fold_kernel, dim3((len + 63) / 64), dim3(256), 0, st, (const float*)part, (int64_t)len, S, len, dW);
+  return 0;
+}
+
+// dW = dY^T X and (db != NULL) db = column sums of dY.  Aligned shapes go through sr_wgrad_kernel; the rest through
+// rocBLAS + the column-sum kernels.
+void colsum(const SrPlan& p, const float* a, const float* s, const float* mean, const float* rstd, int W, int mode, float* ws,
+            float* dst, hipStream_t st);
+int wgrad(const SrPlan& p, const float* dY, const float* X, float* dW, float* db, int64_t T, int K, int M, float* ws, hipStream_t st) {
+  const bool ok = M % 4 == 0 && K % 4 == 0 && (((uintptr_t)dY | (uintptr_t)X) & 15) == 0 && getenv("ULTR_SR_BLAS_WGRAD") == nullptr;
+  if (!ok) {
+    const int rc = gemm_dyTx(p, dY, X, dW, T, K, M, ws, st);
+    if (rc != 0) return rc;
+    if (db != nullptr) colsum(p, dY, nullptr, nullptr, nullptr, M, 0, ws, db, st);
+    return 0;
+  }
+  int rps = 0;
+  const int S = wgrad_chunks(T, M, K, &rps);
+  if ((int64_t)rps * (M > K ? M : K) * 4 >= ((int64_t)1 << 31)) return ULTR_E_UNSUPPORTED;
+  const int nmb = (M + 63) / 64, nkb = (K + 63) / 64;
+  float* part = ws + p.ws_wg;
+  const size_t lds = (size_t)(4 * 64 * 64 + 4 * 64) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sr_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess)
+      return ULTR_E_UNSUPPORTED;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(sr_wgrad_kernel, dim3(nmb * nkb * S), dim3(256), lds, st, dY, X, T, M, K, nkb, S, rps, part);
+  const int64_t stride = (int64_t)M * K + M;
+  const int len = M * K;
+  hipLaunchKernelGGL(sr_fold_kernel, dim3((len + 63) / 64), dim3(256), 0, st, (const float*)part, stride, S, len, dW);
+  if (db != nullptr)
+    hipLaunchKernelGGL(sr_fold_kernel, dim3((M + 63) / 64), dim3(256), 0, st, (const float*)(part + len), stride, S, M, db);
   return 0;
 }
 
@@ -967,8 +1135,7 @@ extern "C" int ultr_setrank_backward(const ultr_setrank_desc* c, const float* pa
   colsum(p, dscores, nullptr, nullptr, nullptr, 1, 0, ws, grads + p.bo2, st);
   SR_CHECK(gemm_dyw(dscores, params + p.wo2, G1, T, dff, 1, 0.f));           // G1 = d oh  [T, dff]
   relu_mask(G1, sv + p.sv_oh, T * dff, st);
-  SR_CHECK(gemm_dyTx(p, G1, sv + p.sv_x[p.nl], grads + p.wo1, T, d, dff, ws, st));
-  colsum(p, G1, nullptr, nullptr, nullptr, dff, 0, ws, grads + p.bo1, st);
+  SR_CHECK(wgrad(p, G1, sv + p.sv_x[p.nl], grads + p.wo1, grads + p.bo1, T, d, dff, ws, st));
   SR_CHECK(gemm_dyw(G1, params + p.wo1, G0, T, d, dff, 0.f));                // G0 = d x_nl  [T, d]
   for (int l = p.nl - 1; l >= 0; --l) {
     const SrLayer& y = p.lay[l];
@@ -982,11 +1149,10 @@ extern "C" int ultr_setrank_backward(const ultr_setrank_desc* c, const float* pa
                          sv + p.sv_r2[l], params + y.g2, T, d, G2);
       colsum(p, G2, nullptr, nullptr, nullptr, d, 0, ws, grads + y.bf2, st);
     }
-    SR_CHECK(gemm_dyTx(p, G2, sv + p.sv_f[l], grads + y.wf2, T, dff, d, ws, st));
+    SR_CHECK(wgrad(p, G2, sv + p.sv_f[l], grads + y.wf2, nullptr, T, dff, d, ws, st));
     SR_CHECK(gemm_dyw(G2, params + y.wf2, G1, T, dff, d, 0.f));              // G1 = d f  [T, dff]
     relu_mask(G1, sv + p.sv_f[l], T * dff, st);
-    SR_CHECK(gemm_dyTx(p, G1, sv + p.sv_out1[l], grads + y.wf1, T, d, dff, ws, st));
-    colsum(p, G1, nullptr, nullptr, nullptr, dff, 0, ws, grads + y.bf1, st);
+    SR_CHECK(wgrad(p, G1, sv + p.sv_out1[l], grads + y.wf1, grads + y.bf1, T, d, dff, ws, st));
     SR_CHECK(gemm_dyw(G1, params + y.wf1, G2, T, d, dff, 1.0f));             // G2 = d out1 (both paths)
     // out1 = LN1(s1),  s1 = x_l + o
     if (d <= 1024) {  // g1 | b1, G0 = d s1 = d x_l (residual) = d o, bd
@@ -998,19 +1164,17 @@ extern "C" int ultr_setrank_backward(const ultr_setrank_desc* c, const float* pa
                          sv + p.sv_r1[l], params + y.g1, T, d, G0);
       colsum(p, G0, nullptr, nullptr, nullptr, d, 0, ws, grads + y.bd, st);
     }
-    SR_CHECK(gemm_dyTx(p, G0, sv + p.sv_A[l], grads + y.wd, T, d, d, ws, st));
+    SR_CHECK(wgrad(p, G0, sv + p.sv_A[l], grads + y.wd, nullptr, T, d, d, ws, st));
     SR_CHECK(gemm_dyw(G0, params + y.wd, G1, T, d, d, 0.f));                 // G1 = d A  [T, d]
     if (attn_mfma_ok(p, L)) SR_CHECK(attn_bwd_mfma(p, sv + p.sv_x[l], G1, batch, L, G0, st));   // G0 += attention path -> d x_l
     else hipLaunchKernelGGL(sr_attn_bwd_kernel, dim3(batch, p.H), dim3(256), lds_att, st, sv + p.sv_x[l], (const float*)G1, L, d,
                             p.dh, G0);
   }
   // ---- embedding FFN and the input LayerNorm's parameters -------------------------------------------------------------
-  SR_CHECK(gemm_dyTx(p, G0, sv + p.sv_h0, grads + p.w2, T, dff, d, ws, st));
-  colsum(p, G0, nullptr, nullptr, nullptr, d, 0, ws, grads + p.b2, st);
+  SR_CHECK(wgrad(p, G0, sv + p.sv_h0, grads + p.w2, grads + p.b2, T, dff, d, ws, st));
   SR_CHECK(gemm_dyw(G0, params + p.w2, G1, T, dff, d, 0.f));
   relu_mask(G1, sv + p.sv_h0, T * dff, st);
-  SR_CHECK(gemm_dyTx(p, G1, sv + p.sv_xn0, grads + p.w1, T, F, dff, ws, st));
-  colsum(p, G1, nullptr, nullptr, nullptr, dff, 0, ws, grads + p.b1, st);
+  SR_CHECK(wgrad(p, G1, sv + p.sv_xn0, grads + p.w1, grads + p.b1, T, F, dff, ws, st));
   SR_CHECK(gemm_dyw(G1, params + p.w1, G2, T, F, dff, 0.f));                 // G2 = d xn0  [T, F]
   colsum_ln(p, G2, sv + p.sv_xg, sv + p.sv_mean_in, sv + p.sv_rstd_in, F, ws, grads + p.g_in, st);  // g_in | b_in
   // ---- step tail: fold the loss partials behind the gradient ----------------------------------------------------------
