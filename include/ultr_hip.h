@@ -172,7 +172,7 @@ int ultr_regem_loss(const float* scores, const float* labels, const float* prope
  * required for validation too (it doubles as scratch).  list_size <= 256.
  * backward: dscores [B, L] from any ultr_*_loss kernel (x D convention), loss_ws/n_loss_parts = that kernel's
  * partials; writes grads [P + step tail]; follow with ultr_grad_sumsq + ultr_apply_update(wt = NULL).
- * list_size <= 120 (two [L, L] matrices per (list, head) live in LDS). */
+ * list_size <= 128 on the matrix-core attention path (head depth 16 / 32 / 64), <= 120 otherwise. */
 typedef struct ultr_setrank_desc {
   int32_t feature_size, d_model, num_heads, num_layers, dff;
 } ultr_setrank_desc;
