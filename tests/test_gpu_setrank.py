@@ -67,7 +67,8 @@ def test_setrank_golden(name):
 
 
 @pytest.mark.parametrize("B,L,F,dm,H,nl,dff", [(16, 10, 136, 64, 4, 2, 32), (3, 37, 20, 48, 6, 1, 20), (5, 100, 220, 256, 8, 2, 64),
-                                               (64, 100, 24, 64, 4, 1, 16), (256, 10, 136, 32, 2, 2, 16)])  # split weight gradients
+                                               (64, 100, 24, 64, 4, 1, 16), (256, 10, 136, 32, 2, 2, 16),  # split weight gradients
+                                               (4, 120, 24, 64, 2, 1, 16), (6, 16, 30, 128, 2, 1, 22)])  # 8 token blocks; head depth 64, unaligned dff
 def test_setrank_oracle(B, L, F, dm, H, nl, dff):
     from oracle import ultr_oracle as O
     from ultra_pytorch_amd import hip_ops, synthetic
