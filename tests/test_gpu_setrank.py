@@ -144,3 +144,34 @@ def test_setrank_with_dla_plugin():
         pg = d[p + "prop_grads"]
         psel = np.abs(pg) > 1e-5 * float(np.abs(pg).max())
         np.testing.assert_allclose(algo.propensity_model.flat_params.cpu().numpy()[psel], d[p + "post_prop_params"][psel], atol=1e-6)
+
+
+def test_setrank_full_size_properties():
+    """BASELINE config 5 at FULL size (F220, list 100, batch 1024, d_model 256, 8 heads, 2 layers, dff 64): the oracle's
+    autograd at 102 400 tokens is minutes of CPU, so the checks are the size-independent ones the model offers -
+    * lists are independent: the first 3 lists' scores equal the oracle's forward on those 3 lists alone;
+    * the encoder has no positional signal and no mask (SetRank.py:229-255): permuting the documents inside every list
+      permutes the scores and leaves the gradient of a permutation-invariant loss unchanged (NA softmax-CE with the
+      labels permuted alongside);
+    * reruns are bitwise identical (fixed-order reductions everywhere)."""
+    from oracle import ultr_oracle as O
+    from ultra_pytorch_amd import hip_ops, synthetic
+    from ultra_pytorch_amd.ranking_model.SetRank import init_setrank_params
+    F, dm, H, nl, dff, B, L = 220, 256, 8, 2, 64, 1024, 100
+    shape = hip_ops.SetRankShape(F, dm, H, nl, dff)
+    rng = np.random.RandomState(5)
+    feats, ids, y = synthetic.make_batch(rng, B, L, F)
+    p0 = init_setrank_params(shape, seed=3).numpy()
+    kw = dict(learning_rate=0.05, max_gradient_norm=5.0)
+    s1, g1, _, _, sc1 = run_step(shape, B, L, kw, p0, np.zeros_like(p0), feats, ids, y, None)
+    s1b, g1b, _, _, sc1b = run_step(shape, B, L, kw, p0, np.zeros_like(p0), feats, ids, y, None)
+    assert np.array_equal(s1, s1b) and np.array_equal(g1, g1b) and np.array_equal(sc1, sc1b)
+    ref = O.setrank_forward(torch.from_numpy(p0), F, dm, H, nl, dff, feats, ids[:, :3]).detach().numpy()
+    np.testing.assert_allclose(s1[:3], ref, atol=1e-5)
+    perm = rng.permutation(L)
+    s2, g2, _, _, sc2 = run_step(shape, B, L, kw, p0, np.zeros_like(p0), feats, ids[perm], y[perm], None)
+    np.testing.assert_allclose(s2, s1[:, perm], atol=2e-5)
+    assert abs(float(sc2[0]) - float(sc1[0])) <= 1e-5 * max(1.0, abs(float(sc1[0])))
+    n = shape.n_params
+    # 102 400-term fp32 sums in a different order: agreement to ~1e-4 of the largest gradient, not to rounding
+    np.testing.assert_allclose(g2[:n], g1[:n], rtol=2e-3, atol=5e-4 * float(np.abs(g1[:n]).max()))
