@@ -22,6 +22,7 @@
 #define SR_EPS 1e-6f  // nn.LayerNorm(eps=1e-6) everywhere in SetRank.py (:100-101, :134)
 #define SR_ROWS 4     // rows per workgroup (= waves) of the row-wise kernels
 #define SR_CS_ROWS 128  // rows per partial of the column-sum kernels
+#define SR_LB_ROWS 64   // rows per workgroup (and per partial) of the fused LayerNorm backward
 
 namespace {
 
@@ -43,7 +44,7 @@ struct SrPlan {
   int maxw;
   int64_t ws_g[3];   // three [T, maxw] gradient buffers
   int64_t ws_part;   // [n_cs][3 * maxw] column-sum partials
-  int n_cs;
+  int n_cs, n_lb;
   int64_t ws_wg;     // [wg_split][max M*K] partial weight gradients (split over lists: rocBLAS would run a
                      // [M, K] = dY^T X product with T = 100k contraction rows on a handful of workgroups)
   int wg_split;      // chunks of whole lists, divides the batch
@@ -104,7 +105,8 @@ bool make_plan(const ultr_setrank_desc* c, int64_t T, SrPlan* p) {
   int64_t w = 0;
   for (int k = 0; k < 3; ++k) { p->ws_g[k] = w; w += (T * p->maxw + 3) & ~(int64_t)3; }
   p->n_cs = (int)((T + SR_CS_ROWS - 1) / SR_CS_ROWS);
-  p->ws_part = w; w += (int64_t)p->n_cs * 3 * p->maxw;
+  p->n_lb = (int)((T + SR_LB_ROWS - 1) / SR_LB_ROWS);
+  p->ws_part = w; w += (int64_t)p->n_lb * 3 * p->maxw;  // n_lb >= n_cs
   // sum-of-squares partials for ultr_apply_update live at offset 0 of a SEPARATE region at the end (ultr_grad_sumsq
   // writes them at the start of the pointer it is given)
   // weight-gradient split: the largest divisor of T that leaves chunks of >= 512 rows, at most 128 chunks
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(SR_ROWS * 64) void sr_ln_bwd_kernel(const float* __
 // LayerNorm backward AND every column sum that hangs off it, one pass over dy and s:
 //   ds = the row gradient above;  part[blk][0:W] = sum_r dy xhat (dgamma),  [W:2W] = sum_r dy (dbeta),
 //   [2W:3W] = sum_r ds (the bias gradient of the Linear that produced s).
-// A workgroup owns SR_CS_ROWS rows, a wave every 4th of them (row in registers, KMAX columns per lane); the four
+// A workgroup owns SR_LB_ROWS rows, a wave every 4th of them (row in registers, KMAX columns per lane); the four
 // waves' column partials are folded in fixed order through LDS.
 template <int KMAX>
 __global__ __launch_bounds__(256) void sr_ln_bwd_cs_kernel(const float* __restrict__ dy, const float* __restrict__ s,
@@ -247,8 +249,8 @@ __global__ __launch_bounds__(256) void sr_ln_bwd_cs_kernel(const float* __restri
                                                            float* __restrict__ ds_out, float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [4 waves][3][W]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t r0 = (int64_t)blockIdx.x * SR_CS_ROWS;
-  const int64_t r1 = (r0 + SR_CS_ROWS < T) ? r0 + SR_CS_ROWS : T;
+  const int64_t r0 = (int64_t)blockIdx.x * SR_LB_ROWS;
+  const int64_t r1 = (r0 + SR_LB_ROWS < T) ? r0 + SR_LB_ROWS : T;
   float gm[KMAX], ag[KMAX], ab[KMAX], ad[KMAX];
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) {
@@ -362,6 +364,33 @@ __global__ __launch_bounds__(256) void sr_fold_kernel(const float* __restrict__ 
   sm[grp][lane] = (c < len) ? strided_sum(part + c, stride, nparts, grp) : 0.f;
   __syncthreads();
   if (grp == 0 && c < len) dst[c] = ((sm[0][lane] + sm[1][lane]) + sm[2][lane]) + sm[3][lane];
+}
+
+// the same for MANY partials (row-block partials of the LayerNorm / column-sum kernels: hundreds to thousands): 16 columns
+// per workgroup, 16 groups of threads each summing every 16th partial in order, fixed-order combine - 4x the workgroups
+// and 4x shorter serial chains than sr_fold_kernel
+__global__ __launch_bounds__(256) void sr_fold16_kernel(const float* __restrict__ part, int64_t stride, int nparts, int len,
+                                                        float* __restrict__ dst) {
+  __shared__ float sm[16][16];
+  const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float a = 0.f;
+  if (c < len) {
+#pragma unroll 8
+    for (int k = grp; k < nparts; k += 16) a += part[(int64_t)k * stride + c];
+  }
+  sm[grp][cl] = a;
+  __syncthreads();
+  if (grp == 0 && c < len) {
+    float t = sm[0][cl];
+#pragma unroll
+    for (int g = 1; g < 16; ++g) t += sm[g][cl];
+    dst[c] = t;
+  }
+}
+void fold(const float* part, int64_t stride, int nparts, int len, float* dst, hipStream_t st) {
+  if (nparts >= 256) hipLaunchKernelGGL(sr_fold16_kernel, dim3((len + 15) / 16), dim3(256), 0, st, part, stride, nparts, len, dst);
+  else hipLaunchKernelGGL(sr_fold_kernel, dim3((len + 63) / 64), dim3(256), 0, st, part, stride, nparts, len, dst);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -923,6 +952,7 @@ int gemm_dyTx(const SrPlan& p, const float* dY, const float* X, float* dW, int64
 // rocBLAS + the column-sum kernels.
 void colsum(const SrPlan& p, const float* a, const float* s, const float* mean, const float* rstd, int W, int mode, float* ws,
             float* dst, hipStream_t st);
+void fold(const float* part, int64_t stride, int nparts, int len, float* dst, hipStream_t st);
 int wgrad(const SrPlan& p, const float* dY, const float* X, float* dW, float* db, int64_t T, int K, int M, float* ws, hipStream_t st) {
   const bool ok = M % 4 == 0 && K % 4 == 0 && (((uintptr_t)dY | (uintptr_t)X) & 15) == 0 && getenv("ULTR_SR_BLAS_WGRAD") == nullptr;
   if (!ok) {
@@ -947,9 +977,12 @@ int wgrad(const SrPlan& p, const float* dY, const float* X, float* dW, float* db
   hipLaunchKernelGGL(sr_wgrad_kernel, dim3(nmb * nkb * S), dim3(256), lds, st, dY, X, T, M, K, nkb, S, rps, part);
   const int64_t stride = (int64_t)M * K + M;
   const int len = M * K;
-  hipLaunchKernelGGL(sr_fold_kernel, dim3((len + 63) / 64), dim3(256), 0, st, (const float*)part, stride, S, len, dW);
-  if (db != nullptr)
-    hipLaunchKernelGGL(sr_fold_kernel, dim3((M + 63) / 64), dim3(256), 0, st, (const float*)(part + len), stride, S, M, db);
+  if (db == dW + len) {  // weight and bias are neighbours in the flat parameter vector, as in the slab: one fold
+    fold(part, stride, S, len + M, dW, st);
+  } else {
+    fold(part, stride, S, len, dW, st);
+    if (db != nullptr) fold(part + len, stride, S, M, db, st);
+  }
   return 0;
 }
 
@@ -1012,7 +1045,7 @@ void colsum(const SrPlan& p, const float* a, const float* s, const float* mean, 
             float* dst, hipStream_t st) {
   float* part = ws + p.ws_part;
   hipLaunchKernelGGL(sr_colsum_kernel, dim3(p.n_cs), dim3(256), 0, st, a, s, mean, rstd, p.T, W, mode, part);
-  hipLaunchKernelGGL(sr_fold_kernel, dim3((W + 63) / 64), dim3(256), 0, st, (const float*)part, (int64_t)W, p.n_cs, W, dst);
+  fold(part, (int64_t)W, p.n_cs, W, dst, st);
 }
 
 // dst[0..W) = d gamma, dst[W..2W) = d beta (adjacent in the flat layout: <ln>.weight then <ln>.bias)
@@ -1021,18 +1054,17 @@ int ln_bwd_cs(const SrPlan& p, const float* dy, const float* s, const float* mea
               float* dx, float* ws, float* dst_gb, float* dst_bias, hipStream_t st) {
   float* part = ws + p.ws_part;
   const size_t lds = (size_t)4 * 3 * W * sizeof(float);
-  if (W <= 256) hipLaunchKernelGGL(sr_ln_bwd_cs_kernel<4>, dim3(p.n_cs), dim3(256), lds, st, dy, s, mean, rstd, gamma, p.T, W, dx, part);
-  else hipLaunchKernelGGL(sr_ln_bwd_cs_kernel<16>, dim3(p.n_cs), dim3(256), lds, st, dy, s, mean, rstd, gamma, p.T, W, dx, part);
-  hipLaunchKernelGGL(sr_fold_kernel, dim3((2 * W + 63) / 64), dim3(256), 0, st, (const float*)part, (int64_t)3 * W, p.n_cs, 2 * W, dst_gb);
-  hipLaunchKernelGGL(sr_fold_kernel, dim3((W + 63) / 64), dim3(256), 0, st, (const float*)(part + 2 * W), (int64_t)3 * W, p.n_cs, W,
-                     dst_bias);
+  if (W <= 256) hipLaunchKernelGGL(sr_ln_bwd_cs_kernel<4>, dim3(p.n_lb), dim3(256), lds, st, dy, s, mean, rstd, gamma, p.T, W, dx, part);
+  else hipLaunchKernelGGL(sr_ln_bwd_cs_kernel<16>, dim3(p.n_lb), dim3(256), lds, st, dy, s, mean, rstd, gamma, p.T, W, dx, part);
+  fold(part, (int64_t)3 * W, p.n_lb, 2 * W, dst_gb, st);
+  fold(part + 2 * W, (int64_t)3 * W, p.n_lb, W, dst_bias, st);
   return 0;
 }
 void colsum_ln(const SrPlan& p, const float* dy, const float* s, const float* mean, const float* rstd, int W, float* ws, float* dst,
                hipStream_t st) {
   float* part = ws + p.ws_part;
   hipLaunchKernelGGL(sr_colsum_ln_kernel, dim3(p.n_cs), dim3(256), 0, st, dy, s, mean, rstd, p.T, W, part);
-  hipLaunchKernelGGL(sr_fold_kernel, dim3((2 * W + 63) / 64), dim3(256), 0, st, (const float*)part, (int64_t)2 * W, p.n_cs, 2 * W, dst);
+  fold(part, (int64_t)2 * W, p.n_cs, 2 * W, dst, st);
 }
 
 }  // namespace
