@@ -1,0 +1,131 @@
+"""Edge cases of the hot path on the GPU against the oracle: degenerate shapes (one list, one document), lists
+without any click under IPW (0/0 -> 0, base_algorithm.py:26-27), lists made of PAD documents only, an all-zero label
+batch, every document of the batch being the same row, and the longest lists the list-wise kernels take."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.hipref import HipRun  # noqa: E402
+
+
+def _step(F, hidden, B, L, feats, ids, labels, ipw, algo="softmax"):
+    from oracle import ultr_oracle as O
+    params = O.init_params(F, hidden, seed=4)
+    run = HipRun(F, hidden, B, L, algo=algo, learning_rate=0.05, max_gradient_norm=5.0)
+    run.set_inputs(feats, ids, labels)
+    scores = run.forward(params)
+    ds, tail = run.loss(ipw_table=ipw)
+    g, tail2 = run.backward()
+    p_new, s_new, _, sc = run.update(np.zeros_like(params))
+    ref = O.train_step_softmax(params, np.zeros_like(params), F, hidden, feats, ids, labels, ipw_list=ipw, lr=0.05, max_norm=5.0)
+    np.testing.assert_allclose(scores, ref["scores"], atol=1e-5, rtol=1e-5)
+    assert np.isfinite(g).all() and np.isfinite(p_new).all()
+    assert abs(float(sc[0]) - ref["loss"]) <= 1e-5 * max(1.0, abs(ref["loss"]))
+    gs = 1.0 / float(tail2[1])
+    gmax = max(1.0, float(np.abs(ref["grads"]).max()))
+    np.testing.assert_allclose(g * gs, ref["grads"], rtol=2e-5, atol=2e-6 * gmax)
+    sel = np.abs(ref["grads"]) > 1e-5 * gmax  # the first Adagrad step is sign-like: compare where the sign is determined
+    np.testing.assert_allclose(p_new[sel], ref["params"][sel], atol=5e-6, rtol=1e-5)
+    return scores, g, sc
+
+
+@pytest.mark.parametrize("B,L", [(1, 1), (1, 7), (2, 1), (300, 1)])
+def test_degenerate_shapes(B, L):
+    rng = np.random.RandomState(B * 10 + L)
+    F, hidden = 12, [16, 8]
+    feats = rng.uniform(-1, 1, size=(B * L, F)).astype(np.float32)
+    ids = rng.permutation(B * L).astype(np.int32).reshape(L, B)
+    labels = np.ones((L, B), np.float32)
+    _step(F, hidden, B, L, feats, ids, labels, None)
+
+
+@pytest.mark.parametrize("F,hidden,B,L", [(136, [256, 256], 256, 10), (20, [32], 9, 13)])  # fused kernel / separate kernels
+def test_lists_without_clicks_under_ipw(F, hidden, B, L):
+    """IPW weights are 0 on unclicked documents, so a list without a click has S_b = 0 and q = 0/0: the reference maps
+    the NaN to 0 (base_algorithm.py:26-27) and the list contributes nothing - not a NaN - to loss and gradient."""
+    rng = np.random.RandomState(3)
+    feats = rng.uniform(-1, 1, size=(B * L, F)).astype(np.float32)
+    ids = rng.permutation(B * L).astype(np.int32).reshape(L, B)
+    labels = (rng.uniform(size=(L, B)) < 0.3).astype(np.float32)
+    labels[:, ::3] = 0.0  # every third list: no click at all
+    labels[0, 1] = 1.0
+    ipw = np.linspace(1.0, 9.0, 40)
+    _step(F, hidden, B, L, feats, ids, labels, ipw)
+
+
+def test_all_pad_lists_and_shared_rows():
+    """Lists made of PAD documents only (id == n_docs -> the zero feature row, base_algorithm.py:148-149) and a batch
+    whose real documents are all the same row."""
+    rng = np.random.RandomState(8)
+    F, hidden, B, L = 24, [32, 16], 12, 10
+    feats = rng.uniform(-1, 1, size=(5, F)).astype(np.float32)
+    ids = np.full((L, B), 2, np.int32)   # everybody is document 2 ...
+    ids[:, 4] = 5                        # ... list 4 is PAD only (n_docs = 5)
+    ids[7:, 9] = 5                       # a ragged tail of PADs
+    labels = (rng.uniform(size=(L, B)) < 0.4).astype(np.float32)
+    labels[0, :] = 1.0
+    scores, g, _ = _step(F, hidden, B, L, feats, ids, labels, None)
+    assert np.allclose(scores[4], scores[4][0])  # one value: the score of the zero row
+    from ultra_pytorch_amd import engine
+    ev = engine.EvalEngine(HipRun(F, hidden, B, L).shape, B, L, torch.device("cuda"), topn=(1, 3, 10))
+    from oracle import ultr_oracle as O
+    params = torch.tensor(O.init_params(F, hidden, seed=4)).cuda()
+    s, nd = ev.run(params, torch.tensor(feats).cuda(), feats.shape[0], torch.tensor(ids).cuda(), torch.tensor(labels).cuda())
+    torch.cuda.synchronize()
+    assert np.isfinite(nd.cpu().numpy()).all()
+    masked = ev.masked.cpu().numpy()
+    assert (masked[4] == -100000.0).all() and (masked[9, 7:] == -100000.0).all()  # remove_padding_for_metric_eval
+    np.testing.assert_allclose(s.cpu().numpy(), scores, atol=1e-6)                  # validation returns UNMASKED scores
+
+
+def test_all_zero_labels_na():
+    """NA with no click anywhere: w = 1e-7 on every document (base_algorithm.py:321), D = B*L*1e-7 - finite, uniform targets."""
+    rng = np.random.RandomState(2)
+    F, hidden, B, L = 16, [24], 6, 8
+    feats = rng.uniform(-1, 1, size=(B * L, F)).astype(np.float32)
+    ids = rng.permutation(B * L).astype(np.int32).reshape(L, B)
+    _step(F, hidden, B, L, feats, ids, np.zeros((L, B), np.float32), None)
+
+
+@pytest.mark.parametrize("algo,L", [("softmax", 256), ("dla", 256), ("pairdebias", 256), ("lambdarank", 256)])
+def test_longest_lists(algo, L):
+    """list_size 256 - the cap of the list-wise kernels (one wavefront x 4 documents per lane)."""
+    from oracle import ultr_oracle as O
+    rng = np.random.RandomState(L)
+    B = 3
+    scores = rng.normal(size=(B, L)).astype(np.float32)
+    labels_LB = (rng.uniform(size=(L, B)) < 0.2).astype(np.float32)
+    if algo == "lambdarank":
+        labels_LB = rng.randint(0, 5, size=(L, B)).astype(np.float32)
+    labels_LB[0, :] = 1.0
+    run = HipRun(8, [4], B, L, algo=algo)
+    run.set_inputs(np.zeros((1, 8), np.float32), np.zeros((L, B), np.int32), labels_LB)
+    s = torch.tensor(scores, requires_grad=True)
+    y = torch.tensor(labels_LB.T.copy())
+    tp = torch.tensor(rng.uniform(0.8, 1.2, size=L).astype(np.float32))
+    tm = torch.tensor(rng.uniform(0.8, 1.2, size=L).astype(np.float32))
+    if algo == "softmax":
+        ipw = rng.uniform(1, 10, size=40)
+        loss = O.softmax_loss(s, y, O.ipw_weights(labels_LB, ipw))
+        ds, tail = run.loss(ipw_table=ipw, scores=scores)
+        gs = 1.0 / tail[1]
+    elif algo == "dla":
+        q = torch.tensor(rng.normal(scale=0.3, size=L + 1).astype(np.float32))
+        with torch.no_grad():
+            pw = O.normalized_weights(torch.softmax(O.denoising_net(q, B, L), -1))
+        loss = O.softmax_loss(s, y, pw)
+        ds, tail = run.loss(aux=q.numpy(), scores=scores)
+        gs = 1.0 / tail[1]
+    elif algo == "pairdebias":
+        loss = O.pairdebias_loss(s, torch.tensor(labels_LB), tp, tm)[0]
+        ds, tail = run.loss(aux=np.concatenate([tp.numpy(), tm.numpy()]), scores=scores)
+        gs = 1.0
+    else:
+        loss = O.lambdarank_loss(s, y, tp, tm, 1.0)[0]
+        ds, tail = run.loss(aux=np.concatenate([tp.numpy(), tm.numpy()]), scores=scores)
+        gs = 1.0 / tail[1]
+    (g,) = torch.autograd.grad(loss, s)
+    g = g.numpy()
+    np.testing.assert_allclose(ds * gs, g, rtol=3e-5, atol=3e-6 * max(1.0, float(np.abs(g).max())))
