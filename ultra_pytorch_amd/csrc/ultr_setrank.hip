@@ -39,6 +39,7 @@ struct SrPlan {
   int64_t sv_xg, sv_mean_in, sv_rstd_in, sv_xn0, sv_h0, sv_oh;
   int64_t sv_x[9];  // x_0 .. x_nl  [T, d]
   int64_t sv_A[8], sv_s1[8], sv_m1[8], sv_r1[8], sv_out1[8], sv_f[8], sv_s2[8], sv_m2[8], sv_r2[8];
+  int64_t sv_lse[8];  // [T, H] attention row statistic (log-sum-exp of the scaled scores)
   int64_t sv_total;
   // workspace (floats)
   int maxw;
@@ -97,6 +98,7 @@ bool make_plan(const ultr_setrank_desc* c, int64_t T, SrPlan* p) {
     p->sv_A[l] = take(T * d); p->sv_s1[l] = take(T * d); p->sv_m1[l] = take(T); p->sv_r1[l] = take(T);
     p->sv_out1[l] = take(T * d); p->sv_f[l] = take(T * dff);
     p->sv_s2[l] = take(T * d); p->sv_m2[l] = take(T); p->sv_r2[l] = take(T);
+    p->sv_lse[l] = take(T * p->H);
   }
   p->sv_oh = take(T * dff);
   p->sv_total = s;
@@ -589,7 +591,7 @@ __device__ __forceinline__ f32x4 sr_tile_nt(const float* arow, const float4 (&bf
 
 template <int DH>
 __global__ __launch_bounds__(SR_MAXT * 64) void sr_attn_fwd_mfma_kernel(const float* __restrict__ x, int L, int d,
-                                                                       float* __restrict__ A) {
+                                                                       float* __restrict__ A, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int KQ = DH / 4, LDX = DH + 4, NC = DH / 16, NF = DH / 16;
   const int Lp = round_up(L, 16), NTL = Lp / 16;
@@ -631,7 +633,10 @@ __global__ __launch_bounds__(SR_MAXT * 64) void sr_attn_fwd_mfma_kernel(const fl
       for (int r = 0; r < 4; ++r) sum += pr[t][r];
     }
   }
-  const float inv = 1.0f / quad_sum(sum);
+  sum = quad_sum(sum);
+  const float inv = 1.0f / sum;
+  // row statistic for the backward: P[i][j] = exp(S[i][j] - lse[i])
+  if (lse != nullptr && q == 0 && wave * 16 + i < L) lse[((int64_t)b * L + wave * 16 + i) * gridDim.y + h] = mx + logf(sum);
   f32x4 o[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) o[c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -657,31 +662,50 @@ __global__ __launch_bounds__(SR_MAXT * 64) void sr_attn_fwd_mfma_kernel(const fl
   }
 }
 
-// backward.  With P and dP = dA x^T,  dS = scale * P o (dP - rowsum(P o dP)),  dx += dS x + dS^T x + P^T dA.
-// A wave owns a block of 16 tokens twice over:
-//  (A) as QUERIES it works on transposed tiles exactly like the forward (softmax row, rowsum and dS in registers),
-//      accumulates dq = dS x, and leaves the three row statistics (max, 1 / sum, rowsum) in LDS;
-//  (B) as KEYS it needs the COLUMNS of dS and P: it recomputes the plain tiles D[query][key] (bitwise the same
-//      products in the same order as the transposed tile the other wave used), rebuilds P and dS from the saved
-//      statistics - lane (i, q) now holds, for ITS key i, the queries {16 t + 4 q + r}, the A operand of
-//      dk = dS^T x and dv = P^T dA.
-// 40% more MFMAs than materialising P and dS, but no [L, L] matrices in LDS: 32 KB instead of 136 KB per workgroup,
-// one barrier, several workgroups per CU.  All three products land in the same accumulator tile.
+// backward.  With P and dP = dA x^T,  dS = scale * P o (dP - t),  t = rowsum(P o dP):   dx += dS x + dS^T x + P^T dA.
+// Flash-attention bookkeeping removes every row reduction from the kernel: the forward left lse[i] (P = exp(S - lse)),
+// and t[i] = rowsum(P o dP) = dA[i] . A[i] (A = P x is the saved forward output) is a 32-float dot product formed
+// while the tiles are staged.  A wave owns a block of 16 tokens in BOTH roles and walks the 7 partner blocks once:
+//  * ONE score tile serves both roles - S = x x^T is symmetric, so the register that holds S[key 16 t + 4 q + r][query i]
+//    for the wave's query i also is S[query 16 t + 4 q + r][key i] for its key i;
+//  * as QUERIES it needs dP^T[key][query] = x[key] . dA[query]  ->  P, dS for its query in 4 lanes = the A operand of
+//    dq = dS x (contraction over the partner block's keys);
+//  * as KEYS it needs dP[query][key] = dA[query] . x[key] and the partner queries' lse / t  ->  P, dS columns = the A
+//    operand of dk = dS^T x and dv = P^T dA (contraction over the partner block's queries).
+// 48 MFMAs per partner block (3 x 8 tiles + 3 x 8 products), no softmax pass, one barrier (after staging), nothing
+// [L, L]-sized anywhere; the three products land on the same output tile (separate accumulator chains, summed at the end).
 template <int DH>
-__global__ __launch_bounds__(SR_MAXT * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void sr_attn_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dA,
-                                                                       int L, int d, float* __restrict__ dx) {
+__global__ __launch_bounds__(SR_MAXT * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void sr_attn_bwd_mfma_kernel(
+    const float* __restrict__ x, const float* __restrict__ dA, const float* __restrict__ Aout, const float* __restrict__ lse, int L,
+    int d, float* __restrict__ dx) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int KQ = DH / 4, LDX = DH + 4, NC = DH / 16, NF = DH / 16;
+  constexpr int KQ = DH / 4, LDX = DH + 4, NC = DH / 16, NF = DH / 16, RT = DH / 4;  // RT threads stage one row
   const int Lp = round_up(L, 16), NTL = Lp / 16;
-  float* xs = smem;              // [Lp][LDX]
-  float* das = xs + Lp * LDX;    // [Lp][LDX]
-  float* st_mx = das + Lp * LDX; // [Lp] row max | [Lp] 1 / row sum | [Lp] rowsum(P o dP)
-  float* st_inv = st_mx + Lp;
-  float* st_t = st_inv + Lp;
-  const int b = blockIdx.x, h = blockIdx.y;
+  float* xs = smem;               // [Lp][LDX]
+  float* das = xs + Lp * LDX;     // [Lp][LDX]
+  float* st_l = das + Lp * LDX;   // [Lp] lse (padding rows: +inf -> P = 0)
+  float* st_t = st_l + Lp;        // [Lp] t = dA . A
+  const int b = blockIdx.x, h = blockIdx.y, H = gridDim.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
   const int64_t base = (int64_t)b * L * d + h * DH;
-  sr_stage_head<DH, true>(x, dA, base, L, Lp, d, xs, das, tid, NTL * 64);
+  for (int e = tid; e < Lp * RT; e += NTL * 64) {
+    const int r = e / RT, c4 = (e - r * RT) * 4;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool ok = r < L;
+    const float4 xv = ok ? ld4(x + base + (int64_t)r * d + c4) : z4;
+    const float4 gv = ok ? ld4(dA + base + (int64_t)r * d + c4) : z4;
+    const float4 av = ok ? ld4(Aout + base + (int64_t)r * d + c4) : z4;
+    st4(xs + r * LDX + c4, xv);
+    st4(das + r * LDX + c4, gv);
+    // the RT threads of a row are consecutive lanes of one wave (RT = 4 / 8 / 16 divides 64): butterfly over them
+    float tt = gv.x * av.x + gv.y * av.y + gv.z * av.z + gv.w * av.w;
+#pragma unroll
+    for (int m = 1; m < RT; m <<= 1) tt += __shfl_xor(tt, m);
+    if ((e - r * RT) == 0) {
+      st_t[r] = tt;
+      st_l[r] = ok ? lse[((int64_t)b * L + r) * H + h] : INFINITY;
+    }
+  }
   __syncthreads();
   const float scale = 1.0f / sqrtf((float)DH);
   float4 bx[NF], bg[NF];  // this wave's block: x rows and dA rows
@@ -690,94 +714,48 @@ __global__ __launch_bounds__(SR_MAXT * 64) __attribute__((amdgpu_waves_per_eu(4,
     bx[f] = ld4(xs + (wave * 16 + i) * LDX + q * KQ + 4 * f);
     bg[f] = ld4(das + (wave * 16 + i) * LDX + q * KQ + 4 * f);
   }
-  f32x4 acc[NC];
+  const float l_own = st_l[wave * 16 + i], t_own = st_t[wave * 16 + i];
+  f32x4 acc[NC], ack[NC], acv[NC];  // dq, dk, dv: separate chains, summed at the end
 #pragma unroll
-  for (int c = 0; c < NC; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-  {  // ---- (A) the block as queries
-    f32x4 pr[SR_MAXT], dp[SR_MAXT];
-    float mx = -INFINITY;
+  for (int c = 0; c < NC; ++c) acc[c] = ack[c] = acv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NTL; ++t) {
+    const float* xrow = xs + (t * 16 + i) * LDX + q * KQ;
+    const float* grow = das + (t * 16 + i) * LDX + q * KQ;
+    // three independent accumulation chains, interleaved:
+    //   sc  = S[16 t + 4 q + r][own i]  (symmetric: serves both roles)
+    //   dpt = dP^T[key 16 t + 4 q + r][query own i] = x[key] . dA[query]
+    //   dpn = dP[query 16 t + 4 q + r][key own i]   = dA[query] . x[key]
+    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dpt = sc, dpn = sc;
 #pragma unroll
-    for (int t = 0; t < SR_MAXT; ++t) {
-      if (t < NTL) {
-        const float* arow = xs + (t * 16 + i) * LDX + q * KQ;
-        pr[t] = sr_tile_nt<DH>(arow, bx);   // S^T[key][query]
-        dp[t] = sr_tile_nt<DH>(arow, bg);   // dP^T[key][query] = x[key] . dA[query]
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          pr[t][r] *= scale;
-          mx = fmaxf(mx, pr[t][r]);
-        }
-      }
+    for (int f = 0; f < NF; ++f) {
+      const float4 xa = ld4(xrow + 4 * f), ga = ld4(grow + 4 * f);
+      sc = mfma16(xa.x, bx[f].x, sc); dpt = mfma16(xa.x, bg[f].x, dpt); dpn = mfma16(ga.x, bx[f].x, dpn);
+      sc = mfma16(xa.y, bx[f].y, sc); dpt = mfma16(xa.y, bg[f].y, dpt); dpn = mfma16(ga.y, bx[f].y, dpn);
+      sc = mfma16(xa.z, bx[f].z, sc); dpt = mfma16(xa.z, bg[f].z, dpt); dpn = mfma16(ga.z, bx[f].z, dpn);
+      sc = mfma16(xa.w, bx[f].w, sc); dpt = mfma16(xa.w, bg[f].w, dpt); dpn = mfma16(ga.w, bx[f].w, dpn);
     }
-    mx = quad_max(mx);
-    float sum = 0.f;
+    const float4 l4 = ld4(st_l + t * 16 + 4 * q), t4 = ld4(st_t + t * 16 + 4 * q);
+    const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, tq[4] = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
-    for (int t = 0; t < SR_MAXT; ++t) {
-      if (t < NTL) {
+    for (int r = 0; r < 4; ++r) {
+      const int pr = t * 16 + 4 * q + r;   // the partner token of this register
+      const float sv = sc[r] * scale;
+      // own token as query, partner as key (a padding key has lse = +inf on ITS row only: mask by index)
+      float pa = exp_nonpos(fminf(sv - l_own, 0.f));
+      pa = (pr < L) ? pa : 0.f;
+      const float dsa = scale * pa * (dpt[r] - t_own);
+      // own token as key, partner as query (padding query: lse = +inf -> exp(-inf) clamps to ~1e-38, times 0 rows)
+      float pb = exp_nonpos(fminf(sv - lq[r], 0.f));
+      pb = (pr < L) ? pb : 0.f;
+      const float dsb = scale * pb * (dpn[r] - tq[r]);
+      const float* xr = xs + pr * LDX + i;
+      const float* gr = das + pr * LDX + i;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pr[t][r] = exp_nonpos(pr[t][r] - mx);
-        if (t == NTL - 1) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) pr[t][r] = (t * 16 + 4 * q + r < L) ? pr[t][r] : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sum += pr[t][r];
-      }
-    }
-    const float inv = 1.0f / quad_sum(sum);
-    float tt = 0.f;
-#pragma unroll
-    for (int t = 0; t < SR_MAXT; ++t) {
-      if (t < NTL) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          pr[t][r] *= inv;
-          tt += pr[t][r] * dp[t][r];
-        }
-      }
-    }
-    tt = quad_sum(tt);
-    if (q == 0) {
-      st_mx[wave * 16 + i] = mx;
-      st_inv[wave * 16 + i] = inv;
-      st_t[wave * 16 + i] = tt;
-    }
-#pragma unroll
-    for (int t = 0; t < SR_MAXT; ++t) {
-      if (t < NTL) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float ds = scale * pr[t][r] * (dp[t][r] - tt);
-          const float* xr = xs + (t * 16 + 4 * q + r) * LDX + i;
-#pragma unroll
-          for (int c = 0; c < NC; ++c) acc[c] = mfma16(ds, xr[c * 16], acc[c]);   // dq
-        }
-      }
-    }
-  }
-  __syncthreads();
-  {  // ---- (B) the block as keys
-#pragma unroll
-    for (int t = 0; t < SR_MAXT; ++t) {
-      if (t < NTL) {
-        const f32x4 s = sr_tile_nt<DH>(xs + (t * 16 + i) * LDX + q * KQ, bx);    // S[query][key]
-        const f32x4 g = sr_tile_nt<DH>(das + (t * 16 + i) * LDX + q * KQ, bx);   // dP[query][key] = dA[query] . x[key]
-        const float4 m4 = ld4(st_mx + t * 16 + 4 * q), i4 = ld4(st_inv + t * 16 + 4 * q), t4 = ld4(st_t + t * 16 + 4 * q);
-        const float mq[4] = {m4.x, m4.y, m4.z, m4.w}, iq[4] = {i4.x, i4.y, i4.z, i4.w}, tq[4] = {t4.x, t4.y, t4.z, t4.w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int qr = t * 16 + 4 * q + r;   // the query of this register
-          float pv = exp_nonpos(s[r] * scale - mq[r]) * iq[r];
-          if (t == NTL - 1) pv = (qr < L) ? pv : 0.f;   // padding queries
-          const float ds = scale * pv * (g[r] - tq[r]);
-          const float* xr = xs + qr * LDX + i;
-          const float* gr = das + qr * LDX + i;
-#pragma unroll
-          for (int c = 0; c < NC; ++c) {
-            acc[c] = mfma16(ds, xr[c * 16], acc[c]);   // dk
-            acc[c] = mfma16(pv, gr[c * 16], acc[c]);   // dv
-          }
-        }
+      for (int c = 0; c < NC; ++c) {
+        const float xv = xr[c * 16];
+        acc[c] = mfma16(dsa, xv, acc[c]);            // dq: dS[own][partner] x[partner]
+        ack[c] = mfma16(dsb, xv, ack[c]);            // dk: dS[partner][own] x[partner]
+        acv[c] = mfma16(pb, gr[c * 16], acv[c]);     // dv: P[partner][own] dA[partner]
       }
     }
   }
@@ -786,7 +764,7 @@ __global__ __launch_bounds__(SR_MAXT * 64) __attribute__((amdgpu_waves_per_eu(4,
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = wave * 16 + 4 * q + r;
-      if (row < L) dx[base + (int64_t)row * d + c * 16 + i] += acc[c][r];
+      if (row < L) dx[base + (int64_t)row * d + c * 16 + i] += (acc[c][r] + ack[c][r]) + acv[c][r];
     }
   }
 }
@@ -1007,28 +985,29 @@ int set_dyn_lds(K kernel, size_t bytes) {
     return ULTR_E_UNSUPPORTED;
   return 0;
 }
-int attn_fwd_mfma(const SrPlan& p, const float* x, int batch, int L, float* A, hipStream_t st) {
+int attn_fwd_mfma(const SrPlan& p, const float* x, int batch, int L, float* A, float* lse, hipStream_t st) {
   const int Lp = round_up(L, 16);
   const size_t lds = (size_t)Lp * (p.dh + 4) * sizeof(float);
   const dim3 grid(batch, p.H), block(Lp * 4);  // one wave per 16 tokens
-  if (p.dh == 16) hipLaunchKernelGGL(sr_attn_fwd_mfma_kernel<16>, grid, block, lds, st, x, L, p.d, A);
-  else if (p.dh == 32) hipLaunchKernelGGL(sr_attn_fwd_mfma_kernel<32>, grid, block, lds, st, x, L, p.d, A);
-  else hipLaunchKernelGGL(sr_attn_fwd_mfma_kernel<64>, grid, block, lds, st, x, L, p.d, A);
+  if (p.dh == 16) hipLaunchKernelGGL(sr_attn_fwd_mfma_kernel<16>, grid, block, lds, st, x, L, p.d, A, lse);
+  else if (p.dh == 32) hipLaunchKernelGGL(sr_attn_fwd_mfma_kernel<32>, grid, block, lds, st, x, L, p.d, A, lse);
+  else hipLaunchKernelGGL(sr_attn_fwd_mfma_kernel<64>, grid, block, lds, st, x, L, p.d, A, lse);
   return 0;
 }
-int attn_bwd_mfma(const SrPlan& p, const float* x, const float* dA, int batch, int L, float* dx, hipStream_t st) {
+int attn_bwd_mfma(const SrPlan& p, const float* x, const float* dA, const float* Aout, const float* lse, int batch, int L, float* dx,
+                  hipStream_t st) {
   const int Lp = round_up(L, 16);
-  const size_t lds = ((size_t)2 * Lp * (p.dh + 4) + 3 * (size_t)Lp) * sizeof(float);
+  const size_t lds = ((size_t)2 * Lp * (p.dh + 4) + 2 * (size_t)Lp) * sizeof(float);
   const dim3 grid(batch, p.H), block(Lp * 4);
   if (p.dh == 16) {
     SR_CHECK(set_dyn_lds(sr_attn_bwd_mfma_kernel<16>, lds));
-    hipLaunchKernelGGL(sr_attn_bwd_mfma_kernel<16>, grid, block, lds, st, x, dA, L, p.d, dx);
+    hipLaunchKernelGGL(sr_attn_bwd_mfma_kernel<16>, grid, block, lds, st, x, dA, Aout, lse, L, p.d, dx);
   } else if (p.dh == 32) {
     SR_CHECK(set_dyn_lds(sr_attn_bwd_mfma_kernel<32>, lds));
-    hipLaunchKernelGGL(sr_attn_bwd_mfma_kernel<32>, grid, block, lds, st, x, dA, L, p.d, dx);
+    hipLaunchKernelGGL(sr_attn_bwd_mfma_kernel<32>, grid, block, lds, st, x, dA, Aout, lse, L, p.d, dx);
   } else {
     SR_CHECK(set_dyn_lds(sr_attn_bwd_mfma_kernel<64>, lds));
-    hipLaunchKernelGGL(sr_attn_bwd_mfma_kernel<64>, grid, block, lds, st, x, dA, L, p.d, dx);
+    hipLaunchKernelGGL(sr_attn_bwd_mfma_kernel<64>, grid, block, lds, st, x, dA, Aout, lse, L, p.d, dx);
   }
   return 0;
 }
@@ -1116,7 +1095,7 @@ extern "C" int ultr_setrank_forward(const ultr_setrank_desc* c, const float* par
   for (int l = 0; l < p.nl; ++l) {
     const SrLayer& y = p.lay[l];
     const float* x = sv + p.sv_x[l];
-    if (mfma_att) SR_CHECK(attn_fwd_mfma(p, x, batch, L, sv + p.sv_A[l], st));
+    if (mfma_att) SR_CHECK(attn_fwd_mfma(p, x, batch, L, sv + p.sv_A[l], sv + p.sv_lse[l], st));
     else hipLaunchKernelGGL(sr_attn_fwd_kernel, dim3(batch, p.H), dim3(256), lds_att, st, x, L, d, p.dh, sv + p.sv_A[l]);
     // A Wd^T lands in out1's buffer, then out1 = LN1(x + (A Wd^T + bd)) in place (s1 keeps the pre-norm sum)
     SR_CHECK(gemm_xwT(sv + p.sv_A[l], params + y.wd, sv + p.sv_out1[l], T, d, d, 0.f));
@@ -1198,7 +1177,8 @@ extern "C" int ultr_setrank_backward(const ultr_setrank_desc* c, const float* pa
     }
     SR_CHECK(wgrad(p, G0, sv + p.sv_A[l], grads + y.wd, nullptr, T, d, d, ws, st));
     SR_CHECK(gemm_dyw(G0, params + y.wd, G1, T, d, d, 0.f));                 // G1 = d A  [T, d]
-    if (attn_mfma_ok(p, L)) SR_CHECK(attn_bwd_mfma(p, sv + p.sv_x[l], G1, batch, L, G0, st));   // G0 += attention path -> d x_l
+    if (attn_mfma_ok(p, L))   // G0 += attention path -> d x_l
+      SR_CHECK(attn_bwd_mfma(p, sv + p.sv_x[l], G1, sv + p.sv_A[l], sv + p.sv_lse[l], batch, L, G0, st));
     else hipLaunchKernelGGL(sr_attn_bwd_kernel, dim3(batch, p.H), dim3(256), lds_att, st, sv + p.sv_x[l], (const float*)G1, L, d,
                             p.dh, G0);
   }
