@@ -683,7 +683,7 @@ __global__ __launch_bounds__(SR_MAXT * 64) __attribute__((amdgpu_waves_per_eu(4,
   const int Lp = round_up(L, 16), NTL = Lp / 16;
   float* xs = smem;               // [Lp][LDX]
   float* das = xs + Lp * LDX;     // [Lp][LDX]
-  float* st_l = das + Lp * LDX;   // [Lp] lse (padding rows: +inf -> P = 0)
+  float* st_l = das + Lp * LDX;   // [Lp] lse * log2(e) (padding rows: +inf -> P = 0)
   float* st_t = st_l + Lp;        // [Lp] t = dA . A
   const int b = blockIdx.x, h = blockIdx.y, H = gridDim.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
@@ -703,7 +703,7 @@ __global__ __launch_bounds__(SR_MAXT * 64) __attribute__((amdgpu_waves_per_eu(4,
     for (int m = 1; m < RT; m <<= 1) tt += __shfl_xor(tt, m);
     if ((e - r * RT) == 0) {
       st_t[r] = tt;
-      st_l[r] = ok ? lse[((int64_t)b * L + r) * H + h] : INFINITY;
+      st_l[r] = ok ? lse[((int64_t)b * L + r) * H + h] * 1.44269504088896341f : INFINITY;
     }
   }
   __syncthreads();
@@ -714,11 +714,17 @@ __global__ __launch_bounds__(SR_MAXT * 64) __attribute__((amdgpu_waves_per_eu(4,
     bx[f] = ld4(xs + (wave * 16 + i) * LDX + q * KQ + 4 * f);
     bg[f] = ld4(das + (wave * 16 + i) * LDX + q * KQ + 4 * f);
   }
+  // VALU instructions do not hide behind the MFMAs here (SQ_VALU_MFMA_COEXEC_CYCLES = 0, and MFMA busy + 4 x VALU count
+  // adds up to the kernel time), so the probabilities cost two instructions each: P = 2^(S * scale*log2(e) - lse*log2(e))
+  // as one fma + v_exp_f32 (st_l holds lse * log2(e); an unreduced argument costs ~|arg| * 4e-8 of relative accuracy).
+  // A padding QUERY has lse = +inf -> P = 0 by itself; padding KEYS exist only in the last block and are masked there.
+  const float c1 = scale * 1.44269504088896341f;
   const float l_own = st_l[wave * 16 + i], t_own = st_t[wave * 16 + i];
   f32x4 acc[NC], ack[NC], acv[NC];  // dq, dk, dv: separate chains, summed at the end
 #pragma unroll
   for (int c = 0; c < NC; ++c) acc[c] = ack[c] = acv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int t = 0; t < NTL; ++t) {
+  auto partner_block = [&](int t, auto last_tag) {
+    constexpr bool LAST = decltype(last_tag)::value;
     const float* xrow = xs + (t * 16 + i) * LDX + q * KQ;
     const float* grow = das + (t * 16 + i) * LDX + q * KQ;
     // three independent accumulation chains, interleaved:
@@ -739,15 +745,13 @@ __global__ __launch_bounds__(SR_MAXT * 64) __attribute__((amdgpu_waves_per_eu(4,
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int pr = t * 16 + 4 * q + r;   // the partner token of this register
-      const float sv = sc[r] * scale;
-      // own token as query, partner as key (a padding key has lse = +inf on ITS row only: mask by index)
-      float pa = exp_nonpos(fminf(sv - l_own, 0.f));
-      pa = (pr < L) ? pa : 0.f;
-      const float dsa = scale * pa * (dpt[r] - t_own);
-      // own token as key, partner as query (padding query: lse = +inf -> exp(-inf) clamps to ~1e-38, times 0 rows)
-      float pb = exp_nonpos(fminf(sv - lq[r], 0.f));
-      pb = (pr < L) ? pb : 0.f;
-      const float dsb = scale * pb * (dpn[r] - tq[r]);
+      // own token as query, partner as key
+      float pa = __builtin_amdgcn_exp2f(fmaf(sc[r], c1, -l_own));
+      if (LAST) pa = (pr < L) ? pa : 0.f;
+      const float dsa = (scale * pa) * (dpt[r] - t_own);
+      // own token as key, partner as query
+      const float pb = __builtin_amdgcn_exp2f(fmaf(sc[r], c1, -lq[r]));
+      const float dsb = (scale * pb) * (dpn[r] - tq[r]);
       const float* xr = xs + pr * LDX + i;
       const float* gr = das + pr * LDX + i;
 #pragma unroll
@@ -758,7 +762,9 @@ __global__ __launch_bounds__(SR_MAXT * 64) __attribute__((amdgpu_waves_per_eu(4,
         acv[c] = mfma16(pb, gr[c * 16], acv[c]);     // dv: P[partner][own] dA[partner]
       }
     }
-  }
+  };
+  for (int t = 0; t < NTL - 1; ++t) partner_block(t, std::false_type{});
+  partner_block(NTL - 1, std::true_type{});
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
 #pragma unroll
