@@ -551,16 +551,6 @@ __device__ __forceinline__ float quad_sum(float v) {
   return v + __shfl_xor(v, 32);
 }
 
-// exp(x) for x <= 0 in 7 instructions: two-constant range reduction, v_exp_f32 on [-0.5, 0.5], v_ldexp (about 1 ulp).
-// Arguments below -87 are clamped (the result is ~1e-38 instead of a denormal or 0).
-__device__ __forceinline__ float exp_nonpos(float x) {
-  x = fmaxf(x, -87.0f);
-  const float n = __builtin_rintf(x * 1.44269504088896341f);
-  float r = fmaf(x, 1.44269504088896341f, -n);
-  r = fmaf(x, 1.92596299112661746e-8f, r);
-  return ldexpf(__builtin_amdgcn_exp2f(r), (int)n);
-}
-
 // stage the head slice(s) into LDS, zero rows past L
 template <int DH, bool WITH_DA>
 __device__ __forceinline__ void sr_stage_head(const float* __restrict__ x, const float* __restrict__ dA, int64_t base, int L, int Lp,
@@ -606,25 +596,24 @@ __global__ __launch_bounds__(SR_MAXT * 64) void sr_attn_fwd_mfma_kernel(const fl
 #pragma unroll
   for (int f = 0; f < NF; ++f) bq[f] = ld4(xs + (wave * 16 + i) * LDX + q * KQ + 4 * f);
   f32x4 pr[SR_MAXT];  // pr[t][r]: key 16 t + 4 q + r, query = this lane's i
-  float mx = -INFINITY;
+  float mx = -INFINITY;  // of the RAW scores (scale > 0)
 #pragma unroll
   for (int t = 0; t < SR_MAXT; ++t) {
     if (t < NTL) {
       pr[t] = sr_tile_nt<DH>(xs + (t * 16 + i) * LDX + q * KQ, bq);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        pr[t][r] *= scale;
-        mx = fmaxf(mx, pr[t][r]);  // padding keys score 0 <= the diagonal |x_i|^2: they never raise the maximum
-      }
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, pr[t][r]);  // padding keys score 0 <= the diagonal |x_i|^2: never the maximum
     }
   }
   mx = quad_max(mx);
+  // exp(scale * (s - mx)) = 2^(s * c1 - mx * c1): one fma + v_exp_f32 per probability (VALU work does not hide behind MFMAs)
+  const float c1 = scale * 1.44269504088896341f, mx2 = mx * c1;
   float sum = 0.f;
 #pragma unroll
   for (int t = 0; t < SR_MAXT; ++t) {
     if (t < NTL) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pr[t][r] = exp_nonpos(pr[t][r] - mx);
+      for (int r = 0; r < 4; ++r) pr[t][r] = __builtin_amdgcn_exp2f(fmaf(pr[t][r], c1, -mx2));
       if (t == NTL - 1) {  // only the last block can hold padding keys
 #pragma unroll
         for (int r = 0; r < 4; ++r) pr[t][r] = (t * 16 + 4 * q + r < L) ? pr[t][r] : 0.f;
@@ -636,7 +625,7 @@ __global__ __launch_bounds__(SR_MAXT * 64) void sr_attn_fwd_mfma_kernel(const fl
   sum = quad_sum(sum);
   const float inv = 1.0f / sum;
   // row statistic for the backward: P[i][j] = exp(S[i][j] - lse[i])
-  if (lse != nullptr && q == 0 && wave * 16 + i < L) lse[((int64_t)b * L + wave * 16 + i) * gridDim.y + h] = mx + logf(sum);
+  if (lse != nullptr && q == 0 && wave * 16 + i < L) lse[((int64_t)b * L + wave * 16 + i) * gridDim.y + h] = mx * scale + logf(sum);
   f32x4 o[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) o[c] = f32x4{0.f, 0.f, 0.f, 0.f};
