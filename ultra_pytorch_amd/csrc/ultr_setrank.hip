@@ -775,7 +775,7 @@ __global__ __launch_bounds__(SR_MAXT * 64) __attribute__((amdgpu_waves_per_eu(4,
 // then a fixed-order LDS reduction over the waves and one slab [M*K + M] per chunk; sr_fold_kernel sums the slabs.
 // (rocBLAS ran these as strided-batched 32x32 macro-tiles at ~43 TFLOP/s; same design as dnn_wgrad_kernel.)
 constexpr int SRW_SPT = 2;  // steps (of 4 rows) per trip
-__global__ __launch_bounds__(256) void sr_wgrad_kernel(const float* __restrict__ dY, const float* __restrict__ X, int64_t T, int M,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void sr_wgrad_kernel(const float* __restrict__ dY, const float* __restrict__ X, int64_t T, int M,
                                                        int K, int nkb, int nsplit, int rps, float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float (*red)[64 * 64] = reinterpret_cast<float (*)[64 * 64]>(smem);
