@@ -278,65 +278,91 @@ extern "C" int ultr_dla_loss(const float* scores, const float* labels, const flo
 // ------------------------------------------------------------------------------------------------
 // a10: PairDebias                                               pairwise_debias.py:142-157
 // ------------------------------------------------------------------------------------------------
-// Lane i owns position i and walks all j != i once, evaluating BOTH ordered pairs (i,j) and (j,i), so every
-// gradient / EM sum it owns is produced locally (the "wavefront pair-diff kernel").
-__global__ __launch_bounds__(LPW * 64) void pairdebias_kernel(const float* __restrict__ scores,
-                                                             const float* __restrict__ labels,
-                                                             const float* __restrict__ t_plus,
-                                                             const float* __restrict__ t_minus, int B, int L,
-                                                             float bscale, float* __restrict__ dscores,
-                                                             float* __restrict__ part) {
+// Lane i owns position i and walks the partner positions j, so every gradient / EM sum it owns is produced locally (the
+// "wavefront pair-diff kernel").  Of the ordered pairs (i,j) and (j,i) at most one is valid (c_i > c_j or c_j > c_i): ONE
+// branch-free evaluation per unordered pair - e = exp(-|x|) gives both softplus(x) = max(x,0) + log1p(e) and sigmoid(x) -
+// with the reciprocals of t_plus / t_minus staged once.  A list is small (L^2 pairs) and there are only `batch` of them, so
+// the kernel is one wavefront's instruction stream long: PD_JW wavefronts share a list (each a slice of the j range; their
+// four partial sums per position are combined in fixed order through LDS).
+#define PD_JW 4  // wavefronts per list
+__global__ __launch_bounds__(LPW * PD_JW * 64) void pairdebias_kernel(const float* __restrict__ scores,
+                                                                     const float* __restrict__ labels,
+                                                                     const float* __restrict__ t_plus,
+                                                                     const float* __restrict__ t_minus, int B, int L,
+                                                                     float bscale, float* __restrict__ dscores,
+                                                                     float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tail = (int)ultr_tail_len(L);
   float* sm_tail = smem;               // [LPW][tail]
   float* sm_s = sm_tail + LPW * tail;  // [LPW][L]
   float* sm_c = sm_s + LPW * L;        // [LPW][L]
-  float* sm_tp = sm_c + LPW * L;       // [L]
-  float* sm_tm = sm_tp + L;            // [L]
+  float* sm_rtp = sm_c + LPW * L;      // [L] 1 / t_plus
+  float* sm_rtm = sm_rtp + L;          // [L] 1 / t_minus
+  float* sm_acc = sm_rtm + L;          // [LPW][PD_JW][L][4]: g, t_plus_loss, t_minus_loss, loss per (slice, position)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.x * LPW + wave;
-  float* ms = sm_s + wave * L;
-  float* mc = sm_c + wave * L;
-  float* mt = sm_tail + wave * tail;
+  const int lw = wave / PD_JW, jw = wave - lw * PD_JW;   // list of the workgroup, slice of the j range
+  const int b = blockIdx.x * LPW + lw;
+  float* ms = sm_s + lw * L;
+  float* mc = sm_c + lw * L;
+  float* mt = sm_tail + lw * tail;
   for (int t = threadIdx.x; t < L; t += blockDim.x) {
-    sm_tp[t] = t_plus[t];
-    sm_tm[t] = t_minus[t];
+    sm_rtp[t] = 1.0f / t_plus[t];
+    sm_rtm[t] = 1.0f / t_minus[t];
   }
-  for (int t = lane; t < tail; t += 64) mt[t] = 0.f;
-  if (b < B)
-    for (int l = lane; l < L; l += 64) {
-      ms[l] = scores[(int64_t)b * L + l];
-      mc[l] = labels[(int64_t)l * B + b];
-    }
+  if (jw == 0) {
+    for (int t = lane; t < tail; t += 64) mt[t] = 0.f;
+    if (b < B)
+      for (int l = lane; l < L; l += 64) {
+        ms[l] = scores[(int64_t)b * L + l];
+        mc[l] = labels[(int64_t)l * B + b];
+      }
+  }
   __syncthreads();
+  const int jlen = (L + PD_JW - 1) / PD_JW, j0 = jw * jlen, j1 = (j0 + jlen < L) ? j0 + jlen : L;
   if (b < B) {
+    for (int i = lane; i < L; i += 64) {
+      const float si = ms[i], ci = mc[i], rtpi = sm_rtp[i], rtmi = sm_rtm[i];
+      float g = 0.f, tpl = 0.f, tml = 0.f, li = 0.f;
+      for (int j = j0; j < j1; ++j) {
+        const float dc = ci - mc[j];                 // > 0: (i, j) is the valid pair; < 0: (j, i); 0 (incl. j == i): neither
+        const bool fwd = dc > 0.f;
+        const float m = fminf(1.0f, fabsf(dc));      // valid_pair_mask value
+        const float x = fwd ? ms[j] - si : si - ms[j];   // s_neg - s_pos of the valid ordered pair
+        const float e = __expf(-fabsf(x));
+        const float r = 1.0f / (1.0f + e);
+        const float sp = fmaxf(x, 0.f) + log1pf(e);      // softplus(x)
+        const float sg = (x >= 0.f) ? r : e * r;         // sigmoid(x)
+        const float pl = bscale * m * sp;                // PL contribution of this list (x B)
+        const float gw = bscale * m * sg;
+        const float rj = fwd ? sm_rtm[j] : sm_rtp[j];    // 1 / t_minus[j]  or  1 / t_plus[j]
+        // (i, j): t_plus_loss[i] += PL_ij / t-_j; loss += PL_ij / t+_i / t-_j; d/ds_i = -gw / t+_i / t-_j
+        // (j, i): t_minus_loss[i] += PL_ji / t+_j;                              d/ds_i = +gw / t+_j / t-_i
+        const float plr = pl * rj;
+        tpl += fwd ? plr : 0.f;
+        tml += fwd ? 0.f : plr;
+        li += fwd ? plr * rtpi : 0.f;
+        g += fwd ? -(gw * rj * rtpi) : gw * rj * rtmi;
+      }
+      float* a = sm_acc + ((size_t)(lw * PD_JW + jw) * L + i) * 4;
+      a[0] = g; a[1] = tpl; a[2] = tml; a[3] = li;
+    }
+  }
+  __syncthreads();
+  if (b < B && jw == 0) {
     float lsum = 0.f;
     for (int i = lane; i < L; i += 64) {
-      const float si = ms[i], ci = mc[i], tpi = sm_tp[i], tmi = sm_tm[i];
-      float g = 0.f, tpl = 0.f, tml = 0.f, li = 0.f;
-      for (int j = 0; j < L; ++j) {
-        if (j == i) continue;
-        const float sj = ms[j], cj = mc[j];
-        const float mij = fminf(1.0f, fmaxf(ci - cj, 0.f));  // valid_pair_mask for (i, j)
-        const float mji = fminf(1.0f, fmaxf(cj - ci, 0.f));  // and for (j, i)
-        if (mij > 0.f) {
-          const float x = sj - si;
-          const float pl = bscale * mij * softplus_pair(x);  // PL_ij contribution of this list (x B)
-          tpl += pl / sm_tm[j];                              // t_plus_loss[i]  += PL_ij / t_minus[j]
-          li += pl / tpi / sm_tm[j];                         // loss           += PL_ij / t_plus[i] / t_minus[j]
-          g -= bscale * mij * sigmoidf_(x) / tpi / sm_tm[j]; // d/ds_i
-        }
-        if (mji > 0.f) {
-          const float x = si - sj;
-          const float pl = bscale * mji * softplus_pair(x);  // PL_ji
-          tml += pl / sm_tp[j];                              // t_minus_loss[i] += PL_ji / t_plus[j]
-          g += bscale * mji * sigmoidf_(x) / sm_tp[j] / tmi; // d PL_ji / ds_i (i is the "negative" doc)
-        }
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float t = sm_acc[((size_t)(lw * PD_JW + 0) * L + i) * 4 + k];
+#pragma unroll
+        for (int w = 1; w < PD_JW; ++w) t += sm_acc[((size_t)(lw * PD_JW + w) * L + i) * 4 + k];
+        v[k] = t;
       }
-      dscores[(int64_t)b * L + i] = g;
-      mt[ULTR_TAIL_FIXED + i] = tpl;
-      mt[ULTR_TAIL_FIXED + L + i] = tml;
-      lsum += li;
+      dscores[(int64_t)b * L + i] = v[0];
+      mt[ULTR_TAIL_FIXED + i] = v[1];
+      mt[ULTR_TAIL_FIXED + L + i] = v[2];
+      lsum += v[3];
     }
     lsum = wave_sum(lsum);
     if (lane == 0) {
@@ -353,10 +379,13 @@ extern "C" int ultr_pairdebias_loss(const float* scores, const float* labels, co
   if (!scores || !labels || !t_plus || !t_minus || !dscores || !loss_ws || batch <= 0 || list_size <= 0 || batch_total <= 0)
     return ULTR_E_BADARG;
   const int tail = (int)ultr_tail_len(list_size);
-  const size_t lds = ((size_t)LPW * (tail + 2 * list_size) + 2 * list_size) * sizeof(float);
-  if (lds > 64 * 1024) return ULTR_E_UNSUPPORTED;
+  const size_t lds = ((size_t)LPW * (tail + 2 * list_size) + 2 * list_size + (size_t)LPW * PD_JW * list_size * 4) * sizeof(float);
+  if (lds > 160 * 1024) return ULTR_E_UNSUPPORTED;
+  if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(pairdebias_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return ULTR_E_UNSUPPORTED;
   UltrProfScope prof(ULTR_K_LOSS, (hipStream_t)stream);
-  ULTR_LAUNCH(prof, pairdebias_kernel, dim3((unsigned)ultr_loss_parts(batch)), dim3(LPW * 64), lds, (hipStream_t)stream,
+  ULTR_LAUNCH(prof, pairdebias_kernel, dim3((unsigned)ultr_loss_parts(batch)), dim3(LPW * PD_JW * 64), lds, (hipStream_t)stream,
                      scores, labels, t_plus, t_minus, (int)batch, (int)list_size, (float)batch_total, dscores,
                      (float*)loss_ws);
   return (int)hipGetLastError();
