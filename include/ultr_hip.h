@@ -70,6 +70,9 @@ int64_t ultr_dnn_bwd_workspace_bytes(const ultr_dnn_desc* d, int64_t n_rows);
 int64_t ultr_step_tail_floats(int32_t list_size);
 /* bytes of `loss_ws` for B lists of size L */
 int64_t ultr_loss_workspace_bytes(int64_t batch, int32_t list_size);
+/* step-tail partials the stand-alone ultr_*_loss kernels leave in `loss_ws` (one per workgroup) = the n_loss_parts of
+ * ultr_setrank_backward */
+int64_t ultr_loss_part_count(int64_t batch);
 
 /* ---- a2 + a3: gather + DNN forward --------------------------------------------------
  * Replaces BaseAlgorithm.get_ranking_scores + ranking_model (base_algorithm.py:118-154)

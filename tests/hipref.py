@@ -56,7 +56,7 @@ class HipRun:
         self.eng.loss(self.labels, aux=self.aux, ipw_table=self.ipw, pw=self.pw, **kw)
         torch.cuda.synchronize()
         tail = self.eng.tail
-        parts = self.eng.loss_ws[: ((self.B + 3) // 4) * tail].view(-1, tail).cpu().numpy()
+        parts = self.eng.loss_ws[: self.hip_ops.loss_part_count(self.B) * tail].view(-1, tail).cpu().numpy()
         return self.eng.dscores.cpu().numpy(), parts.sum(0)
 
     def backward(self, dscores=None):

@@ -50,6 +50,7 @@ SIGNATURES = {
     "ultr_dnn_bwd_workspace_bytes": (c_i64, [ctypes.POINTER(DnnDesc), c_i64]),
     "ultr_step_tail_floats": (c_i64, [c_i32]),
     "ultr_loss_workspace_bytes": (c_i64, [c_i64, c_i32]),
+    "ultr_loss_part_count": (c_i64, [c_i64]),
     "ultr_dnn_forward": (c_i32, [ctypes.POINTER(DnnDesc), c_vp, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "ultr_dnn_wt_floats": (c_i64, [ctypes.POINTER(DnnDesc)]),
     "ultr_dnn_build_wt": (c_i32, [ctypes.POINTER(DnnDesc), c_vp, c_vp, c_vp]),

@@ -2,7 +2,7 @@
 //
 // One 64-lane wavefront owns one ranked list: its scores / labels are staged in LDS, list-level
 // reductions (softmax max/sum, pair sums, rank-by-counting sort) are wavefront shuffles — no atomics, no
-// cross-workgroup traffic.  A workgroup = 4 wavefronts = 4 lists and emits ONE partial "step tail"
+// cross-workgroup traffic.  A workgroup owns LPW lists (currently one) and emits ONE partial "step tail"
 // [loss_sum, D, loss2_sum, D2, per-position sums (2L)] that the gradient reduction adds up in fixed order,
 // so every step is bit-reproducible.  The global normalisers (D) are NOT applied here: the kernels emit
 // d(loss)/d(scores) x D, the update kernel applies 1/D — this is what makes the data-parallel all-reduce
@@ -17,9 +17,11 @@
 
 #define LPW ULTR_LOSS_LISTS_PER_WG  // lists (= waves) per workgroup
 
+extern "C" int64_t ultr_loss_part_count(int64_t batch) { return batch > 0 ? ultr_loss_parts(batch) : 0; }
+
 extern "C" int64_t ultr_loss_workspace_bytes(int64_t batch, int32_t list_size) {
   if (batch <= 0 || list_size <= 0) return 0;
-  // one tail partial per 4 lists (stand-alone loss kernels) or per 16-row block (loss fused into the backward)
+  // one tail partial per workgroup of the stand-alone loss kernels or per 16-row block (loss fused into the backward)
   // or per workgroup of the fused forward+backward kernel (at most one per list)
   int64_t parts_fused = (batch * (int64_t)list_size + 15) / 16;
   if (batch > parts_fused) parts_fused = batch;
@@ -38,10 +40,6 @@ __device__ __forceinline__ void store_wg_tail(const float* sm_tail /*[LPW][tail]
   }
 }
 
-__device__ __forceinline__ float softplus_pair(float x) {
-  // log(1 + exp(x)) = -log_softmax([s_i, s_j])[0] with x = s_j - s_i   (base_algorithm.py:228-248)
-  return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
-}
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // ------------------------------------------------------------------------------------------------
@@ -397,50 +395,62 @@ extern "C" int ultr_pairdebias_loss(const float* scores, const float* labels, co
 // Sort = rank by counting inside the wavefront (stable: ties broken by original index), L^2 compares from
 // LDS; the same trick orders the labels for the ideal DCG.  Then the pair walk of PairDebias on the SORTED
 // list, with delta-NDCG weights and the reference's BCE-with-logits-on-a-probability quirk.
-__device__ __forceinline__ float bce_logits(float x, float t) {
-  // torch.nn.BCEWithLogitsLoss: (1 - t) * x + log(1 + exp(-x)), stable form
-  return fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
-}
 
-__global__ __launch_bounds__(LPW * 64) void lambdarank_kernel(const float* __restrict__ scores,
-                                                             const float* __restrict__ labels,
-                                                             const float* __restrict__ t_plus,
-                                                             const float* __restrict__ t_minus, float sigma, int B,
-                                                             int L, float* __restrict__ dscores,
-                                                             float* __restrict__ part) {
+// PD_JW wavefronts share a list: wave 0 of the list sorts (rank by counting), then every wave walks a slice of the
+// partner positions c for all positions r; the four partial sums per position are combined in fixed order through
+// LDS.  Per pair ONE exp gives both probabilities without cancellation - with ez = exp(-|z|), z = sigma (s_r - s_c):
+// sigmoid(|z|) = 1 / (1 + ez), sigmoid(-|z|) = ez / (1 + ez) - and one more exp per probability gives both its
+// BCE-with-logits value and its derivative (sigmoid(x) - target).  Discounts and reciprocals are staged per position.
+__global__ __launch_bounds__(LPW * PD_JW * 64) void lambdarank_kernel(const float* __restrict__ scores,
+                                                                     const float* __restrict__ labels,
+                                                                     const float* __restrict__ t_plus,
+                                                                     const float* __restrict__ t_minus, float sigma, int B,
+                                                                     int L, float* __restrict__ dscores,
+                                                                     float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tail = (int)ultr_tail_len(L);
   float* sm_tail = smem;                // [LPW][tail]
-  float* sm_s = sm_tail + LPW * tail;   // [LPW][L] raw scores
+  float* sm_s = sm_tail + LPW * tail;   // [LPW][L] raw scores, later d(loss)/d(sorted score)
   float* sm_y = sm_s + LPW * L;         // [LPW][L] raw labels
   float* sm_ps = sm_y + LPW * L;        // [LPW][L] scores sorted desc
   float* sm_ls = sm_ps + LPW * L;       // [LPW][L] labels in score order
   float* sm_g = sm_ls + LPW * L;        // [LPW][L] gains 2^l - 1 in score order
-  float* sm_tp = sm_g + LPW * L;        // [L]
-  float* sm_tm = sm_tp + L;             // [L]
-  int* sm_pos = reinterpret_cast<int*>(sm_tm + L);  // [LPW][L] sorted position of original index
+  float* sm_tp = sm_g + LPW * L;        // [L] t_plus
+  float* sm_tm = sm_tp + L;             // [L] t_minus
+  float* sm_rtp = sm_tm + L;            // [L] 1 / t_plus
+  float* sm_rtm = sm_rtp + L;           // [L] 1 / t_minus
+  float* sm_d = sm_rtm + L;             // [L] discount 1 / log2(rank + 2)
+  int* sm_pos = reinterpret_cast<int*>(sm_d + L);             // [LPW][L] sorted position of original index
+  float* sm_acc = reinterpret_cast<float*>(sm_pos + LPW * L); // [LPW][PD_JW][L][4]: g, t_plus_loss, t_minus_loss, loss
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.x * LPW + wave;
-  float* ms = sm_s + wave * L;
-  float* my = sm_y + wave * L;
-  float* ps = sm_ps + wave * L;
-  float* ls = sm_ls + wave * L;
-  float* gs = sm_g + wave * L;
-  int* pos = sm_pos + wave * L;
-  float* mt = sm_tail + wave * tail;
+  const int lw = wave / PD_JW, jw = wave - lw * PD_JW;
+  const int b = blockIdx.x * LPW + lw;
+  float* ms = sm_s + lw * L;
+  float* my = sm_y + lw * L;
+  float* ps = sm_ps + lw * L;
+  float* ls = sm_ls + lw * L;
+  float* gs = sm_g + lw * L;
+  int* pos = sm_pos + lw * L;
+  float* mt = sm_tail + lw * tail;
   for (int t = threadIdx.x; t < L; t += blockDim.x) {
-    sm_tp[t] = t_plus[t];
-    sm_tm[t] = t_minus[t];
+    const float tp = t_plus[t], tm = t_minus[t];
+    sm_tp[t] = tp;
+    sm_tm[t] = tm;
+    sm_rtp[t] = 1.0f / tp;
+    sm_rtm[t] = 1.0f / tm;
+    sm_d[t] = 1.0f / log2f((float)t + 2.0f);
   }
-  for (int t = lane; t < tail; t += 64) mt[t] = 0.f;
-  if (b < B)
-    for (int l = lane; l < L; l += 64) {
-      ms[l] = scores[(int64_t)b * L + l];
-      my[l] = labels[(int64_t)l * B + b];
-    }
+  if (jw == 0) {
+    for (int t = lane; t < tail; t += 64) mt[t] = 0.f;
+    if (b < B)
+      for (int l = lane; l < L; l += 64) {
+        ms[l] = scores[(int64_t)b * L + l];
+        my[l] = labels[(int64_t)l * B + b];
+      }
+  }
   __syncthreads();
-  if (b < B) {
-    float idcg = 0.f;
+  float idcg = 0.f;
+  if (b < B && jw == 0) {
     for (int i = lane; i < L; i += 64) {
       const float si = ms[i], yi = my[i];
       int rs = 0, ry = 0;
@@ -457,39 +467,59 @@ __global__ __launch_bounds__(LPW * 64) void lambdarank_kernel(const float* __res
       idcg += (exp2f(yi) - 1.0f) / logf((float)ry + 2.0f);
     }
     idcg = wave_sum(idcg);
-  // make the sorted arrays visible to the whole wave (LDS writes by other lanes of the same wave)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+  __syncthreads();  // the sorted arrays are visible to the list's other waves
+  const int clen = (L + PD_JW - 1) / PD_JW, c0 = jw * clen, c1 = (c0 + clen < L) ? c0 + clen : L;
+  if (b < B) {
+    for (int r = lane; r < L; r += 64) {
+      const float sr = ps[r], lr_ = ls[r], gr = gs[r], tpr = sm_tp[r], tmr = sm_tm[r], rtpr = sm_rtp[r], rtmr = sm_rtm[r];
+      const float dr = sm_d[r];
+      float g = 0.f, tpl = 0.f, tml = 0.f, li = 0.f;
+      for (int c = c0; c < c1; ++c) {
+        const float delta = fabsf(gr - gs[c]) * fabsf(dr - sm_d[c]);        // x 1/IDCG applied later
+        const float S = fminf(1.0f, fmaxf(lr_ - ls[c], -1.0f));
+        const float pb_rc = 0.5f * (1.0f + S), pb_cr = 0.5f * (1.0f - S);
+        const float z = sigma * (sr - ps[c]);
+        const float ez = __expf(-fabsf(z));
+        const float r0 = 1.0f / (1.0f + ez);
+        const float xhi = r0, xlo = ez * r0;                                // sigmoid(|z|), sigmoid(-|z|)
+        const float x_rc = (z >= 0.f) ? xhi : xlo, x_cr = (z >= 0.f) ? xlo : xhi;
+        // BCEWithLogits on a probability x in (0, 1): x - x t + log1p(exp(-x)); derivative sigmoid(x) - t
+        const float e1 = __expf(-x_rc), e2 = __expf(-x_cr);
+        const float l_rc = delta * (x_rc - x_rc * pb_rc + log1pf(e1));      // PL[r, c] contribution
+        const float l_cr = delta * (x_cr - x_cr * pb_cr + log1pf(e2));      // PL[c, r]
+        const float rtmc = sm_rtm[c], rtpc = sm_rtp[c];
+        const bool ok_rc = (tpr * sm_tm[c]) != 0.f, ok_cr = (sm_tp[c] * tmr) != 0.f;   // _safe_div
+        tpl += l_rc * rtmc;   // t_plus_loss[r]  = sum_c PL[r,c] / t_minus[c]
+        tml += l_cr * rtpc;   // t_minus_loss[r] = sum_c PL[c,r] / t_plus[c]
+        li += ok_rc ? l_rc * rtpr * rtmc : 0.f;
+        // d PL[r,c]/d s_r  and  d PL[c,r]/d s_r  (x = sigmoid(+-z): dx/ds_r = +-sigma x (1 - x), x (1 - x) = xhi xlo)
+        const float xx = sigma * xhi * xlo;
+        const float d_rc = delta * (1.0f / (1.0f + e1) - pb_rc) * xx;
+        const float d_cr = delta * (1.0f / (1.0f + e2) - pb_cr) * xx;
+        g += ok_rc ? d_rc * rtpr * rtmc : 0.f;
+        g -= ok_cr ? d_cr * rtpc * rtmr : 0.f;
+      }
+      float* a = sm_acc + ((size_t)(lw * PD_JW + jw) * L + r) * 4;
+      a[0] = g; a[1] = tpl; a[2] = tml; a[3] = li;
+    }
+  }
+  __syncthreads();
+  if (b < B && jw == 0) {
     float lsum = 0.f;
     for (int r = lane; r < L; r += 64) {
-      const float sr = ps[r], lr_ = ls[r], gr = gs[r], tpr = sm_tp[r], tmr = sm_tm[r];
-      const float dr = 1.0f / log2f((float)r + 2.0f);
-      float g = 0.f, tpl = 0.f, tml = 0.f, li = 0.f;
-      for (int c = 0; c < L; ++c) {
-        const float sc = ps[c], lc = ls[c], gc = gs[c];
-        const float dc = 1.0f / log2f((float)c + 2.0f);
-        const float delta = fabsf(gr - gc) * fabsf(dr - dc);                // x 1/IDCG applied later
-        const float S = fminf(1.0f, fmaxf(lr_ - lc, -1.0f));
-        const float pb_rc = 0.5f * (1.0f + S), pb_cr = 0.5f * (1.0f - S);
-        const float x_rc = 1.0f / (expf(-sigma * (sr - sc)) + 1.0f);
-        const float x_cr = 1.0f / (expf(-sigma * (sc - sr)) + 1.0f);
-        const float l_rc = delta * bce_logits(x_rc, pb_rc);                 // PL[r, c] contribution
-        const float l_cr = delta * bce_logits(x_cr, pb_cr);                 // PL[c, r]
-        const float den_rc = tpr * sm_tm[c], den_cr = sm_tp[c] * tmr;
-        tpl += l_rc / sm_tm[c];   // t_plus_loss[r]  = sum_c PL[r,c] / t_minus[c]
-        tml += l_cr / sm_tp[c];   // t_minus_loss[r] = sum_c PL[c,r] / t_plus[c]
-        li += (den_rc == 0.f) ? 0.f : l_rc / den_rc;                        // _safe_div
-        // d PL[r,c]/d s_r  and  d PL[c,r]/d s_r  (x = sigmoid(sigma * diff); BCE'(x) = sigmoid(x) - target)
-        const float d_rc = delta * (sigmoidf_(x_rc) - pb_rc) * sigma * x_rc * (1.0f - x_rc);
-        const float d_cr = delta * (sigmoidf_(x_cr) - pb_cr) * sigma * x_cr * (1.0f - x_cr);
-        g += (den_rc == 0.f) ? 0.f : d_rc / den_rc;
-        g -= (den_cr == 0.f) ? 0.f : d_cr / den_cr;
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float t = sm_acc[((size_t)(lw * PD_JW + 0) * L + r) * 4 + k];
+#pragma unroll
+        for (int w = 1; w < PD_JW; ++w) t += sm_acc[((size_t)(lw * PD_JW + w) * L + r) * 4 + k];
+        v[k] = t;
       }
-      mt[ULTR_TAIL_FIXED + r] = tpl;
-      mt[ULTR_TAIL_FIXED + L + r] = tml;
-      ms[r] = g;  // raw scores are dead after the sort: reuse as d(loss)/d(sorted score r)
-      lsum += li;
+      mt[ULTR_TAIL_FIXED + r] = v[1];
+      mt[ULTR_TAIL_FIXED + L + r] = v[2];
+      ms[r] = v[0];  // raw scores are dead after the sort: reuse as d(loss)/d(sorted score r)
+      lsum += v[3];
     }
     lsum = wave_sum(lsum);
     if (lane == 0) {
@@ -499,7 +529,7 @@ __global__ __launch_bounds__(LPW * 64) void lambdarank_kernel(const float* __res
   }
   // ms[] (now gradients by sorted position) written by lane r, read by the lane owning the original index
   __syncthreads();
-  if (b < B)
+  if (b < B && jw == 0)
     for (int i = lane; i < L; i += 64) dscores[(int64_t)b * L + i] = ms[pos[i]];
   store_wg_tail(sm_tail, tail, part + (int64_t)blockIdx.x * tail);
 }
@@ -510,10 +540,13 @@ extern "C" int ultr_lambdarank_loss(const float* scores, const float* labels, co
   if (!scores || !labels || !t_plus || !t_minus || !dscores || !loss_ws || batch <= 0 || list_size <= 0)
     return ULTR_E_BADARG;
   const int tail = (int)ultr_tail_len(list_size);
-  const size_t lds = ((size_t)LPW * (tail + 6 * list_size) + 2 * list_size) * sizeof(float);
-  if (lds > 64 * 1024) return ULTR_E_UNSUPPORTED;
+  const size_t lds = ((size_t)LPW * (tail + 6 * list_size) + 5 * list_size + (size_t)LPW * PD_JW * list_size * 4) * sizeof(float);
+  if (lds > 160 * 1024) return ULTR_E_UNSUPPORTED;
+  if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(lambdarank_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return ULTR_E_UNSUPPORTED;
   UltrProfScope prof(ULTR_K_LOSS, (hipStream_t)stream);
-  ULTR_LAUNCH(prof, lambdarank_kernel, dim3((unsigned)ultr_loss_parts(batch)), dim3(LPW * 64), lds, (hipStream_t)stream,
+  ULTR_LAUNCH(prof, lambdarank_kernel, dim3((unsigned)ultr_loss_parts(batch)), dim3(LPW * PD_JW * 64), lds, (hipStream_t)stream,
                      scores, labels, t_plus, t_minus, sigma, (int)batch, (int)list_size, dscores, (float*)loss_ws);
   return (int)hipGetLastError();
 }

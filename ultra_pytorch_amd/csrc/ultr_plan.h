@@ -141,5 +141,5 @@ __host__ __device__ static inline int64_t ultr_tail_len(int L) { return ULTR_TAI
 __host__ __device__ static inline int64_t ultr_red_blocks(int64_t P, int tail) { return (P + tail + 63) / 64; }
 
 // loss workspace: [0] int n_partials (as float bits unused) ; partials [MAXPART][tail]
-#define ULTR_LOSS_LISTS_PER_WG 4
+#define ULTR_LOSS_LISTS_PER_WG 1  // one list per workgroup: a step has only `batch` lists, spread them over the CUs
 __host__ __device__ static inline int64_t ultr_loss_parts(int64_t B) { return (B + ULTR_LOSS_LISTS_PER_WG - 1) / ULTR_LOSS_LISTS_PER_WG; }

@@ -183,7 +183,7 @@ class SetRankStepEngine(StepEngine):
         return scores
 
     def backward(self, params, features, n_docs, docids):
-        hip_ops.setrank_backward(self.shape, params, self.B, self.L, self.saved, self.dscores, self.loss_ws, (self.B + 3) // 4,
+        hip_ops.setrank_backward(self.shape, params, self.B, self.L, self.saved, self.dscores, self.loss_ws, hip_ops.loss_part_count(self.B),
                                  self.sr_ws, self.grads)
         if self.pg is not None:
             torch.distributed.all_reduce(self.grads, group=self.pg)

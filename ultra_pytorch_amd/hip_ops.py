@@ -130,6 +130,11 @@ def loss_workspace_bytes(B, L):
     return int(_lib.load().ultr_loss_workspace_bytes(int(B), int(L)))
 
 
+def loss_part_count(B):
+    """Step-tail partials a stand-alone loss kernel writes for B lists."""
+    return int(_lib.load().ultr_loss_part_count(int(B)))
+
+
 class WeightCopy:
     """The k-major copy of the hidden Linear weights the fast forward reads (ultr_dnn_build_wt).  Rebuilt whenever
     torch reports an in-place modification of `params` (load_state_dict, .copy_, init); ultr_apply_update keeps it
