@@ -9,6 +9,10 @@ CONFIGS = {"cfg2 IPW F136 L10 B256 [256,256]": (136, [256, 256], 256, 10, "softm
            "cfg4 PairDebias F700 L50 B256 [512,256,128]": (700, [512, 256, 128], 256, 50, "pairdebias", 0.005),
            "cfg4 LambdaRank F700 L50 B256 [512,256,128]": (700, [512, 256, 128], 256, 50, "lambdarank", 0.05),
            "cfg2x4 IPW F136 L10 B1024 [256,256]": (136, [256, 256], 1024, 10, "softmax", 0.05)}
+if os.environ.get("ULTR_BENCH_BIG", "0") == "1":  # throughput end of the batch axis (saved activations: 0.5 GB at B = 65536)
+    CONFIGS = {"cfg2x32 IPW F136 L10 B8192 [256,256]": (136, [256, 256], 8192, 10, "softmax", 0.05),
+               "cfg2x256 IPW F136 L10 B65536 [256,256]": (136, [256, 256], 65536, 10, "softmax", 0.05),
+               "cfg3x16 DLA F136 L20 B8192 [512,256,128]": (136, [512, 256, 128], 8192, 20, "dla", 0.05)}
 dev = torch.device("cuda")
 for name, (F, hidden, B, L, algo, lr) in CONFIGS.items():
     shape = hip_ops.DnnShape(F, hidden, "elu")
