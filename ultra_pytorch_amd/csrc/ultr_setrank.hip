@@ -213,6 +213,51 @@ __global__ __launch_bounds__(SR_ROWS * 64) void sr_ln_fwd_kernel(const float* a,
   }
 }
 
+// the residual LayerNorms (W = d_model a multiple of 256, no gather): 16-byte accesses, NV float4 per lane
+template <int NV>
+__global__ __launch_bounds__(SR_ROWS * 64) void sr_ln_fwd_v4_kernel(const float* a, const float* b /* may alias y */,
+                                                                   const float* __restrict__ bias, int64_t T,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   float* __restrict__ sum_out, float* y,
+                                                                   float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  constexpr int W = NV * 256;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t n = (int64_t)blockIdx.x * SR_ROWS + wave;
+  if (n >= T) return;
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c = 4 * lane + 256 * k;
+    const float4 av = ld4(a + n * W + c);
+    float4 bv = ld4(b + n * W + c);
+    if (bias != nullptr) {
+      bv.x += bias[c]; bv.y += bias[c + 1]; bv.z += bias[c + 2]; bv.w += bias[c + 3];  // parameters: any float offset
+    }
+    v[k] = make_float4(av.x + bv.x, av.y + bv.y, av.z + bv.z, av.w + bv.w);
+    st4(sum_out + n * W + c, v[k]);
+    s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+  }
+  const float mean = wave_sum(s) / (float)W;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const float dx = v[k].x - mean, dy = v[k].y - mean, dz = v[k].z - mean, dw = v[k].w - mean;
+    q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)W + SR_EPS);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c = 4 * lane + 256 * k;
+    st4(y + n * W + c, make_float4((v[k].x - mean) * rstd * gamma[c] + beta[c], (v[k].y - mean) * rstd * gamma[c + 1] + beta[c + 1],
+                                   (v[k].z - mean) * rstd * gamma[c + 2] + beta[c + 2], (v[k].w - mean) * rstd * gamma[c + 3] + beta[c + 3]));
+  }
+  if (lane == 0) {
+    mean_out[n] = mean;
+    rstd_out[n] = rstd;
+  }
+}
+
 // LayerNorm backward per row: ds = rstd * (g - mean(g) - xh * mean(g * xh)), g = dy * gamma, xh = (s - mean) * rstd.
 // ds_out may be NULL (only the parameter gradients are wanted); accumulate: ds_out += instead of =.
 __global__ __launch_bounds__(SR_ROWS * 64) void sr_ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ s,
@@ -959,6 +1004,21 @@ int wgrad(const SrPlan& p, const float* dY, const float* X, float* dW, float* db
   return 0;
 }
 
+// residual LayerNorm forward: y = LN(a + (b + bias)); float4 kernel when the rows allow it
+void ln_residual_fwd(const float* a, const float* b, const float* bias, int64_t T, int W, const float* gamma, const float* beta,
+                     float* sum_out, float* y, float* mean_out, float* rstd_out, int batch, int L, hipStream_t st) {
+  const unsigned rblk = (unsigned)((T + SR_ROWS - 1) / SR_ROWS);
+  const bool v4 = (W == 256 || W == 512 || W == 768 || W == 1024) &&
+                  ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)sum_out | (uintptr_t)y) & 15) == 0);
+  if (v4 && W == 256) hipLaunchKernelGGL(sr_ln_fwd_v4_kernel<1>, dim3(rblk), dim3(SR_ROWS * 64), 0, st, a, b, bias, T, gamma, beta, sum_out, y, mean_out, rstd_out);
+  else if (v4 && W == 512) hipLaunchKernelGGL(sr_ln_fwd_v4_kernel<2>, dim3(rblk), dim3(SR_ROWS * 64), 0, st, a, b, bias, T, gamma, beta, sum_out, y, mean_out, rstd_out);
+  else if (v4 && W == 768) hipLaunchKernelGGL(sr_ln_fwd_v4_kernel<3>, dim3(rblk), dim3(SR_ROWS * 64), 0, st, a, b, bias, T, gamma, beta, sum_out, y, mean_out, rstd_out);
+  else if (v4) hipLaunchKernelGGL(sr_ln_fwd_v4_kernel<4>, dim3(rblk), dim3(SR_ROWS * 64), 0, st, a, b, bias, T, gamma, beta, sum_out, y, mean_out, rstd_out);
+  else
+    hipLaunchKernelGGL(sr_ln_fwd_kernel, dim3(rblk), dim3(SR_ROWS * 64), 0, st, a, b, bias, (const int32_t*)nullptr, (int64_t)0, batch, L, T, W,
+                       gamma, beta, sum_out, y, mean_out, rstd_out);
+}
+
 #define SR_CHECK(call)        \
   do {                        \
     const int rc_ = (call);   \
@@ -1094,15 +1154,13 @@ extern "C" int ultr_setrank_forward(const ultr_setrank_desc* c, const float* par
     else hipLaunchKernelGGL(sr_attn_fwd_kernel, dim3(batch, p.H), dim3(256), lds_att, st, x, L, d, p.dh, sv + p.sv_A[l]);
     // A Wd^T lands in out1's buffer, then out1 = LN1(x + (A Wd^T + bd)) in place (s1 keeps the pre-norm sum)
     SR_CHECK(gemm_xwT(sv + p.sv_A[l], params + y.wd, sv + p.sv_out1[l], T, d, d, 0.f));
-    hipLaunchKernelGGL(sr_ln_fwd_kernel, dim3(rblk), dim3(SR_ROWS * 64), 0, st, x, (const float*)(sv + p.sv_out1[l]), params + y.bd,
-                       (const int32_t*)nullptr, (int64_t)0, (int)batch, L, T, d, params + y.g1, params + y.b1, sv + p.sv_s1[l],
-                       sv + p.sv_out1[l], sv + p.sv_m1[l], sv + p.sv_r1[l]);
+    ln_residual_fwd(x, sv + p.sv_out1[l], params + y.bd, T, d, params + y.g1, params + y.b1, sv + p.sv_s1[l], sv + p.sv_out1[l],
+                    sv + p.sv_m1[l], sv + p.sv_r1[l], (int)batch, L, st);
     SR_CHECK(gemm_xwT(sv + p.sv_out1[l], params + y.wf1, sv + p.sv_f[l], T, d, dff, 0.f));
     bias_act(sv + p.sv_f[l], params + y.bf1, T, dff, 1, st);
     SR_CHECK(gemm_xwT(sv + p.sv_f[l], params + y.wf2, sv + p.sv_x[l + 1], T, dff, d, 0.f));
-    hipLaunchKernelGGL(sr_ln_fwd_kernel, dim3(rblk), dim3(SR_ROWS * 64), 0, st, (const float*)(sv + p.sv_out1[l]),
-                       (const float*)(sv + p.sv_x[l + 1]), params + y.bf2, (const int32_t*)nullptr, (int64_t)0, (int)batch, L, T, d, params + y.g2,
-                       params + y.b2, sv + p.sv_s2[l], sv + p.sv_x[l + 1], sv + p.sv_m2[l], sv + p.sv_r2[l]);
+    ln_residual_fwd(sv + p.sv_out1[l], sv + p.sv_x[l + 1], params + y.bf2, T, d, params + y.g2, params + y.b2, sv + p.sv_s2[l],
+                    sv + p.sv_x[l + 1], sv + p.sv_m2[l], sv + p.sv_r2[l], (int)batch, L, st);
   }
   // output FFN (SetRank.py:136, 153)
   SR_CHECK(gemm_xwT(sv + p.sv_x[p.nl], params + p.wo1, sv + p.sv_oh, T, d, dff, 0.f));
