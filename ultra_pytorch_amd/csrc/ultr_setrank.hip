@@ -348,6 +348,65 @@ __global__ __launch_bounds__(256) void sr_ln_bwd_cs_kernel(const float* __restri
     part[(int64_t)blockIdx.x * 3 * W + e] = ((smem[e] + smem[3 * W + e]) + smem[6 * W + e]) + smem[9 * W + e];
 }
 
+// the same with 16-byte accesses (W a multiple of 256): lane owns columns 4 lane .. 4 lane + 3 (+ 256 k)
+template <int NV>
+__global__ __launch_bounds__(256) void sr_ln_bwd_cs_v4_kernel(const float* __restrict__ dy, const float* __restrict__ s,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const float* __restrict__ gamma, int64_t T,
+                                                              float* __restrict__ ds_out, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [4 waves][3][W]
+  constexpr int W = NV * 256;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * SR_LB_ROWS;
+  const int64_t r1 = (r0 + SR_LB_ROWS < T) ? r0 + SR_LB_ROWS : T;
+  float4 gm[NV], ag[NV], ab[NV], ad[NV];
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c = 4 * lane + 256 * k;
+    gm[k] = make_float4(gamma[c], gamma[c + 1], gamma[c + 2], gamma[c + 3]);  // parameters: any float offset
+    ag[k] = ab[k] = ad[k] = z4;
+  }
+  const float invw = 1.0f / (float)W;
+  for (int64_t n = r0 + wave; n < r1; n += 4) {
+    const float m = mean[n], r = rstd[n];
+    float4 g[NV], xh[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = 4 * lane + 256 * k;
+      const float4 d = ld4(dy + n * W + c), sv = ld4(s + n * W + c);
+      xh[k] = make_float4((sv.x - m) * r, (sv.y - m) * r, (sv.z - m) * r, (sv.w - m) * r);
+      g[k] = make_float4(d.x * gm[k].x, d.y * gm[k].y, d.z * gm[k].z, d.w * gm[k].w);
+      s1 += (g[k].x + g[k].y) + (g[k].z + g[k].w);
+      s2 += (g[k].x * xh[k].x + g[k].y * xh[k].y) + (g[k].z * xh[k].z + g[k].w * xh[k].w);
+      ag[k].x += d.x * xh[k].x; ag[k].y += d.y * xh[k].y; ag[k].z += d.z * xh[k].z; ag[k].w += d.w * xh[k].w;
+      ab[k].x += d.x; ab[k].y += d.y; ab[k].z += d.z; ab[k].w += d.w;
+    }
+    s1 = wave_sum(s1) * invw;
+    s2 = wave_sum(s2) * invw;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = 4 * lane + 256 * k;
+      const float4 v = make_float4(r * (g[k].x - s1 - xh[k].x * s2), r * (g[k].y - s1 - xh[k].y * s2),
+                                   r * (g[k].z - s1 - xh[k].z * s2), r * (g[k].w - s1 - xh[k].w * s2));
+      st4(ds_out + n * W + c, v);
+      ad[k].x += v.x; ad[k].y += v.y; ad[k].z += v.z; ad[k].w += v.w;
+    }
+  }
+  float* mine = smem + (size_t)wave * 3 * W;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c = 4 * lane + 256 * k;
+    st4(mine + c, ag[k]);
+    st4(mine + W + c, ab[k]);
+    st4(mine + 2 * W + c, ad[k]);
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 3 * W; e += 256)
+    part[(int64_t)blockIdx.x * 3 * W + e] = ((smem[e] + smem[3 * W + e]) + smem[6 * W + e]) + smem[9 * W + e];
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // element-wise epilogues
 // ---------------------------------------------------------------------------------------------------------
@@ -1088,7 +1147,10 @@ int ln_bwd_cs(const SrPlan& p, const float* dy, const float* s, const float* mea
               float* dx, float* ws, float* dst_gb, float* dst_bias, hipStream_t st) {
   float* part = ws + p.ws_part;
   const size_t lds = (size_t)4 * 3 * W * sizeof(float);
-  if (W <= 256) hipLaunchKernelGGL(sr_ln_bwd_cs_kernel<4>, dim3(p.n_lb), dim3(256), lds, st, dy, s, mean, rstd, gamma, p.T, W, dx, part);
+  const bool v4 = (W == 256 || W == 512) && ((((uintptr_t)dy | (uintptr_t)s | (uintptr_t)dx) & 15) == 0);
+  if (v4 && W == 256) hipLaunchKernelGGL(sr_ln_bwd_cs_v4_kernel<1>, dim3(p.n_lb), dim3(256), lds, st, dy, s, mean, rstd, gamma, p.T, dx, part);
+  else if (v4) hipLaunchKernelGGL(sr_ln_bwd_cs_v4_kernel<2>, dim3(p.n_lb), dim3(256), lds, st, dy, s, mean, rstd, gamma, p.T, dx, part);
+  else if (W <= 256) hipLaunchKernelGGL(sr_ln_bwd_cs_kernel<4>, dim3(p.n_lb), dim3(256), lds, st, dy, s, mean, rstd, gamma, p.T, W, dx, part);
   else hipLaunchKernelGGL(sr_ln_bwd_cs_kernel<16>, dim3(p.n_lb), dim3(256), lds, st, dy, s, mean, rstd, gamma, p.T, W, dx, part);
   fold(part, (int64_t)3 * W, p.n_lb, 2 * W, dst_gb, st);
   fold(part + 2 * W, (int64_t)3 * W, p.n_lb, W, dst_bias, st);
