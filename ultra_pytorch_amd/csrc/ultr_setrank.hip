@@ -213,6 +213,55 @@ __global__ __launch_bounds__(SR_ROWS * 64) void sr_ln_fwd_kernel(const float* a,
   }
 }
 
+// the input LayerNorm on gathered feature rows with 16-byte accesses (W % 4 == 0, W <= 1024): lane owns the float4
+// chunks lane, lane + 64, ... of the row; stores the gathered row (for the backward) and the normalised row
+__global__ __launch_bounds__(SR_ROWS * 64) void sr_ln_gather_v4_kernel(const float* __restrict__ feats, const int32_t* __restrict__ docids,
+                                                                      int64_t n_docs, int B, int L, int64_t T, int W,
+                                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                      float* __restrict__ sum_out, float* __restrict__ y,
+                                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t n = (int64_t)blockIdx.x * SR_ROWS + wave;
+  if (n >= T) return;
+  const int bb = (int)(n / L), ll = (int)(n % L);
+  const int id = docids[(int64_t)ll * B + bb];
+  const float* ra = (id >= 0 && id < n_docs) ? feats + (int64_t)id * W : nullptr;  // PAD -> zero row
+  const int nq = W / 4;
+  float4 v[4];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int qd = lane + 64 * k;
+    v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (qd < nq) {
+      if (ra != nullptr) v[k] = ld4(ra + 4 * qd);
+      st4(sum_out + n * W + 4 * qd, v[k]);
+    }
+    s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+  }
+  const float mean = wave_sum(s) / (float)W;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (lane + 64 * k < nq) {
+      const float dx = v[k].x - mean, dy = v[k].y - mean, dz = v[k].z - mean, dw = v[k].w - mean;
+      q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)W + SR_EPS);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int qd = lane + 64 * k, c = 4 * qd;
+    if (qd < nq)
+      st4(y + n * W + c, make_float4((v[k].x - mean) * rstd * gamma[c] + beta[c], (v[k].y - mean) * rstd * gamma[c + 1] + beta[c + 1],
+                                     (v[k].z - mean) * rstd * gamma[c + 2] + beta[c + 2], (v[k].w - mean) * rstd * gamma[c + 3] + beta[c + 3]));
+  }
+  if (lane == 0) {
+    mean_out[n] = mean;
+    rstd_out[n] = rstd;
+  }
+}
+
 // the residual LayerNorms (W = d_model a multiple of 256, no gather): 16-byte accesses, NV float4 per lane
 template <int NV>
 __global__ __launch_bounds__(SR_ROWS * 64) void sr_ln_fwd_v4_kernel(const float* a, const float* b /* may alias y */,
@@ -417,6 +466,25 @@ __global__ __launch_bounds__(256) void sr_bias_act_kernel(float* __restrict__ y,
   float v = y[e] + bias[e % W];
   if (relu) v = fmaxf(v, 0.f);
   y[e] = v;
+}
+// 16-byte variants (W % 4 == 0: a float4 never straddles a row; tensors 16-byte aligned; the bias at any float offset)
+__global__ __launch_bounds__(256) void sr_bias_act_v4_kernel(float* __restrict__ y, const float* __restrict__ bias, int64_t n4, int W,
+                                                             int relu) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n4) return;
+  const int c = (int)((e * 4) % W);
+  float4 v = ld4(y + e * 4);
+  v.x += bias[c]; v.y += bias[c + 1]; v.z += bias[c + 2]; v.w += bias[c + 3];
+  if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+  st4(y + e * 4, v);
+}
+__global__ __launch_bounds__(256) void sr_relu_mask_v4_kernel(float* __restrict__ dy, const float* __restrict__ act, int64_t n4) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n4) return;
+  const float4 a = ld4(act + e * 4);
+  float4 v = ld4(dy + e * 4);
+  v.x = (a.x > 0.f) ? v.x : 0.f; v.y = (a.y > 0.f) ? v.y : 0.f; v.z = (a.z > 0.f) ? v.z : 0.f; v.w = (a.w > 0.f) ? v.w : 0.f;
+  st4(dy + e * 4, v);
 }
 // dy *= (act > 0)
 __global__ __launch_bounds__(256) void sr_relu_mask_kernel(float* __restrict__ dy, const float* __restrict__ act, int64_t n) {
@@ -1128,10 +1196,16 @@ int attn_bwd_mfma(const SrPlan& p, const float* x, const float* dA, const float*
 
 void bias_act(float* y, const float* bias, int64_t T, int W, int relu, hipStream_t st) {
   const int64_t n = T * W;
-  hipLaunchKernelGGL(sr_bias_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, bias, T, W, relu);
+  if (W % 4 == 0 && ((uintptr_t)y & 15) == 0)
+    hipLaunchKernelGGL(sr_bias_act_v4_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, y, bias, n / 4, W, relu);
+  else
+    hipLaunchKernelGGL(sr_bias_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, bias, T, W, relu);
 }
 void relu_mask(float* dy, const float* act, int64_t n, hipStream_t st) {
-  hipLaunchKernelGGL(sr_relu_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dy, act, n);
+  if (n % 4 == 0 && ((((uintptr_t)dy | (uintptr_t)act) & 15) == 0))
+    hipLaunchKernelGGL(sr_relu_mask_v4_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, dy, act, n / 4);
+  else
+    hipLaunchKernelGGL(sr_relu_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dy, act, n);
 }
 // dst[0..W) = column sums of a (mode 0) or of a o xhat (mode 1)
 void colsum(const SrPlan& p, const float* a, const float* s, const float* mean, const float* rstd, int W, int mode, float* ws,
@@ -1195,9 +1269,13 @@ extern "C" int ultr_setrank_forward(const ultr_setrank_desc* c, const float* par
   const unsigned rblk = (unsigned)((T + SR_ROWS - 1) / SR_ROWS);
   const int F = p.F, d = p.d, dff = p.dff;
   // input LayerNorm on the gathered rows, then the embedding FFN (SetRank.py:134-135, 146)
-  hipLaunchKernelGGL(sr_ln_fwd_kernel, dim3(rblk), dim3(SR_ROWS * 64), 0, st, features, (const float*)nullptr, (const float*)nullptr, docids, n_docs,
-                     (int)batch, L, T, F, params + p.g_in, params + p.b_in, sv + p.sv_xg, sv + p.sv_xn0, sv + p.sv_mean_in,
-                     sv + p.sv_rstd_in);
+  if (F % 4 == 0 && F <= 1024 && ((uintptr_t)features & 15) == 0)
+    hipLaunchKernelGGL(sr_ln_gather_v4_kernel, dim3(rblk), dim3(SR_ROWS * 64), 0, st, features, docids, n_docs, (int)batch, L, T, F,
+                       params + p.g_in, params + p.b_in, sv + p.sv_xg, sv + p.sv_xn0, sv + p.sv_mean_in, sv + p.sv_rstd_in);
+  else
+    hipLaunchKernelGGL(sr_ln_fwd_kernel, dim3(rblk), dim3(SR_ROWS * 64), 0, st, features, (const float*)nullptr, (const float*)nullptr, docids, n_docs,
+                       (int)batch, L, T, F, params + p.g_in, params + p.b_in, sv + p.sv_xg, sv + p.sv_xn0, sv + p.sv_mean_in,
+                       sv + p.sv_rstd_in);
   SR_CHECK(gemm_xwT(sv + p.sv_xn0, params + p.w1, sv + p.sv_h0, T, F, dff, 0.f));
   bias_act(sv + p.sv_h0, params + p.b1, T, dff, 1, st);
   SR_CHECK(gemm_xwT(sv + p.sv_h0, params + p.w2, sv + p.sv_x[0], T, dff, d, 0.f));
