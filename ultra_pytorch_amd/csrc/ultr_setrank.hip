@@ -529,6 +529,44 @@ __global__ __launch_bounds__(256) void sr_colsum_ln_kernel(const float* __restri
     part[(int64_t)blockIdx.x * 2 * W + W + c] = ab;
   }
 }
+// the same with 16-byte accesses (W % 4 == 0, W <= 1024): SR_LB_ROWS rows per workgroup, a wave every 4th row, a lane the
+// float4 chunks lane, lane + 64, ...; the four waves' partials are folded in fixed order through LDS
+__global__ __launch_bounds__(256) void sr_colsum_ln_v4_kernel(const float* __restrict__ dy, const float* __restrict__ s,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              int64_t T, int W, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [4 waves][2][W]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * SR_LB_ROWS;
+  const int64_t r1 = (r0 + SR_LB_ROWS < T) ? r0 + SR_LB_ROWS : T;
+  const int nq = W / 4;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 ag[4] = {z4, z4, z4, z4}, ab[4] = {z4, z4, z4, z4};
+  for (int64_t n = r0 + wave; n < r1; n += 4) {
+    const float m = mean[n], r = rstd[n];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int qd = lane + 64 * k;
+      if (qd < nq) {
+        const float4 g = ld4(dy + n * W + 4 * qd), sv = ld4(s + n * W + 4 * qd);
+        ag[k].x += g.x * ((sv.x - m) * r); ag[k].y += g.y * ((sv.y - m) * r);
+        ag[k].z += g.z * ((sv.z - m) * r); ag[k].w += g.w * ((sv.w - m) * r);
+        ab[k].x += g.x; ab[k].y += g.y; ab[k].z += g.z; ab[k].w += g.w;
+      }
+    }
+  }
+  float* mine = smem + (size_t)wave * 2 * W;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int qd = lane + 64 * k;
+    if (qd < nq) {
+      st4(mine + 4 * qd, ag[k]);
+      st4(mine + W + 4 * qd, ab[k]);
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2 * W; e += 256)
+    part[(int64_t)blockIdx.x * 2 * W + e] = ((smem[e] + smem[2 * W + e]) + smem[4 * W + e]) + smem[6 * W + e];
+}
 // dst[c] = sum over nparts partials (canonical order)
 __global__ __launch_bounds__(256) void sr_fold_kernel(const float* __restrict__ part, int64_t stride, int nparts, int len,
                                                       float* __restrict__ dst) {
@@ -1233,6 +1271,11 @@ int ln_bwd_cs(const SrPlan& p, const float* dy, const float* s, const float* mea
 void colsum_ln(const SrPlan& p, const float* dy, const float* s, const float* mean, const float* rstd, int W, float* ws, float* dst,
                hipStream_t st) {
   float* part = ws + p.ws_part;
+  if (W % 4 == 0 && W <= 1024 && ((((uintptr_t)dy | (uintptr_t)s) & 15) == 0)) {
+    hipLaunchKernelGGL(sr_colsum_ln_v4_kernel, dim3(p.n_lb), dim3(256), (size_t)8 * W * sizeof(float), st, dy, s, mean, rstd, p.T, W, part);
+    fold(part, (int64_t)2 * W, p.n_lb, 2 * W, dst, st);
+    return;
+  }
   hipLaunchKernelGGL(sr_colsum_ln_kernel, dim3(p.n_cs), dim3(256), 0, st, dy, s, mean, rstd, p.T, W, part);
   fold(part, (int64_t)2 * W, p.n_cs, 2 * W, dst, st);
 }
