@@ -44,6 +44,7 @@ extern "C" {
 #define ULTR_E_BADARG (-1)
 #define ULTR_E_UNSUPPORTED (-2)
 #define ULTR_E_WORKSPACE (-3)
+#define ULTR_E_COMM_TIMEOUT (-4) /* a peer did not arrive within the bounded wait of ultr_comm_allreduce */
 
 enum ultr_activation { ULTR_ACT_ELU = 0, ULTR_ACT_RELU = 1 };
 
@@ -283,6 +284,34 @@ int ultr_click_batch(const int32_t* lists, const float* labels, int64_t n_querie
                      uint64_t step, int32_t batch, int32_t list_size, int32_t max_tries, int32_t* docids, float* clicks,
                      int32_t* query_idx, void* stream);
 
+/* ---- e: data-parallel gradient exchange over xGMI -----------------------------
+ * No reference counterpart: the reference is single-process.  One process per GPU; queries shard across ranks,
+ * parameters / optimizer / EM state are replicated, and ONE sum per step of the flat vector
+ * grads[P + tail] (what ultr_dnn_backward / ultr_train_step(skip_update) leave) makes every rank's update identical.
+ * ultr_comm_allreduce is that sum as ONE kernel: every rank publishes its vector into a fine-grained exchange
+ * buffer mapped by all peers (hipIpc handles), reads every peer's copy over xGMI, adds them in rank order (bitwise
+ * identical results on all ranks, deterministic) and leaves the sum-of-squares partials of the reduced gradient
+ * where ultr_apply_update expects them (so no ultr_grad_sumsq pass).  Waits are bounded; a timeout is reported by
+ * ultr_comm_status (ULTR_E_COMM_TIMEOUT) and the caller falls back to its collective library.
+ * The exchange buffer is the one allocation this library makes (it must be IPC-exportable fine-grained memory);
+ * handles are ULTR_COMM_HANDLE_BYTES opaque bytes the caller moves between processes (parallel.py: all_gather).
+ *   create(rank, world, n_floats)  n_floats >= P + tail; zeroed flags, device-synchronising
+ *   export(handle_out) / import(peer, handle)   once per peer, before the first all-reduce
+ *   allreduce(step, src, n, n_params, out, sumsq_ws, sumsq_parts, stream)   step = 0, 1, 2, ... in lockstep on all
+ *       ranks; src/out [n] local device vectors (may alias); sumsq_ws = head of bwd_ws, sumsq_parts =
+ *       ceil((P + tail) / 64) as for ultr_grad_sumsq.  world == 1 degenerates to copy + partials. */
+#define ULTR_COMM_MAX_WORLD 8
+#define ULTR_COMM_HANDLE_BYTES 64
+typedef struct ultr_comm ultr_comm;
+int ultr_comm_create(int32_t rank, int32_t world, int64_t n_floats, ultr_comm** out);
+int ultr_comm_export(ultr_comm* c, void* handle_out);
+int ultr_comm_import(ultr_comm* c, int32_t peer, const void* handle);
+int ultr_comm_allreduce(ultr_comm* c, uint64_t step, const float* src, int64_t n, int64_t n_params, float* out,
+                        void* sumsq_ws, int32_t sumsq_parts, void* stream);
+/* synchronises `stream`, then 0 or ULTR_E_COMM_TIMEOUT */
+int ultr_comm_status(ultr_comm* c, void* stream);
+int ultr_comm_destroy(ultr_comm* c);
+
 /* ---- measurement hooks (bench.py only; not part of the reference's interface) ----------
  * Per-kernel timers: an armed kernel is launched with a start and a stop event taken from its OWN dispatch
  * packet (hipExtLaunchKernelGGL), i.e. the duration rocprofv3 --kernel-trace reports, without marker packets
@@ -293,6 +322,10 @@ int ultr_click_batch(const int32_t* lists, const float* labels, int64_t n_querie
 int ultr_prof_enable(uint32_t kernel_mask, int32_t max_samples);
 int ultr_prof_set_stride(int32_t every_nth_launch);
 int ultr_prof_collect(double* total_ms, int64_t* counts);
+
+/* The ULTR_* tuning knobs (README.md) are read from the environment once, at first use; this re-reads them (tests and the
+ * A/B tools flip knobs inside one process). */
+int ultr_config_reload(void);
 
 #ifdef __cplusplus
 }

@@ -416,6 +416,12 @@ CASES = {
     "dla_odd": lambda u: run_train_case(u, "dla_odd", "dla", 13, 7, 9, [19, 6, 3], 2, 17, n_queries=32),
     "pairdebias_odd": lambda u: run_train_case(u, "pairdebias_odd", "pairdebias", 13, 7, 9, [19, 6, 3], 2, 18, n_queries=32),
     "lambdarank_odd": lambda u: run_train_case(u, "lambdarank_odd", "lambdarank", 13, 7, 9, [19, 6, 3], 2, 19, n_queries=32),
+    # DLA with logits_to_prob=sigmoid (dla.py:21-22: sigmoid(x - mean(x))) and non-default loss weight / propensity lr
+    "dla_sigmoid": lambda u: run_train_case(u, "dla_sigmoid", "dla", 136, 10, 8, [32, 16], 2, 25,
+                                            algo_hparams="logits_to_prob=sigmoid"),
+    "dla_sigmoid_odd": lambda u: run_train_case(u, "dla_sigmoid_odd", "dla", 13, 7, 9, [19, 6], 2, 26, n_queries=32,
+                                                algo_hparams="logits_to_prob=sigmoid,ranker_loss_weight=0.5,"
+                                                             "propensity_learning_rate=0.02"),
     # next row 8f.3: RegressionEM (uniforms of the Bernoulli draw recorded)
     "regem_tiny": lambda u: run_train_case(u, "regem_tiny", "regem", 136, 10, 8, [32, 16], 2, 23),
     "regem_odd": lambda u: run_train_case(u, "regem_odd", "regem", 13, 7, 9, [19, 6, 3], 2, 24, n_queries=32),

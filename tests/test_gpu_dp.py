@@ -1,0 +1,232 @@
+"""The PRODUCT data-parallel path at world size 2, on one GPU: two processes share cuda:0, each takes its
+shard of ONE global batch (parallel.shard_input_feed; uneven shards on purpose), runs StepEngine(process_group=...)
+.train_step - i.e. ultr_train_step(skip_update) -> the gradient exchange -> ultr_apply_update - and must end with the
+parameters / Adagrad state / EM state of the single-process step on the whole batch and of the oracle.
+
+Both exchange paths run: "peer" = ultr_comm_allreduce (hipIpc-mapped exchange buffers, one kernel; the two processes
+map each other's buffer exactly as two GPUs of a node would) and "pg" = the process group's all-reduce + ultr_grad_sumsq
+(gloo here, RCCL in bench.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F, HIDDEN, B, L = 24, [32, 16], 7, 6  # 7 lists -> shards of 4 and 3
+ALGOS = ["softmax", "pairdebias", "lambdarank", "dla", "regem"]
+
+
+def make_global(seed):
+    rng = np.random.RandomState(seed)
+    n_docs = B * L - 3
+    feats = rng.uniform(-1, 1, size=(n_docs, F)).astype(np.float32)
+    ids = rng.permutation(B * L)
+    ids = np.where(ids >= n_docs, n_docs, ids).reshape(L, B)  # three PAD documents
+    clicks = (rng.uniform(size=(L, B)) < 0.4).astype(np.float32)
+    # every list has a click; position 0 is clicked in some lists and not in others (PairDebias normalises its EM ratios by
+    # the position-0 sums: 0/0 = NaN when no pair involves position 0 on both sides - the reference does the same)
+    clicks[0, :] = np.arange(B) % 2
+    clicks[1, :] = 1.0 - clicks[0, :]
+    rel = rng.randint(0, 5, size=(L, B)).astype(np.float32)
+    names_d = ["docid_input%d" % l for l in range(L)]
+    names_l = ["label%d" % l for l in range(L)]
+    feed = {"letor_features": feats}
+    for l in range(L):
+        feed[names_d[l]] = ids[l].astype(np.float32)
+        feed[names_l[l]] = clicks[l]
+    return feed, names_d, names_l, rel
+
+
+def feed_arrays(feed, names_d, names_l, labels=None):
+    ids = np.stack([np.asarray(feed[n]) for n in names_d]).astype(np.int32)
+    y = np.stack([np.asarray(feed[n]) for n in names_l]).astype(np.float32) if labels is None else labels
+    return np.asarray(feed["letor_features"], np.float32), ids, y
+
+
+def initial_state(algo):
+    sys.path.insert(0, ROOT)
+    from oracle import ultr_oracle as O
+    params = O.init_params(F, HIDDEN, seed=5)
+    rng = np.random.RandomState(11)
+    state = None if algo == "dla" else (0.01 * rng.uniform(size=params.shape)).astype(np.float32)
+    if algo == "dla":
+        aux = (0.1 * rng.randn(L + 1)).astype(np.float32)
+    elif algo in ("pairdebias", "lambdarank"):
+        aux = np.linspace(0.9, 1.2, 2 * L).astype(np.float32)
+    elif algo == "regem":
+        aux = np.linspace(0.9, 0.3, L).astype(np.float32)
+    else:
+        aux = None
+    uniforms = rng.uniform(size=(B, L)).astype(np.float32)
+    return params, state, aux, uniforms
+
+
+def n_steps_of(algo):
+    # DLA's per-step optimizers make its update sign-like, p -= lr * g / (|g| + 1e-10) (dla.py:141-177): an element whose
+    # gradient is ~0 moves by +-lr depending on rounding, so DLA is compared after ONE step and only where |g| is not ~0
+    return 1 if algo == "dla" else 2
+
+
+def run_engine(algo, feats, ids, y, pg, uniforms):
+    """n_steps train steps of the product engine on (feats, ids, y); returns numpy post-state."""
+    import torch
+    from ultra_pytorch_amd import engine, hip_ops
+    dev = torch.device("cuda", 0)
+    params0, state0, aux0, _ = initial_state(algo)
+    shape = hip_ops.DnnShape(F, HIDDEN, "elu")
+    Bl = ids.shape[1]
+    eng = engine.StepEngine(shape, Bl, L, dev, algo=algo, learning_rate=0.005 if algo == "pairdebias" else 0.05,
+                            process_group=pg)
+    p = torch.tensor(params0, device=dev)
+    st = None if state0 is None else torch.tensor(state0, device=dev)
+    aux = None if aux0 is None else torch.tensor(aux0, device=dev)
+    ipw = torch.linspace(1.0, 3.0, 4, device=dev) if algo == "softmax" else None  # shorter than L: saturates
+    f = torch.tensor(feats, device=dev) if feats.shape[0] > 0 else None
+    i, yy = torch.tensor(ids, device=dev), torch.tensor(y, device=dev)
+    u = torch.tensor(uniforms, device=dev) if algo == "regem" else None
+    losses = []
+    for _ in range(n_steps_of(algo)):
+        sc = eng.train_step(p, st, f, feats.shape[0], i, yy, aux=aux, ipw_table=ipw, uniforms=u)
+        torch.cuda.synchronize()
+        losses.append(float(sc[0]))
+    status = 0 if eng.comm is None else eng.comm.status()
+    out = dict(params=p.cpu().numpy(), grads=eng.grads[:shape.n_params].cpu().numpy(), state=None if st is None else st.cpu().numpy(),
+               aux=None if aux is None else aux.cpu().numpy(), losses=losses, norm=float(eng.scalars[1]),
+               peer=eng.comm is not None, status=status, batch_total=eng.batch_total, rng_seed=eng.rng_seed)
+    if eng.comm is not None:
+        eng.comm.close()
+    return out
+
+
+def worker(rank, world, port, mode, algo, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", ULTR_DP_COMM=mode, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+    from ultra_pytorch_amd import parallel
+    torch.cuda.set_device(0)
+    r, w, _, pg = parallel.init_process_group_from_env(backend="gloo")
+    assert (r, w) == (rank, world) and pg is not None
+    feed, names_d, names_l, rel = make_global(3)
+    if algo == "lambdarank":  # relevance labels
+        for l in range(L):
+            feed[names_l[l]] = rel[l]
+    local = parallel.shard_input_feed(feed, "letor_features", names_d, names_l, L, rank, world)
+    feats, ids, y = feed_arrays(local, names_d, names_l)
+    lo, hi = parallel.shard_bounds(B, rank, world)
+    assert ids.shape == (L, hi - lo)
+    _, _, _, uniforms = initial_state(algo)
+    res = run_engine(algo, feats, ids, y, pg, uniforms[lo:hi])
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def single_process(algo):
+    feed, names_d, names_l, rel = make_global(3)
+    feats, ids, y = feed_arrays(feed, names_d, names_l, rel if algo == "lambdarank" else None)
+    _, _, _, uniforms = initial_state(algo)
+    return run_engine(algo, feats, ids, y, None, uniforms), (feats, ids, y)
+
+
+def oracle_two_steps(algo, feats, ids, y):
+    from oracle import ultr_oracle as O
+    params, state, aux, uniforms = initial_state(algo)
+    ids64 = ids.astype(np.int64)
+    for _ in range(n_steps_of(algo)):
+        if algo == "softmax":
+            r = O.train_step_softmax(params, state, F, HIDDEN, feats, ids64, y, ipw_list=np.linspace(1.0, 3.0, 4))
+            params, state = r["params"], r["state"]
+        elif algo == "pairdebias":
+            r = O.pairdebias_step(params, state, aux[:L], aux[L:], F, HIDDEN, feats, ids64, y)
+            params, state, aux = r["params"], r["state"], np.concatenate([r["t_plus"].ravel(), r["t_minus"].ravel()])
+        elif algo == "lambdarank":
+            r = O.lambdarank_step(params, state, aux[:L], aux[L:], F, HIDDEN, feats, ids64, y)
+            params, state, aux = r["params"], r["state"], np.concatenate([r["t_plus"].ravel(), r["t_minus"].ravel()])
+        elif algo == "dla":
+            r = O.dla_step(params, aux, F, HIDDEN, feats, ids64, y)
+            params, aux = r["params"], r["prop_params"]
+        else:
+            r = O.regression_em_step(params, state, aux, uniforms, F, HIDDEN, feats, ids64, y)
+            params, state, aux = r["params"], r["state"], r["propensity"].ravel()
+    return dict(params=params, state=state, aux=aux, loss=r["loss"])
+
+
+@pytest.mark.parametrize("mode", ["peer", "pg"])
+@pytest.mark.parametrize("algo", ALGOS)
+def test_two_rank_step_equals_single_process(mode, algo):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + ALGOS.index(algo) * 2 + (0 if mode == "peer" else 1)
+    procs = [ctx.Process(target=worker, args=(r, 2, port, mode, algo, q)) for r in range(2)]
+    [p.start() for p in procs]
+    got = dict(q.get(timeout=300) for _ in range(2))
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    one, (feats, ids, y) = single_process(algo)
+    ref = oracle_two_steps(algo, feats, ids, y)
+    for rank in (0, 1):
+        res = got[rank]
+        assert res["status"] == 0, "a peer wait timed out"
+        assert res["batch_total"] == B
+        if mode == "peer":
+            assert res["peer"], "the hipIpc exchange path was not taken (PeerComm.create fell back)"
+        else:
+            assert not res["peer"]
+        # the ranks are replicas: bitwise equal to each other
+        assert np.array_equal(res["params"], got[0]["params"])
+        if res["aux"] is not None:
+            assert np.array_equal(res["aux"], got[0]["aux"])
+        # equal to the single-process step up to the summation order of the shards
+        gmax = np.abs(one["params"]).max()
+        ok = np.ones(one["params"].shape, bool)
+        if algo == "dla":
+            ok = np.abs(one["grads"]) > 1e-4 * np.abs(one["grads"]).max()
+            assert ok.mean() > 0.9
+        np.testing.assert_allclose(res["params"][ok], one["params"][ok], rtol=2e-5, atol=2e-6 * gmax, err_msg="vs single process")
+        np.testing.assert_allclose(res["losses"], one["losses"], rtol=1e-5, atol=1e-6)
+        if res["state"] is not None:
+            np.testing.assert_allclose(res["state"], one["state"], rtol=2e-4, atol=1e-9)
+        if res["aux"] is not None:
+            np.testing.assert_allclose(res["aux"], one["aux"], atol=2e-6)
+    assert got[0]["rng_seed"] != got[1]["rng_seed"]  # RegressionEM's device draw is keyed per rank
+    # and to the oracle (the first step is teacher-forced identical; the second starts from slightly different params)
+    res = got[0]
+    assert abs(res["losses"][-1] - ref["loss"]) <= 2e-5 * max(1.0, abs(ref["loss"]))
+    sel = np.abs(ref["params"] - initial_state(algo)[0]) > 1e-4  # parameters that actually moved
+    if algo == "dla":
+        sel &= np.abs(one["grads"]) > 1e-4 * np.abs(one["grads"]).max()
+    np.testing.assert_allclose(res["params"][sel], ref["params"][sel], rtol=2e-3, atol=2e-4)
+    if res["aux"] is not None:
+        np.testing.assert_allclose(res["aux"], ref["aux"], atol=1e-5)
+
+
+def test_peer_comm_world1_matches_grad_sumsq():
+    """world 1 through the exchange kernel (ULTR_FORCE_DP): copy + partials == ultr_grad_sumsq."""
+    import ctypes
+    import torch
+    from ultra_pytorch_amd import _lib, hip_ops
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    P, Ls = 5000, 10
+    tail = hip_ops.tail_floats(Ls)
+    g = torch.randn(P + tail, device=dev)
+    h = ctypes.c_void_p()
+    _lib.check(lib.ultr_comm_create(0, 1, P + tail, ctypes.byref(h)), "create")
+    out = torch.empty_like(g)
+    nsq = (P + tail + 63) // 64
+    ws = torch.zeros(nsq + 8, device=dev)
+    ws2 = torch.zeros(nsq + 8, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.ultr_comm_allreduce(h, 0, ctypes.c_void_p(g.data_ptr()), P + tail, P, ctypes.c_void_p(out.data_ptr()),
+                                       ctypes.c_void_p(ws.data_ptr()), nsq, st), "allreduce")
+    hip_ops.grad_sumsq(g, P, Ls, ws2)
+    assert lib.ultr_comm_status(h, st) == 0
+    assert torch.equal(out, g)
+    np.testing.assert_allclose(ws[:nsq].cpu().numpy(), ws2[:nsq].cpu().numpy(), rtol=1e-6, atol=1e-7)
+    lib.ultr_comm_destroy(h)

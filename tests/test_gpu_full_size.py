@@ -107,7 +107,7 @@ def test_shard_sum_equals_full_batch(name):
         lids = np.stack([loc[n] for n in names_d]).astype(np.int32)
         ly = np.stack([loc[n] for n in names_l]).astype(np.float32)
         run = HipRun(F, hidden, B // 2, L, algo=algo)
-        run.eng.world = 2  # PairDebias' xB factor uses the GLOBAL batch
+        run.eng.batch_total = B  # PairDebias' xB factor uses the GLOBAL batch
         run.set_inputs(loc["f"], lids, ly)
         run.forward(params)
         from ultra_pytorch_amd import synthetic

@@ -13,7 +13,7 @@ from tests.hipref import HipRun, dev, load_golden  # noqa: E402
 
 ALGO = {"na": "softmax", "ipw": "softmax", "dla": "dla", "pairdebias": "pairdebias", "lambdarank": "lambdarank",
         "regem": "regem"}
-TRAIN_CASES = ["na_tiny", "ipw_tiny", "dla_tiny", "pairdebias_tiny", "lambdarank_tiny", "ipw_odd", "dla_odd",
+TRAIN_CASES = ["na_tiny", "ipw_tiny", "dla_tiny", "dla_sigmoid", "dla_sigmoid_odd", "pairdebias_tiny", "lambdarank_tiny", "ipw_odd", "dla_odd",
                "pairdebias_odd", "lambdarank_odd", "na_linear", "ipw_relu", "ipw_sgd", "ipw_cfg2", "regem_tiny", "regem_odd"]
 
 
@@ -31,6 +31,11 @@ def make_run(m, name):
     kw = dict(learning_rate=m["lr"], max_gradient_norm=m["max_gradient_norm"])
     if "sgd" in name:
         kw["optimizer"] = "sgd"
+    hp = dict(kv.split("=") for kv in m.get("algo_hparams", "").split(",") if kv)
+    if m["algo"] == "dla":  # dla.py:70-77 hparams
+        kw["logits_to_prob"] = hp.get("logits_to_prob", "softmax")
+        kw["ranker_loss_weight"] = float(hp.get("ranker_loss_weight", 1.0))
+        kw["propensity_learning_rate"] = float(hp.get("propensity_learning_rate", -1.0))
     return HipRun(m["F"], m["hidden"] or [], m["B"], m["L"], algo=ALGO[m["algo"]], act="relu" if "relu" in name else "elu", **kw)
 
 
@@ -71,7 +76,7 @@ def test_golden_train_step(name):
             # the pseudo-labels are the only discrete quantity: dscores x D = sigmoid(s) - y  =>  y = sigmoid(s) - ds
             y = 1.0 / (1.0 + np.exp(-scores.astype(np.float64))) - ds
             np.testing.assert_allclose(y, d[p + "ranker_labels"], atol=1e-5)
-        gs, loss = gscale_and_loss(m["algo"], tail)
+        gs, loss = gscale_and_loss(m["algo"], tail, rw=run.eng.udesc.ranker_loss_weight)
         ref_loss = float(d[p + "loss"])
         assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), ("loss", loss, ref_loss)
         # --- backward
@@ -97,7 +102,10 @@ def test_golden_train_step(name):
             assert abs(sc[4] - float(d[p + "rank_loss"])) < 1e-5 and abs(sc[5] - float(d[p + "exam_loss"])) < 1e-5
         if state is not None and "sgd" not in name:
             ref_state = d[p + "post_adagrad"]
-            np.testing.assert_allclose(state2, ref_state, rtol=5e-4, atol=1e-6 * float(ref_state.max()))
+            # s' = s + g^2 with g at the 1e-5 bar: 2e-5 relative (+ 2e-6 * max for elements with g ~ 0); the ill-conditioned
+            # *_odd nets carry their 1e-4 gradient bar (gtol) into the accumulator
+            np.testing.assert_allclose(state2, ref_state, rtol=2e-4 if name.endswith("_odd") else 2e-5,
+                                       atol=2e-6 * float(ref_state.max()))
 
 
 @pytest.mark.parametrize("name", ["valid_tiny", "valid_odd"])

@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libultr_hip.so")
 
 ULTR_MAX_HIDDEN = 7
+COMM_HANDLE_BYTES, COMM_MAX_WORLD = 64, 8
 ACT = {"elu": 0, "relu": 1}
 ALGO_SOFTMAX, ALGO_DLA, ALGO_PAIRDEBIAS, ALGO_LAMBDARANK, ALGO_REGEM = 0, 1, 2, 3, 4
 OPT_ADAGRAD, OPT_SGD = 0, 1
@@ -75,6 +76,13 @@ SIGNATURES = {
     "ultr_train_step": (c_i32, [ctypes.POINTER(StepArgs), c_vp]),
     "ultr_click_batch": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_i32, ctypes.c_uint64, ctypes.c_uint64,
                                  c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "ultr_comm_create": (c_i32, [c_i32, c_i32, c_i64, ctypes.POINTER(c_vp)]),
+    "ultr_comm_export": (c_i32, [c_vp, c_vp]),
+    "ultr_comm_import": (c_i32, [c_vp, c_i32, c_vp]),
+    "ultr_comm_allreduce": (c_i32, [c_vp, ctypes.c_uint64, c_vp, c_i64, c_i64, c_vp, c_vp, c_i32, c_vp]),
+    "ultr_comm_status": (c_i32, [c_vp, c_vp]),
+    "ultr_comm_destroy": (c_i32, [c_vp]),
+    "ultr_config_reload": (c_i32, []),
     "ultr_prof_enable": (c_i32, [ctypes.c_uint32, c_i32]),
     "ultr_prof_set_stride": (c_i32, [c_i32]),
     "ultr_prof_collect": (c_i32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
@@ -129,5 +137,5 @@ class UltrHipError(RuntimeError):
 
 def check(rc, what):
     if rc != 0:
-        kind = {-1: "bad argument", -2: "unsupported shape", -3: "workspace too small"}.get(rc, "hipError_t %d" % rc)
+        kind = {-1: "bad argument", -2: "unsupported shape", -3: "workspace too small", -4: "peer wait timed out"}.get(rc, "hipError_t %d" % rc)
         raise UltrHipError("%s failed: %s" % (what, kind))

@@ -1,0 +1,265 @@
+// ultr_comm.hip — data-parallel gradient exchange over xGMI without a collective library call in the step.
+//
+// The reference is single-process; row 8(e) shards the queries of a batch over the GPUs of one node and
+// needs ONE sum per step of the flat vector  [ unscaled gradients (P) | step tail ]  (0.41 MB at BASELINE config 2).
+// At a ~55 us step an RCCL all-reduce (launch + protocol latency, then a separate sum-of-squares pass) is a large
+// fixed cost, so the exchange is ONE kernel here ("one-shot" all-reduce, every rank reads every peer):
+//
+//   * every rank owns an exchange buffer in FINE-GRAINED device memory, exported with hipIpcGetMemHandle and mapped by
+//     every peer (xGMI peer-to-peer loads/stores; one process per GPU, handles travel over the host process group);
+//   * a workgroup owns a 1024-float slice: it PUBLISHES its slice of the local vector into the local exchange slot with
+//     system-scope write-through stores, waits for them (vmcnt), then raises its per-(slice, rank) flag in EVERY peer's
+//     flag array (one 4-byte posted store per peer); it then polls its OWN flag row until every peer's slice of the
+//     same step has landed and sums the W slices IN RANK ORDER with system-scope loads (bitwise identical on all
+//     ranks, no atomics), writes the reduced slice to local memory and the sum-of-squares partials ultr_apply_update
+//     consumes (the geometry of ultr_grad_sumsq: one partial per 64 gradient elements);
+//   * two slots alternate by step parity: a peer's flag for step s+1 can only be raised after it finished reading step s,
+//     so slot (s & 1) is free again at step s+2 without a second synchronisation;
+//   * flags carry the step number (monotonic, never reset); every wait is bounded (wall clock) and a timeout is
+//     reported through ultr_comm_status instead of hanging the GPU.
+//
+// Nothing here is torch- or RCCL-specific: the host side (parallel.py) moves the 64-byte handles with whatever process
+// group exists (gloo in tests, nccl = RCCL in bench.py) and falls back to torch.distributed.all_reduce when the
+// self-test of this path fails.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <new>
+
+#include "../../include/ultr_hip.h"
+#include "ultr_device.h"
+#include "ultr_plan.h"
+
+#define ULTR_SYS 0x11  // cache policy sc0 | sc1: system scope (write-through stores, loads served from memory)
+#define COMM_SLICE 1024  // floats per workgroup (256 threads x float4)
+#define COMM_FLAG_STRIDE 1  // uint32 per (slice, rank) flag
+
+struct ultr_comm {
+  int rank, world;
+  int64_t cap;         // floats per slot (multiple of COMM_SLICE)
+  int nslice;          // cap / COMM_SLICE
+  void* base;          // local allocation: [flags: nslice * world u32, padded to 4 KB][status 4 KB][slot 0][slot 1]
+  size_t bytes, flag_bytes;
+  void* peer_base[ULTR_COMM_MAX_WORLD];  // mapped peer allocations (peer_base[rank] = base)
+  bool mapped[ULTR_COMM_MAX_WORLD];
+  int device;
+};
+
+struct CommDev {
+  int rank, world;
+  float* x_local;                          // local slot of this step
+  const float* x[ULTR_COMM_MAX_WORLD];     // every rank's slot of this step (x[rank] = x_local)
+  uint32_t* flags[ULTR_COMM_MAX_WORLD];    // every rank's flag array [nslice][world]
+  uint32_t* status;                        // local: [0] != 0 after a timed-out wait
+  long long timeout_ticks;                 // wall_clock64 ticks (100 MHz)
+};
+
+static inline size_t round4k(size_t v) { return (v + 4095) & ~(size_t)4095; }
+
+__device__ __forceinline__ void sys_st4(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, float4 v) {
+  const u32x4 d = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(d, rs, byte_off, 0, ULTR_SYS);
+}
+__device__ __forceinline__ float4 sys_ld4(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, ULTR_SYS);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sys_rsrc(const float* p, int64_t nfloats) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)(nfloats * 4), 0x00020000);
+}
+
+// src [n] local vector -> out [n] = sum over ranks; sumsq_part[k] = sum of out[e]^2 over e in [64k, 64k+64), e < n_params
+template <int W>
+__global__ __launch_bounds__(256) void comm_allreduce_kernel(CommDev c, uint32_t epoch, int64_t n, int64_t n_params, int64_t cap,
+                                                             const float* __restrict__ src, float* __restrict__ out,
+                                                             float* __restrict__ sumsq_part, int nsq) {
+  __shared__ int sm_fail;
+  const int tid = threadIdx.x;
+  const int64_t e4 = ((int64_t)blockIdx.x * 256 + tid) * 4;
+  if (tid == 0) sm_fail = 0;
+  // ---- publish this workgroup's slice of the local vector (system-scope write-through) ------------------------------
+  float4 mine = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e4 + 3 < n) {
+    mine = ld4(src + e4);
+  } else if (e4 < n) {
+    mine.x = src[e4];
+    if (e4 + 1 < n) mine.y = src[e4 + 1];
+    if (e4 + 2 < n) mine.z = src[e4 + 2];
+  }
+  if constexpr (W > 1) {
+    sys_st4(sys_rsrc(c.x_local, cap), (unsigned)(e4 * 4), mine);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores are acknowledged at system scope
+    __syncthreads();
+    if (tid < W) {
+      // raise flag (slice, rank) in rank tid's array; then wait for rank tid's flag in ours
+      uint32_t* dst = c.flags[tid] + ((int64_t)blockIdx.x * W + c.rank) * COMM_FLAG_STRIDE;
+      __hip_atomic_store(dst, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const uint32_t* mineflag = c.flags[c.rank] + ((int64_t)blockIdx.x * W + tid) * COMM_FLAG_STRIDE;
+      const long long t0 = wall_clock64();
+      bool ok = true;
+      // flags carry the step number; a peer may already be one step ahead (>=); the difference is taken modulo 2^32
+      while ((int32_t)(__hip_atomic_load(mineflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
+        __builtin_amdgcn_s_sleep(2);
+        if (wall_clock64() - t0 > c.timeout_ticks) {
+          ok = false;
+          break;
+        }
+      }
+      if (!ok) {
+        sm_fail = 1;
+        __hip_atomic_store(c.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- sum the W slices in rank order ---------------------------------------------------------------------------------
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (W > 1) {
+    float4 v[W];
+#pragma unroll
+    for (int p = 0; p < W; ++p) v[p] = sys_ld4(sys_rsrc(c.x[p], cap), (unsigned)(e4 * 4));
+#pragma unroll
+    for (int p = 0; p < W; ++p) {
+      s.x += v[p].x; s.y += v[p].y; s.z += v[p].z; s.w += v[p].w;
+    }
+    if (sm_fail) s = mine;  // timed out: keep the local vector (the host sees ultr_comm_status != 0)
+  } else {
+    s = mine;
+  }
+  if (e4 + 3 < n) {
+    st4(out + e4, s);
+  } else if (e4 < n) {
+    out[e4] = s.x;
+    if (e4 + 1 < n) out[e4 + 1] = s.y;
+    if (e4 + 2 < n) out[e4 + 2] = s.z;
+  }
+  // ---- sum-of-squares partials of the reduced gradient (64 elements = 16 lanes) ---------------------------------------
+  float q = 0.f;
+  if (e4 < n_params) q += s.x * s.x;
+  if (e4 + 1 < n_params) q += s.y * s.y;
+  if (e4 + 2 < n_params) q += s.z * s.z;
+  if (e4 + 3 < n_params) q += s.w * s.w;
+  q += dpp_or<0xb1>(0.f, q);
+  q += dpp_or<0x4e>(0.f, q);
+  q += dpp_or<0x124>(0.f, q);
+  q += dpp_or<0x128>(0.f, q);
+  const int64_t k = e4 >> 6;
+  if ((tid & 15) == 0 && k < nsq) sumsq_part[k] = q;
+}
+
+extern "C" int ultr_comm_create(int32_t rank, int32_t world, int64_t n_floats, ultr_comm** out) {
+  if (!out || world < 1 || world > ULTR_COMM_MAX_WORLD || rank < 0 || rank >= world || n_floats <= 0 ||
+      n_floats * 4 >= ((int64_t)1 << 31))
+    return ULTR_E_BADARG;
+  ultr_comm* c = new (std::nothrow) ultr_comm;
+  if (!c) return ULTR_E_WORKSPACE;
+  memset(c, 0, sizeof(*c));
+  c->rank = rank;
+  c->world = world;
+  c->cap = (n_floats + COMM_SLICE - 1) / COMM_SLICE * COMM_SLICE;
+  c->nslice = (int)(c->cap / COMM_SLICE);
+  c->flag_bytes = round4k((size_t)c->nslice * world * COMM_FLAG_STRIDE * sizeof(uint32_t));
+  c->bytes = c->flag_bytes + 4096 + 2 * round4k((size_t)c->cap * sizeof(float));
+  hipError_t e = hipGetDevice(&c->device);
+  if (e == hipSuccess) e = hipExtMallocWithFlags(&c->base, c->bytes, hipDeviceMallocFinegrained);
+  if (e == hipSuccess) e = hipMemset(c->base, 0, c->bytes);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    if (c->base) (void)hipFree(c->base);
+    delete c;
+    return (int)e;
+  }
+  c->peer_base[rank] = c->base;
+  c->mapped[rank] = true;
+  *out = c;
+  return 0;
+}
+
+extern "C" int ultr_comm_export(ultr_comm* c, void* handle_out) {
+  if (!c || !handle_out) return ULTR_E_BADARG;
+  hipIpcMemHandle_t h;
+  const hipError_t e = hipIpcGetMemHandle(&h, c->base);
+  if (e != hipSuccess) return (int)e;
+  static_assert(sizeof(hipIpcMemHandle_t) <= ULTR_COMM_HANDLE_BYTES, "handle size");
+  memset(handle_out, 0, ULTR_COMM_HANDLE_BYTES);
+  memcpy(handle_out, &h, sizeof(h));
+  return 0;
+}
+
+extern "C" int ultr_comm_import(ultr_comm* c, int32_t peer, const void* handle) {
+  if (!c || !handle || peer < 0 || peer >= c->world || peer == c->rank) return ULTR_E_BADARG;
+  if (c->mapped[peer]) return 0;
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle, sizeof(h));
+  void* p = nullptr;
+  const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+  if (e != hipSuccess) return (int)e;
+  c->peer_base[peer] = p;
+  c->mapped[peer] = true;
+  return 0;
+}
+
+static bool comm_ready(const ultr_comm* c) {
+  for (int p = 0; p < c->world; ++p)
+    if (!c->mapped[p]) return false;
+  return true;
+}
+
+extern "C" int ultr_comm_allreduce(ultr_comm* c, uint64_t step, const float* src, int64_t n, int64_t n_params, float* out,
+                                   void* sumsq_ws, int32_t sumsq_parts, void* stream) {
+  if (!c || !src || !out || !sumsq_ws || n <= 0 || n > c->cap || n_params < 0 || n_params > n || sumsq_parts < 0)
+    return ULTR_E_BADARG;
+  if (!comm_ready(c)) return ULTR_E_UNSUPPORTED;
+  CommDev d;
+  memset(&d, 0, sizeof(d));
+  d.rank = c->rank;
+  d.world = c->world;
+  const size_t slot_bytes = round4k((size_t)c->cap * sizeof(float));
+  const size_t slot_off = c->flag_bytes + 4096 + (size_t)(step & 1) * slot_bytes;
+  for (int p = 0; p < c->world; ++p) {
+    d.flags[p] = reinterpret_cast<uint32_t*>(c->peer_base[p]);
+    d.x[p] = reinterpret_cast<const float*>(reinterpret_cast<char*>(c->peer_base[p]) + slot_off);
+  }
+  d.x_local = reinterpret_cast<float*>(reinterpret_cast<char*>(c->base) + slot_off);
+  d.status = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(c->base) + c->flag_bytes);
+  d.timeout_ticks = 300000000LL;  // 3 s of the 100 MHz wall clock
+  const uint32_t epoch = (uint32_t)(step + 1);
+  const int nblk = (int)((n + COMM_SLICE - 1) / COMM_SLICE);
+  hipStream_t st = (hipStream_t)stream;
+#define COMM_LAUNCH(WW)                                                                                                      \
+  hipLaunchKernelGGL(comm_allreduce_kernel<WW>, dim3(nblk), dim3(256), 0, st, d, epoch, n, n_params, c->cap, src, out, \
+                     (float*)sumsq_ws, (int)sumsq_parts)
+  switch (c->world) {
+    case 1: COMM_LAUNCH(1); break;
+    case 2: COMM_LAUNCH(2); break;
+    case 3: COMM_LAUNCH(3); break;
+    case 4: COMM_LAUNCH(4); break;
+    case 5: COMM_LAUNCH(5); break;
+    case 6: COMM_LAUNCH(6); break;
+    case 7: COMM_LAUNCH(7); break;
+    default: COMM_LAUNCH(8); break;
+  }
+#undef COMM_LAUNCH
+  return (int)hipGetLastError();
+}
+
+extern "C" int ultr_comm_status(ultr_comm* c, void* stream) {
+  if (!c) return ULTR_E_BADARG;
+  uint32_t v = 0;
+  hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+  if (e == hipSuccess)
+    e = hipMemcpy(&v, reinterpret_cast<char*>(c->base) + c->flag_bytes, sizeof(v), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return (int)e;
+  return v ? ULTR_E_COMM_TIMEOUT : 0;
+}
+
+extern "C" int ultr_comm_destroy(ultr_comm* c) {
+  if (!c) return 0;
+  (void)hipDeviceSynchronize();
+  for (int p = 0; p < c->world; ++p)
+    if (p != c->rank && c->mapped[p] && c->peer_base[p]) (void)hipIpcCloseMemHandle(c->peer_base[p]);
+  if (c->base) (void)hipFree(c->base);
+  delete c;
+  return 0;
+}

@@ -2327,9 +2327,41 @@ __global__ __launch_bounds__(64) void grad_sumsq_kernel(int64_t P, const float* 
 // ================================================================================================
 // Host side: plans and launches
 // ================================================================================================
-static int env_int(const char* name, int dflt) {
+// Tuning / experiment knobs (README.md): read from the environment ONCE (first use), not on every step - a getenv() walk
+// per knob per launch is host time on the critical path of a ~50 us step.  ultr_config_reload() re-reads them (tests and
+// the A/B tools flip knobs inside one process).
+struct Knobs {
+  int fwd_r, bwd_r, wgrad_wgs, fwd_nw, bwd_nw, no_vec, no_l0g, bwd_v1, no_fused_fb, fb_max_wg_per_cu, fb_lists;
+  bool loaded;
+};
+static Knobs g_knobs = {};
+static int env_read(const char* name, int dflt) {
   const char* s = getenv(name);
   return (s && *s) ? atoi(s) : dflt;
+}
+static void knobs_load() {
+  Knobs k;
+  k.fwd_r = env_read("ULTR_FWD_R", 0);
+  k.bwd_r = env_read("ULTR_BWD_R", 0);
+  k.wgrad_wgs = env_read("ULTR_WGRAD_WGS", -1);  // -1: the size-dependent default
+  k.fwd_nw = env_read("ULTR_FWD_NW", 8);
+  k.bwd_nw = env_read("ULTR_BWD_NW", 8);
+  k.no_vec = env_read("ULTR_NO_VEC", 0);
+  k.no_l0g = env_read("ULTR_NO_L0G", 0);
+  k.bwd_v1 = env_read("ULTR_BWD_V1", 0);
+  k.no_fused_fb = env_read("ULTR_NO_FUSED_FB", 0);
+  k.fb_max_wg_per_cu = env_read("ULTR_FB_MAX_WG_PER_CU", 1);
+  k.fb_lists = env_read("ULTR_FB_LISTS", 0);
+  k.loaded = true;
+  g_knobs = k;
+}
+static inline const Knobs& knobs() {
+  if (!g_knobs.loaded) knobs_load();
+  return g_knobs;
+}
+extern "C" int ultr_config_reload(void) {
+  knobs_load();
+  return 0;
 }
 
 extern "C" int ultr_abi_version(void) { return ULTR_ABI_VERSION; }
@@ -2453,7 +2485,7 @@ bool ultr_make_dnn_plan(const ultr_dnn_desc* d, int64_t N, DnnPlan* p) {
 static size_t fwd_pv_floats(const DnnPlan& p) { return (size_t)p.pv_total; }
 static size_t fwd_lds_bytes(const DnnPlan& p, int R) { return ((size_t)2 * R * fwd_ld(p.maxdim) + fwd_pv_floats(p)) * sizeof(float); }
 static int fwd_rows_per_wg(const DnnPlan& p, int64_t N) {
-  int r = env_int("ULTR_FWD_R", 0);
+  int r = knobs().fwd_r;
   if (r == 16 || r == 32) return r;
   // 16-row tiles everywhere: 32-row tiles halve the W stream per row, but their LDS footprint leaves one workgroup per CU and
   // the grid quantises badly (measured at cfg3 / B=1024: 114 -> 100 us and 57 -> 43 us with 16 rows); ULTR_FWD_R=32 forces them
@@ -2464,7 +2496,7 @@ static size_t bwd_lds_bytes(const DnnPlan& p, int R) {
   return ((size_t)R * (2 * bwd_ldu(p.maxdim) + bwd_ldz(p.maxdim)) + 2 * (size_t)bwd_ldu(p.maxdim) + 5 * (size_t)R) * sizeof(float) + (size_t)R * sizeof(int64_t);
 }
 static int bwd_rows_per_wg(const DnnPlan& p, int64_t N) {
-  int r = env_int("ULTR_BWD_R", 0);
+  int r = knobs().bwd_r;
   if (r == 16 || r == 32) return r;
   return ((N + 15) / 16 > 512 && bwd_lds_bytes(p, 32) <= 160 * 1024) ? 32 : 16;
 }
@@ -2501,7 +2533,7 @@ bool ultr_make_bwd_plan(const DnnPlan& p, int64_t N, BwdPlan* bp) {
   // workgroups over all hidden Linears: about one per CU for a small batch (every workgroup is a chain of latencies and a
   // second one on the CU only slows both), about two per CU otherwise - measured (tools/sweep_wgrad.sh, bench_configs.py):
   // N = 2560 rows: 224 -> 12.3 us, 392 -> 12.7, 448 -> 13.0;  N = 10240: 224 -> 36, 392 -> 33, 448 -> 30 us
-  const int target = env_int("ULTR_WGRAD_WGS", N < 4096 ? 224 : 448);
+  const int target = knobs().wgrad_wgs > 0 ? knobs().wgrad_wgs : (N < 4096 ? 224 : 448);
   int blk = 0;
   for (int j = 0; j < p.nl - 1; ++j) {
     WgradLayer& w = bp->wl[j];
@@ -2662,14 +2694,14 @@ extern "C" int ultr_dnn_forward(const ultr_dnn_desc* d, const float* params, con
   const int R = fwd_rows_per_wg(p, N);
   const size_t lds = fwd_lds_bytes(p, R);
   if (lds > 160 * 1024) return ULTR_E_UNSUPPORTED;
-  const int nw = env_int("ULTR_FWD_NW", 8);
+  const int nw = knobs().fwd_nw;
   const int vm = vecmask_for(p, params, features);
   const dim3 grid((unsigned)((N + R - 1) / R));
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipSuccess;
   UltrProfScope prof(ULTR_K_FWD, st);
   // the fast path needs the k-major weight copy (ultr_dnn_build_wt / kept current by ultr_apply_update)
-  const bool av = all_vec(p, vm, N, n_docs) && env_int("ULTR_NO_VEC", 0) == 0 && (wt != nullptr || p.nl == 1) &&
+  const bool av = all_vec(p, vm, N, n_docs) && knobs().no_vec == 0 && (wt != nullptr || p.nl == 1) &&
                   ((uintptr_t)wt & 15) == 0;
 #define LAUNCH_FWD(RR, NWW, VV)                                                                                     \
   do {                                                                                                              \
@@ -2706,17 +2738,17 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
   BwdPlan bp;
   if (!ultr_make_dnn_plan(d, N, &p) || !ultr_make_bwd_plan(p, N, &bp)) return ULTR_E_BADARG;
   if (fused_rb > 0) bp.nrb = (int)((N + fused_rb - 1) / fused_rb);  // vector slabs / loss partials: one per fused block
-  const bool l0g_ok = p.nl >= 2 && env_int("ULTR_NO_L0G", 0) == 0;
+  const bool l0g_ok = p.nl >= 2 && knobs().no_l0g == 0;
   const int tail = (int)ultr_tail_len(list_size);
   if (tail > 4096) return ULTR_E_UNSUPPORTED;
   const size_t lds = bwd_lds_bytes(p, bp.rblk);
   if (lds > 160 * 1024) return ULTR_E_UNSUPPORTED;
-  const int nw = env_int("ULTR_BWD_NW", 8);
+  const int nw = knobs().bwd_nw;
   const int vm = vecmask_for(p, params, features);
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipSuccess;
   float* ws = (float*)bwd_ws;
-  const bool av = all_vec(p, vm, N, n_docs) && env_int("ULTR_NO_VEC", 0) == 0;
+  const bool av = all_vec(p, vm, N, n_docs) && knobs().no_vec == 0;
 #define LAUNCH_BWD(RR, NWW, VV)                                                                                        \
   do {                                                                                                                 \
     e = set_lds(dnn_bwd_kernel<RR, NWW, VV>, lds);                                                                     \
@@ -2732,7 +2764,7 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
   // fast variant: aligned shapes, K_j <= 512, 8 waves, LDS budget (see dnn_bwd2_kernel)
   const size_t lds2 = bwd2_lds_floats(p, bp.rblk, 8) * sizeof(float);
   const bool v2 = av && nw == 8 && p.maxdim <= 512 && lds2 <= 160 * 1024 && p.sv_total * 4 < ((int64_t)1 << 31) &&
-                  p.P * 4 < ((int64_t)1 << 31) && env_int("ULTR_BWD_V1", 0) == 0;
+                  p.P * 4 < ((int64_t)1 << 31) && knobs().bwd_v1 == 0;
 #define LAUNCH_BWDV2(RR, XX)                                                                                           \
   do {                                                                                                                 \
     e = set_lds(dnn_bwd2_kernel<RR, 8, XX>, lds2);                                                                     \
@@ -2819,7 +2851,7 @@ int ultr_fused_step_softmax(const ultr_dnn_desc* d, const float* params, const f
   if (!params || !wt || !docids || !scores || !saved || !labels || !loss_ws || !bwd_ws || !grads || batch <= 0 ||
       list_size <= 0 || n_docs < 0 || (n_docs > 0 && !features) || (ipw_table && n_ipw <= 0))
     return ULTR_E_BADARG;
-  if (env_int("ULTR_NO_FUSED_FB", 0) != 0) return ULTR_E_UNSUPPORTED;
+  if (knobs().no_fused_fb != 0) return ULTR_E_UNSUPPORTED;
   const int L = list_size;
   if (L > 16) return ULTR_E_UNSUPPORTED;
   const int64_t N = (int64_t)batch * L;
@@ -2836,15 +2868,15 @@ int ultr_fused_step_softmax(const ultr_dnn_desc* d, const float* params, const f
   }
   const int vm = vecmask_for(p, params, features);
   const size_t lds = fb_lds_floats(p) * sizeof(float);
-  const bool ok = all_vec(p, vm, N, n_docs) && env_int("ULTR_NO_VEC", 0) == 0 && ((uintptr_t)wt & 15) == 0 &&
+  const bool ok = all_vec(p, vm, N, n_docs) && knobs().no_vec == 0 && ((uintptr_t)wt & 15) == 0 &&
                   p.nl >= 2 && p.maxdim <= 512 && p.pv_total <= 3 * 512 * 4 && lds <= 160 * 1024 &&
-                  nblk <= (int64_t)env_int("ULTR_FB_MAX_WG_PER_CU", 1) * cus &&  // one round of workgroups (tools/fused_threshold.py:
+                  nblk <= (int64_t)knobs().fb_max_wg_per_cu * cus &&  // one round of workgroups (tools/fused_threshold.py:
                                                                           // B=256 62 vs 68 us, B=288 94 vs 70 us)
                   nblk <= (N + 8) / 9 + 1 &&                               // vector-slab allocation (>= 9 live rows / block)
                   p.sv_total * 4 < ((int64_t)1 << 31) && p.P * 4 < ((int64_t)1 << 31);
   if (!ok) return ULTR_E_UNSUPPORTED;
   bp.nrb = (int)nblk;
-  bp.l0g = (p.nl >= 2 && env_int("ULTR_NO_L0G", 0) == 0) ? 1 : 0;  // must match backward_impl's choice
+  bp.l0g = (p.nl >= 2 && knobs().no_l0g == 0) ? 1 : 0;  // must match backward_impl's choice
   bp.wg_prenorm = 1;
   hipStream_t st = (hipStream_t)stream;
   FusedSoftmax fl = {nullptr, labels, pw, ipw_table, (int)n_ipw, dscores_out, (float*)loss_ws};

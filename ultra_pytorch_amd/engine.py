@@ -3,8 +3,8 @@
 Owns the per-shape device workspaces (torch tensors = plumbing for HBM allocations) and
 sequences the C-ABI calls on the current HIP stream:
 
-    train:  ultr_dnn_forward -> ultr_<loss> -> ultr_dnn_backward [-> RCCL all-reduce -> ultr_grad_sumsq]
-            -> ultr_apply_update                                             (6 kernels on one GPU)
+    train:  ultr_dnn_forward -> ultr_<loss> -> ultr_dnn_backward [-> ultr_comm_allreduce (one kernel over xGMI; or
+            the process group's all-reduce + ultr_grad_sumsq)] -> ultr_apply_update
     valid:  ultr_dnn_forward -> ultr_ndcg
 
 Nothing here synchronises with the host; the caller decides when to read `scalars`
@@ -32,15 +32,31 @@ class StepEngine:
         if not torch.cuda.is_available():
             raise RuntimeError("ultra_pytorch_amd needs an MI355X/ROCm GPU: there is no CPU fallback")
         self.shape, self.B, self.L, self.device = shape, int(batch), int(list_size), device
+        shape.lib.ultr_config_reload()  # the ULTR_* knobs are read when an engine is built, never per step
         self.N = self.B * self.L
         self.algo = algo
         self.sigma = float(sigma)
-        self.rng_seed, self.rng_step = int(rng_seed), 0  # RegressionEM's Bernoulli draw when no uniforms are injected
         self.l2p = 1 if logits_to_prob == "sigmoid" else 0
         self.pg = process_group
         self.world = 1 if process_group is None else torch.distributed.get_world_size(process_group)
+        self.rank = 0 if process_group is None else torch.distributed.get_rank(process_group)
+        # RegressionEM's Bernoulli draw when no uniforms are injected: Philox keyed by (seed, step); every shard gets its own
+        # key, otherwise list i of every rank would draw the same uniforms
+        self.rng_seed, self.rng_step = (int(rng_seed) + 0x9E3779B1 * self.rank) & 0xFFFFFFFFFFFFFFFF, 0
+        # PairDebias' xB factor (base_algorithm.py:242-248) is the GLOBAL batch: shards may be uneven (parallel.shard_bounds),
+        # so it is the sum of the local batches, not B * world
+        self.batch_total = self.B
+        if process_group is not None:
+            cpu_pg = torch.distributed.get_backend(process_group) == "gloo"
+            t = torch.tensor([self.B], dtype=torch.int64, device="cpu" if cpu_pg else device)
+            torch.distributed.all_reduce(t, group=process_group)
+            self.batch_total = int(t.item())
         P, tail = shape.n_params, hip_ops.tail_floats(self.L)
         self.P, self.tail = P, tail
+        self.comm = None
+        if process_group is not None:
+            from . import parallel
+            self.comm = parallel.PeerComm.create(process_group, P + tail, device)
         self._alloc(shape, device)
         self.loss_ws = _f32(hip_ops.loss_workspace_bytes(self.B, self.L) // 4, device, zero=True)
         self.scores = _f32(self.N, device).view(self.B, self.L)
@@ -83,7 +99,7 @@ class StepEngine:
         elif self.algo == "dla":
             hip_ops.dla_loss(self.scores, labels, aux, self.l2p, B, L, self.dscores, self.loss_ws)
         elif self.algo == "pairdebias":
-            hip_ops.pairdebias_loss(self.scores, labels, aux[:L], aux[L:], B, L, B * self.world, self.dscores, self.loss_ws)
+            hip_ops.pairdebias_loss(self.scores, labels, aux[:L], aux[L:], B, L, self.batch_total, self.dscores, self.loss_ws)
         elif self.algo == "lambdarank":
             hip_ops.lambdarank_loss(self.scores, labels, aux[:L], aux[L:], self.sigma, B, L, self.dscores, self.loss_ws)
         elif self.algo == "regem":
@@ -96,8 +112,16 @@ class StepEngine:
     def backward(self, params, features, n_docs, docids):
         hip_ops.dnn_backward(self.shape, params, features, n_docs, docids, self.B, self.L, self.saved, self.dscores,
                              self.loss_ws, self.bwd_ws, self.grads)
-        if self.pg is not None:
-            # queries shard across ranks; ONE sum all-reduce (RCCL over xGMI) of [grads | step tail]
+        self.dp_reduce()
+
+    def dp_reduce(self):
+        """Queries shard across ranks: ONE sum of [grads | step tail] per step, then the sum-of-squares partials of the
+        reduced gradient for the clip."""
+        if self.pg is None:
+            return
+        if self.comm is not None:  # one kernel: publish, xGMI reads of every peer, fixed-order sum, partials
+            self.comm.allreduce(self.grads, self.P + self.tail, self.P, self.grads, self.bwd_ws)
+        else:  # the process group's collective (RCCL over xGMI; gloo in tests)
             torch.distributed.all_reduce(self.grads, group=self.pg)
             hip_ops.grad_sumsq(self.grads, self.P, self.L, self.bwd_ws)
 
@@ -115,7 +139,7 @@ class StepEngine:
             a.scores, a.dscores = self.scores.data_ptr(), self.dscores.data_ptr()
             a.saved, a.loss_ws, a.bwd_ws = self.saved.data_ptr(), self.loss_ws.data_ptr(), self.bwd_ws.data_ptr()
             a.grads, a.scalars = self.grads.data_ptr(), self.scalars.data_ptr()
-            a.batch, a.list_size, a.batch_total = self.B, self.L, self.B * self.world
+            a.batch, a.list_size, a.batch_total = self.B, self.L, self.batch_total
             a.sigma = self.sigma
             a.skip_update = 1 if self.pg is not None else 0
             self._fn = self.shape.lib.ultr_train_step
@@ -135,8 +159,7 @@ class StepEngine:
             self.rng_step += 1
         _lib.check(self._fn(ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ultr_train_step")
         if self.pg is not None:
-            torch.distributed.all_reduce(self.grads, group=self.pg)
-            hip_ops.grad_sumsq(self.grads, self.P, self.L, self.bwd_ws)
+            self.dp_reduce()
             self.update(params, state, aux)
         return self.scalars
 
@@ -186,8 +209,9 @@ class SetRankStepEngine(StepEngine):
         hip_ops.setrank_backward(self.shape, params, self.B, self.L, self.saved, self.dscores, self.loss_ws, hip_ops.loss_part_count(self.B),
                                  self.sr_ws, self.grads)
         if self.pg is not None:
-            torch.distributed.all_reduce(self.grads, group=self.pg)
-        hip_ops.grad_sumsq(self.grads, self.P, self.L, self.bwd_ws)
+            self.dp_reduce()
+        else:
+            hip_ops.grad_sumsq(self.grads, self.P, self.L, self.bwd_ws)
 
     def update(self, params, state, aux=None):
         check = _lib.check
