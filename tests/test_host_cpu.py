@@ -119,3 +119,35 @@ def test_synthetic_batch_contract():
     assert feats.shape == (16 * 8, 136) and ids.shape == (10, 16) and clicks.shape == (10, 16)
     assert (ids[8:] == feats.shape[0]).all() and (clicks.sum(0) > 0).all() and (clicks[8:] == 0).all()
     assert len(synthetic.load_ipw()) == 40
+
+
+def test_ranklist_by_scores_follows_reference_semantics():
+    """data_utils.py:567-617: positions are ranked (not document ids), pads (doc index < 0) are dropped, and a score
+    matrix whose shape does not match the initial lists raises instead of producing a truncated run file."""
+    from ultra_pytorch_amd.utils import data_utils
+
+    class D:
+        qids = ["q1", "q2"]
+        dids = ["a", "b", "c", "d"]
+        initial_list = [[0, 1, 1, -1], [2, 3, -1, -1]]  # the same document twice in q1: both positions are kept
+
+    out = data_utils.generate_ranklist_by_scores(D, [[0.1, 0.9, 0.5, 7.0], [1.0, 2.0, 3.0, 4.0]])
+    assert out["q1"] == [("b", 0.9), ("b", 0.5), ("a", 0.1)]
+    assert out["q2"] == [("d", 2.0), ("c", 1.0)]
+    with pytest.raises(ValueError):
+        data_utils.generate_ranklist_by_scores(D, [[0.1, 0.9, 0.5, 7.0]])
+    with pytest.raises(ValueError):
+        data_utils.generate_ranklist_by_scores(D, [[0.1, 0.9, 0.5], [1.0, 2.0, 3.0, 4.0]])
+
+
+def test_setrank_forward_consumes_the_reference_random_stream():
+    """SetRank.py:245-246 shuffles an index list on every forward: the same draws must be consumed here."""
+    import random
+    from ultra_pytorch_amd import engine
+    random.seed(5)
+    engine._setrank_draw(10)
+    got = random.random()
+    random.seed(5)
+    ind = list(range(10))
+    random.shuffle(ind)
+    assert got == random.random()

@@ -126,6 +126,8 @@ int main(int argc, char** argv) {
   hipMemcpy(dW, h.data(), nfloats * sizeof(float), hipMemcpyHostToDevice);
   run<0, 8, 8>("V0 dwordx2 16x8B x4rows (CT=2)", dW, nfloats, rowlen, G, dout, dcyc);
   run<0, 8, 16>("V0 dwordx2 16x8B x4rows (CT=2)", dW, nfloats, rowlen, G, dout, dcyc);
+  run<0, 8, 32>("V0 dwordx2 16x8B x4rows (CT=2)", dW, nfloats, rowlen, G, dout, dcyc);
+  run<0, 8, 64>("V0 dwordx2 16x8B x4rows (CT=2)", dW, nfloats, rowlen, G, dout, dcyc);
   run<1, 4, 8>("V1 dwordx4 16x16B x4rows (CT=4)", dW, nfloats, rowlen, G, dout, dcyc);
   run<1, 4, 16>("V1 dwordx4 16x16B x4rows (CT=4)", dW, nfloats, rowlen, G, dout, dcyc);
   run<2, 8, 4>("V2 dwordx4 1KiB contiguous", dW, nfloats, rowlen, G, dout, dcyc);

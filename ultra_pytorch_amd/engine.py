@@ -11,6 +11,7 @@ Nothing here synchronises with the host; the caller decides when to read `scalar
 (the reference's `loss.item()` is the only sync, base_algorithm.py / ipw_rank.py:182).
 """
 import ctypes
+import random
 
 import torch
 
@@ -185,6 +186,13 @@ class EvalEngine:
         return self.scores, self.ndcg
 
 
+def _setrank_draw(list_size):
+    """The reference's SetRank.build shuffles an index list on EVERY forward and never uses it (SetRank.py:245-246), but the
+    call advances Python's global `random` stream - the one ClickSimulationFeed draws queries and clicks from.  Consuming
+    the same draws keeps a seeded SetRank run on the reference's batches and clicks."""
+    random.shuffle(list(range(int(list_size))))
+
+
 class SetRankStepEngine(StepEngine):
     """The same step for the SetRank ranking model: ultr_setrank_forward -> ultr_<loss> ->
     ultr_setrank_backward -> [all-reduce] -> ultr_grad_sumsq -> ultr_apply_update.  Stage calls instead of ONE C call:
@@ -202,6 +210,7 @@ class SetRankStepEngine(StepEngine):
 
     def forward(self, params, features, n_docs, docids, scores=None, train=False):
         scores = self.scores if scores is None else scores
+        _setrank_draw(self.L)
         hip_ops.setrank_forward(self.shape, params, features, n_docs, docids, self.B, self.L, scores, self.saved)
         return scores
 
@@ -239,6 +248,7 @@ class SetRankEvalEngine(EvalEngine):
         self.saved = _f32(shape.saved_bytes(self.B * self.L) // 4, device)
 
     def run(self, params, features, n_docs, docids, labels):
+        _setrank_draw(self.L)
         hip_ops.setrank_forward(self.shape, params, features, n_docs, docids, self.B, self.L, self.scores, self.saved)
         hip_ops.ndcg(self.scores, labels, docids, n_docs, self.B, self.L, self.topn, self.ndcg, self.ndcg_ws,
                      order_out=self.order, masked_out=self.masked)

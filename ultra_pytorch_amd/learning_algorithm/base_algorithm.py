@@ -44,7 +44,7 @@ class BaseAlgorithm(object):
         self.model = self.create_model(self.feature_size).to(self.cuda)
         self.learning_rate = float(self.hparams.learning_rate)
         self.state_sum = torch.zeros_like(self.model.flat_params)  # Adagrad accumulator (initial value 0)
-        self._train_engines, self._eval_engines, self._stage = {}, {}, {}
+        self._train_engines, self._eval_engines, self._stage, self._stage_events = {}, {}, {}, {}
         self.process_group = exp_settings.get("process_group", None)  # data parallel: one rank per GPU
 
     def create_model(self, feature_size):
@@ -66,8 +66,15 @@ class BaseAlgorithm(object):
 
     def _upload(self, key, array, dtype):
         host = self._pinned(key, array.shape, dtype)
+        ev = self._stage_events.get(key)
+        if ev is not None:
+            ev.synchronize()  # the previous asynchronous copy out of this staging buffer must have read it
         host.copy_(torch.from_numpy(np.ascontiguousarray(array)))  # casts (f64 features -> f32, f32 ids -> i32)
-        return host.to(self.cuda, non_blocking=True)
+        dev = host.to(self.cuda, non_blocking=True)
+        if ev is None:
+            ev = self._stage_events[key] = torch.cuda.Event()
+        ev.record()
+        return dev
 
     def create_input_feed(self, input_feed, list_size):
         """numpy feed -> device tensors: features [n_docs,F] f32, docids [L,B] i32, labels [L,B] f32.
@@ -135,7 +142,10 @@ class BaseAlgorithm(object):
                 else:
                     if masked is None:
                         masked = ev.masked.cpu()
-                        lab_BL = torch.from_numpy(np.ascontiguousarray(labels_host.T.astype(np.float32)))
+                        if labels_host is None:  # device feed: the labels live in HBM
+                            lab_BL = self.labels_LB.t().contiguous().cpu()
+                        else:
+                            lab_BL = torch.from_numpy(np.ascontiguousarray(labels_host.T.astype(np.float32)))
                     values = metrics_mod.make_ranking_metric_fn(metric, topn)(lab_BL, masked, None)
                 for n, v in zip(topn, values):
                     self.eval_summary["%s_%d" % (metric, n)] = float(v)

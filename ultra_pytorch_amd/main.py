@@ -96,6 +96,7 @@ def train(args, exp_settings):
     test_set = None
     if args.test_while_train:
         test_set = utils.read_data(args.data_dir, args.test_data_prefix, args.click_model_dir, rank_cut)
+        utils.find_class(exp_settings["train_input_feed"]).preprocess_data(test_set, exp_settings["train_input_hparams"], exp_settings)
         exp_settings["max_candidate_num"] = max(test_set.rank_list_size, exp_settings["max_candidate_num"])
         test_set.pad(exp_settings["max_candidate_num"])
     _set_cutoffs(args, exp_settings)
@@ -153,6 +154,7 @@ def test(args, exp_settings):
     print("Reading data in %s" % args.data_dir)
     rank_cut = args.max_list_cutoff if args.max_list_cutoff > 0 else None
     test_set = utils.read_data(args.data_dir, args.test_data_prefix, args.click_model_dir, rank_cut)
+    utils.find_class(exp_settings["train_input_feed"]).preprocess_data(test_set, exp_settings["train_input_hparams"], exp_settings)
     exp_settings["max_candidate_num"] = test_set.rank_list_size
     _set_cutoffs(args, exp_settings)
     test_set.pad(exp_settings["max_candidate_num"])

@@ -99,6 +99,7 @@ class SetRank(nn.Module):
             raise RuntimeError("ultra_pytorch_amd.ranking_model.SetRank.build needs the model on the GPU; there is no CPU fallback")
         dev = self.flat_params.device
         L, B = len(input_list), int(input_list[0].shape[0])
+        engine._setrank_draw(L)  # SetRank.py:245-246 consumes the global `random` stream on every forward
         x = torch.cat([t.to(dev, torch.float32) for t in input_list], dim=0).contiguous()  # position-major rows
         docids = torch.arange(L * B, dtype=torch.int32, device=dev)
         scores = torch.empty(B, L, dtype=torch.float32, device=dev)

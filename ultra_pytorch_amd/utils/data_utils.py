@@ -132,20 +132,19 @@ def merge_Summary(summary_list, weights):
 
 
 def generate_ranklist_by_scores(data, rerank_scores):
-    """qid -> [(did, score)] sorted by descending score, pads skipped (data_utils.py:567-617)."""
+    """qid -> [(did, score)] by descending score over the LIST POSITIONS, pads (doc index < 0) dropped; a score matrix
+    whose shape does not match the initial lists raises, as the reference does (data_utils.py:567-617)."""
+    if len(rerank_scores) != len(data.initial_list):
+        raise ValueError("Rerank ranklists number must be equal to the initial list, %d != %d."
+                         % (len(rerank_scores), len(data.initial_list)))
     out = {}
     for i, qid in enumerate(data.qids):
         scores = [float(s) for s in rerank_scores[i]]
-        order = sorted(range(len(scores)), key=lambda k: scores[k], reverse=True)
-        seen, lst = set(), []
-        for k in order:
-            if k >= len(data.initial_list[i]):
-                continue
-            d = data.initial_list[i][k]
-            if d >= 0 and d not in seen:
-                seen.add(d)
-                lst.append((data.dids[d], scores[k]))
-        out[qid] = lst
+        if len(scores) != len(data.initial_list[i]):
+            raise ValueError("Rerank ranklists length must be equal to the gold list, %d != %d."
+                             % (len(scores), len(data.initial_list[i])))
+        order = sorted(range(len(scores)), key=lambda k: scores[k], reverse=True)  # a permutation: every position once
+        out[qid] = [(data.dids[data.initial_list[i][k]], scores[k]) for k in order if data.initial_list[i][k] >= 0]
     return out
 
 
