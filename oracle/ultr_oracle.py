@@ -293,8 +293,26 @@ def logits_to_prob(x: torch.Tensor, kind: str = "softmax") -> torch.Tensor:
     return torch.softmax(x, dim=-1)
 
 
+def _fresh_adagrad_step(flat, grad, F_, hidden, lr, max_norm, split):
+    """DLA.separate_gradient_update in the reference's own STRUCTURE (dla.py:141-177): one leaf tensor per parameter,
+    clip_grad_norm_ over them, a torch.optim.Adagrad object constructed for this step only, .step().  Numerically the
+    stateless update of apply_update(stateless=True); used for the bench's "reference structure" CPU timing and checked
+    against it in tests/test_quirks_cpu.py."""
+    if split:
+        leaves = [flat[o:o + int(np.prod(s))].detach().clone().view(*s).requires_grad_(True) for _, s, o in param_layout(F_, hidden)]
+        grads = [grad[o:o + int(np.prod(s))].view(*s) for _, s, o in param_layout(F_, hidden)]
+    else:
+        leaves, grads = [flat.detach().clone().requires_grad_(True)], [grad]
+    for p, g in zip(leaves, grads):
+        p.grad = g.clone()
+    opt = torch.optim.Adagrad(leaves, lr=lr)
+    norm = torch.nn.utils.clip_grad_norm_(leaves, max_norm)
+    opt.step()
+    return torch.cat([p.detach().reshape(-1) for p in leaves]), float(norm)
+
+
 def dla_step(params, prop_params, F_, hidden, features, docids, labels_LB, lr=0.05, prop_lr=None, max_norm=5.0,
-             ranker_loss_weight=1.0, strategy="ada", l2p="softmax", act="elu"):
+             ranker_loss_weight=1.0, strategy="ada", l2p="softmax", act="elu", fresh_optimizers=False):
     prop_lr = lr if prop_lr is None or prop_lr < 0 else prop_lr
     L, B = docids.shape
     p = torch.as_tensor(params, dtype=torch.float32).clone().requires_grad_(True)
@@ -310,10 +328,14 @@ def dla_step(params, prop_params, F_, hidden, features, docids, labels_LB, lr=0.
     exam_loss = softmax_loss(propensity, labels, rw)  # dla.py:221-224
     loss = exam_loss + ranker_loss_weight * rank_loss  # dla.py:237
     gp, gq = torch.autograd.grad(loss, (p, q))
-    with torch.no_grad():
-        # separate clips (dla.py:161-163), fresh optimizers (dla.py:153-154) => stateless Adagrad
-        q2, _, nq, _ = apply_update(q.detach(), gq, torch.zeros_like(gq), prop_lr, max_norm, strategy, stateless=True)
-        p2, _, np_, _ = apply_update(p.detach(), gp, torch.zeros_like(gp), lr, max_norm, strategy, stateless=True)
+    if fresh_optimizers and strategy == "ada":
+        q2, nq = _fresh_adagrad_step(q.detach(), gq, F_, hidden, prop_lr, max_norm, split=False)
+        p2, np_ = _fresh_adagrad_step(p.detach(), gp, F_, hidden, lr, max_norm, split=True)
+    else:
+        with torch.no_grad():
+            # separate clips (dla.py:161-163), fresh optimizers (dla.py:153-154) => stateless Adagrad
+            q2, _, nq, _ = apply_update(q.detach(), gq, torch.zeros_like(gq), prop_lr, max_norm, strategy, stateless=True)
+            p2, _, np_, _ = apply_update(p.detach(), gp, torch.zeros_like(gp), lr, max_norm, strategy, stateless=True)
     return dict(loss=float(loss.detach()), rank_loss=float(rank_loss.detach()), exam_loss=float(exam_loss.detach()), scores=scores.detach().numpy(),
                 grads=gp.numpy(), norm=float(np_), prop_grads=gq.numpy(), prop_norm=float(nq), params=p2.numpy(),
                 prop_params=q2.numpy(), propensity_weights=pw.numpy(), relevance_weights=rw.numpy())
@@ -339,6 +361,34 @@ def pairdebias_loss(scores: torch.Tensor, clicks_LB: torch.Tensor, t_plus: torch
     return loss, PL, t_plus_loss, t_minus_loss
 
 
+def pairdebias_loss_loops(scores: torch.Tensor, clicks_LB: torch.Tensor, t_plus: torch.Tensor, t_minus: torch.Tensor):
+    """The same quantities in the reference's own STRUCTURE (pairwise_debias.py:142-157): a Python loop over the L*(L-1)
+    ordered position pairs, each a handful of small tensor ops, with the [B] x [B,1] broadcast of
+    pairwise_cross_entropy_loss (base_algorithm.py:242-248) left in place (it is where the factor B comes from).
+    Used for the bench's "reference structure" CPU timing; equal to pairdebias_loss (tests/test_quirks_cpu.py)."""
+    B, L = scores.shape
+    cols = [scores[:, l:l + 1] for l in range(L)]  # [B, 1] each, as torch.split gives the reference
+    tp, tm = t_plus.view(-1), t_minus.view(-1)
+    tpl = [scores.new_zeros(()) for _ in range(L)]
+    tml = [scores.new_zeros(()) for _ in range(L)]
+    PL = [[scores.new_zeros(()) for _ in range(L)] for _ in range(L)]
+    loss = scores.new_zeros(())
+    for i in range(L):
+        for j in range(L):
+            if i == j:
+                continue
+            mask = torch.minimum(torch.ones_like(clicks_LB[i]), F.relu(clicks_LB[i] - clicks_LB[j]))  # [B]
+            logits = torch.cat([cols[i], cols[j]], dim=1)
+            ce = -(torch.log_softmax(logits, dim=-1)[:, 0])  # [B]: label distribution (1, 0), base_algorithm.py:18-30
+            ce = ce * torch.ones_like(cols[i])  # [B] * [B, 1] -> [B, B]: every pair loss counted B times (:242-248)
+            pl = torch.sum(mask * ce)
+            PL[i][j] = pl
+            tpl[i] = tpl[i] + pl / tm[j]
+            tml[j] = tml[j] + pl / tp[i]
+            loss = loss + pl / tp[i] / tm[j]
+    return loss, torch.stack([torch.stack(r) for r in PL]), torch.stack(tpl), torch.stack(tml)
+
+
 def em_update(t, t_loss, alpha, p, safe=False):
     """pairwise_debias.py:160-163 (plain /) and lambda_rank.py:138-142 (_safe_div)."""
     ratio = torch.where(t_loss[0] == 0, torch.zeros_like(t_loss), t_loss / t_loss[0]) if safe else t_loss / t_loss[0]
@@ -346,12 +396,13 @@ def em_update(t, t_loss, alpha, p, safe=False):
 
 
 def pairdebias_step(params, state_sum, t_plus, t_minus, F_, hidden, features, docids, labels_LB, lr=0.005,
-                    max_norm=5.0, em_step=0.05, reg_p=1, strategy="ada", act="elu"):
+                    max_norm=5.0, em_step=0.05, reg_p=1, strategy="ada", act="elu", loops=False):
     p = torch.as_tensor(params, dtype=torch.float32).clone().requires_grad_(True)
     tp = torch.as_tensor(t_plus, dtype=torch.float32)
     tm = torch.as_tensor(t_minus, dtype=torch.float32)
     scores = ranking_scores(p, F_, hidden, features, docids, act)
-    loss, PL, tpl, tml = pairdebias_loss(scores, torch.as_tensor(labels_LB, dtype=torch.float32), tp, tm)
+    loss_fn = pairdebias_loss_loops if loops else pairdebias_loss
+    loss, PL, tpl, tml = loss_fn(scores, torch.as_tensor(labels_LB, dtype=torch.float32), tp, tm)
     (g,) = torch.autograd.grad(loss, p)
     with torch.no_grad():
         tp2 = em_update(tp, tpl, em_step, reg_p)

@@ -403,8 +403,88 @@ def run_feed_case(ultra, name, seed=0):
     print("wrote", name)
 
 
+def run_driver_case(ultra, name, seed=0):
+    """The reference DRIVER (main.py:85-227) end to end on the toy ULTRA dataset (tests/golden/ultra_toy_data = the
+    reference's tests/data, stored as data): NA + DNN[32,16] + DirectLabelFeed, batch 8, a checkpoint every 3 steps,
+    --max_train_iteration 4 (the stop test only runs at checkpoint boundaries: 6 steps, 2 checkpoints).  Records the
+    initial weights (so that the counterpart can be teacher-forced), every step's loss, what was printed at each
+    checkpoint (global step, averaged loss, merged validation metrics) and every state_dict handed to torch.save."""
+    import runpy
+    import tempfile
+    data_dir = os.path.join(HERE, "ultra_toy_data") + "/"
+    tmp = tempfile.mkdtemp(prefix="ultr_driver_")
+    settings = {
+        "train_input_feed": "ultra.input_layer.DirectLabelFeed", "train_input_hparams": "",
+        "valid_input_feed": "ultra.input_layer.DirectLabelFeed", "valid_input_hparams": "",
+        "test_input_feed": "ultra.input_layer.DirectLabelFeed", "test_input_hparams": "",
+        "ranking_model": "ultra.ranking_model.DNN", "ranking_model_hparams": "hidden_layer_sizes=[32, 16]",
+        "learning_algorithm": "ultra.learning_algorithm.NavieAlgorithm", "learning_algorithm_hparams": "",
+        "metrics": ["mrr", "ndcg"], "metrics_topn": [1, 3, 5, 10], "objective_metric": "ndcg_10",
+    }
+    sf = os.path.join(tmp, "settings.json")
+    json.dump(settings, open(sf, "w"))
+    argv = ["--data_dir", data_dir, "--setting_file", sf, "--model_dir", tmp + "/model/", "--output_dir", tmp + "/out/",
+            "--batch_size", "8", "--max_train_iteration", "4", "--steps_per_checkpoint", "3"]
+    os.makedirs(tmp + "/model/", exist_ok=True)
+    torch.manual_seed(seed)
+    random.seed(seed)
+    np.random.seed(seed)
+    cls = ultra.learning_algorithm.NavieAlgorithm
+    rec = {"init": None, "losses": [], "saves": []}
+    orig_train, orig_save = cls.train, torch.save
+
+    def train(self, input_feed):
+        if rec["init"] is None:
+            rec["init"] = flat_state(self.model)
+        out = orig_train(self, input_feed)
+        rec["losses"].append(float(out[0]))
+        return out
+
+    def save(obj, path, *a, **k):
+        rec["saves"].append((len(rec["losses"]), {kk: vv.detach().cpu().numpy().copy() for kk, vv in obj.items()}))
+        return orig_save(obj, path, *a, **k)
+
+    cls.train, torch.save = train, save
+    buf = io.StringIO()
+    old_argv = sys.argv
+    try:
+        sys.argv = ["main.py"] + argv
+        with contextlib.redirect_stdout(buf):
+            runpy.run_path(os.path.join(REF, "main.py"), run_name="__main__")
+    finally:
+        sys.argv = old_argv
+        cls.train, torch.save = orig_train, orig_save
+    # parse what the driver printed at each checkpoint
+    history, cur = [], None
+    for line in buf.getvalue().splitlines():
+        if line.startswith("global step "):
+            tok = line.split()
+            cur = {"global_step": int(tok[2]), "loss": float(tok[-1]), "metrics": {}}
+            history.append(cur)
+        elif cur is not None:
+            tok = line.split()
+            if len(tok) == 2 and tok[0].rsplit("_", 1)[-1].isdigit() and ":" not in tok[0]:
+                try:
+                    cur["metrics"][tok[0]] = float(tok[1])
+                except ValueError:
+                    pass
+    out = {"meta": json.dumps({"name": name, "seed": seed, "argv": argv[6:], "settings": settings, "history": history,
+                               "save_steps": [s for s, _ in rec["saves"]], "n_steps": len(rec["losses"]),
+                               "param_keys": list(rec["init"].keys())})}
+    out["losses"] = np.asarray(rec["losses"], np.float64)
+    for k, v in rec["init"].items():
+        out["init_" + k] = v
+    for i, (_, sd) in enumerate(rec["saves"]):
+        for k, v in sd.items():
+            out["save%d_%s" % (i, k)] = v
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, "steps", len(rec["losses"]), "checkpoints at", [s for s, _ in rec["saves"]], history)
+
+
 CASES = {
     "feeds_toy": lambda u: run_feed_case(u, "feeds_toy"),
+    # the driver itself (main.py) on the toy dataset: losses, checkpoint schedule, printed metrics, saved tensors
+    "driver_toy": lambda u: run_driver_case(u, "driver_toy"),
     # tiny, two teacher-forced steps each
     "na_tiny": lambda u: run_train_case(u, "na_tiny", "na", 136, 10, 8, [32, 16], 2, 11),
     "ipw_tiny": lambda u: run_train_case(u, "ipw_tiny", "ipw", 136, 10, 8, [32, 16], 2, 12),

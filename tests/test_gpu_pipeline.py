@@ -73,3 +73,59 @@ def test_training_improves_ndcg(tmp_path):
     model, history = driver.main(argv)
     assert history[-1][1] < history[0][1]  # training loss falls
     assert history[-1][2]["ndcg_10"] >= history[0][2]["ndcg_10"] - 0.02
+
+
+def test_driver_matches_the_reference_run(tmp_path, monkeypatch):
+    """The driver pinned to the reference's own main.py: tests/golden/driver_toy.npz holds a seeded run of the
+    reference driver on this toy dataset - initial weights, the loss of every step, what it printed at each checkpoint and
+    every state_dict it saved.  Same seed, same settings (class paths swapped to the plugin package), the reference's
+    initial weights loaded through the driver's own checkpoint path: the first step is teacher-forced (loss to 1e-5), the
+    step count, the checkpoint schedule and the stop rule are exact, later steps / metrics / saved tensors agree to the
+    fp32 trajectory band."""
+    from ultra_pytorch_amd import main as driver
+    from ultra_pytorch_amd.learning_algorithm import NavieAlgorithm
+    d = np.load(os.path.join(GOLDEN, "driver_toy.npz"))
+    m = json.loads(str(d["meta"]))
+    s = dict(m["settings"])
+    for k in ("train_input_feed", "valid_input_feed", "test_input_feed", "ranking_model", "learning_algorithm"):
+        s[k] = s[k].replace("ultra.", "ultra_pytorch_amd.", 1)
+    sf = os.path.join(str(tmp_path), "settings.json")
+    json.dump(s, open(sf, "w"))
+    model_dir = str(tmp_path) + "/model/"
+    os.makedirs(model_dir)
+    init = {k: torch.from_numpy(d["init_" + k].copy()) for k in m["param_keys"]}
+    ckpt = os.path.join(model_dir, "%s.ckpt" % s["learning_algorithm"])
+    torch.save(init, ckpt)  # create_model loads it: the run starts from the reference's initial weights
+    losses, saves = [], []
+    orig_train, orig_save = NavieAlgorithm.train, torch.save
+
+    def train(self, feed):
+        out = orig_train(self, feed)
+        losses.append(float(out[0]))
+        return out
+
+    def save(obj, path, *a, **k):
+        saves.append((len(losses), {kk: vv.detach().cpu().numpy().copy() for kk, vv in obj.items()}))
+        return orig_save(obj, path, *a, **k)
+
+    monkeypatch.setattr(NavieAlgorithm, "train", train)
+    monkeypatch.setattr(torch, "save", save)
+    random.seed(m["seed"])
+    torch.manual_seed(m["seed"])
+    np.random.seed(m["seed"])
+    argv = ["--data_dir", DATA, "--setting_file", sf, "--model_dir", model_dir, "--output_dir", str(tmp_path) + "/out/"] + m["argv"]
+    model, history = driver.main(argv)
+    ref_losses = d["losses"]
+    assert len(losses) == m["n_steps"] == len(ref_losses)                     # stop rule: only at checkpoint boundaries
+    assert abs(losses[0] - ref_losses[0]) <= 1e-5 * max(1.0, abs(ref_losses[0]))  # teacher-forced first step
+    np.testing.assert_allclose(losses, ref_losses, rtol=2e-3)                # fp32 trajectory band afterwards
+    assert [h[0] for h in history] == [h["global_step"] for h in m["history"]]
+    assert [st for st, _ in saves] == m["save_steps"]                        # checkpoint schedule (objective_metric rule)
+    for (_, loss, metrics), ref in zip(history, m["history"]):
+        assert abs(loss - ref["loss"]) <= 2e-3 * max(1.0, abs(ref["loss"]))
+        assert set(metrics) == set(ref["metrics"])
+        for k, v in ref["metrics"].items():
+            assert abs(metrics[k] - v) <= 1e-6 + (0.0 if k.startswith("ndcg") or k.startswith("mrr") else 1e-3), (k, metrics[k], v)
+    for i, (_, sd) in enumerate(saves):
+        for k in m["param_keys"]:
+            np.testing.assert_allclose(sd[k], d["save%d_%s" % (i, k)], rtol=5e-3, atol=5e-4, err_msg=k)

@@ -174,3 +174,31 @@ def test_a14_ranklist_scores_are_plain_numbers(tmp_path):
     lines = open(str(tmp_path) + "/t.ranklist").read().strip().split("\n")
     assert len(lines) == 2 and "tensor" not in lines[0]
     assert lines[0].split()[2] == "d1" and float(lines[0].split()[4]) == 0.75
+
+
+def test_reference_structure_variants_equal_the_vectorised_oracle():
+    """bench.py times the oracle in the reference's own structure as well: the 2-level Python pair loop of
+    PairDebias and DLA's per-step torch.optim.Adagrad objects.  Both must be the same computation."""
+    rng = np.random.RandomState(0)
+    F_, hidden, B, L = 9, [7, 5], 5, 4
+    feats = rng.uniform(-1, 1, size=(B * L, F_)).astype(np.float32)
+    ids = np.arange(B * L, dtype=np.int64).reshape(B, L).T.copy()
+    clicks = (rng.uniform(size=(L, B)) < 0.5).astype(np.float32)
+    clicks[0, :] = np.arange(B) % 2
+    clicks[1, :] = 1 - clicks[0, :]
+    p0 = O.init_params(F_, hidden, seed=2)
+    s0 = (0.01 * rng.uniform(size=p0.shape)).astype(np.float32)
+    tp, tm = np.linspace(0.9, 1.1, L).astype(np.float32), np.linspace(1.1, 0.9, L).astype(np.float32)
+    a = O.pairdebias_step(p0, s0, tp, tm, F_, hidden, feats, ids, clicks)
+    b = O.pairdebias_step(p0, s0, tp, tm, F_, hidden, feats, ids, clicks, loops=True)
+    assert abs(a["loss"] - b["loss"]) <= 1e-5 * abs(a["loss"])
+    np.testing.assert_allclose(a["grads"], b["grads"], rtol=1e-4, atol=1e-5 * np.abs(a["grads"]).max())
+    np.testing.assert_allclose(a["t_plus"], b["t_plus"], atol=1e-6)
+    np.testing.assert_allclose(a["t_minus"], b["t_minus"], atol=1e-6)
+    q0 = (0.1 * rng.randn(L + 1)).astype(np.float32)
+    c = O.dla_step(p0, q0, F_, hidden, feats, ids, clicks)
+    d = O.dla_step(p0, q0, F_, hidden, feats, ids, clicks, fresh_optimizers=True)
+    sel = np.abs(c["grads"]) > 1e-6 * np.abs(c["grads"]).max()  # the sign-like update is ill-conditioned at g ~ 0
+    np.testing.assert_allclose(c["params"][sel], d["params"][sel], atol=2e-6)
+    np.testing.assert_allclose(c["prop_params"], d["prop_params"], atol=2e-6)
+    assert abs(c["norm"] - d["norm"]) < 1e-5 and abs(c["prop_norm"] - d["prop_norm"]) < 1e-6
