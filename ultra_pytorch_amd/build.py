@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libultr_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc"]
-LIBS = ["-L/opt/rocm/lib", "-lrocblas"]  # plain GEMMs of the SetRank model (ultr_setrank.hip)
+LIBS = []  # no vendor BLAS: every GEMM is the library's own matrix-core code (ultr_gemm.h)
 
 
 def _hipcc():

@@ -1,0 +1,391 @@
+// ultr_gemm.h — LDS-tiled fp32 GEMM on the matrix cores for the THROUGHPUT regime (many rows per launch).
+//
+//   C[R x N] = epilogue( A'[R x K] . B[K x N] )        v_mfma_f32_16x16x4_f32, exact fp32
+//
+// The fused per-workgroup kernels of ultr_dnn.hip own 16 rows end to end and re-stream every weight matrix per 16 rows
+// (8 flops per weight byte): right for a few thousand rows, where latency decides, but capped near 38 % of the matrix
+// peak at tens of thousands of rows (round-1 profiles).  Here a workgroup owns a 128 x BN tile of ONE layer's output:
+// every A and B element staged in LDS feeds 128 / BN outputs, the activations make one HBM round trip per layer
+// (fine: >= 100 flops per byte at these shapes), and the per-row work that needs whole rows (LayerNorm statistics,
+// LayerNorm backward) lives in separate HBM-bound row kernels (ultr_dnn_big.hip).
+//
+// Structure (one k-tile = 32 contraction steps):
+//   * 256 threads = 4 waves as WM x WN; a wave owns (16 RT) x 64 outputs in RT x 4 accumulator tiles;
+//   * A tile [BM][32 (+8 pad)] and B tile in LDS, double-buffered; the NEXT tile's global loads are issued into
+//     registers before the MFMAs of the current one and written to the other LDS buffer after them: ONE barrier per
+//     k-tile, global latency hidden behind 128 MFMAs per wave;
+//   * fragments: A by ds_read_b128 along k (lane (i, q) holds A[row i][k0 + 4q .. +3] = four k-steps); B either
+//       k-major  B[k][n]  (NN: weights stored [K][N]; the dgrad's W[M][K] with M as the contraction):  one b128 read
+//                         B[k0 + 4q + s][n0 + 4i .. +3] per k-step s feeds FOUR interleaved column tiles, or
+//       n-major  B[n][k]  (NT: nn.Linear's weight [out][in] read as it is stored):  one b128 read B[n0 + 16t + i][k0 + 4q ..]
+//                         per column tile t feeds four k-steps;
+//     either way 2 RT.. 8 LDS reads per 16 RT MFMAs;
+//   * the A operand is produced by a functor at staging time (plain rows, rows gathered by document id, LayerNorm
+//     applied on the fly from per-row statistics), the epilogue is a functor applied to float4 pieces of the output
+//     tile after a transposing trip through LDS (coalesced 16-byte stores for both B layouts; bias / activation /
+//     mask / accumulate ride there);
+//   * out-of-range rows / columns / contraction indices are zeros at staging (buffer-resource bounds checks), stores
+//     are masked: any R, N, K (K % 4 == 0 and 16-byte aligned rows for the vector loads; checked by the launcher).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ultr_device.h"
+
+namespace ugemm {
+
+#ifdef UGEMM_DEBUG_CYC
+__device__ unsigned long long g_ugemm_cyc[4096], g_ugemm_xcc[4096];
+#endif
+constexpr int BK = 32;        // contraction steps per k-tile
+constexpr int LDA = BK + 8;   // LDS row stride of k-contiguous tiles (A, n-major B): stride = 8 (mod 16) floats is the
+                              // conflict-free one for ds_read_b128 with 16 rows x 4 k-groups per wave (its 4 x 16 lane groups)
+
+// ---- A-operand producers ------------------------------------------------------------------------------------------------
+// A thread stages the same rows (and the same four contraction columns k4 of every k-tile) throughout the k loop:
+//   row(r)            once per staged row before the loop: whatever is per-row (source offset, LayerNorm statistics);
+//   raw(ctx, k)       ISSUES the global load of [k, k+4) of that row for one k-tile (no arithmetic on the result here:
+//                     the load must stay in flight behind the current tile's MFMAs);
+//   cols(k) / finish  per-column operands and the arithmetic, applied when the registers are written to LDS.
+struct APlain {  // A[r][k], row stride lda; rows >= R and k >= K read as zero
+  const float* a;
+  int64_t R;
+  int K, lda;
+  struct Row { unsigned off; };
+  struct Cols {};
+  __device__ __forceinline__ Row row(int64_t r) const { return Row{r < R ? (unsigned)(r * lda * 4) : ULTR_OOB}; }
+  __device__ __forceinline__ float4 raw(const Row& c, int k) const {
+    return buf_ld4(make_src(a, R * lda), (c.off != ULTR_OOB && k < K) ? c.off + (unsigned)k * 4u : ULTR_OOB);
+  }
+  __device__ __forceinline__ Cols cols(int) const { return Cols{}; }
+  __device__ __forceinline__ float4 finish(const Row&, const Cols&, int, float4 v) const { return v; }
+};
+// LayerNorm applied on the fly: (x - mean[r]) * rstd[r] * gamma[k] + beta[k]; x rows either consecutive (ids == nullptr)
+// or gathered through the feed's position-major document ids (row r = b * L + l reads x[ids[l * B + b]]; PAD = zero row)
+struct ALayerNorm {
+  const float* x;         // [x_rows][K]
+  const float* gb;        // the flat parameter vector (gamma at g_off, beta at b_off), gb_floats long
+  int64_t x_rows, gb_floats;
+  const float* mean;      // [R]
+  const float* rstd;      // [R]
+  const int32_t* ids;     // nullptr: row r of x
+  int64_t R, n_docs, g_off, b_off;
+  int K, B, L;
+  struct Row { unsigned off; float mean, rstd; bool in; };
+  struct Cols { float4 g, b; };
+  __device__ __forceinline__ Row row(int64_t r) const {
+    Row c;
+    c.in = r < R;
+    c.mean = c.in ? mean[r] : 0.f;
+    c.rstd = c.in ? rstd[r] : 0.f;
+    int64_t src = r;
+    bool live = c.in;
+    if (ids != nullptr && c.in) {
+      const uint32_t rr = (uint32_t)r;
+      const int32_t id = ids[(int64_t)(rr % (uint32_t)L) * B + rr / (uint32_t)L];
+      live = id >= 0 && id < n_docs;
+      src = id;
+    }
+    c.off = live ? (unsigned)(src * K * 4) : ULTR_OOB;
+    return c;
+  }
+  __device__ __forceinline__ float4 raw(const Row& c, int k) const {
+    return buf_ld4(make_src(x, x_rows * K), (c.off != ULTR_OOB && k < K) ? c.off + (unsigned)k * 4u : ULTR_OOB);
+  }
+  __device__ __forceinline__ Cols cols(int k) const {
+    Cols o;
+    const Src g = make_src(gb, gb_floats);
+    o.g = buf_ld4(g, k < K ? (unsigned)((g_off + k) * 4) : ULTR_OOB);
+    o.b = buf_ld4(g, k < K ? (unsigned)((b_off + k) * 4) : ULTR_OOB);
+    return o;
+  }
+  // rows past R and columns past K must come out as exact zeros (they meet finite B values): gamma = beta = 0 past K,
+  // rstd = 0 and beta masked past R
+  __device__ __forceinline__ float4 finish(const Row& c, const Cols& o, int, float4 v) const {
+    const float m = c.in ? 1.f : 0.f;
+    return make_float4((v.x - c.mean) * c.rstd * o.g.x + m * o.b.x, (v.y - c.mean) * c.rstd * o.g.y + m * o.b.y,
+                       (v.z - c.mean) * c.rstd * o.g.z + m * o.b.z, (v.w - c.mean) * c.rstd * o.g.w + m * o.b.w);
+  }
+};
+
+// ---- epilogues: called with the global row, the first of four consecutive columns (all < N unless noted) -------------
+// y = act(c + bias); act: -1 none, 0 elu, 1 relu.  n_valid = columns of this piece that exist (1..4)
+struct EBiasAct {
+  float* y;
+  const float* bias;  // may be nullptr
+  int ldy, act;
+  __device__ __forceinline__ void operator()(int64_t r, int c, float4 v, int n_valid) const {
+    float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < n_valid) {
+        float t = o[j] + (bias != nullptr ? bias[c + j] : 0.f);
+        o[j] = (act < 0) ? t : act_fwd(t, act);
+      }
+    }
+    float* dst = y + r * ldy + c;
+    if (n_valid == 4 && ((ldy & 3) == 0)) st4(dst, make_float4(o[0], o[1], o[2], o[3]));
+    else
+      for (int j = 0; j < n_valid; ++j) dst[j] = o[j];
+  }
+};
+// y = (accumulate ? y : 0) + c, then (mask != nullptr) zeroed where mask <= 0 (ReLU backward through the saved output)
+struct EStore {
+  float* y;
+  const float* mask;  // same shape as y, or nullptr
+  int ldy, accumulate;
+  __device__ __forceinline__ void operator()(int64_t r, int c, float4 v, int n_valid) const {
+    float o[4] = {v.x, v.y, v.z, v.w};
+    float* dst = y + r * ldy + c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < n_valid) {
+        if (accumulate) o[j] += dst[j];
+        if (mask != nullptr && !(mask[r * ldy + c + j] > 0.f)) o[j] = 0.f;
+      }
+    }
+    if (n_valid == 4 && ((ldy & 3) == 0)) st4(dst, make_float4(o[0], o[1], o[2], o[3]));
+    else
+      for (int j = 0; j < n_valid; ++j) dst[j] = o[j];
+  }
+};
+
+struct Dims {
+  int64_t R;  // rows of A and C
+  int N, K;   // columns of C, contraction length
+  int ldb;    // row stride of B: N-ish for k-major ([K][ldb]), K-ish for n-major ([N][ldb])
+};
+
+template <int BM, int BN, int WM, int WN, bool B_NMAJOR>
+struct Cfg {
+  static constexpr int NT = WM * WN * 64;
+  static constexpr int RT = BM / WM / 16;
+  static constexpr int CT = BN / WN / 16;
+  static_assert(CT == 4, "a wave owns 64 output columns (four column tiles)");
+  static constexpr int LDB = B_NMAJOR ? LDA : BN;           // floats per LDS row of the B tile
+  static constexpr int A_FLOATS = BM * LDA;
+  static constexpr int B_FLOATS = B_NMAJOR ? BN * LDA : BK * BN;
+  static constexpr int LDC = BN + 4;
+  static constexpr int STAGE_FLOATS = 2 * (A_FLOATS + B_FLOATS);
+  static constexpr int C_FLOATS = BM * LDC;
+  static constexpr int LDS_FLOATS = (B_NMAJOR && C_FLOATS > STAGE_FLOATS) ? C_FLOATS : STAGE_FLOATS;
+  static constexpr int A_LOADS = BM * (BK / 4) / NT;        // float4 per thread per k-tile
+  static constexpr int B_LOADS = (B_NMAJOR ? BN * (BK / 4) : BK * (BN / 4)) / NT;
+  static_assert(BM * (BK / 4) % NT == 0 && (BK * BN / 4) % NT == 0, "staging divides evenly");
+};
+
+template <int BM, int BN, int WM, int WN, bool B_NMAJOR, class AProd, class Epi>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(Dims d, AProd aprod, const float* __restrict__ Bg, Epi epi) {
+  using C = Cfg<BM, BN, WM, WN, B_NMAJOR>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                        // [2][BM][LDA]
+  float* Bs = smem + 2 * C::A_FLOATS;      // [2][...]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, q = lane >> 4;
+  const int wr = (wave / WN) * (BM / WM), wc = (wave % WN) * (BN / WN);  // wave origin inside the tile
+  // XCD-aware tile order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs, so consecutive ids
+  // should NOT be neighbours; give every XCD a contiguous band of row blocks (they share the B panel in that XCD's L2
+  // and walk A rows no other XCD touches)
+  const int ncb = (d.N + BN - 1) / BN;
+  const int nrb = (int)((d.R + BM - 1) / BM);
+  const int total = nrb * ncb;
+  int wg = blockIdx.x;
+  {
+    const int per = (total + 7) / 8;
+    const int x = wg & 7, k = wg >> 3;
+    const int cand = x * per + k;
+    if (per * 8 == total) wg = cand;  // only when the grid splits evenly; otherwise keep the plain order
+  }
+  const int rb = wg / ncb, cb = wg - rb * ncb;
+  const int64_t r0 = (int64_t)rb * BM;
+  const int n0 = cb * BN;
+  const Src bsrc = make_src(Bg, B_NMAJOR ? (int64_t)d.N * d.ldb : (int64_t)d.K * d.ldb);
+
+  f32x4 acc[C::RT][C::CT];
+#pragma unroll
+  for (int rt = 0; rt < C::RT; ++rt)
+#pragma unroll
+    for (int t = 0; t < C::CT; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float4 areg[C::A_LOADS], breg[C::B_LOADS];
+  // a thread stages rows (tid >> 3) + (NT / 8) j, always the four contraction columns k4 of a k-tile
+  const int k4 = (tid & 7) * 4;
+  typename AProd::Row arow[C::A_LOADS];
+#pragma unroll
+  for (int j = 0; j < C::A_LOADS; ++j) arow[j] = aprod.row(r0 + ((tid + C::NT * j) >> 3));
+  typename AProd::Cols acol;
+  auto load_tile = [&](int k0) {
+    acol = aprod.cols(k0 + k4);
+#pragma unroll
+    for (int j = 0; j < C::A_LOADS; ++j) areg[j] = aprod.raw(arow[j], k0 + k4);
+#pragma unroll
+    for (int j = 0; j < C::B_LOADS; ++j) {
+      const int idx = tid + C::NT * j;
+      if constexpr (B_NMAJOR) {
+        const int n = idx >> 3, k4 = (idx & 7) * 4;
+        const bool ok = n0 + n < d.N && k0 + k4 < d.K;
+        breg[j] = buf_ld4(bsrc, ok ? (unsigned)(((int64_t)(n0 + n) * d.ldb + k0 + k4) * 4) : ULTR_OOB);
+      } else {
+        const int kk = idx / (BN / 4), c4 = (idx - kk * (BN / 4)) * 4;
+        const bool ok = k0 + kk < d.K && n0 + c4 < d.N;
+        breg[j] = buf_ld4(bsrc, ok ? (unsigned)(((int64_t)(k0 + kk) * d.ldb + n0 + c4) * 4) : ULTR_OOB);
+      }
+    }
+    // keep the staging loads ABOVE the MFMAs of the current tile (hipcc otherwise sinks each load to its first use)
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto store_tile = [&](int buf, int k0) {
+    float* Ab = As + buf * C::A_FLOATS;
+    float* Bb = Bs + buf * C::B_FLOATS;
+#pragma unroll
+    for (int j = 0; j < C::A_LOADS; ++j) {
+      const int idx = tid + C::NT * j;
+      st4(Ab + (idx >> 3) * LDA + k4, aprod.finish(arow[j], acol, k0 + k4, areg[j]));
+    }
+#pragma unroll
+    for (int j = 0; j < C::B_LOADS; ++j) {
+      const int idx = tid + C::NT * j;
+      if constexpr (B_NMAJOR) st4(Bb + (idx >> 3) * LDA + (idx & 7) * 4, breg[j]);
+      else {
+        const int kk = idx / (BN / 4), c4 = (idx - kk * (BN / 4)) * 4;
+        st4(Bb + kk * C::LDB + c4, breg[j]);
+      }
+    }
+  };
+  auto compute = [&](int buf) {
+    const float* Ab = As + buf * C::A_FLOATS + (wr + i) * LDA + 4 * q;
+    const float* Bb = Bs + buf * C::B_FLOATS;
+    // every fragment of the k-tile is requested before the first MFMA: one LDS round trip per 32 contraction steps is
+    // exposed instead of one per 16 (2 x (RT + 4) x 4 registers)
+    float4 a[2][C::RT], b[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int rt = 0; rt < C::RT; ++rt) a[h][rt] = ld4(Ab + rt * 16 * LDA + 16 * h);
+      if constexpr (B_NMAJOR) {
+#pragma unroll
+        for (int t = 0; t < C::CT; ++t) b[h][t] = ld4(Bb + (wc + 16 * t + i) * LDA + 16 * h + 4 * q);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) b[h][s] = ld4(Bb + (16 * h + 4 * q + s) * C::LDB + wc + 4 * i);
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if constexpr (B_NMAJOR) {
+#pragma unroll
+        for (int rt = 0; rt < C::RT; ++rt) {
+          const float av[4] = {a[h][rt].x, a[h][rt].y, a[h][rt].z, a[h][rt].w};
+#pragma unroll
+          for (int t = 0; t < C::CT; ++t) {
+            const float bv[4] = {b[h][t].x, b[h][t].y, b[h][t].z, b[h][t].w};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[rt][t] = mfma16(av[s], bv[s], acc[rt][t]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const float bv[4] = {b[h][s].x, b[h][s].y, b[h][s].z, b[h][s].w};
+#pragma unroll
+          for (int rt = 0; rt < C::RT; ++rt) {
+            const float as = (s == 0) ? a[h][rt].x : (s == 1) ? a[h][rt].y : (s == 2) ? a[h][rt].z : a[h][rt].w;
+#pragma unroll
+            for (int t = 0; t < C::CT; ++t) acc[rt][t] = mfma16(as, bv[t], acc[rt][t]);
+          }
+        }
+      }
+    }
+  };
+
+  const int nk = (d.K + BK - 1) / BK;
+  load_tile(0);
+  store_tile(0, 0);
+  lds_barrier();
+#ifdef UGEMM_DEBUG_CYC
+  const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef UGEMM_DEBUG_NOSTAGE  // experiment: MFMA + fragment reads only
+  for (int t = 0; t < nk; ++t) compute(t & 1);
+#else
+  for (int t = 0; t < nk; ++t) {
+    if (t + 1 < nk) load_tile((t + 1) * BK);
+#ifndef UGEMM_DEBUG_NOMFMA
+    compute(t & 1);
+#endif
+    if (t + 1 < nk) store_tile((t + 1) & 1, (t + 1) * BK);
+    lds_barrier();
+  }
+#endif
+#ifdef UGEMM_DEBUG_CYC
+  if (tid == 0) {
+    g_ugemm_cyc[blockIdx.x % 4096] = __builtin_amdgcn_s_memtime() - dbg_t0;
+    g_ugemm_xcc[blockIdx.x % 4096] = dbg_t0;
+  }
+#endif
+  // ---- epilogue -----------------------------------------------------------------------------------------------------------
+  if constexpr (!B_NMAJOR) {
+    // k-major B: a lane already holds four consecutive output columns of a row (the four interleaved column tiles):
+    // straight to the functor, 256 contiguous bytes per 16 lanes
+#pragma unroll
+    for (int rt = 0; rt < C::RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = r0 + wr + 16 * rt + 4 * q + r;
+        const int c = n0 + wc + 4 * i;
+        if (row < d.R && c < d.N) {
+          const int nv = d.N - c < 4 ? d.N - c : 4;
+          epi(row, c, make_float4(acc[rt][0][r], acc[rt][1][r], acc[rt][2][r], acc[rt][3][r]), nv);
+        }
+      }
+  } else {
+    // n-major B: a lane holds one column of four tiles; transpose through LDS into float4 pieces
+    float* Cs = smem;
+#pragma unroll
+    for (int rt = 0; rt < C::RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wr + 16 * rt + 4 * q + r;
+#pragma unroll
+        for (int t = 0; t < C::CT; ++t) Cs[row * C::LDC + wc + 16 * t + i] = acc[rt][t][r];
+      }
+    lds_barrier();
+    constexpr int PIECES = BM * (BN / 4);
+#pragma unroll 4
+    for (int idx = tid; idx < PIECES; idx += C::NT) {
+      const int row = idx / (BN / 4), c4 = (idx - row * (BN / 4)) * 4;
+      const int64_t r = r0 + row;
+      const int c = n0 + c4;
+      if (r < d.R && c < d.N) {
+        const int nv = d.N - c < 4 ? d.N - c : 4;
+        epi(r, c, ld4(Cs + row * C::LDC + c4), nv);
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, bool B_NMAJOR, class AProd, class Epi>
+inline hipError_t launch(const Dims& d, const AProd& aprod, const float* B, const Epi& epi, hipStream_t st) {
+  using C = Cfg<BM, BN, WM, WN, B_NMAJOR>;
+  auto kern = gemm_kernel<BM, BN, WM, WN, B_NMAJOR, AProd, Epi>;
+  const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
+  static bool attr = false;  // one per template instance
+  if (!attr && lds > 64 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  const int64_t nrb = (d.R + BM - 1) / BM;
+  const int ncb = (d.N + BN - 1) / BN;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(nrb * ncb)), dim3(C::NT), lds, st, d, aprod, B, epi);
+  return hipGetLastError();
+}
+
+// C = epi(A' . B): picks the 128 x 128 tile (2 x 2 waves) or, for narrow outputs, 128 x 64 (4 x 1 waves)
+template <bool B_NMAJOR, class AProd, class Epi>
+inline hipError_t run(const Dims& d, const AProd& aprod, const float* B, const Epi& epi, hipStream_t st) {
+  if (d.N > 64) return launch<128, 128, 2, 2, B_NMAJOR>(d, aprod, B, epi, st);
+  return launch<128, 64, 4, 1, B_NMAJOR>(d, aprod, B, epi, st);
+}
+
+}  // namespace ugemm

@@ -10,13 +10,13 @@
 // reference's state_dict order (ultr_setrank_param_offsets).  fp16 MFMA attention (BASELINE config 5) is the next
 // step; fp32 keeps the 1e-5 parity bar of the rest of the path.
 #include <hip/hip_runtime.h>
-#include <rocblas/rocblas.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include "../../include/ultr_hip.h"
 #include "ultr_device.h"
+#include "ultr_gemm.h"
 #include "ultr_plan.h"
 
 #define SR_EPS 1e-6f  // nn.LayerNorm(eps=1e-6) everywhere in SetRank.py (:100-101, :134)
@@ -1091,53 +1091,96 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
-rocblas_handle g_handle = nullptr;
-
-int blas_setup(hipStream_t st) {
-  if (g_handle == nullptr) {
-    if (rocblas_create_handle(&g_handle) != rocblas_status_success) return ULTR_E_UNSUPPORTED;
-    rocblas_set_atomics_mode(g_handle, rocblas_atomics_not_allowed);
-    rocblas_set_pointer_mode(g_handle, rocblas_pointer_mode_host);
+// The token-local Linear layers (round 1: rocBLAS sgemm + separate bias / ReLU / mask passes) run on the library's own
+// LDS-tiled matrix-core GEMM (ultr_gemm.h) with the bias, the ReLU, the ReLU mask of the backward and the accumulation
+// into an existing gradient fused into the epilogue.  Shapes the vector path cannot take (contraction or row length not
+// a multiple of 4, unaligned bases, single-column outputs) go through plain one-thread-per-output kernels: they only
+// occur in toy configurations and for the width-1 scorer.
+__global__ __launch_bounds__(256) void sr_gemm_xwT_ref_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                              const float* __restrict__ bias, float* __restrict__ Y, int64_t T,
+                                                              int K, int M, int relu) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= T * M) return;
+  const int64_t t = e / M;
+  const int m = (int)(e - t * M);
+  float acc = 0.f;
+  for (int k = 0; k < K; ++k) acc = fmaf(X[t * K + k], W[(int64_t)m * K + k], acc);
+  if (bias != nullptr) acc += bias[m];
+  Y[e] = relu ? fmaxf(acc, 0.f) : acc;
+}
+__global__ __launch_bounds__(256) void sr_gemm_dyw_ref_kernel(const float* __restrict__ dY, const float* __restrict__ W,
+                                                              float* __restrict__ dX, const float* __restrict__ mask, int64_t T,
+                                                              int K, int M, int accumulate) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= T * K) return;
+  const int64_t t = e / K;
+  const int k = (int)(e - t * K);
+  float acc = accumulate ? dX[e] : 0.f;
+  for (int m = 0; m < M; ++m) acc = fmaf(dY[t * M + m], W[(int64_t)m * K + k], acc);
+  if (mask != nullptr && !(mask[e] > 0.f)) acc = 0.f;
+  dX[e] = acc;
+}
+// part[chunk][m * K + k] = sum over the chunk's rows of dY[t][m] X[t][k]
+__global__ __launch_bounds__(256) void sr_gemm_dyTx_ref_kernel(const float* __restrict__ dY, const float* __restrict__ X,
+                                                               float* __restrict__ part, int64_t rows, int K, int M) {
+  const int64_t t0 = (int64_t)blockIdx.y * rows;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < M * K; e += gridDim.x * 256) {
+    const int m = e / K, k = e - m * K;
+    float acc = 0.f;
+    for (int64_t t = t0; t < t0 + rows; ++t) acc = fmaf(dY[t * M + m], X[t * K + k], acc);
+    part[(int64_t)blockIdx.y * M * K + e] = acc;
   }
-  return rocblas_set_stream(g_handle, st) == rocblas_status_success ? 0 : ULTR_E_UNSUPPORTED;
 }
-// row-major  Y[T, M] (+)= X[T, K] . W[M, K]^T
-int gemm_xwT(const float* X, const float* W, float* Y, int64_t T, int K, int M, float beta) {
-  const float alpha = 1.0f;
-  return rocblas_sgemm(g_handle, rocblas_operation_transpose, rocblas_operation_none, M, (int)T, K, &alpha, W, K, X, K, &beta, Y,
-                       M) == rocblas_status_success ? 0 : ULTR_E_UNSUPPORTED;
+
+// activations (a, c) must be 16-byte aligned with rows a multiple of 4 floats (LDS staging and float4 stores); the weight
+// matrix only needs its natural 4-byte alignment: in SetRank's flat parameter vector every encoder matrix sits at an odd
+// float offset (the width-1 scorer bias precedes them), and buffer_load_dwordx4 takes dword-aligned addresses
+bool vec_ok(const void* a, const void* w, const void* c, int K, int ld_out) {
+  (void)w;
+  return K % 4 == 0 && ld_out % 4 == 0 && ((((uintptr_t)a | (uintptr_t)c) & 15) == 0);
 }
-// row-major  dX[T, K] (+)= dY[T, M] . W[M, K]
-int gemm_dyw(const float* dY, const float* W, float* dX, int64_t T, int K, int M, float beta) {
-  const float alpha = 1.0f;
-  return rocblas_sgemm(g_handle, rocblas_operation_none, rocblas_operation_none, K, (int)T, M, &alpha, W, K, dY, M, &beta, dX,
-                       K) == rocblas_status_success ? 0 : ULTR_E_UNSUPPORTED;
+// row-major  Y[T, M] = act(X[T, K] . W[M, K]^T + bias)      (bias may be NULL; relu 0 / 1)
+int gemm_xwT(const float* X, const float* W, const float* bias, float* Y, int64_t T, int K, int M, int relu, hipStream_t st) {
+  if (M >= 16 && vec_ok(X, W, Y, K, M) && T * (K > M ? K : M) * 4 < ((int64_t)1 << 31)) {
+    const ugemm::Dims d{T, M, K, K};
+    const ugemm::APlain a{X, T, K, K};
+    const ugemm::EBiasAct e{Y, bias, M, relu ? 1 : -1};
+    return ugemm::run<true>(d, a, W, e, st) == hipSuccess ? 0 : ULTR_E_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(sr_gemm_xwT_ref_kernel, dim3((unsigned)((T * M + 255) / 256)), dim3(256), 0, st, X, W, bias, Y, T, K, M, relu);
+  return 0;
 }
-// row-major  dW[M, K] = dY[T, M]^T . X[T, K]: `split` equal row chunks as ONE strided-batched sgemm into partials,
-// folded in canonical order (split == 1: straight into dW)
+// row-major  dX[T, K] = (accumulate ? dX : 0) + dY[T, M] . W[M, K], then zeroed where mask <= 0 (mask may be NULL)
+int gemm_dyw(const float* dY, const float* W, float* dX, const float* mask, int64_t T, int K, int M, int accumulate, hipStream_t st) {
+  if (M % 4 == 0 && K >= 16 && vec_ok(dY, W, dX, K, K) && (mask == nullptr || ((uintptr_t)mask & 15) == 0) &&
+      T * (K > M ? K : M) * 4 < ((int64_t)1 << 31)) {
+    const ugemm::Dims d{T, K, M, K};
+    const ugemm::APlain a{dY, T, M, M};
+    const ugemm::EStore e{dX, mask, K, accumulate};
+    return ugemm::run<false>(d, a, W, e, st) == hipSuccess ? 0 : ULTR_E_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(sr_gemm_dyw_ref_kernel, dim3((unsigned)((T * K + 255) / 256)), dim3(256), 0, st, dY, W, dX, mask, T, K, M, accumulate);
+  return 0;
+}
+// row-major  dW[M, K] = dY[T, M]^T . X[T, K] for the shapes sr_wgrad_kernel does not take: `wg_split` equal row chunks
+// into partials, folded in canonical order
 int gemm_dyTx(const SrPlan& p, const float* dY, const float* X, float* dW, int64_t T, int K, int M, float* ws, hipStream_t st) {
-  const float alpha = 1.0f, beta = 0.0f;
   const int S = p.wg_split;
-  if (S <= 1 || (int64_t)M * K < 64)
-    return rocblas_sgemm(g_handle, rocblas_operation_none, rocblas_operation_transpose, K, M, (int)T, &alpha, X, K, dY, M, &beta,
-                         dW, K) == rocblas_status_success ? 0 : ULTR_E_UNSUPPORTED;
   const int64_t rows = T / S;
   float* part = ws + p.ws_wg;
-  if (rocblas_sgemm_strided_batched(g_handle, rocblas_operation_none, rocblas_operation_transpose, K, M, (int)rows, &alpha, X, K,
-                                    rows * K, dY, M, rows * M, &beta, part, K, (int64_t)M * K, S) != rocblas_status_success)
-    return ULTR_E_UNSUPPORTED;
   const int len = M * K;
-  hipLaunchKernelGGL(sr_fold_kernel, dim3((len + 63) / 64), dim3(256), 0, st, (const float*)part, (int64_t)len, S, len, dW);
+  hipLaunchKernelGGL(sr_gemm_dyTx_ref_kernel, dim3((len + 255) / 256, S), dim3(256), 0, st, dY, X, part, rows, K, M);
+  fold(part, (int64_t)len, S, len, dW, st);
   return 0;
 }
 
 // dW = dY^T X and (db != NULL) db = column sums of dY.  Aligned shapes go through sr_wgrad_kernel; the rest through
-// rocBLAS + the column-sum kernels.
+// the plain chunked kernel + the column-sum kernels.
 void colsum(const SrPlan& p, const float* a, const float* s, const float* mean, const float* rstd, int W, int mode, float* ws,
             float* dst, hipStream_t st);
 void fold(const float* part, int64_t stride, int nparts, int len, float* dst, hipStream_t st);
 int wgrad(const SrPlan& p, const float* dY, const float* X, float* dW, float* db, int64_t T, int K, int M, float* ws, hipStream_t st) {
-  const bool ok = M % 4 == 0 && K % 4 == 0 && (((uintptr_t)dY | (uintptr_t)X) & 15) == 0 && getenv("ULTR_SR_BLAS_WGRAD") == nullptr;
+  const bool ok = M % 4 == 0 && K % 4 == 0 && (((uintptr_t)dY | (uintptr_t)X) & 15) == 0;
   if (!ok) {
     const int rc = gemm_dyTx(p, dY, X, dW, T, K, M, ws, st);
     if (rc != 0) return rc;
@@ -1307,7 +1350,6 @@ extern "C" int ultr_setrank_forward(const ultr_setrank_desc* c, const float* par
   if (L > 64 * SR_KPL) return ULTR_E_UNSUPPORTED;
   if (T > 0x7fffffff / 4) return ULTR_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  SR_CHECK(blas_setup(st));
   float* sv = (float*)saved;
   const unsigned rblk = (unsigned)((T + SR_ROWS - 1) / SR_ROWS);
   const int F = p.F, d = p.d, dff = p.dff;
@@ -1319,10 +1361,8 @@ extern "C" int ultr_setrank_forward(const ultr_setrank_desc* c, const float* par
     hipLaunchKernelGGL(sr_ln_fwd_kernel, dim3(rblk), dim3(SR_ROWS * 64), 0, st, features, (const float*)nullptr, (const float*)nullptr, docids, n_docs,
                        (int)batch, L, T, F, params + p.g_in, params + p.b_in, sv + p.sv_xg, sv + p.sv_xn0, sv + p.sv_mean_in,
                        sv + p.sv_rstd_in);
-  SR_CHECK(gemm_xwT(sv + p.sv_xn0, params + p.w1, sv + p.sv_h0, T, F, dff, 0.f));
-  bias_act(sv + p.sv_h0, params + p.b1, T, dff, 1, st);
-  SR_CHECK(gemm_xwT(sv + p.sv_h0, params + p.w2, sv + p.sv_x[0], T, dff, d, 0.f));
-  bias_act(sv + p.sv_x[0], params + p.b2, T, d, 0, st);
+  SR_CHECK(gemm_xwT(sv + p.sv_xn0, params + p.w1, params + p.b1, sv + p.sv_h0, T, F, dff, 1, st));
+  SR_CHECK(gemm_xwT(sv + p.sv_h0, params + p.w2, params + p.b2, sv + p.sv_x[0], T, dff, d, 0, st));
   const size_t lds_att = ((size_t)L * (p.dh + 1) + 4 * (size_t)L) * sizeof(float);
   if (lds_att > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(sr_attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1336,20 +1376,17 @@ extern "C" int ultr_setrank_forward(const ultr_setrank_desc* c, const float* par
     if (mfma_att) SR_CHECK(attn_fwd_mfma(p, x, batch, L, sv + p.sv_A[l], sv + p.sv_lse[l], st));
     else hipLaunchKernelGGL(sr_attn_fwd_kernel, dim3(batch, p.H), dim3(256), lds_att, st, x, L, d, p.dh, sv + p.sv_A[l]);
     // A Wd^T lands in out1's buffer, then out1 = LN1(x + (A Wd^T + bd)) in place (s1 keeps the pre-norm sum)
-    SR_CHECK(gemm_xwT(sv + p.sv_A[l], params + y.wd, sv + p.sv_out1[l], T, d, d, 0.f));
+    SR_CHECK(gemm_xwT(sv + p.sv_A[l], params + y.wd, nullptr, sv + p.sv_out1[l], T, d, d, 0, st));
     ln_residual_fwd(x, sv + p.sv_out1[l], params + y.bd, T, d, params + y.g1, params + y.b1, sv + p.sv_s1[l], sv + p.sv_out1[l],
                     sv + p.sv_m1[l], sv + p.sv_r1[l], (int)batch, L, st);
-    SR_CHECK(gemm_xwT(sv + p.sv_out1[l], params + y.wf1, sv + p.sv_f[l], T, d, dff, 0.f));
-    bias_act(sv + p.sv_f[l], params + y.bf1, T, dff, 1, st);
-    SR_CHECK(gemm_xwT(sv + p.sv_f[l], params + y.wf2, sv + p.sv_x[l + 1], T, dff, d, 0.f));
+    SR_CHECK(gemm_xwT(sv + p.sv_out1[l], params + y.wf1, params + y.bf1, sv + p.sv_f[l], T, d, dff, 1, st));
+    SR_CHECK(gemm_xwT(sv + p.sv_f[l], params + y.wf2, nullptr, sv + p.sv_x[l + 1], T, dff, d, 0, st));
     ln_residual_fwd(sv + p.sv_out1[l], sv + p.sv_x[l + 1], params + y.bf2, T, d, params + y.g2, params + y.b2, sv + p.sv_s2[l],
                     sv + p.sv_x[l + 1], sv + p.sv_m2[l], sv + p.sv_r2[l], (int)batch, L, st);
   }
   // output FFN (SetRank.py:136, 153)
-  SR_CHECK(gemm_xwT(sv + p.sv_x[p.nl], params + p.wo1, sv + p.sv_oh, T, d, dff, 0.f));
-  bias_act(sv + p.sv_oh, params + p.bo1, T, dff, 1, st);
-  SR_CHECK(gemm_xwT(sv + p.sv_oh, params + p.wo2, scores, T, dff, 1, 0.f));
-  bias_act(scores, params + p.bo2, T, 1, 0, st);
+  SR_CHECK(gemm_xwT(sv + p.sv_x[p.nl], params + p.wo1, params + p.bo1, sv + p.sv_oh, T, d, dff, 1, st));
+  SR_CHECK(gemm_xwT(sv + p.sv_oh, params + p.wo2, params + p.bo2, scores, T, dff, 1, 0, st));
   return (int)hipGetLastError();
 }
 
@@ -1363,7 +1400,6 @@ extern "C" int ultr_setrank_backward(const ultr_setrank_desc* c, const float* pa
   const int L = list_size;
   if (!attn_mfma_ok(p, L) && L > 120) return ULTR_E_UNSUPPORTED;  // the scalar attention backward keeps two [L, L] matrices in LDS
   hipStream_t st = (hipStream_t)stream;
-  SR_CHECK(blas_setup(st));
   const float* sv = (const float*)saved;
   float* ws = (float*)ws_;
   float* G0 = ws + p.ws_g[0];
@@ -1380,10 +1416,9 @@ extern "C" int ultr_setrank_backward(const ultr_setrank_desc* c, const float* pa
   // ---- output FFN:  s = oh wo2^T + bo2,  oh = relu(x_nl Wo1^T + bo1) ----------------------------------------------
   SR_CHECK(gemm_dyTx(p, dscores, sv + p.sv_oh, grads + p.wo2, T, dff, 1, ws, st));
   colsum(p, dscores, nullptr, nullptr, nullptr, 1, 0, ws, grads + p.bo2, st);
-  SR_CHECK(gemm_dyw(dscores, params + p.wo2, G1, T, dff, 1, 0.f));           // G1 = d oh  [T, dff]
-  relu_mask(G1, sv + p.sv_oh, T * dff, st);
+  SR_CHECK(gemm_dyw(dscores, params + p.wo2, G1, sv + p.sv_oh, T, dff, 1, 0, st));  // G1 = d oh  [T, dff], ReLU mask fused
   SR_CHECK(wgrad(p, G1, sv + p.sv_x[p.nl], grads + p.wo1, grads + p.bo1, T, d, dff, ws, st));
-  SR_CHECK(gemm_dyw(G1, params + p.wo1, G0, T, d, dff, 0.f));                // G0 = d x_nl  [T, d]
+  SR_CHECK(gemm_dyw(G1, params + p.wo1, G0, nullptr, T, d, dff, 0, st));     // G0 = d x_nl  [T, d]
   for (int l = p.nl - 1; l >= 0; --l) {
     const SrLayer& y = p.lay[l];
     // x_{l+1} = LN2(s2),  s2 = out1 + ffn
@@ -1397,10 +1432,9 @@ extern "C" int ultr_setrank_backward(const ultr_setrank_desc* c, const float* pa
       colsum(p, G2, nullptr, nullptr, nullptr, d, 0, ws, grads + y.bf2, st);
     }
     SR_CHECK(wgrad(p, G2, sv + p.sv_f[l], grads + y.wf2, nullptr, T, dff, d, ws, st));
-    SR_CHECK(gemm_dyw(G2, params + y.wf2, G1, T, dff, d, 0.f));              // G1 = d f  [T, dff]
-    relu_mask(G1, sv + p.sv_f[l], T * dff, st);
+    SR_CHECK(gemm_dyw(G2, params + y.wf2, G1, sv + p.sv_f[l], T, dff, d, 0, st));  // G1 = d f  [T, dff], ReLU mask fused
     SR_CHECK(wgrad(p, G1, sv + p.sv_out1[l], grads + y.wf1, grads + y.bf1, T, d, dff, ws, st));
-    SR_CHECK(gemm_dyw(G1, params + y.wf1, G2, T, d, dff, 1.0f));             // G2 = d out1 (both paths)
+    SR_CHECK(gemm_dyw(G1, params + y.wf1, G2, nullptr, T, d, dff, 1, st));   // G2 = d out1 (both paths): accumulated
     // out1 = LN1(s1),  s1 = x_l + o
     if (d <= 1024) {  // g1 | b1, G0 = d s1 = d x_l (residual) = d o, bd
       SR_CHECK(ln_bwd_cs(p, G2, sv + p.sv_s1[l], sv + p.sv_m1[l], sv + p.sv_r1[l], params + y.g1, d, G0, ws, grads + y.g1,
@@ -1412,7 +1446,7 @@ extern "C" int ultr_setrank_backward(const ultr_setrank_desc* c, const float* pa
       colsum(p, G0, nullptr, nullptr, nullptr, d, 0, ws, grads + y.bd, st);
     }
     SR_CHECK(wgrad(p, G0, sv + p.sv_A[l], grads + y.wd, nullptr, T, d, d, ws, st));
-    SR_CHECK(gemm_dyw(G0, params + y.wd, G1, T, d, d, 0.f));                 // G1 = d A  [T, d]
+    SR_CHECK(gemm_dyw(G0, params + y.wd, G1, nullptr, T, d, d, 0, st));      // G1 = d A  [T, d]
     if (attn_mfma_ok(p, L))   // G0 += attention path -> d x_l
       SR_CHECK(attn_bwd_mfma(p, sv + p.sv_x[l], G1, sv + p.sv_A[l], sv + p.sv_lse[l], batch, L, G0, st));
     else hipLaunchKernelGGL(sr_attn_bwd_kernel, dim3(batch, p.H), dim3(256), lds_att, st, sv + p.sv_x[l], (const float*)G1, L, d,
@@ -1420,10 +1454,9 @@ extern "C" int ultr_setrank_backward(const ultr_setrank_desc* c, const float* pa
   }
   // ---- embedding FFN and the input LayerNorm's parameters -------------------------------------------------------------
   SR_CHECK(wgrad(p, G0, sv + p.sv_h0, grads + p.w2, grads + p.b2, T, dff, d, ws, st));
-  SR_CHECK(gemm_dyw(G0, params + p.w2, G1, T, dff, d, 0.f));
-  relu_mask(G1, sv + p.sv_h0, T * dff, st);
+  SR_CHECK(gemm_dyw(G0, params + p.w2, G1, sv + p.sv_h0, T, dff, d, 0, st));  // ReLU mask fused
   SR_CHECK(wgrad(p, G1, sv + p.sv_xn0, grads + p.w1, grads + p.b1, T, F, dff, ws, st));
-  SR_CHECK(gemm_dyw(G1, params + p.w1, G2, T, F, dff, 0.f));                 // G2 = d xn0  [T, F]
+  SR_CHECK(gemm_dyw(G1, params + p.w1, G2, nullptr, T, F, dff, 0, st));      // G2 = d xn0  [T, F]
   colsum_ln(p, G2, sv + p.sv_xg, sv + p.sv_mean_in, sv + p.sv_rstd_in, F, ws, grads + p.g_in, st);  // g_in | b_in
   // ---- step tail: fold the loss partials behind the gradient ----------------------------------------------------------
   if (loss_ws != nullptr && n_loss_parts > 0) {
