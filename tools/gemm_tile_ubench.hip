@@ -72,7 +72,13 @@ void bench(int64_t R, int K, int N) {
   (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC); (void)hipFree(dbias);
 }
 
-int main() {
+int main(int argc, char** argv) {
+  if (argc > 1) {  // one shape only (counter passes): tools/bin/gemm_tile_ub 1
+    bench<false, 64, 128, 2, 2>(102400, 256, 256);
+    bench<true, 64, 128, 2, 2>(102400, 256, 256);
+    bench<false, 64, 64, 4, 1>(102400, 256, 64);
+    return 0;
+  }
   bench<false>(12800, 700, 512);
   bench<false>(12800, 512, 256);
   bench<false>(12800, 256, 128);

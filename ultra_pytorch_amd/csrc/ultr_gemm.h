@@ -381,11 +381,13 @@ inline hipError_t launch(const Dims& d, const AProd& aprod, const float* B, cons
   return hipGetLastError();
 }
 
-// C = epi(A' . B): picks the 128 x 128 tile (2 x 2 waves) or, for narrow outputs, 128 x 64 (4 x 1 waves)
+// C = epi(A' . B).  Tile choice (tools/gemm_tile_ubench.hip): 64 x 128 (3 workgroups per CU: 53 KB of LDS each) beats
+// 128 x 128 (2 per CU) at every shape measured - more workgroups in different phases per CU hide each other's staging,
+// barriers, prologue and epilogue; narrow outputs take 64 x 64 (4 per CU)
 template <bool B_NMAJOR, class AProd, class Epi>
 inline hipError_t run(const Dims& d, const AProd& aprod, const float* B, const Epi& epi, hipStream_t st) {
-  if (d.N > 64) return launch<128, 128, 2, 2, B_NMAJOR>(d, aprod, B, epi, st);
-  return launch<128, 64, 4, 1, B_NMAJOR>(d, aprod, B, epi, st);
+  if (d.N > 64) return launch<64, 128, 2, 2, B_NMAJOR>(d, aprod, B, epi, st);
+  return launch<64, 64, 4, 1, B_NMAJOR>(d, aprod, B, epi, st);
 }
 
 }  // namespace ugemm

@@ -459,40 +459,6 @@ __global__ __launch_bounds__(256) void sr_ln_bwd_cs_v4_kernel(const float* __res
 // ---------------------------------------------------------------------------------------------------------
 // element-wise epilogues
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sr_bias_act_kernel(float* __restrict__ y, const float* __restrict__ bias, int64_t T, int W,
-                                                          int relu) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= T * W) return;
-  float v = y[e] + bias[e % W];
-  if (relu) v = fmaxf(v, 0.f);
-  y[e] = v;
-}
-// 16-byte variants (W % 4 == 0: a float4 never straddles a row; tensors 16-byte aligned; the bias at any float offset)
-__global__ __launch_bounds__(256) void sr_bias_act_v4_kernel(float* __restrict__ y, const float* __restrict__ bias, int64_t n4, int W,
-                                                             int relu) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= n4) return;
-  const int c = (int)((e * 4) % W);
-  float4 v = ld4(y + e * 4);
-  v.x += bias[c]; v.y += bias[c + 1]; v.z += bias[c + 2]; v.w += bias[c + 3];
-  if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-  st4(y + e * 4, v);
-}
-__global__ __launch_bounds__(256) void sr_relu_mask_v4_kernel(float* __restrict__ dy, const float* __restrict__ act, int64_t n4) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= n4) return;
-  const float4 a = ld4(act + e * 4);
-  float4 v = ld4(dy + e * 4);
-  v.x = (a.x > 0.f) ? v.x : 0.f; v.y = (a.y > 0.f) ? v.y : 0.f; v.z = (a.z > 0.f) ? v.z : 0.f; v.w = (a.w > 0.f) ? v.w : 0.f;
-  st4(dy + e * 4, v);
-}
-// dy *= (act > 0)
-__global__ __launch_bounds__(256) void sr_relu_mask_kernel(float* __restrict__ dy, const float* __restrict__ act, int64_t n) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e < n && !(act[e] > 0.f)) dy[e] = 0.f;
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // column sums (bias gradients, LayerNorm gamma/beta gradients): partials per SR_CS_ROWS rows, then a fixed-order fold
 // ---------------------------------------------------------------------------------------------------------
 // part[blk][c]      = sum_r a[r][c]                       (mode 0)
@@ -1135,6 +1101,29 @@ __global__ __launch_bounds__(256) void sr_gemm_dyTx_ref_kernel(const float* __re
 // activations (a, c) must be 16-byte aligned with rows a multiple of 4 floats (LDS staging and float4 stores); the weight
 // matrix only needs its natural 4-byte alignment: in SetRank's flat parameter vector every encoder matrix sits at an odd
 // float offset (the width-1 scorer bias precedes them), and buffer_load_dwordx4 takes dword-aligned addresses
+// width-1 output (the scorer, SetRank.py:136): y[t] = x[t] . w + b, one wavefront per row, 4 rows per workgroup
+__global__ __launch_bounds__(256) void sr_rowdot_kernel(const float* __restrict__ X, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y, int64_t T, int K) {
+  const int lane = threadIdx.x & 63;
+  const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= T) return;
+  float acc = 0.f;
+  for (int k = lane; k < K; k += 64) acc = fmaf(X[t * K + k], w[k], acc);
+  acc = wave_sum(acc);
+  if (lane == 0) y[t] = acc + (bias != nullptr ? bias[0] : 0.f);
+}
+// its weight gradient: part[blk][k] = sum over SR_CS_ROWS rows of dy[t] X[t][k]
+__global__ __launch_bounds__(256) void sr_colsum_w_kernel(const float* __restrict__ dy, const float* __restrict__ X, int64_t T,
+                                                          int K, float* __restrict__ part) {
+  const int64_t r0 = (int64_t)blockIdx.x * SR_CS_ROWS;
+  const int64_t r1 = (r0 + SR_CS_ROWS < T) ? r0 + SR_CS_ROWS : T;
+  for (int c = threadIdx.x; c < K; c += 256) {
+    float acc = 0.f;
+    for (int64_t r = r0; r < r1; ++r) acc = fmaf(dy[r], X[r * K + c], acc);
+    part[(int64_t)blockIdx.x * K + c] = acc;
+  }
+}
+
 bool vec_ok(const void* a, const void* w, const void* c, int K, int ld_out) {
   (void)w;
   return K % 4 == 0 && ld_out % 4 == 0 && ((((uintptr_t)a | (uintptr_t)c) & 15) == 0);
@@ -1146,6 +1135,10 @@ int gemm_xwT(const float* X, const float* W, const float* bias, float* Y, int64_
     const ugemm::APlain a{X, T, K, K};
     const ugemm::EBiasAct e{Y, bias, M, relu ? 1 : -1};
     return ugemm::run<true>(d, a, W, e, st) == hipSuccess ? 0 : ULTR_E_UNSUPPORTED;
+  }
+  if (M == 1 && !relu) {
+    hipLaunchKernelGGL(sr_rowdot_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, st, X, W, bias, Y, T, K);
+    return 0;
   }
   hipLaunchKernelGGL(sr_gemm_xwT_ref_kernel, dim3((unsigned)((T * M + 255) / 256)), dim3(256), 0, st, X, W, bias, Y, T, K, M, relu);
   return 0;
@@ -1165,6 +1158,12 @@ int gemm_dyw(const float* dY, const float* W, float* dX, const float* mask, int6
 // row-major  dW[M, K] = dY[T, M]^T . X[T, K] for the shapes sr_wgrad_kernel does not take: `wg_split` equal row chunks
 // into partials, folded in canonical order
 int gemm_dyTx(const SrPlan& p, const float* dY, const float* X, float* dW, int64_t T, int K, int M, float* ws, hipStream_t st) {
+  if (M == 1 && K <= 3 * p.maxw) {  // the scorer's weight row: weighted column sums, partials per SR_CS_ROWS rows
+    float* cpart = ws + p.ws_part;
+    hipLaunchKernelGGL(sr_colsum_w_kernel, dim3(p.n_cs), dim3(256), 0, st, dY, X, T, K, cpart);
+    fold(cpart, (int64_t)K, p.n_cs, K, dW, st);
+    return 0;
+  }
   const int S = p.wg_split;
   const int64_t rows = T / S;
   float* part = ws + p.ws_wg;
@@ -1275,19 +1274,6 @@ int attn_bwd_mfma(const SrPlan& p, const float* x, const float* dA, const float*
   return 0;
 }
 
-void bias_act(float* y, const float* bias, int64_t T, int W, int relu, hipStream_t st) {
-  const int64_t n = T * W;
-  if (W % 4 == 0 && ((uintptr_t)y & 15) == 0)
-    hipLaunchKernelGGL(sr_bias_act_v4_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, y, bias, n / 4, W, relu);
-  else
-    hipLaunchKernelGGL(sr_bias_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, bias, T, W, relu);
-}
-void relu_mask(float* dy, const float* act, int64_t n, hipStream_t st) {
-  if (n % 4 == 0 && ((((uintptr_t)dy | (uintptr_t)act) & 15) == 0))
-    hipLaunchKernelGGL(sr_relu_mask_v4_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, dy, act, n / 4);
-  else
-    hipLaunchKernelGGL(sr_relu_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dy, act, n);
-}
 // dst[0..W) = column sums of a (mode 0) or of a o xhat (mode 1)
 void colsum(const SrPlan& p, const float* a, const float* s, const float* mean, const float* rstd, int W, int mode, float* ws,
             float* dst, hipStream_t st) {
