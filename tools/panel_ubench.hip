@@ -1,10 +1,73 @@
 // Micro-benchmark (GPU box) of the fused kernels' per-workgroup GEMM phase: 512 threads, A tile [16 x K] in LDS, W^T [K x M]
 // streamed from L2, Y [16 x M] to LDS; G workgroups run it `reps` times.  Variants: the 2-trip register ring (GemmPipe, what
-// round 1 shipped) against whole-panel prefetch (PanelGemm).
+// ships) against whole-panel prefetch (PanelGemm, below), an LDS-DMA ring and 16-byte loads with contraction halves.
+// Findings (round 2): more loads in flight is SLOWER (panel 7.1 us, DMA ring 6.9 us vs 6.05 us for the 2-trip
+// ring; loads-only 4.1 us and MFMA-only 4.0 us do not overlap on a CU), 16-byte loads win 17 % here (5.04 us) but nothing
+// inside the real kernel, where every GEMM phase starts cold behind a LayerNorm.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/panel_ubench.hip ultra_pytorch_amd/csrc/ultr_prof.hip -o tools/bin/panel_ub
 #include "../ultra_pytorch_amd/csrc/ultr_dnn.hip"
 #include <cstdio>
 #include <vector>
+
+// The same contraction with the WHOLE W panel of the wave requested up front (NT trips of 32 contraction rows, NT <= 8: 16 * NT
+// registers): for the layer widths of the latency regime (K <= 256) a wave's panel is at most 64 loads, so nothing is
+// gained by metering them - every byte the wave will need is in flight before its first MFMA and the matrix cores chase
+// the arriving data with counted waits (tools/l2stream_ubench: a CU sustains ~60 B/clk from L2 when >= 64 KB are in
+// flight, ~23 B/clk with the 2-trip ring's 32 KB).  issue() and run() are separate so that a caller may issue the panel
+// ahead of the phase that produces the A tile.
+template <int RT, int NT>
+struct PanelGemm {
+  f32x2 b[NT][8];
+  __device__ __forceinline__ void issue(const Src& W, int ldw, int kb, int ke, int c0, bool valid, int lane) {
+    const int i = lane & 15, q = lane >> 4;
+    const unsigned rs = (unsigned)ldw * 4u;
+    const unsigned of = ((unsigned)(kb + 4 * q) * (unsigned)ldw + (unsigned)(c0 + 2 * i)) * 4u;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const bool ok0 = valid && kb + 32 * t < ke, ok1 = valid && kb + 32 * t + 16 < ke;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        b[t][s] = buf_ldv<2>(W, ok0 ? (of + (unsigned)(32 * t + s) * rs) : ULTR_OOB);
+        b[t][4 + s] = buf_ldv<2>(W, ok1 ? (of + (unsigned)(32 * t + 16 + s) * rs) : ULTR_OOB);
+      }
+    }
+    // hipcc's scheduler otherwise sinks every load to just above the MFMA that reads it (one exposed round trip each)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // As = A tile in LDS (zero beyond the real contraction length up to a multiple of 32); trips past the slice multiply zeros
+  __device__ __forceinline__ void run(const float* __restrict__ As, int lda, int kb, f32x4 (&acc)[RT][2], int lane) {
+    const int i = lane & 15, q = lane >> 4;
+    const float* ap = As + i * lda + kb + 4 * q;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      {
+        float4 a0[RT], a1[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          a0[rt] = ld4(ap + rt * 16 * lda + 32 * t);
+          a1[rt] = ld4(ap + rt * 16 * lda + 32 * t + 16);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const float av[4] = {a0[rt].x, a0[rt].y, a0[rt].z, a0[rt].w};
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[rt][c] = mfma16(av[s], b[t][s][c], acc[rt][c]);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const float av[4] = {a1[rt].x, a1[rt].y, a1[rt].z, a1[rt].w};
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[rt][c] = mfma16(av[s], b[t][4 + s][c], acc[rt][c]);
+        }
+      }
+    }
+  }
+};
+
 
 template <int V, int NT>
 __global__ __launch_bounds__(512) void ub_kernel(const float* __restrict__ W, int Kc, int Mo, float* __restrict__ out,

@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 src = sorted(os.path.join(ROOT, "ultra_pytorch_amd/csrc", f) for f in os.listdir(os.path.join(ROOT, "ultra_pytorch_amd/csrc")) if f.endswith(".hip"))
 out = "/tmp/libultr_trace.so"
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DULTR_TRACE"] + src + ["-L/opt/rocm/lib", "-lrocblas", "-o", out])
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DULTR_TRACE"] + src + ["-o", out])
 from ultra_pytorch_amd import _lib
 lib = _lib.load(out)
 _lib._LIB = lib
