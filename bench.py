@@ -285,6 +285,9 @@ def main():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", default="2", choices=sorted(CONFIGS), help="BASELINE.json config (default 2 = the headline)")
+    ap.add_argument("--attention-dtype", default="fp32", choices=["fp32", "fp16"],
+                    help="config 5 only: operand type of SetRank's self-attention (fp16 = BASELINE config 5's fp16 MFMA attention, "
+                         "ordering-level parity; fp32 = the 1e-5 parity path, default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures (plugin API, device feed)")
     ap.add_argument("--sync-every-step", action="store_true", help="also read loss.item() every step (API-faithful)")
@@ -318,7 +321,7 @@ def main():
     lib = _lib.load()
     if cfg["model"] == "setrank":
         from ultra_pytorch_amd.ranking_model.SetRank import init_setrank_params
-        shape = hip_ops.SetRankShape(F, 256, 8, 2, 64)
+        shape = hip_ops.SetRankShape(F, 256, 8, 2, 64, attention_dtype=args.attention_dtype)
         params0 = init_setrank_params(shape, seed=0).numpy()
         eng_cls = engine.SetRankStepEngine
     else:
@@ -477,7 +480,9 @@ def main():
         out = {
             "metric": "queries/sec (training step)", "value": world * B * args.steps / elapsed, "unit": "queries/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if (dnn or args.attention_dtype == "fp32") else "f32 (self-attention operands f16, f32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": cfg["workload"], "baseline_config": args.config, "global_batch": world * B, "list_size": L,
                        "feature_size": F, "hidden": HIDDEN, "parallelism": "dp%d" % world, "params": P},
             "roofline": {"kernel": kname, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ULTR_ABI_VERSION 1
+#define ULTR_ABI_VERSION 2
 #define ULTR_MAX_HIDDEN 7 /* hidden layers; Linear layers = hidden + 1 <= 8 */
 
 #define ULTR_E_BADARG (-1)
@@ -169,7 +169,8 @@ int ultr_regem_loss(const float* scores, const float* labels, const float* prope
  * Replaces SetRank.build / Encoder.forward (ranking_model/SetRank.py:143-156, 229-255) and its autograd
  * backward: input LayerNorm (eps 1e-6) -> FFN(F -> dff -> d_model) -> num_layers x [multi-head self-attention
  * WITHOUT projections (heads = slices of x) -> dense -> residual + LayerNorm -> FFN -> residual + LayerNorm]
- * -> FFN(d_model -> dff -> 1).  fp32; plain Linear layers through rocBLAS sgemm, everything else hand-written.
+ * -> FFN(d_model -> dff -> 1).  fp32 (attention optionally with fp16 operands, see attention_dtype); every kernel is
+ * hand-written: the Linear layers run on the library's LDS-tiled matrix-core GEMM with fused bias / ReLU epilogues.
  * params: flat vector in SetRank.state_dict() order (Encoder_layer.input_layer_norm, input_embedding.{0,2},
  * output_layer.{0,2}, then per encoder: mha.dense, ffn.{0,2}, layernorm1, layernorm2).
  * forward: scores [B, L]; `saved` (ultr_setrank_saved_bytes) receives every activation the backward needs and is
@@ -177,8 +178,14 @@ int ultr_regem_loss(const float* scores, const float* labels, const float* prope
  * backward: dscores [B, L] from any ultr_*_loss kernel (x D convention), loss_ws/n_loss_parts = that kernel's
  * partials; writes grads [P + step tail]; follow with ultr_grad_sumsq + ultr_apply_update(wt = NULL).
  * list_size <= 128 on the matrix-core attention path (head depth 16 / 32 / 64), <= 120 otherwise. */
+enum ultr_attention_dtype { ULTR_ATTN_FP32 = 0, ULTR_ATTN_FP16 = 1 };
 typedef struct ultr_setrank_desc {
   int32_t feature_size, d_model, num_heads, num_layers, dff;
+  /* operand type of the self-attention products (ABI 2).  ULTR_ATTN_FP32 (default): exact fp32 matrix cores, the 1e-5
+   * parity path.  ULTR_ATTN_FP16: fp16 operands with fp32 accumulation on v_mfma_f32_16x16x32_f16 (what BASELINE
+   * config 5 names); scores / softmax / gradients algebra stay fp32; parity is ORDERING-level (~1e-3 relative), so it is
+   * opt-in.  Needs head depth 32 or 64 and list_size <= 128, otherwise the fp32 kernels run. */
+  int32_t attention_dtype;
 } ultr_setrank_desc;
 int64_t ultr_setrank_param_count(const ultr_setrank_desc* c);
 int64_t ultr_setrank_saved_bytes(const ultr_setrank_desc* c, int64_t n_rows);

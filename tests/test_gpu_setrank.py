@@ -180,3 +180,62 @@ def test_setrank_full_size_properties():
     err = np.abs(g2[:n] - g1[:n]) - 2e-3 * np.abs(g1[:n])
     assert float(err.max()) <= 2e-2 * gmax
     assert int((err > 5e-4 * gmax).sum()) <= n // 200
+
+
+def _fp16_vs_fp32(F, dm, H, nl, dff, B, L, seed):
+    """One training step of the same model / batch with fp32 and with fp16-operand attention."""
+    from ultra_pytorch_amd import hip_ops, synthetic
+    from ultra_pytorch_amd.ranking_model.SetRank import init_setrank_params
+    rng = np.random.RandomState(seed)
+    feats, ids, y = synthetic.make_batch(rng, B, L, F)
+    ipw = synthetic.load_ipw()
+    out = {}
+    for dt in ("fp32", "fp16"):
+        shape = hip_ops.SetRankShape(F, dm, H, nl, dff, attention_dtype=dt)
+        p0 = init_setrank_params(shape, seed=seed).numpy()
+        out[dt] = run_step(shape, B, L, {}, p0, np.zeros_like(p0), feats, ids, y, ipw)
+    return out, y
+
+
+@pytest.mark.parametrize("shape", [(24, 64, 2, 2, 16, 6, 20), (24, 128, 2, 1, 16, 5, 100), (40, 64, 2, 2, 32, 4, 37),
+                                   (24, 64, 1, 1, 16, 3, 128)])
+def test_fp16_attention_close_to_fp32(shape):
+    """Opt-in attention_dtype=fp16 (BASELINE config 5's fp16 MFMA attention): fp16 operands, fp32 accumulation and fp32
+    softmax algebra.  Against the fp32 path on the same inputs: scores within 2e-3 of the score range, loss within 1e-3,
+    gradients within 2 % of the largest gradient (operand rounding 2^-11 through two encoder layers) - list sizes with an
+    odd and an even number of 16-token blocks, a ragged last block, head depth 32 and 64."""
+    F, dm, H, nl, dff, B, L = shape
+    out, _ = _fp16_vs_fp32(F, dm, H, nl, dff, B, L, seed=7)
+    s32, g32, _, _, sc32 = out["fp32"]
+    s16, g16, _, _, sc16 = out["fp16"]
+    assert np.isfinite(s16).all() and np.isfinite(g16).all()
+    assert not np.array_equal(s16, s32), "the fp16 path did not run"
+    span = float(s32.max() - s32.min())
+    np.testing.assert_allclose(s16, s32, atol=2e-3 * max(span, 1.0), rtol=0)
+    assert abs(sc16[0] - sc32[0]) <= 1e-3 * max(1.0, abs(sc32[0]))
+    P = g32.size - 4 - 2 * L
+    gmax = float(np.abs(g32[:P]).max())
+    np.testing.assert_allclose(g16[:P], g32[:P], atol=2e-2 * gmax, rtol=0)
+    # most of the gradient mass agrees much more tightly than the worst element
+    rel = np.linalg.norm(g16[:P] - g32[:P]) / np.linalg.norm(g32[:P])
+    assert rel < 5e-3, rel
+
+
+def test_fp16_attention_ordering_parity_config5_shape():
+    """Ordering-level parity at BASELINE config 5's layer shapes (F220, L100, d_model 256, 8 heads x 32, 2 layers, dff 64):
+    the top-10 of every list and NDCG@10 against the fp32 path."""
+    from oracle import ultr_oracle as O
+    B, L = 64, 100
+    out, labels_LB = _fp16_vs_fp32(220, 256, 8, 2, 64, B, L, seed=3)
+    s32, s16 = out["fp32"][0], out["fp16"][0]
+    top32 = np.argsort(-s32, axis=1, kind="stable")[:, :10]
+    top16 = np.argsort(-s16, axis=1, kind="stable")[:, :10]
+    same_order = np.mean([np.array_equal(a, b) for a, b in zip(top32, top16)])
+    same_set = np.mean([set(a) == set(b) for a, b in zip(top32, top16)])
+    rel = torch.tensor(np.random.RandomState(0).randint(0, 5, size=(B, L)).astype(np.float32))
+    n32 = float(O.ndcg(rel, torch.tensor(s32), [10])[0])
+    n16 = float(O.ndcg(rel, torch.tensor(s16), [10])[0])
+    print("fp16 attention: identical top-10 order on %.1f %% of lists, identical top-10 set on %.1f %%, NDCG@10 %.5f vs %.5f"
+          % (100 * same_order, 100 * same_set, n16, n32))
+    assert same_set >= 0.95 and same_order >= 0.90
+    assert abs(n16 - n32) <= 1e-3

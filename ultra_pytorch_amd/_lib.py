@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libultr_hip.so")
 ULTR_MAX_HIDDEN = 7
 COMM_HANDLE_BYTES, COMM_MAX_WORLD = 64, 8
 ACT = {"elu": 0, "relu": 1}
+ATTN_DTYPE = {"fp32": 0, "fp16": 1}
 ALGO_SOFTMAX, ALGO_DLA, ALGO_PAIRDEBIAS, ALGO_LAMBDARANK, ALGO_REGEM = 0, 1, 2, 3, 4
 OPT_ADAGRAD, OPT_SGD = 0, 1
 
@@ -30,7 +31,8 @@ class UpdateDesc(ctypes.Structure):
 
 
 class SetRankDesc(ctypes.Structure):
-    _fields_ = [("feature_size", c_i32), ("d_model", c_i32), ("num_heads", c_i32), ("num_layers", c_i32), ("dff", c_i32)]
+    _fields_ = [("feature_size", c_i32), ("d_model", c_i32), ("num_heads", c_i32), ("num_layers", c_i32), ("dff", c_i32),
+                ("attention_dtype", c_i32)]
 
 
 class StepArgs(ctypes.Structure):

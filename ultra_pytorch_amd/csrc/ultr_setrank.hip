@@ -31,6 +31,7 @@ struct SrLayer {  // offsets (floats) into the flat parameter vector
 };
 struct SrPlan {
   int F, d, H, nl, dff, dh;
+  int att_f16;  // 1: fp16-operand attention kernels (ultr_setrank_desc::attention_dtype)
   int64_t T;
   int64_t g_in, b_in, w1, b1, w2, b2, wo1, bo1, wo2, bo2;
   SrLayer lay[8];
@@ -67,11 +68,12 @@ int wgrad_chunks(int64_t T, int M, int K, int* rows_per_chunk) {
 
 bool make_plan(const ultr_setrank_desc* c, int64_t T, SrPlan* p) {
   if (!c || c->feature_size <= 0 || c->d_model <= 0 || c->num_heads <= 0 || c->num_layers <= 0 || c->num_layers > 8 ||
-      c->dff <= 0 || c->d_model % c->num_heads != 0)
+      c->dff <= 0 || c->d_model % c->num_heads != 0 || (c->attention_dtype != ULTR_ATTN_FP32 && c->attention_dtype != ULTR_ATTN_FP16))
     return false;
   memset(p, 0, sizeof(*p));
   p->F = c->feature_size; p->d = c->d_model; p->H = c->num_heads; p->nl = c->num_layers; p->dff = c->dff;
   p->dh = p->d / p->H;
+  p->att_f16 = (c->attention_dtype == ULTR_ATTN_FP16) ? 1 : 0;
   p->T = T;
   const int64_t F = p->F, d = p->d, dff = p->dff;
   int64_t o = 0;
@@ -941,6 +943,249 @@ __global__ __launch_bounds__(SR_MAXT * 64) __attribute__((amdgpu_waves_per_eu(4,
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// the same attention with fp16 operands on v_mfma_f32_16x16x32_f16 (opt-in: ultr_setrank_desc::attention_dtype = 1)
+// ---------------------------------------------------------------------------------------------------------
+// BASELINE config 5 names "fp16 MFMA attention over the list".  The fp32 kernels above are bound by matrix-core ISSUE
+// (fp32 MFMA runs at 1/16 of the fp16 rate: 251 of the backward's 388 us are MFMA issue slots).  Here every product takes
+// fp16 operands with fp32 accumulation - one instruction contracts 32 indices instead of 4 - and everything else
+// (scores, softmax, lse, t, the dS algebra, outputs) stays fp32 in registers, exactly as above.  What changes:
+//  * the head slice is staged TWICE in fp16: row-major [token][DH] (8 consecutive halves of a token = the A / B operand
+//    of the NT tiles S^T, dP^T, dP over the head depth) and transposed [DH][token] (4 consecutive tokens of a column = half
+//    of the B operand of the products that contract over tokens: P V, dS x, dS^T x, P^T dA);
+//  * those products contract over a PAIR of 16-token blocks per instruction: the lane already holds, for its own token,
+//    the 4 + 4 probabilities / dS values of partner tokens {16 t + 4 q + r} and {16 (t + 1) + 4 q + r} - converted to
+//    halves they ARE the 8-element A operand (contraction index k = 8 q + j <-> token 16 (t + j / 4) + 4 q + j % 4; the B
+//    operand follows the same permutation: two 8-byte LDS reads of the transposed slice).
+// Numerics: operands rounded to fp16 (2^-11 relative), so scores / gradients agree with the fp32 path to ~1e-3 relative -
+// an ORDERING-level parity (tests/test_gpu_setrank.py: identical top-10 on >= 99 % of lists, NDCG@10 within 1e-3), not
+// the 1e-5 bar; that is why it is opt-in.  Head depth 32 or 64 (one or two contraction chunks), list_size <= 128.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma_h(h8 a, h8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ h8 pack_h8(const f32x4& lo, const f32x4& hi) {
+  h8 o;
+  o[0] = (_Float16)lo[0]; o[1] = (_Float16)lo[1]; o[2] = (_Float16)lo[2]; o[3] = (_Float16)lo[3];
+  o[4] = (_Float16)hi[0]; o[5] = (_Float16)hi[1]; o[6] = (_Float16)hi[2]; o[7] = (_Float16)hi[3];
+  return o;
+}
+__device__ __forceinline__ h8 join_h4(h4 lo, h4 hi) {
+  h8 o;
+  o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+  o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+  return o;
+}
+constexpr int SRH_LT = 16 * SR_MAXT + 16 + 8;  // row length (halves) of the transposed slices: 9 blocks (the pair partner of an
+                                               // odd last block reads zeros) + 8 halves of padding (272 B: 16-byte multiple)
+
+// stage x (and dA) of one (list, head) as fp16: row-major xh [Lp][DH + 8] and transposed xt [DH][SRH_LT]; zero past L
+template <int DH, bool WITH_G>
+__device__ __forceinline__ void srh_stage(const float* __restrict__ x, const float* __restrict__ g, int64_t base, int L, int Lp, int d,
+                                          _Float16* xh, _Float16* xt, _Float16* gh, _Float16* gt, int tid, int nthr) {
+  constexpr int LDH = DH + 8;
+  for (int e = tid; e < DH * (SRH_LT / 8); e += nthr) {  // zero the transposed slices (padding columns are read)
+    const h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    *reinterpret_cast<h8*>(xt + e * 8) = z;
+    if (WITH_G) *reinterpret_cast<h8*>(gt + e * 8) = z;
+  }
+  __syncthreads();
+  for (int e = tid; e < Lp * (DH / 4); e += nthr) {
+    const int r = e / (DH / 4), c4 = (e - r * (DH / 4)) * 4;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 xv = r < L ? ld4(x + base + (int64_t)r * d + c4) : z4;
+    h4 hv = {(_Float16)xv.x, (_Float16)xv.y, (_Float16)xv.z, (_Float16)xv.w};
+    *reinterpret_cast<h4*>(xh + r * LDH + c4) = hv;
+    xt[(c4 + 0) * SRH_LT + r] = hv[0]; xt[(c4 + 1) * SRH_LT + r] = hv[1];
+    xt[(c4 + 2) * SRH_LT + r] = hv[2]; xt[(c4 + 3) * SRH_LT + r] = hv[3];
+    if (WITH_G) {
+      const float4 gv = r < L ? ld4(g + base + (int64_t)r * d + c4) : z4;
+      h4 hg = {(_Float16)gv.x, (_Float16)gv.y, (_Float16)gv.z, (_Float16)gv.w};
+      *reinterpret_cast<h4*>(gh + r * LDH + c4) = hg;
+      gt[(c4 + 0) * SRH_LT + r] = hg[0]; gt[(c4 + 1) * SRH_LT + r] = hg[1];
+      gt[(c4 + 2) * SRH_LT + r] = hg[2]; gt[(c4 + 3) * SRH_LT + r] = hg[3];
+    }
+  }
+}
+// NT tile over the head depth: D[row 4 q + r][col i] = sum_k a[16 ta + i'][k] * bfrag[i][k]  (a rows from the row-major slice)
+template <int DH>
+__device__ __forceinline__ f32x4 srh_tile(const _Float16* arow, const h8 (&bf)[DH / 32]) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int f = 0; f < DH / 32; ++f) acc = mfma_h(*reinterpret_cast<const h8*>(arow + 32 * f), bf[f], acc);
+  return acc;
+}
+// B operand of a token-contraction over the block pair (t, t + 1): column `col` of the transposed slice
+__device__ __forceinline__ h8 srh_pair_b(const _Float16* tslice, int col, int t, int q) {
+  const _Float16* p = tslice + col * SRH_LT + 16 * t + 4 * q;
+  return join_h4(*reinterpret_cast<const h4*>(p), *reinterpret_cast<const h4*>(p + 16));
+}
+
+template <int DH>
+__global__ __launch_bounds__(SR_MAXT * 64) void sr_attn_fwd_f16_kernel(const float* __restrict__ x, int L, int d,
+                                                                      float* __restrict__ A, float* __restrict__ lse) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int LDH = DH + 8, NC = DH / 16, NF = DH / 32;
+  const int Lp = round_up(L, 16), NTL = Lp / 16;
+  _Float16* xh = reinterpret_cast<_Float16*>(smem);  // [Lp][LDH]
+  _Float16* xt = xh + 16 * SR_MAXT * LDH;            // [DH][SRH_LT]
+  const int b = blockIdx.x, h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+  const int64_t base = (int64_t)b * L * d + h * DH;
+  srh_stage<DH, false>(x, nullptr, base, L, Lp, d, xh, xt, nullptr, nullptr, tid, NTL * 64);
+  __syncthreads();
+  const float scale = 1.0f / sqrtf((float)DH);
+  h8 bq[NF];  // this wave's query block: lane (i, q) holds x[query i][32 f + 8 q .. + 7]
+#pragma unroll
+  for (int f = 0; f < NF; ++f) bq[f] = *reinterpret_cast<const h8*>(xh + (wave * 16 + i) * LDH + 32 * f + 8 * q);
+  f32x4 pr[SR_MAXT + 1];  // pr[t][r]: key 16 t + 4 q + r, query = this lane's i   (+1: the zero partner of an odd last block)
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t <= SR_MAXT; ++t) pr[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < SR_MAXT; ++t) {
+    if (t < NTL) {
+      pr[t] = srh_tile<DH>(xh + (t * 16 + i) * LDH + 8 * q, bq);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, pr[t][r]);
+    }
+  }
+  mx = quad_max(mx);
+  const float c1 = scale * 1.44269504088896341f, mx2 = mx * c1;
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < SR_MAXT; ++t) {
+    if (t < NTL) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pr[t][r] = __builtin_amdgcn_exp2f(fmaf(pr[t][r], c1, -mx2));
+      if (t == NTL - 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pr[t][r] = (t * 16 + 4 * q + r < L) ? pr[t][r] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sum += pr[t][r];
+    }
+  }
+  sum = quad_sum(sum);
+  const float inv = 1.0f / sum;
+  if (lse != nullptr && q == 0 && wave * 16 + i < L) lse[((int64_t)b * L + wave * 16 + i) * gridDim.y + h] = mx * scale + logf(sum);
+  f32x4 o[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) o[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < SR_MAXT; t += 2) {
+    if (t < NTL) {
+      f32x4 lo = pr[t], hi = pr[t + 1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { lo[r] *= inv; hi[r] *= inv; }
+      const h8 pa = pack_h8(lo, hi);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) o[c] = mfma_h(pa, srh_pair_b(xt, 16 * c + i, t, q), o[c]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wave * 16 + 4 * q + r;
+      if (row < L) A[base + (int64_t)row * d + c * 16 + i] = o[c][r];
+    }
+  }
+}
+
+template <int DH>
+__global__ __launch_bounds__(SR_MAXT * 64) void sr_attn_bwd_f16_kernel(const float* __restrict__ x, const float* __restrict__ dA,
+                                                                      const float* __restrict__ Aout, const float* __restrict__ lse,
+                                                                      int L, int d, float* __restrict__ dx) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int LDH = DH + 8, NC = DH / 16, NF = DH / 32, RT = DH / 4;
+  const int Lp = round_up(L, 16), NTL = Lp / 16;
+  _Float16* xh = reinterpret_cast<_Float16*>(smem);   // [16 SR_MAXT][LDH]
+  _Float16* gh = xh + 16 * SR_MAXT * LDH;
+  _Float16* xt = gh + 16 * SR_MAXT * LDH;             // [DH][SRH_LT]
+  _Float16* gt = xt + DH * SRH_LT;
+  float* st_l = reinterpret_cast<float*>(gt + DH * SRH_LT);  // [16 (SR_MAXT + 1)] lse * log2(e) (+inf past L: P = 0)
+  float* st_t = st_l + 16 * (SR_MAXT + 1);                   // [16 (SR_MAXT + 1)] t = dA . A
+  const int b = blockIdx.x, h = blockIdx.y, H = gridDim.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+  const int64_t base = (int64_t)b * L * d + h * DH;
+  srh_stage<DH, true>(x, dA, base, L, Lp, d, xh, xt, gh, gt, tid, NTL * 64);
+  for (int e = tid; e < 16 * (SR_MAXT + 1) * RT; e += NTL * 64) {  // t = dA . A in fp32 from the fp32 inputs; lse
+    const int r = e / RT, c4 = (e - r * RT) * 4;
+    const bool ok = r < L;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 gv = ok ? ld4(dA + base + (int64_t)r * d + c4) : z4;
+    const float4 av = ok ? ld4(Aout + base + (int64_t)r * d + c4) : z4;
+    float tt = gv.x * av.x + gv.y * av.y + gv.z * av.z + gv.w * av.w;
+#pragma unroll
+    for (int m = 1; m < RT; m <<= 1) tt += __shfl_xor(tt, m);
+    if ((e - r * RT) == 0) {
+      st_t[r] = tt;
+      st_l[r] = ok ? lse[((int64_t)b * L + r) * H + h] * 1.44269504088896341f : INFINITY;
+    }
+  }
+  __syncthreads();
+  const float scale = 1.0f / sqrtf((float)DH);
+  h8 bx[NF], bg[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    bx[f] = *reinterpret_cast<const h8*>(xh + (wave * 16 + i) * LDH + 32 * f + 8 * q);
+    bg[f] = *reinterpret_cast<const h8*>(gh + (wave * 16 + i) * LDH + 32 * f + 8 * q);
+  }
+  const float c1 = scale * 1.44269504088896341f;
+  const float l_own = st_l[wave * 16 + i], t_own = st_t[wave * 16 + i];
+  f32x4 acc[NC], ack[NC], acv[NC];  // dq, dk, dv
+#pragma unroll
+  for (int c = 0; c < NC; ++c) acc[c] = ack[c] = acv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // one partner block: the three NT tiles and the element-wise dS algebra; results in (dsa, dsb, pb) for tokens 16 t + 4 q + r
+  auto block_vals = [&](int t, bool live, f32x4& dsa, f32x4& dsb, f32x4& pb) {
+    dsa = dsb = pb = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!live) return;
+    const _Float16* xrow = xh + (t * 16 + i) * LDH + 8 * q;
+    const _Float16* grow = gh + (t * 16 + i) * LDH + 8 * q;
+    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dpt = sc, dpn = sc;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const h8 xa = *reinterpret_cast<const h8*>(xrow + 32 * f), ga = *reinterpret_cast<const h8*>(grow + 32 * f);
+      sc = mfma_h(xa, bx[f], sc);    // S[16 t + 4 q + r][own i]  (symmetric: both roles)
+      dpt = mfma_h(xa, bg[f], dpt);  // dP^T[key 16 t + 4 q + r][query own i] = x[key] . dA[query]
+      dpn = mfma_h(ga, bx[f], dpn);  // dP[query 16 t + 4 q + r][key own i]   = dA[query] . x[key]
+    }
+    const float4 l4 = ld4(st_l + t * 16 + 4 * q), t4 = ld4(st_t + t * 16 + 4 * q);
+    const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, tq[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int prt = t * 16 + 4 * q + r;
+      float pa = __builtin_amdgcn_exp2f(fmaf(sc[r], c1, -l_own));  // own token as query, partner as key
+      pa = (prt < L) ? pa : 0.f;                                    // padding keys (only the last block has any)
+      dsa[r] = (scale * pa) * (dpt[r] - t_own);
+      const float pbv = __builtin_amdgcn_exp2f(fmaf(sc[r], c1, -lq[r]));  // own token as key, partner as query (lse = +inf past L)
+      pb[r] = pbv;
+      dsb[r] = (scale * pbv) * (dpn[r] - tq[r]);
+    }
+  };
+  for (int t = 0; t < NTL; t += 2) {
+    f32x4 a0, b0, p0, a1, b1, p1;
+    block_vals(t, true, a0, b0, p0);
+    block_vals(t + 1, t + 1 < NTL, a1, b1, p1);
+    const h8 ha = pack_h8(a0, a1), hb = pack_h8(b0, b1), hp = pack_h8(p0, p1);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const h8 xb = srh_pair_b(xt, 16 * c + i, t, q), gb = srh_pair_b(gt, 16 * c + i, t, q);
+      acc[c] = mfma_h(ha, xb, acc[c]);  // dq: dS[own][partner] x[partner]
+      ack[c] = mfma_h(hb, xb, ack[c]);  // dk: dS[partner][own] x[partner]
+      acv[c] = mfma_h(hp, gb, acv[c]);  // dv: P[partner][own] dA[partner]
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wave * 16 + 4 * q + r;
+      if (row < L) dx[base + (int64_t)row * d + c * 16 + i] += (acc[c][r] + ack[c][r]) + acv[c][r];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // weight gradients of the plain Linears:  dW[M, K] = dY[T, M]^T X[T, K],  db[M] = column sums of dY
 // ---------------------------------------------------------------------------------------------------------
 // T is ~100k rows and the outputs are small (at most d x d), so the contraction is split over row chunks:
@@ -1256,6 +1501,36 @@ int attn_fwd_mfma(const SrPlan& p, const float* x, int batch, int L, float* A, f
   else hipLaunchKernelGGL(sr_attn_fwd_mfma_kernel<64>, grid, block, lds, st, x, L, p.d, A, lse);
   return 0;
 }
+// fp16-operand kernels: requested by the descriptor AND head depth 32 / 64, list_size <= 128 (otherwise the fp32 path runs)
+bool attn_f16_ok(const SrPlan& p, int L) { return p.att_f16 && attn_mfma_ok(p, L) && (p.dh == 32 || p.dh == 64); }
+int attn_fwd_f16(const SrPlan& p, const float* x, int batch, int L, float* A, float* lse, hipStream_t st) {
+  const int Lp = round_up(L, 16);
+  const size_t lds = ((size_t)16 * SR_MAXT * (p.dh + 8) + (size_t)p.dh * SRH_LT) * sizeof(_Float16);
+  const dim3 grid(batch, p.H), block(Lp * 4);
+  if (p.dh == 32) {
+    SR_CHECK(set_dyn_lds(sr_attn_fwd_f16_kernel<32>, lds));
+    hipLaunchKernelGGL(sr_attn_fwd_f16_kernel<32>, grid, block, lds, st, x, L, p.d, A, lse);
+  } else {
+    SR_CHECK(set_dyn_lds(sr_attn_fwd_f16_kernel<64>, lds));
+    hipLaunchKernelGGL(sr_attn_fwd_f16_kernel<64>, grid, block, lds, st, x, L, p.d, A, lse);
+  }
+  return 0;
+}
+int attn_bwd_f16(const SrPlan& p, const float* x, const float* dA, const float* Aout, const float* lse, int batch, int L, float* dx,
+                 hipStream_t st) {
+  const int Lp = round_up(L, 16);
+  const size_t lds = ((size_t)2 * 16 * SR_MAXT * (p.dh + 8) + (size_t)2 * p.dh * SRH_LT) * sizeof(_Float16) +
+                     (size_t)2 * 16 * (SR_MAXT + 1) * sizeof(float);
+  const dim3 grid(batch, p.H), block(Lp * 4);
+  if (p.dh == 32) {
+    SR_CHECK(set_dyn_lds(sr_attn_bwd_f16_kernel<32>, lds));
+    hipLaunchKernelGGL(sr_attn_bwd_f16_kernel<32>, grid, block, lds, st, x, dA, Aout, lse, L, p.d, dx);
+  } else {
+    SR_CHECK(set_dyn_lds(sr_attn_bwd_f16_kernel<64>, lds));
+    hipLaunchKernelGGL(sr_attn_bwd_f16_kernel<64>, grid, block, lds, st, x, dA, Aout, lse, L, p.d, dx);
+  }
+  return 0;
+}
 int attn_bwd_mfma(const SrPlan& p, const float* x, const float* dA, const float* Aout, const float* lse, int batch, int L, float* dx,
                   hipStream_t st) {
   const int Lp = round_up(L, 16);
@@ -1359,7 +1634,8 @@ extern "C" int ultr_setrank_forward(const ultr_setrank_desc* c, const float* par
   for (int l = 0; l < p.nl; ++l) {
     const SrLayer& y = p.lay[l];
     const float* x = sv + p.sv_x[l];
-    if (mfma_att) SR_CHECK(attn_fwd_mfma(p, x, batch, L, sv + p.sv_A[l], sv + p.sv_lse[l], st));
+    if (attn_f16_ok(p, L)) SR_CHECK(attn_fwd_f16(p, x, batch, L, sv + p.sv_A[l], sv + p.sv_lse[l], st));
+    else if (mfma_att) SR_CHECK(attn_fwd_mfma(p, x, batch, L, sv + p.sv_A[l], sv + p.sv_lse[l], st));
     else hipLaunchKernelGGL(sr_attn_fwd_kernel, dim3(batch, p.H), dim3(256), lds_att, st, x, L, d, p.dh, sv + p.sv_A[l]);
     // A Wd^T lands in out1's buffer, then out1 = LN1(x + (A Wd^T + bd)) in place (s1 keeps the pre-norm sum)
     SR_CHECK(gemm_xwT(sv + p.sv_A[l], params + y.wd, nullptr, sv + p.sv_out1[l], T, d, d, 0, st));
@@ -1393,12 +1669,14 @@ extern "C" int ultr_setrank_backward(const ultr_setrank_desc* c, const float* pa
   float* G2 = ws + p.ws_g[2];
   const unsigned rblk = (unsigned)((T + SR_ROWS - 1) / SR_ROWS);
   const int F = p.F, d = p.d, dff = p.dff;
-  const size_t lds_att = ((size_t)2 * L * (p.dh + 1) + 2 * (size_t)L * L) * sizeof(float);
-  if (lds_att > 160 * 1024) return ULTR_E_UNSUPPORTED;
-  if (lds_att > 64 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(sr_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)lds_att) != hipSuccess)
-    return ULTR_E_UNSUPPORTED;
+  const size_t lds_att = ((size_t)2 * L * (p.dh + 1) + 2 * (size_t)L * L) * sizeof(float);  // scalar kernel only
+  if (!attn_mfma_ok(p, L)) {
+    if (lds_att > 160 * 1024) return ULTR_E_UNSUPPORTED;
+    if (lds_att > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(sr_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_att) != hipSuccess)
+      return ULTR_E_UNSUPPORTED;
+  }
   // ---- output FFN:  s = oh wo2^T + bo2,  oh = relu(x_nl Wo1^T + bo1) ----------------------------------------------
   SR_CHECK(gemm_dyTx(p, dscores, sv + p.sv_oh, grads + p.wo2, T, dff, 1, ws, st));
   colsum(p, dscores, nullptr, nullptr, nullptr, 1, 0, ws, grads + p.bo2, st);
@@ -1433,7 +1711,9 @@ extern "C" int ultr_setrank_backward(const ultr_setrank_desc* c, const float* pa
     }
     SR_CHECK(wgrad(p, G0, sv + p.sv_A[l], grads + y.wd, nullptr, T, d, d, ws, st));
     SR_CHECK(gemm_dyw(G0, params + y.wd, G1, nullptr, T, d, d, 0, st));      // G1 = d A  [T, d]
-    if (attn_mfma_ok(p, L))   // G0 += attention path -> d x_l
+    if (attn_f16_ok(p, L))    // G0 += attention path -> d x_l
+      SR_CHECK(attn_bwd_f16(p, sv + p.sv_x[l], G1, sv + p.sv_A[l], sv + p.sv_lse[l], batch, L, G0, st));
+    else if (attn_mfma_ok(p, L))
       SR_CHECK(attn_bwd_mfma(p, sv + p.sv_x[l], G1, sv + p.sv_A[l], sv + p.sv_lse[l], batch, L, G0, st));
     else hipLaunchKernelGGL(sr_attn_bwd_kernel, dim3(batch, p.H), dim3(256), lds_att, st, sv + p.sv_x[l], (const float*)G1, L, d,
                             p.dh, G0);

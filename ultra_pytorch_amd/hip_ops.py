@@ -68,11 +68,15 @@ class SetRankShape:
     """Host-side geometry of one SetRank model: descriptor + flat parameter layout in the reference's
     state_dict order (SetRank.py:95-103, 130-141)."""
 
-    def __init__(self, feature_size, d_model=256, num_heads=8, num_layers=2, dff=64):
+    def __init__(self, feature_size, d_model=256, num_heads=8, num_layers=2, dff=64, attention_dtype="fp32"):
         self.lib = _lib.load()
         self.feature_size, self.d_model, self.num_heads = int(feature_size), int(d_model), int(num_heads)
         self.num_layers, self.dff = int(num_layers), int(dff)
-        self.desc = _lib.SetRankDesc(self.feature_size, self.d_model, self.num_heads, self.num_layers, self.dff)
+        if attention_dtype not in _lib.ATTN_DTYPE:
+            raise ValueError("attention_dtype must be one of %s (got %r)" % (sorted(_lib.ATTN_DTYPE), attention_dtype))
+        self.attention_dtype = attention_dtype
+        self.desc = _lib.SetRankDesc(self.feature_size, self.d_model, self.num_heads, self.num_layers, self.dff,
+                                     _lib.ATTN_DTYPE[attention_dtype])
         self.n_params = int(self.lib.ultr_setrank_param_count(ctypes.byref(self.desc)))
         if self.n_params <= 0:
             raise ValueError("bad SetRank description (d_model must be a multiple of num_heads, 1..8 layers)")

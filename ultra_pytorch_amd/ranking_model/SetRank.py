@@ -49,13 +49,17 @@ class SetRank(nn.Module):
     def __init__(self, hparams_str, feature_size=None):
         super().__init__()
         print("build SetRank")
-        self.hparams = HParams(d_model=256, num_heads=8, num_layers=2, diff=64, rate=0.0, initializer=None)
+        # attention_dtype is this package's one extension of the reference's hparams: "fp32" (default, the 1e-5 parity
+        # path) or "fp16" (fp16 matrix-core operands in the self-attention, ordering-level parity; BASELINE config 5)
+        self.hparams = HParams(d_model=256, num_heads=8, num_layers=2, diff=64, rate=0.0, initializer=None,
+                               attention_dtype="fp32")
         self.hparams.parse(hparams_str)
         if float(self.hparams.rate) != 0.0:
             raise NotImplementedError("rate=%r: dropout is not implemented (the reference's default is 0.0)" % self.hparams.rate)
         self.feature_size = int(feature_size)
         self.shape = hip_ops.SetRankShape(self.feature_size, self.hparams.d_model, self.hparams.num_heads,
-                                          self.hparams.num_layers, self.hparams.diff)
+                                          self.hparams.num_layers, self.hparams.diff,
+                                          attention_dtype=str(self.hparams.attention_dtype))
         self._bind(init_setrank_params(self.shape))
         self._fwd_saved = {}
 
