@@ -73,10 +73,27 @@ void bench(int64_t R, int K, int N) {
 }
 
 int main(int argc, char** argv) {
+#ifdef UGEMM_DEBUG_GRID
+  if (argc > 2) ugemm::g_ugemm_grid_mode = atoi(argv[2]);
+#endif
   if (argc > 1) {  // one shape only (counter passes): tools/bin/gemm_tile_ub 1
     bench<false, 64, 128, 2, 2>(102400, 256, 256);
-    bench<true, 64, 128, 2, 2>(102400, 256, 256);
+    bench<false, 64, 128, 4, 2>(102400, 256, 256);
+    bench<true, 64, 128, 4, 2>(102400, 256, 256);
     bench<false, 64, 64, 4, 1>(102400, 256, 64);
+    bench<false, 64, 128, 4, 2>(12800, 700, 512);
+    bench<false, 64, 128, 2, 2>(12800, 700, 512);
+    bench<false, 128, 128, 2, 2>(102400, 256, 256);
+    bench<false, 128, 128, 4, 2>(102400, 256, 256);
+    bench<false, 256, 128, 4, 2>(102400, 256, 256);
+    bench<true, 64, 128, 2, 2>(102400, 256, 256);
+    bench<true, 128, 128, 4, 2>(102400, 256, 256);
+    bench<false, 64, 64, 4, 1>(102400, 256, 64);
+    bench<false, 128, 64, 8, 1>(102400, 256, 64);
+    bench<true, 64, 64, 4, 1>(102400, 256, 64);
+    bench<true, 128, 64, 8, 1>(102400, 256, 64);
+    bench<false, 64, 128, 2, 2>(102400, 64, 256);
+    bench<false, 128, 128, 4, 2>(102400, 64, 256);
     return 0;
   }
   bench<false>(12800, 700, 512);

@@ -43,7 +43,8 @@ constexpr int LDA = BK + 8;   // LDS row stride of k-contiguous tiles (A, n-majo
 
 // ---- A-operand producers ------------------------------------------------------------------------------------------------
 // A thread stages the same rows (and the same four contraction columns k4 of every k-tile) throughout the k loop:
-//   row(r)            once per staged row before the loop: whatever is per-row (source offset, LayerNorm statistics);
+//   row(r, rend)      once per staged row of a chunk (rows >= rend read as zeros): whatever is per-row (source offset,
+//                     LayerNorm statistics);
 //   raw(ctx, k)       ISSUES the global load of [k, k+4) of that row for one k-tile (no arithmetic on the result here:
 //                     the load must stay in flight behind the current tile's MFMAs);
 //   cols(k) / finish  per-column operands and the arithmetic, applied when the registers are written to LDS.
@@ -53,7 +54,7 @@ struct APlain {  // A[r][k], row stride lda; rows >= R and k >= K read as zero
   int K, lda;
   struct Row { unsigned off; };
   struct Cols {};
-  __device__ __forceinline__ Row row(int64_t r) const { return Row{r < R ? (unsigned)(r * lda * 4) : ULTR_OOB}; }
+  __device__ __forceinline__ Row row(int64_t r, int64_t rend) const { return Row{r < rend ? (unsigned)(r * lda * 4) : ULTR_OOB}; }
   __device__ __forceinline__ float4 raw(const Row& c, int k) const {
     return buf_ld4(make_src(a, R * lda), (c.off != ULTR_OOB && k < K) ? c.off + (unsigned)k * 4u : ULTR_OOB);
   }
@@ -73,9 +74,9 @@ struct ALayerNorm {
   int K, B, L;
   struct Row { unsigned off; float mean, rstd; bool in; };
   struct Cols { float4 g, b; };
-  __device__ __forceinline__ Row row(int64_t r) const {
+  __device__ __forceinline__ Row row(int64_t r, int64_t rend) const {
     Row c;
-    c.in = r < R;
+    c.in = r < rend;
     c.mean = c.in ? mean[r] : 0.f;
     c.rstd = c.in ? rstd[r] : 0.f;
     int64_t src = r;
@@ -174,6 +175,11 @@ struct Cfg {
   static_assert(BM * (BK / 4) % NT == 0 && (BK * BN / 4) % NT == 0, "staging divides evenly");
 };
 
+// Balanced persistent schedule.  The unit of work is 16 output rows x BN columns; a workgroup owns a CONTIGUOUS range of
+// units (column-block-major: its chunks mostly share one B panel) and walks it in chunks of up to BM / 16 units.  launch()
+// starts exactly the workgroups the GPU holds at once, so every workgroup gets total / grid units +- 1: no tail round of
+// half-empty compute units, and with RT = 1 (a wave = one 16-row tile) a short last chunk only issues its own MFMAs.  The next chunk's first k-tile is requested before the epilogue of the current
+// one (k-major B: the epilogue needs no LDS).
 template <int BM, int BN, int WM, int WN, bool B_NMAJOR, class AProd, class Epi>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(Dims d, AProd aprod, const float* __restrict__ Bg, Epi epi) {
   using C = Cfg<BM, BN, WM, WN, B_NMAJOR>;
@@ -182,38 +188,40 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(Dims d, AProd aprod,
   float* Bs = smem + 2 * C::A_FLOATS;      // [2][...]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, q = lane >> 4;
-  const int wr = (wave / WN) * (BM / WM), wc = (wave % WN) * (BN / WN);  // wave origin inside the tile
-  // XCD-aware tile order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs, so consecutive ids
-  // should NOT be neighbours; give every XCD a contiguous band of row blocks (they share the B panel in that XCD's L2
-  // and walk A rows no other XCD touches)
+  const int wr = (wave / WN) * (BM / WM), wc = (wave % WN) * (BN / WN);  // wave origin inside the chunk
   const int ncb = (d.N + BN - 1) / BN;
-  const int nrb = (int)((d.R + BM - 1) / BM);
-  const int total = nrb * ncb;
-  int wg = blockIdx.x;
-  {
-    const int per = (total + 7) / 8;
-    const int x = wg & 7, k = wg >> 3;
-    const int cand = x * per + k;
-    if (per * 8 == total) wg = cand;  // only when the grid splits evenly; otherwise keep the plain order
-  }
-  const int rb = wg / ncb, cb = wg - rb * ncb;
-  const int64_t r0 = (int64_t)rb * BM;
-  const int n0 = cb * BN;
+  const int64_t nru = (d.R + 15) / 16;      // 16-row units per column block
+  const int64_t U = nru * ncb;
+  // consecutive block ids are dealt round-robin to the 8 XCDs: give every XCD a contiguous band of the unit range (its
+  // workgroups share B panels and neighbouring A rows in that XCD's L2)
+  int64_t w = blockIdx.x;
+  const int64_t G = gridDim.x;
+  if ((G & 7) == 0) w = (w & 7) * (G >> 3) + (w >> 3);
+  int64_t u = w * U / G;
+  const int64_t u_end = (w + 1) * U / G;
+  if (u >= u_end) return;
   const Src bsrc = make_src(Bg, B_NMAJOR ? (int64_t)d.N * d.ldb : (int64_t)d.K * d.ldb);
+  const int nk = (d.K + BK - 1) / BK;
 
-  f32x4 acc[C::RT][C::CT];
-#pragma unroll
-  for (int rt = 0; rt < C::RT; ++rt)
-#pragma unroll
-    for (int t = 0; t < C::CT; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
+  // ---- the chunk being staged / computed ------------------------------------------------------------------------------
+  int64_t r0 = 0, rend = 0;  // rows [r0, rend) of the chunk
+  int n0 = 0, m_units = 0;
   float4 areg[C::A_LOADS], breg[C::B_LOADS];
-  // a thread stages rows (tid >> 3) + (NT / 8) j, always the four contraction columns k4 of a k-tile
-  const int k4 = (tid & 7) * 4;
+  const int k4 = (tid & 7) * 4;  // a thread stages rows (tid >> 3) + (NT / 8) j, always columns k4 .. k4 + 3 of a k-tile
   typename AProd::Row arow[C::A_LOADS];
-#pragma unroll
-  for (int j = 0; j < C::A_LOADS; ++j) arow[j] = aprod.row(r0 + ((tid + C::NT * j) >> 3));
   typename AProd::Cols acol;
+  auto begin_chunk = [&](int64_t uu) {
+    const int64_t cb = uu / nru, ru = uu - cb * nru;
+    int64_t m = u_end - uu;
+    if (m > BM / 16) m = BM / 16;
+    if (m > nru - ru) m = nru - ru;
+    m_units = (int)m;
+    r0 = ru * 16;
+    rend = r0 + 16 * m < d.R ? r0 + 16 * m : d.R;
+    n0 = (int)cb * BN;
+#pragma unroll
+    for (int j = 0; j < C::A_LOADS; ++j) arow[j] = aprod.row(r0 + ((tid + C::NT * j) >> 3), rend);
+  };
   auto load_tile = [&](int k0) {
     acol = aprod.cols(k0 + k4);
 #pragma unroll
@@ -222,16 +230,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(Dims d, AProd aprod,
     for (int j = 0; j < C::B_LOADS; ++j) {
       const int idx = tid + C::NT * j;
       if constexpr (B_NMAJOR) {
-        const int n = idx >> 3, k4 = (idx & 7) * 4;
-        const bool ok = n0 + n < d.N && k0 + k4 < d.K;
-        breg[j] = buf_ld4(bsrc, ok ? (unsigned)(((int64_t)(n0 + n) * d.ldb + k0 + k4) * 4) : ULTR_OOB);
+        const int n = idx >> 3, kk4 = (idx & 7) * 4;
+        const bool ok = n0 + n < d.N && k0 + kk4 < d.K;
+        breg[j] = buf_ld4(bsrc, ok ? (unsigned)(((int64_t)(n0 + n) * d.ldb + k0 + kk4) * 4) : ULTR_OOB);
       } else {
         const int kk = idx / (BN / 4), c4 = (idx - kk * (BN / 4)) * 4;
         const bool ok = k0 + kk < d.K && n0 + c4 < d.N;
         breg[j] = buf_ld4(bsrc, ok ? (unsigned)(((int64_t)(k0 + kk) * d.ldb + n0 + c4) * 4) : ULTR_OOB);
       }
     }
-    // keep the staging loads ABOVE the MFMAs of the current tile (hipcc otherwise sinks each load to its first use)
+    // keep the staging loads ABOVE the MFMAs / the epilogue that follow (hipcc otherwise sinks each load to its first use)
     __builtin_amdgcn_sched_barrier(0);
   };
   auto store_tile = [&](int buf, int k0) {
@@ -252,11 +260,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(Dims d, AProd aprod,
       }
     }
   };
-  auto compute = [&](int buf) {
+  f32x4 acc[C::RT][C::CT];
+  auto compute = [&](int buf, int live_rt) {  // live_rt: row tiles of this wave inside the chunk (wave-uniform)
     const float* Ab = As + buf * C::A_FLOATS + (wr + i) * LDA + 4 * q;
     const float* Bb = Bs + buf * C::B_FLOATS;
-    // every fragment of the k-tile is requested before the first MFMA: one LDS round trip per 32 contraction steps is
-    // exposed instead of one per 16 (2 x (RT + 4) x 4 registers)
+    // every fragment of the k-tile is requested before the first MFMA: one LDS round trip per 32 contraction steps
     float4 a[2][C::RT], b[2][4];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -275,12 +283,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(Dims d, AProd aprod,
       if constexpr (B_NMAJOR) {
 #pragma unroll
         for (int rt = 0; rt < C::RT; ++rt) {
-          const float av[4] = {a[h][rt].x, a[h][rt].y, a[h][rt].z, a[h][rt].w};
+          if (rt < live_rt) {
+            const float av[4] = {a[h][rt].x, a[h][rt].y, a[h][rt].z, a[h][rt].w};
 #pragma unroll
-          for (int t = 0; t < C::CT; ++t) {
-            const float bv[4] = {b[h][t].x, b[h][t].y, b[h][t].z, b[h][t].w};
+            for (int t = 0; t < C::CT; ++t) {
+              const float bv[4] = {b[h][t].x, b[h][t].y, b[h][t].z, b[h][t].w};
 #pragma unroll
-            for (int s = 0; s < 4; ++s) acc[rt][t] = mfma16(av[s], bv[s], acc[rt][t]);
+              for (int s = 0; s < 4; ++s) acc[rt][t] = mfma16(av[s], bv[s], acc[rt][t]);
+            }
           }
         }
       } else {
@@ -289,79 +299,104 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(Dims d, AProd aprod,
           const float bv[4] = {b[h][s].x, b[h][s].y, b[h][s].z, b[h][s].w};
 #pragma unroll
           for (int rt = 0; rt < C::RT; ++rt) {
-            const float as = (s == 0) ? a[h][rt].x : (s == 1) ? a[h][rt].y : (s == 2) ? a[h][rt].z : a[h][rt].w;
+            if (rt < live_rt) {
+              const float as = (s == 0) ? a[h][rt].x : (s == 1) ? a[h][rt].y : (s == 2) ? a[h][rt].z : a[h][rt].w;
 #pragma unroll
-            for (int t = 0; t < C::CT; ++t) acc[rt][t] = mfma16(as, bv[t], acc[rt][t]);
+              for (int t = 0; t < C::CT; ++t) acc[rt][t] = mfma16(as, bv[t], acc[rt][t]);
+            }
           }
         }
       }
     }
   };
 
-  const int nk = (d.K + BK - 1) / BK;
+  begin_chunk(u);
   load_tile(0);
   store_tile(0, 0);
   lds_barrier();
-#ifdef UGEMM_DEBUG_CYC
-  const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
-#endif
-#ifdef UGEMM_DEBUG_NOSTAGE  // experiment: MFMA + fragment reads only
-  for (int t = 0; t < nk; ++t) compute(t & 1);
-#else
-  for (int t = 0; t < nk; ++t) {
-    if (t + 1 < nk) load_tile((t + 1) * BK);
-#ifndef UGEMM_DEBUG_NOMFMA
-    compute(t & 1);
-#endif
-    if (t + 1 < nk) store_tile((t + 1) & 1, (t + 1) * BK);
-    lds_barrier();
-  }
-#endif
-#ifdef UGEMM_DEBUG_CYC
-  if (tid == 0) {
-    g_ugemm_cyc[blockIdx.x % 4096] = __builtin_amdgcn_s_memtime() - dbg_t0;
-    g_ugemm_xcc[blockIdx.x % 4096] = dbg_t0;
-  }
-#endif
-  // ---- epilogue -----------------------------------------------------------------------------------------------------------
-  if constexpr (!B_NMAJOR) {
-    // k-major B: a lane already holds four consecutive output columns of a row (the four interleaved column tiles):
-    // straight to the functor, 256 contiguous bytes per 16 lanes
+  for (;;) {
 #pragma unroll
     for (int rt = 0; rt < C::RT; ++rt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t row = r0 + wr + 16 * rt + 4 * q + r;
-        const int c = n0 + wc + 4 * i;
-        if (row < d.R && c < d.N) {
+      for (int t = 0; t < C::CT; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int live_rt = (16 * m_units - wr + 15) / 16;  // this wave's row tiles that hold rows of the chunk
+    live_rt = live_rt < 0 ? 0 : (live_rt > C::RT ? C::RT : live_rt);
+    for (int t = 0; t < nk; ++t) {
+      if (t + 1 < nk) load_tile((t + 1) * BK);
+      if (live_rt > 0) compute(t & 1, live_rt);
+      if (t + 1 < nk) store_tile((t + 1) & 1, (t + 1) * BK);
+      lds_barrier();
+    }
+    // ---- this chunk's output; the next chunk's first k-tile goes in flight before it (k-major B) -----------------------
+    const int64_t e_r0 = r0, e_rend = rend;
+    const int e_n0 = n0;
+    const int64_t un = u + m_units;
+    const bool more = un < u_end;
+    if (more) {
+      begin_chunk(un);
+      if constexpr (!B_NMAJOR) load_tile(0);
+    }
+    if constexpr (!B_NMAJOR) {
+      // a lane already holds four consecutive output columns of a row (the four interleaved column tiles): straight to
+      // the functor, 256 contiguous bytes per 16 lanes
+#pragma unroll
+      for (int rt = 0; rt < C::RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t row = e_r0 + wr + 16 * rt + 4 * q + r;
+          const int c = e_n0 + wc + 4 * i;
+          if (row < e_rend && c < d.N) {
+            const int nv = d.N - c < 4 ? d.N - c : 4;
+            epi(row, c, make_float4(acc[rt][0][r], acc[rt][1][r], acc[rt][2][r], acc[rt][3][r]), nv);
+          }
+        }
+    } else {
+      // n-major B: a lane holds one column of four tiles; transpose through LDS (the staging buffers are free: every wave
+      // passed the barrier behind the last k-tile) into float4 pieces
+      float* Cs = smem;
+#pragma unroll
+      for (int rt = 0; rt < C::RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wr + 16 * rt + 4 * q + r;
+#pragma unroll
+          for (int t = 0; t < C::CT; ++t) Cs[row * C::LDC + wc + 16 * t + i] = acc[rt][t][r];
+        }
+      lds_barrier();
+      constexpr int PIECES = BM * (BN / 4);
+#pragma unroll 4
+      for (int idx = tid; idx < PIECES; idx += C::NT) {
+        const int row = idx / (BN / 4), c4 = (idx - row * (BN / 4)) * 4;
+        const int64_t r = e_r0 + row;
+        const int c = e_n0 + c4;
+        if (r < e_rend && c < d.N) {
           const int nv = d.N - c < 4 ? d.N - c : 4;
-          epi(row, c, make_float4(acc[rt][0][r], acc[rt][1][r], acc[rt][2][r], acc[rt][3][r]), nv);
+          epi(r, c, ld4(Cs + row * C::LDC + c4), nv);
         }
       }
-  } else {
-    // n-major B: a lane holds one column of four tiles; transpose through LDS into float4 pieces
-    float* Cs = smem;
-#pragma unroll
-    for (int rt = 0; rt < C::RT; ++rt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = wr + 16 * rt + 4 * q + r;
-#pragma unroll
-        for (int t = 0; t < C::CT; ++t) Cs[row * C::LDC + wc + 16 * t + i] = acc[rt][t][r];
-      }
-    lds_barrier();
-    constexpr int PIECES = BM * (BN / 4);
-#pragma unroll 4
-    for (int idx = tid; idx < PIECES; idx += C::NT) {
-      const int row = idx / (BN / 4), c4 = (idx - row * (BN / 4)) * 4;
-      const int64_t r = r0 + row;
-      const int c = n0 + c4;
-      if (r < d.R && c < d.N) {
-        const int nv = d.N - c < 4 ? d.N - c : 4;
-        epi(r, c, ld4(Cs + row * C::LDC + c4), nv);
+      if (more) {
+        lds_barrier();  // the tile in LDS has been read
+        load_tile(0);
       }
     }
+    if (!more) break;
+    store_tile(0, 0);
+    lds_barrier();
+    u = un;
   }
+}
+
+#ifdef UGEMM_DEBUG_GRID
+static int g_ugemm_grid_mode = 0;
+#endif
+inline int device_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+  }
+  return cus;
 }
 
 template <int BM, int BN, int WM, int WN, bool B_NMAJOR, class AProd, class Epi>
@@ -375,18 +410,38 @@ inline hipError_t launch(const Dims& d, const AProd& aprod, const float* B, cons
     if (e != hipSuccess) return e;
     attr = true;
   }
-  const int64_t nrb = (d.R + BM - 1) / BM;
+  // resident workgroups: LDS (160 KB per CU) and wave slots (32 per CU); the kernels stay under 80 registers at 8 waves
+  // and under 128 at 4, so registers do not bind first
+  int per_cu = (int)((160 * 1024) / lds);
+  const int by_waves = 32 / (WM * WN);
+  if (per_cu > by_waves) per_cu = by_waves;
+  if (per_cu < 1) per_cu = 1;
+  const int64_t slots = (int64_t)per_cu * device_cus();
+  const int64_t nru = (d.R + 15) / 16;
   const int ncb = (d.N + BN - 1) / BN;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(nrb * ncb)), dim3(C::NT), lds, st, d, aprod, B, epi);
+  // One full chunk per workgroup when everything fits at once; otherwise exactly the workgroups the GPU holds, each with
+  // total / grid units +- 1.  Measured (tools/gemm_tile_ubench.hip, grid modes): at 102400 x 256 x 256 this ties one
+  // workgroup per chunk (157 us both; 3200 chunks on 768 slots), at 12800 x 700 x 512 (800 chunks: 1.04 rounds) it wins
+  // 108 vs 114 us; "whole rounds" grids (floor(chunks / slots) x slots workgroups of a chunk and a bit) lost at the
+  // large shape (184 us: the second, short chunk of a workgroup pays the full k-loop latency).
+  const int64_t chunks = ((nru + BM / 16 - 1) / (BM / 16)) * ncb;
+  int64_t grid = chunks <= slots ? chunks : slots;
+#ifdef UGEMM_DEBUG_GRID
+  if (g_ugemm_grid_mode == 1) grid = chunks;
+  if (g_ugemm_grid_mode == 2) grid = chunks <= slots ? chunks : slots;
+  if (g_ugemm_grid_mode >= 16) grid = chunks <= slots ? chunks : (int64_t)g_ugemm_grid_mode * device_cus();
+#endif
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::NT), lds, st, d, aprod, B, epi);
   return hipGetLastError();
 }
 
-// C = epi(A' . B).  Tile choice (tools/gemm_tile_ubench.hip): 64 x 128 (3 workgroups per CU: 53 KB of LDS each) beats
-// 128 x 128 (2 per CU) at every shape measured - more workgroups in different phases per CU hide each other's staging,
-// barriers, prologue and epilogue; narrow outputs take 64 x 64 (4 per CU)
+// C = epi(A' . B).  Tile choice (tools/gemm_tile_ubench.hip): 64 x 128 with 8 waves (a wave = one 16-row tile x 64
+// columns, 3 workgroups = 24 waves per CU) for wide outputs, 64 x 64 with 4 waves for narrow ones: more, shorter waves
+// per CU hide each other's staging, barriers and epilogues better than the classic 128 x 128 / 4-wave shape here
+// (83 -> 90 TFLOP/s at 102400 x 256 x 256 before the persistent schedule), and RT = 1 makes short chunks cheap
 template <bool B_NMAJOR, class AProd, class Epi>
 inline hipError_t run(const Dims& d, const AProd& aprod, const float* B, const Epi& epi, hipStream_t st) {
-  if (d.N > 64) return launch<64, 128, 2, 2, B_NMAJOR>(d, aprod, B, epi, st);
+  if (d.N > 64) return launch<64, 128, 4, 2, B_NMAJOR>(d, aprod, B, epi, st);
   return launch<64, 64, 4, 1, B_NMAJOR>(d, aprod, B, epi, st);
 }
 
