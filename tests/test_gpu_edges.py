@@ -129,3 +129,24 @@ def test_longest_lists(algo, L):
     (g,) = torch.autograd.grad(loss, s)
     g = g.numpy()
     np.testing.assert_allclose(ds * gs, g, rtol=3e-5, atol=3e-6 * max(1.0, float(np.abs(g).max())))
+
+
+def test_weight_copy_staleness_guard(monkeypatch):
+    """The forward reads a k-major COPY of the hidden weights.  In-place tensor ops bump torch's version counter and rebuild
+    it; a write through `.data` does not - ULTR_CHECK_WT=1 turns that into an error, invalidate_weight_copy() is the fix."""
+    from ultra_pytorch_amd import hip_ops
+    from ultra_pytorch_amd.ranking_model import DNN
+    monkeypatch.setenv("ULTR_CHECK_WT", "1")
+    model = DNN("hidden_layer_sizes=[16, 8]", 12).cuda()
+    x = [torch.randn(5, 12, device="cuda") for _ in range(3)]
+    s0 = torch.cat(model.build(x), dim=1).clone()
+    w = model.sequential.linear0.weight
+    w.copy_(w * 2.0)                      # in place: version counter moves, copy rebuilt
+    s1 = torch.cat(model.build(x), dim=1).clone()
+    assert not torch.allclose(s0, s1)
+    w.data.mul_(0.5)                      # behind the counter: the copy is stale ...
+    with pytest.raises(RuntimeError, match="stale k-major weight copy"):
+        model.build(x)
+    model.invalidate_weight_copy()        # ... until the writer says so
+    s2 = torch.cat(model.build(x), dim=1)
+    torch.testing.assert_close(s2, s0, rtol=1e-5, atol=1e-6)

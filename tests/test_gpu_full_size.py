@@ -70,14 +70,24 @@ def test_full_size_step_matches_oracle(name):
     aux = aux_for(name, rng)
     ref = run_oracle(name, params, feats, ids, y, aux)
     run, scores, ds, g, tail = run_hip(name, params, feats, ids, y, aux)
-    np.testing.assert_allclose(scores, ref["scores"], atol=2e-5)
+    gsx = {"softmax": 1.0 / tail[1], "dla": 1.0 / tail[1], "pairdebias": 1.0, "lambdarank": 1.0 / tail[1]}[algo]
+    gd = np.abs(g * gsx - ref["grads"])
+    print("%s: max |score diff| %.2e, grads: max abs diff / max|g| %.2e, max rel diff over |g| > 1e-3 max|g|: %.2e"
+          % (name, np.abs(scores - ref["scores"]).max(), gd.max() / np.abs(ref["grads"]).max(),
+             (gd / np.maximum(np.abs(ref["grads"]), 1e-30))[np.abs(ref["grads"]) > 1e-3 * np.abs(ref["grads"]).max()].max()))
+    np.testing.assert_allclose(scores, ref["scores"], atol=1e-5)  # measured: <= 2e-6 at every config
     state = None if algo == "dla" else np.zeros_like(params)
     new_params, _, aux2, sc = run.update(state)
-    assert abs(sc[0] - ref["loss"]) <= 2e-5 * max(1.0, abs(ref["loss"]))
+    assert abs(sc[0] - ref["loss"]) <= 1e-5 * max(1.0, abs(ref["loss"]))
     gs = {"softmax": 1.0 / tail[1], "dla": 1.0 / tail[1], "pairdebias": 1.0, "lambdarank": 1.0 / tail[1]}[algo]
     gref = ref["grads"]
-    np.testing.assert_allclose(g * gs, gref, rtol=1e-4, atol=1e-5 * float(np.abs(gref).max()))
-    assert abs(sc[1] - ref["norm"]) <= 1e-4 * ref["norm"]
+    # The 1e-5 bar of the golden cases, with the absolute floor scaled to the gradient: every entry is a sum over
+    # 2 560 - 12 800 rows of products that mostly cancel, so the error of an entry is accumulation-order noise proportional to
+    # the size of its TERMS, not of the sum (the printed figures: max abs diff 0.9e-6 .. 4.2e-6 x max|g| over the four
+    # configs; entries 1000x smaller than max|g| therefore differ by up to 3e-4 relative - torch-CPU shows the same spread
+    # against itself between 1 and 16 threads, and tools/diag_precision.py puts both paths equally far from an fp64 evaluation)
+    np.testing.assert_allclose(g * gs, gref, rtol=1e-5, atol=1e-5 * float(np.abs(gref).max()))
+    assert abs(sc[1] - ref["norm"]) <= 1e-5 * ref["norm"]
     if algo in ("pairdebias", "lambdarank"):
         np.testing.assert_allclose(aux2[:L], ref["t_plus"].ravel(), atol=2e-6)
         np.testing.assert_allclose(aux2[L:], ref["t_minus"].ravel(), atol=2e-6)
@@ -158,7 +168,7 @@ def test_batch_permutation_invariance_and_determinism():
     np.testing.assert_allclose(t2[:4], t1[:4], rtol=1e-5)
 
 
-@pytest.mark.parametrize("algo", ["ipw", "dla"])
+@pytest.mark.parametrize("algo", ["ipw", "dla", "ipw_cfg2"])
 def test_multi_step_trajectory_and_ndcg_parity(algo):
     """BASELINE metric, second half: NDCG@10 parity.  40 training steps on the SAME batch sequence from the SAME
     initialisation, once on the HIP path and once with the oracle; trajectories are not compared bit-wise (fp32 order
@@ -168,6 +178,8 @@ def test_multi_step_trajectory_and_ndcg_parity(algo):
     from ultra_pytorch_amd import engine, hip_ops, synthetic
     from ultra_pytorch_amd.ranking_model import init_flat_params
     F, hidden, B, L, steps = 136, [64, 32], 64, 10, 40
+    if algo == "ipw_cfg2":  # the BASELINE headline shape itself: DNN[256,256], batch 256 (the fused forward+loss+backward kernel)
+        algo, hidden, B = "ipw", [256, 256], 256
     shape = hip_ops.DnnShape(F, hidden, "elu")
     rng = np.random.RandomState(21)
     batches = [synthetic.make_batch(rng, B, L, F) for _ in range(steps)]

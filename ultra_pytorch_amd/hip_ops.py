@@ -4,6 +4,7 @@ Every function takes CUDA(ROCm) float32 / int32 tensors, passes raw pointers + t
 HIP stream to libultr_hip.so and returns immediately (asynchronous w.r.t. the host).
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -148,6 +149,21 @@ class WeightCopy:
         self.shape = shape
         self.n = int(shape.lib.ultr_dnn_wt_floats(ctypes.byref(shape.desc)))
         self.wt, self.key, self.ref = None, None, None
+        self.check = os.environ.get("ULTR_CHECK_WT", "0") == "1"
+
+    def invalidate(self):
+        """Force a rebuild on the next use.  torch's version counter sees every in-place tensor op (copy_, load_state_dict,
+        optimizers), but NOT writes through `.data`, raw pointers (other than this library's own update kernel, which
+        maintains the copy itself) or DLPack aliases: whoever writes the parameters that way must call this
+        (`ranking_model.DNN.invalidate_weight_copy()`); ULTR_CHECK_WT=1 verifies the copy on every use (debug, synchronises)."""
+        self.key = None
+
+    def _verify(self, params):
+        fresh = torch.empty_like(self.wt)
+        check(self.shape.lib.ultr_dnn_build_wt(ctypes.byref(self.shape.desc), _p(params), _p(fresh), _stream()), "ultr_dnn_build_wt")
+        if not torch.equal(fresh, self.wt):
+            raise RuntimeError("stale k-major weight copy: the parameters were written behind torch's version counter "
+                               "(.data / raw pointer); call invalidate_weight_copy() after such writes")
 
     def get(self, params):
         # identity of the tensor OBJECT (weakref: a freed tensor's address and version 0 can both be reused)
@@ -160,6 +176,8 @@ class WeightCopy:
             check(self.shape.lib.ultr_dnn_build_wt(ctypes.byref(self.shape.desc), _p(params), _p(self.wt), _stream()),
                   "ultr_dnn_build_wt")
             self.key, self.ref = key, weakref.ref(params)
+        elif self.check:
+            self._verify(params)
         return self.wt
 
 

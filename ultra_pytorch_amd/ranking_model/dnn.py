@@ -80,6 +80,11 @@ class DNN(nn.Module):
         self._fwd_cache = {}
         return self
 
+    def invalidate_weight_copy(self):
+        """Call after writing parameters behind torch's back (`.data`, raw pointers, DLPack): the forward kernels read a
+        k-major COPY of the hidden weights that is rebuilt only when torch's version counter moves (hip_ops.WeightCopy)."""
+        hip_ops.weight_copy(self.shape).invalidate()
+
     def load_state_dict(self, state_dict, strict=True):
         own = dict(self.state_dict())
         missing = [k for k in own if k not in state_dict]
