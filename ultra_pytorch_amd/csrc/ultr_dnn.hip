@@ -502,7 +502,11 @@ extern "C" int ultr_trace_read(unsigned long long* host_out) {
 #ifndef FWD_D
 #define FWD_D 2
 #endif
-template <int R, int NW, bool VEC>
+// Q4: the variant with 64-column chunks / 16-byte weight loads in the GEMM phases.  It needs ~170 registers (four
+// accumulator tiles + a two-trip ring of 16-byte loads), so the launcher picks it only where the LDS footprint leaves ONE
+// workgroup per CU anyway (2 waves per SIMD: 256 registers each) - e.g. BASELINE config 4 (700-wide input: 228 -> 220 us);
+// where two workgroups share a CU (config 3) the 128-register build below is the faster one (84 vs 103 us).
+template <int R, int NW, bool VEC, bool Q4 = false>
 __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float* __restrict__ params,
                                                           const float* __restrict__ features, int64_t n_docs,
                                                           const int32_t* __restrict__ docids, int B, int L,
@@ -750,8 +754,62 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
       if constexpr (VEC) {
         // Y = act(X . W^T + b) on the k-major weight copy.  (Issuing the first trips before the LayerNorm was
         // measured SLOWER: hipcc then drains vmcnt(0) inside the LayerNorm / epilogue code, see DESIGN.md.)
-        pipe.begin(Wt, M, kb, ke, c0, has, 0, lane);
-        if (ksplit == 1) {
+        // 64-column chunks with 16-byte weight loads (a lane holds 4 consecutive outputs of a weight row: 256 contiguous
+        // bytes per 16 lanes, half the load instructions of the 32-column form) whenever the waves can be kept busy that way:
+        // >= NW chunks (a wave walks chunks over the whole contraction) or chunks x equal 32-aligned contraction slices = NW
+        int q4 = 0;  // 0: no; else contraction slices
+        if constexpr (NW == 8 && Q4) {
+          if ((M & 63) == 0) {
+            const int nch4 = M >> 6;
+            if (nch4 >= NW) q4 = 1;
+            else if (NW % nch4 == 0 && K % (32 * (NW / nch4)) == 0 && K / (NW / nch4) >= 64) q4 = NW / nch4;
+          }
+        }
+        if (Q4 && q4 == 1) {
+          GemmPipe<RT, 4, FWD_D, 0> pipe4;
+          const int c4 = wave * 64;
+          pipe4.begin(Wt, M, 0, K, c4, c4 < M, 0, lane);
+          for (int cc = c4; cc < M; cc += NW * 64) {
+            f32x4 acc[RT][4];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+              for (int t = 0; t < 4; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            pipe4.run(X, ld, Wt, 0, K, 0, acc, lane);
+            if (cc + NW * 64 < M) pipe4.begin(Wt, M, 0, K, cc + NW * 64, true, 0, lane);
+            finish_fwd_nn<RT, 4>(acc, Y, ld, M, cc, lane, bias, p.act, gout, rows_valid);
+          }
+        } else if (Q4 && q4 > 1) {
+          const int nch4 = NW / q4;
+          int wq = 0, wr = wave;
+          while (wr >= nch4) { wr -= nch4; ++wq; }
+          const int c4 = wr * 64, kl = K / q4, kb4 = wq * kl;
+          GemmPipe<RT, 4, FWD_D, 0> pipe4;
+          pipe4.begin(Wt, M, kb4, kb4 + kl, c4, true, 0, lane);
+          f32x4 acc[RT][4];
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          pipe4.run(X, ld, Wt, kb4, kb4 + kl, 0, acc, lane);
+          for (int r = 0; r < q4; ++r) {
+            if (wq == r) store_nn<RT, 4>(acc, Y, ld, M, c4, lane, r > 0);
+            lds_barrier();
+          }
+          const int M4 = M >> 2;
+          for (int e = tid; e < R * M4; e += NW * 64) {
+            const int row = e / M4, c4e = (e - row * M4) * 4;
+            float4 v = ld4(Y + row * ld + c4e);
+            const float4 b4 = ld4(bias + c4e);
+            v.x = act_fwd(v.x + b4.x, p.act);
+            v.y = act_fwd(v.y + b4.y, p.act);
+            v.z = act_fwd(v.z + b4.z, p.act);
+            v.w = act_fwd(v.w + b4.w, p.act);
+            st4(Y + row * ld + c4e, v);
+            if (gout != nullptr && row < rows_valid) st4(gout + (int64_t)row * M + c4e, v);
+          }
+        } else if (ksplit == 1) {
+          pipe.begin(Wt, M, kb, ke, c0, has, 0, lane);
           for (int cc = c0; cc < M; cc += NW * 32) {
             f32x4 acc[RT][2];
 #pragma unroll
@@ -763,6 +821,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
             finish_fwd_nn<RT, 2>(acc, Y, ld, M, cc, lane, bias, p.act, gout, rows_valid);
           }
         } else {
+          pipe.begin(Wt, M, kb, ke, c0, has, 0, lane);
           f32x4 acc[RT][2];
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
@@ -2331,7 +2390,7 @@ __global__ __launch_bounds__(64) void grad_sumsq_kernel(int64_t P, const float* 
 // per knob per launch is host time on the critical path of a ~50 us step.  ultr_config_reload() re-reads them (tests and
 // the A/B tools flip knobs inside one process).
 struct Knobs {
-  int fwd_r, bwd_r, wgrad_wgs, fwd_nw, bwd_nw, no_vec, no_l0g, bwd_v1, no_fused_fb, fb_max_wg_per_cu, fb_lists;
+  int fwd_r, bwd_r, wgrad_wgs, fwd_nw, bwd_nw, no_vec, no_l0g, bwd_v1, no_fused_fb, fb_max_wg_per_cu, fb_lists, fwd_q4;
   bool loaded;
 };
 static Knobs g_knobs = {};
@@ -2352,6 +2411,7 @@ static void knobs_load() {
   k.no_fused_fb = env_read("ULTR_NO_FUSED_FB", 0);
   k.fb_max_wg_per_cu = env_read("ULTR_FB_MAX_WG_PER_CU", 1);
   k.fb_lists = env_read("ULTR_FB_LISTS", 0);
+  k.fwd_q4 = env_read("ULTR_FWD_Q4", 1);
   k.loaded = true;
   g_knobs = k;
 }
@@ -2715,7 +2775,15 @@ extern "C" int ultr_dnn_forward(const ultr_dnn_desc* d, const float* params, con
     if (av) LAUNCH_FWD(RR, NWW, true); \
     else LAUNCH_FWD(RR, NWW, false);   \
   } while (0)
-  if (R == 16 && nw == 4) LAUNCH_FWD2(16, 4);
+  bool q4 = false;  // one workgroup per CU anyway and a layer that takes 64-column chunks: the 16-byte-load build
+  if (av && R == 16 && nw == 8 && knobs().fwd_q4 && lds > 80 * 1024)
+    for (int j = 0; j < p.nl - 1; ++j) q4 = q4 || (p.M[j] % 64 == 0 && p.M[j] >= 512);
+  if (q4) {
+    e = set_lds(dnn_fwd_kernel<16, 8, true, true>, lds);
+    if (e != hipSuccess) return (int)e;
+    ULTR_LAUNCH(prof, (dnn_fwd_kernel<16, 8, true, true>), grid, dim3(512), lds, st, p, params, features, n_docs, docids,
+                (int)batch, (int)list_size, scores, (float*)saved, wt, vm);
+  } else if (R == 16 && nw == 4) LAUNCH_FWD2(16, 4);
   else if (R == 16 && nw == 16) LAUNCH_FWD2(16, 16);
   else if (R == 16) LAUNCH_FWD2(16, 8);
   else if (nw == 4) LAUNCH_FWD2(32, 4);
