@@ -31,7 +31,8 @@ def _step(F, hidden, B, L, feats, ids, labels, ipw, algo="softmax"):
     return scores, g, sc
 
 
-@pytest.mark.parametrize("B,L", [(1, 1), (1, 7), (2, 1), (300, 1)])
+# (1500, 2) and (70000, 1): more than 1024 / 65536 loss partials (one per list) -> the two-level fold of the step tail
+@pytest.mark.parametrize("B,L", [(1, 1), (1, 7), (2, 1), (300, 1), (1500, 2), (70000, 1)])
 def test_degenerate_shapes(B, L):
     rng = np.random.RandomState(B * 10 + L)
     F, hidden = 12, [16, 8]

@@ -2059,16 +2059,22 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
       ws[bp.vred_off + e] = ((smem[lane] + smem[64 + lane]) + smem[128 + lane]) + smem[192 + lane];
     return;
   }
-  if ((int)blockIdx.x == bp.wgrad_blocks + bp.vred_blocks) {
-    // last spare workgroup: fold the loss partials into the step tail grads[P ..] (so the kernels after this one read
-    // it with plain loads; the reduction launch then only folds gradient slabs)
+  if ((int)blockIdx.x >= bp.wgrad_blocks + bp.vred_blocks) {
+    // last spare workgroup(s): fold the loss partials into the step tail grads[P ..] (so the kernels after this one read
+    // it with plain loads; the reduction launch then only folds gradient slabs).  More than 1024 partials (one per list
+    // for the stand-alone loss stages): bp.lf_chunks workgroups fold bp.lf_len partials each into a scratch row and the
+    // reduction launch folds those - a single workgroup would be a serial chain of n / 32 dependent trips
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int c = (int)blockIdx.x - (bp.wgrad_blocks + bp.vred_blocks);
+    const int beg = bp.lf_chunks > 0 ? c * bp.lf_len : 0;
+    const int cnt = bp.lf_chunks > 0 ? (n_loss_part - beg < bp.lf_len ? n_loss_part - beg : bp.lf_len) : n_loss_part;
+    float* out = bp.lf_chunks > 0 ? ws + bp.lfold_off + (int64_t)c * tail : grads + p.P;
     for (int t0 = 0; t0 < tail; t0 += 64) {
       const int t = t0 + lane;
-      smem[grp * 64 + lane] = (t < tail && loss_part != nullptr) ? strided_sum(loss_part + t, tail, n_loss_part, grp) : 0.f;
+      smem[grp * 64 + lane] = (t < tail && loss_part != nullptr) ? strided_sum(loss_part + (int64_t)beg * tail + t, tail, cnt, grp) : 0.f;
       lds_barrier();
       if (grp == 0 && t < tail && loss_part != nullptr)
-        grads[p.P + t] = ((smem[lane] + smem[64 + lane]) + smem[128 + lane]) + smem[192 + lane];
+        out[t] = ((smem[lane] + smem[64 + lane]) + smem[128 + lane]) + smem[192 + lane];
       lds_barrier();
     }
     return;
@@ -2357,6 +2363,17 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(RedPlan rp, int64_t P,
                                                           float* __restrict__ grads, float* __restrict__ sumsq_part) {
   __shared__ float sm[4][64];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  if (n_loss_part > 0 && blockIdx.x == gridDim.x - 1) {
+    // second level of the loss-partial fold (see dnn_wgrad_kernel): loss_part = [n_loss_part][tail] chunk sums
+    for (int t0 = 0; t0 < tail; t0 += 64) {
+      const int t = t0 + lane;
+      sm[grp][lane] = t < tail ? strided_sum(loss_part + t, tail, n_loss_part, grp) : 0.f;
+      __syncthreads();
+      if (grp == 0 && t < tail) grads[P + t] = ((sm[0][lane] + sm[1][lane]) + sm[2][lane]) + sm[3][lane];
+      __syncthreads();
+    }
+    return;
+  }
   const int64_t e = (int64_t)blockIdx.x * 64 + lane;
   float part = 0.f;
   if (e < P) {
@@ -2390,7 +2407,7 @@ __global__ __launch_bounds__(64) void grad_sumsq_kernel(int64_t P, const float* 
 // per knob per launch is host time on the critical path of a ~50 us step.  ultr_config_reload() re-reads them (tests and
 // the A/B tools flip knobs inside one process).
 struct Knobs {
-  int fwd_r, bwd_r, wgrad_wgs, fwd_nw, bwd_nw, no_vec, no_l0g, bwd_v1, no_fused_fb, fb_max_wg_per_cu, fb_lists, fwd_q4;
+  int fwd_r, bwd_r, wgrad_wgs, fwd_nw, bwd_nw, no_vec, no_l0g, bwd_v1, no_fused_fb, fb_max_wg_per_cu, fb_lists, fwd_q4, big_fwd, big_bwd;
   bool loaded;
 };
 static Knobs g_knobs = {};
@@ -2412,6 +2429,9 @@ static void knobs_load() {
   k.fb_max_wg_per_cu = env_read("ULTR_FB_MAX_WG_PER_CU", 1);
   k.fb_lists = env_read("ULTR_FB_LISTS", 0);
   k.fwd_q4 = env_read("ULTR_FWD_Q4", 1);
+  // the per-layer big-batch path (ultr_dnn_big.hip): 0 never, 1 by the measured rule (big_*_wanted), 2 whenever legal
+  k.big_fwd = env_read("ULTR_BIG_FWD", 1);
+  k.big_bwd = env_read("ULTR_BIG_BWD", 1);
   k.loaded = true;
   g_knobs = k;
 }
@@ -2587,6 +2607,11 @@ bool ultr_make_bwd_plan(const DnnPlan& p, int64_t N, BwdPlan* bp) {
   for (int j = 0; j < p.nl - 1; ++j) {
     bp->dz_off[j] = off; off += N * p.M[j]; off = (off + 3) & ~(int64_t)3;
   }
+  {
+    int kmax = 0;
+    for (int j = 1; j < p.nl - 1; ++j) kmax = p.K[j] > kmax ? p.K[j] : kmax;
+    bp->du_off = off; off += N * kmax; off = (off + 3) & ~(int64_t)3;
+  }
   // wgrad geometry
   int tiles = 0;
   for (int j = 0; j < p.nl - 1; ++j) tiles += ((p.M[j] + 63) / 64) * ((p.K[j] + 63) / 64);
@@ -2614,6 +2639,7 @@ bool ultr_make_bwd_plan(const DnnPlan& p, int64_t N, BwdPlan* bp) {
     w.slab_off = off; off += (int64_t)w.nsplit * ((int64_t)w.M * w.K + w.M); off = (off + 3) & ~(int64_t)3;
   }
   bp->wgrad_blocks = blk;
+  bp->lfold_off = off; off += 64 * tail_max;  // second level of the loss-partial fold (more than 1024 partials)
   bp->l0g = 0;
   bp->l0part_off = off;
   if (p.nl >= 2) off += ((int64_t)bp->wl[0].nmb * bp->wl[0].nsplit * 2 * p.K[0] + 3) & ~(int64_t)3;
@@ -2737,6 +2763,24 @@ extern "C" int ultr_dnn_build_wt(const ultr_dnn_desc* d, const float* params, fl
   return (int)hipGetLastError();
 }
 
+// Which shapes take the per-layer path (ultr_dnn_big.hip) instead of the row-tile kernels below; mode = the knob (0 never,
+// 1 the measured rule, 2 whenever legal).  Measured ("big-batch path"; us, row-tile -> per-layer):
+//   forward   never faster: config 4 220 -> 240, config 3 85 -> 120, 81 920 rows x [256,256] 258 -> 297 (the tiled GEMM core
+//             runs at 63-85 TFLOP/s, the row-tile forward at 61-70 with no activation round trips) - only when the row-tile
+//             kernel's LDS footprint does not fit;
+//   backward  wins when dnn_bwd2_kernel does not apply (a layer wider than 512: config 4 128 -> 85) and for big batches
+//             (81 920 x [256,256] 202 -> 182, 163 840 x [512,256,128] 980 -> 830); a tie at config 3 (10 240 rows: 74 / 74).
+static bool big_fwd_wanted(const DnnPlan&, int64_t) {
+  return knobs().big_fwd >= 2;
+}
+static bool big_bwd_wanted(const DnnPlan& p, int64_t N) {
+  const int mode = knobs().big_bwd;
+  if (mode != 1) return mode >= 2;
+  const bool v2 = knobs().bwd_nw == 8 && knobs().bwd_v1 == 0 && p.maxdim <= 512 &&
+                  bwd2_lds_floats(p, bwd_rows_per_wg(p, N), 8) * sizeof(float) <= 160 * 1024;
+  return N >= (v2 ? 16384 : 4096);
+}
+
 template <typename KernelT>
 static hipError_t set_lds(KernelT k, size_t bytes) {
   if (bytes <= 64 * 1024) return hipSuccess;
@@ -2753,7 +2797,6 @@ extern "C" int ultr_dnn_forward(const ultr_dnn_desc* d, const float* params, con
   if (!ultr_make_dnn_plan(d, N, &p)) return ULTR_E_BADARG;
   const int R = fwd_rows_per_wg(p, N);
   const size_t lds = fwd_lds_bytes(p, R);
-  if (lds > 160 * 1024) return ULTR_E_UNSUPPORTED;
   const int nw = knobs().fwd_nw;
   const int vm = vecmask_for(p, params, features);
   const dim3 grid((unsigned)((N + R - 1) / R));
@@ -2763,6 +2806,12 @@ extern "C" int ultr_dnn_forward(const ultr_dnn_desc* d, const float* params, con
   // the fast path needs the k-major weight copy (ultr_dnn_build_wt / kept current by ultr_apply_update)
   const bool av = all_vec(p, vm, N, n_docs) && knobs().no_vec == 0 && (wt != nullptr || p.nl == 1) &&
                   ((uintptr_t)wt & 15) == 0;
+  // training forward of a big batch: one pass per layer (needs `saved` for the activations between the passes)
+  if (saved != nullptr && wt != nullptr && av && ultr_dnn_big_ok(p, N, n_docs) &&
+      knobs().big_fwd != 0 && (big_fwd_wanted(p, N) || lds > 160 * 1024))
+    return ultr_dnn_big_forward(p, params, wt, features, n_docs, docids, (int)batch, (int)list_size, scores, (float*)saved, st,
+                                prof.on ? prof.a : nullptr, prof.on ? prof.b : nullptr);
+  if (lds > 160 * 1024) return ULTR_E_UNSUPPORTED;
 #define LAUNCH_FWD(RR, NWW, VV)                                                                                     \
   do {                                                                                                              \
     e = set_lds(dnn_fwd_kernel<RR, NWW, VV>, lds);                                                                  \
@@ -2810,13 +2859,15 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
   const int tail = (int)ultr_tail_len(list_size);
   if (tail > 4096) return ULTR_E_UNSUPPORTED;
   const size_t lds = bwd_lds_bytes(p, bp.rblk);
-  if (lds > 160 * 1024) return ULTR_E_UNSUPPORTED;
   const int nw = knobs().bwd_nw;
   const int vm = vecmask_for(p, params, features);
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipSuccess;
   float* ws = (float*)bwd_ws;
   const bool av = all_vec(p, vm, N, n_docs) && knobs().no_vec == 0;
+  const bool big = fused_rb == 0 && dscores != nullptr && av && l0g_ok && ultr_dnn_big_ok(p, N, n_docs) &&
+                   knobs().big_bwd != 0 && (big_bwd_wanted(p, N) || lds > 160 * 1024);
+  if (lds > 160 * 1024 && !big) return ULTR_E_UNSUPPORTED;
 #define LAUNCH_BWD(RR, NWW, VV)                                                                                        \
   do {                                                                                                                 \
     e = set_lds(dnn_bwd_kernel<RR, NWW, VV>, lds);                                                                     \
@@ -2844,6 +2895,12 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
   bp.wg_prenorm = (fused_rb > 0) ? 1 : 0;  // the fused kernel left the ready-made wgrad operands in `saved`
   if (fused_rb > 0) {
     // the row-local half already ran inside dnn_fb_kernel
+  } else if (big) {
+    UltrProfScope prof(ULTR_K_BWD, st);
+    bp.nrb = (int)((N + ULTR_BIG_ROWS - 1) / ULTR_BIG_ROWS);  // one vector slab per row block of the row kernels
+    const int rc = ultr_dnn_big_backward(p, bp, params, (const float*)saved, dscores, ws, st, prof.on ? prof.a : nullptr,
+                                         prof.on ? prof.b : nullptr);
+    if (rc) return rc;
   } else if (v2) {
     UltrProfScope prof(ULTR_K_BWD, st);
     const int xc = p.maxdim <= 256 ? 1 : 2;
@@ -2864,20 +2921,27 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
 #undef LAUNCH_BWD
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
+  const float* lp = (const float*)loss_ws;
+  const int nlp = fl.scores ? bp.nrb : (int)ultr_loss_parts(batch);
+  if (nlp > 1024) {
+    int len = (nlp + 63) / 64;
+    len = len < 1024 ? 1024 : (len + 31) / 32 * 32;
+    bp.lf_len = len;
+    bp.lf_chunks = (nlp + len - 1) / len;
+  }
   {
     UltrProfScope prof(ULTR_K_WGRAD, st);
-    const float* lp = (const float*)loss_ws;
-    const int nlp = fl.scores ? bp.nrb : (int)ultr_loss_parts(batch);
     int maxrps = 0;
     for (int j = 0; j < p.nl - 1; ++j) maxrps = bp.wl[j].rows_per_split > maxrps ? bp.wl[j].rows_per_split : maxrps;
     const size_t wlds = (size_t)(4 * 64 * 64 + 4 * 64 + maxrps) * sizeof(float);
     e = av ? set_lds(dnn_wgrad_kernel<true>, wlds) : set_lds(dnn_wgrad_kernel<false>, wlds);
     if (e != hipSuccess) return (int)e;
+    const dim3 wgrid(bp.wgrad_blocks + bp.vred_blocks + (bp.lf_chunks > 0 ? bp.lf_chunks : 1));
     if (av)
-      ULTR_LAUNCH(prof, dnn_wgrad_kernel<true>, dim3(bp.wgrad_blocks + bp.vred_blocks + 1), dim3(256), wlds, st, p, bp, params, features, n_docs,
+      ULTR_LAUNCH(prof, dnn_wgrad_kernel<true>, wgrid, dim3(256), wlds, st, p, bp, params, features, n_docs,
                          docids, (int)batch, (int)list_size, (const float*)saved, ws, (vm >> 31) & 1, grads, lp, nlp, tail);
     else
-      ULTR_LAUNCH(prof, dnn_wgrad_kernel<false>, dim3(bp.wgrad_blocks + bp.vred_blocks + 1), dim3(256), wlds, st, p, bp, params, features, n_docs,
+      ULTR_LAUNCH(prof, dnn_wgrad_kernel<false>, wgrid, dim3(256), wlds, st, p, bp, params, features, n_docs,
                          docids, (int)batch, (int)list_size, (const float*)saved, ws, (vm >> 31) & 1, grads, lp, nlp, tail);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
@@ -2885,10 +2949,9 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
   RedPlan rp;
   ultr_make_red_plan(p, bp, &rp);
   const int nblk = (int)ultr_red_blocks(p.P, tail);
-  const float* lp = (const float*)loss_ws;
   UltrProfScope prof(ULTR_K_REDUCE, st);
-  ULTR_LAUNCH(prof, grad_reduce_kernel, dim3(nblk), dim3(256), 0, st, rp, p.P, tail, (const float*)ws, lp,
-                     fl.scores ? bp.nrb : (int)ultr_loss_parts(batch), grads, ws + bp.sumsq_off);
+  ULTR_LAUNCH(prof, grad_reduce_kernel, dim3(nblk + (bp.lf_chunks > 0 ? 1 : 0)), dim3(256), 0, st, rp, p.P, tail, (const float*)ws,
+              (const float*)(ws + bp.lfold_off), bp.lf_chunks, grads, ws + bp.sumsq_off);
   return (int)hipGetLastError();
 }
 
@@ -2905,6 +2968,18 @@ extern "C" int ultr_dnn_backward_softmax(const ultr_dnn_desc* d, const float* pa
                                          int32_t n_ipw, float* dscores_out, void* loss_ws, void* bwd_ws, float* grads,
                                          void* stream) {
   if (!scores || !labels || !loss_ws || (ipw_table && n_ipw <= 0)) return ULTR_E_BADARG;
+  {
+    // big batches take the per-layer backward, which wants the loss as its own stage
+    DnnPlan p;
+    const int64_t N = (int64_t)batch * list_size;
+    if (dscores_out && batch > 0 && list_size > 0 && ultr_make_dnn_plan(d, N, &p) && big_bwd_wanted(p, N) &&
+        knobs().no_l0g == 0 && knobs().no_vec == 0 && ultr_dnn_big_ok(p, N, n_docs)) {
+      const int rc = ultr_softmax_ce(scores, labels, pw, ipw_table, n_ipw, batch, list_size, dscores_out, loss_ws, stream);
+      if (rc) return rc;
+      FusedSoftmax none = {nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
+      return backward_impl(d, params, features, n_docs, docids, batch, list_size, saved, dscores_out, loss_ws, bwd_ws, grads, stream, none);
+    }
+  }
   FusedSoftmax fl = {scores, labels, pw, ipw_table, (int)n_ipw, dscores_out, (float*)loss_ws};
   return backward_impl(d, params, features, n_docs, docids, batch, list_size, saved, nullptr, loss_ws, bwd_ws, grads, stream, fl);
 }

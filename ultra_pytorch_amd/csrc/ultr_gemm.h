@@ -28,6 +28,7 @@
 //     are masked: any R, N, K (K % 4 == 0 and 16-byte aligned rows for the vector loads; checked by the launcher).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "ultr_device.h"
@@ -400,7 +401,8 @@ inline int device_cus() {
 }
 
 template <int BM, int BN, int WM, int WN, bool B_NMAJOR, class AProd, class Epi>
-inline hipError_t launch(const Dims& d, const AProd& aprod, const float* B, const Epi& epi, hipStream_t st) {
+inline hipError_t launch(const Dims& d, const AProd& aprod, const float* B, const Epi& epi, hipStream_t st, hipEvent_t ev_start = nullptr,
+                         hipEvent_t ev_stop = nullptr) {
   using C = Cfg<BM, BN, WM, WN, B_NMAJOR>;
   auto kern = gemm_kernel<BM, BN, WM, WN, B_NMAJOR, AProd, Epi>;
   const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
@@ -431,7 +433,9 @@ inline hipError_t launch(const Dims& d, const AProd& aprod, const float* B, cons
   if (g_ugemm_grid_mode == 2) grid = chunks <= slots ? chunks : slots;
   if (g_ugemm_grid_mode >= 16) grid = chunks <= slots ? chunks : (int64_t)g_ugemm_grid_mode * device_cus();
 #endif
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::NT), lds, st, d, aprod, B, epi);
+  if (ev_start != nullptr || ev_stop != nullptr)  // timed by the dispatch packet's own timestamps (ultr_prof.h)
+    hipExtLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::NT), (uint32_t)lds, st, ev_start, ev_stop, 0, d, aprod, B, epi);
+  else hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::NT), lds, st, d, aprod, B, epi);
   return hipGetLastError();
 }
 
@@ -440,9 +444,10 @@ inline hipError_t launch(const Dims& d, const AProd& aprod, const float* B, cons
 // per CU hide each other's staging, barriers and epilogues better than the classic 128 x 128 / 4-wave shape here
 // (83 -> 90 TFLOP/s at 102400 x 256 x 256 before the persistent schedule), and RT = 1 makes short chunks cheap
 template <bool B_NMAJOR, class AProd, class Epi>
-inline hipError_t run(const Dims& d, const AProd& aprod, const float* B, const Epi& epi, hipStream_t st) {
-  if (d.N > 64) return launch<64, 128, 4, 2, B_NMAJOR>(d, aprod, B, epi, st);
-  return launch<64, 64, 4, 1, B_NMAJOR>(d, aprod, B, epi, st);
+inline hipError_t run(const Dims& d, const AProd& aprod, const float* B, const Epi& epi, hipStream_t st, hipEvent_t ev_start = nullptr,
+                      hipEvent_t ev_stop = nullptr) {
+  if (d.N > 64) return launch<64, 128, 4, 2, B_NMAJOR>(d, aprod, B, epi, st, ev_start, ev_stop);
+  return launch<64, 64, 4, 1, B_NMAJOR>(d, aprod, B, epi, st, ev_start, ev_stop);
 }
 
 }  // namespace ugemm

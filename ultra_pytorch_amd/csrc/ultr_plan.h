@@ -94,6 +94,7 @@ struct BwdPlan {
   int64_t vred_off;         // [vlen]: the vector slabs pre-reduced (by spare workgroups of the wgrad launch)
   int vred_blocks;          // ceil(vlen / 64)
   int64_t dz_off[ULTR_MAXL];// dz_j [N, M_j], j < nl-1
+  int64_t du_off;           // [N, max K_j over 1 <= j < nl-1]: du_j scratch of the big-batch backward (ultr_dnn_big.hip)
   WgradLayer wl[ULTR_MAXL];
   int wgrad_blocks;
   // Layer-0 shortcut of the fast backward kernels: the dgrad du_0 = dz_0 . W_0 exists only to feed LayerNorm_0's gamma/beta
@@ -106,6 +107,8 @@ struct BwdPlan {
   // The wgrad loop then issues two loads per 16 MFMAs instead of four and applies no transform.
   int wg_prenorm;
   int64_t l0part_off;       // [nmb_0 * nsplit_0][2][K_0]
+  int64_t lfold_off;        // [64][tail <= 4096]: first level of the loss-partial fold when there are more than 1024 partials
+  int lf_chunks, lf_len;    // 0: one workgroup folds all; else lf_chunks workgroups x lf_len partials (set by the launcher)
   int64_t sumsq_off;        // [n_red_blocks]
   int n_red_blocks;
   int64_t total;            // floats in bwd_ws
@@ -126,6 +129,15 @@ struct ultr_dnn_desc;
 bool ultr_make_dnn_plan(const ultr_dnn_desc* d, int64_t N, DnnPlan* p);  // ultr_dnn.hip
 bool ultr_make_bwd_plan(const DnnPlan& p, int64_t N, BwdPlan* bp);         // ultr_dnn.hip
 void ultr_make_red_plan(const DnnPlan& p, const BwdPlan& bp, RedPlan* rp); // ultr_dnn.hip
+
+// library-internal, ultr_dnn_big.hip: the per-layer (un-fused) training forward / row-local backward for big batches
+#define ULTR_BIG_ROWS 32  // rows per workgroup of its row kernels = rows per vector slab
+bool ultr_dnn_big_ok(const DnnPlan& p, int64_t N, int64_t n_docs);
+int ultr_dnn_big_forward(const DnnPlan& p, const float* params, const float* wt, const float* features, int64_t n_docs,
+                         const int32_t* docids, int B, int L, float* scores, float* saved, hipStream_t st, hipEvent_t ev_start,
+                         hipEvent_t ev_stop);
+int ultr_dnn_big_backward(const DnnPlan& p, const BwdPlan& bp, const float* params, const float* saved, const float* dscores, float* ws,
+                          hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop);
 
 // library-internal: the small-batch NA/IPW step as one fused forward+loss+backward launch (+ weight gradients +
 // reduction); ULTR_E_UNSUPPORTED = shape does not qualify, use the separate calls
