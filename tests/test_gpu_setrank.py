@@ -237,5 +237,5 @@ def test_fp16_attention_ordering_parity_config5_shape():
     n16 = float(O.ndcg(rel, torch.tensor(s16), [10])[0])
     print("fp16 attention: identical top-10 order on %.1f %% of lists, identical top-10 set on %.1f %%, NDCG@10 %.5f vs %.5f"
           % (100 * same_order, 100 * same_set, n16, n32))
-    assert same_set >= 0.95 and same_order >= 0.90
+    assert same_set >= 0.99 and same_order >= 0.99  # VERDICT r01 item 4's bar; measured 100 % / 100 % (deterministic kernels, fixed seed)
     assert abs(n16 - n32) <= 1e-3

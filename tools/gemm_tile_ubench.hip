@@ -76,6 +76,34 @@ int main(int argc, char** argv) {
 #ifdef UGEMM_DEBUG_GRID
   if (argc > 2) ugemm::g_ugemm_grid_mode = atoi(argv[2]);
 #endif
+  if (argc > 1 && argv[1][0] == 'c') {  // counter passes: two tile shapes at a long contraction
+    bench<false, 64, 128, 4, 2>(16384, 4096, 512);
+    bench<false, 256, 128, 4, 2>(16384, 4096, 512);
+    return 0;
+  }
+  if (argc > 1 && argv[1][0] == 'b') {  // exactly one full chunk per resident workgroup (768 = 3 per CU): the steady-state loop, no tail
+    bench<false, 64, 128, 4, 2>(49152, 4096, 128);
+    bench<false, 64, 128, 4, 2>(12288, 4096, 512);
+    bench<false, 64, 128, 4, 2>(24576, 4096, 512);  // two full chunks each
+    bench<false, 64, 128, 4, 2>(12288, 704, 512);
+    bench<false, 64, 128, 4, 2>(12288, 256, 512);
+    bench<false, 64, 128, 4, 2>(24576, 256, 512);
+    bench<false, 64, 128, 4, 2>(98304, 256, 512);   // eight full chunks each
+    bench<false, 128, 128, 4, 2>(32768, 4096, 512); // 128 x 128: 1 per CU by LDS? (launch decides) - 256 x 4 = 1024 chunks
+    return 0;
+  }
+  if (argc > 1 && argv[1][0] == 'k') {  // long contraction: the k loop's own efficiency (prologue / epilogue amortised)
+    bench<false, 64, 128, 4, 2>(16384, 4096, 512);
+    bench<false, 64, 128, 2, 2>(16384, 4096, 512);
+    bench<false, 128, 128, 4, 2>(16384, 4096, 512);
+    bench<false, 128, 128, 2, 2>(16384, 4096, 512);
+    bench<false, 256, 128, 4, 2>(16384, 4096, 512);
+    bench<true, 64, 128, 4, 2>(16384, 4096, 512);
+    bench<true, 128, 128, 2, 2>(16384, 4096, 512);
+    bench<false, 64, 128, 4, 2>(16384, 1024, 512);
+    bench<false, 128, 128, 2, 2>(16384, 1024, 512);
+    return 0;
+  }
   if (argc > 1) {  // one shape only (counter passes): tools/bin/gemm_tile_ub 1
     bench<false, 64, 128, 2, 2>(102400, 256, 256);
     bench<false, 64, 128, 4, 2>(102400, 256, 256);

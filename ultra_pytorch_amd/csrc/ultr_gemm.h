@@ -31,12 +31,28 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "ultr_device.h"
 
 namespace ugemm {
 
 #ifdef UGEMM_DEBUG_CYC
 __device__ unsigned long long g_ugemm_cyc[4096], g_ugemm_xcc[4096];
+#endif
+#ifndef UGEMM_STAGES
+// LDS ring depth.  3 = fragments of the next half k-tile are read while the current half's MFMAs run (register
+// double-buffered fragments; a chunk starts with two tiles).  Measured (tools/gemm_tile_ubench.hip): it helps only where the
+// k loop is long (16384 x 4096 x 512: 98 -> 103 TFLOP/s) and loses at the shapes this library runs (12800 x 700 x 512: 86 -> 78,
+// 102400 x 256 x 256: 84 -> 77: the second tile of every chunk prologue and one workgroup fewer per CU cost more than the
+// LDS round trip per barrier that it hides) - kept selectable, default 2.
+#define UGEMM_STAGES 2
+#endif
+// 1 = all ten fragment reads of a k-tile in front of its MFMAs (counted lgkmcnt waits) instead of hipcc's own order (two
+// reads, wait, eight MFMAs - four LDS round trips per k-tile but 52 registers).  Measured: 102 registers -> two workgroups
+// per CU instead of three, 101 -> 91 TFLOP/s at 12288 x 704 x 512: occupancy beats the shorter dependency chain.  Default 0.
+#ifndef UGEMM_FRAG_SCHED
+#define UGEMM_FRAG_SCHED 0
 #endif
 constexpr int BK = 32;        // contraction steps per k-tile
 constexpr int LDA = BK + 8;   // LDS row stride of k-contiguous tiles (A, n-major B): stride = 8 (mod 16) floats is the
@@ -160,6 +176,7 @@ struct Dims {
 
 template <int BM, int BN, int WM, int WN, bool B_NMAJOR>
 struct Cfg {
+  static constexpr int STAGES = UGEMM_STAGES;
   static constexpr int NT = WM * WN * 64;
   static constexpr int RT = BM / WM / 16;
   static constexpr int CT = BN / WN / 16;
@@ -168,7 +185,7 @@ struct Cfg {
   static constexpr int A_FLOATS = BM * LDA;
   static constexpr int B_FLOATS = B_NMAJOR ? BN * LDA : BK * BN;
   static constexpr int LDC = BN + 4;
-  static constexpr int STAGE_FLOATS = 2 * (A_FLOATS + B_FLOATS);
+  static constexpr int STAGE_FLOATS = STAGES * (A_FLOATS + B_FLOATS);
   static constexpr int C_FLOATS = BM * LDC;
   static constexpr int LDS_FLOATS = (B_NMAJOR && C_FLOATS > STAGE_FLOATS) ? C_FLOATS : STAGE_FLOATS;
   static constexpr int A_LOADS = BM * (BK / 4) / NT;        // float4 per thread per k-tile
@@ -185,8 +202,8 @@ template <int BM, int BN, int WM, int WN, bool B_NMAJOR, class AProd, class Epi>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(Dims d, AProd aprod, const float* __restrict__ Bg, Epi epi) {
   using C = Cfg<BM, BN, WM, WN, B_NMAJOR>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                        // [2][BM][LDA]
-  float* Bs = smem + 2 * C::A_FLOATS;      // [2][...]
+  float* As = smem;                                // [STAGES][BM][LDA]
+  float* Bs = smem + C::STAGES * C::A_FLOATS;      // [STAGES][...]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, q = lane >> 4;
   const int wr = (wave / WN) * (BM / WM), wc = (wave % WN) * (BN / WN);  // wave origin inside the chunk
@@ -207,10 +224,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(Dims d, AProd aprod,
   // ---- the chunk being staged / computed ------------------------------------------------------------------------------
   int64_t r0 = 0, rend = 0;  // rows [r0, rend) of the chunk
   int n0 = 0, m_units = 0;
-  float4 areg[C::A_LOADS], breg[C::B_LOADS];
+  constexpr int NSET = C::STAGES == 3 ? 2 : 1;  // register sets of staged tiles (the 3-stage ring starts a chunk with two tiles)
+  float4 areg[NSET][C::A_LOADS], breg[NSET][C::B_LOADS];
   const int k4 = (tid & 7) * 4;  // a thread stages rows (tid >> 3) + (NT / 8) j, always columns k4 .. k4 + 3 of a k-tile
   typename AProd::Row arow[C::A_LOADS];
-  typename AProd::Cols acol;
+  typename AProd::Cols acol[NSET];
   auto begin_chunk = [&](int64_t uu) {
     const int64_t cb = uu / nru, ru = uu - cb * nru;
     int64_t m = u_end - uu;
@@ -223,88 +241,88 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(Dims d, AProd aprod,
 #pragma unroll
     for (int j = 0; j < C::A_LOADS; ++j) arow[j] = aprod.row(r0 + ((tid + C::NT * j) >> 3), rend);
   };
-  auto load_tile = [&](int k0) {
-    acol = aprod.cols(k0 + k4);
+  auto load_tile = [&](int k0, auto SET) {
+    constexpr int set = decltype(SET)::value;
+    acol[set] = aprod.cols(k0 + k4);
 #pragma unroll
-    for (int j = 0; j < C::A_LOADS; ++j) areg[j] = aprod.raw(arow[j], k0 + k4);
+    for (int j = 0; j < C::A_LOADS; ++j) areg[set][j] = aprod.raw(arow[j], k0 + k4);
 #pragma unroll
     for (int j = 0; j < C::B_LOADS; ++j) {
       const int idx = tid + C::NT * j;
       if constexpr (B_NMAJOR) {
         const int n = idx >> 3, kk4 = (idx & 7) * 4;
         const bool ok = n0 + n < d.N && k0 + kk4 < d.K;
-        breg[j] = buf_ld4(bsrc, ok ? (unsigned)(((int64_t)(n0 + n) * d.ldb + k0 + kk4) * 4) : ULTR_OOB);
+        breg[set][j] = buf_ld4(bsrc, ok ? (unsigned)(((int64_t)(n0 + n) * d.ldb + k0 + kk4) * 4) : ULTR_OOB);
       } else {
         const int kk = idx / (BN / 4), c4 = (idx - kk * (BN / 4)) * 4;
         const bool ok = k0 + kk < d.K && n0 + c4 < d.N;
-        breg[j] = buf_ld4(bsrc, ok ? (unsigned)(((int64_t)(k0 + kk) * d.ldb + n0 + c4) * 4) : ULTR_OOB);
+        breg[set][j] = buf_ld4(bsrc, ok ? (unsigned)(((int64_t)(k0 + kk) * d.ldb + n0 + c4) * 4) : ULTR_OOB);
       }
     }
     // keep the staging loads ABOVE the MFMAs / the epilogue that follow (hipcc otherwise sinks each load to its first use)
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto store_tile = [&](int buf, int k0) {
+  auto store_tile = [&](int buf, int k0, auto SET) {
+    constexpr int set = decltype(SET)::value;
     float* Ab = As + buf * C::A_FLOATS;
     float* Bb = Bs + buf * C::B_FLOATS;
 #pragma unroll
     for (int j = 0; j < C::A_LOADS; ++j) {
       const int idx = tid + C::NT * j;
-      st4(Ab + (idx >> 3) * LDA + k4, aprod.finish(arow[j], acol, k0 + k4, areg[j]));
+      st4(Ab + (idx >> 3) * LDA + k4, aprod.finish(arow[j], acol[set], k0 + k4, areg[set][j]));
     }
 #pragma unroll
     for (int j = 0; j < C::B_LOADS; ++j) {
       const int idx = tid + C::NT * j;
-      if constexpr (B_NMAJOR) st4(Bb + (idx >> 3) * LDA + (idx & 7) * 4, breg[j]);
+      if constexpr (B_NMAJOR) st4(Bb + (idx >> 3) * LDA + (idx & 7) * 4, breg[set][j]);
       else {
         const int kk = idx / (BN / 4), c4 = (idx - kk * (BN / 4)) * 4;
-        st4(Bb + kk * C::LDB + c4, breg[j]);
+        st4(Bb + kk * C::LDB + c4, breg[set][j]);
       }
     }
   };
+  constexpr std::integral_constant<int, 0> S0{};
+  constexpr std::integral_constant<int, NSET - 1> S1{};
   f32x4 acc[C::RT][C::CT];
-  auto compute = [&](int buf, int live_rt) {  // live_rt: row tiles of this wave inside the chunk (wave-uniform)
-    const float* Ab = As + buf * C::A_FLOATS + (wr + i) * LDA + 4 * q;
+  // fragments of one half k-tile (16 contraction steps): a[rt] = A[row i of tile rt][16 h + 4 q ..+3];
+  // k-major B: b[s] = B[16 h + 4 q + s][wc + 4 i ..+3] (four interleaved column tiles), n-major B: b[t] = B[col i of tile t][16 h + 4 q ..+3]
+  auto read_frags = [&](int buf, int h, float4 (&a)[C::RT], float4 (&b)[4]) {
+    const float* Ab = As + buf * C::A_FLOATS + (wr + i) * LDA + 4 * q + 16 * h;
     const float* Bb = Bs + buf * C::B_FLOATS;
-    // every fragment of the k-tile is requested before the first MFMA: one LDS round trip per 32 contraction steps
-    float4 a[2][C::RT], b[2][4];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int rt = 0; rt < C::RT; ++rt) a[rt] = ld4(Ab + rt * 16 * LDA);
+    if constexpr (B_NMAJOR) {
 #pragma unroll
-      for (int rt = 0; rt < C::RT; ++rt) a[h][rt] = ld4(Ab + rt * 16 * LDA + 16 * h);
-      if constexpr (B_NMAJOR) {
+      for (int t = 0; t < C::CT; ++t) b[t] = ld4(Bb + (wc + 16 * t + i) * LDA + 16 * h + 4 * q);
+    } else {
 #pragma unroll
-        for (int t = 0; t < C::CT; ++t) b[h][t] = ld4(Bb + (wc + 16 * t + i) * LDA + 16 * h + 4 * q);
-      } else {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) b[h][s] = ld4(Bb + (16 * h + 4 * q + s) * C::LDB + wc + 4 * i);
-      }
+      for (int s = 0; s < 4; ++s) b[s] = ld4(Bb + (16 * h + 4 * q + s) * C::LDB + wc + 4 * i);
     }
+  };
+  auto mfma_half = [&](const float4 (&a)[C::RT], const float4 (&b)[4], int live_rt) {  // live_rt: wave-uniform
+    if constexpr (B_NMAJOR) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      if constexpr (B_NMAJOR) {
+      for (int rt = 0; rt < C::RT; ++rt) {
+        if (rt < live_rt) {
+          const float av[4] = {a[rt].x, a[rt].y, a[rt].z, a[rt].w};
+#pragma unroll
+          for (int t = 0; t < C::CT; ++t) {
+            const float bv[4] = {b[t].x, b[t].y, b[t].z, b[t].w};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[rt][t] = mfma16(av[s], bv[s], acc[rt][t]);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float bv[4] = {b[s].x, b[s].y, b[s].z, b[s].w};
 #pragma unroll
         for (int rt = 0; rt < C::RT; ++rt) {
           if (rt < live_rt) {
-            const float av[4] = {a[h][rt].x, a[h][rt].y, a[h][rt].z, a[h][rt].w};
+            const float as = (s == 0) ? a[rt].x : (s == 1) ? a[rt].y : (s == 2) ? a[rt].z : a[rt].w;
 #pragma unroll
-            for (int t = 0; t < C::CT; ++t) {
-              const float bv[4] = {b[h][t].x, b[h][t].y, b[h][t].z, b[h][t].w};
-#pragma unroll
-              for (int s = 0; s < 4; ++s) acc[rt][t] = mfma16(av[s], bv[s], acc[rt][t]);
-            }
-          }
-        }
-      } else {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const float bv[4] = {b[h][s].x, b[h][s].y, b[h][s].z, b[h][s].w};
-#pragma unroll
-          for (int rt = 0; rt < C::RT; ++rt) {
-            if (rt < live_rt) {
-              const float as = (s == 0) ? a[h][rt].x : (s == 1) ? a[h][rt].y : (s == 2) ? a[h][rt].z : a[h][rt].w;
-#pragma unroll
-              for (int t = 0; t < C::CT; ++t) acc[rt][t] = mfma16(as, bv[t], acc[rt][t]);
-            }
+            for (int t = 0; t < C::CT; ++t) acc[rt][t] = mfma16(as, bv[t], acc[rt][t]);
           }
         }
       }
@@ -312,8 +330,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(Dims d, AProd aprod,
   };
 
   begin_chunk(u);
-  load_tile(0);
-  store_tile(0, 0);
+  load_tile(0, S0);
+  if constexpr (C::STAGES == 3) {
+    if (nk > 1) load_tile(BK, S1);
+  }
+  store_tile(0, 0, S0);
+  if constexpr (C::STAGES == 3) {
+    if (nk > 1) store_tile(1, BK, S1);
+  }
   lds_barrier();
   for (;;) {
 #pragma unroll
@@ -322,20 +346,68 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(Dims d, AProd aprod,
       for (int t = 0; t < C::CT; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     int live_rt = (16 * m_units - wr + 15) / 16;  // this wave's row tiles that hold rows of the chunk
     live_rt = live_rt < 0 ? 0 : (live_rt > C::RT ? C::RT : live_rt);
-    for (int t = 0; t < nk; ++t) {
-      if (t + 1 < nk) load_tile((t + 1) * BK);
-      if (live_rt > 0) compute(t & 1, live_rt);
-      if (t + 1 < nk) store_tile((t + 1) & 1, (t + 1) * BK);
-      lds_barrier();
+    if constexpr (C::STAGES == 3) {
+      // Three LDS stages, fragments double-buffered by half k-tile: while the MFMAs of one half run, the LDS reads of the
+      // next half (the other half of this tile, then the first half of the NEXT tile - already in LDS since the previous
+      // barrier) are in flight, so a wave's MFMA stream does not stop for an LDS round trip at every barrier.  Tile t + 2
+      // goes global -> registers at the top of iteration t and registers -> LDS (stage of tile t - 1) at its bottom.
+      float4 fa0[C::RT], fb0[4], fa1[C::RT], fb1[4];
+      if (live_rt > 0) read_frags(0, 0, fa0, fb0);
+      int st = 0;
+      for (int t = 0; t < nk; ++t) {
+        const int st1 = st == 2 ? 0 : st + 1, st2 = st1 == 2 ? 0 : st1 + 1;
+        if (t + 2 < nk) load_tile((t + 2) * BK, S0);
+        if (live_rt > 0) {
+          read_frags(st, 1, fa1, fb1);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_half(fa0, fb0, live_rt);
+          __builtin_amdgcn_sched_barrier(0);
+          if (t + 1 < nk) read_frags(st1, 0, fa0, fb0);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_half(fa1, fb1, live_rt);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (t + 2 < nk) store_tile(st2, (t + 2) * BK, S0);
+        lds_barrier();
+        st = st1;
+      }
+    } else {
+      for (int t = 0; t < nk; ++t) {
+        if (t + 1 < nk) load_tile((t + 1) * BK, S0);
+        if (live_rt > 0) {
+          // every fragment of the k-tile is requested before the first MFMA: one LDS round trip per 32 contraction steps
+          float4 fa0[C::RT], fb0[4], fa1[C::RT], fb1[4];
+          read_frags(t & 1, 0, fa0, fb0);
+          read_frags(t & 1, 1, fa1, fb1);
+#if UGEMM_FRAG_SCHED
+          // left alone, hipcc issues two fragment reads at a time and waits for each pair in front of its eight MFMAs: four
+          // exposed LDS round trips per k-tile.  All ten reads first, then the MFMAs behind counted lgkmcnt waits
+          __builtin_amdgcn_sched_barrier(0);
+#endif
+          mfma_half(fa0, fb0, live_rt);
+#if UGEMM_FRAG_SCHED
+          __builtin_amdgcn_sched_barrier(0);
+#endif
+          mfma_half(fa1, fb1, live_rt);
+        }
+        if (t + 1 < nk) store_tile((t + 1) & 1, (t + 1) * BK, S0);
+        lds_barrier();
+      }
     }
-    // ---- this chunk's output; the next chunk's first k-tile goes in flight before it (k-major B) -----------------------
+    // ---- this chunk's output; the next chunk's first k-tile(s) go in flight before it (k-major B) ------------------------
     const int64_t e_r0 = r0, e_rend = rend;
     const int e_n0 = n0;
     const int64_t un = u + m_units;
     const bool more = un < u_end;
+    auto load_first = [&]() {
+      load_tile(0, S0);
+      if constexpr (C::STAGES == 3) {
+        if (nk > 1) load_tile(BK, S1);
+      }
+    };
     if (more) {
       begin_chunk(un);
-      if constexpr (!B_NMAJOR) load_tile(0);
+      if constexpr (!B_NMAJOR) load_first();
     }
     if constexpr (!B_NMAJOR) {
       // a lane already holds four consecutive output columns of a row (the four interleaved column tiles): straight to
@@ -377,11 +449,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(Dims d, AProd aprod,
       }
       if (more) {
         lds_barrier();  // the tile in LDS has been read
-        load_tile(0);
+        load_first();
       }
     }
     if (!more) break;
-    store_tile(0, 0);
+    store_tile(0, 0, S0);
+    if constexpr (C::STAGES == 3) {
+      if (nk > 1) store_tile(1, BK, S1);
+    }
     lds_barrier();
     u = un;
   }

@@ -50,6 +50,10 @@ struct SrPlan {
   int64_t ws_wg;     // [wg_split][max M*K] partial weight gradients (split over lists: rocBLAS would run a
                      // [M, K] = dY^T X product with T = 100k contraction rows on a handful of workgroups)
   int wg_split;      // chunks of whole lists, divides the batch
+  int64_t wg_floats; // floats of one weight-gradient partial region
+  // the backward queues every partial-sum fold and runs them as ONE launch at its end (sr_fold_all_kernel): partials then
+  // cannot share scratch, each producer takes a fresh piece of this arena
+  int64_t ws_arena, arena_floats;
   int64_t ws_total;
 };
 
@@ -128,6 +132,9 @@ bool make_plan(const ultr_setrank_desc* c, int64_t T, SrPlan* p) {
     if (need > wg_floats) wg_floats = need;
   }
   p->ws_wg = w; w += wg_floats;
+  p->wg_floats = wg_floats;
+  p->arena_floats = (int64_t)(3 * p->nl + 4) * ((wg_floats + 3) & ~(int64_t)3) + (int64_t)(2 * p->nl + 5) * p->n_lb * 3 * p->maxw;
+  p->ws_arena = w; w += p->arena_floats;
   p->ws_total = w;
   return true;
 }
@@ -568,10 +575,97 @@ __global__ __launch_bounds__(256) void sr_fold16_kernel(const float* __restrict_
     dst[c] = t;
   }
 }
-void fold(const float* part, int64_t stride, int nparts, int len, float* dst, hipStream_t st) {
-  if (nparts >= 256) hipLaunchKernelGGL(sr_fold16_kernel, dim3((len + 15) / 16), dim3(256), 0, st, part, stride, nparts, len, dst);
+// ---- deferred folds -------------------------------------------------------------------------------------------------------
+// ultr_setrank_backward produces ~20 sets of partial sums (weight-gradient slabs per row chunk, LayerNorm / bias column
+// partials per row block); their folds only feed the update at the very end.  Instead of one 7 us launch behind every
+// producer (21 of the step's 69 launches, 0.15 ms) the backward queues them and ONE launch folds all - same arithmetic
+// order per job as sr_fold_kernel / sr_fold16_kernel, so the gradients keep their bits.
+#define SR_MAX_FOLDS 72
+struct FoldJob {
+  const float* part;
+  float* dst;
+  int64_t stride;
+  int nparts, len, wide, blk_begin;  // wide: 16 columns per workgroup (many partials) instead of 64
+};
+struct FoldTable {
+  int n, nblocks;
+  FoldJob job[SR_MAX_FOLDS];
+};
+__global__ __launch_bounds__(256) void sr_fold_all_kernel(FoldTable t) {
+  __shared__ float sm[256];
+  int j = 0;
+  while (j + 1 < t.n && (int)blockIdx.x >= t.job[j + 1].blk_begin) ++j;
+  const FoldJob jb = t.job[j];
+  const int b = (int)blockIdx.x - jb.blk_begin;
+  if (jb.wide) {
+    const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int c = b * 16 + cl;
+    float a = 0.f;
+    if (c < jb.len) {
+#pragma unroll 8
+      for (int k = grp; k < jb.nparts; k += 16) a += jb.part[(int64_t)k * jb.stride + c];
+    }
+    sm[grp * 16 + cl] = a;
+    __syncthreads();
+    if (grp == 0 && c < jb.len) {
+      float v = sm[cl];
+#pragma unroll
+      for (int g = 1; g < 16; ++g) v += sm[g * 16 + cl];
+      jb.dst[c] = v;
+    }
+  } else {
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int c = b * 64 + lane;
+    sm[grp * 64 + lane] = (c < jb.len) ? strided_sum(jb.part + c, jb.stride, jb.nparts, grp) : 0.f;
+    __syncthreads();
+    if (grp == 0 && c < jb.len) jb.dst[c] = ((sm[lane] + sm[64 + lane]) + sm[128 + lane]) + sm[192 + lane];
+  }
+}
+struct FoldCtx {
+  bool active = false;
+  int64_t used = 0, cap = 0;
+  float* arena = nullptr;
+  FoldTable tab;
+};
+thread_local FoldCtx g_folds;
+// scratch for one producer's partials: a fresh arena piece while a backward is queueing, the shared region otherwise
+float* part_scratch(float* shared_region, int64_t floats) {
+  FoldCtx& f = g_folds;
+  const int64_t need = (floats + 3) & ~(int64_t)3;
+  if (f.active && f.used + need <= f.cap && f.tab.n + 2 <= SR_MAX_FOLDS) {
+    float* at = f.arena + f.used;
+    f.used += need;
+    return at;
+  }
+  return shared_region;
+}
+void fold(const float* part, int64_t stride, int nparts, int len, float* dst, hipStream_t st, bool own_buffer = false) {
+  FoldCtx& f = g_folds;
+  const bool wide = nparts >= 256;
+  const bool in_arena = f.active && part >= f.arena && part < f.arena + f.cap;
+  if (f.active && (in_arena || own_buffer) && f.tab.n < SR_MAX_FOLDS) {
+    FoldJob& j = f.tab.job[f.tab.n++];
+    j.part = part; j.dst = dst; j.stride = stride; j.nparts = nparts; j.len = len; j.wide = wide ? 1 : 0;
+    j.blk_begin = f.tab.nblocks;
+    f.tab.nblocks += wide ? (len + 15) / 16 : (len + 63) / 64;
+    return;
+  }
+  if (wide) hipLaunchKernelGGL(sr_fold16_kernel, dim3((len + 15) / 16), dim3(256), 0, st, part, stride, nparts, len, dst);
   else hipLaunchKernelGGL(sr_fold_kernel, dim3((len + 63) / 64), dim3(256), 0, st, part, stride, nparts, len, dst);
 }
+// RAII: queue folds for the lifetime of the scope; flush() launches them (an early error return just drops the queue)
+struct FoldScope {
+  FoldScope(float* arena, int64_t cap) {
+    FoldCtx& f = g_folds;
+    f.active = true; f.used = 0; f.cap = cap; f.arena = arena; f.tab.n = 0; f.tab.nblocks = 0;
+  }
+  ~FoldScope() { g_folds.active = false; }
+  void flush(hipStream_t st) {
+    FoldCtx& f = g_folds;
+    if (f.tab.n > 0) hipLaunchKernelGGL(sr_fold_all_kernel, dim3(f.tab.nblocks), dim3(256), 0, st, f.tab);
+    f.tab.n = 0; f.tab.nblocks = 0; f.used = 0;
+  }
+};
 
 // ---------------------------------------------------------------------------------------------------------
 // self-attention over one list, one head per workgroup (no projections: q = k = v = x[:, head slice])
@@ -1404,15 +1498,15 @@ int gemm_dyw(const float* dY, const float* W, float* dX, const float* mask, int6
 // into partials, folded in canonical order
 int gemm_dyTx(const SrPlan& p, const float* dY, const float* X, float* dW, int64_t T, int K, int M, float* ws, hipStream_t st) {
   if (M == 1 && K <= 3 * p.maxw) {  // the scorer's weight row: weighted column sums, partials per SR_CS_ROWS rows
-    float* cpart = ws + p.ws_part;
+    float* cpart = part_scratch(ws + p.ws_part, (int64_t)p.n_cs * K);
     hipLaunchKernelGGL(sr_colsum_w_kernel, dim3(p.n_cs), dim3(256), 0, st, dY, X, T, K, cpart);
     fold(cpart, (int64_t)K, p.n_cs, K, dW, st);
     return 0;
   }
   const int S = p.wg_split;
   const int64_t rows = T / S;
-  float* part = ws + p.ws_wg;
   const int len = M * K;
+  float* part = part_scratch(ws + p.ws_wg, (int64_t)S * len);
   hipLaunchKernelGGL(sr_gemm_dyTx_ref_kernel, dim3((len + 255) / 256, S), dim3(256), 0, st, dY, X, part, rows, K, M);
   fold(part, (int64_t)len, S, len, dW, st);
   return 0;
@@ -1422,7 +1516,6 @@ int gemm_dyTx(const SrPlan& p, const float* dY, const float* X, float* dW, int64
 // the plain chunked kernel + the column-sum kernels.
 void colsum(const SrPlan& p, const float* a, const float* s, const float* mean, const float* rstd, int W, int mode, float* ws,
             float* dst, hipStream_t st);
-void fold(const float* part, int64_t stride, int nparts, int len, float* dst, hipStream_t st);
 int wgrad(const SrPlan& p, const float* dY, const float* X, float* dW, float* db, int64_t T, int K, int M, float* ws, hipStream_t st) {
   const bool ok = M % 4 == 0 && K % 4 == 0 && (((uintptr_t)dY | (uintptr_t)X) & 15) == 0;
   if (!ok) {
@@ -1435,7 +1528,7 @@ int wgrad(const SrPlan& p, const float* dY, const float* X, float* dW, float* db
   const int S = wgrad_chunks(T, M, K, &rps);
   if ((int64_t)rps * (M > K ? M : K) * 4 >= ((int64_t)1 << 31)) return ULTR_E_UNSUPPORTED;
   const int nmb = (M + 63) / 64, nkb = (K + 63) / 64;
-  float* part = ws + p.ws_wg;
+  float* part = part_scratch(ws + p.ws_wg, (int64_t)S * ((int64_t)M * K + M));
   const size_t lds = (size_t)(4 * 64 * 64 + 4 * 64) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
@@ -1552,7 +1645,7 @@ int attn_bwd_mfma(const SrPlan& p, const float* x, const float* dA, const float*
 // dst[0..W) = column sums of a (mode 0) or of a o xhat (mode 1)
 void colsum(const SrPlan& p, const float* a, const float* s, const float* mean, const float* rstd, int W, int mode, float* ws,
             float* dst, hipStream_t st) {
-  float* part = ws + p.ws_part;
+  float* part = part_scratch(ws + p.ws_part, (int64_t)p.n_cs * W);
   hipLaunchKernelGGL(sr_colsum_kernel, dim3(p.n_cs), dim3(256), 0, st, a, s, mean, rstd, p.T, W, mode, part);
   fold(part, (int64_t)W, p.n_cs, W, dst, st);
 }
@@ -1561,7 +1654,7 @@ void colsum(const SrPlan& p, const float* a, const float* s, const float* mean, 
 // dx = LayerNorm backward of dy; dst_gb = dgamma | dbeta; dst_bias = column sums of dx.  W <= 1024.
 int ln_bwd_cs(const SrPlan& p, const float* dy, const float* s, const float* mean, const float* rstd, const float* gamma, int W,
               float* dx, float* ws, float* dst_gb, float* dst_bias, hipStream_t st) {
-  float* part = ws + p.ws_part;
+  float* part = part_scratch(ws + p.ws_part, (int64_t)p.n_lb * 3 * W);
   const size_t lds = (size_t)4 * 3 * W * sizeof(float);
   const bool v4 = (W == 256 || W == 512) && ((((uintptr_t)dy | (uintptr_t)s | (uintptr_t)dx) & 15) == 0);
   if (v4 && W == 256) hipLaunchKernelGGL(sr_ln_bwd_cs_v4_kernel<1>, dim3(p.n_lb), dim3(256), lds, st, dy, s, mean, rstd, gamma, p.T, dx, part);
@@ -1574,7 +1667,7 @@ int ln_bwd_cs(const SrPlan& p, const float* dy, const float* s, const float* mea
 }
 void colsum_ln(const SrPlan& p, const float* dy, const float* s, const float* mean, const float* rstd, int W, float* ws, float* dst,
                hipStream_t st) {
-  float* part = ws + p.ws_part;
+  float* part = part_scratch(ws + p.ws_part, (int64_t)p.n_lb * 2 * W);  // n_lb >= n_cs
   if (W % 4 == 0 && W <= 1024 && ((((uintptr_t)dy | (uintptr_t)s) & 15) == 0)) {
     hipLaunchKernelGGL(sr_colsum_ln_v4_kernel, dim3(p.n_lb), dim3(256), (size_t)8 * W * sizeof(float), st, dy, s, mean, rstd, p.T, W, part);
     fold(part, (int64_t)2 * W, p.n_lb, 2 * W, dst, st);
@@ -1678,6 +1771,7 @@ extern "C" int ultr_setrank_backward(const ultr_setrank_desc* c, const float* pa
       return ULTR_E_UNSUPPORTED;
   }
   // ---- output FFN:  s = oh wo2^T + bo2,  oh = relu(x_nl Wo1^T + bo1) ----------------------------------------------
+  FoldScope folds(ws + p.ws_arena, p.arena_floats);  // every fold below is queued; ONE launch at the end
   SR_CHECK(gemm_dyTx(p, dscores, sv + p.sv_oh, grads + p.wo2, T, dff, 1, ws, st));
   colsum(p, dscores, nullptr, nullptr, nullptr, 1, 0, ws, grads + p.bo2, st);
   SR_CHECK(gemm_dyw(dscores, params + p.wo2, G1, sv + p.sv_oh, T, dff, 1, 0, st));  // G1 = d oh  [T, dff], ReLU mask fused
@@ -1727,8 +1821,8 @@ extern "C" int ultr_setrank_backward(const ultr_setrank_desc* c, const float* pa
   // ---- step tail: fold the loss partials behind the gradient ----------------------------------------------------------
   if (loss_ws != nullptr && n_loss_parts > 0) {
     const int tail = (int)ultr_tail_len(list_size);
-    hipLaunchKernelGGL(sr_fold_kernel, dim3((tail + 63) / 64), dim3(256), 0, st, (const float*)loss_ws, (int64_t)tail, (int)n_loss_parts,
-                       tail, grads + p.P);
+    fold((const float*)loss_ws, (int64_t)tail, (int)n_loss_parts, tail, grads + p.P, st, /*own_buffer=*/true);
   }
+  folds.flush(st);
   return (int)hipGetLastError();
 }
