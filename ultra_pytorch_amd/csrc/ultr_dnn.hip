@@ -2407,7 +2407,7 @@ __global__ __launch_bounds__(64) void grad_sumsq_kernel(int64_t P, const float* 
 // per knob per launch is host time on the critical path of a ~50 us step.  ultr_config_reload() re-reads them (tests and
 // the A/B tools flip knobs inside one process).
 struct Knobs {
-  int fwd_r, bwd_r, wgrad_wgs, fwd_nw, bwd_nw, no_vec, no_l0g, bwd_v1, no_fused_fb, fb_max_wg_per_cu, fb_lists, fwd_q4, big_fwd, big_bwd;
+  int fwd_r, bwd_r, wgrad_wgs, fwd_nw, bwd_nw, no_vec, no_l0g, bwd_v1, no_fused_fb, fb_max_wg_per_cu, fwd_q4, big_fwd, big_bwd;
   bool loaded;
 };
 static Knobs g_knobs = {};
@@ -2427,7 +2427,6 @@ static void knobs_load() {
   k.bwd_v1 = env_read("ULTR_BWD_V1", 0);
   k.no_fused_fb = env_read("ULTR_NO_FUSED_FB", 0);
   k.fb_max_wg_per_cu = env_read("ULTR_FB_MAX_WG_PER_CU", 1);
-  k.fb_lists = env_read("ULTR_FB_LISTS", 0);
   k.fwd_q4 = env_read("ULTR_FWD_Q4", 1);
   // the per-layer big-batch path (ultr_dnn_big.hip): 0 never, 1 by the measured rule (big_*_wanted), 2 whenever legal
   k.big_fwd = env_read("ULTR_BIG_FWD", 1);
