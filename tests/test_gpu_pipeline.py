@@ -126,6 +126,18 @@ def test_driver_matches_the_reference_run(tmp_path, monkeypatch):
         assert set(metrics) == set(ref["metrics"])
         for k, v in ref["metrics"].items():
             assert abs(metrics[k] - v) <= 1e-6 + (0.0 if k.startswith("ndcg") or k.startswith("mrr") else 1e-3), (k, metrics[k], v)
-    for i, (_, sd) in enumerate(saves):
+    # Two parameters are excluded from the saved-tensor comparison: the last LayerNorm's bias and the scorer's bias shift
+    # every score of a list by the same amount, which a softmax loss cannot see - their exact gradient is 0, what both
+    # implementations compute is w_k * (rounding residue of sum(dscores)), and Adagrad's first steps turn the SIGN of that
+    # residue into +-lr moves (the fixture's values for them are sums of +-0.05, +-0.035, +-0.029).  They are checked
+    # against that envelope instead of the reference's coin flips.
+    top = max(int(k.split("layer_norm")[1].split(".")[0]) for k in m["param_keys"] if "layer_norm" in k)
+    noise = {"sequential.layer_norm%d.bias" % top, "sequential.linear%d.bias" % top}
+    for i, (st, sd) in enumerate(saves):
         for k in m["param_keys"]:
+            if k in noise:
+                lr = 0.05
+                bound = lr * sum(1.0 / np.sqrt(t + 1.0) for t in range(st)) * 1.05
+                assert np.all(np.abs(sd[k] - d["init_" + k]) <= bound), k
+                continue
             np.testing.assert_allclose(sd[k], d["save%d_%s" % (i, k)], rtol=5e-3, atol=5e-4, err_msg=k)

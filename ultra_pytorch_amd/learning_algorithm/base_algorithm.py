@@ -69,7 +69,9 @@ class BaseAlgorithm(object):
         ev = self._stage_events.get(key)
         if ev is not None:
             ev.synchronize()  # the previous asynchronous copy out of this staging buffer must have read it
-        host.copy_(torch.from_numpy(np.ascontiguousarray(array)))  # casts (f64 features -> f32, f32 ids -> i32)
+        # casts (f64 features -> f32, f32 ids -> i32) straight into the pinned buffer through its numpy view: torch's
+        # cross-dtype copy_ is ~40x slower than numpy's for these sizes (5.4 ms vs 0.14 ms for 2560 x 136 f64 -> f32)
+        np.copyto(host.numpy(), array, casting="unsafe")
         dev = host.to(self.cuda, non_blocking=True)
         if ev is None:
             ev = self._stage_events[key] = torch.cuda.Event()
