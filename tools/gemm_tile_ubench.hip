@@ -81,6 +81,18 @@ int main(int argc, char** argv) {
     bench<false, 256, 128, 4, 2>(16384, 4096, 512);
     return 0;
   }
+  if (argc > 1 && argv[1][0] == 'o') {  // balanced for 512 resident workgroups (2 per CU) and for 768 (3 per CU)
+    bench<false, 64, 128, 4, 2>(8192, 4096, 512);
+    bench<false, 64, 128, 4, 2>(16384, 704, 512);
+    bench<false, 64, 128, 4, 2>(65536, 256, 512);
+    bench<false, 64, 128, 4, 2>(12288, 4096, 512);
+    bench<false, 64, 128, 4, 2>(24576, 704, 512);
+    bench<false, 64, 128, 4, 2>(98304, 256, 512);
+    bench<false, 64, 128, 4, 2>(12800, 700, 512);
+    bench<false, 64, 128, 4, 2>(102400, 256, 256);
+    bench<true, 64, 128, 4, 2>(102400, 256, 256);
+    return 0;
+  }
   if (argc > 1 && argv[1][0] == 'b') {  // exactly one full chunk per resident workgroup (768 = 3 per CU): the steady-state loop, no tail
     bench<false, 64, 128, 4, 2>(49152, 4096, 128);
     bench<false, 64, 128, 4, 2>(12288, 4096, 512);

@@ -487,12 +487,19 @@ inline hipError_t launch(const Dims& d, const AProd& aprod, const float* B, cons
     if (e != hipSuccess) return e;
     attr = true;
   }
-  // resident workgroups: LDS (160 KB per CU) and wave slots (32 per CU); the kernels stay under 80 registers at 8 waves
-  // and under 128 at 4, so registers do not bind first
-  int per_cu = (int)((160 * 1024) / lds);
-  const int by_waves = 32 / (WM * WN);
-  if (per_cu > by_waves) per_cu = by_waves;
-  if (per_cu < 1) per_cu = 1;
+  // resident workgroups per CU: asked from the runtime once per template instance (LDS, wave slots and the registers
+  // the compiler actually used all bind: 53 KB of LDS -> 3 at <= 80 registers, 2 above)
+  static int per_cu = 0;
+  if (per_cu == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), C::NT, lds) != hipSuccess || nb < 1) {
+      nb = (int)((160 * 1024) / lds);
+      const int by_waves = 32 / (WM * WN);
+      if (nb > by_waves) nb = by_waves;
+      if (nb < 1) nb = 1;
+    }
+    per_cu = nb;
+  }
   const int64_t slots = (int64_t)per_cu * device_cus();
   const int64_t nru = (d.R + 15) / 16;
   const int ncb = (d.N + BN - 1) / BN;
