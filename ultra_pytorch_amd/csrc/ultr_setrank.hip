@@ -1,14 +1,18 @@
 // ultr_setrank.hip — the SetRank ranking model (reference ultra/ranking_model/SetRank.py:23-255),
-// forward and backward, fp32.  First correct path of this "next" row:
-//   * the token-local Linear layers are PLAIN GEMMs and go to rocBLAS (sgemm, atomics off -> deterministic);
-//   * everything that is not a plain GEMM is hand-written here: feature gather + LayerNorm, bias / ReLU epilogues,
-//     residual + LayerNorm (forward and backward with the gamma/beta column sums), bias-gradient column sums, and
-//     the per-(list, head) self-attention WITHOUT Q/K/V projections (the heads are slices of x itself,
-//     SetRank.py:57-66) forward and backward, deterministic (no atomics: the key/value-side sums are a second pass
-//     over LDS-resident P and dS matrices).
+// forward and backward.  Everything is a kernel of this library (no vendor BLAS):
+//   * the token-local Linear layers run on the LDS-tiled fp32 matrix-core GEMM of ultr_gemm.h: forward Y = X.W^T + b
+//     (+ReLU) with the reference's [out, in] weights as the n-major operand and the bias / activation in the epilogue,
+//     dgrad dX (+)= dY.W with the accumulate / ReLU-mask epilogue; the two M = 1 products of the scorer have row kernels;
+//   * feature gather + LayerNorm, residual + LayerNorm (forward, and backward fused with the gamma / beta / bias column
+//     sums), weight gradients (sr_wgrad_kernel: 64 x 64 blocks x row chunks -> slabs), and the per-(list, head)
+//     self-attention WITHOUT Q/K/V projections (the heads are slices of x itself, SetRank.py:57-66), forward and backward,
+//     on the matrix cores with the score tiles in registers: exact fp32 by default, fp16 operands with fp32 accumulation
+//     and fp32 softmax algebra when ultr_setrank_desc.attention_dtype = ULTR_ATTN_FP16 (BASELINE config 5; ordering-level
+//     parity); a scalar fallback covers head depths the matrix-core kernels do not take;
+//   * deterministic: no atomics; every partial sum (slabs, row-block partials) is folded in a fixed order, all folds of a
+//     backward in ONE launch at its end (sr_fold_all_kernel).
 // Token n = b*L + l (list-major), all activations row-major [T, width].  Parameters: ONE flat vector in the
-// reference's state_dict order (ultr_setrank_param_offsets).  fp16 MFMA attention (BASELINE config 5) is the next
-// step; fp32 keeps the 1e-5 parity bar of the rest of the path.
+// reference's state_dict order (ultr_setrank_param_offsets).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -47,7 +51,7 @@ struct SrPlan {
   int64_t ws_g[3];   // three [T, maxw] gradient buffers
   int64_t ws_part;   // [n_cs][3 * maxw] column-sum partials
   int n_cs, n_lb;
-  int64_t ws_wg;     // [wg_split][max M*K] partial weight gradients (split over lists: rocBLAS would run a
+  int64_t ws_wg;     // [wg_split][max M*K] partial weight gradients (split over lists: one launch would run a
                      // [M, K] = dY^T X product with T = 100k contraction rows on a handful of workgroups)
   int wg_split;      // chunks of whole lists, divides the batch
   int64_t wg_floats; // floats of one weight-gradient partial region
@@ -124,7 +128,7 @@ bool make_plan(const ultr_setrank_desc* c, int64_t T, SrPlan* p) {
   int64_t maxmk = dff * F;
   if (d * dff > maxmk) maxmk = d * dff;
   if (d * d > maxmk) maxmk = d * d;
-  int64_t wg_floats = (int64_t)p->wg_split * maxmk;  // rocBLAS path (unaligned shapes)
+  int64_t wg_floats = (int64_t)p->wg_split * maxmk;  // the plain chunked kernel (unaligned shapes)
   const int shapes[4][2] = {{(int)dff, (int)F}, {(int)d, (int)dff}, {(int)d, (int)d}, {(int)dff, (int)d}};  // [M, K]
   for (int k = 0; k < 4; ++k) {
     int rps = 0;
