@@ -206,6 +206,32 @@ def test_two_rank_step_equals_single_process(mode, algo):
         np.testing.assert_allclose(res["aux"], ref["aux"], atol=1e-5)
 
 
+@pytest.mark.parametrize("world,algo", [(4, "softmax"), (4, "pairdebias"), (7, "softmax")])
+def test_more_ranks_peer_exchange(world, algo):
+    """The exchange kernel is compiled per world size (2 .. 8 ranks: flag matrix [slice][rank], rank-ordered sums): 4 ranks
+    (shards of 2, 2, 2, 1 lists) and 7 ranks (one list each - the scaling run goes to 8) on the one GPU, against the
+    single-process step; PairDebias also carries the agreed global batch through uneven shards."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29760 + world + (10 if algo == "pairdebias" else 0)
+    procs = [ctx.Process(target=worker, args=(r, world, port, "peer", algo, q)) for r in range(world)]
+    [p.start() for p in procs]
+    got = dict(q.get(timeout=600) for _ in range(world))
+    [p.join(180) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    one, _ = single_process(algo)
+    gmax = np.abs(one["params"]).max()
+    for rank in range(world):
+        res = got[rank]
+        assert res["status"] == 0 and res["peer"] and res["batch_total"] == B
+        assert np.array_equal(res["params"], got[0]["params"])
+        np.testing.assert_allclose(res["params"], one["params"], rtol=2e-5, atol=2e-6 * gmax)
+        np.testing.assert_allclose(res["losses"], one["losses"], rtol=1e-5, atol=1e-6)
+        if res["aux"] is not None:
+            np.testing.assert_allclose(res["aux"], one["aux"], atol=2e-6)
+
+
 def test_peer_comm_world1_matches_grad_sumsq():
     """world 1 through the exchange kernel (ULTR_FORCE_DP): copy + partials == ultr_grad_sumsq."""
     import ctypes
