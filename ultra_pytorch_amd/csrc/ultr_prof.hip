@@ -21,7 +21,9 @@ int g_stride = 1;
 
 void ultr_prof_tick() {
   if (g_ultr_prof_mask == 0) return;
-  g_ultr_prof_live = (g_ticks++ % (uint64_t)g_stride) == 0;
+  // the sampled step sits in the MIDDLE of each stride window: the first step behind a host synchronisation (device just idle)
+  // is not the one that gets timed
+  g_ultr_prof_live = (g_ticks++ % (uint64_t)g_stride) == (uint64_t)(g_stride / 2);
 }
 
 bool ultr_prof_take(int kid, hipEvent_t* a, hipEvent_t* b) {
