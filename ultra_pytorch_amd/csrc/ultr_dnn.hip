@@ -2358,9 +2358,13 @@ __device__ __forceinline__ float block_sum_256(float v, float* sm) {
   return t;
 }
 
+// ONE = a thread folds all partials of its element (full_sum: the same bits as the four cooperating groups of strided_sum),
+// 256 elements per workgroup: a quarter of the workgroups for the same work - the launch is latency-bound when there are few
+// slabs (config 2: 8 per layer, 1600 -> 400 workgroups).  Sum-of-squares partials keep their geometry (one per 64 elements).
+template <bool ONE>
 __global__ __launch_bounds__(256) void grad_reduce_kernel(RedPlan rp, int64_t P, int tail, const float* __restrict__ ws,
                                                           const float* __restrict__ loss_part, int n_loss_part,
-                                                          float* __restrict__ grads, float* __restrict__ sumsq_part) {
+                                                          float* __restrict__ grads, float* __restrict__ sumsq_part, int nsq) {
   __shared__ float sm[4][64];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   if (n_loss_part > 0 && blockIdx.x == gridDim.x - 1) {
@@ -2372,6 +2376,21 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(RedPlan rp, int64_t P,
       if (grp == 0 && t < tail) grads[P + t] = ((sm[0][lane] + sm[1][lane]) + sm[2][lane]) + sm[3][lane];
       __syncthreads();
     }
+    return;
+  }
+  if constexpr (ONE) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float g = 0.f;
+    if (e < P) {
+      int s = 0;
+      while (s + 1 < rp.nseg && e >= rp.seg[s + 1].off) ++s;
+      const RedSeg sg = rp.seg[s];
+      g = full_sum(ws + sg.base + (e - sg.off), sg.stride, sg.nparts);
+      grads[e] = g;
+    }
+    const float sq = wave_sum(g * g);
+    const int k = (int)blockIdx.x * 4 + grp;
+    if (lane == 0 && k < nsq) sumsq_part[k] = sq;
     return;
   }
   const int64_t e = (int64_t)blockIdx.x * 64 + lane;
@@ -2949,8 +2968,14 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
   ultr_make_red_plan(p, bp, &rp);
   const int nblk = (int)ultr_red_blocks(p.P, tail);
   UltrProfScope prof(ULTR_K_REDUCE, st);
-  ULTR_LAUNCH(prof, grad_reduce_kernel, dim3(nblk + (bp.lf_chunks > 0 ? 1 : 0)), dim3(256), 0, st, rp, p.P, tail, (const float*)ws,
-              (const float*)(ws + bp.lfold_off), bp.lf_chunks, grads, ws + bp.sumsq_off);
+  int maxparts = 1;
+  for (int k = 0; k < rp.nseg; ++k) maxparts = rp.seg[k].nparts > maxparts ? rp.seg[k].nparts : maxparts;
+  if (maxparts <= 16)
+    ULTR_LAUNCH(prof, grad_reduce_kernel<true>, dim3((nblk + 3) / 4 + (bp.lf_chunks > 0 ? 1 : 0)), dim3(256), 0, st, rp, p.P, tail,
+                (const float*)ws, (const float*)(ws + bp.lfold_off), bp.lf_chunks, grads, ws + bp.sumsq_off, nblk);
+  else
+    ULTR_LAUNCH(prof, grad_reduce_kernel<false>, dim3(nblk + (bp.lf_chunks > 0 ? 1 : 0)), dim3(256), 0, st, rp, p.P, tail,
+                (const float*)ws, (const float*)(ws + bp.lfold_off), bp.lf_chunks, grads, ws + bp.sumsq_off, nblk);
   return (int)hipGetLastError();
 }
 
