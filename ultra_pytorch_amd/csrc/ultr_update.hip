@@ -171,58 +171,82 @@ __global__ __launch_bounds__(256) void update_kernel(ultr_update_desc u, DnnPlan
 // the tile goes out transposed through LDS as WT_j[k0 + r][m0 + c] (64-byte segments again; a per-element scatter wrote
 // 4 bytes per 64-byte sector: 3.5 MB of write traffic for 0.4 MB of data and ~1 us of the kernel).  The remaining
 // workgroups walk the vector parameters segment by segment and write the image.
+// TPW tiles (or 256-element pieces of the vector parameters) per workgroup: every workgroup re-sums ALL sum-of-squares
+// partials (one per 64 parameters) for its copy of the clip coefficient - at 0.5 M parameters (config 4) that is 32 KB per
+// workgroup and 2050 workgroups; four units per workgroup quarter that traffic (update 14 -> 8 us there).
+template <int TPW>
 __global__ __launch_bounds__(256) void update_tiled_kernel(ultr_update_desc u, DnnPlan dp, float* __restrict__ params,
                                                            float* __restrict__ state, const float* __restrict__ grads,
                                                            float* __restrict__ aux, float* __restrict__ wt,
                                                            const float* __restrict__ sumsq_part, int nsq,
-                                                           float* __restrict__ scalars_out) {
+                                                           float* __restrict__ scalars_out, int n_tile_blocks) {
   __shared__ float sm[4];
-  __shared__ float tile[16][17];
+  __shared__ float tile[TPW][16][17];
   const int64_t P = u.n_params;
   const int n_tiles = dp.upd_tile_begin[dp.nl - 1];
   const int tid = threadIdx.x, r = tid >> 4, c = tid & 15;
-  int64_t ea[1] = {-1};
-  int j = 0, m0 = 0, k0 = 0, pvpos = -1;
-  const bool is_tile = (int)blockIdx.x < n_tiles;
-  if (is_tile) {
-    while (j + 1 < dp.nl - 1 && (int)blockIdx.x >= dp.upd_tile_begin[j + 1]) ++j;
-    const int t = (int)blockIdx.x - dp.upd_tile_begin[j];
-    const int tm = t / dp.upd_ntk[j];
-    m0 = tm * 16;
-    k0 = (t - tm * dp.upd_ntk[j]) * 16;
-    if (m0 + r < dp.M[j] && k0 + c < dp.K[j]) ea[0] = dp.off_w[j] + (int64_t)(m0 + r) * dp.K[j] + k0 + c;
-  } else {
-    const int v = ((int)blockIdx.x - n_tiles) * 256 + tid;
-    if (v < dp.vs_begin[dp.n_vs]) {
-      int sg = 0;
-      while (sg + 1 < dp.n_vs && v >= dp.vs_begin[sg + 1]) ++sg;
-      ea[0] = dp.vs_off[sg] + (v - dp.vs_begin[sg]);
-      pvpos = dp.vs_pv[sg] + (v - dp.vs_begin[sg]);
+  int64_t ea[TPW];
+  int jj[TPW], m0[TPW], k0[TPW], pvpos[TPW];
+  const bool is_tile = (int)blockIdx.x < n_tile_blocks;
+#pragma unroll
+  for (int q = 0; q < TPW; ++q) {
+    ea[q] = -1; jj[q] = -1; m0[q] = 0; k0[q] = 0; pvpos[q] = -1;
+    if (is_tile) {
+      const int tb = (int)blockIdx.x * TPW + q;
+      if (tb < n_tiles) {
+        int j = 0;
+        while (j + 1 < dp.nl - 1 && tb >= dp.upd_tile_begin[j + 1]) ++j;
+        const int t = tb - dp.upd_tile_begin[j];
+        const int tm = t / dp.upd_ntk[j];
+        jj[q] = j;
+        m0[q] = tm * 16;
+        k0[q] = (t - tm * dp.upd_ntk[j]) * 16;
+        if (m0[q] + r < dp.M[j] && k0[q] + c < dp.K[j]) ea[q] = dp.off_w[j] + (int64_t)(m0[q] + r) * dp.K[j] + k0[q] + c;
+      }
+    } else {
+      const int v = (((int)blockIdx.x - n_tile_blocks) * TPW + q) * 256 + tid;
+      if (v < dp.vs_begin[dp.n_vs]) {
+        int sg = 0;
+        while (sg + 1 < dp.n_vs && v >= dp.vs_begin[sg + 1]) ++sg;
+        ea[q] = dp.vs_off[sg] + (v - dp.vs_begin[sg]);
+        pvpos[q] = dp.vs_pv[sg] + (v - dp.vs_begin[sg]);
+      }
     }
   }
-  const int64_t e = ea[0];
-  const bool live = e >= 0;
-  const float g_raw[1] = {live ? grads[e] : 0.f};
-  const float p_old[1] = {live ? params[e] : 0.f};
-  const float s_old[1] = {(live && state != nullptr) ? state[e] : 0.f};
+  float g_raw[TPW], p_old[TPW], s_old[TPW];
+#pragma unroll
+  for (int q = 0; q < TPW; ++q) {
+    const bool live = ea[q] >= 0;
+    g_raw[q] = live ? grads[ea[q]] : 0.f;
+    p_old[q] = live ? params[ea[q]] : 0.f;
+    s_old[q] = (live && state != nullptr) ? state[ea[q]] : 0.f;
+  }
   float ss = 0.f;
 #pragma unroll 8
   for (int k = tid; k < nsq; k += 256) ss += sumsq_part[k];
   ss = block_sum256(ss, sm);
-  float pn[1];
+  float pn[TPW];
   // block 0's extra duties (EM / propensity updates, step scalars) run inside update_body and need all 256 threads
   if (blockIdx.x != 0) {
-    update_body<1>(u, dp, params, state, grads + P, aux, ss, ea, g_raw, p_old, s_old, pn, sm, nullptr);
+    update_body<TPW>(u, dp, params, state, grads + P, aux, ss, ea, g_raw, p_old, s_old, pn, sm, nullptr);
   } else {
-    update_body<1>(u, dp, params, state, grads + P, aux, ss, ea, g_raw, p_old, s_old, pn, sm, scalars_out);
+    update_body<TPW>(u, dp, params, state, grads + P, aux, ss, ea, g_raw, p_old, s_old, pn, sm, scalars_out);
   }
   if (is_tile) {
-    tile[r][c] = pn[0];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) tile[q][r][c] = pn[q];
     __syncthreads();
-    const int k = k0 + r, m = m0 + c;  // transposed ownership
-    if (k < dp.K[j] && m < dp.M[j]) wt[dp.wt_off[j] + (int64_t)k * dp.M[j] + m] = tile[c][r];
-  } else if (pvpos >= 0) {
-    wt[dp.wt_pv_off + pvpos] = pn[0];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+      const int j = jj[q];
+      if (j < 0) continue;
+      const int k = k0[q] + r, m = m0[q] + c;  // transposed ownership
+      if (k < dp.K[j] && m < dp.M[j]) wt[dp.wt_off[j] + (int64_t)k * dp.M[j] + m] = tile[q][c][r];
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < TPW; ++q)
+      if (pvpos[q] >= 0) wt[dp.wt_pv_off + pvpos[q]] = pn[q];
   }
 }
 
@@ -242,9 +266,16 @@ extern "C" int ultr_apply_update(const ultr_update_desc* u, const ultr_dnn_desc*
   const int nsq = (int)ultr_red_blocks(u->n_params, tail);
   UltrProfScope prof(ULTR_K_UPDATE, (hipStream_t)stream);
   if (wt != nullptr) {
-    const int nblk = dp.upd_tile_begin[dp.nl - 1] + (dp.vs_begin[dp.n_vs] + 255) / 256;
-    ULTR_LAUNCH(prof, update_tiled_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *u, dp, params, state, grads, aux, wt,
-                (const float*)bwd_ws, nsq, scalars_out);
+    const int n_tiles = dp.upd_tile_begin[dp.nl - 1], n_vec = dp.vs_begin[dp.n_vs];
+    if (n_tiles + (n_vec + 255) / 256 < 1536) {  // one unit per workgroup keeps the launch wide (config 2: 401 units, config 3: 940 -
+                                                 // four per workgroup left 235 workgroups for 256 CUs: 7.0 -> 9.0 us)
+      ULTR_LAUNCH(prof, update_tiled_kernel<1>, dim3(n_tiles + (n_vec + 255) / 256), dim3(256), 0, (hipStream_t)stream, *u, dp, params, state,
+                  grads, aux, wt, (const float*)bwd_ws, nsq, scalars_out, n_tiles);
+    } else {
+      const int tb = (n_tiles + 3) / 4;
+      ULTR_LAUNCH(prof, update_tiled_kernel<4>, dim3(tb + (n_vec + 1023) / 1024), dim3(256), 0, (hipStream_t)stream, *u, dp, params, state,
+                  grads, aux, wt, (const float*)bwd_ws, nsq, scalars_out, tb);
+    }
   } else {
     const int nblk = (int)((u->n_params + 255) / 256);
     ULTR_LAUNCH(prof, update_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *u, dp, params, state, grads, aux,
