@@ -147,6 +147,33 @@ struct EBiasAct {
       for (int j = 0; j < n_valid; ++j) dst[j] = o[j];
   }
 };
+// y = (c + bias) + res: a Linear's output added to the residual stream (the pre-LayerNorm sum of a transformer block); the
+// association matches "a + (b + bias)" of a separate residual pass bit for bit
+struct EBiasRes {
+  float* y;
+  const float* bias;  // may be nullptr
+  const float* res;   // same shape as y
+  int ldy;
+  __device__ __forceinline__ void operator()(int64_t r, int c, float4 v, int n_valid) const {
+    float o[4] = {v.x, v.y, v.z, v.w};
+    const float* rs = res + r * ldy + c;
+    float* dst = y + r * ldy + c;
+    const bool vec = n_valid == 4 && ((ldy & 3) == 0);
+    float rv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (vec) {
+      const float4 r4 = ld4(rs);
+      rv[0] = r4.x; rv[1] = r4.y; rv[2] = r4.z; rv[3] = r4.w;
+    } else {
+      for (int j = 0; j < n_valid; ++j) rv[j] = rs[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < n_valid) o[j] = (o[j] + (bias != nullptr ? bias[c + j] : 0.f)) + rv[j];
+    if (vec) st4(dst, make_float4(o[0], o[1], o[2], o[3]));
+    else
+      for (int j = 0; j < n_valid; ++j) dst[j] = o[j];
+  }
+};
 // y = (accumulate ? y : 0) + c, then (mask != nullptr) zeroed where mask <= 0 (ReLU backward through the saved output)
 struct EStore {
   float* y;

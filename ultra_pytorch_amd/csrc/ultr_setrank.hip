@@ -292,12 +292,16 @@ __global__ __launch_bounds__(SR_ROWS * 64) void sr_ln_fwd_v4_kernel(const float*
   for (int k = 0; k < NV; ++k) {
     const int c = 4 * lane + 256 * k;
     const float4 av = ld4(a + n * W + c);
-    float4 bv = ld4(b + n * W + c);
-    if (bias != nullptr) {
-      bv.x += bias[c]; bv.y += bias[c + 1]; bv.z += bias[c + 2]; bv.w += bias[c + 3];  // parameters: any float offset
+    if (b != nullptr) {  // wave-uniform: b == NULL = `a` already is the pre-norm sum (a GEMM epilogue wrote it)
+      float4 bv = ld4(b + n * W + c);
+      if (bias != nullptr) {
+        bv.x += bias[c]; bv.y += bias[c + 1]; bv.z += bias[c + 2]; bv.w += bias[c + 3];  // parameters: any float offset
+      }
+      v[k] = make_float4(av.x + bv.x, av.y + bv.y, av.z + bv.z, av.w + bv.w);
+      st4(sum_out + n * W + c, v[k]);
+    } else {
+      v[k] = av;
     }
-    v[k] = make_float4(av.x + bv.x, av.y + bv.y, av.z + bv.z, av.w + bv.w);
-    st4(sum_out + n * W + c, v[k]);
     s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
   }
   const float mean = wave_sum(s) / (float)W;
@@ -1486,6 +1490,16 @@ int gemm_xwT(const float* X, const float* W, const float* bias, float* Y, int64_
   hipLaunchKernelGGL(sr_gemm_xwT_ref_kernel, dim3((unsigned)((T * M + 255) / 256)), dim3(256), 0, st, X, W, bias, Y, T, K, M, relu);
   return 0;
 }
+// S[T, M] = (X[T, K] . W[M, K]^T + bias) + res: a Linear onto the residual stream, fused (the tiled GEMM only); false = the
+// shape does not take it and the caller runs the Linear and the residual pass separately
+bool gemm_xwT_res(const float* X, const float* W, const float* bias, const float* res, float* S, int64_t T, int K, int M, hipStream_t st) {
+  if (!(M >= 16 && M % 4 == 0 && vec_ok(X, W, S, K, M) && (((uintptr_t)res) & 15) == 0 && T * (K > M ? K : M) * 4 < ((int64_t)1 << 31)))
+    return false;
+  const ugemm::Dims d{T, M, K, K};
+  const ugemm::APlain a{X, T, K, K};
+  const ugemm::EBiasRes e{S, bias, res, M};
+  return ugemm::run<true>(d, a, W, e, st) == hipSuccess;
+}
 // row-major  dX[T, K] = (accumulate ? dX : 0) + dY[T, M] . W[M, K], then zeroed where mask <= 0 (mask may be NULL)
 int gemm_dyw(const float* dY, const float* W, float* dX, const float* mask, int64_t T, int K, int M, int accumulate, hipStream_t st) {
   if (M % 4 == 0 && K >= 16 && vec_ok(dY, W, dX, K, K) && (mask == nullptr || ((uintptr_t)mask & 15) == 0) &&
@@ -1558,7 +1572,7 @@ void ln_residual_fwd(const float* a, const float* b, const float* bias, int64_t 
                      float* sum_out, float* y, float* mean_out, float* rstd_out, int batch, int L, hipStream_t st) {
   const unsigned rblk = (unsigned)((T + SR_ROWS - 1) / SR_ROWS);
   const bool v4 = (W == 256 || W == 512 || W == 768 || W == 1024) &&
-                  ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)sum_out | (uintptr_t)y) & 15) == 0);
+                  ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)sum_out | (uintptr_t)y) & 15) == 0);  // b / sum_out may be NULL
   if (v4 && W == 256) hipLaunchKernelGGL(sr_ln_fwd_v4_kernel<1>, dim3(rblk), dim3(SR_ROWS * 64), 0, st, a, b, bias, T, gamma, beta, sum_out, y, mean_out, rstd_out);
   else if (v4 && W == 512) hipLaunchKernelGGL(sr_ln_fwd_v4_kernel<2>, dim3(rblk), dim3(SR_ROWS * 64), 0, st, a, b, bias, T, gamma, beta, sum_out, y, mean_out, rstd_out);
   else if (v4 && W == 768) hipLaunchKernelGGL(sr_ln_fwd_v4_kernel<3>, dim3(rblk), dim3(SR_ROWS * 64), 0, st, a, b, bias, T, gamma, beta, sum_out, y, mean_out, rstd_out);
@@ -1735,13 +1749,26 @@ extern "C" int ultr_setrank_forward(const ultr_setrank_desc* c, const float* par
     else if (mfma_att) SR_CHECK(attn_fwd_mfma(p, x, batch, L, sv + p.sv_A[l], sv + p.sv_lse[l], st));
     else hipLaunchKernelGGL(sr_attn_fwd_kernel, dim3(batch, p.H), dim3(256), lds_att, st, x, L, d, p.dh, sv + p.sv_A[l]);
     // A Wd^T lands in out1's buffer, then out1 = LN1(x + (A Wd^T + bd)) in place (s1 keeps the pre-norm sum)
-    SR_CHECK(gemm_xwT(sv + p.sv_A[l], params + y.wd, nullptr, sv + p.sv_out1[l], T, d, d, 0, st));
-    ln_residual_fwd(x, sv + p.sv_out1[l], params + y.bd, T, d, params + y.g1, params + y.b1, sv + p.sv_s1[l], sv + p.sv_out1[l],
-                    sv + p.sv_m1[l], sv + p.sv_r1[l], (int)batch, L, st);
+    // the Linear's epilogue writes the pre-norm sum s1 = x + (A Wd^T + bd) straight into `saved` (one pass over [T, d] less on
+    // each side of the LayerNorm); shapes the tiled GEMM does not take: Linear, then the residual pass
+    const bool ln_v4 = (d == 256 || d == 512 || d == 768 || d == 1024);
+    if (ln_v4 && gemm_xwT_res(sv + p.sv_A[l], params + y.wd, params + y.bd, x, sv + p.sv_s1[l], T, d, d, st)) {
+      ln_residual_fwd(sv + p.sv_s1[l], nullptr, nullptr, T, d, params + y.g1, params + y.b1, nullptr, sv + p.sv_out1[l],
+                      sv + p.sv_m1[l], sv + p.sv_r1[l], (int)batch, L, st);
+    } else {
+      SR_CHECK(gemm_xwT(sv + p.sv_A[l], params + y.wd, nullptr, sv + p.sv_out1[l], T, d, d, 0, st));
+      ln_residual_fwd(x, sv + p.sv_out1[l], params + y.bd, T, d, params + y.g1, params + y.b1, sv + p.sv_s1[l], sv + p.sv_out1[l],
+                      sv + p.sv_m1[l], sv + p.sv_r1[l], (int)batch, L, st);
+    }
     SR_CHECK(gemm_xwT(sv + p.sv_out1[l], params + y.wf1, params + y.bf1, sv + p.sv_f[l], T, d, dff, 1, st));
-    SR_CHECK(gemm_xwT(sv + p.sv_f[l], params + y.wf2, nullptr, sv + p.sv_x[l + 1], T, dff, d, 0, st));
-    ln_residual_fwd(sv + p.sv_out1[l], sv + p.sv_x[l + 1], params + y.bf2, T, d, params + y.g2, params + y.b2, sv + p.sv_s2[l],
-                    sv + p.sv_x[l + 1], sv + p.sv_m2[l], sv + p.sv_r2[l], (int)batch, L, st);
+    if (ln_v4 && gemm_xwT_res(sv + p.sv_f[l], params + y.wf2, params + y.bf2, sv + p.sv_out1[l], sv + p.sv_s2[l], T, dff, d, st)) {
+      ln_residual_fwd(sv + p.sv_s2[l], nullptr, nullptr, T, d, params + y.g2, params + y.b2, nullptr, sv + p.sv_x[l + 1],
+                      sv + p.sv_m2[l], sv + p.sv_r2[l], (int)batch, L, st);
+    } else {
+      SR_CHECK(gemm_xwT(sv + p.sv_f[l], params + y.wf2, nullptr, sv + p.sv_x[l + 1], T, dff, d, 0, st));
+      ln_residual_fwd(sv + p.sv_out1[l], sv + p.sv_x[l + 1], params + y.bf2, T, d, params + y.g2, params + y.b2, sv + p.sv_s2[l],
+                      sv + p.sv_x[l + 1], sv + p.sv_m2[l], sv + p.sv_r2[l], (int)batch, L, st);
+    }
   }
   // output FFN (SetRank.py:136, 153)
   SR_CHECK(gemm_xwT(sv + p.sv_x[p.nl], params + p.wo1, params + p.bo1, sv + p.sv_oh, T, d, dff, 1, st));
