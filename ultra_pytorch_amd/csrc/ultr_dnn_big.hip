@@ -1,9 +1,11 @@
 // ultr_dnn_big.hip — the DNN ranking model's training forward / backward for LARGE batches (tens of thousands of rows).
 //
 // The kernels of ultr_dnn.hip keep a 16-row tile on chip through every layer and re-stream every weight matrix per tile:
-// right where latency decides (BASELINE config 2: 2 560 rows), but at config 4 (12 800 rows x 700 features,
-// [512, 256, 128]) the 16-row tiles cap the forward at 61 TFLOP/s and the row-local backward - whose LDS footprint leaves
-// one workgroup per CU with ten serial phases - at 33 TFLOP/s.  Here every layer is ONE pass over the rows instead:
+// right where latency decides (BASELINE config 2: 2 560 rows).  For big batches every layer can be ONE pass over the rows
+// instead.  Which half is taken is a measured rule of the launcher (ultr_dnn.hip, big_fwd_wanted / big_bwd_wanted):
+// the BACKWARD from 16 384 rows, and from 4 096 rows when a layer is wider than 512 (config 4: 12 800 rows x [512, 256, 128]
+// behind 700 features, 128 -> 85 us); the FORWARD only for rows too wide for the row tile's LDS (it measures 10-40 % slower
+// than the row-tile forward where both run).
 //   forward   per layer  row statistics (mean, rstd; HBM-bound, a wave per row)  ->  tiled GEMM (ultr_gemm.h) whose
 //             A-operand producer applies the LayerNorm on the fly (and gathers the feature rows by document id for
 //             layer 0) and whose epilogue adds the bias, applies the activation and writes x_{j+1} for the backward;
