@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "../../include/ultr_hip.h"
 #include "ultr_device.h"
@@ -2032,8 +2033,16 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
 // Per step a lane issues two 16-byte loads (dz row piece along m, x row piece along k) feeding 16 MFMAs:
 // A[i][kk] = dz[n+kk][m0+4i+ta], B[kk][j] = u[n+kk][k0+4j+tb]  ->  D_{ta,tb}[i][j] = dW[m0+4i+ta][k0+4j+tb].
 #ifndef WG_D
-#define WG_D 3  // register sets of the wgrad operand ring (operands requested two trips ahead; pays with one workgroup per CU)
+#define WG_D 3  // register sets of the wgrad operand ring (operands requested WG_D - 1 trips ahead)
 #endif
+template <int N, class F, int... I>
+__device__ __forceinline__ void wg_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void wg_static_for(F&& f) {
+  wg_static_for_impl<N>(f, std::make_integer_sequence<int, N>{});
+}
 template <bool VEC>
 __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, const float* __restrict__ params,
                                                         const float* __restrict__ features, int64_t n_docs,
@@ -2228,31 +2237,19 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
     nn += 4 * SPT;
   };
   const int ntrip = (int)((nend - nbeg + 4 * SPT - 1) / (4 * SPT));
-  StepRegs ra[SPT], rb[SPT];
+  // WG_D register sets in a ring: the operands of trip t + WG_D - 1 are requested while trip t is consumed - the dz / x rows
+  // were written by the previous launches, mostly on other XCDs, and come from beyond the local L2
+  StepRegs r[WG_D][SPT];
 #pragma unroll
-  for (int u = 0; u < SPT; ++u) load_step(nbeg + 4 * u + q, ra[u].a, ra[u].x, ra[u].mean, ra[u].rstd);
-  if constexpr (WG_D == 2) {
-    int t = 0;
-    for (; t + 1 < ntrip; t += 2) {
-      trip(ra, rb);
-      trip(rb, ra);
-    }
-    if (t < ntrip) trip(ra, rb);
-  } else {
-    // three register sets: operands are requested two trips (64 MFMAs per wave) before they are consumed - the
-    // dz / x rows were written by the previous launches, mostly on other XCDs, and come from beyond the local L2
-    StepRegs rc[SPT];
+  for (int d = 0; d < WG_D - 1; ++d)
 #pragma unroll
-    for (int u = 0; u < SPT; ++u) load_step(nbeg + 4 * SPT + 4 * u + q, rb[u].a, rb[u].x, rb[u].mean, rb[u].rstd);
-    int t = 0;
-    for (; t + 2 < ntrip; t += 3) {
-      trip(ra, rc);
-      trip(rb, ra);
-      trip(rc, rb);
-    }
-    if (t < ntrip) trip(ra, rc);
-    if (t + 1 < ntrip) trip(rb, ra);
-  }
+    for (int u = 0; u < SPT; ++u) load_step(nbeg + 4 * SPT * d + 4 * u + q, r[d][u].a, r[d][u].x, r[d][u].mean, r[d][u].rstd);
+  int t = 0;
+  for (; t + WG_D <= ntrip; t += WG_D)
+    wg_static_for<WG_D>([&](auto I) { trip(r[decltype(I)::value], r[(decltype(I)::value + WG_D - 1) % WG_D]); });
+  wg_static_for<WG_D - 1>([&](auto I) {
+    if (t + decltype(I)::value < ntrip) trip(r[decltype(I)::value], r[(decltype(I)::value + WG_D - 1) % WG_D]);
+  });
   };  // mainloop
   // the layer-0 variant (doc ids -> feature rows through LDS) and the plain variant are separate straight-line
   // loops: a branch on j inside the loop would put the loads in control flow and drain vmcnt(0) every step
