@@ -132,6 +132,9 @@ struct EBiasAct {
   float* y;
   const float* bias;  // may be nullptr
   int ldy, act;
+  struct Pre {};
+  __device__ __forceinline__ Pre prefetch(int64_t, int, int) const { return Pre{}; }
+  __device__ __forceinline__ void operator()(int64_t r, int c, float4 v, int n_valid, const Pre&) const { (*this)(r, c, v, n_valid); }
   __device__ __forceinline__ void operator()(int64_t r, int c, float4 v, int n_valid) const {
     float o[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -154,31 +157,36 @@ struct EBiasRes {
   const float* bias;  // may be nullptr
   const float* res;   // same shape as y
   int ldy;
-  __device__ __forceinline__ void operator()(int64_t r, int c, float4 v, int n_valid) const {
-    float o[4] = {v.x, v.y, v.z, v.w};
+  // the residual piece is REQUESTED before the accumulators go through LDS (n-major epilogue) and consumed behind the barrier
+  struct Pre { float4 r; };
+  __device__ __forceinline__ Pre prefetch(int64_t r, int c, int n_valid) const {
+    Pre p;
     const float* rs = res + r * ldy + c;
+    if (n_valid == 4 && ((ldy & 3) == 0)) p.r = ld4(rs);
+    else p.r = make_float4(rs[0], n_valid > 1 ? rs[1] : 0.f, n_valid > 2 ? rs[2] : 0.f, 0.f);
+    return p;
+  }
+  __device__ __forceinline__ void operator()(int64_t r, int c, float4 v, int n_valid, const Pre& p) const {
+    float o[4] = {v.x, v.y, v.z, v.w};
+    const float rv[4] = {p.r.x, p.r.y, p.r.z, p.r.w};
     float* dst = y + r * ldy + c;
-    const bool vec = n_valid == 4 && ((ldy & 3) == 0);
-    float rv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (vec) {
-      const float4 r4 = ld4(rs);
-      rv[0] = r4.x; rv[1] = r4.y; rv[2] = r4.z; rv[3] = r4.w;
-    } else {
-      for (int j = 0; j < n_valid; ++j) rv[j] = rs[j];
-    }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (j < n_valid) o[j] = (o[j] + (bias != nullptr ? bias[c + j] : 0.f)) + rv[j];
-    if (vec) st4(dst, make_float4(o[0], o[1], o[2], o[3]));
+    if (n_valid == 4 && ((ldy & 3) == 0)) st4(dst, make_float4(o[0], o[1], o[2], o[3]));
     else
       for (int j = 0; j < n_valid; ++j) dst[j] = o[j];
   }
+  __device__ __forceinline__ void operator()(int64_t r, int c, float4 v, int n_valid) const { (*this)(r, c, v, n_valid, prefetch(r, c, n_valid)); }
 };
 // y = (accumulate ? y : 0) + c, then (mask != nullptr) zeroed where mask <= 0 (ReLU backward through the saved output)
 struct EStore {
   float* y;
   const float* mask;  // same shape as y, or nullptr
   int ldy, accumulate;
+  struct Pre {};
+  __device__ __forceinline__ Pre prefetch(int64_t, int, int) const { return Pre{}; }
+  __device__ __forceinline__ void operator()(int64_t r, int c, float4 v, int n_valid, const Pre&) const { (*this)(r, c, v, n_valid); }
   __device__ __forceinline__ void operator()(int64_t r, int c, float4 v, int n_valid) const {
     float o[4] = {v.x, v.y, v.z, v.w};
     float* dst = y + r * ldy + c;
@@ -454,6 +462,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(Dims d, AProd aprod,
       // n-major B: a lane holds one column of four tiles; transpose through LDS (the staging buffers are free: every wave
       // passed the barrier behind the last k-tile) into float4 pieces
       float* Cs = smem;
+      constexpr int PIECES = BM * (BN / 4);
+      constexpr int PPT = PIECES / C::NT;  // pieces per thread
+      static_assert(PIECES % C::NT == 0, "epilogue pieces divide evenly");
+      // whatever the functor reads besides the accumulators (a residual tile) is requested NOW, in front of the LDS transpose
+      typename Epi::Pre pre[PPT];
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) {
+        const int idx = tid + C::NT * k;
+        const int row = idx / (BN / 4), c4 = (idx - row * (BN / 4)) * 4;
+        const int64_t r = e_r0 + row;
+        const int c = e_n0 + c4;
+        if (r < e_rend && c < d.N) pre[k] = epi.prefetch(r, c, d.N - c < 4 ? d.N - c : 4);
+      }
 #pragma unroll
       for (int rt = 0; rt < C::RT; ++rt)
 #pragma unroll
@@ -463,15 +484,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(Dims d, AProd aprod,
           for (int t = 0; t < C::CT; ++t) Cs[row * C::LDC + wc + 16 * t + i] = acc[rt][t][r];
         }
       lds_barrier();
-      constexpr int PIECES = BM * (BN / 4);
-#pragma unroll 4
-      for (int idx = tid; idx < PIECES; idx += C::NT) {
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) {
+        const int idx = tid + C::NT * k;
         const int row = idx / (BN / 4), c4 = (idx - row * (BN / 4)) * 4;
         const int64_t r = e_r0 + row;
         const int c = e_n0 + c4;
         if (r < e_rend && c < d.N) {
           const int nv = d.N - c < 4 ? d.N - c : 4;
-          epi(r, c, ld4(Cs + row * C::LDC + c4), nv);
+          epi(r, c, ld4(Cs + row * C::LDC + c4), nv, pre[k]);
         }
       }
       if (more) {
