@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ULTR_ABI_VERSION 2
+#define ULTR_ABI_VERSION 3
 #define ULTR_MAX_HIDDEN 7 /* hidden layers; Linear layers = hidden + 1 <= 8 */
 
 #define ULTR_E_BADARG (-1)
@@ -264,6 +264,11 @@ typedef struct ultr_step_args {
   const float* uniforms; /* RegressionEM: [B, L] uniforms of the Bernoulli draw, or NULL = Philox(rng_seed, rng_step) */
   uint64_t rng_seed;
   uint64_t rng_step;
+  /* data parallel (ABI 3): with a communicator the call runs the WHOLE sharded step - backward, then ultr_comm_allreduce of
+   * grads[P + tail] (step number comm_step: the caller counts), then the update - instead of stopping for the host to issue
+   * the exchange and the update as two more calls (skip_update = 1 keeps that protocol for a process-group all-reduce). */
+  struct ultr_comm* comm;
+  uint64_t comm_step;
 } ultr_step_args;
 int ultr_train_step(const ultr_step_args* a, void* stream);
 

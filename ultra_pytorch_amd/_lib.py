@@ -41,7 +41,8 @@ class StepArgs(ctypes.Structure):
                 ("ipw_table", c_vp), ("scores", c_vp), ("dscores", c_vp), ("saved", c_vp), ("loss_ws", c_vp),
                 ("bwd_ws", c_vp), ("grads", c_vp), ("scalars", c_vp), ("n_docs", c_i64), ("n_ipw", c_i32),
                 ("batch", c_i32), ("list_size", c_i32), ("batch_total", c_i32), ("skip_update", c_i32), ("sigma", c_f32),
-                ("uniforms", c_vp), ("rng_seed", ctypes.c_uint64), ("rng_step", ctypes.c_uint64)]
+                ("uniforms", c_vp), ("rng_seed", ctypes.c_uint64), ("rng_step", ctypes.c_uint64),
+                ("comm", c_vp), ("comm_step", ctypes.c_uint64)]
 
 
 # name -> (restype, argtypes); must list EVERY symbol include/ultr_hip.h declares

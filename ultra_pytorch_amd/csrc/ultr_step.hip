@@ -8,6 +8,21 @@
 #include "ultr_plan.h"
 #include "ultr_prof.h"
 
+// behind the backward: (data parallel) the one-kernel exchange of grads[P + tail] with its sum-of-squares partials, then the
+// update - or stop for the caller (skip_update: it runs a process-group all-reduce + ultr_grad_sumsq + ultr_apply_update)
+static int finish_step(const ultr_step_args* a, void* stream) {
+  if (a->comm != nullptr && !a->skip_update) {
+    const int64_t P = ultr_dnn_param_count(a->desc);
+    if (P <= 0) return ULTR_E_BADARG;
+    const int64_t n = P + ultr_tail_len(a->list_size);
+    const int rc = ultr_comm_allreduce(a->comm, a->comm_step, a->grads, n, P, a->grads, a->bwd_ws, (int32_t)((n + 63) / 64), stream);
+    if (rc) return rc;
+  } else if (a->skip_update) {
+    return 0;
+  }
+  return ultr_apply_update(a->upd, a->desc, a->params, a->wt, a->state, a->grads, a->aux, a->bwd_ws, a->scalars, stream);
+}
+
 extern "C" int ultr_train_step(const ultr_step_args* a, void* stream) {
   if (!a || !a->desc || !a->upd) return ULTR_E_BADARG;
   ultr_prof_tick();
@@ -17,10 +32,7 @@ extern "C" int ultr_train_step(const ultr_step_args* a, void* stream) {
     rc = ultr_fused_step_softmax(a->desc, a->params, a->wt, a->features, a->n_docs, a->docids, a->batch, a->list_size,
                                  a->scores, a->saved, a->labels, a->pw, a->ipw_table, a->n_ipw, a->dscores, a->loss_ws,
                                  a->bwd_ws, a->grads, stream);
-    if (rc == 0) {
-      if (a->skip_update) return 0;
-      return ultr_apply_update(a->upd, a->desc, a->params, a->wt, a->state, a->grads, a->aux, a->bwd_ws, a->scalars, stream);
-    }
+    if (rc == 0) return finish_step(a, stream);
     if (rc != ULTR_E_UNSUPPORTED) return rc;
   }
   rc = ultr_dnn_forward(a->desc, a->params, a->wt, a->features, a->n_docs, a->docids, a->batch, a->list_size,
@@ -32,8 +44,8 @@ extern "C" int ultr_train_step(const ultr_step_args* a, void* stream) {
     rc = ultr_dnn_backward_softmax(a->desc, a->params, a->features, a->n_docs, a->docids, a->batch, a->list_size, a->saved,
                                    a->scores, a->labels, a->pw, a->ipw_table, a->n_ipw, a->dscores, a->loss_ws, a->bwd_ws,
                                    a->grads, stream);
-    if (rc || a->skip_update) return rc;
-    return ultr_apply_update(a->upd, a->desc, a->params, a->wt, a->state, a->grads, a->aux, a->bwd_ws, a->scalars, stream);
+    if (rc) return rc;
+    return finish_step(a, stream);
   }
   switch (a->upd->algo) {
     case ULTR_ALGO_DLA:
@@ -58,6 +70,6 @@ extern "C" int ultr_train_step(const ultr_step_args* a, void* stream) {
   if (rc) return rc;
   rc = ultr_dnn_backward(a->desc, a->params, a->features, a->n_docs, a->docids, a->batch, a->list_size, a->saved,
                          a->dscores, a->loss_ws, a->bwd_ws, a->grads, stream);
-  if (rc || a->skip_update) return rc;
-  return ultr_apply_update(a->upd, a->desc, a->params, a->wt, a->state, a->grads, a->aux, a->bwd_ws, a->scalars, stream);
+  if (rc) return rc;
+  return finish_step(a, stream);
 }

@@ -142,7 +142,10 @@ class StepEngine:
             a.grads, a.scalars = self.grads.data_ptr(), self.scalars.data_ptr()
             a.batch, a.list_size, a.batch_total = self.B, self.L, self.batch_total
             a.sigma = self.sigma
-            a.skip_update = 1 if self.pg is not None else 0
+            # data parallel: with the peer exchange the whole sharded step is still ONE C call (backward -> exchange kernel ->
+            # update); with the process group's all-reduce the call stops behind the backward and the host issues the rest
+            a.skip_update = 1 if (self.pg is not None and self.comm is None) else 0
+            a.comm = self.comm.h if self.comm is not None else None
             self._fn = self.shape.lib.ultr_train_step
         a.params = params.data_ptr()
         a.wt = hip_ops.weight_copy(self.shape).get(params).data_ptr()
@@ -158,8 +161,11 @@ class StepEngine:
             a.uniforms = uniforms.data_ptr() if uniforms is not None else None
             a.rng_seed, a.rng_step = self.rng_seed, self.rng_step
             self.rng_step += 1
+        if self.comm is not None:
+            a.comm_step = self.comm.step
+            self.comm.step += 1
         _lib.check(self._fn(ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ultr_train_step")
-        if self.pg is not None:
+        if self.pg is not None and self.comm is None:
             self.dp_reduce()
             self.update(params, state, aux)
         return self.scalars
