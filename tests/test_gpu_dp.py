@@ -101,10 +101,11 @@ def run_engine(algo, feats, ids, y, pg, uniforms):
     return out
 
 
-def worker(rank, world, port, mode, algo, q):
+def worker(rank, world, port, mode, algo, q, extra_env=None):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0", ULTR_DP_COMM=mode, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.update(extra_env or {})
     import torch
     import torch.distributed as dist
     from ultra_pytorch_amd import parallel
@@ -230,6 +231,27 @@ def test_more_ranks_peer_exchange(world, algo):
         np.testing.assert_allclose(res["losses"], one["losses"], rtol=1e-5, atol=1e-6)
         if res["aux"] is not None:
             np.testing.assert_allclose(res["aux"], one["aux"], atol=2e-6)
+
+
+@pytest.mark.parametrize("mode", ["peer", "pg"])
+def test_forced_data_parallel_world1_equals_plain_step(mode):
+    """ULTR_FORCE_DP=1 with one rank (what profiles/r02_cfg2_forced_dp_world1_bench.json measures): the data-parallel step -
+    ONE C call that queues backward -> exchange kernel -> update (peer), or backward | all-reduce | sumsq | update (pg) - must
+    leave exactly the parameters of the plain single-GPU step (the exchange with W = 1 is a copy; same kernels otherwise)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    proc = ctx.Process(target=worker, args=(0, 1, 29790 + (0 if mode == "peer" else 1), mode, "softmax", q, {"ULTR_FORCE_DP": "1"}))
+    proc.start()
+    rank, res = q.get(timeout=300)
+    proc.join(120)
+    assert proc.exitcode == 0 and rank == 0
+    one, _ = single_process("softmax")
+    assert res["status"] == 0 and res["peer"] == (mode == "peer") and res["batch_total"] == B
+    np.testing.assert_allclose(res["losses"], one["losses"], rtol=1e-6, atol=1e-7)
+    gmax = np.abs(one["params"]).max()
+    np.testing.assert_allclose(res["params"], one["params"], rtol=2e-6, atol=2e-7 * gmax)
+    np.testing.assert_allclose(res["state"], one["state"], rtol=2e-5, atol=1e-10)
 
 
 def test_peer_comm_world1_matches_grad_sumsq():
