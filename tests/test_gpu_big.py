@@ -99,6 +99,35 @@ def test_big_path_train_steps_match_row_tile_path(algo, monkeypatch):
     np.testing.assert_allclose(a["losses"][:n], b["losses"][:n], rtol=2e-5, atol=1e-6)
 
 
+def test_xhat0_marker_follows_the_forward_that_ran(monkeypatch):
+    """A per-layer forward over a wide gathered input (K_0 > 512) leaves xhat_0 in saved.x_0 and says so in the marker word
+    behind the saved activations; the weight-gradient launch then contracts layer 0 with it instead of gathering and
+    normalising again.  Every forward writes the marker: switch the SAME engine (same `saved` buffer) between the two
+    forwards and the gradients must stay right both ways."""
+    from oracle import ultr_oracle as O
+    from ultra_pytorch_amd import _lib
+    F, hidden, B, L = 700, [512, 256, 128], 37, 9
+    feats, ids, labels = synth(F, B, L, 5)
+    rng = np.random.RandomState(9)
+    params = perturbed_params(O, F, hidden, rng)
+    ds = rng.normal(size=(B, L)).astype(np.float32)
+    p = torch.tensor(params, requires_grad=True)
+    ref = O.ranking_scores(p, F, hidden, feats, ids)
+    (gref,) = torch.autograd.grad((ref * torch.tensor(ds)).sum(), p)
+    gref = gref.numpy()
+    monkeypatch.setenv("ULTR_BIG_BWD", "0")
+    monkeypatch.setenv("ULTR_BIG_FWD", "2")
+    run = HipRun(F, hidden, B, L)
+    run.set_inputs(feats, ids, labels)
+    for mode in ("2", "0", "2", "0"):
+        monkeypatch.setenv("ULTR_BIG_FWD", mode)
+        _lib.load().ultr_config_reload()
+        scores = run.forward(params)
+        np.testing.assert_allclose(scores, ref.detach().numpy(), atol=1e-5, rtol=1e-5)
+        g, _ = run.backward(dscores=ds)
+        np.testing.assert_allclose(g, gref, rtol=2e-5, atol=2e-6 * max(1.0, float(np.abs(gref).max())), err_msg="forward mode " + mode)
+
+
 def test_big_path_is_deterministic(monkeypatch):
     """Fixed-order partial sums everywhere: two runs give bit-identical gradients."""
     from oracle import ultr_oracle as O

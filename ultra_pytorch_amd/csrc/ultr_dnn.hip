@@ -523,6 +523,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave: SGPR
   const int64_t n0 = (int64_t)blockIdx.x * R;
   const int rows_valid = (int)((N - n0) < R ? (N - n0) : R);
+  if (saved != nullptr && blockIdx.x == 0 && tid == 0) saved[p.sv_total] = 0.f;  // marker: saved.x_0 does NOT hold xhat_0
   TRACE_STAMP(0);
 
   // LayerNorm gamma/beta, biases and the scorer's weight row go to LDS up front, overlapped with the feature
@@ -2107,7 +2108,10 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
   if (nend > N) nend = N;
 
   const Src dz = make_src(ws + wl.dz_off, N * M);
-  const bool prenorm = bp.wg_prenorm != 0;  // `saved` holds the ready-made operand (also for layer 0: no ids, no gather)
+  // `saved` holds the ready-made operand (no ids, no gather, no transform): every layer after the fused kernel (wg_prenorm);
+  // layer 0 alone after a per-layer forward that wrote xhat_0 (it says so in the marker word behind the saved activations -
+  // every forward writes that word, so the two calls cannot disagree)
+  const bool prenorm = bp.wg_prenorm != 0 || (VEC && j == 0 && bp.l0g != 0 && saved[p.sv_total] != 0.f);
   const Src xs = (j == 0 && !prenorm) ? make_src(features, n_docs * K) : make_src(saved + p.sv_x[j], N * K);
   const Src meansrc = make_src(saved + p.sv_mean[j], N);
   const Src rstdsrc = make_src(saved + p.sv_rstd[j], N);
@@ -2780,13 +2784,35 @@ extern "C" int ultr_dnn_build_wt(const ultr_dnn_desc* d, const float* params, fl
 
 // Which shapes take the per-layer path (ultr_dnn_big.hip) instead of the row-tile kernels below; mode = the knob (0 never,
 // 1 the measured rule, 2 whenever legal).  Measured ("big-batch path"; us, row-tile -> per-layer):
-//   forward   never faster: config 4 220 -> 240, config 3 85 -> 120, 81 920 rows x [256,256] 258 -> 297 (the tiled GEMM core
-//             runs at 63-85 TFLOP/s, the row-tile forward at 61-70 with no activation round trips) - only when the row-tile
-//             kernel's LDS footprint does not fit;
+//   forward   slower in general: config 3 85 -> 120, 81 920 rows x [256,256] 258 -> 297 (the tiled GEMM core runs at 63-85
+//             TFLOP/s, the row-tile forward at 61-70 with no activation round trips) - taken when the row-tile kernel's LDS
+//             footprint does not fit, and in the case big_fwd_wanted describes (config 4: 220 -> 210);
 //   backward  wins when dnn_bwd2_kernel does not apply (a layer wider than 512: config 4 128 -> 85) and for big batches
 //             (81 920 x [256,256] 202 -> 182, 163 840 x [512,256,128] 980 -> 830); a tie at config 3 (10 240 rows: 74 / 74).
-static bool big_fwd_wanted(const DnnPlan&, int64_t) {
-  return knobs().big_fwd >= 2;
+static int dnn_device_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+  }
+  return cus;
+}
+// The one case where the per-layer forward wins: a wide gathered input (K_0 > 512: the statistics pass then writes xhat_0
+// contiguously and the first GEMM reads plain rows, ultr_dnn_big.hip) AND both staircases line up - the row tiles would
+// run >= 3 full rounds of resident workgroups plus a last round less than a quarter full (their time is a staircase in the
+// tile count: config 4 = 800 tiles of a one-per-CU workgroup: 172 us at 750 tiles, 221 us at 800), while the first GEMM's
+// 64 x 128 chunks still fit about one round of ITS resident workgroups (3 per CU).  Measured, row tiles -> per-layer (us),
+// F700 [512,256,128]: 257 tiles 111 -> 133 (fixed cost of seven launches), 750 tiles 176 -> 193, 800 tiles 221 -> 209,
+// 938 tiles 224 -> 215, 1063 tiles 274 -> 281 (the GEMM's own second round).
+static bool big_fwd_wanted(const DnnPlan& p, int64_t N, size_t row_tile_lds) {
+  if (knobs().big_fwd != 1) return knobs().big_fwd >= 2;
+  if (p.K[0] <= 512 || p.nl < 2) return false;
+  const int cus = dnn_device_cus();
+  const int per_cu = row_tile_lds > 80 * 1024 ? 1 : (row_tile_lds > 53 * 1024 ? 2 : 3);
+  const int64_t slots = (int64_t)per_cu * cus, tiles = (N + 15) / 16, full = tiles / slots, rem = tiles % slots;
+  const int64_t chunks0 = ((N + 63) / 64) * ((p.M[0] + 127) / 128), gslots = 3 * (int64_t)cus;
+  return full >= 3 && rem != 0 && rem * 4 <= slots && chunks0 <= gslots + gslots / 8;
 }
 static bool big_bwd_wanted(const DnnPlan& p, int64_t N) {
   const int mode = knobs().big_bwd;
@@ -2823,7 +2849,7 @@ extern "C" int ultr_dnn_forward(const ultr_dnn_desc* d, const float* params, con
                   ((uintptr_t)wt & 15) == 0;
   // training forward of a big batch: one pass per layer (needs `saved` for the activations between the passes)
   if (saved != nullptr && wt != nullptr && av && ultr_dnn_big_ok(p, N, n_docs) &&
-      knobs().big_fwd != 0 && (big_fwd_wanted(p, N) || lds > 160 * 1024))
+      knobs().big_fwd != 0 && (big_fwd_wanted(p, N, lds) || lds > 160 * 1024))
     return ultr_dnn_big_forward(p, params, wt, features, n_docs, docids, (int)batch, (int)list_size, scores, (float*)saved, st,
                                 prof.on ? prof.a : nullptr, prof.on ? prof.b : nullptr);
   if (lds > 160 * 1024) return ULTR_E_UNSUPPORTED;

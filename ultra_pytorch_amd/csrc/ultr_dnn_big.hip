@@ -39,8 +39,11 @@ __global__ __launch_bounds__(256) void big_rowstats_kernel(const float* __restri
                                                            int64_t n_docs, int B, int L, int64_t N, int K, float* __restrict__ mean_out,
                                                            float* __restrict__ rstd_out, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ wlast,
-                                                           const float* __restrict__ blast, float* __restrict__ scores) {
+                                                           const float* __restrict__ blast, float* __restrict__ scores,
+                                                           float* __restrict__ xhat_out, float* __restrict__ marker) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // layer 0's pass tells the weight-gradient launch whether saved.x_0 holds xhat_0 (DnnPlan::sv_total: the marker word)
+  if (marker != nullptr && blockIdx.x == 0 && threadIdx.x == 0) marker[0] = xhat_out != nullptr ? 1.0f : 0.0f;
   const Src xs = make_src(x, x_rows * K);
   const float invK = 1.0f / (float)K;
   const bool top = scores != nullptr;
@@ -87,6 +90,13 @@ __global__ __launch_bounds__(256) void big_rowstats_kernel(const float* __restri
       if (top) t += (v[u].x * gw[u].x + v[u].y * gw[u].y) + (v[u].z * gw[u].z + v[u].w * gw[u].w);
     }
     const float rstd = rsqrt_nr(wave_sum(q) * invK + ULTR_LN_EPS);
+    if (xhat_out != nullptr) {  // the normalised row, contiguous: the layer's GEMM (and nothing else) reads it back
+#pragma unroll
+      for (int u = 0; u < XC; ++u) {
+        const int c = 4 * lane + 256 * u;
+        if (c < K) st4(xhat_out + r * K + c, make_float4(v[u].x * rstd, v[u].y * rstd, v[u].z * rstd, v[u].w * rstd));
+      }
+    }
     if (top) t = wave_sum(t);
     if (lane == 0) {
       mean_out[r] = mean;
@@ -207,12 +217,12 @@ hipError_t big_set_lds(Kern k, size_t bytes) {
 
 struct StatsArgs {
   const float* x; int64_t x_rows; const int32_t* ids; int64_t n_docs; int B, L; int64_t N; int K;
-  float *mean, *rstd; const float *gamma, *beta, *wlast, *blast; float* scores;
+  float *mean, *rstd; const float *gamma, *beta, *wlast, *blast; float* scores; float* xhat_out; float* marker;
 };
 template <int XC>
 void stats_launch(const StatsArgs& a, unsigned blocks, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
   BIG_LAUNCH(big_rowstats_kernel<XC>, dim3(blocks), 0, st, ea, eb, a.x, a.x_rows, a.ids, a.n_docs, a.B, a.L, a.N, a.K, a.mean, a.rstd,
-             a.gamma, a.beta, a.wlast, a.blast, a.scores);
+             a.gamma, a.beta, a.wlast, a.blast, a.scores, a.xhat_out, a.marker);
 }
 void stats_dispatch(const StatsArgs& a, unsigned blocks, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
   const int xc = (a.K + 255) / 256;
@@ -272,11 +282,25 @@ int ultr_dnn_big_forward(const DnnPlan& p, const float* params, const float* wt,
     float* mean = saved + p.sv_mean[j];
     float* rstd = saved + p.sv_rstd[j];
     const bool last = (j == top);
+    // wide gathered input (config 4: 700 features): the statistics pass also writes the normalised rows xhat_0 contiguously
+    // (saved.x_0 is free in this mode) and the GEMM applies gamma / beta to plain rows - the LayerNorm + gather producer
+    // costs the first GEMM a third (145 vs 108 us there)
+    const bool pre0 = (j == 0) && !last && K > 512;
+    float* xhat0 = pre0 ? saved + p.sv_x[0] : nullptr;
     const StatsArgs sa{x, x_rows, ids, n_docs, B, L, N, K, mean, rstd, params + p.off_lnw[j], params + p.off_lnb[j],
-                       last ? params + p.off_w[j] : nullptr, last ? params + p.off_b[j] : nullptr, last ? scores : nullptr};
+                       last ? params + p.off_w[j] : nullptr, last ? params + p.off_b[j] : nullptr, last ? scores : nullptr, xhat0,
+                       j == 0 ? saved + p.sv_total : nullptr};
     stats_dispatch(sa, rblocks, st, j == 0 ? ev_start : nullptr, last ? ev_stop : nullptr);
     if (last) break;
     const int M = p.M[j];
+    if (pre0) {
+      const ugemm::AAffine a{xhat0, params, N, p.P, p.off_lnw[j], p.off_lnb[j], K};
+      const ugemm::Dims d0{N, M, K, M};
+      const ugemm::EBiasAct e0{saved + p.sv_x[j + 1], params + p.off_b[j], M, p.act};
+      const hipError_t rc0 = ugemm::run<false>(d0, a, wt + p.wt_off[j], e0, st);
+      if (rc0 != hipSuccess) return (int)rc0;
+      continue;
+    }
     ugemm::ALayerNorm a;
     a.x = x;
     a.gb = params;

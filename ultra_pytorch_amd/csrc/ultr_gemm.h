@@ -126,6 +126,37 @@ struct ALayerNorm {
   }
 };
 
+// x * gamma[k] + beta[k] on consecutive rows (x = an already normalised input, e.g. xhat_0 written by the statistics pass):
+// no per-row operands, no gather
+struct AAffine {
+  const float* x;   // [R][K]
+  const float* gb;  // the flat parameter vector (gamma at g_off, beta at b_off), gb_floats long
+  int64_t R, gb_floats, g_off, b_off;
+  int K;
+  struct Row { unsigned off; bool in; };
+  struct Cols { float4 g, b; };
+  __device__ __forceinline__ Row row(int64_t r, int64_t rend) const {
+    Row c;
+    c.in = r < rend;
+    c.off = c.in ? (unsigned)(r * K * 4) : ULTR_OOB;
+    return c;
+  }
+  __device__ __forceinline__ float4 raw(const Row& c, int k) const {
+    return buf_ld4(make_src(x, R * K), (c.off != ULTR_OOB && k < K) ? c.off + (unsigned)k * 4u : ULTR_OOB);
+  }
+  __device__ __forceinline__ Cols cols(int k) const {
+    Cols o;
+    const Src g = make_src(gb, gb_floats);
+    o.g = buf_ld4(g, k < K ? (unsigned)((g_off + k) * 4) : ULTR_OOB);
+    o.b = buf_ld4(g, k < K ? (unsigned)((b_off + k) * 4) : ULTR_OOB);
+    return o;
+  }
+  __device__ __forceinline__ float4 finish(const Row& c, const Cols& o, int, float4 v) const {
+    const float m = c.in ? 1.f : 0.f;
+    return make_float4(v.x * o.g.x + m * o.b.x, v.y * o.g.y + m * o.b.y, v.z * o.g.z + m * o.b.z, v.w * o.g.w + m * o.b.w);
+  }
+};
+
 // ---- epilogues: called with the global row, the first of four consecutive columns (all < N unless noted) -------------
 // y = act(c + bias); act: -1 none, 0 elu, 1 relu.  n_valid = columns of this piece that exist (1..4)
 struct EBiasAct {
