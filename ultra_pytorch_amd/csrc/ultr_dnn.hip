@@ -2360,8 +2360,8 @@ __device__ __forceinline__ float block_sum_256(float v, float* sm) {
 }
 
 // ONE = a thread folds all partials of its element (full_sum: the same bits as the four cooperating groups of strided_sum),
-// 256 elements per workgroup: a quarter of the workgroups for the same work - the launch is latency-bound when there are few
-// slabs (config 2: 8 per layer, 1600 -> 400 workgroups).  Sum-of-squares partials keep their geometry (one per 64 elements).
+// 256 elements per workgroup: a quarter of the workgroups for the same work when there are at most 32 slabs per segment
+// (config 2: 1600 -> 400 workgroups, no change in time; config 4: 11.9 -> 8.8 us).  Sum-of-squares partials keep their geometry (one per 64 elements).
 template <bool ONE>
 __global__ __launch_bounds__(256) void grad_reduce_kernel(RedPlan rp, int64_t P, int tail, const float* __restrict__ ws,
                                                           const float* __restrict__ loss_part, int n_loss_part,
@@ -2389,7 +2389,12 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(RedPlan rp, int64_t P,
       g = full_sum(ws + sg.base + (e - sg.off), sg.stride, sg.nparts);
       grads[e] = g;
     }
-    const float sq = wave_sum(g * g);
+    // the product must be ROUNDED before the first cross-lane add: left alone (and with __fmul_rn as well) hipcc turns
+    // `g * g + shuffled(g * g)` into an fma in this variant and not in the other - one-ulp different partials, a different clip
+    // coefficient, forked trajectories.  The empty asm makes the product opaque.
+    float gg = g * g;
+    asm volatile("" : "+v"(gg));
+    const float sq = wave_sum(gg);
     const int k = (int)blockIdx.x * 4 + grp;
     if (lane == 0 && k < nsq) sumsq_part[k] = sq;
     return;
@@ -2407,7 +2412,9 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(RedPlan rp, int64_t P,
   if (grp == 0) {
     const float g = ((sm[0][lane] + sm[1][lane]) + sm[2][lane]) + sm[3][lane];
     if (e < P) grads[e] = g;
-    const float sq = wave_sum(e < P ? g * g : 0.f);
+    float gg = e < P ? g * g : 0.f;
+    asm volatile("" : "+v"(gg));
+    const float sq = wave_sum(gg);
     if (lane == 0) sumsq_part[blockIdx.x] = sq;
   }
 }
@@ -2993,7 +3000,7 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
   UltrProfScope prof(ULTR_K_REDUCE, st);
   int maxparts = 1;
   for (int k = 0; k < rp.nseg; ++k) maxparts = rp.seg[k].nparts > maxparts ? rp.seg[k].nparts : maxparts;
-  if (maxparts <= 16)
+  if (maxparts <= 32)
     ULTR_LAUNCH(prof, grad_reduce_kernel<true>, dim3((nblk + 3) / 4 + (bp.lf_chunks > 0 ? 1 : 0)), dim3(256), 0, st, rp, p.P, tail,
                 (const float*)ws, (const float*)(ws + bp.lfold_off), bp.lf_chunks, grads, ws + bp.sumsq_off, nblk);
   else
