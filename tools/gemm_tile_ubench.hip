@@ -81,6 +81,19 @@ int main(int argc, char** argv) {
     bench<false, 256, 128, 4, 2>(16384, 4096, 512);
     return 0;
   }
+  if (argc > 1 && argv[1][0] == 'q') {  // config 4's first GEMM: tile shapes against the 800-chunks-on-768-slots imbalance
+    bench<false, 64, 128, 4, 2>(12800, 700, 512);
+    bench<false, 128, 128, 4, 2>(12800, 700, 512);
+    bench<false, 128, 128, 2, 2>(12800, 700, 512);
+    bench<false, 256, 128, 4, 2>(12800, 700, 512);
+    bench<false, 64, 128, 4, 2>(12800, 512, 256);
+    bench<false, 128, 128, 4, 2>(12800, 512, 256);
+    bench<false, 64, 64, 4, 1>(12800, 512, 256);
+    bench<false, 64, 128, 4, 2>(12800, 256, 128);
+    bench<false, 64, 64, 4, 1>(12800, 256, 128);
+    bench<false, 128, 64, 8, 1>(12800, 256, 128);
+    return 0;
+  }
   if (argc > 1 && argv[1][0] == 'o') {  // balanced for 512 resident workgroups (2 per CU) and for 768 (3 per CU)
     bench<false, 64, 128, 4, 2>(8192, 4096, 512);
     bench<false, 64, 128, 4, 2>(16384, 704, 512);
