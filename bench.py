@@ -499,7 +499,11 @@ def main():
                        "feature_size": F, "hidden": HIDDEN, "parallelism": "dp%d" % world, "params": P},
             "roofline": {"kernel": kname, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source,
-                         "avg_launch_us": 1e6 * dom_s, "launches_timed": dom_samples, "algorithmic_per_launch": amount},
+                         "avg_launch_us": 1e6 * dom_s, "launches_timed": dom_samples, "algorithmic_per_launch": amount,
+                         "stage_note": ("the forward / backward slots are STAGES: dnn_fwd_kernel / dnn_bwd2_kernel, or - where the "
+                                        "launcher's measured rule sends the shape (config 4: both) - the per-layer launches of "
+                                        "ultr_dnn_big.hip (statistics passes + tiled GEMMs), one sample = first launch's start to last "
+                                        "launch's stop") if dnn else None},
             "step_tflops": flops / (1e-3 * ms_step) / 1e12, "step_frac_of_fp32_mfma_peak": flops / (1e-3 * ms_step) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
             "kernel_us": {KNAMES[k]: round(cal_us[k], 3) for k in KSLOTS if cal_cnt[k] > 0} if dnn else {},
             "kernel_us_source": "calibration pass in front of the timed region (all kernel timers armed); roofline.avg_launch_us is "
