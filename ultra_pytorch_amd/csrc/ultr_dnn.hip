@@ -2652,10 +2652,19 @@ bool ultr_make_bwd_plan(const DnnPlan& p, int64_t N, BwdPlan* bp) {
     w.nmb = (w.M + 63) / 64; w.nkb = (w.K + 63) / 64;
     int nsplit = tiles > 0 ? (target + tiles - 1) / tiles : 1;
     if (nsplit < 1) nsplit = 1;
+    const int by_cap = (int)((N + 4095) / 4096);  // the doc-id table of a split lives in LDS: at most 4096 rows
+    if (nsplit < by_cap) nsplit = by_cap;
+    // XCD-friendly split count.  Blocks are numbered split-fastest and consecutive block ids go round-robin to the 8 XCDs, so
+    // with nsplit a divisor or a multiple of 8 each XCD works on ONE row chunk of a layer at a time and the blocks that
+    // re-read the same dz / x rows (every 64 x 64 tile of that chunk) meet in one L2.  Misaligned counts fetch every operand
+    // once per tile from HBM: config 4 (rocprofv3) 311 MB per launch at nsplit = 4, 115 us - nsplit 3 / 5: 154 / 158 us;
+    // config 3 at nsplit = 7: 342 MB for 74 MB of operands, HBM-bound at 5.6 TB/s.
+    if (knobs().wgrad_wgs <= 0) nsplit = nsplit <= 1 ? 1 : nsplit <= 2 ? 2 : nsplit <= 5 ? 4 : nsplit <= 11 ? 8 : (nsplit + 4) / 8 * 8;
+    if (nsplit < by_cap) nsplit = (by_cap + 7) / 8 * 8;
     int64_t rps = (N + nsplit - 1) / nsplit;
     rps = (rps + 31) / 32 * 32;  // 8 rows per wave-trip
     if (rps < 64) rps = 64;
-    if (rps > 4096) rps = 4096;  // the doc-id table of a split lives in LDS
+    if (rps > 4096) rps = 4096;
     w.rows_per_split = (int)rps;
     w.nsplit = (int)((N + rps - 1) / rps);
     w.blk_begin = blk;
