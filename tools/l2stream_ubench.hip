@@ -15,7 +15,7 @@
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-template <int V, int NW, int U>
+template <int V, int NW, int U, int AUX = 0>
 __global__ __launch_bounds__(NW * 64) void stream_kernel(const float* __restrict__ W, int nfloats, int rowlen, int reps,
                                                          float* __restrict__ out, unsigned long long* __restrict__ cyc) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -39,10 +39,10 @@ __global__ __launch_bounds__(NW * 64) void stream_kernel(const float* __restrict
             const int row = m0 + 4 * q + (u & 3) + 16 * (u >> 2);
             const unsigned off = ((unsigned)row * rowlen + col) * 4u;
             if constexpr (V == 0) {
-              const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0);
+              const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, AUX);
               acc += __uint_as_float(v.x) + __uint_as_float(v.y);
             } else {
-              const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+              const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, AUX);
               acc += __uint_as_float(v.x) + __uint_as_float(v.w);
             }
           }
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(NW * 64) void stream_kernel(const float* __restrict
         for (int u = 0; u < U; ++u) {
           const unsigned off = (unsigned)(o + u * per_wave_instr + lane * BPL);
           if constexpr (V == 2) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, AUX);
             acc += __uint_as_float(v.x) + __uint_as_float(v.w);
           } else {
             acc += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
@@ -86,19 +86,19 @@ __global__ __launch_bounds__(NW * 64) void stream_kernel(const float* __restrict
   out[blockIdx.x * NW * 64 + tid] = acc;
 }
 
-template <int V, int NW, int U>
+template <int V, int NW, int U, int AUX = 0>
 void run(const char* name, const float* dW, int nfloats, int rowlen, int G, float* dout, unsigned long long* dcyc) {
   const int reps = 100;
   const size_t lds = (V == 3) ? (size_t)NW * U * 1024 : 0;
   if (lds > 64 * 1024)
-    hipFuncSetAttribute(reinterpret_cast<const void*>(stream_kernel<V, NW, U>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(stream_kernel<V, NW, U, AUX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  hipLaunchKernelGGL((stream_kernel<V, NW, U>), dim3(G), dim3(NW * 64), lds, 0, dW, nfloats, rowlen, 2, dout, dcyc);
+  hipLaunchKernelGGL((stream_kernel<V, NW, U, AUX>), dim3(G), dim3(NW * 64), lds, 0, dW, nfloats, rowlen, 2, dout, dcyc);
   hipDeviceSynchronize();
   hipEventRecord(e0, 0);
-  hipLaunchKernelGGL((stream_kernel<V, NW, U>), dim3(G), dim3(NW * 64), lds, 0, dW, nfloats, rowlen, reps, dout, dcyc);
+  hipLaunchKernelGGL((stream_kernel<V, NW, U, AUX>), dim3(G), dim3(NW * 64), lds, 0, dW, nfloats, rowlen, reps, dout, dcyc);
   hipEventRecord(e1, 0);
   hipDeviceSynchronize();
   float ms = 0;
@@ -115,6 +115,7 @@ void run(const char* name, const float* dW, int nfloats, int rowlen, int G, floa
 
 int main(int argc, char** argv) {
   const int G = argc > 1 ? atoi(argv[1]) : 256;
+  const bool policy = argc > 2;  // cache-policy sweep (aux bits of the buffer loads: 1 sc0, 2 nt, 16 sc1)
   const int rowlen = 256, nrows = 256, nfloats = rowlen * nrows;  // 256 KB: one 256x256 layer
   std::vector<float> h(nfloats);
   for (int i = 0; i < nfloats; ++i) h[i] = 0.001f * (float)(i % 101);
@@ -124,6 +125,27 @@ int main(int argc, char** argv) {
   hipMalloc(&dout, (size_t)G * 1024 * sizeof(float));
   hipMalloc(&dcyc, G * sizeof(unsigned long long));
   hipMemcpy(dW, h.data(), nfloats * sizeof(float), hipMemcpyHostToDevice);
+  if (policy) {
+    run<0, 8, 8, 0>("V0 dwordx2 4 rows  aux 0", dW, nfloats, rowlen, G, dout, dcyc);
+    run<0, 8, 8, 1>("V0 dwordx2 4 rows  aux sc0", dW, nfloats, rowlen, G, dout, dcyc);
+    run<0, 8, 8, 2>("V0 dwordx2 4 rows  aux nt", dW, nfloats, rowlen, G, dout, dcyc);
+    run<0, 8, 8, 16>("V0 dwordx2 4 rows  aux sc1", dW, nfloats, rowlen, G, dout, dcyc);
+    run<0, 8, 8, 17>("V0 dwordx2 4 rows  aux sc0 sc1", dW, nfloats, rowlen, G, dout, dcyc);
+    run<0, 8, 8, 18>("V0 dwordx2 4 rows  aux nt sc1", dW, nfloats, rowlen, G, dout, dcyc);
+    run<0, 8, 8, 3>("V0 dwordx2 4 rows  aux sc0 nt", dW, nfloats, rowlen, G, dout, dcyc);
+    run<1, 4, 8, 0>("V1 dwordx4 4 rows  aux 0", dW, nfloats, rowlen, G, dout, dcyc);
+    run<1, 4, 8, 1>("V1 dwordx4 4 rows  aux sc0", dW, nfloats, rowlen, G, dout, dcyc);
+    run<1, 4, 8, 2>("V1 dwordx4 4 rows  aux nt", dW, nfloats, rowlen, G, dout, dcyc);
+    run<1, 4, 8, 16>("V1 dwordx4 4 rows  aux sc1", dW, nfloats, rowlen, G, dout, dcyc);
+    run<1, 4, 8, 17>("V1 dwordx4 4 rows  aux sc0 sc1", dW, nfloats, rowlen, G, dout, dcyc);
+    run<1, 4, 8, 18>("V1 dwordx4 4 rows  aux nt sc1", dW, nfloats, rowlen, G, dout, dcyc);
+    run<2, 8, 8, 0>("V2 dwordx4 1KiB  aux 0", dW, nfloats, rowlen, G, dout, dcyc);
+    run<2, 8, 8, 1>("V2 dwordx4 1KiB  aux sc0", dW, nfloats, rowlen, G, dout, dcyc);
+    run<2, 8, 8, 2>("V2 dwordx4 1KiB  aux nt", dW, nfloats, rowlen, G, dout, dcyc);
+    run<2, 8, 8, 16>("V2 dwordx4 1KiB  aux sc1", dW, nfloats, rowlen, G, dout, dcyc);
+    run<2, 8, 8, 17>("V2 dwordx4 1KiB  aux sc0 sc1", dW, nfloats, rowlen, G, dout, dcyc);
+    return 0;
+  }
   run<0, 8, 8>("V0 dwordx2 16x8B x4rows (CT=2)", dW, nfloats, rowlen, G, dout, dcyc);
   run<0, 8, 16>("V0 dwordx2 16x8B x4rows (CT=2)", dW, nfloats, rowlen, G, dout, dcyc);
   run<0, 8, 32>("V0 dwordx2 16x8B x4rows (CT=2)", dW, nfloats, rowlen, G, dout, dcyc);
