@@ -523,7 +523,11 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave: SGPR
   const int64_t n0 = (int64_t)blockIdx.x * R;
   const int rows_valid = (int)((N - n0) < R ? (N - n0) : R);
-  if (saved != nullptr && blockIdx.x == 0 && tid == 0) saved[p.sv_total] = 0.f;  // marker: saved.x_0 does NOT hold xhat_0
+  // marker word behind the saved activations: does saved.x_0 hold xhat_0 for the weight-gradient launch?  (the LayerNorm fast
+  // path below writes it for inputs up to 256 wide; the launch then contracts layer 0 with it instead of gathering by id and
+  // normalising again)
+  const bool write_xhat0 = saved != nullptr && p.nl >= 2 && p.K[0] <= 256;
+  if (saved != nullptr && blockIdx.x == 0 && tid == 0) saved[p.sv_total] = write_xhat0 ? 1.f : 0.f;
   TRACE_STAMP(0);
 
   // LayerNorm gamma/beta, biases and the scorer's weight row go to LDS up front, overlapped with the feature
@@ -715,6 +719,14 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
             for (int k = 0; k < 4; ++k) {
               const int c = lane + 64 * k;
               if (c < K16) row[c] = x[q][k] * rstd * g[k] + be[k];  // c in [K, K16): 0 * rstd * 0 + 0 = 0 (zero padding)
+            }
+            if (j == 0 && write_xhat0 && n0 + r < N) {
+              float* xh = saved + p.sv_x[0] + (n0 + r) * K;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const int c = lane + 64 * k;
+                if (c < K) xh[c] = x[q][k] * rstd;
+              }
             }
           }
           if (lane == 0 && n0 + r < N) {
