@@ -30,6 +30,19 @@ def test_library_exports_every_declared_symbol():
     assert _lib.load().ultr_abi_version() == 3
 
 
+def test_header_is_plain_c(tmp_path):
+    """include/ultr_hip.h is the drop-in boundary: it must compile as C99 (no torch / C++ types in any signature) and as C++."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi.c"
+    src.write_text('#include "include/ultr_hip.h"\nint main(void) { ultr_step_args a; ultr_setrank_desc s; (void)a; (void)s; return ULTR_ABI_VERSION; }\n')
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", root, str(src)])
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", "-I", root, str(src)])
+
+
 def test_host_only_queries_match_reference_layout():
     from oracle import ultr_oracle as O
     from ultra_pytorch_amd import hip_ops
