@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ULTR_ABI_VERSION 3
+#define ULTR_ABI_VERSION 4
 #define ULTR_MAX_HIDDEN 7 /* hidden layers; Linear layers = hidden + 1 <= 8 */
 
 #define ULTR_E_BADARG (-1)
@@ -46,7 +46,9 @@ extern "C" {
 #define ULTR_E_WORKSPACE (-3)
 #define ULTR_E_COMM_TIMEOUT (-4) /* a peer did not arrive within the bounded wait of ultr_comm_allreduce */
 
-enum ultr_activation { ULTR_ACT_ELU = 0, ULTR_ACT_RELU = 1 };
+/* base_ranking_model.py:63-69 (ACT_FUNC_DIC): elu, relu, tanh, sigmoid.  ('selu' is listed there as a plain function and
+ * nn.Sequential.add_module rejects it - TypeError at DNN.py:52-53 - so it is not an option of the reference.) */
+enum ultr_activation { ULTR_ACT_ELU = 0, ULTR_ACT_RELU = 1, ULTR_ACT_TANH = 2, ULTR_ACT_SIGMOID = 3 };
 
 /* DNN.__init__ hyper-parameters (DNN.py:25-38).  norm is always 'layer'
  * (LayerNorm before EVERY Linear, DNN.py:43-47). */
@@ -217,7 +219,23 @@ typedef struct ultr_update_desc {
   float propensity_learning_rate; /* DLA */
   float em_step_size;      /* PairDebias / LambdaRank */
   float regulation_p;      /* PairDebias / LambdaRank */
-  float reserved;
+  /* l2_loss hyper-parameter (ipw_rank.py:154-157, navie_algorithm.py:109-114, pairwise_debias.py:166-169,
+   * regression_EM.py:166-169, dla.py:146-150): loss += l2_loss * sum_p ||p||^2 / 2 over the ranking model's parameters, i.e.
+   * g += l2_loss * p.  As in the reference, l2_loss > 0 DISABLES the gradient clip for every algorithm but DLA (the
+   * `params` generator handed to clip_grad_norm_ is already exhausted by the L2 loop); DLA adds the term
+   * to rank_loss (so it is scaled by ranker_loss_weight) and clips the full gradient. */
+  float l2_loss;
+  /* ---- ABI 4: per-step reporting / safety (all optional) ----
+   * guard: device word; when it is non-zero at launch the update changes NOTHING (parameters, optimizer state, aux stay as
+   *   they are) - ultr_train_step points it at the communicator's status word, so a rank whose gradient exchange timed
+   *   out (or that was told so by a peer) never applies a partly reduced gradient.
+   * host_scalars: 16 floats of HOST-mapped pinned memory (device-accessible pointer): block 0 writes scalars_out[0..8) to
+   *   [0..8), then the guard word to [8] and `seq` to [9] (as uint32, system-scope stores, seq LAST).  The host reads the
+   *   loss by spinning on [9] == seq instead of a stream synchronisation + device-to-host copy (the reference's loss.item()). */
+  const uint32_t* guard;
+  float* host_scalars;
+  uint32_t seq;
+  uint32_t pad_;
 } ultr_update_desc;
 
 /* params/state [P] updated in place; grads = the buffer ultr_dnn_backward filled (possibly
@@ -225,8 +243,9 @@ typedef struct ultr_update_desc {
  * LambdaRank), updated in place; NULL for SOFTMAX.  d + wt (both may be NULL): keep the k-major weight copy
  * in sync with the updated parameters.  bwd_ws = the workspace ultr_dnn_backward (or
  * ultr_grad_sumsq) left the sum-of-squares partials in.
- * scalars_out[8]: [0] loss [1] ranker grad norm (pre-clip) [2] clip coef [3] D
- *                 [4] rank_loss (DLA) [5] exam_loss (DLA) [6] propensity grad norm (DLA) [7] sum g^2 */
+ * scalars_out[16]: [0] loss [1] ranker grad norm (pre-clip) [2] clip coef [3] D
+ *                  [4] rank_loss (DLA) [5] exam_loss (DLA) [6] propensity grad norm (DLA) [7] sum g^2
+ *                  [8] sum p^2  [9] sum g.p  (written by a pre-pass only when l2_loss > 0)  [10..16) reserved */
 int ultr_apply_update(const ultr_update_desc* u, const ultr_dnn_desc* d, float* params, float* wt, float* state,
                       const float* grads, float* aux, const void* bwd_ws, float* scalars_out, void* stream);
 

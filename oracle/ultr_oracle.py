@@ -101,8 +101,19 @@ def gather_rows(features: np.ndarray, docids: np.ndarray) -> torch.Tensor:
 # a3: DNN forward   (DNN.py:41-55, 58-88)
 # --------------------------------------------------------------------------------------
 def _act(name: str):
-    # base_ranking_model.py:63-69 ACT_FUNC_DIC; elu alpha = 1
+    # base_ranking_model.py:63-69 ACT_FUNC_DIC; elu alpha = 1.  ('selu' is in the table as a plain function, which
+    # nn.Sequential.add_module rejects with a TypeError: DNN.py:52-53 - not a usable option of the reference)
     return {"elu": F.elu, "relu": F.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid}[name]
+
+
+def l2_term(flat: torch.Tensor, l2_loss: float, layout) -> torch.Tensor:
+    """`for p in params: loss += l2_loss * self.l2_loss(p)` with l2_loss(p) = sum(p ** 2) / 2 (ipw_rank.py:154-157,
+    base_algorithm.py:332-333), one term per parameter TENSOR in state_dict order.  `layout` = [(name, shape, offset)]."""
+    t = torch.zeros((), dtype=torch.float32)
+    for _, shape, off in layout:
+        n = int(np.prod(shape))
+        t = t + l2_loss * (torch.sum(flat[off:off + n] ** 2) / 2)
+    return t
 
 
 def dnn_forward(params: torch.Tensor, feature_size: int, hidden: Sequence[int], x: torch.Tensor,
@@ -133,7 +144,7 @@ def dnn_backward_manual(params: np.ndarray, feature_size: int, hidden: Sequence[
     """Closed-form backward of dnn_forward (what autograd does for DNN.py:41-55) in numpy
     float64-free fp32 — this is the written-out spec the HIP backward kernels implement.
     Returns the flat gradient."""
-    assert act in ("elu", "relu")
+    assert act in ("elu", "relu", "tanh", "sigmoid")
     x = np.asarray(x, np.float32)
     dims = layer_dims(feature_size, hidden)
     lay = {n: (s, o) for n, s, o in param_layout(feature_size, hidden)}
@@ -153,7 +164,8 @@ def dnn_backward_manual(params: np.ndarray, feature_size: int, hidden: Sequence[
         z = u @ get("sequential.linear%d.weight" % j).T + get("sequential.linear%d.bias" % j)
         xs.append(h), xhats.append(xhat), rstds.append(r), us.append(u)
         if j != len(dims) - 1:
-            h = np.where(z > 0, z, np.expm1(np.minimum(z, 0))).astype(np.float32) if act == "elu" else np.maximum(z, 0)
+            h = {"elu": lambda: np.where(z > 0, z, np.expm1(np.minimum(z, 0))), "relu": lambda: np.maximum(z, 0),
+                 "tanh": lambda: np.tanh(z), "sigmoid": lambda: 1.0 / (1.0 + np.exp(-z))}[act]().astype(np.float32)
     grads = np.zeros_like(params)
 
     def put(n, g):
@@ -175,7 +187,8 @@ def dnn_backward_manual(params: np.ndarray, feature_size: int, hidden: Sequence[
         c2 = (dxhat * xhats[j]).mean(axis=1, keepdims=True)
         dx = rstds[j] * (dxhat - c1 - xhats[j] * c2)
         a = xs[j]  # = act(z_{j-1})
-        dact = np.where(a > 0, 1.0, a + 1.0) if act == "elu" else (a > 0).astype(np.float32)
+        dact = {"elu": lambda: np.where(a > 0, 1.0, a + 1.0), "relu": lambda: (a > 0).astype(np.float32),
+                "tanh": lambda: 1.0 - a * a, "sigmoid": lambda: a * (1.0 - a)}[act]()
         dz = (dx * dact).astype(np.float32)
     return grads
 
@@ -257,13 +270,18 @@ def apply_update(p, g, state_sum, lr, max_norm, strategy="ada", stateless=False)
 # a7/a8: NA and IPW train steps   (navie_algorithm.py:76-120, ipw_rank.py:102-182)
 # --------------------------------------------------------------------------------------
 def train_step_softmax(params, state_sum, F_, hidden, features, docids, labels_LB, ipw_list=None, lr=0.05,
-                       max_norm=5.0, strategy="ada", act="elu"):
-    """One NA (ipw_list None) / IPW step.  Returns dict(loss, scores, grads, norm, params, state)."""
+                       max_norm=5.0, strategy="ada", act="elu", l2_loss=0.0):
+    """One NA (ipw_list None) / IPW step.  Returns dict(loss, scores, grads, norm, params, state).
+    l2_loss > 0 (ipw_rank.py:154-159, navie_algorithm.py:109-116): the L2 loop exhausts the `params` generator that is then
+    handed to clip_grad_norm_, so the clip sees NO parameters and nothing is clipped."""
     p = torch.as_tensor(params, dtype=torch.float32).clone().requires_grad_(True)
     scores = ranking_scores(p, F_, hidden, features, docids, act)
     labels = torch.from_numpy(np.ascontiguousarray(np.transpose(labels_LB))).float()  # base_algorithm.py:182
     pw = None if ipw_list is None else ipw_weights(labels_LB, ipw_list)
     loss = softmax_loss(scores, labels, pw)
+    if l2_loss > 0:
+        loss = loss + l2_term(p, l2_loss, param_layout(F_, hidden))
+        max_norm = 0.0
     (g,) = torch.autograd.grad(loss, p)
     with torch.no_grad():
         p2, s2, n, gc = apply_update(p.detach(), g, torch.as_tensor(state_sum, dtype=torch.float32), lr, max_norm, strategy)
@@ -312,7 +330,7 @@ def _fresh_adagrad_step(flat, grad, F_, hidden, lr, max_norm, split):
 
 
 def dla_step(params, prop_params, F_, hidden, features, docids, labels_LB, lr=0.05, prop_lr=None, max_norm=5.0,
-             ranker_loss_weight=1.0, strategy="ada", l2p="softmax", act="elu", fresh_optimizers=False):
+             ranker_loss_weight=1.0, strategy="ada", l2p="softmax", act="elu", fresh_optimizers=False, l2_loss=0.0):
     prop_lr = lr if prop_lr is None or prop_lr < 0 else prop_lr
     L, B = docids.shape
     p = torch.as_tensor(params, dtype=torch.float32).clone().requires_grad_(True)
@@ -326,6 +344,8 @@ def dla_step(params, prop_params, F_, hidden, features, docids, labels_LB, lr=0.
     with torch.no_grad():
         rw = normalized_weights(logits_to_prob(scores, l2p))  # dla.py:217-219
     exam_loss = softmax_loss(propensity, labels, rw)  # dla.py:221-224
+    if l2_loss > 0:  # dla.py:146-150: on the ranking model only, INSIDE rank_loss; both clips stay active (fresh .parameters())
+        rank_loss = rank_loss + l2_term(p, l2_loss, param_layout(F_, hidden))
     loss = exam_loss + ranker_loss_weight * rank_loss  # dla.py:237
     gp, gq = torch.autograd.grad(loss, (p, q))
     if fresh_optimizers and strategy == "ada":
@@ -396,13 +416,16 @@ def em_update(t, t_loss, alpha, p, safe=False):
 
 
 def pairdebias_step(params, state_sum, t_plus, t_minus, F_, hidden, features, docids, labels_LB, lr=0.005,
-                    max_norm=5.0, em_step=0.05, reg_p=1, strategy="ada", act="elu", loops=False):
+                    max_norm=5.0, em_step=0.05, reg_p=1, strategy="ada", act="elu", loops=False, l2_loss=0.0):
     p = torch.as_tensor(params, dtype=torch.float32).clone().requires_grad_(True)
     tp = torch.as_tensor(t_plus, dtype=torch.float32)
     tm = torch.as_tensor(t_minus, dtype=torch.float32)
     scores = ranking_scores(p, F_, hidden, features, docids, act)
     loss_fn = pairdebias_loss_loops if loops else pairdebias_loss
     loss, PL, tpl, tml = loss_fn(scores, torch.as_tensor(labels_LB, dtype=torch.float32), tp, tm)
+    if l2_loss > 0:  # pairwise_debias.py:166-171: same exhausted-generator quirk, the clip is skipped
+        loss = loss + l2_term(p, l2_loss, param_layout(F_, hidden))
+        max_norm = 0.0
     (g,) = torch.autograd.grad(loss, p)
     with torch.no_grad():
         tp2 = em_update(tp, tpl, em_step, reg_p)
@@ -478,7 +501,7 @@ def regression_em_estimation(scores: torch.Tensor, labels: torch.Tensor, propens
 
 
 def regression_em_step(params, state_sum, propensity, uniforms, F_, hidden, features, docids, labels_LB, lr=0.05,
-                       max_norm=5.0, em_step=0.05, strategy="ada", act="elu"):
+                       max_norm=5.0, em_step=0.05, strategy="ada", act="elu", l2_loss=0.0):
     """One RegressionEM.train step with the Bernoulli uniforms INJECTED (the reference draws them from an unseeded
     torch.rand: get_bernoulli_sample, regression_EM.py:20-34, sample = ceil(p - u)).  Loss = BCEWithLogits(scores,
     pseudo-labels), mean over all B*L elements (:149-151); persistent Adagrad + global-norm clip (:165-176); M-step
@@ -492,6 +515,9 @@ def regression_em_step(params, state_sum, propensity, uniforms, F_, hidden, feat
         p_e1_r0_c0, p_r1 = regression_em_estimation(scores.detach(), labels, prop)
         ranker_labels = torch.ceil(p_r1 - u)
     loss = torch.nn.functional.binary_cross_entropy_with_logits(scores, ranker_labels)
+    if l2_loss > 0:  # regression_EM.py:166-176: same exhausted-generator quirk, the clip is skipped
+        loss = loss + l2_term(p, l2_loss, param_layout(F_, hidden))
+        max_norm = 0.0
     (g,) = torch.autograd.grad(loss, p)
     with torch.no_grad():
         prop2 = (1 - em_step) * prop + em_step * torch.mean(labels + (1 - labels) * p_e1_r0_c0, dim=0, keepdim=True)

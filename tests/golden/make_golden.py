@@ -160,7 +160,10 @@ class Recorder:
 
         def clip(parameters, max_norm, *a, **k):
             ps = [parameters] if isinstance(parameters, torch.Tensor) else list(parameters)
-            g = np.concatenate([p.grad.detach().cpu().numpy().ravel() for p in ps]).astype(np.float32)
+            # l2_loss > 0: the caller's generator is already exhausted by its L2 loop (ipw_rank.py:154-159), the clip sees
+            # NO parameters (and returns 0); the gradients are then read off the model
+            src = ps if ps else list(self.algo.model.parameters())
+            g = np.concatenate([p.grad.detach().cpu().numpy().ravel() for p in src]).astype(np.float32)
             tn = self._orig_clip(ps, max_norm, *a, **k)
             self.clips.append((g, float(tn)))
             return tn
@@ -525,6 +528,17 @@ CASES = {
     # relu activation
     "ipw_relu": lambda u: run_train_case(u, "ipw_relu", "ipw", 24, 10, 8, [16, 8], 1, 21,
                                          model_extra=",activation_func=relu"),
+    # the remaining activations of base_ranking_model.py:63-69
+    "na_tanh": lambda u: run_train_case(u, "na_tanh", "na", 24, 10, 8, [16, 8], 2, 51, model_extra=",activation_func=tanh"),
+    "na_sigmoid": lambda u: run_train_case(u, "na_sigmoid", "na", 24, 10, 8, [16, 8], 2, 52, model_extra=",activation_func=sigmoid"),
+    # (activation_func=selu raises in the reference: ACT_FUNC_DIC holds a plain function, nn.Sequential.add_module rejects it)
+    # l2_loss > 0: g += l2 * p and - every algorithm but DLA - the gradient clip silently skipped;
+    # l2_loss = 1 makes ||l2 * p|| > max_gradient_norm, so a clip that was NOT skipped would show
+    "ipw_l2": lambda u: run_train_case(u, "ipw_l2", "ipw", 24, 10, 8, [16, 8], 2, 54, algo_hparams="l2_loss=1.0"),
+    "na_l2": lambda u: run_train_case(u, "na_l2", "na", 24, 10, 8, [16, 8], 2, 55, algo_hparams="l2_loss=1.0"),
+    "dla_l2": lambda u: run_train_case(u, "dla_l2", "dla", 24, 10, 8, [16, 8], 1, 56, algo_hparams="l2_loss=1.0"),
+    "pairdebias_l2": lambda u: run_train_case(u, "pairdebias_l2", "pairdebias", 24, 10, 8, [16, 8], 2, 57, algo_hparams="l2_loss=1.0"),
+    "regem_l2": lambda u: run_train_case(u, "regem_l2", "regem", 24, 10, 8, [16, 8], 2, 58, algo_hparams="l2_loss=1.0"),
     # sgd strategy
     "ipw_sgd": lambda u: run_train_case(u, "ipw_sgd", "ipw", 24, 10, 8, [16, 8], 2, 22,
                                         algo_hparams="grad_strategy=sgd"),

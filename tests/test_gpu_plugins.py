@@ -36,7 +36,7 @@ def build(m, model_cls="DNN", extra=None):
         "learning_algorithm": "ultra_pytorch_amd.learning_algorithm." + CLS[m["algo"]],
         "learning_algorithm_hparams": m.get("algo_hparams", ""),
         "ranking_model": "ultra_pytorch_amd.ranking_model." + model_cls,
-        "ranking_model_hparams": ("hidden_layer_sizes=%s" % json.dumps(hidden)) if hidden is not None else "",
+        "ranking_model_hparams": (("hidden_layer_sizes=%s" % json.dumps(hidden)) if hidden is not None else "") + m.get("model_extra", ""),
         "max_candidate_num": m["L"], "selection_bias_cutoff": m["L"],
         "metrics": ["ndcg", "mrr", "err"], "metrics_topn": [1, 3, 5, 10],
     }
@@ -53,9 +53,12 @@ def load_flat(model, flat):
 
 
 @pytest.mark.parametrize("name", ["na_tiny", "ipw_tiny", "dla_tiny", "pairdebias_tiny", "lambdarank_tiny", "na_linear", "ipw_cfg2",
-                                  "regem_tiny"])
+                                  "regem_tiny", "na_tanh", "na_sigmoid", "ipw_l2", "na_l2", "dla_l2", "pairdebias_l2", "regem_l2"])
 def test_train_matches_golden(name):
     d, m = load_golden(name)
+    for a in ("tanh", "sigmoid"):  # activation_func travels in ranking_model_hparams (DNN.py:25-32)
+        if name.endswith("_" + a):
+            m = dict(m, model_extra=",activation_func=" + a)
     algo = build(m, model_cls="Linear" if m["model"] == "Linear" else "DNN")
     assert list(algo.model.state_dict().keys()) == m["param_keys"]  # checkpoint interchange
     L = m["L"]
@@ -131,9 +134,21 @@ def test_dnn_build_contract():
 def test_unsupported_options_raise():
     d, m = load_golden("ipw_tiny")
     with pytest.raises(NotImplementedError):
-        build(dict(m, algo_hparams="l2_loss=0.1"))
-    with pytest.raises(NotImplementedError):
         build(dict(m, algo_hparams="loss_func=sigmoid_loss"))
+    with pytest.raises(TypeError):  # as the reference: ACT_FUNC_DIC['selu'] is a plain function, add_module rejects it
+        build(dict(m, model_extra=",activation_func=selu"))
+
+
+def test_lazy_propensity_columns_behave_like_the_reference_lists():
+    """IPWrank.train leaves `propensity_weights{l}` in the caller's feed (ipw_rank.py:118-128) - materialised lazily here."""
+    d, m = load_golden("ipw_tiny")
+    algo = build(m)
+    feed = make_feed(algo, d["s0_features"], d["s0_docids"], d["s0_labels"])
+    algo.train(feed)
+    col = feed["propensity_weights0"]
+    assert len(col) == m["B"] and isinstance(col[0], float) and list(col) == col.tolist()
+    np.testing.assert_allclose(np.asarray(col), d["s0_pw"][:, 0], rtol=1e-6)
+    np.testing.assert_allclose(algo.propensity_weights, d["s0_pw"], rtol=1e-6)
 
 
 def test_regression_em_device_rng():

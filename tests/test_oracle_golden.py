@@ -22,31 +22,42 @@ def state_tol(ref_state):
     return dict(rtol=2e-5, atol=2e-6 * float(np.max(ref_state)))
 
 
-def check_common(d, m, t, r, atol_scores=1e-5):
+def check_common(d, m, t, r, atol_scores=1e-5, clip_skipped=False):
     p = "s%d_" % t
     np.testing.assert_allclose(r["scores"], d[p + "scores"], atol=atol_scores, rtol=0)
     lt = 1e-5 * max(1.0, abs(float(d[p + "loss"])))
     assert abs(r["loss"] - float(d[p + "loss"])) <= lt
     g = d[p + "grads"]
     np.testing.assert_allclose(r["grads"], g, rtol=1e-5, atol=1e-6 * max(1.0, float(np.abs(g).max())))
-    assert abs(r["norm"] - float(d[p + "norm"])) <= 1e-5 * max(1.0, float(d[p + "norm"]))
+    if clip_skipped:  # l2_loss > 0: the reference's clip_grad_norm_ was handed an exhausted generator -> norm of nothing
+        assert float(d[p + "norm"]) == 0.0
+    else:
+        assert abs(r["norm"] - float(d[p + "norm"])) <= 1e-5 * max(1.0, float(d[p + "norm"]))
     # params only where |g| is not ~0 (sign-like first Adagrad step is ill-conditioned at g~0)
     sel = np.abs(g) > 1e-6 * max(1.0, float(np.abs(g).max()))
     np.testing.assert_allclose(r["params"][sel], d[p + "post_params"][sel], atol=2e-6, rtol=1e-5)
 
 
-@pytest.mark.parametrize("name", ["na_tiny", "ipw_tiny", "ipw_odd", "na_linear", "ipw_relu", "ipw_sgd", "ipw_cfg2"])
+def act_of(name):
+    return next((a for a in ("relu", "tanh", "sigmoid") if a in name), "elu")
+
+
+@pytest.mark.parametrize("name", ["na_tiny", "ipw_tiny", "ipw_odd", "na_linear", "ipw_relu", "ipw_sgd", "ipw_cfg2", "na_tanh",
+                                  "na_sigmoid", "ipw_l2", "na_l2"])
 def test_softmax_algorithms(name):
     d, m = load(name)
     hidden = m["hidden"] or []
-    act = "relu" if "relu" in name else "elu"
+    act = act_of(name)
     strat = "sgd" if "sgd" in name else "ada"
+    l2 = float(hparams_of(m).get("l2_loss", 0.0))
     for t in range(m["n_steps"]):
         p = "s%d_" % t
         r = O.train_step_softmax(d[p + "pre_params"], d[p + "pre_adagrad"], m["F"], hidden, d[p + "features"],
                                  d[p + "docids"], d[p + "labels"], ipw_list=d["ipw_list"] if m["algo"] == "ipw" else None,
-                                 lr=m["lr"], max_norm=m["max_gradient_norm"], strategy=strat, act=act)
-        check_common(d, m, t, r)
+                                 lr=m["lr"], max_norm=m["max_gradient_norm"], strategy=strat, act=act, l2_loss=l2)
+        check_common(d, m, t, r, clip_skipped=l2 > 0)
+        if l2 > 0:  # the fixture is only a test of the "clip skipped" quirk if a clip WOULD have acted
+            assert r["norm"] > m["max_gradient_norm"]
         if m["algo"] == "ipw":
             np.testing.assert_array_equal(r["pw"], d[p + "pw"])
         if strat == "ada":
@@ -58,7 +69,7 @@ def hparams_of(m):
     return dict(kv.split("=") for kv in m.get("algo_hparams", "").split(",") if kv)
 
 
-@pytest.mark.parametrize("name", ["dla_tiny", "dla_odd", "dla_sigmoid", "dla_sigmoid_odd"])
+@pytest.mark.parametrize("name", ["dla_tiny", "dla_odd", "dla_sigmoid", "dla_sigmoid_odd", "dla_l2"])
 def test_dla(name):
     d, m = load(name)
     hp = hparams_of(m)
@@ -67,7 +78,7 @@ def test_dla(name):
         r = O.dla_step(d[p + "pre_params"], d[p + "pre_prop_params"], m["F"], m["hidden"], d[p + "features"],
                        d[p + "docids"], d[p + "labels"], lr=m["lr"], max_norm=m["max_gradient_norm"],
                        l2p=hp.get("logits_to_prob", "softmax"), ranker_loss_weight=float(hp.get("ranker_loss_weight", 1.0)),
-                       prop_lr=float(hp.get("propensity_learning_rate", -1.0)))
+                       prop_lr=float(hp.get("propensity_learning_rate", -1.0)), l2_loss=float(hp.get("l2_loss", 0.0)))
         check_common(d, m, t, r)
         assert abs(r["rank_loss"] - float(d[p + "rank_loss"])) < 1e-5
         assert abs(r["exam_loss"] - float(d[p + "exam_loss"])) < 1e-5
@@ -78,32 +89,35 @@ def test_dla(name):
         np.testing.assert_allclose(r["prop_params"], d[p + "post_prop_params"], atol=1e-6)
 
 
-@pytest.mark.parametrize("name", ["pairdebias_tiny", "pairdebias_odd", "lambdarank_tiny", "lambdarank_odd"])
+@pytest.mark.parametrize("name", ["pairdebias_tiny", "pairdebias_odd", "lambdarank_tiny", "lambdarank_odd", "pairdebias_l2"])
 def test_pairwise_em(name):
     d, m = load(name)
     step = O.pairdebias_step if m["algo"] == "pairdebias" else O.lambdarank_step
+    l2 = float(hparams_of(m).get("l2_loss", 0.0))
+    kw = dict(l2_loss=l2) if l2 > 0 else {}
     for t in range(m["n_steps"]):
         p = "s%d_" % t
         r = step(d[p + "pre_params"], d[p + "pre_adagrad"], d[p + "pre_t_plus"], d[p + "pre_t_minus"], m["F"],
                  m["hidden"], d[p + "features"], d[p + "docids"], d[p + "labels"], lr=m["lr"],
-                 max_norm=m["max_gradient_norm"])
-        check_common(d, m, t, r)
+                 max_norm=m["max_gradient_norm"], **kw)
+        check_common(d, m, t, r, clip_skipped=l2 > 0)
         np.testing.assert_allclose(r["t_plus"], d[p + "post_t_plus"], atol=1e-6)
         np.testing.assert_allclose(r["t_minus"], d[p + "post_t_minus"], atol=1e-6)
         np.testing.assert_allclose(r["state"], d[p + "post_adagrad"], **state_tol(d[p + "post_adagrad"]))
 
 
-@pytest.mark.parametrize("name", ["regem_tiny", "regem_odd"])
+@pytest.mark.parametrize("name", ["regem_tiny", "regem_odd", "regem_l2"])
 def test_regression_em(name):
     """teacher-forced with the uniforms the reference drew (recorded by make_golden.py)."""
     d, m = load(name)
+    l2 = float(hparams_of(m).get("l2_loss", 0.0))
     for t in range(m["n_steps"]):
         p = "s%d_" % t
         r = O.regression_em_step(d[p + "pre_params"], d[p + "pre_adagrad"], d[p + "pre_propensity"], d[p + "uniforms"],
                                  m["F"], m["hidden"], d[p + "features"], d[p + "docids"], d[p + "labels"], lr=m["lr"],
-                                 max_norm=m["max_gradient_norm"])
+                                 max_norm=m["max_gradient_norm"], l2_loss=l2)
         np.testing.assert_array_equal(r["ranker_labels"], d[p + "ranker_labels"])
-        check_common(d, m, t, r)
+        check_common(d, m, t, r, clip_skipped=l2 > 0)
         np.testing.assert_allclose(r["propensity"], d[p + "post_propensity"], atol=1e-6)
         np.testing.assert_allclose(r["state"], d[p + "post_adagrad"], **state_tol(d[p + "post_adagrad"]))
 

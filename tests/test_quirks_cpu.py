@@ -1,5 +1,6 @@
 """SURVEY Appendix A - the reference quirks that affect parity, one explicit test each (CPU: oracle + host logic).
 The GPU-side counterparts live in test_gpu_parity.py / test_gpu_plugins.py (golden vectors exercise all of them)."""
+import os
 import random
 
 import numpy as np
@@ -7,6 +8,8 @@ import pytest
 import torch
 
 from oracle import ultr_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_a1_layernorm_before_every_linear():
@@ -202,3 +205,40 @@ def test_reference_structure_variants_equal_the_vectorised_oracle():
     np.testing.assert_allclose(c["params"][sel], d["params"][sel], atol=2e-6)
     np.testing.assert_allclose(c["prop_params"], d["prop_params"], atol=2e-6)
     assert abs(c["norm"] - d["norm"]) < 1e-5 and abs(c["prop_norm"] - d["prop_norm"]) < 1e-6
+
+
+@pytest.mark.parametrize("algo", ["softmax", "dla", "pairdebias", "lambdarank"])
+def test_torch_baseline_matches_oracle(algo):
+    """tools/torch_rocm_baseline.py (bench.py's `torch_rocm_baseline` leg: the reference's step in stock torch ops, timed on the
+    GPU for context) computes the oracle's step: same loss and same post-step parameters on CPU."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import torch_rocm_baseline as TB
+    from ultra_pytorch_amd import synthetic
+    Fs, L, B, hidden = 12, 6, 5, [8, 4]
+    rng = np.random.RandomState(3)
+    feats, ids, y = synthetic.make_batch(rng, B, L, Fs, clicks=(algo != "lambdarank"))
+    if algo == "pairdebias":  # position 0 must take part in pairs on both sides (EM ratios are normalised by its sums)
+        y[0, :] = np.arange(B) % 2
+        y[1, :] = 1.0 - y[0, :]
+    params = O.init_params(Fs, hidden, seed=2)
+    ipw = [1.0, 2.0, 3.5]
+    cfg = dict(F=Fs, L=L, B=B, hidden=hidden, algo=algo, model="dnn")
+    lr = 0.005 if algo == "pairdebias" else 0.05
+    st = TB.Stepper(cfg, params, ipw if algo == "softmax" else None, torch.device("cpu"), lr)
+    loss = st.step(st.stage((feats, ids, y)))
+    got = torch.cat([p.detach().reshape(-1) for p in st.model.parameters()]).numpy()
+    z = np.zeros_like(params)
+    if algo == "softmax":
+        r = O.train_step_softmax(params, z, Fs, hidden, feats, ids, y, ipw_list=ipw)
+    elif algo == "dla":
+        r = O.dla_step(params, np.zeros(L + 1, np.float32), Fs, hidden, feats, ids, y)
+    elif algo == "pairdebias":
+        r = O.pairdebias_step(params, z, np.ones(L, np.float32), np.ones(L, np.float32), Fs, hidden, feats, ids, y)
+    else:
+        r = O.lambdarank_step(params, z, np.ones(L, np.float32), np.ones(L, np.float32), Fs, hidden, feats, ids, y)
+    assert abs(loss - r["loss"]) <= 1e-5 * max(1.0, abs(r["loss"]))
+    sel = np.abs(r["grads"]) > 1e-4 * np.abs(r["grads"]).max()  # first Adagrad step is sign-like where g ~ 0
+    np.testing.assert_allclose(got[sel], r["params"][sel], rtol=1e-4, atol=1e-5)
+    if algo in ("pairdebias", "lambdarank"):
+        np.testing.assert_allclose(st.tp.numpy(), r["t_plus"].ravel(), atol=1e-5)

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libultr_hip.so")
 
 ULTR_MAX_HIDDEN = 7
 COMM_HANDLE_BYTES, COMM_MAX_WORLD = 64, 8
-ACT = {"elu": 0, "relu": 1}
+ACT = {"elu": 0, "relu": 1, "tanh": 2, "sigmoid": 3}  # base_ranking_model.py:63-69 ("selu" raises in the reference)
 ATTN_DTYPE = {"fp32": 0, "fp16": 1}
 ALGO_SOFTMAX, ALGO_DLA, ALGO_PAIRDEBIAS, ALGO_LAMBDARANK, ALGO_REGEM = 0, 1, 2, 3, 4
 OPT_ADAGRAD, OPT_SGD = 0, 1
@@ -27,7 +27,8 @@ class UpdateDesc(ctypes.Structure):
     _fields_ = [("algo", c_i32), ("optimizer", c_i32), ("list_size", c_i32), ("logits_to_prob", c_i32),
                 ("n_params", c_i64), ("learning_rate", c_f32), ("max_gradient_norm", c_f32), ("adagrad_eps", c_f32),
                 ("ranker_loss_weight", c_f32), ("propensity_learning_rate", c_f32), ("em_step_size", c_f32),
-                ("regulation_p", c_f32), ("reserved", c_f32)]
+                ("regulation_p", c_f32), ("l2_loss", c_f32), ("guard", c_vp), ("host_scalars", c_vp),
+                ("seq", ctypes.c_uint32), ("pad_", ctypes.c_uint32)]
 
 
 class SetRankDesc(ctypes.Structure):

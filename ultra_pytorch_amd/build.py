@@ -12,7 +12,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libultr_hip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc"]
+OBJ = os.path.join(HERE, "lib", "obj")
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]
 LIBS = []  # no vendor BLAS: every GEMM is the library's own matrix-core code (ultr_gemm.h)
 
 
@@ -27,8 +28,12 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def headers():
+    return sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "ultr_hip.h")]
+
+
 def deps():
-    return sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "ultr_hip.h")]
+    return sources() + headers()
 
 
 def up_to_date():
@@ -47,8 +52,24 @@ def build_library(force=False, verbose=True):
         if os.path.exists(LIB):  # GPU box without a toolchain change: use what travelled
             return LIB
         raise RuntimeError("hipcc not found and %s does not exist" % LIB)
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = [cc] + FLAGS + sources() + LIBS + ["-o", LIB]
+    os.makedirs(OBJ, exist_ok=True)
+    # one object per source, compiled in parallel, rebuilt only when the source or any header is newer
+    hdr_t = max(os.path.getmtime(h) for h in headers())
+    jobs, objs = [], []
+    for src in sources():
+        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+            jobs.append([cc] + CFLAGS + ["-c", src, "-o", obj])
+    procs = []
+    for cmd in jobs:
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc"] + objs + LIBS + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -51,7 +51,9 @@ struct CommDev {
   float* x_local;                          // local slot of this step
   const float* x[ULTR_COMM_MAX_WORLD];     // every rank's slot of this step (x[rank] = x_local)
   uint32_t* flags[ULTR_COMM_MAX_WORLD];    // every rank's flag array [nslice][world]
-  uint32_t* status;                        // local: [0] != 0 after a timed-out wait
+  uint32_t* status[ULTR_COMM_MAX_WORLD];   // every rank's status word: != 0 after a timed-out wait on ANY rank (the rank
+                                           // that times out raises it everywhere, so no replica applies an update its
+                                           // peers did not)
   long long timeout_ticks;                 // wall_clock64 ticks (100 MHz)
 };
 
@@ -108,10 +110,14 @@ __global__ __launch_bounds__(256) void comm_allreduce_kernel(CommDev c, uint32_t
       }
       if (!ok) {
         sm_fail = 1;
-        __hip_atomic_store(c.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int p = 0; p < W; ++p) __hip_atomic_store(c.status[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
     __syncthreads();
+    // acquire at system scope behind the flag reads: nothing this workgroup cached before the peers published (L1 / non-local
+    // L2 lines) may serve the slice loads below.  (The publishing side needs no L2-wide release: its slice went out with
+    // write-through sc0|sc1 stores that were waited for - vmcnt(0) - before the flag stores were issued.)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   }
   // ---- sum the W slices in rank order ---------------------------------------------------------------------------------
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -123,7 +129,8 @@ __global__ __launch_bounds__(256) void comm_allreduce_kernel(CommDev c, uint32_t
     for (int p = 0; p < W; ++p) {
       s.x += v[p].x; s.y += v[p].y; s.z += v[p].z; s.w += v[p].w;
     }
-    if (sm_fail) s = mine;  // timed out: keep the local vector (the host sees ultr_comm_status != 0)
+    if (sm_fail) s = mine;  // timed out: the local vector stays; the status word (raised on every rank) makes the update
+                            // launches no-ops from here on and the host's next read of the loss raises
   } else {
     s = mine;
   }
@@ -222,7 +229,8 @@ extern "C" int ultr_comm_allreduce(ultr_comm* c, uint64_t step, const float* src
     d.x[p] = reinterpret_cast<const float*>(reinterpret_cast<char*>(c->peer_base[p]) + slot_off);
   }
   d.x_local = reinterpret_cast<float*>(reinterpret_cast<char*>(c->base) + slot_off);
-  d.status = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(c->base) + c->flag_bytes);
+  for (int p = 0; p < c->world; ++p)
+    d.status[p] = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(c->peer_base[p]) + c->flag_bytes);
   d.timeout_ticks = 300000000LL;  // 3 s of the 100 MHz wall clock
   const uint32_t epoch = (uint32_t)(step + 1);
   const int nblk = (int)((n + COMM_SLICE - 1) / COMM_SLICE);
@@ -242,6 +250,11 @@ extern "C" int ultr_comm_allreduce(ultr_comm* c, uint64_t step, const float* src
   }
 #undef COMM_LAUNCH
   return (int)hipGetLastError();
+}
+
+// library-internal: the device address of this rank's status word (ultr_update_desc::guard of the update behind the exchange)
+const uint32_t* ultr_comm_status_word(const ultr_comm* c) {
+  return c ? reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(c->base) + c->flag_bytes) : nullptr;
 }
 
 extern "C" int ultr_comm_status(ultr_comm* c, void* stream) {

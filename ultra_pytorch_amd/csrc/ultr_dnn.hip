@@ -2488,7 +2488,7 @@ static bool desc_ok(const ultr_dnn_desc* d) {
   if (!d || d->feature_size <= 0 || d->n_hidden < 0 || d->n_hidden > ULTR_MAX_HIDDEN) return false;
   for (int j = 0; j < d->n_hidden; ++j)
     if (d->hidden[j] <= 0) return false;
-  return d->activation == ULTR_ACT_ELU || d->activation == ULTR_ACT_RELU;
+  return d->activation >= ULTR_ACT_ELU && d->activation <= ULTR_ACT_SIGMOID;
 }
 
 bool ultr_make_dnn_plan(const ultr_dnn_desc* d, int64_t N, DnnPlan* p) {

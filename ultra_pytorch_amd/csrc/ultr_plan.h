@@ -146,6 +146,10 @@ int ultr_fused_step_softmax(const ultr_dnn_desc* d, const float* params, const f
                             const float* labels, const float* pw, const float* ipw_table, int32_t n_ipw, float* dscores_out,
                             void* loss_ws, void* bwd_ws, float* grads, void* stream);
 
+// library-internal, ultr_comm.hip: device address of a communicator's status word (the guard of the update behind the exchange)
+struct ultr_comm;
+const uint32_t* ultr_comm_status_word(const ultr_comm* c);
+
 #define ULTR_TAIL_FIXED 4
 __host__ __device__ static inline int64_t ultr_tail_len(int L) { return ULTR_TAIL_FIXED + 2 * (int64_t)L; }
 

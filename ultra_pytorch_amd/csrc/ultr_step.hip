@@ -17,6 +17,11 @@ static int finish_step(const ultr_step_args* a, void* stream) {
     const int64_t n = P + ultr_tail_len(a->list_size);
     const int rc = ultr_comm_allreduce(a->comm, a->comm_step, a->grads, n, P, a->grads, a->bwd_ws, (int32_t)((n + 63) / 64), stream);
     if (rc) return rc;
+    // the update behind the exchange is guarded by the communicator's status word: after a timed-out peer wait (here or on
+    // any peer - the rank that times out raises the word everywhere) no replica moves its parameters again
+    ultr_update_desc u = *a->upd;
+    u.guard = ultr_comm_status_word(a->comm);
+    return ultr_apply_update(&u, a->desc, a->params, a->wt, a->state, a->grads, a->aux, a->bwd_ws, a->scalars, stream);
   } else if (a->skip_update) {
     return 0;
   }

@@ -32,6 +32,61 @@ __device__ __forceinline__ float opt_step(float p, float g, float* st, int opt, 
   return p - lr * (g / (sqrtf(s) + eps));
 }
 
+// Step report into HOST-mapped pinned memory (ultr_update_desc::host_scalars): eight scalars + the guard word, waited for
+// (the stores are acknowledged by the host bridge), THEN the sequence number the host spins on - what loss.item() costs
+// becomes one posted PCIe write instead of a stream synchronisation and a device-to-host copy.
+__device__ __forceinline__ void host_report(const ultr_update_desc& u, const float (&v)[8], uint32_t status) {
+  float* hs = u.host_scalars;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) __hip_atomic_store(hs + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(reinterpret_cast<uint32_t*>(hs) + 8, status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __hip_atomic_store(reinterpret_cast<uint32_t*>(hs) + 9, u.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// guard word set (a timed-out gradient exchange on this rank or on a peer): the launch must change nothing.  Block 0 still
+// reports, with the status, so that the host's read of the loss raises instead of waiting for a sequence number forever.
+__device__ __forceinline__ bool update_guarded(const ultr_update_desc& u) {
+  if (u.guard == nullptr) return false;
+  const uint32_t gv = __hip_atomic_load(u.guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (gv == 0u) return false;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && u.host_scalars != nullptr) {
+    const float nanv = __uint_as_float(0x7fc00000u);
+    const float v[8] = {nanv, nanv, 0.f, 0.f, nanv, nanv, 0.f, 0.f};
+    host_report(u, v, gv);
+  }
+  return true;
+}
+
+// pre-pass of ultr_apply_update when l2_loss > 0: out[0] = sum p^2, out[1] = sum g.p over the P parameters (one workgroup,
+// fixed order: thread-strided partials, wave sums, 16 wave partials added in order)
+__global__ __launch_bounds__(1024) void l2_sums_kernel(const float* __restrict__ params, const float* __restrict__ grads,
+                                                       int64_t P, float* __restrict__ out) {
+  __shared__ float sm[2][16];
+  float a = 0.f, b = 0.f;
+  for (int64_t e = threadIdx.x; e < P; e += 1024) {
+    const float p = params[e];
+    a += p * p;
+    b += grads[e] * p;
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if ((threadIdx.x & 63) == 0) {
+    sm[0][threadIdx.x >> 6] = a;
+    sm[1][threadIdx.x >> 6] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float sa = 0.f, sb = 0.f;
+    for (int w = 0; w < 16; ++w) {
+      sa += sm[0][w];
+      sb += sm[1][w];
+    }
+    out[0] = sa;
+    out[1] = sb;
+  }
+}
+
 // Everything after the gradient and the sum of squares are known: step scalars, clip, optimizer, k-major copy /
 // image, and (block 0) the per-position state.  EPT elements per thread, indices e_a (-1 = none); the new parameter
 // values come back in p_new_a for the caller's k-major / image writes.
@@ -41,7 +96,7 @@ __device__ __forceinline__ void update_body(const ultr_update_desc& u, const Dnn
                                             float* __restrict__ aux, float ss, const int64_t (&e_a)[EPT],
                                             const float (&g_raw_a)[EPT], const float (&p_old_a)[EPT],
                                             const float (&s_old_a)[EPT], float (&p_new_a)[EPT], float* sm,
-                                            float* __restrict__ scalars_out) {
+                                            float* __restrict__ scalars_out, const float* __restrict__ l2_sums) {
   const int64_t P = u.n_params;
   const int L = u.list_size;
   const float loss_sum = tail[0], D = tail[1], loss2 = tail[2], D2 = tail[3];
@@ -70,8 +125,26 @@ __device__ __forceinline__ void update_body(const ultr_update_desc& u, const Dnn
       loss = loss_sum / D;
       break;
   }
-  const float norm = fabsf(gs) * sqrtf(ss);
-  const float coef = (u.max_gradient_norm > 0.f) ? fminf(1.0f, u.max_gradient_norm / (norm + 1e-6f)) : 1.0f;
+  float norm = fabsf(gs) * sqrtf(ss);
+  // l2_loss > 0 (ipw_rank.py:154-157 and siblings): g += lam * p, loss += l2_loss * sum p^2 / 2.  Every algorithm but DLA
+  // hands clip_grad_norm_ a parameter generator the L2 loop has already exhausted, so NOTHING is clipped (Appendix A.8);
+  // DLA adds the term to rank_loss (scaled by ranker_loss_weight with it) and clips the full gradient (dla.py:146-162).
+  float lam = 0.f;
+  bool clip = u.max_gradient_norm > 0.f;
+  if (u.l2_loss > 0.f && l2_sums != nullptr) {
+    const float sp2 = l2_sums[0], sgp = l2_sums[1];
+    if (u.algo == ULTR_ALGO_DLA) {
+      lam = u.ranker_loss_weight * u.l2_loss;
+      rank_loss += u.l2_loss * (0.5f * sp2);
+      loss = exam_loss + u.ranker_loss_weight * rank_loss;
+    } else {
+      lam = u.l2_loss;
+      loss += u.l2_loss * (0.5f * sp2);
+      clip = false;
+    }
+    norm = sqrtf(fmaxf(gs * gs * ss + 2.0f * gs * lam * sgp + lam * lam * sp2, 0.f));
+  }
+  const float coef = clip ? fminf(1.0f, u.max_gradient_norm / (norm + 1e-6f)) : 1.0f;
   const bool stateless = (u.algo == ULTR_ALGO_DLA);
 #pragma unroll
   for (int k = 0; k < EPT; ++k) {
@@ -80,6 +153,7 @@ __device__ __forceinline__ void update_body(const ultr_update_desc& u, const Dnn
     p_new_a[k] = 0.f;
     if (e >= 0 && e < P) {
       float g = g_raw * gs;
+      if (lam != 0.f) g += lam * p_old;
       g *= coef;
       float s_new = s_old;
       const float pn = opt_step(p_old, g, &s_new, u.optimizer, stateless || state == nullptr, u.learning_rate, u.adagrad_eps);
@@ -142,12 +216,17 @@ __device__ __forceinline__ void update_body(const ultr_update_desc& u, const Dnn
     scalars_out[6] = pnorm;
     scalars_out[7] = ss;
   }
+  if (threadIdx.x == 0 && u.host_scalars != nullptr) {
+    const float v[8] = {loss, norm, coef, D, rank_loss, exam_loss, pnorm, ss};
+    host_report(u, v, 0u);
+  }
 }
 
 __global__ __launch_bounds__(256) void update_kernel(ultr_update_desc u, DnnPlan dp, float* __restrict__ params,
                                                      float* __restrict__ state, const float* __restrict__ grads,
                                                      float* __restrict__ aux, const float* __restrict__ sumsq_part, int nsq,
-                                                     float* __restrict__ scalars_out) {
+                                                     float* __restrict__ scalars_out, const float* __restrict__ l2_sums) {
+  if (update_guarded(u)) return;
   // flat variant (no k-major copy to maintain): one element per thread, loads issued BEFORE the norm reduction so
   // that the two memory round trips overlap
   __shared__ float sm[4];
@@ -163,7 +242,7 @@ __global__ __launch_bounds__(256) void update_kernel(ultr_update_desc u, DnnPlan
   for (int k = threadIdx.x; k < nsq; k += 256) ss += sumsq_part[k];
   ss = block_sum256(ss, sm);
   float pn[1];
-  update_body<1>(u, dp, params, state, grads + P, aux, ss, ea, g_raw, p_old, s_old, pn, sm, scalars_out);
+  update_body<1>(u, dp, params, state, grads + P, aux, ss, ea, g_raw, p_old, s_old, pn, sm, scalars_out, l2_sums);
 }
 
 // Variant that keeps the k-major weight copy and the vector-parameter image current (DnnPlan::wt_*).  Workgroups
@@ -179,9 +258,11 @@ __global__ __launch_bounds__(256) void update_tiled_kernel(ultr_update_desc u, D
                                                            float* __restrict__ state, const float* __restrict__ grads,
                                                            float* __restrict__ aux, float* __restrict__ wt,
                                                            const float* __restrict__ sumsq_part, int nsq,
-                                                           float* __restrict__ scalars_out, int n_tile_blocks) {
+                                                           float* __restrict__ scalars_out, int n_tile_blocks,
+                                                           const float* __restrict__ l2_sums) {
   __shared__ float sm[4];
   __shared__ float tile[TPW][16][17];
+  if (update_guarded(u)) return;
   const int64_t P = u.n_params;
   const int n_tiles = dp.upd_tile_begin[dp.nl - 1];
   const int tid = threadIdx.x, r = tid >> 4, c = tid & 15;
@@ -228,9 +309,9 @@ __global__ __launch_bounds__(256) void update_tiled_kernel(ultr_update_desc u, D
   float pn[TPW];
   // block 0's extra duties (EM / propensity updates, step scalars) run inside update_body and need all 256 threads
   if (blockIdx.x != 0) {
-    update_body<TPW>(u, dp, params, state, grads + P, aux, ss, ea, g_raw, p_old, s_old, pn, sm, nullptr);
+    update_body<TPW>(u, dp, params, state, grads + P, aux, ss, ea, g_raw, p_old, s_old, pn, sm, nullptr, l2_sums);
   } else {
-    update_body<TPW>(u, dp, params, state, grads + P, aux, ss, ea, g_raw, p_old, s_old, pn, sm, scalars_out);
+    update_body<TPW>(u, dp, params, state, grads + P, aux, ss, ea, g_raw, p_old, s_old, pn, sm, scalars_out, l2_sums);
   }
   if (is_tile) {
 #pragma unroll
@@ -262,24 +343,32 @@ extern "C" int ultr_apply_update(const ultr_update_desc* u, const ultr_dnn_desc*
     return ULTR_E_BADARG;
   if (u->algo != ULTR_ALGO_SOFTMAX && !aux) return ULTR_E_BADARG;
   if (u->optimizer == ULTR_OPT_ADAGRAD && u->algo != ULTR_ALGO_DLA && !state) return ULTR_E_BADARG;
+  if (u->l2_loss < 0.f || (u->l2_loss > 0.f && !scalars_out) || (u->l2_loss > 0.f && u->algo == ULTR_ALGO_LAMBDARANK))
+    return ULTR_E_BADARG;  // LambdaRank has no l2_loss hyper-parameter (lambda_rank.py:42-49)
   const int tail = (int)ultr_tail_len(u->list_size);
   const int nsq = (int)ultr_red_blocks(u->n_params, tail);
+  const float* l2_sums = nullptr;
+  if (u->l2_loss > 0.f) {
+    hipLaunchKernelGGL(l2_sums_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)params, grads, u->n_params,
+                       scalars_out + 8);
+    l2_sums = scalars_out + 8;
+  }
   UltrProfScope prof(ULTR_K_UPDATE, (hipStream_t)stream);
   if (wt != nullptr) {
     const int n_tiles = dp.upd_tile_begin[dp.nl - 1], n_vec = dp.vs_begin[dp.n_vs];
     if (n_tiles + (n_vec + 255) / 256 < 1536) {  // one unit per workgroup keeps the launch wide (config 2: 401 units, config 3: 940 -
                                                  // four per workgroup left 235 workgroups for 256 CUs: 7.0 -> 9.0 us)
       ULTR_LAUNCH(prof, update_tiled_kernel<1>, dim3(n_tiles + (n_vec + 255) / 256), dim3(256), 0, (hipStream_t)stream, *u, dp, params, state,
-                  grads, aux, wt, (const float*)bwd_ws, nsq, scalars_out, n_tiles);
+                  grads, aux, wt, (const float*)bwd_ws, nsq, scalars_out, n_tiles, l2_sums);
     } else {
       const int tb = (n_tiles + 3) / 4;
       ULTR_LAUNCH(prof, update_tiled_kernel<4>, dim3(tb + (n_vec + 1023) / 1024), dim3(256), 0, (hipStream_t)stream, *u, dp, params, state,
-                  grads, aux, wt, (const float*)bwd_ws, nsq, scalars_out, tb);
+                  grads, aux, wt, (const float*)bwd_ws, nsq, scalars_out, tb, l2_sums);
     }
   } else {
     const int nblk = (int)((u->n_params + 255) / 256);
     ULTR_LAUNCH(prof, update_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *u, dp, params, state, grads, aux,
-                (const float*)bwd_ws, nsq, scalars_out);
+                (const float*)bwd_ws, nsq, scalars_out, l2_sums);
   }
   return (int)hipGetLastError();
 }

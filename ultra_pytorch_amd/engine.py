@@ -11,8 +11,11 @@ Nothing here synchronises with the host; the caller decides when to read `scalar
 (the reference's `loss.item()` is the only sync, base_algorithm.py / ipw_rank.py:182).
 """
 import ctypes
+import os
 import random
+import time
 
+import numpy as np
 import torch
 
 from . import _lib, hip_ops
@@ -29,7 +32,8 @@ def _f32(n, device, zero=False):
 class StepEngine:
     def __init__(self, shape, batch, list_size, device, algo="softmax", optimizer="ada", learning_rate=0.05,
                  max_gradient_norm=5.0, ranker_loss_weight=1.0, propensity_learning_rate=None, em_step_size=0.05,
-                 regulation_p=1.0, sigma=1.0, logits_to_prob="softmax", process_group=None, rng_seed=0):
+                 regulation_p=1.0, sigma=1.0, logits_to_prob="softmax", process_group=None, rng_seed=0, l2_loss=0.0,
+                 batch_total=None, comm=None, no_peer_comm=False):
         if not torch.cuda.is_available():
             raise RuntimeError("ultra_pytorch_amd needs an MI355X/ROCm GPU: there is no CPU fallback")
         self.shape, self.B, self.L, self.device = shape, int(batch), int(list_size), device
@@ -46,24 +50,39 @@ class StepEngine:
         self.rng_seed, self.rng_step = (int(rng_seed) + 0x9E3779B1 * self.rank) & 0xFFFFFFFFFFFFFFFF, 0
         # PairDebias' xB factor (base_algorithm.py:242-248) is the GLOBAL batch: shards may be uneven (parallel.shard_bounds),
         # so it is the sum of the local batches, not B * world
-        self.batch_total = self.B
-        if process_group is not None:
+        # (`batch_total` given: the caller already agreed on it - learning_algorithm.BaseAlgorithm does, per step, so that a
+        # cached engine can never sit on a stale value or enter a collective its peers do not)
+        self.batch_total = self.B if batch_total is None else int(batch_total)
+        if process_group is not None and batch_total is None:
             cpu_pg = torch.distributed.get_backend(process_group) == "gloo"
             t = torch.tensor([self.B], dtype=torch.int64, device="cpu" if cpu_pg else device)
             torch.distributed.all_reduce(t, group=process_group)
             self.batch_total = int(t.item())
         P, tail = shape.n_params, hip_ops.tail_floats(self.L)
         self.P, self.tail = P, tail
-        self.comm = None
-        if process_group is not None:
+        # the gradient exchange: a communicator handed in by the caller (one per process group, shared by every engine of an
+        # algorithm object), or this engine's own
+        self.comm, self._own_comm = comm, False
+        if process_group is not None and comm is None and not no_peer_comm:
             from . import parallel
             self.comm = parallel.PeerComm.create(process_group, P + tail, device)
+            self._own_comm = self.comm is not None
+        if self.comm is not None and self.comm.n < P + tail:
+            raise ValueError("the shared communicator is too small for this model")
         self._alloc(shape, device)
         self.loss_ws = _f32(hip_ops.loss_workspace_bytes(self.B, self.L) // 4, device, zero=True)
         self.scores = _f32(self.N, device).view(self.B, self.L)
         self.dscores = _f32(self.N, device).view(self.B, self.L)
         self.grads = _f32(P + tail, device, zero=True)
-        self.scalars = _f32(8, device, zero=True)
+        self.scalars = _f32(16, device, zero=True)
+        # step report in HOST-mapped pinned memory (ultr_update_desc::host_scalars): the update kernel's block 0 writes the step
+        # scalars, the exchange's status word and - last - the step's sequence number there; read_loss() spins on the sequence
+        # number instead of a stream synchronisation + device-to-host copy (the reference's loss.item(): 16-18 us -> one PCIe write)
+        self._hs = torch.zeros(16, dtype=torch.float32).pin_memory()
+        self._hs_f = self._hs.numpy()
+        self._hs_u = self._hs_f.view(np.uint32)
+        self._seq = 0
+        self._host_report = os.environ.get("ULTR_HOST_REPORT", "1") != "0"
         u = _lib.UpdateDesc()
         u.algo = ALGOS[algo]
         u.optimizer = _lib.OPT_SGD if optimizer == "sgd" else _lib.OPT_ADAGRAD
@@ -78,6 +97,10 @@ class StepEngine:
         u.propensity_learning_rate = float(learning_rate if plr is None or plr < 0 else plr)
         u.em_step_size = float(em_step_size)
         u.regulation_p = float(regulation_p)
+        u.l2_loss = float(l2_loss)
+        u.guard = None
+        u.host_scalars = self._hs.data_ptr() if self._host_report else None
+        u.seq = 0
         self.udesc = u
         self._args = None
 
@@ -129,6 +152,43 @@ class StepEngine:
     def update(self, params, state, aux=None):
         hip_ops.apply_update(self.shape, self.udesc, params, state, self.grads, aux, self.bwd_ws, self.scalars)
 
+    def _next_seq(self):
+        self._seq = (self._seq % 0xFFFFFFFF) + 1  # 1 .. 2^32-1: never 0, the buffer's initial content
+        self.udesc.seq = self._seq
+
+    def read_scalars(self, timeout_s=60.0):
+        """The step scalars of the LAST queued step as a numpy array ([0] loss, [1] gradient norm, [2] clip coefficient, [3] D,
+        [4] rank_loss, [5] exam_loss, [6] propensity gradient norm, [7] sum g^2) - the reference's `loss.item()`.  Waits for the
+        update kernel's report in host-mapped memory (no stream synchronisation); raises if the gradient exchange of a
+        data-parallel step timed out on any rank (the update was then NOT applied, ultr_update_desc::guard)."""
+        if not self._host_report:
+            torch.cuda.current_stream().synchronize()
+            if self.comm is not None and self.comm.status() != 0:
+                raise _lib.UltrHipError("data-parallel gradient exchange timed out (ULTR_E_COMM_TIMEOUT): the update was not applied")
+            return self.scalars[:8].cpu().numpy()
+        seq, u, spins, t0 = self._seq, self._hs_u, 0, None
+        if seq == 0:
+            raise RuntimeError("read_scalars() before the first train_step()")
+        while int(u[9]) != seq:
+            spins += 1
+            if spins & 0x3FF == 0:  # look at the clock every 1024 polls only
+                now = time.perf_counter()
+                t0 = now if t0 is None else t0
+                if now - t0 > timeout_s:
+                    raise _lib.UltrHipError("no step report from the GPU within %.0f s (step %d)" % (timeout_s, seq))
+        if int(u[8]) != 0:
+            raise _lib.UltrHipError("data-parallel gradient exchange timed out on some rank (ULTR_E_COMM_TIMEOUT): this and all "
+                                    "later updates were NOT applied - restart from the last checkpoint")
+        return self._hs_f[:8].copy()
+
+    def read_loss(self):
+        return float(self.read_scalars()[0])
+
+    def close(self):
+        if self._own_comm and self.comm is not None:
+            self.comm.close()
+        self.comm = None
+
     def train_step(self, params, state, features, n_docs, docids, labels, aux=None, ipw_table=None, pw=None,
                    uniforms=None):
         """One full step through ONE C call (ultr_train_step); returns the device tensor of step scalars ([0] = loss)."""
@@ -140,13 +200,14 @@ class StepEngine:
             a.scores, a.dscores = self.scores.data_ptr(), self.dscores.data_ptr()
             a.saved, a.loss_ws, a.bwd_ws = self.saved.data_ptr(), self.loss_ws.data_ptr(), self.bwd_ws.data_ptr()
             a.grads, a.scalars = self.grads.data_ptr(), self.scalars.data_ptr()
-            a.batch, a.list_size, a.batch_total = self.B, self.L, self.batch_total
+            a.batch, a.list_size = self.B, self.L
             a.sigma = self.sigma
             # data parallel: with the peer exchange the whole sharded step is still ONE C call (backward -> exchange kernel ->
             # update); with the process group's all-reduce the call stops behind the backward and the host issues the rest
             a.skip_update = 1 if (self.pg is not None and self.comm is None) else 0
             a.comm = self.comm.h if self.comm is not None else None
             self._fn = self.shape.lib.ultr_train_step
+        a.batch_total = self.batch_total  # per step: uneven data-parallel shards may change it (PairDebias' xB factor)
         a.params = params.data_ptr()
         a.wt = hip_ops.weight_copy(self.shape).get(params).data_ptr()
         a.state = state.data_ptr() if state is not None else None
@@ -164,6 +225,7 @@ class StepEngine:
         if self.comm is not None:
             a.comm_step = self.comm.step
             self.comm.step += 1
+        self._next_seq()
         _lib.check(self._fn(ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ultr_train_step")
         if self.pg is not None and self.comm is None:
             self.dp_reduce()
@@ -238,6 +300,7 @@ class SetRankStepEngine(StepEngine):
                                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ultr_apply_update")
 
     def train_step(self, params, state, features, n_docs, docids, labels, aux=None, ipw_table=None, pw=None, uniforms=None):
+        self._next_seq()
         self.forward(params, features, n_docs, docids, train=True)
         if self.algo == "regem":
             self.loss(labels, aux=aux, uniforms=uniforms)

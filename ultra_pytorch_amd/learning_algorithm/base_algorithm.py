@@ -11,6 +11,8 @@ The hot path — gather + DNN forward, the loss, DNN backward, clip, optimizer, 
 (engine.StepEngine / EvalEngine).  This file only marshals the feed (host numpy -> pinned -> HBM) and keeps the
 reference's bookkeeping.  There is no CPU path: constructing an algorithm without a GPU raises.
 """
+import collections
+
 import numpy as np
 import torch
 
@@ -44,8 +46,12 @@ class BaseAlgorithm(object):
         self.model = self.create_model(self.feature_size).to(self.cuda)
         self.learning_rate = float(self.hparams.learning_rate)
         self.state_sum = torch.zeros_like(self.model.flat_params)  # Adagrad accumulator (initial value 0)
-        self._train_engines, self._eval_engines, self._stage, self._stage_events = {}, {}, {}, {}
+        # per-(batch, list size) workspaces, least recently used first: DirectLabelFeed may return short batches (SURVEY Appendix
+        # A.13), each distinct size is a workspace set - at most MAX_ENGINES of them are kept
+        self._train_engines, self._eval_engines = collections.OrderedDict(), collections.OrderedDict()
+        self._stage, self._stage_events = {}, {}
         self.process_group = exp_settings.get("process_group", None)  # data parallel: one rank per GPU
+        self._dp_comm, self._dp_comm_tried = None, False
 
     def create_model(self, feature_size):
         """base_algorithm.py:156-167: the ranking model is a plugin too."""
@@ -103,21 +109,54 @@ class BaseAlgorithm(object):
     def _engine_kwargs(self):
         return {}
 
+    MAX_ENGINES = 8
+
+    def _dp_batch_total(self, B):
+        """Data parallel: the GLOBAL batch of this step (shards may be uneven and may change from step to step).  Only
+        PairDebias' xB factor consumes it (base_algorithm.py:242-248), so only PairDebias pays for the agreement - one
+        integer all-reduce per step, entered by EVERY rank on EVERY step (never from inside a lazily built engine, where one
+        rank could enter a collective its peers do not)."""
+        if self.process_group is None:
+            return B
+        import torch.distributed as dist
+        if self.ENGINE_ALGO != "pairdebias":
+            return B * dist.get_world_size(self.process_group)
+        cpu_pg = dist.get_backend(self.process_group) == "gloo"
+        t = torch.tensor([B], dtype=torch.int64, device="cpu" if cpu_pg else self.cuda)
+        dist.all_reduce(t, group=self.process_group)
+        return int(t.item())
+
     def _train_engine(self, B, L):
+        bt = self._dp_batch_total(B)
+        if self.process_group is not None and not self._dp_comm_tried:
+            # ONE gradient-exchange communicator per algorithm object, created at the first step (all ranks are here
+            # together) and shared by every engine built later - engine construction itself runs no collective
+            from .. import parallel
+            from ..hip_ops import tail_floats
+            self._dp_comm_tried = True
+            self._dp_comm = parallel.PeerComm.create(self.process_group, self.model.shape.n_params + tail_floats(L), self.cuda)
         key = (B, L)
-        if key not in self._train_engines:
+        eng = self._train_engines.get(key)
+        if eng is None:
             kw = dict(learning_rate=self.learning_rate, max_gradient_norm=float(self.hparams.max_gradient_norm),
                       optimizer="sgd" if self.hparams.grad_strategy == "sgd" else "ada",
-                      process_group=self.process_group)
+                      l2_loss=float(getattr(self.hparams, "l2_loss", 0.0)), process_group=self.process_group)
+            if self.process_group is not None:
+                kw.update(batch_total=bt, comm=self._dp_comm)
+                if self._dp_comm is None:
+                    kw.update(no_peer_comm=True)
             kw.update(self._engine_kwargs())
             cls = getattr(self.model, "step_engine_cls", engine.StepEngine)  # the ranking model picks its engine
-            self._train_engines[key] = cls(self.model.shape, B, L, self.cuda, algo=self.ENGINE_ALGO, **kw)
-        return self._train_engines[key]
+            eng = self._train_engines[key] = cls(self.model.shape, B, L, self.cuda, algo=self.ENGINE_ALGO, **kw)
+            while len(self._train_engines) > self.MAX_ENGINES:
+                _, old = self._train_engines.popitem(last=False)
+                old.close()
+        else:
+            self._train_engines.move_to_end(key)
+        eng.batch_total = bt
+        return eng
 
     def _check_hparams(self):
-        if float(getattr(self.hparams, "l2_loss", 0.0)) > 0:
-            raise NotImplementedError("l2_loss > 0: in the reference this also silently disables gradient clipping "
-                                      "(ipw_rank.py:154-159); only l2_loss = 0 is supported")
         lf = getattr(self.hparams, "loss_func", "softmax_loss")
         if lf in ("sigmoid_loss", "pairwise_loss"):
             raise NotImplementedError("loss_func=%r raises in the reference too (base_algorithm.py:267,307)" % lf)
@@ -133,6 +172,10 @@ class BaseAlgorithm(object):
         if key not in self._eval_engines:
             cls = getattr(self.model, "eval_engine_cls", engine.EvalEngine)
             self._eval_engines[key] = cls(self.model.shape, B, L, self.cuda, topn=topn)
+            while len(self._eval_engines) > self.MAX_ENGINES:
+                self._eval_engines.popitem(last=False)
+        else:
+            self._eval_engines.move_to_end(key)
         ev = self._eval_engines[key]
         scores, ndcg = ev.run(self.model.flat_params, self.letor_features, self.n_docs, self.docid_inputs, self.labels_LB)
         self.output = scores.clone()  # the UNMASKED scores are what callers get (base_algorithm.py / main.py:266)

@@ -64,7 +64,7 @@ class DLA(BaseAlgorithm):
         eng = self._train_engine(self.batch_size, self.rank_list_size)
         sc = eng.train_step(self.model.flat_params, None, self.letor_features, self.n_docs, self.docid_inputs,
                             self.labels_LB, aux=self.propensity_model.flat_params)
-        vals = sc.cpu()
+        vals = eng.read_scalars()
         self.loss, self.rank_loss, self.exam_loss = float(vals[0]), float(vals[4]), float(vals[5])
         print(" Loss %f at Global Step %d: " % (self.loss, self.global_step))
         self.global_step += 1

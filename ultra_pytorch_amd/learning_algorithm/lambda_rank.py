@@ -42,6 +42,6 @@ class LambdaRank(BaseAlgorithm):
         eng = self._train_engine(self.batch_size, self.rank_list_size)
         sc = eng.train_step(self.model.flat_params, self.state_sum, self.letor_features, self.n_docs, self.docid_inputs,
                             self.labels_LB, aux=self.t_state)
-        self.loss = float(sc[0].item())
+        self.loss = eng.read_loss()  # the reference's only host sync: loss.item()
         print(" Loss %f at Global Step %d: " % (self.loss, self.global_step))
         return self.loss, None, self.train_summary

@@ -42,7 +42,7 @@ class RegressionEM(BaseAlgorithm):
         eng = self._train_engine(self.batch_size, self.rank_list_size)
         sc = eng.train_step(self.model.flat_params, self.state_sum, self.letor_features, self.n_docs, self.docid_inputs,
                             self.labels_LB, aux=self.propensity_state, uniforms=self.uniforms)
-        self.loss = float(sc[0].item())
+        self.loss = eng.read_loss()  # the reference's only host sync: loss.item()
         self.update_propensity_op = self.propensity
         self.global_step += 1
         print("Loss %f at global step %d" % (self.loss, self.global_step))

@@ -48,8 +48,11 @@ class DNN(nn.Module):
         if self.hparams.norm != "layer":
             raise NotImplementedError("norm=%r: only 'layer' is supported (the reference's 'batch' branch builds "
                                       "BatchNorm2d on 2-D input and cannot run, DNN.py:48-50)" % self.hparams.norm)
-        if self.hparams.activation_func not in ("elu", "relu"):
-            raise NotImplementedError("activation_func=%r: the HIP path implements elu and relu" % self.hparams.activation_func)
+        if self.hparams.activation_func == "selu":  # a plain function in ACT_FUNC_DIC: nn.Sequential.add_module raises (DNN.py:52-53)
+            raise TypeError("activation_func='selu' raises in the reference too (base_ranking_model.selu is not a Module subclass)")
+        if self.hparams.activation_func not in ("elu", "relu", "tanh", "sigmoid"):
+            raise NotImplementedError("activation_func=%r: base_ranking_model.py:63-69 knows elu, relu, tanh, sigmoid"
+                                      % self.hparams.activation_func)
         self.feature_size = int(feature_size)
         self._init_shape(list(self.hparams.hidden_layer_sizes))
 
