@@ -230,8 +230,11 @@ typedef struct ultr_update_desc {
    *   they are) - ultr_train_step points it at the communicator's status word, so a rank whose gradient exchange timed
    *   out (or that was told so by a peer) never applies a partly reduced gradient.
    * host_scalars: 16 floats of HOST-mapped pinned memory (device-accessible pointer): block 0 writes scalars_out[0..8) to
-   *   [0..8), then the guard word to [8] and `seq` to [9] (as uint32, system-scope stores, seq LAST).  The host reads the
-   *   loss by spinning on [9] == seq instead of a stream synchronisation + device-to-host copy (the reference's loss.item()). */
+   *   [0..8), then the guard word to [8] and `seq` to [9] and [10] (as uint32, system-scope stores, seq LAST).  The host reads
+   *   the step scalars by spinning on [9] == seq instead of a stream synchronisation + device-to-host copy.  [10] == seq means
+   *   "the LOSS of step seq is in [0]": ultr_train_step raises it EARLIER where it can - single GPU, l2_loss = 0: from the
+   *   weight-gradient launch, as soon as the loss is final, while that step's reduction and update still run (the reference's
+   *   loss.item() then costs no pipeline bubble: the next step queues behind the update on the stream). */
   const uint32_t* guard;
   float* host_scalars;
   uint32_t seq;

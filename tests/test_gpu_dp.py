@@ -74,7 +74,7 @@ def run_engine(algo, feats, ids, y, pg, uniforms):
     """n_steps train steps of the product engine on (feats, ids, y); returns numpy post-state."""
     import torch
     from ultra_pytorch_amd import engine, hip_ops
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", torch.cuda.current_device())
     params0, state0, aux0, _ = initial_state(algo)
     shape = hip_ops.DnnShape(F, HIDDEN, "elu")
     Bl = ids.shape[1]
@@ -101,16 +101,19 @@ def run_engine(algo, feats, ids, y, pg, uniforms):
     return out
 
 
-def worker(rank, world, port, mode, algo, q, extra_env=None):
+def worker(rank, world, port, mode, algo, q, extra_env=None, multi_gpu=False):
+    """multi_gpu: one PHYSICAL GPU per rank (LOCAL_RANK = rank) and the RCCL process group - what bench.py --gpus N and a
+    real data-parallel job run; otherwise every rank shares cuda:0 and the group is gloo (the 1-GPU box of the -m gpu tier)."""
     sys.path.insert(0, ROOT)
+    local = rank if multi_gpu else 0
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK="0", ULTR_DP_COMM=mode, HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      LOCAL_RANK=str(local), ULTR_DP_COMM=mode, HSA_ENABLE_IPC_MODE_LEGACY="0")
     os.environ.update(extra_env or {})
     import torch
     import torch.distributed as dist
     from ultra_pytorch_amd import parallel
-    torch.cuda.set_device(0)
-    r, w, _, pg = parallel.init_process_group_from_env(backend="gloo")
+    torch.cuda.set_device(local)
+    r, w, _, pg = parallel.init_process_group_from_env(backend="nccl" if multi_gpu else "gloo")
     assert (r, w) == (rank, world) and pg is not None
     feed, names_d, names_l, rel = make_global(3)
     if algo == "lambdarank":  # relevance labels
@@ -157,14 +160,33 @@ def oracle_two_steps(algo, feats, ids, y):
     return dict(params=params, state=state, aux=aux, loss=r["loss"])
 
 
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
 @pytest.mark.parametrize("mode", ["peer", "pg"])
 @pytest.mark.parametrize("algo", ALGOS)
 def test_two_rank_step_equals_single_process(mode, algo):
+    two_rank_case(mode, algo, multi_gpu=False)
+
+
+@pytest.mark.parametrize("mode", ["peer", "pg"])
+@pytest.mark.parametrize("algo", ALGOS)
+def test_two_physical_gpus_step_equals_single_process(mode, algo):
+    """The same assertions with one PHYSICAL GPU per rank and the RCCL process group: the exchange kernel's publish / flag /
+    peer-read protocol then really crosses xGMI (on a shared device "peer" memory is local HBM).  Skips on a 1-GPU box."""
+    if _n_gpus() < 2:
+        pytest.skip("needs >= 2 GPUs (found %d)" % _n_gpus())
+    two_rank_case(mode, algo, multi_gpu=True)
+
+
+def two_rank_case(mode, algo, multi_gpu):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + ALGOS.index(algo) * 2 + (0 if mode == "peer" else 1)
-    procs = [ctx.Process(target=worker, args=(r, 2, port, mode, algo, q)) for r in range(2)]
+    port = 29700 + ALGOS.index(algo) * 2 + (0 if mode == "peer" else 1) + (20 if multi_gpu else 0)
+    procs = [ctx.Process(target=worker, args=(r, 2, port, mode, algo, q, None, multi_gpu)) for r in range(2)]
     [p.start() for p in procs]
     got = dict(q.get(timeout=300) for _ in range(2))
     [p.join(120) for p in procs]
@@ -207,16 +229,28 @@ def test_two_rank_step_equals_single_process(mode, algo):
         np.testing.assert_allclose(res["aux"], ref["aux"], atol=1e-5)
 
 
+@pytest.mark.parametrize("world,algo", [(4, "softmax"), (8, "softmax"), (8, "pairdebias")])
+def test_more_physical_gpus_peer_exchange(world, algo):
+    """4 / 8 ranks, one physical GPU each (the driver's scaling run goes to 8).  Skips when the node has fewer GPUs."""
+    if _n_gpus() < world:
+        pytest.skip("needs >= %d GPUs (found %d)" % (world, _n_gpus()))
+    more_ranks_case(min(world, B), algo, multi_gpu=True)
+
+
 @pytest.mark.parametrize("world,algo", [(4, "softmax"), (4, "pairdebias"), (7, "softmax")])
 def test_more_ranks_peer_exchange(world, algo):
+    more_ranks_case(world, algo, multi_gpu=False)
+
+
+def more_ranks_case(world, algo, multi_gpu):
     """The exchange kernel is compiled per world size (2 .. 8 ranks: flag matrix [slice][rank], rank-ordered sums): 4 ranks
     (shards of 2, 2, 2, 1 lists) and 7 ranks (one list each - the scaling run goes to 8) on the one GPU, against the
     single-process step; PairDebias also carries the agreed global batch through uneven shards."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29760 + world + (10 if algo == "pairdebias" else 0)
-    procs = [ctx.Process(target=worker, args=(r, world, port, "peer", algo, q)) for r in range(world)]
+    port = 29760 + world + (10 if algo == "pairdebias" else 0) + (20 if multi_gpu else 0)
+    procs = [ctx.Process(target=worker, args=(r, world, port, "peer", algo, q, None, multi_gpu)) for r in range(world)]
     [p.start() for p in procs]
     got = dict(q.get(timeout=600) for _ in range(world))
     [p.join(180) for p in procs]
@@ -278,3 +312,60 @@ def test_peer_comm_world1_matches_grad_sumsq():
     assert torch.equal(out, g)
     np.testing.assert_allclose(ws[:nsq].cpu().numpy(), ws2[:nsq].cpu().numpy(), rtol=1e-6, atol=1e-7)
     lib.ultr_comm_destroy(h)
+
+
+def timeout_worker(rank, port, q):
+    """rank 0 runs a data-parallel step, rank 1 never publishes: rank 0's peer wait must time out (bounded, 3 s), leave the
+    parameters untouched (the update behind the exchange is guarded by the status word), make read_loss() raise, and raise the
+    status word on rank 1 as well."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0",
+                      ULTR_DP_COMM="peer", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+    from ultra_pytorch_amd import _lib, engine, hip_ops, parallel
+    torch.cuda.set_device(0)
+    _, _, _, pg = parallel.init_process_group_from_env(backend="gloo")
+    dev = torch.device("cuda", 0)
+    feed, names_d, names_l, _ = make_global(3)
+    local = parallel.shard_input_feed(feed, "letor_features", names_d, names_l, L, rank, 2)
+    feats, ids, y = feed_arrays(local, names_d, names_l)
+    params0, state0, _, _ = initial_state("softmax")
+    shape = hip_ops.DnnShape(F, HIDDEN, "elu")
+    eng = engine.StepEngine(shape, ids.shape[1], L, dev, algo="softmax", process_group=pg)
+    assert eng.comm is not None
+    p, st = torch.tensor(params0, device=dev), torch.tensor(state0, device=dev)
+    res = {"rank": rank}
+    dist.barrier()
+    if rank == 0:
+        eng.train_step(p, st, torch.tensor(feats, device=dev), feats.shape[0], torch.tensor(ids, device=dev),
+                       torch.tensor(y, device=dev), ipw_table=torch.linspace(1.0, 3.0, 4, device=dev))
+        try:
+            eng.read_loss()
+            res["raised"] = False
+        except _lib.UltrHipError as ex:
+            res["raised"] = "timed out" in str(ex)
+        torch.cuda.synchronize()
+        res["params_unchanged"] = bool(np.array_equal(p.cpu().numpy(), params0))
+        res["state_unchanged"] = bool(np.array_equal(st.cpu().numpy(), state0))
+        res["status"] = eng.comm.status()
+    dist.barrier()  # rank 1 waits here while rank 0 times out
+    if rank == 1:
+        res["status"] = eng.comm.status()  # raised remotely by rank 0
+    q.put(res)
+    dist.barrier()
+    eng.close()
+    dist.destroy_process_group()
+
+
+def test_comm_timeout_freezes_the_update_and_raises():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=timeout_worker, args=(r, 29795, q)) for r in range(2)]
+    [p.start() for p in procs]
+    got = {r["rank"]: r for r in (q.get(timeout=300) for _ in range(2))}
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert got[0]["raised"] is True and got[0]["params_unchanged"] and got[0]["state_unchanged"]
+    assert got[0]["status"] == -4 and got[1]["status"] == -4  # ULTR_E_COMM_TIMEOUT on BOTH ranks

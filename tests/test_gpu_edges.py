@@ -7,7 +7,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from tests.hipref import HipRun  # noqa: E402
+from tests.hipref import HipRun, dev  # noqa: E402
 
 
 def _step(F, hidden, B, L, feats, ids, labels, ipw, algo="softmax"):
@@ -151,3 +151,24 @@ def test_weight_copy_staleness_guard(monkeypatch):
     model.invalidate_weight_copy()        # ... until the writer says so
     s2 = torch.cat(model.build(x), dim=1)
     torch.testing.assert_close(s2, s0, rtol=1e-5, atol=1e-6)
+
+
+def test_host_mapped_step_report_equals_device_scalars():
+    """StepEngine.read_scalars() (the update kernel's report in host-mapped pinned memory, what the plugins' loss read uses
+    instead of loss.item()) returns exactly the device-side scalars, for consecutive steps, without a stream sync."""
+    from oracle import ultr_oracle as O
+    from ultra_pytorch_amd import engine, hip_ops, synthetic
+    F, hidden, B, L = 24, [16, 8], 12, 6
+    rng = np.random.RandomState(5)
+    shape = hip_ops.DnnShape(F, hidden, "elu")
+    eng = engine.StepEngine(shape, B, L, torch.device("cuda"), algo="softmax")
+    p = dev(O.init_params(F, hidden, seed=3))
+    st = torch.zeros_like(p)
+    for k in range(5):
+        feats, ids, y = synthetic.make_batch(rng, B, L, F)
+        eng.train_step(p, st, dev(feats), feats.shape[0], dev(ids, torch.int32), dev(y))
+        got = eng.read_scalars()
+        torch.cuda.synchronize()
+        want = eng.scalars[:8].cpu().numpy()
+        assert np.array_equal(got, want), (k, got, want)
+        assert np.isfinite(got[0]) and eng.read_loss() == float(want[0])

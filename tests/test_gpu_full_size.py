@@ -7,6 +7,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from tests import margins  # noqa: E402
 from tests.hipref import HipRun, dev  # noqa: E402
 
 CONFIGS = {
@@ -75,6 +76,10 @@ def test_full_size_step_matches_oracle(name):
     print("%s: max |score diff| %.2e, grads: max abs diff / max|g| %.2e, max rel diff over |g| > 1e-3 max|g|: %.2e"
           % (name, np.abs(scores - ref["scores"]).max(), gd.max() / np.abs(ref["grads"]).max(),
              (gd / np.maximum(np.abs(ref["grads"]), 1e-30))[np.abs(ref["grads"]) > 1e-3 * np.abs(ref["grads"]).max()].max()))
+    sel3 = np.abs(ref["grads"]) > 1e-3 * np.abs(ref["grads"]).max()
+    margins.check("full_size/" + name, "scores_max_abs_diff", np.abs(scores - ref["scores"]).max())
+    margins.check("full_size/" + name, "grads_max_abs_diff_over_max_abs_g", gd.max() / np.abs(ref["grads"]).max())
+    margins.check("full_size/" + name, "grads_max_rel_diff_where_g_above_1e-3_max", (gd / np.maximum(np.abs(ref["grads"]), 1e-30))[sel3].max())
     np.testing.assert_allclose(scores, ref["scores"], atol=1e-5)  # measured: <= 2e-6 at every config
     state = None if algo == "dla" else np.zeros_like(params)
     new_params, _, aux2, sc = run.update(state)
@@ -88,6 +93,8 @@ def test_full_size_step_matches_oracle(name):
     # against itself between 1 and 16 threads, and tools/diag_precision.py puts both paths equally far from an fp64 evaluation)
     np.testing.assert_allclose(g * gs, gref, rtol=1e-5, atol=1e-5 * float(np.abs(gref).max()))
     assert abs(sc[1] - ref["norm"]) <= 1e-5 * ref["norm"]
+    margins.check("full_size/" + name, "loss_rel_diff", abs(sc[0] - ref["loss"]) / max(1.0, abs(ref["loss"])))
+    margins.check("full_size/" + name, "grad_norm_rel_diff", abs(sc[1] - ref["norm"]) / ref["norm"])
     if algo in ("pairdebias", "lambdarank"):
         np.testing.assert_allclose(aux2[:L], ref["t_plus"].ravel(), atol=2e-6)
         np.testing.assert_allclose(aux2[L:], ref["t_minus"].ravel(), atol=2e-6)

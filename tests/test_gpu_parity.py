@@ -9,6 +9,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from tests import margins  # noqa: E402
 from tests.hipref import HipRun, dev, load_golden  # noqa: E402
 
 ALGO = {"na": "softmax", "ipw": "softmax", "dla": "dla", "pairdebias": "pairdebias", "lambdarank": "lambdarank",
@@ -20,7 +21,7 @@ TRAIN_CASES = ["na_tiny", "ipw_tiny", "dla_tiny", "dla_sigmoid", "dla_sigmoid_od
 
 
 def act_of(name):
-    return next((a for a in ("relu", "tanh", "sigmoid") if a in name.split("_")), "elu")
+    return {"ipw_relu": "relu", "na_tanh": "tanh", "na_sigmoid": "sigmoid"}.get(name, "elu")  # activation_func of the fixture's model
 
 
 def gtol(g, name=""):
@@ -96,6 +97,10 @@ def test_golden_train_step(name):
         g, tail2 = run.backward()
         np.testing.assert_allclose(tail2, tail, rtol=1e-6, atol=1e-6)
         gref = d[p + "grads"]
+        if name.endswith("_odd"):  # widened band (gtol): keep the measured figure visible
+            gdiff = np.abs(g * gs + lam * d[p + "pre_params"] - gref)
+            margins.check("golden/" + name, "s%d_grads_max_abs_diff_over_max_abs_g" % t, gdiff.max() / max(1.0, float(np.abs(gref).max())))
+            margins.check("golden/" + name, "s%d_scores_max_abs_diff" % t, np.abs(scores - d[p + "scores"]).max())
         np.testing.assert_allclose(g * gs + lam * d[p + "pre_params"], gref, err_msg="grads", **gtol(gref, name))
         # --- update
         state = d[p + "pre_adagrad"] if (p + "pre_adagrad") in d.files else None

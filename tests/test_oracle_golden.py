@@ -39,7 +39,7 @@ def check_common(d, m, t, r, atol_scores=1e-5, clip_skipped=False):
 
 
 def act_of(name):
-    return next((a for a in ("relu", "tanh", "sigmoid") if a in name), "elu")
+    return {"ipw_relu": "relu", "na_tanh": "tanh", "na_sigmoid": "sigmoid"}.get(name, "elu")  # activation_func of the fixture's model
 
 
 @pytest.mark.parametrize("name", ["na_tiny", "ipw_tiny", "ipw_odd", "na_linear", "ipw_relu", "ipw_sgd", "ipw_cfg2", "na_tanh",

@@ -500,6 +500,9 @@ extern "C" int ultr_trace_read(unsigned long long* host_out) {
 // Forward
 // ------------------------------------------------------------------------------------------------
 // prefetch depth (trips of 32 W rows) of the forward GEMM pipeline
+#ifndef FB_L2PF
+#define FB_L2PF 0  // dnn_fb_kernel: warm the XCD's L2 with the weights from the prologue (A/B: tools/ab_build.sh)
+#endif
 #ifndef FWD_D
 #define FWD_D 2
 #endif
@@ -1673,6 +1676,25 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
     if (tid < R) sm_ds[tid] = 0.f;
     if (lane < 2) sm_lt[wave * 2 + lane] = 0.f;
   }
+#if FB_L2PF
+  // Warm THIS XCD's L2 with the weights: a launch starts with cold L2s (they are invalidated at every kernel boundary;
+  // the weights sit in the memory-side cache), and the workgroups of an XCD stream the same matrices in lockstep, so
+  // without this every trip of every GEMM phase waits for a first touch beyond L2.  Workgroup b runs on XCD b % 8: the
+  // gridDim / 8 workgroups of an XCD each touch a different 1 / (gridDim / 8) of [k-major copy | parameters], one 4-byte
+  // load per 128-byte line (64 lines per wave instruction), issued behind the prologue's own loads and never waited for
+  // before the end of the kernel.
+  float pf0, pf1;
+  {
+    const int nslot = ((int)gridDim.x + 7) >> 3, slot = (int)blockIdx.x >> 3;
+    const int l_wt = (int)((p.wt_total * 4 + 127) >> 7), l_p = (int)((p.P * 4 + 127) >> 7);
+    const int per_wt = (l_wt + nslot - 1) / nslot, per_p = (l_p + nslot - 1) / nslot;
+    const int e = wave * 64 + lane;
+    const int lw = slot * per_wt + e, lp = slot * per_p + e;
+    const Src s_wt = make_src(wt, p.wt_total), s_p = make_src(params, p.P);
+    pf0 = buf_ld1(s_wt, (e < per_wt && lw < l_wt) ? (unsigned)lw * 128u : ULTR_OOB);
+    pf1 = buf_ld1(s_p, (e < per_p && lp < l_p) ? (unsigned)lp * 128u : ULTR_OOB);
+  }
+#endif
   // loss inputs of the wave's first list (lane = position), in flight during the whole forward
   const int li0 = wave;  // list index inside the block handled by this wave (then + NW)
   const bool lact0 = li0 < LPB && b_first + li0 < B && lane < L;
@@ -2036,6 +2058,9 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
     lds_barrier();
   }
   finalize(jlow);
+#if FB_L2PF
+  asm volatile("" ::"v"(pf0), "v"(pf1));  // the warming loads are only "used" here
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2062,7 +2087,8 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
                                                         const int32_t* __restrict__ docids, int B, int L,
                                                         const float* __restrict__ saved, float* __restrict__ ws,
                                                         int vecf, float* __restrict__ grads,
-                                                        const float* __restrict__ loss_part, int n_loss_part, int tail) {
+                                                        const float* __restrict__ loss_part, int n_loss_part, int tail,
+                                                        EarlyReport er) {
   // ONE dynamic LDS array: [4][64*64] cross-wave reduction | [4][64] bias partials | [rows_per_split] doc ids
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float (*red)[64 * 64] = reinterpret_cast<float (*)[64 * 64]>(smem);
@@ -2091,13 +2117,33 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
     const int beg = bp.lf_chunks > 0 ? c * bp.lf_len : 0;
     const int cnt = bp.lf_chunks > 0 ? (n_loss_part - beg < bp.lf_len ? n_loss_part - beg : bp.lf_len) : n_loss_part;
     float* out = bp.lf_chunks > 0 ? ws + bp.lfold_off + (int64_t)c * tail : grads + p.P;
+    float head = 0.f;  // group 0, lanes 0..3: loss_sum, D, loss2_sum, D2 of the whole batch
     for (int t0 = 0; t0 < tail; t0 += 64) {
       const int t = t0 + lane;
       smem[grp * 64 + lane] = (t < tail && loss_part != nullptr) ? strided_sum(loss_part + (int64_t)beg * tail + t, tail, cnt, grp) : 0.f;
       lds_barrier();
-      if (grp == 0 && t < tail && loss_part != nullptr)
-        out[t] = ((smem[lane] + smem[64 + lane]) + smem[128 + lane]) + smem[192 + lane];
+      if (grp == 0 && t < tail && loss_part != nullptr) {
+        const float v = ((smem[lane] + smem[64 + lane]) + smem[128 + lane]) + smem[192 + lane];
+        out[t] = v;
+        if (t0 == 0) head = v;
+      }
       lds_barrier();
+    }
+    if (er.host != nullptr && grp == 0 && loss_part != nullptr) {
+      // early loss report (EarlyReport, ultr_plan.h): the same expressions as update_body, so the update kernel's later
+      // report of the same step carries the same bits
+      const float loss_sum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(head), 0));
+      const float D = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(head), 1));
+      const float loss2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(head), 2));
+      const float D2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(head), 3));
+      float loss = loss_sum / D;
+      if (er.algo == ULTR_ALGO_DLA) loss = loss2 / D2 + er.rlw * (loss_sum / D);
+      else if (er.algo == ULTR_ALGO_PAIRDEBIAS) loss = loss_sum;
+      if (lane == 0) {
+        __hip_atomic_store(er.host, loss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(er.host) + 10, er.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
     return;
   }
@@ -3006,12 +3052,14 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
     e = av ? set_lds(dnn_wgrad_kernel<true>, wlds) : set_lds(dnn_wgrad_kernel<false>, wlds);
     if (e != hipSuccess) return (int)e;
     const dim3 wgrid(bp.wgrad_blocks + bp.vred_blocks + (bp.lf_chunks > 0 ? bp.lf_chunks : 1));
+    EarlyReport er = g_ultr_early;
+    if (bp.lf_chunks > 0) er.host = nullptr;  // two-level fold of > 1024 partials: the loss is only final in the reduction launch
     if (av)
       ULTR_LAUNCH(prof, dnn_wgrad_kernel<true>, wgrid, dim3(256), wlds, st, p, bp, params, features, n_docs,
-                         docids, (int)batch, (int)list_size, (const float*)saved, ws, (vm >> 31) & 1, grads, lp, nlp, tail);
+                         docids, (int)batch, (int)list_size, (const float*)saved, ws, (vm >> 31) & 1, grads, lp, nlp, tail, er);
     else
       ULTR_LAUNCH(prof, dnn_wgrad_kernel<false>, wgrid, dim3(256), wlds, st, p, bp, params, features, n_docs,
-                         docids, (int)batch, (int)list_size, (const float*)saved, ws, (vm >> 31) & 1, grads, lp, nlp, tail);
+                         docids, (int)batch, (int)list_size, (const float*)saved, ws, (vm >> 31) & 1, grads, lp, nlp, tail, er);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }

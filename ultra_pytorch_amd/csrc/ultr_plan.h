@@ -150,6 +150,20 @@ int ultr_fused_step_softmax(const ultr_dnn_desc* d, const float* params, const f
 struct ultr_comm;
 const uint32_t* ultr_comm_status_word(const ultr_comm* c);
 
+// Early loss report (single GPU, l2_loss = 0): the spare workgroup of the weight-gradient launch that folds the loss partials
+// into the step tail also writes the step's loss to the host-mapped report (ultr_update_desc::host_scalars) - [0] = loss, then
+// [10] = seq - i.e. as soon as the loss is FINAL (behind forward + loss), while the weight gradients, the reduction and the
+// update of the same step are still running.  The host's read of the loss (the reference's loss.item()) then returns ~20 us
+// before the step's last kernel ends and the next step is queued behind it without a bubble.  ultr_train_step sets this
+// around its backward call; every other caller leaves host == nullptr (the update kernel's report is the only one then).
+struct EarlyReport {
+  float* host;
+  uint32_t seq;
+  int algo;
+  float rlw;
+};
+extern thread_local EarlyReport g_ultr_early;  // ultr_step.hip
+
 #define ULTR_TAIL_FIXED 4
 __host__ __device__ static inline int64_t ultr_tail_len(int L) { return ULTR_TAIL_FIXED + 2 * (int64_t)L; }
 

@@ -28,9 +28,25 @@ static int finish_step(const ultr_step_args* a, void* stream) {
   return ultr_apply_update(a->upd, a->desc, a->params, a->wt, a->state, a->grads, a->aux, a->bwd_ws, a->scalars, stream);
 }
 
+thread_local EarlyReport g_ultr_early = {nullptr, 0u, 0, 1.0f};
+
+namespace {
+// early loss report for the backward call(s) of this step (EarlyReport, ultr_plan.h): only where the local loss sums ARE the
+// batch's (no data-parallel exchange) and the reported loss has no L2 term (that one is formed by the update launch)
+struct EarlyScope {
+  explicit EarlyScope(const ultr_step_args* a) {
+    const ultr_update_desc* u = a->upd;
+    const bool ok = u->host_scalars != nullptr && a->comm == nullptr && !a->skip_update && u->l2_loss == 0.f;
+    g_ultr_early = {ok ? u->host_scalars : nullptr, u->seq, u->algo, u->ranker_loss_weight};
+  }
+  ~EarlyScope() { g_ultr_early.host = nullptr; }
+};
+}  // namespace
+
 extern "C" int ultr_train_step(const ultr_step_args* a, void* stream) {
   if (!a || !a->desc || !a->upd) return ULTR_E_BADARG;
   ultr_prof_tick();
+  EarlyScope early(a);
   int rc;
   if (a->upd->algo == ULTR_ALGO_SOFTMAX) {
     // small batches (NA / IPW): forward + loss + backward as ONE launch when the shape qualifies

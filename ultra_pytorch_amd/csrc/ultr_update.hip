@@ -42,6 +42,8 @@ __device__ __forceinline__ void host_report(const ultr_update_desc& u, const flo
   __hip_atomic_store(reinterpret_cast<uint32_t*>(hs) + 8, status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __hip_atomic_store(reinterpret_cast<uint32_t*>(hs) + 9, u.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // [10]: "the loss of step seq is in [0]" - already raised by the weight-gradient launch when an early report was possible
+  __hip_atomic_store(reinterpret_cast<uint32_t*>(hs) + 10, u.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // guard word set (a timed-out gradient exchange on this rank or on a peer): the launch must change nothing.  Block 0 still

@@ -181,8 +181,26 @@ class StepEngine:
                                     "later updates were NOT applied - restart from the last checkpoint")
         return self._hs_f[:8].copy()
 
-    def read_loss(self):
-        return float(self.read_scalars()[0])
+    def read_loss(self, timeout_s=60.0):
+        """The loss of the last queued step (the reference's `loss.item()`).  Returns as soon as the loss is FINAL: on one GPU
+        that is behind forward + loss (the weight-gradient launch reports it, include/ultr_hip.h: host_scalars[10]), while the
+        step's reduction and update are still running - later work simply queues behind them on the stream."""
+        if not self._host_report:
+            return float(self.read_scalars()[0])
+        seq, u, spins, t0 = self._seq, self._hs_u, 0, None
+        if seq == 0:
+            raise RuntimeError("read_loss() before the first train_step()")
+        while int(u[10]) != seq:
+            spins += 1
+            if spins & 0x3FF == 0:
+                now = time.perf_counter()
+                t0 = now if t0 is None else t0
+                if now - t0 > timeout_s:
+                    raise _lib.UltrHipError("no loss report from the GPU within %.0f s (step %d)" % (timeout_s, seq))
+        if int(u[9]) == seq and int(u[8]) != 0:  # the full report is in as well and carries a communication failure
+            raise _lib.UltrHipError("data-parallel gradient exchange timed out on some rank (ULTR_E_COMM_TIMEOUT): this and all "
+                                    "later updates were NOT applied - restart from the last checkpoint")
+        return float(self._hs_f[0])
 
     def close(self):
         if self._own_comm and self.comm is not None:
