@@ -36,6 +36,11 @@ if os.environ.get("ULTR_NO_FUSED_FB", "0") != "1":
               "fin+GEMM0'=%d sync=%d rowcol0=%d  total(0->27)=%d" % (blk * 32, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4],
                                                                t[6] - t[5], t[16] - t[6], t[19] - t[18], t[21] - t[19], t[22] - t[21],
                                                                t[23] - t[22], t[25] - t[23], t[26] - t[25], t[27] - t[26], t[27] - t[0]))
+    for blk in range(3):
+        t = a[blk].astype(np.int64)
+        print("fused wg %3d detail: prologue: start->params in LDS=%d ->features in LDS=%d ->barrier=%d | LN0: ->row sums=%d ->var=%d "
+              "->written=%d ->barrier=%d | rowcol1 done->kernel end=%d  total(0->13)=%d"
+              % (blk * 32, t[28] - t[0], t[29] - t[28], t[1] - t[29], t[30] - t[1], t[31] - t[30], t[7] - t[31], t[2] - t[7], t[13] - t[23], t[13] - t[0]))
     for blk in range(0, 7, 1):
         t = a[blk].astype(np.int64)
         print("wgrad wg %3d: preamble=%d mainloop=%d ldswrite+sync=%d reduce+store=%d total=%d" % (blk * 32, t[9] - t[8], t[10] - t[9], t[11] - t[10], t[12] - t[11], t[12] - t[8]))

@@ -401,6 +401,75 @@ struct GemmPipe {
   }
 };
 
+// The same contraction over a FRAGMENT-MAJOR copy of the weights (DnnPlan::wsf_off / wsb_off, ultr_sw_index): a wave owns
+// a chunk of 32 output columns (two 16-column MFMA tiles); one trip = 32 steps of the contraction = FOUR buffer_load_dwordx4,
+// each 1 KiB contiguous per wave and carrying two steps x two column tiles per lane.  Same products in the same order as
+// GemmPipe<1, 2, D> over the k-major copy (bitwise identical results, tools/swz_ubench.hip); the vector L1 returns 16-byte
+// lanes at twice the rate of 8-byte ones and half as many load instructions are issued.
+template <int D>
+struct PipeSw {
+  float4 b[D][4];
+  unsigned of;
+  int left;
+  template <int S>
+  __device__ __forceinline__ void fetch(const Src& W) {
+    const bool ok = left > 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) b[S][u] = buf_ld4(W, ok ? (of + (unsigned)u * 1024u) : ULTR_OOB);
+    --left;
+    of += 4096u;
+  }
+  // trips [t0, t0 + n) of chunk `chunk` (ntrips per chunk in the matrix); !valid => no traffic
+  __device__ __forceinline__ void begin(const Src& W, int chunk, int ntrips, int t0, int n, bool valid, int lane) {
+    of = (((unsigned)chunk * (unsigned)ntrips + (unsigned)t0) * 256u + (unsigned)lane) * 16u;
+    left = valid ? n : 0;
+    if constexpr (D > 1) fetch<0>(W);
+    if constexpr (D > 2) fetch<1>(W);
+    if constexpr (D > 3) fetch<2>(W);
+    static_assert(D >= 2 && D <= 4, "pipeline depth");
+  }
+  template <int S>
+  __device__ __forceinline__ void consume(const float* __restrict__ ap, f32x4 (&acc)[2]) {
+    const float4 a0 = ld4(ap), a1 = ld4(ap + 16);
+    const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc[0] = mfma16(av[2 * u], b[S][u].x, acc[0]);
+      acc[1] = mfma16(av[2 * u], b[S][u].y, acc[1]);
+      acc[0] = mfma16(av[2 * u + 1], b[S][u].z, acc[0]);
+      acc[1] = mfma16(av[2 * u + 1], b[S][u].w, acc[1]);
+    }
+  }
+  // As = A tile in LDS (zero beyond the real contraction length up to a multiple of 32); consumes the n trips begun above
+  __device__ __forceinline__ void run(const float* __restrict__ As, int lda, const Src& W, int t0, int n, f32x4 (&acc)[2], int lane) {
+    const int i = lane & 15, q = lane >> 4;
+    const float* ap = As + i * lda + 32 * t0 + 4 * q;
+    auto step = [&](auto uc) {
+      constexpr int U = decltype(uc)::value;
+      fetch<(U + D - 1) % D>(W);
+      __builtin_amdgcn_sched_barrier(0);
+      consume<U>(ap, acc);
+      ap += 32;
+    };
+    int t = 0;
+    for (; t + D <= n; t += D) {
+      step(std::integral_constant<int, 0>());
+      step(std::integral_constant<int, 1>());
+      if constexpr (D > 2) step(std::integral_constant<int, 2>());
+      if constexpr (D > 3) step(std::integral_constant<int, 3>());
+    }
+    if (t < n) { consume<0>(ap, acc); ap += 32; }
+    if constexpr (D > 2) if (t + 1 < n) { consume<1>(ap, acc); ap += 32; }
+    if constexpr (D > 3) if (t + 2 < n) { consume<2>(ap, acc); ap += 32; }
+  }
+};
+#ifndef FB_SWD
+#define FB_SWD 2  // trips in flight per wave of the fragment-major pipeline (tools/swz_ubench.hip: 2, 3, 4 within 4 %)
+#endif
+#ifndef FB_SW
+#define FB_SW 1   // dnn_fb_kernel streams the fragment-major copies when the plan has them (0: the k-major / row-major paths)
+#endif
+
 // forward epilogue of the last contraction slice: (+ partial sums of earlier slices) + bias, activation; to LDS
 // (next layer's input) and, when training, to HBM — 4*CT-byte stores, the lane owns CT consecutive output columns
 template <int RT, int CT>
@@ -500,6 +569,19 @@ extern "C" int ultr_trace_read(unsigned long long* host_out) {
 // Forward
 // ------------------------------------------------------------------------------------------------
 // prefetch depth (trips of 32 W rows) of the forward GEMM pipeline
+#ifndef WG_WT
+#define WG_WT 1   // dnn_wgrad_kernel: slabs leave with streaming stores (config 2: step 53.6 -> 53.1 us)
+#endif
+#ifndef RED_WT
+#define RED_WT 0  // grad_reduce_kernel: the flat gradient leaves with streaming stores
+#endif
+#ifndef FB_KAPF
+#define FB_KAPF 1  // dnn_fb_kernel: pull the kernel-argument segment into L2 with one vector load at the top (-0.2 us)
+#endif
+#ifndef FB_WT
+#define FB_WT 1  // dnn_fb_kernel: operands for the weight-gradient launch (u_j / xhat_0, dz_j) leave with write-through stores
+                 // (1: sc1 buffer stores, 2: nt; 0: plain) - config 2: step 55.4 -> 53.4 (sc1) / 53.6 (nt) us
+#endif
 #ifndef FB_L2PF
 #define FB_L2PF 0  // dnn_fb_kernel: warm the XCD's L2 with the weights from the prologue (A/B: tools/ab_build.sh)
 #endif
@@ -1636,6 +1718,19 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
   float* vslab = ws + bp.vslab_off + (int64_t)blockIdx.x * bp.vlen;
   const int top = p.nl - 1;
   TRACE_STAMP(0);
+#if FB_KAPF
+  // The plans travel as kernel arguments (~2.7 KB = 43 cache lines in HBM) and are read with scalar loads at the top of every
+  // layer of both loops (runtime-indexed records): each first touch of a line was a ~2k-cycle miss on the critical path of
+  // every workgroup.  One vector load per workgroup (lane = line) pulls the whole segment into the XCD's L2 from the first
+  // cycle; the scalar-cache misses later cost an L2 hit.  The value is never used (kept live to the end of the kernel).
+  float ka_pf = 0.f;
+  if (wave == 0) {
+    const float* ka = (const float*)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int KA_LINES = (int)((sizeof(DnnPlan) + sizeof(BwdPlan) + sizeof(FusedSoftmax) + 96 + 63) / 64);
+    static_assert(KA_LINES <= 64, "one lane per kernel-argument cache line");
+    ka_pf = ka[(lane < KA_LINES ? lane : 0) * 16];
+  }
+#endif
 
   // ---- prologue: ids, loss inputs of this wave's list, parameter image, feature rows - all issued back to back -----
   {
@@ -1666,6 +1761,7 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
       const int o = (tid + u * NT) * 4;
       if (o < p.pv_total) st4(PV + o, pvr[u]);
     }
+    TRACE_STAMP(28);
 #pragma unroll
     for (int k = 0; k < RPW; ++k)
 #pragma unroll
@@ -1673,6 +1769,7 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
         const int c = lane * 4 + 256 * u;
         if (c < F) st4(XSall + (wave + NW * k) * ld + c, fr[k][u]);
       }
+    TRACE_STAMP(29);
     if (tid < R) sm_ds[tid] = 0.f;
     if (lane < 2) sm_lt[wave * 2 + lane] = 0.f;
   }
@@ -1748,6 +1845,7 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
         }
       }
       wave_sum_n<RPW>(s);
+      if (j == 0) TRACE_STAMP(30);
       float v[RPW], t[RPW + 1];
 #pragma unroll
       for (int q = 0; q < RPW; ++q) {
@@ -1766,6 +1864,7 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
         }
       }
       wave_sum_n<RPW>(v);
+      if (j == 0) TRACE_STAMP(31);
       if (last) {
         t[RPW] = 0.f;
 #pragma unroll
@@ -1779,6 +1878,10 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
         if (!last) {
           // the weight gradients' operand goes to HBM from here: u_j, or xhat_0 for the layer-0 shortcut
           float* wop = saved + p.sv_x[j] + (n0 + r) * K;
+#if FB_WT == 1
+          const Src svs = make_src(saved, p.sv_total);
+          const unsigned wop_b = (unsigned)((p.sv_x[j] + (n0 + r) * K) * 4);
+#endif
           const bool xhat_only = (j == 0) && bp.l0g != 0;
 #pragma unroll
           for (int u = 0; u < XC; ++u) {
@@ -1789,7 +1892,13 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
               const float4 uu = make_float4(xh.x * g4[u].x + b4[u].x, xh.y * g4[u].y + b4[u].y, xh.z * g4[u].z + b4[u].z,
                                             xh.w * g4[u].w + b4[u].w);
               st4(UZ + r * ld + c, uu);
+#if FB_WT == 2
+              if (c < K && r < rows_valid) st4_stream(wop + c, xhat_only ? xh : uu);
+#elif FB_WT
+              if (c < K && r < rows_valid) coh_st4(svs, wop_b + (unsigned)c * 4u, xhat_only ? xh : uu);
+#else
               if (c < K && r < rows_valid) st4(wop + c, xhat_only ? xh : uu);
+#endif
             }
           }
         }
@@ -1808,6 +1917,7 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
           }
         }
       }
+      if (j == 0) TRACE_STAMP(7);
     }
     lds_barrier();
     TRACE_STAMP(2 + 2 * j);
@@ -1818,7 +1928,21 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
       const Src Wt = make_src(wt + lay.wt_off, (int64_t)K * M);
       const int nch = lay.nch, ksplit = lay.ksplit, klen = lay.klen;
       GemmPipe<RT, 2, FWD_D, 0> pipe;
-      if (ksplit == 1) {
+      if (FB_SW && p.sw_ok && ksplit == 1) {
+        const int ntr = K32 >> 5;
+        const Src Ws = make_src(wt + p.wsf_off[j], (int64_t)K32 * M);
+        PipeSw<FB_SWD> ps;
+        const int c0 = wave * 32;
+        ps.begin(Ws, wave, ntr, 0, ntr, c0 < M, lane);
+        for (int cc = c0; cc < M; cc += NW * 32) {
+          f32x4 acc[RT][2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) acc[0][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          ps.run(UZ, ld, Ws, 0, ntr, acc[0], lane);
+          if (cc + NW * 32 < M) ps.begin(Ws, (cc + NW * 32) >> 5, ntr, 0, ntr, true, lane);
+          finish_fwd_nn<RT, 2>(acc, Y, ld, M, cc, lane, bias, p.act, gout, rows_valid);
+        }
+      } else if (ksplit == 1) {
         const int c0 = wave * 32;
         pipe.begin(Wt, M, 0, K, c0, c0 < M, 0, lane);
         for (int cc = c0; cc < M; cc += NW * 32) {
@@ -1934,7 +2058,21 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
       finalize(j + 1);
       const Src Wsrc = make_src(params + p.off_w[j], (int64_t)M * K);
       const int nch = p.bwd_nch[j], msplit = p.bwd_msplit[j], mode = p.bwd_mode[j];
-      if (mode == 1) {
+      if (FB_SW && p.sw_ok && j >= 1) {
+        // du_j = dz_j . W_j over the fragment-major copy of W_j: 32-column chunks of K over the whole contraction M
+        const int ntr = (M + 31) >> 5;
+        const Src Wb = make_src(wt + p.wsb_off[j], (int64_t)round_up(M, 32) * round_up(K, 32));
+        PipeSw<FB_SWD> ps;
+        ps.begin(Wb, wave, ntr, 0, ntr, wave * 32 < K, lane);
+        for (int ch = wave; ch * 32 < K; ch += NW) {
+          f32x4 acc[RT][2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) acc[0][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          ps.run(DZ, ldz, Wb, 0, ntr, acc[0], lane);
+          if ((ch + NW) * 32 < K) ps.begin(Wb, ch + NW, ntr, 0, ntr, true, lane);
+          store_nn<RT, 2>(acc, DU, ldu, K, ch * 32, lane, false);
+        }
+      } else if (mode == 1) {
         for (int ch = wave; ch * 32 < K; ch += NW) {
           f32x4 acc[RT][2];
 #pragma unroll
@@ -2047,7 +2185,13 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
               dz.z = rstd[k] * (gx.z - s1 - (x4.z - mean[k]) * rstd[k] * s2) * act_grad_from_out(x4.z, p.act);
               dz.w = rstd[k] * (gx.w - s1 - (x4.w - mean[k]) * rstd[k] * s2) * act_grad_from_out(x4.w, p.act);
               st4(DZ + r * ldz + c, dz);
+#if FB_WT == 2
+              if (r < rows_valid) st4_stream(dzg + (n0 + r) * K + c, dz);
+#elif FB_WT
+              if (r < rows_valid) coh_st4(make_src(ws, bp.total), (unsigned)((bp.dz_off[j - 1] + (n0 + r) * K + c) * 4), dz);
+#else
               if (r < rows_valid) st4(dzg + (n0 + r) * K + c, dz);
+#endif
             }
           }
           for (int c = K + lane; c < round_up(K, 32); c += 64) DZ[r * ldz + c] = 0.f;
@@ -2058,6 +2202,10 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
     lds_barrier();
   }
   finalize(jlow);
+  TRACE_STAMP(13);
+#if FB_KAPF
+  asm volatile("" ::"v"(ka_pf));
+#endif
 #if FB_L2PF
   asm volatile("" ::"v"(pf0), "v"(pf1));  // the warming loads are only "used" here
 #endif
@@ -2372,7 +2520,11 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
     if (m < M && k < K) {
       float* dst = slab + (int64_t)m * K + k;
       if (vec && k + 3 < K) {
+#if WG_WT
+        st4_stream(dst, s);
+#else
         st4(dst, s);
+#endif
       } else {
         dst[0] = s.x;
         if (k + 1 < K) dst[1] = s.y;
@@ -2445,7 +2597,11 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(RedPlan rp, int64_t P,
       while (s + 1 < rp.nseg && e >= rp.seg[s + 1].off) ++s;
       const RedSeg sg = rp.seg[s];
       g = full_sum(ws + sg.base + (e - sg.off), sg.stride, sg.nparts);
+#if RED_WT
+      st1_stream(grads + e, g);
+#else
       grads[e] = g;
+#endif
     }
     // the product must be ROUNDED before the first cross-lane add: left alone (and with __fmul_rn as well) hipcc turns
     // `g * g + shuffled(g * g)` into an fma in this variant and not in the other - one-ulp different partials, a different clip
@@ -2596,6 +2752,25 @@ bool ultr_make_dnn_plan(const ultr_dnn_desc* d, int64_t N, DnnPlan* p) {
   pv += p->K[p->nl - 1];
   p->pv_total = (pv + 3) & ~3;
   p->wt_total = wt + p->pv_total;
+  {  // fragment-major copies (DnnPlan::wsf_off / wsb_off)
+    bool ok = p->nl >= 2;
+    for (int j = 0; j < p->nl - 1; ++j) ok = ok && (p->M[j] % 32 == 0);
+    p->sw_ok = ok ? 1 : 0;
+    int64_t o = (p->wt_total + 255) & ~(int64_t)255;  // 1 KiB aligned
+    p->ws_begin = o;
+    if (ok) {
+      for (int j = 0; j < p->nl - 1; ++j) {
+        const int64_t n = (int64_t)round_up(p->K[j], 32) * round_up(p->M[j], 32);
+        p->wsf_off[j] = o;
+        o += n;
+        if (j >= 1) {
+          p->wsb_off[j] = o;
+          o += n;
+        }
+      }
+      p->wt_total = o;
+    }
+  }
   int64_t sv = 0;
   for (int j = 1; j < p->nl; ++j) {
     p->sv_x[j] = sv;
@@ -2842,7 +3017,12 @@ __global__ __launch_bounds__(256) void wt_build_kernel(DnnPlan p, const float* _
     const int64_t r = e - p.off_w[j];
     if (r >= 0 && r < (int64_t)p.M[j] * p.K[j]) {
       const int m = (int)(r / p.K[j]), k = (int)(r % p.K[j]);
-      wt[p.wt_off[j] + (int64_t)k * p.M[j] + m] = params[e];
+      const float v = params[e];
+      wt[p.wt_off[j] + (int64_t)k * p.M[j] + m] = v;
+      if (p.sw_ok) {
+        wt[p.wsf_off[j] + ultr_sw_index(m, k, (p.K[j] + 31) >> 5)] = v;
+        if (j >= 1) wt[p.wsb_off[j] + ultr_sw_index(k, m, (p.M[j] + 31) >> 5)] = v;
+      }
       return;
     }
   }
@@ -2852,6 +3032,10 @@ extern "C" int ultr_dnn_build_wt(const ultr_dnn_desc* d, const float* params, fl
   DnnPlan p;
   if (!params || !wt || !ultr_make_dnn_plan(d, 0, &p)) return ULTR_E_BADARG;
   const int64_t n = p.P + 4;
+  if (p.sw_ok && p.wt_total > p.ws_begin) {  // the fragment-major copies are padded to whole 32 x 32 blocks: zeros there
+    const hipError_t e = hipMemsetAsync(wt + p.ws_begin, 0, (size_t)(p.wt_total - p.ws_begin) * sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+  }
   hipLaunchKernelGGL(wt_build_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, params, wt);
   return (int)hipGetLastError();
 }

@@ -28,7 +28,18 @@ struct DnnPlan {
   int pv_off[ULTR_MAXL];  // offset of layer j's gamma inside the image
   int pv_wlast;           // offset of the scorer's weight row
   int pv_total;           // floats, padded to a multiple of 4
-  int64_t wt_total;       // weights + image
+  int64_t wt_total;       // weights + image + fragment-major copies
+  // ... followed by the FRAGMENT-MAJOR ("swizzled") copies the fused small-batch kernel streams (sw_ok: every hidden width a
+  // multiple of 32): a wave's MFMA B operands of one 32-deep trip of the contraction are four 1-KiB-contiguous
+  // buffer_load_dwordx4 - [chunk of 32 output columns][trip of 32][u = 0..3][lane = 16 q + i][ka.c0 ka.c1 kb.c0 kb.c1] with
+  // ka = 32 trip + 16 (u / 2) + 4 q + 2 (u % 2), kb = ka + 1, columns 32 chunk + 2 i + {0, 1} (ultr_sw_index).  The k-major
+  // copy gives 16 lanes x 8 B x 4 rows per instruction; measured on the forward product of config 2's second layer
+  // (tools/swz_ubench.hip): 6.25 -> 4.65 us, with the matrix cores alone at 3.9.
+  //   wsf_off[j]: W_j^T (contraction k, output m), j < nl-1        - forward  Y = U . W_j^T
+  //   wsb_off[j]: W_j   (contraction m, output k), 1 <= j < nl-1   - dgrad    du = dz . W_j
+  int64_t wsf_off[ULTR_MAXL], wsb_off[ULTR_MAXL];
+  int64_t ws_begin;       // first float of the fragment-major region (zero-filled by ultr_dnn_build_wt: it is padded)
+  int sw_ok;
   int maxdim;             // max over all K_j (and M_j)
   // work map of the update kernel when it maintains the copies above: 16x16 tiles over every hidden W_j (a tile is
   // read row-major and written k-major through an LDS transpose: 64-byte segments both ways instead of a 4-byte
@@ -57,6 +68,14 @@ struct DnnPlan {
   int64_t sv_rstd[ULTR_MAXL];  // [N]
   int64_t sv_total;
 };
+
+// position of element (output column c, contraction index k) of a fragment-major matrix with `ntrips` = ceil(Kc / 32) trips
+__host__ __device__ inline int64_t ultr_sw_index(int c, int k, int ntrips) {
+  const int chunk = c >> 5, i = (c & 31) >> 1, e_lo = c & 1;
+  const int trip = k >> 5, kk = k & 31, h = kk >> 4, r = kk & 15, q = r >> 2, s = r & 3;
+  const int u = 2 * h + (s >> 1), e_hi = s & 1;
+  return ((((int64_t)chunk * ntrips + trip) * 4 + u) * 64 + (q * 16 + i)) * 4 + (e_hi * 2 + e_lo);
+}
 
 // position of parameter e inside the PV image (DnnPlan::pv_*), or -1 when e is a hidden Linear weight
 __host__ __device__ inline int ultr_pv_index(const DnnPlan& p, int64_t e) {

@@ -14,6 +14,9 @@
 #include "ultr_plan.h"
 #include "ultr_prof.h"
 
+#ifndef UPD_WT
+#define UPD_WT 0  // parameters / optimizer state / weight copies leave with streaming stores
+#endif
 __device__ __forceinline__ float block_sum256(float v, float* sm) {
   v = wave_sum(v);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -159,8 +162,13 @@ __device__ __forceinline__ void update_body(const ultr_update_desc& u, const Dnn
       g *= coef;
       float s_new = s_old;
       const float pn = opt_step(p_old, g, &s_new, u.optimizer, stateless || state == nullptr, u.learning_rate, u.adagrad_eps);
+#if UPD_WT
+      st1_stream(params + e, pn);
+      if (state != nullptr && !stateless && u.optimizer != ULTR_OPT_SGD) st1_stream(state + e, s_new);
+#else
       params[e] = pn;
       if (state != nullptr && !stateless && u.optimizer != ULTR_OPT_SGD) state[e] = s_new;
+#endif
       p_new_a[k] = pn;
     }
   }
@@ -325,6 +333,24 @@ __global__ __launch_bounds__(256) void update_tiled_kernel(ultr_update_desc u, D
       if (j < 0) continue;
       const int k = k0[q] + r, m = m0[q] + c;  // transposed ownership
       if (k < dp.K[j] && m < dp.M[j]) wt[dp.wt_off[j] + (int64_t)k * dp.M[j] + m] = tile[q][c][r];
+      if (dp.sw_ok && tid < 128) {
+        // the fragment-major copies (DnnPlan::wsf_off / wsb_off): the 16 x 16 tile is 64 float4 pieces of each, 8 pieces
+        // (128 bytes) contiguous; threads 0..63 write the forward copy, 64..127 the dgrad copy (layers >= 1).  Elements
+        // beyond K are zero in the tile (and M is a multiple of 32), as the padding of the copies requires.
+        const int t6 = tid & 63, uu = t6 >> 5, qq = (t6 >> 3) & 3, ii = t6 & 7;
+        const int a = 4 * qq + 2 * uu, b = 2 * ii;  // a: contraction offset inside the tile, b: output-column offset
+        if (tid < 64) {
+          const int h = (k0[q] & 31) >> 4, ntr = (dp.K[j] + 31) >> 5;
+          const int64_t pos = ((((int64_t)(m0[q] >> 5) * ntr + (k0[q] >> 5)) * 4 + (2 * h + uu)) * 64 +
+                               (qq * 16 + ((m0[q] & 31) >> 1) + ii)) * 4;
+          st4(wt + dp.wsf_off[j] + pos, make_float4(tile[q][b][a], tile[q][b + 1][a], tile[q][b][a + 1], tile[q][b + 1][a + 1]));
+        } else if (j >= 1) {
+          const int h = (m0[q] & 31) >> 4, ntr = (dp.M[j] + 31) >> 5;
+          const int64_t pos = ((((int64_t)(k0[q] >> 5) * ntr + (m0[q] >> 5)) * 4 + (2 * h + uu)) * 64 +
+                               (qq * 16 + ((k0[q] & 31) >> 1) + ii)) * 4;
+          st4(wt + dp.wsb_off[j] + pos, make_float4(tile[q][a][b], tile[q][a][b + 1], tile[q][a + 1][b], tile[q][a + 1][b + 1]));
+        }
+      }
     }
   } else {
 #pragma unroll
