@@ -88,8 +88,14 @@ __device__ __forceinline__ float expm1_neg(float z) {
 //   sigmoid       : a = 1 / (1 + e^{-z}); act' = a (1 - a)
 // `act` is a kernel argument (wave-uniform): the chain below is scalar branches, elu first.
 __device__ __forceinline__ float act_fwd(float z, int act) {
+#ifdef ULTR_ACT2
   if (act == 0) return z > 0.0f ? z : expm1_neg(z);
-  if (act == 1) return fmaxf(z, 0.0f);
+  return fmaxf(z, 0.0f);
+#endif
+  if (act <= 1) {  // elu / relu share one select: the negative branch is expm1(z) or 0 (wave-uniform factor)
+    const float neg = expm1_neg(z) * (act == 0 ? 1.0f : 0.0f);
+    return z > 0.0f ? z : neg;
+  }
   if (act == 2) {
     const float z2 = z * z;
     float p = -5.3968254e-2f;            // -17/315
@@ -103,11 +109,21 @@ __device__ __forceinline__ float act_fwd(float z, int act) {
   const float zc = fminf(fmaxf(z, -30.0f), 30.0f);
   return __builtin_amdgcn_rcpf(1.0f + __expf(-zc));
 }
+// One branch-free form for all four: act'(z) from the OUTPUT a is  a > thr ? 1 : c0 + a (c1 + c2 a)  with wave-uniform
+// constants (elu: thr 0, 1 + a; relu: thr 0, 0; tanh: never, 1 - a^2; sigmoid: never, a - a^2).  `act` is a kernel argument:
+// the constants are scalar selects hoisted out of every loop, the per-element cost is two fmas, a compare and a select
+// (an if-chain over four formulas in the backward row passes cost config 3 8 us per step).
 __device__ __forceinline__ float act_grad_from_out(float a, int act) {
+#ifdef ULTR_ACT2
   if (act == 0) return a > 0.0f ? 1.0f : (a + 1.0f);
-  if (act == 1) return a > 0.0f ? 1.0f : 0.0f;
-  if (act == 2) return 1.0f - a * a;
-  return a * (1.0f - a);
+  return a > 0.0f ? 1.0f : 0.0f;
+#else
+  const float thr = act < 2 ? 0.0f : __builtin_huge_valf();
+  const float c0 = (act == 0 || act == 2) ? 1.0f : 0.0f;
+  const float c1 = (act == 0 || act == 3) ? 1.0f : 0.0f;
+  const float c2 = act >= 2 ? -1.0f : 0.0f;
+  return a > thr ? 1.0f : fmaf(a, fmaf(a, c2, c1), c0);
+#endif
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -121,6 +137,25 @@ __device__ __forceinline__ void st4_stream(float* p, float4 v) {
   __builtin_nontemporal_store(x, reinterpret_cast<f32x4*>(p));
 }
 __device__ __forceinline__ void st1_stream(float* p, float v) { __builtin_nontemporal_store(v, p); }
+// bulk kernel OUTPUTS that only later launches read (saved activations, dz, GEMM results): streaming when ULTR_STREAM_OUT
+#ifndef ULTR_STREAM_OUT
+#define ULTR_STREAM_OUT 0
+#endif
+__device__ __forceinline__ void st2_out(float* p, float2 v) {
+#if ULTR_STREAM_OUT
+  const f32x2 x = {v.x, v.y};
+  __builtin_nontemporal_store(x, reinterpret_cast<f32x2*>(p));
+#else
+  *reinterpret_cast<float2*>(p) = v;
+#endif
+}
+__device__ __forceinline__ void st4_out(float* p, float4 v) {
+#if ULTR_STREAM_OUT
+  st4_stream(p, v);
+#else
+  st4(p, v);
+#endif
+}
 
 // masked 4-wide row load: elements [c, c+4) of a row of length `len`; vec => 16-byte aligned fast path
 __device__ __forceinline__ float4 ld4_masked(const float* row, int c, int len, bool vec) {

@@ -496,8 +496,8 @@ __device__ __forceinline__ void finish_fwd_nn(const f32x4 (&acc)[RT][CT], float*
       else *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
       if (gout != nullptr && row < rows_valid) {
         float* g = gout + (int64_t)row * M + col;
-        if constexpr (CT == 4) st4(g, make_float4(v[0], v[1], v[2], v[3]));
-        else *reinterpret_cast<float2*>(g) = make_float2(v[0], v[1]);
+        if constexpr (CT == 4) st4_out(g, make_float4(v[0], v[1], v[2], v[3]));
+        else st2_out(g, make_float2(v[0], v[1]));
       }
     }
 }
@@ -905,7 +905,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
             v.z = act_fwd(v.z + b4.z, p.act);
             v.w = act_fwd(v.w + b4.w, p.act);
             st4(Y + row * ld + c4e, v);
-            if (gout != nullptr && row < rows_valid) st4(gout + (int64_t)row * M + c4e, v);
+            if (gout != nullptr && row < rows_valid) st4_out(gout + (int64_t)row * M + c4e, v);
           }
         } else if (ksplit == 1) {
           pipe.begin(Wt, M, kb, ke, c0, has, 0, lane);
@@ -944,7 +944,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
             v.z = act_fwd(v.z + b4.z, p.act);
             v.w = act_fwd(v.w + b4.w, p.act);
             st4(Y + row * ld + c4, v);
-            if (gout != nullptr && row < rows_valid) st4(gout + (int64_t)row * M + c4, v);
+            if (gout != nullptr && row < rows_valid) st4_out(gout + (int64_t)row * M + c4, v);
           }
         }
       } else {
@@ -1657,7 +1657,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
               dz.z = rstd[k] * (gx.z - s1 - (x4.z - mean[k]) * rstd[k] * s2) * act_grad_from_out(x4.z, p.act);
               dz.w = rstd[k] * (gx.w - s1 - (x4.w - mean[k]) * rstd[k] * s2) * act_grad_from_out(x4.w, p.act);
               st4(DZ + r * ldz + c, dz);
-              if (n < N) st4(dzg + n * K + c, dz);
+              if (n < N) st4_out(dzg + n * K + c, dz);
             }
           }
           for (int c = K + lane; c < round_up(K, 32); c += 64) DZ[r * ldz + c] = 0.f;  // zero pad (gemm_nn reads it)

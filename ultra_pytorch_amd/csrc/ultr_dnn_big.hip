@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void big_rowstats_kernel(const float* __restri
 #pragma unroll
       for (int u = 0; u < XC; ++u) {
         const int c = 4 * lane + 256 * u;
-        if (c < K) st4(xhat_out + r * K + c, make_float4(v[u].x * rstd, v[u].y * rstd, v[u].z * rstd, v[u].w * rstd));
+        if (c < K) st4_out(xhat_out + r * K + c, make_float4(v[u].x * rstd, v[u].y * rstd, v[u].z * rstd, v[u].w * rstd));
       }
     }
     if (top) t = wave_sum(t);
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void big_lnbwd_kernel(const float* __restrict_
         dz.y = rstd * (gx[u].y - s1 - (xv[u].y - mean) * rstd * s2) * act_grad_from_out(xv[u].y, act);
         dz.z = rstd * (gx[u].z - s1 - (xv[u].z - mean) * rstd * s2) * act_grad_from_out(xv[u].z, act);
         dz.w = rstd * (gx[u].w - s1 - (xv[u].w - mean) * rstd * s2) * act_grad_from_out(xv[u].w, act);
-        st4(dz_out + r * K + c, dz);
+        st4_out(dz_out + r * K + c, dz);
       }
     }
   }

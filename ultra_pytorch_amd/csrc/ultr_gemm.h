@@ -176,7 +176,7 @@ struct EBiasAct {
       }
     }
     float* dst = y + r * ldy + c;
-    if (n_valid == 4 && ((ldy & 3) == 0)) st4(dst, make_float4(o[0], o[1], o[2], o[3]));
+    if (n_valid == 4 && ((ldy & 3) == 0)) st4_out(dst, make_float4(o[0], o[1], o[2], o[3]));
     else
       for (int j = 0; j < n_valid; ++j) dst[j] = o[j];
   }
@@ -204,7 +204,7 @@ struct EBiasRes {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (j < n_valid) o[j] = (o[j] + (bias != nullptr ? bias[c + j] : 0.f)) + rv[j];
-    if (n_valid == 4 && ((ldy & 3) == 0)) st4(dst, make_float4(o[0], o[1], o[2], o[3]));
+    if (n_valid == 4 && ((ldy & 3) == 0)) st4_out(dst, make_float4(o[0], o[1], o[2], o[3]));
     else
       for (int j = 0; j < n_valid; ++j) dst[j] = o[j];
   }
@@ -228,7 +228,7 @@ struct EStore {
         if (mask != nullptr && !(mask[r * ldy + c + j] > 0.f)) o[j] = 0.f;
       }
     }
-    if (n_valid == 4 && ((ldy & 3) == 0)) st4(dst, make_float4(o[0], o[1], o[2], o[3]));
+    if (n_valid == 4 && ((ldy & 3) == 0)) st4_out(dst, make_float4(o[0], o[1], o[2], o[3]));
     else
       for (int j = 0; j < n_valid; ++j) dst[j] = o[j];
   }
