@@ -145,3 +145,25 @@ def test_big_path_is_deterministic(monkeypatch):
         g, _ = run.backward(dscores=ds)
         got.append((s, g.copy()))
     assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+
+
+def test_wide_layer_small_batch_softmax_train_step():
+    """A layer wider than the row-tile kernels hold (1024 > 512) at a SMALL batch under NA / IPW: ultr_train_step must route
+    the backward through the stand-alone loss + per-layer path by itself (ultr_dnn_backward_softmax used to return
+    ULTR_E_UNSUPPORTED here, while the other algorithms took that route) - and match the oracle."""
+    from oracle import ultr_oracle as O
+    from ultra_pytorch_amd import engine, hip_ops
+    F, hidden, B, L = 64, [1024, 32], 9, 7
+    feats, ids, labels = synth(F, B, L, 8)
+    params = O.init_params(F, hidden, seed=4)
+    ipw = np.linspace(1.0, 4.0, 5)
+    ref = O.train_step_softmax(params, np.zeros_like(params), F, hidden, feats, ids, labels, ipw_list=ipw)
+    shape = hip_ops.DnnShape(F, hidden, "elu")
+    eng = engine.StepEngine(shape, B, L, torch.device("cuda"), algo="softmax")
+    p, st = dev(params), dev(np.zeros_like(params))
+    eng.train_step(p, st, dev(feats), feats.shape[0], dev(ids, torch.int32), dev(labels), ipw_table=dev(ipw.astype(np.float32)))
+    sc = eng.read_scalars()
+    assert abs(sc[0] - ref["loss"]) <= 1e-5 * max(1.0, abs(ref["loss"]))
+    np.testing.assert_allclose(eng.scores.cpu().numpy(), ref["scores"], atol=1e-5)
+    g = eng.grads[:shape.n_params].cpu().numpy() / sc[3]
+    np.testing.assert_allclose(g, ref["grads"], rtol=2e-5, atol=2e-6 * float(np.abs(ref["grads"]).max()))

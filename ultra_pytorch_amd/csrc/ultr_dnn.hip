@@ -569,11 +569,19 @@ extern "C" int ultr_trace_read(unsigned long long* host_out) {
 // Forward
 // ------------------------------------------------------------------------------------------------
 // prefetch depth (trips of 32 W rows) of the forward GEMM pipeline
+#ifndef WG_ATOMIC
+#define WG_ATOMIC 0  // TIMING EXPERIMENT: the weight-gradient epilogue adds its 64 x 64 partial into ONE slab
+                     // with hardware fp32 atomics (all row splits of a block hit the same 16 KB) instead of writing its own slab;
+                     // results are not consumed correctly in this mode - it measures what an atomic epilogue would cost
+#endif
 #ifndef WG_WT
 #define WG_WT 1   // dnn_wgrad_kernel: slabs leave with streaming stores (config 2: step 53.6 -> 53.1 us)
 #endif
 #ifndef RED_WT
 #define RED_WT 0  // grad_reduce_kernel: the flat gradient leaves with streaming stores
+#endif
+#ifndef FB_LATE_ST
+#define FB_LATE_ST 0  // dnn_fb_kernel: the HBM copies of u_j / xhat_0 / dz_j are issued BEHIND the product that follows them
 #endif
 #ifndef FB_KAPF
 #define FB_KAPF 1  // dnn_fb_kernel: pull the kernel-argument segment into L2 with one vector load at the top (-0.2 us)
@@ -1818,6 +1826,10 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
     const float* wlp = PV + p.pv_wlast;
     const float invK = 1.0f / (float)K;
     // ---- LayerNorm_j: XS_j -> UZ (zero-padded to a multiple of 32 columns); the scorer folded into the last one ----
+#if FB_LATE_ST
+    float4 wst[RPW][XC];  // this wave's rows of the weight-gradient operand, stored behind the product (vmcnt is in order:
+                          // a write-through store in front of the product's first loads is waited for with them)
+#endif
     {
       float4 x[RPW][XC], g4[XC], b4[XC];
       float s[RPW];
@@ -1892,7 +1904,9 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
               const float4 uu = make_float4(xh.x * g4[u].x + b4[u].x, xh.y * g4[u].y + b4[u].y, xh.z * g4[u].z + b4[u].z,
                                             xh.w * g4[u].w + b4[u].w);
               st4(UZ + r * ld + c, uu);
-#if FB_WT == 2
+#if FB_LATE_ST
+              wst[q][u] = xhat_only ? xh : uu;
+#elif FB_WT == 2
               if (c < K && r < rows_valid) st4_stream(wop + c, xhat_only ? xh : uu);
 #elif FB_WT
               if (c < K && r < rows_valid) coh_st4(svs, wop_b + (unsigned)c * 4u, xhat_only ? xh : uu);
@@ -1980,6 +1994,20 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
           st4(Y + row * ld + c4, vv);
         }
       }
+#if FB_LATE_ST
+      {
+        const Src svs = make_src(saved, p.sv_total);
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+          const int r = wave + NW * q;
+#pragma unroll
+          for (int u = 0; u < XC; ++u) {
+            const int c = 4 * lane + 256 * u;
+            if (c < K && r < rows_valid) coh_st4(svs, (unsigned)((p.sv_x[j] + (n0 + r) * K + c) * 4), wst[q][u]);
+          }
+        }
+      }
+#endif
       lds_barrier();
       TRACE_STAMP(3 + 2 * j);
     }
@@ -2051,6 +2079,25 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
   };
   float* DZ = UZ;
   const int jlow = bp.l0g ? 1 : 0;  // layer-0 shortcut: du_0 is never formed (BwdPlan::l0g)
+#if FB_LATE_ST
+  float4 dzst[RPW][XC];
+  int dzst_j = -1;  // layer whose dz rows wait in dzst (stored behind the next dgrad product / at the end)
+  auto flush_dz = [&]() {
+    if (dzst_j < 0) return;
+    const int Kd = p.M[dzst_j];
+    const Src wss = make_src(ws, bp.total);
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+      const int r = wave + NW * k;
+#pragma unroll
+      for (int u = 0; u < XC; ++u) {
+        const int c = 4 * lane + 256 * u;
+        if (c < Kd && r < rows_valid) coh_st4(wss, (unsigned)((bp.dz_off[dzst_j] + (n0 + r) * Kd + c) * 4), dzst[k][u]);
+      }
+    }
+    dzst_j = -1;
+  };
+#endif
   for (int j = top; j >= jlow; --j) {
     const int K = p.K[j], M = p.M[j];
     const bool last = (j == top);
@@ -2106,6 +2153,9 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
           if (r + 1 < msplit) lds_barrier();
         }
       }
+#if FB_LATE_ST
+      flush_dz();
+#endif
       TRACE_STAMP(17 + 4 * (top - j));
       lds_barrier();
     }
@@ -2185,7 +2235,9 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
               dz.z = rstd[k] * (gx.z - s1 - (x4.z - mean[k]) * rstd[k] * s2) * act_grad_from_out(x4.z, p.act);
               dz.w = rstd[k] * (gx.w - s1 - (x4.w - mean[k]) * rstd[k] * s2) * act_grad_from_out(x4.w, p.act);
               st4(DZ + r * ldz + c, dz);
-#if FB_WT == 2
+#if FB_LATE_ST
+              dzst[k][u] = dz;
+#elif FB_WT == 2
               if (r < rows_valid) st4_stream(dzg + (n0 + r) * K + c, dz);
 #elif FB_WT
               if (r < rows_valid) coh_st4(make_src(ws, bp.total), (unsigned)((bp.dz_off[j - 1] + (n0 + r) * K + c) * 4), dz);
@@ -2196,12 +2248,18 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
           }
           for (int c = K + lane; c < round_up(K, 32); c += 64) DZ[r * ldz + c] = 0.f;
         }
+#if FB_LATE_ST
+        dzst_j = j - 1;
+#endif
       }
     }
     TRACE_STAMP(19 + 4 * (top - j));
     lds_barrier();
   }
   finalize(jlow);
+#if FB_LATE_ST
+  flush_dz();
+#endif
   TRACE_STAMP(13);
 #if FB_KAPF
   asm volatile("" ::"v"(ka_pf));
@@ -2495,7 +2553,11 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
   }
   lds_barrier();
   TRACE_STAMP(11);
+#if WG_ATOMIC
+  float* slab = ws + wl.slab_off;  // every split of a block into the same slab
+#else
   float* slab = ws + wl.slab_off + (int64_t)split * ((int64_t)M * K + M);
+#endif
   float4 l0pg = make_float4(0.f, 0.f, 0.f, 0.f), l0pb = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
@@ -2520,7 +2582,12 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
     if (m < M && k < K) {
       float* dst = slab + (int64_t)m * K + k;
       if (vec && k + 3 < K) {
-#if WG_WT
+#if WG_ATOMIC
+        unsafeAtomicAdd(dst + 0, s.x);
+        unsafeAtomicAdd(dst + 1, s.y);
+        unsafeAtomicAdd(dst + 2, s.z);
+        unsafeAtomicAdd(dst + 3, s.w);
+#elif WG_WT
         st4_stream(dst, s);
 #else
         st4(dst, s);
@@ -3279,7 +3346,11 @@ extern "C" int ultr_dnn_backward_softmax(const ultr_dnn_desc* d, const float* pa
     // big batches take the per-layer backward, which wants the loss as its own stage
     DnnPlan p;
     const int64_t N = (int64_t)batch * list_size;
-    if (dscores_out && batch > 0 && list_size > 0 && ultr_make_dnn_plan(d, N, &p) && big_bwd_wanted(p, N) &&
+    // ... and so do shapes whose row tile does not fit the LDS (a layer wider than 512 at a small batch): the same condition
+    // backward_impl applies to the other algorithms - without it this entry point returned ULTR_E_UNSUPPORTED there
+    BwdPlan bp0;
+    const bool planned = dscores_out && batch > 0 && list_size > 0 && ultr_make_dnn_plan(d, N, &p) && ultr_make_bwd_plan(p, N, &bp0);
+    if (planned && (big_bwd_wanted(p, N) || bwd_lds_bytes(p, bp0.rblk) > 160 * 1024) && knobs().big_bwd != 0 &&
         knobs().no_l0g == 0 && knobs().no_vec == 0 && ultr_dnn_big_ok(p, N, n_docs)) {
       const int rc = ultr_softmax_ce(scores, labels, pw, ipw_table, n_ipw, batch, list_size, dscores_out, loss_ws, stream);
       if (rc) return rc;

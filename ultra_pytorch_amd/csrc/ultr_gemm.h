@@ -27,6 +27,7 @@
 //   * out-of-range rows / columns / contraction indices are zeros at staging (buffer-resource bounds checks), stores
 //     are masked: any R, N, K (K % 4 == 0 and 16-byte aligned rows for the vector loads; checked by the launcher).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
@@ -544,14 +545,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(Dims d, AProd aprod,
 #ifdef UGEMM_DEBUG_GRID
 static int g_ugemm_grid_mode = 0;
 #endif
+// per-DEVICE caches (a process may drive several GPUs; function attributes and occupancy belong to the device current at
+// the call): index = hipGetDevice(), guarded by atomics - the worst a race does is set the same value twice
+constexpr int UGEMM_MAX_DEV = 64;
+inline int current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= UGEMM_MAX_DEV) dev = 0;
+  return dev;
+}
 inline int device_cus() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-      cus = 256;
+  static std::atomic<int> cus[UGEMM_MAX_DEV];
+  const int dev = current_device();
+  int c = cus[dev].load(std::memory_order_relaxed);
+  if (c == 0) {
+    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+    cus[dev].store(c, std::memory_order_relaxed);
   }
-  return cus;
+  return c;
 }
 
 template <int BM, int BN, int WM, int WN, bool B_NMAJOR, class AProd, class Epi>
@@ -560,15 +570,17 @@ inline hipError_t launch(const Dims& d, const AProd& aprod, const float* B, cons
   using C = Cfg<BM, BN, WM, WN, B_NMAJOR>;
   auto kern = gemm_kernel<BM, BN, WM, WN, B_NMAJOR, AProd, Epi>;
   const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
-  static bool attr = false;  // one per template instance
-  if (!attr && lds > 64 * 1024) {
+  const int dev = current_device();
+  static std::atomic<bool> attr[UGEMM_MAX_DEV];  // one set per template instance and device
+  if (lds > 64 * 1024 && !attr[dev].load(std::memory_order_acquire)) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr = true;
+    attr[dev].store(true, std::memory_order_release);
   }
   // resident workgroups per CU: asked from the runtime once per template instance (LDS, wave slots and the registers
   // the compiler actually used all bind: 53 KB of LDS -> 3 at <= 80 registers, 2 above)
-  static int per_cu = 0;
+  static std::atomic<int> per_cu_dev[UGEMM_MAX_DEV];
+  int per_cu = per_cu_dev[dev].load(std::memory_order_relaxed);
   if (per_cu == 0) {
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), C::NT, lds) != hipSuccess || nb < 1) {
@@ -578,6 +590,7 @@ inline hipError_t launch(const Dims& d, const AProd& aprod, const float* B, cons
       if (nb < 1) nb = 1;
     }
     per_cu = nb;
+    per_cu_dev[dev].store(nb, std::memory_order_relaxed);
   }
   const int64_t slots = (int64_t)per_cu * device_cus();
   const int64_t nru = (d.R + 15) / 16;
