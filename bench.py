@@ -715,6 +715,7 @@ def main():
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)  # whatever the teardown prints (RCCL's banner arrives at communicator destruction) must not follow the line
     for e in engs.values():
         e.close()
     if pg is not None:

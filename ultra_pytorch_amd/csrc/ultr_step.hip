@@ -94,3 +94,4 @@ extern "C" int ultr_train_step(const ultr_step_args* a, void* stream) {
   if (rc) return rc;
   return finish_step(a, stream);
 }
+
