@@ -75,8 +75,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t sys_rsrc(const float* p, int64
 template <int W>
 __global__ __launch_bounds__(256) void comm_allreduce_kernel(CommDev c, uint32_t epoch, int64_t n, int64_t n_params, int64_t cap,
                                                              const float* __restrict__ src, float* __restrict__ out,
-                                                             float* __restrict__ sumsq_part, int nsq) {
+                                                             float* __restrict__ sumsq_part, int nsq, EarlyReport er) {
   __shared__ int sm_fail;
+  __shared__ float sm_head[4];
   const int tid = threadIdx.x;
   const int64_t e4 = ((int64_t)blockIdx.x * 256 + tid) * 4;
   if (tid == 0) sm_fail = 0;
@@ -140,6 +141,32 @@ __global__ __launch_bounds__(256) void comm_allreduce_kernel(CommDev c, uint32_t
     out[e4] = s.x;
     if (e4 + 1 < n) out[e4 + 1] = s.y;
     if (e4 + 2 < n) out[e4 + 2] = s.z;
+  }
+  // ---- early loss report (EarlyReport, ultr_plan.h): the workgroup whose slice holds the head of the step tail
+  // (loss_sum, D, loss2_sum, D2 at out[n_params .. n_params + 4)) now has the GLOBAL sums: the loss is final here, one
+  // launch before the update reports everything else.  Not after a timed-out wait (the guarded update reports that).
+  {
+    const int64_t b0 = (int64_t)blockIdx.x * COMM_SLICE;
+    if (er.host != nullptr && n_params >= b0 && n_params + 4 <= b0 + COMM_SLICE && n_params + 4 <= n) {  // block-uniform
+      const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int64_t idx = e4 + k - n_params;
+        if (idx >= 0 && idx < 4) sm_head[idx] = sv[k];
+      }
+      __syncthreads();
+      bool failed = false;
+      if constexpr (W > 1) failed = sm_fail != 0;
+      if (tid == 0 && !failed) {
+        const float loss_sum = sm_head[0], D = sm_head[1], loss2 = sm_head[2], D2 = sm_head[3];
+        float loss = loss_sum / D;
+        if (er.algo == ULTR_ALGO_DLA) loss = loss2 / D2 + er.rlw * (loss_sum / D);
+        else if (er.algo == ULTR_ALGO_PAIRDEBIAS) loss = loss_sum;
+        __hip_atomic_store(er.host, loss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(er.host) + 10, er.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
   }
   // ---- sum-of-squares partials of the reduced gradient (64 elements = 16 lanes) ---------------------------------------
   float q = 0.f;
@@ -215,6 +242,13 @@ static bool comm_ready(const ultr_comm* c) {
 
 extern "C" int ultr_comm_allreduce(ultr_comm* c, uint64_t step, const float* src, int64_t n, int64_t n_params, float* out,
                                    void* sumsq_ws, int32_t sumsq_parts, void* stream) {
+  const EarlyReport none = {nullptr, 0u, 0, 1.0f};
+  return ultr_comm_allreduce_ex(c, step, src, n, n_params, out, sumsq_ws, sumsq_parts, stream, none);
+}
+
+// library-internal (ultr_train_step): the same with an early loss report from the workgroup that reduces the step tail
+int ultr_comm_allreduce_ex(ultr_comm* c, uint64_t step, const float* src, int64_t n, int64_t n_params, float* out, void* sumsq_ws,
+                           int32_t sumsq_parts, void* stream, EarlyReport er) {
   if (!c || !src || !out || !sumsq_ws || n <= 0 || n > c->cap || n_params < 0 || n_params > n || sumsq_parts < 0)
     return ULTR_E_BADARG;
   if (!comm_ready(c)) return ULTR_E_UNSUPPORTED;
@@ -237,7 +271,7 @@ extern "C" int ultr_comm_allreduce(ultr_comm* c, uint64_t step, const float* src
   hipStream_t st = (hipStream_t)stream;
 #define COMM_LAUNCH(WW)                                                                                                      \
   hipLaunchKernelGGL(comm_allreduce_kernel<WW>, dim3(nblk), dim3(256), 0, st, d, epoch, n, n_params, c->cap, src, out, \
-                     (float*)sumsq_ws, (int)sumsq_parts)
+                     (float*)sumsq_ws, (int)sumsq_parts, er)
   switch (c->world) {
     case 1: COMM_LAUNCH(1); break;
     case 2: COMM_LAUNCH(2); break;

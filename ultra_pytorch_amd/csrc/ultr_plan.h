@@ -182,6 +182,11 @@ struct EarlyReport {
   float rlw;
 };
 extern thread_local EarlyReport g_ultr_early;  // ultr_step.hip
+// ... and in the data-parallel step the loss needs the GLOBAL sums: the exchange kernel's workgroup that reduces the head of
+// the step tail reports it (ultr_comm.hip), one launch ahead of the update
+struct ultr_comm;
+int ultr_comm_allreduce_ex(ultr_comm* c, uint64_t step, const float* src, int64_t n, int64_t n_params, float* out, void* sumsq_ws,
+                           int32_t sumsq_parts, void* stream, EarlyReport er);
 
 #define ULTR_TAIL_FIXED 4
 __host__ __device__ static inline int64_t ultr_tail_len(int L) { return ULTR_TAIL_FIXED + 2 * (int64_t)L; }

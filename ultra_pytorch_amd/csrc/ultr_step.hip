@@ -15,7 +15,10 @@ static int finish_step(const ultr_step_args* a, void* stream) {
     const int64_t P = ultr_dnn_param_count(a->desc);
     if (P <= 0) return ULTR_E_BADARG;
     const int64_t n = P + ultr_tail_len(a->list_size);
-    const int rc = ultr_comm_allreduce(a->comm, a->comm_step, a->grads, n, P, a->grads, a->bwd_ws, (int32_t)((n + 63) / 64), stream);
+    const ultr_update_desc* u0 = a->upd;
+    const bool early = u0->host_scalars != nullptr && u0->l2_loss == 0.f;
+    const EarlyReport er = {early ? u0->host_scalars : nullptr, u0->seq, u0->algo, u0->ranker_loss_weight};
+    const int rc = ultr_comm_allreduce_ex(a->comm, a->comm_step, a->grads, n, P, a->grads, a->bwd_ws, (int32_t)((n + 63) / 64), stream, er);
     if (rc) return rc;
     // the update behind the exchange is guarded by the communicator's status word: after a timed-out peer wait (here or on
     // any peer - the rank that times out raises the word everywhere) no replica moves its parameters again
