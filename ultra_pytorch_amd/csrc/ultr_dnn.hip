@@ -580,9 +580,6 @@ extern "C" int ultr_trace_read(unsigned long long* host_out) {
 #ifndef RED_WT
 #define RED_WT 0  // grad_reduce_kernel: the flat gradient leaves with streaming stores
 #endif
-#ifndef FB_LATE_ST
-#define FB_LATE_ST 0  // dnn_fb_kernel: the HBM copies of u_j / xhat_0 / dz_j are issued BEHIND the product that follows them
-#endif
 #ifndef FB_KAPF
 #define FB_KAPF 1  // dnn_fb_kernel: pull the kernel-argument segment into L2 with one vector load at the top (-0.2 us)
 #endif
@@ -1702,8 +1699,9 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
                                                      const float* __restrict__ wt, const float* __restrict__ features,
                                                      int64_t n_docs, const int32_t* __restrict__ docids, int B, int L,
                                                      int LPB, float* __restrict__ scores, float* __restrict__ saved,
-                                                     float* __restrict__ ws, FusedSoftmax fl) {
+                                                     float* __restrict__ ws, FusedSoftmax fl, FbPlan fp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ int sm_plan[ULTR_MAXL * FbPlan::NFIELD];
   constexpr int R = 16, NW = 8, RT = 1, NT = NW * 64, RPW = R / NW;
   const int64_t N = (int64_t)B * L;
   const int ld = fwd_ld(p.maxdim), ldu = bwd_ldu(p.maxdim), ldz = ld;
@@ -1726,6 +1724,12 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
   float* vslab = ws + bp.vslab_off + (int64_t)blockIdx.x * bp.vlen;
   const int top = p.nl - 1;
   TRACE_STAMP(0);
+  // per-layer records -> LDS (FbPlan, ultr_plan.h): a runtime-indexed read of a by-value kernel argument with a per-thread
+  // index is a vector load from the argument segment; visible to every wave behind the prologue's barrier
+  if (tid < ULTR_MAXL * FbPlan::NFIELD) sm_plan[tid] = reinterpret_cast<const int*>(&fp)[tid];
+  auto rec_of = [&](int jj) { return sm_plan[jj * FbPlan::NFIELD + (lane & (FbPlan::NFIELD - 1))]; };  // lane = field
+#define FBF(rv, k) __builtin_amdgcn_readlane((rv), (k))
+#define FBF64(rv, k) ((int64_t)(((uint64_t)(uint32_t)FBF(rv, (k) + 1) << 32) | (uint64_t)(uint32_t)FBF(rv, (k))))
 #if FB_KAPF
   // The plans travel as kernel arguments (~2.7 KB = 43 cache lines in HBM) and are read with scalar loads at the top of every
   // layer of both loops (runtime-indexed records): each first touch of a line was a ~2k-cycle miss on the critical path of
@@ -1734,7 +1738,7 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
   float ka_pf = 0.f;
   if (wave == 0) {
     const float* ka = (const float*)__builtin_amdgcn_kernarg_segment_ptr();
-    constexpr int KA_LINES = (int)((sizeof(DnnPlan) + sizeof(BwdPlan) + sizeof(FusedSoftmax) + 96 + 63) / 64);
+    constexpr int KA_LINES = (int)((sizeof(DnnPlan) + sizeof(BwdPlan) + sizeof(FusedSoftmax) + sizeof(FbPlan) + 96 + 63) / 64);
     static_assert(KA_LINES <= 64, "one lane per kernel-argument cache line");
     ka_pf = ka[(lane < KA_LINES ? lane : 0) * 16];
   }
@@ -1815,21 +1819,17 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
 
   // =================================== forward ===================================
   for (int j = 0; j < p.nl; ++j) {
-    const DnnPlan::FwdLayer lay = p.fl[j];
-    const int K = lay.K, M = lay.M;
+    const int rv = rec_of(j);
+    const int K = FBF(rv, FbPlan::K), M = FBF(rv, FbPlan::M);
     const int K32 = round_up(K, 32);
     const bool last = (j == top);
     const float* XS = XSall + (size_t)j * R * ld;
-    const float* gs = PV + p.pv_off[j];
+    const float* gs = PV + FBF(rv, FbPlan::PV_OFF);
     const float* bs = gs + K;
     const float* bias = bs + K;
     const float* wlp = PV + p.pv_wlast;
     const float invK = 1.0f / (float)K;
     // ---- LayerNorm_j: XS_j -> UZ (zero-padded to a multiple of 32 columns); the scorer folded into the last one ----
-#if FB_LATE_ST
-    float4 wst[RPW][XC];  // this wave's rows of the weight-gradient operand, stored behind the product (vmcnt is in order:
-                          // a write-through store in front of the product's first loads is waited for with them)
-#endif
     {
       float4 x[RPW][XC], g4[XC], b4[XC];
       float s[RPW];
@@ -1889,10 +1889,11 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
         const float rstd = rsqrt_nr(v[q] * invK + ULTR_LN_EPS);
         if (!last) {
           // the weight gradients' operand goes to HBM from here: u_j, or xhat_0 for the layer-0 shortcut
-          float* wop = saved + p.sv_x[j] + (n0 + r) * K;
+          const int64_t svx = FBF64(rv, FbPlan::SV_X);
+          float* wop = saved + svx + (n0 + r) * K;
 #if FB_WT == 1
           const Src svs = make_src(saved, p.sv_total);
-          const unsigned wop_b = (unsigned)((p.sv_x[j] + (n0 + r) * K) * 4);
+          const unsigned wop_b = (unsigned)((svx + (n0 + r) * K) * 4);
 #endif
           const bool xhat_only = (j == 0) && bp.l0g != 0;
 #pragma unroll
@@ -1904,9 +1905,7 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
               const float4 uu = make_float4(xh.x * g4[u].x + b4[u].x, xh.y * g4[u].y + b4[u].y, xh.z * g4[u].z + b4[u].z,
                                             xh.w * g4[u].w + b4[u].w);
               st4(UZ + r * ld + c, uu);
-#if FB_LATE_ST
-              wst[q][u] = xhat_only ? xh : uu;
-#elif FB_WT == 2
+#if FB_WT == 2
               if (c < K && r < rows_valid) st4_stream(wop + c, xhat_only ? xh : uu);
 #elif FB_WT
               if (c < K && r < rows_valid) coh_st4(svs, wop_b + (unsigned)c * 4u, xhat_only ? xh : uu);
@@ -1921,8 +1920,8 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
           sm_mean[j * R + r] = valid ? s[q] : 0.f;
           sm_rstd[j * R + r] = valid ? rstd : 0.f;
           if (valid) {
-            saved[lay.sv_mean + n0 + r] = s[q];
-            saved[lay.sv_rstd + n0 + r] = rstd;
+            saved[FBF64(rv, FbPlan::SV_MEAN) + n0 + r] = s[q];
+            saved[FBF64(rv, FbPlan::SV_RSTD) + n0 + r] = rstd;
           }
           if (last) {
             const float sc = rstd * t[q] + t[RPW] + bias[0];
@@ -1939,12 +1938,12 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
       // ---- Linear_j + activation: UZ . WT_j -> XS_{j+1} (LDS) and saved x_{j+1} (HBM, for the weight gradients) ----
       float* Y = XSall + (size_t)(j + 1) * R * ld;
       float* gout = nullptr;  // x_{j+1} stays on chip; `saved` gets the wgrad operand in the next LayerNorm
-      const Src Wt = make_src(wt + lay.wt_off, (int64_t)K * M);
-      const int nch = lay.nch, ksplit = lay.ksplit, klen = lay.klen;
+      const Src Wt = make_src(wt + FBF64(rv, FbPlan::WT_OFF), (int64_t)K * M);
+      const int nch = FBF(rv, FbPlan::NCH), ksplit = FBF(rv, FbPlan::KSPLIT), klen = FBF(rv, FbPlan::KLEN);
       GemmPipe<RT, 2, FWD_D, 0> pipe;
       if (FB_SW && p.sw_ok && ksplit == 1) {
         const int ntr = K32 >> 5;
-        const Src Ws = make_src(wt + p.wsf_off[j], (int64_t)K32 * M);
+        const Src Ws = make_src(wt + FBF64(rv, FbPlan::WSF_OFF), (int64_t)K32 * M);
         PipeSw<FB_SWD> ps;
         const int c0 = wave * 32;
         ps.begin(Ws, wave, ntr, 0, ntr, c0 < M, lane);
@@ -1994,20 +1993,6 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
           st4(Y + row * ld + c4, vv);
         }
       }
-#if FB_LATE_ST
-      {
-        const Src svs = make_src(saved, p.sv_total);
-#pragma unroll
-        for (int q = 0; q < RPW; ++q) {
-          const int r = wave + NW * q;
-#pragma unroll
-          for (int u = 0; u < XC; ++u) {
-            const int c = 4 * lane + 256 * u;
-            if (c < K && r < rows_valid) coh_st4(svs, (unsigned)((p.sv_x[j] + (n0 + r) * K + c) * 4), wst[q][u]);
-          }
-        }
-      }
-#endif
       lds_barrier();
       TRACE_STAMP(3 + 2 * j);
     }
@@ -2057,7 +2042,9 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
 
   // =================================== backward (as dnn_bwd2_kernel, tiles already on chip) ===================================
   auto finalize = [&](int jj) {
-    const int K = p.K[jj], K4 = round_up(K, 4);
+    const int rvf = rec_of(jj);
+    const int K = FBF(rvf, FbPlan::K), K4 = round_up(K, 4);
+    const int vg = FBF(rvf, FbPlan::VOFF_G), vb = FBF(rvf, FbPlan::VOFF_B);
     const bool lastl = (jj == top);
     for (int c = tid; c < K; c += NT) {
       float pg = 0.f, pb = 0.f, pw = 0.f;
@@ -2067,8 +2054,8 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
         pb += CP[w * cpw + K4 + c];
         if (lastl) pw += CP[w * cpw + 2 * K4 + c];
       }
-      vslab[bp.voff_g[jj] + c] = pg;
-      vslab[bp.voff_b[jj] + c] = pb;
+      vslab[vg + c] = pg;
+      vslab[vb + c] = pb;
       if (lastl) vslab[bp.voff_wk + c] = pw;
     }
     if (lastl && tid == 0) {
@@ -2079,36 +2066,18 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
   };
   float* DZ = UZ;
   const int jlow = bp.l0g ? 1 : 0;  // layer-0 shortcut: du_0 is never formed (BwdPlan::l0g)
-#if FB_LATE_ST
-  float4 dzst[RPW][XC];
-  int dzst_j = -1;  // layer whose dz rows wait in dzst (stored behind the next dgrad product / at the end)
-  auto flush_dz = [&]() {
-    if (dzst_j < 0) return;
-    const int Kd = p.M[dzst_j];
-    const Src wss = make_src(ws, bp.total);
-#pragma unroll
-    for (int k = 0; k < RPW; ++k) {
-      const int r = wave + NW * k;
-#pragma unroll
-      for (int u = 0; u < XC; ++u) {
-        const int c = 4 * lane + 256 * u;
-        if (c < Kd && r < rows_valid) coh_st4(wss, (unsigned)((bp.dz_off[dzst_j] + (n0 + r) * Kd + c) * 4), dzst[k][u]);
-      }
-    }
-    dzst_j = -1;
-  };
-#endif
   for (int j = top; j >= jlow; --j) {
-    const int K = p.K[j], M = p.M[j];
+    const int rv = rec_of(j);
+    const int K = FBF(rv, FbPlan::K), M = FBF(rv, FbPlan::M);
     const bool last = (j == top);
     if (!last) {
       finalize(j + 1);
-      const Src Wsrc = make_src(params + p.off_w[j], (int64_t)M * K);
-      const int nch = p.bwd_nch[j], msplit = p.bwd_msplit[j], mode = p.bwd_mode[j];
+      const Src Wsrc = make_src(params + FBF64(rv, FbPlan::OFF_W), (int64_t)M * K);
+      const int nch = FBF(rv, FbPlan::BWD_NCH), msplit = FBF(rv, FbPlan::BWD_MSPLIT), mode = FBF(rv, FbPlan::BWD_MODE);
       if (FB_SW && p.sw_ok && j >= 1) {
         // du_j = dz_j . W_j over the fragment-major copy of W_j: 32-column chunks of K over the whole contraction M
         const int ntr = (M + 31) >> 5;
-        const Src Wb = make_src(wt + p.wsb_off[j], (int64_t)round_up(M, 32) * round_up(K, 32));
+        const Src Wb = make_src(wt + FBF64(rv, FbPlan::WSB_OFF), (int64_t)round_up(M, 32) * round_up(K, 32));
         PipeSw<FB_SWD> ps;
         ps.begin(Wb, wave, ntr, 0, ntr, wave * 32 < K, lane);
         for (int ch = wave; ch * 32 < K; ch += NW) {
@@ -2136,7 +2105,7 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
           store_nn<RT, 4>(acc, DU, ldu, K, ch * 64, lane, false);
         }
       } else {
-        const int mlen = p.bwd_mlen[j];
+        const int mlen = FBF(rv, FbPlan::BWD_MLEN);
         const bool has = wave < nch * msplit;
         int ms = 0, ch = wave;
         while (ch >= nch) { ch -= nch; ++ms; }
@@ -2153,16 +2122,13 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
           if (r + 1 < msplit) lds_barrier();
         }
       }
-#if FB_LATE_ST
-      flush_dz();
-#endif
       TRACE_STAMP(17 + 4 * (top - j));
       lds_barrier();
     }
     TRACE_STAMP(18 + 4 * (top - j));
     {
       const float* XS = XSall + (size_t)j * R * ld;
-      const float* gs = PV + p.pv_off[j];
+      const float* gs = PV + FBF(rv, FbPlan::PV_OFF);
       const float* bs = gs + K;
       const float* wlp = PV + p.pv_wlast;
       const float invK = 1.0f / (float)K;
@@ -2219,7 +2185,8 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
       }
       if (j > 0) {
         wave_sum_n<2 * RPW>(red);
-        float* dzg = ws + bp.dz_off[j - 1];
+        const int64_t dzo = FBF64(rec_of(j - 1), FbPlan::DZ_OFF);
+        float* dzg = ws + dzo;
 #pragma unroll
         for (int k = 0; k < RPW; ++k) {
           const int r = wave + NW * k;
@@ -2235,12 +2202,10 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
               dz.z = rstd[k] * (gx.z - s1 - (x4.z - mean[k]) * rstd[k] * s2) * act_grad_from_out(x4.z, p.act);
               dz.w = rstd[k] * (gx.w - s1 - (x4.w - mean[k]) * rstd[k] * s2) * act_grad_from_out(x4.w, p.act);
               st4(DZ + r * ldz + c, dz);
-#if FB_LATE_ST
-              dzst[k][u] = dz;
-#elif FB_WT == 2
+#if FB_WT == 2
               if (r < rows_valid) st4_stream(dzg + (n0 + r) * K + c, dz);
 #elif FB_WT
-              if (r < rows_valid) coh_st4(make_src(ws, bp.total), (unsigned)((bp.dz_off[j - 1] + (n0 + r) * K + c) * 4), dz);
+              if (r < rows_valid) coh_st4(make_src(ws, bp.total), (unsigned)((dzo + (n0 + r) * K + c) * 4), dz);
 #else
               if (r < rows_valid) st4(dzg + (n0 + r) * K + c, dz);
 #endif
@@ -2248,18 +2213,12 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
           }
           for (int c = K + lane; c < round_up(K, 32); c += 64) DZ[r * ldz + c] = 0.f;
         }
-#if FB_LATE_ST
-        dzst_j = j - 1;
-#endif
       }
     }
     TRACE_STAMP(19 + 4 * (top - j));
     lds_barrier();
   }
   finalize(jlow);
-#if FB_LATE_ST
-  flush_dz();
-#endif
   TRACE_STAMP(13);
 #if FB_KAPF
   asm volatile("" ::"v"(ka_pf));
@@ -2267,6 +2226,8 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
 #if FB_L2PF
   asm volatile("" ::"v"(pf0), "v"(pf1));  // the warming loads are only "used" here
 #endif
+#undef FBF
+#undef FBF64
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3402,6 +3363,19 @@ int ultr_fused_step_softmax(const ultr_dnn_desc* d, const float* params, const f
   hipStream_t st = (hipStream_t)stream;
   FusedSoftmax fl = {nullptr, labels, pw, ipw_table, (int)n_ipw, dscores_out, (float*)loss_ws};
   float* ws = (float*)bwd_ws;
+  FbPlan fp;
+  memset(&fp, 0, sizeof(fp));
+  for (int j = 0; j < p.nl; ++j) {
+    int* r = fp.rec[j];
+    auto put64 = [&](int k, int64_t v) { r[k] = (int)(uint32_t)(uint64_t)v; r[k + 1] = (int)(uint32_t)((uint64_t)v >> 32); };
+    r[FbPlan::K] = p.K[j]; r[FbPlan::M] = p.M[j]; r[FbPlan::PV_OFF] = p.pv_off[j];
+    r[FbPlan::KSPLIT] = p.fl[j].ksplit; r[FbPlan::KLEN] = p.fl[j].klen; r[FbPlan::NCH] = p.fl[j].nch;
+    r[FbPlan::BWD_NCH] = p.bwd_nch[j]; r[FbPlan::BWD_MSPLIT] = p.bwd_msplit[j]; r[FbPlan::BWD_MODE] = p.bwd_mode[j];
+    r[FbPlan::BWD_MLEN] = p.bwd_mlen[j]; r[FbPlan::VOFF_G] = bp.voff_g[j]; r[FbPlan::VOFF_B] = bp.voff_b[j];
+    put64(FbPlan::WSF_OFF, p.wsf_off[j]); put64(FbPlan::WSB_OFF, p.wsb_off[j]); put64(FbPlan::SV_X, p.sv_x[j]);
+    put64(FbPlan::OFF_W, p.off_w[j]); put64(FbPlan::SV_MEAN, p.sv_mean[j]); put64(FbPlan::SV_RSTD, p.sv_rstd[j]);
+    put64(FbPlan::DZ_OFF, j < p.nl - 1 ? bp.dz_off[j] : 0); put64(FbPlan::WT_OFF, p.wt_off[j]);
+  }
   hipError_t e;
   {
     UltrProfScope prof(ULTR_K_FUSED, st);
@@ -3409,12 +3383,12 @@ int ultr_fused_step_softmax(const ultr_dnn_desc* d, const float* params, const f
       e = set_lds(dnn_fb_kernel<1>, lds);
       if (e != hipSuccess) return (int)e;
       ULTR_LAUNCH(prof, dnn_fb_kernel<1>, dim3((unsigned)nblk), dim3(512), lds, st, p, bp, params, wt, features, n_docs, docids,
-                  (int)batch, L, lpb, scores, (float*)saved, ws, fl);
+                  (int)batch, L, lpb, scores, (float*)saved, ws, fl, fp);
     } else {
       e = set_lds(dnn_fb_kernel<2>, lds);
       if (e != hipSuccess) return (int)e;
       ULTR_LAUNCH(prof, dnn_fb_kernel<2>, dim3((unsigned)nblk), dim3(512), lds, st, p, bp, params, wt, features, n_docs, docids,
-                  (int)batch, L, lpb, scores, (float*)saved, ws, fl);
+                  (int)batch, L, lpb, scores, (float*)saved, ws, fl, fp);
     }
   }
   e = hipGetLastError();

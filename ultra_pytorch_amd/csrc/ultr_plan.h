@@ -133,6 +133,16 @@ struct BwdPlan {
   int64_t total;            // floats in bwd_ws
 };
 
+// Everything dnn_fb_kernel needs about layer j of BOTH loops, one 128-byte record per layer (32 ints; 64-bit offsets as lo, hi).
+// The plans travel as kernel arguments in HBM; runtime-indexed reads of them are scalar loads whose first touch of a cache
+// line is a miss on the critical path at the top of every phase.  The kernel copies these records into LDS with one vector
+// load per thread at its start and reads a record with ONE ds_read per wave (lane = field), fields by v_readlane.
+struct FbPlan {
+  enum { K = 0, M, PV_OFF, KSPLIT, KLEN, NCH, BWD_NCH, BWD_MSPLIT, BWD_MODE, BWD_MLEN, VOFF_G, VOFF_B,
+         WSF_OFF = 12, WSB_OFF = 14, SV_X = 16, OFF_W = 18, SV_MEAN = 20, SV_RSTD = 22, DZ_OFF = 24, WT_OFF = 26, NFIELD = 32 };
+  int rec[ULTR_MAXL][NFIELD];
+};
+
 // Segment table for the deterministic slab reduction: grads[off .. off+len) =
 //   sum_{s < nparts} ws[base + s*stride + e]
 struct RedSeg {
