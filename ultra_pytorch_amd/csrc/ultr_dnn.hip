@@ -569,6 +569,12 @@ extern "C" int ultr_trace_read(unsigned long long* host_out) {
 // Forward
 // ------------------------------------------------------------------------------------------------
 // prefetch depth (trips of 32 W rows) of the forward GEMM pipeline
+#ifndef FWD_SW
+#define FWD_SW 1  // dnn_fwd_kernel: layers with >= 8 chunks of 32 output columns stream the fragment-major copy (PipeSw)
+#endif
+#ifndef BWD_SW
+#define BWD_SW 1  // dnn_bwd2_kernel: the dgrad products of layers >= 1 with >= 8 chunks stream the fragment-major copy of W_j
+#endif
 #ifndef WG_ATOMIC
 #define WG_ATOMIC 0  // TIMING EXPERIMENT: the weight-gradient epilogue adds its 64 x 64 partial into ONE slab
                      // with hardware fp32 atomics (all row splits of a block hit the same 16 KB) instead of writing its own slab;
@@ -869,7 +875,28 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
             else if (NW % nch4 == 0 && K % (32 * (NW / nch4)) == 0 && K / (NW / nch4) >= 64) q4 = NW / nch4;
           }
         }
-        if (Q4 && q4 == 1) {
+        bool sw_done = false;
+        if constexpr (RT == 1 && NW == 8) {
+          if (FWD_SW && p.sw_ok && M >= 32 * NW) {
+            // fragment-major copy (DnnPlan::wsf_off): 32-column chunks, every wave over the whole contraction
+            const int ntr = K16 >> 5;
+            const Src Ws = make_src(wt + p.wsf_off[j], (int64_t)K16 * M);
+            PipeSw<FB_SWD> ps;
+            const int cs = wave * 32;
+            ps.begin(Ws, wave, ntr, 0, ntr, cs < M, lane);
+            for (int cc = cs; cc < M; cc += NW * 32) {
+              f32x4 acc[RT][2];
+#pragma unroll
+              for (int t = 0; t < 2; ++t) acc[0][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+              ps.run(X, ld, Ws, 0, ntr, acc[0], lane);
+              if (cc + NW * 32 < M) ps.begin(Ws, (cc + NW * 32) >> 5, ntr, 0, ntr, true, lane);
+              finish_fwd_nn<RT, 2>(acc, Y, ld, M, cc, lane, bias, p.act, gout, rows_valid);
+            }
+            sw_done = true;
+          }
+        }
+        if (sw_done) {
+        } else if (Q4 && q4 == 1) {
           GemmPipe<RT, 4, FWD_D, 0> pipe4;
           const int c4 = wave * 64;
           pipe4.begin(Wt, M, 0, K, c4, c4 < M, 0, lane);
@@ -1318,7 +1345,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
                                                            const int32_t* __restrict__ docids, int B, int L,
                                                            const float* __restrict__ saved,
                                                            const float* __restrict__ dscores, float* __restrict__ ws,
-                                                           FusedSoftmax fl) {
+                                                           FusedSoftmax fl, const float* __restrict__ wt) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int RT = R / 16, NT = NW * 64, RPW = R / NW;
   static_assert(R % NW == 0, "a wave owns whole rows");
@@ -1542,7 +1569,27 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
       const Src Wsrc = make_src(params + p.off_w[j], (int64_t)M * K);
       static_assert(NW == 8, "the precomputed split is for 8 waves");
       const int nch = p.bwd_nch[j], msplit = p.bwd_msplit[j], mode = p.bwd_mode[j];
-      if (mode == 1) {
+      bool sw_done = false;
+      if constexpr (RT == 1) {
+        if (BWD_SW && wt != nullptr && p.sw_ok && j >= 1 && K >= 32 * NW) {
+          // fragment-major copy of W_j (DnnPlan::wsb_off; M is a multiple of 32 there): 32-column chunks of K, whole contraction
+          const int ntr = M >> 5;
+          const Src Wb = make_src(wt + p.wsb_off[j], (int64_t)M * round_up(K, 32));
+          PipeSw<FB_SWD> ps;
+          ps.begin(Wb, wave, ntr, 0, ntr, wave * 32 < K, lane);
+          for (int ch = wave; ch * 32 < K; ch += NW) {
+            f32x4 acc[RT][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[0][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            ps.run(DZ, ldz, Wb, 0, ntr, acc[0], lane);
+            if ((ch + NW) * 32 < K) ps.begin(Wb, ch + NW, ntr, 0, ntr, true, lane);
+            store_nn<RT, 2>(acc, DU, ldu, K, ch * 32, lane, false);
+          }
+          sw_done = true;
+        }
+      }
+      if (sw_done) {
+      } else if (mode == 1) {
         for (int ch = wave; ch * 32 < K; ch += NW) {
           f32x4 acc[RT][2];
 #pragma unroll
@@ -3216,7 +3263,7 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
     e = set_lds(dnn_bwd2_kernel<RR, 8, XX>, lds2);                                                                     \
     if (e != hipSuccess) return (int)e;                                                                                \
     ULTR_LAUNCH(prof, (dnn_bwd2_kernel<RR, 8, XX>), dim3(bp.nrb), dim3(512), lds2, st, p, bp, params, features,        \
-                       n_docs, docids, (int)batch, (int)list_size, (const float*)saved, dscores, ws, fl);              \
+                       n_docs, docids, (int)batch, (int)list_size, (const float*)saved, dscores, ws, fl, g_ultr_step_wt); \
   } while (0)
   bp.l0g = l0g_ok ? 1 : 0;  // every backward kernel skips du_0; the wgrad launch makes up for it
   bp.wg_prenorm = (fused_rb > 0) ? 1 : 0;  // the fused kernel left the ready-made wgrad operands in `saved`

@@ -192,6 +192,9 @@ struct EarlyReport {
   float rlw;
 };
 extern thread_local EarlyReport g_ultr_early;  // ultr_step.hip
+// the weight copies of the step in flight (ultr_step_args::wt) for the backward kernels ultr_train_step launches: the public
+// ultr_dnn_backward has no such argument (nullptr there: the row-major parameters are streamed)
+extern thread_local const float* g_ultr_step_wt;  // ultr_step.hip
 // ... and in the data-parallel step the loss needs the GLOBAL sums: the exchange kernel's workgroup that reduces the head of
 // the step tail reports it (ultr_comm.hip), one launch ahead of the update
 struct ultr_comm;

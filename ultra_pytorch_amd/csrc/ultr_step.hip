@@ -32,6 +32,7 @@ static int finish_step(const ultr_step_args* a, void* stream) {
 }
 
 thread_local EarlyReport g_ultr_early = {nullptr, 0u, 0, 1.0f};
+thread_local const float* g_ultr_step_wt = nullptr;
 
 namespace {
 // early loss report for the backward call(s) of this step (EarlyReport, ultr_plan.h): only where the local loss sums ARE the
@@ -41,8 +42,12 @@ struct EarlyScope {
     const ultr_update_desc* u = a->upd;
     const bool ok = u->host_scalars != nullptr && a->comm == nullptr && !a->skip_update && u->l2_loss == 0.f;
     g_ultr_early = {ok ? u->host_scalars : nullptr, u->seq, u->algo, u->ranker_loss_weight};
+    g_ultr_step_wt = a->wt;
   }
-  ~EarlyScope() { g_ultr_early.host = nullptr; }
+  ~EarlyScope() {
+    g_ultr_early.host = nullptr;
+    g_ultr_step_wt = nullptr;
+  }
 };
 }  // namespace
 
