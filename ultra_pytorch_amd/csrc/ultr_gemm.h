@@ -28,6 +28,9 @@
 //     are masked: any R, N, K (K % 4 == 0 and 16-byte aligned rows for the vector loads; checked by the launcher).
 #pragma once
 #include <atomic>
+#ifndef UGEMM_BM128
+#define UGEMM_BM128 0
+#endif
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
@@ -620,6 +623,10 @@ inline hipError_t launch(const Dims& d, const AProd& aprod, const float* B, cons
 template <bool B_NMAJOR, class AProd, class Epi>
 inline hipError_t run(const Dims& d, const AProd& aprod, const float* B, const Epi& epi, hipStream_t st, hipEvent_t ev_start = nullptr,
                       hipEvent_t ev_stop = nullptr) {
+#if UGEMM_BM128
+  // experiment: 128 x 128 chunks (a wave = two 16-row tiles x 64 columns: twice the MFMAs per fragment read and per barrier)
+  if (d.N > 64 && d.R >= 16384) return launch<128, 128, 4, 2, B_NMAJOR>(d, aprod, B, epi, st, ev_start, ev_stop);
+#endif
   if (d.N > 64) return launch<64, 128, 4, 2, B_NMAJOR>(d, aprod, B, epi, st, ev_start, ev_stop);
   return launch<64, 64, 4, 1, B_NMAJOR>(d, aprod, B, epi, st, ev_start, ev_stop);
 }
