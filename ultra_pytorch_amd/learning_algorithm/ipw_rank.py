@@ -90,7 +90,7 @@ class IPWrank(BaseAlgorithm):
         if clicks is not None:
             if self._pw_table is None or self._pw_table.shape[0] != L:
                 self._pw_table = np.asarray([self.IPW_list[min(l, len(self.IPW_list) - 1)] for l in range(L)])
-            self._lazy_pw = lazy = _LazyWeights(clicks, self._pw_table)
+            self._lazy_pw = lazy = _LazyWeights(clicks.copy(), self._pw_table)  # own copy: `clicks` is a view of the staging buffer
             for l in range(L):
                 input_feed[self._pw_names[l]] = _LazyColumn(lazy, l)
         eng = self._train_engine(self.batch_size, L)
