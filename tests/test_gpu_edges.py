@@ -172,3 +172,78 @@ def test_host_mapped_step_report_equals_device_scalars():
         want = eng.scalars[:8].cpu().numpy()
         assert np.array_equal(got, want), (k, got, want)
         assert np.isfinite(got[0]) and eng.read_loss() == float(want[0])
+
+
+@pytest.mark.parametrize("F,hidden,B,L", [(136, [256, 256], 33, 10),    # config 2's layers, ragged batch (fragment-major path)
+                                          (40, [512, 256], 7, 10),      # 512-wide rows: the two-chunk-per-lane build of the fused kernel
+                                          (24, [64, 32, 32], 20, 8),    # three hidden layers; 64 / 32-wide: split contraction (k-major path)
+                                          (136, [128], 16, 16),         # one hidden layer, full 16-row tiles
+                                          (32, [96, 64], 12, 5),        # three lists per 16-row tile
+                                          (20, [48, 24], 9, 3)])        # widths not multiples of 32: no fragment-major copies
+def test_fused_step_shapes_match_oracle(F, hidden, B, L):
+    """The small-batch NA / IPW step (ONE fused forward + loss + backward launch, dnn_fb_kernel) through ultr_train_step at
+    shapes that reach every path of the kernel - fragment-major and k-major weight streaming, one / two column chunks per
+    lane, 1 - 5 lists per tile - against the oracle: scores, loss, gradient, norm, updated parameters."""
+    from oracle import ultr_oracle as O
+    from ultra_pytorch_amd import engine, hip_ops
+    rng = np.random.RandomState(F + B)
+    n_docs = B * L - 2
+    feats = rng.uniform(-1, 1, size=(n_docs, F)).astype(np.float32)
+    ids = rng.permutation(B * L)
+    ids = np.where(ids >= n_docs, n_docs, ids).astype(np.int32).reshape(L, B)  # two PAD documents
+    clicks = (rng.uniform(size=(L, B)) < 0.35).astype(np.float32)
+    clicks[0, :] = 1.0
+    params = O.init_params(F, hidden, seed=7)
+    for name, shape, off in O.param_layout(F, hidden):  # non-trivial LayerNorm affine parameters
+        if "layer_norm" in name:
+            n = int(np.prod(shape))
+            params[off:off + n] += rng.uniform(-0.3, 0.3, size=n).astype(np.float32)
+    state0 = (0.01 * rng.uniform(size=params.shape)).astype(np.float32)
+    ipw = np.linspace(1.0, 6.0, 12)
+    ref = O.train_step_softmax(params, state0, F, hidden, feats, ids, clicks, ipw_list=ipw)
+    shape = hip_ops.DnnShape(F, hidden, "elu")
+    eng = engine.StepEngine(shape, B, L, torch.device("cuda"), algo="softmax")
+    p, st = dev(params), dev(state0)
+    eng.train_step(p, st, dev(feats), n_docs, dev(ids, torch.int32), dev(clicks), ipw_table=dev(ipw.astype(np.float32)))
+    sc = eng.read_scalars()
+    np.testing.assert_allclose(eng.scores.cpu().numpy(), ref["scores"], atol=1e-5, rtol=1e-5)
+    assert abs(sc[0] - ref["loss"]) <= 1e-5 * max(1.0, abs(ref["loss"]))
+    g = eng.grads[:shape.n_params].cpu().numpy() / sc[3]
+    np.testing.assert_allclose(g, ref["grads"], rtol=2e-5, atol=2e-6 * max(1.0, float(np.abs(ref["grads"]).max())))
+    assert abs(sc[1] - ref["norm"]) <= 1e-5 * max(1.0, ref["norm"])
+    sel = np.abs(ref["grads"]) > 1e-4 * np.abs(ref["grads"]).max()
+    np.testing.assert_allclose(p.cpu().numpy()[sel], ref["params"][sel], rtol=1e-5, atol=5e-6)
+    # the step that follows streams the weight copies the update kernel maintained (k-major, image, fragment-major): its scores
+    # must be the oracle's forward on the oracle's updated parameters (they differ from the kernel's by the 1e-5 bar)
+    eng.train_step(p, st, dev(feats), n_docs, dev(ids, torch.int32), dev(clicks), ipw_table=dev(ipw.astype(np.float32)))
+    sc2 = eng.read_scalars()
+    ref2 = O.train_step_softmax(ref["params"], ref["state"], F, hidden, feats, ids, clicks, ipw_list=ipw)
+    np.testing.assert_allclose(eng.scores.cpu().numpy(), ref2["scores"], atol=2e-4, rtol=2e-4)
+    assert abs(sc2[0] - ref2["loss"]) <= 1e-4 * max(1.0, abs(ref2["loss"]))
+
+
+def test_update_kernel_keeps_every_weight_copy_current():
+    """k-major copy, packed image and the fragment-major copies after ultr_apply_update == a fresh ultr_dnn_build_wt of the
+    updated parameters (bitwise), for a model that has the fragment-major copies (widths multiples of 32) and a ragged F."""
+    import ctypes
+    from oracle import ultr_oracle as O
+    from ultra_pytorch_amd import engine, hip_ops, synthetic
+    F, hidden, B, L = 136, [256, 64], 16, 10
+    rng = np.random.RandomState(1)
+    shape = hip_ops.DnnShape(F, hidden, "elu")
+    eng = engine.StepEngine(shape, B, L, torch.device("cuda"), algo="softmax")
+    p = dev(O.init_params(F, hidden, seed=9))
+    st = torch.zeros_like(p)
+    for _ in range(3):
+        feats, ids, y = synthetic.make_batch(rng, B, L, F)
+        eng.train_step(p, st, dev(feats), feats.shape[0], dev(ids, torch.int32), dev(y))
+    torch.cuda.synchronize()
+    kept = hip_ops.weight_copy(shape).get(p).clone()
+    fresh = torch.zeros_like(kept)
+    from ultra_pytorch_amd._lib import check
+    check(shape.lib.ultr_dnn_build_wt(ctypes.byref(shape.desc), ctypes.c_void_p(p.data_ptr()), ctypes.c_void_p(fresh.data_ptr()),
+                                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ultr_dnn_build_wt")
+    torch.cuda.synchronize()
+    assert kept.numel() > shape.n_params  # copies + image + fragment-major region
+    diff = (kept != fresh).nonzero().flatten()
+    assert diff.numel() == 0, (diff[:8].tolist(), diff.numel(), kept.numel())

@@ -170,7 +170,7 @@ class WeightCopy:
         key = (params.data_ptr(), params._version)
         same = self.ref is not None and self.ref() is params and key == self.key
         if self.wt is None or self.wt.device != params.device:
-            self.wt = torch.empty(self.n, dtype=torch.float32, device=params.device)
+            self.wt = torch.zeros(self.n, dtype=torch.float32, device=params.device)  # alignment gaps stay zero
             same = False
         if not same:
             check(self.shape.lib.ultr_dnn_build_wt(ctypes.byref(self.shape.desc), _p(params), _p(self.wt), _stream()),
