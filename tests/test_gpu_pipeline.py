@@ -12,6 +12,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DATA = os.path.join(GOLDEN, "ultra_toy_data") + "/"
 
 
@@ -141,3 +142,24 @@ def test_driver_matches_the_reference_run(tmp_path, monkeypatch):
                 assert np.all(np.abs(sd[k] - d["init_" + k]) <= bound), k
                 continue
             np.testing.assert_allclose(sd[k], d["save%d_%s" % (i, k)], rtol=5e-3, atol=5e-4, err_msg=k)
+
+
+def test_bench_multi_rank_logic_on_one_gpu():
+    """`python bench.py --gpus 2` launches its own ranks and prints ONE JSON line carrying both gradient exchanges and the
+    checks - exercised here with both ranks on cuda:0 over gloo (ULTR_BENCH_SHARE_GPU=1: a test of bench.py's N > 1 logic, the
+    same code the driver's scaling run takes; not a measurement)."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, ULTR_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "5", "--no-cpu-baseline",
+                        "--no-extras"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 512 and d["steps"] == 40
+    assert len(d["dp_exchanges"]) == 2 and all("ms_per_step" in v for v in d["dp_exchanges"].values())
+    assert d["dp_checks"]["replicas_bit_identical_after_run"] and d["dp_checks"]["peer_exchange_matches_rccl_allreduce"]
+    assert d["rccl_ranks"] == 2 and d["value"] > 0
