@@ -239,3 +239,28 @@ def test_fp16_attention_ordering_parity_config5_shape():
           % (100 * same_order, 100 * same_set, n16, n32))
     assert same_set >= 0.99 and same_order >= 0.99  # VERDICT r01 item 4's bar; measured 100 % / 100 % (deterministic kernels, fixed seed)
     assert abs(n16 - n32) <= 1e-3
+
+
+@pytest.mark.parametrize("shape", [(24, 64, 2, 2, 16, 6, 20), (40, 64, 2, 2, 32, 4, 37)])
+def test_fp16_attention_against_the_oracle_directly(shape):
+    """The opt-in fp16-operand attention against the ORACLE itself (not only against the library's fp32 path): scores, loss and
+    gradient of one IPW step at its ordering-level bar - scores within 2e-3 of the score range, loss
+    within 1e-3, the whole gradient within 0.5 % in norm."""
+    from oracle import ultr_oracle as O
+    from ultra_pytorch_amd import hip_ops, synthetic
+    from ultra_pytorch_amd.ranking_model.SetRank import init_setrank_params
+    F, dm, H, nl, dff, B, L = shape
+    rng = np.random.RandomState(11)
+    feats, ids, y = synthetic.make_batch(rng, B, L, F)
+    ipw = synthetic.load_ipw()
+    sh = hip_ops.SetRankShape(F, dm, H, nl, dff, attention_dtype="fp16")
+    p0 = init_setrank_params(sh, seed=5).numpy()
+    s16, g16, _, _, sc16 = run_step(sh, B, L, {}, p0, np.zeros_like(p0), feats, ids, y, ipw)
+    ref = O.train_step_setrank_softmax(p0, np.zeros_like(p0), (F, dm, H, nl, dff), feats, ids, y, ipw_list=ipw)
+    span = float(ref["scores"].max() - ref["scores"].min())
+    np.testing.assert_allclose(s16, ref["scores"], atol=2e-3 * max(span, 1.0), rtol=0)
+    assert abs(float(sc16[0]) - ref["loss"]) <= 1e-3 * max(1.0, abs(ref["loss"]))
+    P = sh.n_params
+    g = g16[:P] / float(sc16[3])
+    rel = np.linalg.norm(g - ref["grads"]) / np.linalg.norm(ref["grads"])
+    assert rel < 5e-3, rel

@@ -52,6 +52,23 @@ __device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
 #pragma unroll
   for (int k = 0; k < N; ++k) v[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[k]), 63));
 }
+template <int N>
+__device__ __forceinline__ void wave_max_n(float (&v)[N]) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = fmaxf(v[k], dpp_or<0xb1>(v[k], v[k]));
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = fmaxf(v[k], dpp_or<0x4e>(v[k], v[k]));
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = fmaxf(v[k], dpp_or<0x124>(v[k], v[k]));
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = fmaxf(v[k], dpp_or<0x128>(v[k], v[k]));
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = fmaxf(v[k], dpp_or<0x142>(v[k], v[k]));
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = fmaxf(v[k], dpp_or<0x143>(v[k], v[k]));
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[k]), 63));
+}
 __device__ __forceinline__ float wave_max(float v) {
   v = fmaxf(v, dpp_or<0xb1>(v, v));
   v = fmaxf(v, dpp_or<0x4e>(v, v));

@@ -470,6 +470,101 @@ struct PipeSw {
 #define FB_SW 1   // dnn_fb_kernel streams the fragment-major copies when the plan has them (0: the k-major / row-major paths)
 #endif
 
+// Products on the fp16 matrix cores with SPLIT operands (DnnPlan::whf_off / whb_off, ultr_h3_index): the A tile lives in LDS as two
+// fp16 planes (hi, lo of the row-scaled activations), the weights arrive as hi / lo fragments, and a . w = ah.wh + (ah.wl + al.wh)
+// with fp32 accumulation on v_mfma_f32_16x16x32_f16 - 22 bits of operand mantissa, 6 MFMAs of 16 cycles per 32-deep step and
+// two column tiles where the fp32 path issues 16 MFMAs of 32 cycles.  One step = FOUR buffer_load_dwordx4 per lane (tile 0 hi,
+// tile 0 lo, tile 1 hi, tile 1 lo), each 1 KiB contiguous per wave: the bytes of the fp32 copy.  The cross terms go to their
+// own accumulators (they are 2^-11 of the main term) and are added at the end.
+typedef _Float16 fbh8 __attribute__((ext_vector_type(8)));
+typedef _Float16 fbh4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 fb_mfma_h(fbh8 a, fbh8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ fbh8 fb_as_h8(float4 v) {
+  union { float4 f; fbh8 h; } u;
+  u.f = v;
+  return u.h;
+}
+// power-of-two scale that brings a row's largest magnitude just below 2^14 (fp16 overflows at 65504), and its inverse
+__device__ __forceinline__ void fb_h3_scale(float amax, float& rs, float& inv) {
+  int se = 267 - (int)((__float_as_uint(amax) >> 23) & 0xffu);  // amax in [2^(E-127), 2^(E-126)): amax * 2^(se-127) < 2^14
+  se = se < 1 ? 1 : (se > 253 ? 253 : se);
+  rs = __uint_as_float((unsigned)se << 23);
+  inv = __uint_as_float((unsigned)(254 - se) << 23);
+}
+__device__ __forceinline__ void fb_h3_split4(float4 v, float rs, fbh4& hi, fbh4& lo) {
+  const float a[4] = {v.x * rs, v.y * rs, v.z * rs, v.w * rs};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    hi[k] = (_Float16)a[k];
+    lo[k] = (_Float16)(a[k] - (float)hi[k]);
+  }
+}
+template <int D>
+struct PipeH3 {
+  float4 b[D][4];
+  unsigned of;
+  int left;
+  template <int S>
+  __device__ __forceinline__ void fetch(const Src& W) {
+    const bool ok = left > 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) b[S][u] = buf_ld4(W, ok ? (of + (unsigned)u * 1024u) : ULTR_OOB);
+    --left;
+    of += 4096u;
+  }
+  __device__ __forceinline__ void begin(const Src& W, int chunk, int nks, bool valid, int lane) {
+    of = ((unsigned)chunk * (unsigned)nks * 256u + (unsigned)lane) * 16u;
+    left = valid ? nks : 0;
+    if constexpr (D > 1) fetch<0>(W);
+    if constexpr (D > 2) fetch<1>(W);
+    static_assert(D >= 2 && D <= 3, "pipeline depth");
+  }
+  template <int S>
+  __device__ __forceinline__ void consume(const _Float16* __restrict__ ah_p, const _Float16* __restrict__ al_p, f32x4 (&acc)[2],
+                                          f32x4 (&accx)[2]) {
+    const fbh8 ah = *reinterpret_cast<const fbh8*>(ah_p), al = *reinterpret_cast<const fbh8*>(al_p);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const fbh8 wh = fb_as_h8(b[S][2 * t]), wl = fb_as_h8(b[S][2 * t + 1]);
+      acc[t] = fb_mfma_h(ah, wh, acc[t]);
+      accx[t] = fb_mfma_h(ah, wl, accx[t]);
+      accx[t] = fb_mfma_h(al, wh, accx[t]);
+    }
+  }
+  // Ah / Al: the two planes of the A tile, row stride ldh halves, zero beyond the real contraction length up to nks * 32
+  __device__ __forceinline__ void run(const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al, int ldh, const Src& W, int nks,
+                                      f32x4 (&acc)[2], f32x4 (&accx)[2], int lane) {
+    const int i = lane & 15, q = lane >> 4;
+    const _Float16* ph = Ah + i * ldh + 8 * q;
+    const _Float16* pl = Al + i * ldh + 8 * q;
+    auto step = [&](auto uc) {
+      constexpr int U = decltype(uc)::value;
+      fetch<(U + D - 1) % D>(W);
+      __builtin_amdgcn_sched_barrier(0);
+      consume<U>(ph, pl, acc, accx);
+      ph += 32;
+      pl += 32;
+    };
+    int t = 0;
+    for (; t + D <= nks; t += D) {
+      step(std::integral_constant<int, 0>());
+      step(std::integral_constant<int, 1>());
+      if constexpr (D > 2) step(std::integral_constant<int, 2>());
+    }
+    if (t < nks) { consume<0>(ph, pl, acc, accx); ph += 32; pl += 32; }
+    if constexpr (D > 2) if (t + 1 < nks) { consume<1>(ph, pl, acc, accx); ph += 32; pl += 32; }
+  }
+};
+// rows 4 q + r of the accumulators times the per-row output scales (1 / (row scale x weight scale)), cross terms folded in
+__device__ __forceinline__ void fb_h3_finish(f32x4 (&acc)[1][2], const f32x4 (&accx)[2], const float* __restrict__ os, int lane) {
+  const float4 o4 = ld4(os + 4 * (lane >> 4));
+  const float o[4] = {o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[0][t][r] = (acc[0][t][r] + accx[t][r]) * o[r];
+}
+
 // forward epilogue of the last contraction slice: (+ partial sums of earlier slices) + bias, activation; to LDS
 // (next layer's input) and, when training, to HBM — 4*CT-byte stores, the lane owns CT consecutive output columns
 template <int RT, int CT>
@@ -1738,10 +1833,11 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
 __host__ __device__ static inline size_t fb_lds_floats(const DnnPlan& p) {
   const size_t ld = fwd_ld(p.maxdim), ldu = bwd_ldu(p.maxdim);
   return (size_t)16 * ld * (p.nl + 1) + 16 * ldu + (size_t)8 * bwd2_cp_stride(p) + (size_t)p.pv_total + 2 * 16 * (size_t)p.nl +
-         2 * 16 + 2 * 8 + 8;
+         2 * 16 + 2 * 8 + 8 +
+         (p.h3_ok ? (size_t)16 * (round_up(p.maxdim, 32) + 8) + 8 : 0);  // two fp16 planes [16][ldh] (4 bytes per element)
 }
 
-template <int XC>
+template <int XC, bool H3>
 __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, const float* __restrict__ params,
                                                      const float* __restrict__ wt, const float* __restrict__ features,
                                                      int64_t n_docs, const int32_t* __restrict__ docids, int B, int L,
@@ -1763,6 +1859,11 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
   float* sm_s = sm_rstd + p.nl * R;             // [16] scores
   float* sm_ds = sm_s + R;                      // [16]
   float* sm_lt = sm_ds + R;                     // [NW][2]
+  // H3: the A tile of every product as two fp16 planes (hi / lo of the row-scaled values) + the per-row output scales
+  const int ldh = round_up(p.maxdim, 32) + 8;   // halves per plane row (528-byte rows at 256: conflict-free 16-byte reads)
+  _Float16* AH = reinterpret_cast<_Float16*>(sm_lt + 2 * NW);  // [16][ldh]
+  _Float16* AL = AH + R * ldh;                                 // [16][ldh]
+  __shared__ float sm_os[R];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int RB = LPB * L;                       // live rows of this block
   const int64_t n0 = (int64_t)blockIdx.x * RB;
@@ -1930,6 +2031,10 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
         for (int u = 0; u < XC; ++u) t[RPW] += (b4[u].x + b4[u].y) + (b4[u].z + b4[u].w);
         wave_sum_n<RPW + 1>(t);
       }
+      float4 uq[RPW][XC];  // H3: the rows' LayerNorm outputs wait here for their scale
+      float am[RPW];
+#pragma unroll
+      for (int q = 0; q < RPW; ++q) am[q] = 0.f;
 #pragma unroll
       for (int q = 0; q < RPW; ++q) {
         const int r = wave + NW * q;
@@ -1951,7 +2056,12 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
               const float4 xh = make_float4(xx.x * rstd, xx.y * rstd, xx.z * rstd, xx.w * rstd);
               const float4 uu = make_float4(xh.x * g4[u].x + b4[u].x, xh.y * g4[u].y + b4[u].y, xh.z * g4[u].z + b4[u].z,
                                             xh.w * g4[u].w + b4[u].w);
-              st4(UZ + r * ld + c, uu);
+              if constexpr (H3) {
+                uq[q][u] = uu;
+                am[q] = fmaxf(am[q], fmaxf(fmaxf(fabsf(uu.x), fabsf(uu.y)), fmaxf(fabsf(uu.z), fabsf(uu.w))));
+              } else {
+                st4(UZ + r * ld + c, uu);
+              }
 #if FB_WT == 2
               if (c < K && r < rows_valid) st4_stream(wop + c, xhat_only ? xh : uu);
 #elif FB_WT
@@ -1977,6 +2087,28 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
           }
         }
       }
+      if constexpr (H3) {
+        if (!last) {
+          wave_max_n<RPW>(am);
+#pragma unroll
+          for (int q = 0; q < RPW; ++q) {
+            const int r = wave + NW * q;
+            float rs, inv;
+            fb_h3_scale(am[q], rs, inv);
+#pragma unroll
+            for (int u = 0; u < XC; ++u) {
+              const int c = 4 * lane + 256 * u;
+              if (c < K32) {
+                fbh4 hi, lo;
+                fb_h3_split4(uq[q][u], rs, hi, lo);
+                *reinterpret_cast<fbh4*>(AH + r * ldh + c) = hi;
+                *reinterpret_cast<fbh4*>(AL + r * ldh + c) = lo;
+              }
+            }
+            if (lane == 0) sm_os[r] = inv * (1.0f / ULTR_H3_WSCALE);
+          }
+        }
+      }
       if (j == 0) TRACE_STAMP(7);
     }
     lds_barrier();
@@ -1988,7 +2120,22 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
       const Src Wt = make_src(wt + FBF64(rv, FbPlan::WT_OFF), (int64_t)K * M);
       const int nch = FBF(rv, FbPlan::NCH), ksplit = FBF(rv, FbPlan::KSPLIT), klen = FBF(rv, FbPlan::KLEN);
       GemmPipe<RT, 2, FWD_D, 0> pipe;
-      if (FB_SW && p.sw_ok && ksplit == 1) {
+      if constexpr (H3) {
+        const int nks = K32 >> 5;
+        const Src Wh = make_src(wt + FBF64(rv, FbPlan::WHF_OFF), (int64_t)K32 * M);
+        PipeH3<FB_SWD> ph;
+        const int c0 = wave * 32;
+        ph.begin(Wh, wave, nks, c0 < M, lane);
+        for (int cc = c0; cc < M; cc += NW * 32) {
+          f32x4 acc[RT][2], accx[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) acc[0][t] = accx[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          ph.run(AH, AL, ldh, Wh, nks, acc[0], accx, lane);
+          if (cc + NW * 32 < M) ph.begin(Wh, (cc + NW * 32) >> 5, nks, true, lane);
+          fb_h3_finish(acc, accx, sm_os, lane);
+          finish_fwd_nn<RT, 2>(acc, Y, ld, M, cc, lane, bias, p.act, gout, rows_valid);
+        }
+      } else if (FB_SW && p.sw_ok && ksplit == 1) {
         const int ntr = K32 >> 5;
         const Src Ws = make_src(wt + FBF64(rv, FbPlan::WSF_OFF), (int64_t)K32 * M);
         PipeSw<FB_SWD> ps;
@@ -2121,7 +2268,22 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
       finalize(j + 1);
       const Src Wsrc = make_src(params + FBF64(rv, FbPlan::OFF_W), (int64_t)M * K);
       const int nch = FBF(rv, FbPlan::BWD_NCH), msplit = FBF(rv, FbPlan::BWD_MSPLIT), mode = FBF(rv, FbPlan::BWD_MODE);
-      if (FB_SW && p.sw_ok && j >= 1) {
+      if (H3 && j >= 1) {
+        // du_j = dz_j . W_j on the fp16 matrix cores: the row pass left dz_j as hi / lo planes with per-row scales
+        const int nks = (M + 31) >> 5;
+        const Src Wh = make_src(wt + FBF64(rv, FbPlan::WHB_OFF), (int64_t)round_up(M, 32) * round_up(K, 32));
+        PipeH3<FB_SWD> ph;
+        ph.begin(Wh, wave, nks, wave * 32 < K, lane);
+        for (int ch = wave; ch * 32 < K; ch += NW) {
+          f32x4 acc[RT][2], accx[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) acc[0][t] = accx[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          ph.run(AH, AL, ldh, Wh, nks, acc[0], accx, lane);
+          if ((ch + NW) * 32 < K) ph.begin(Wh, ch + NW, nks, true, lane);
+          fb_h3_finish(acc, accx, sm_os, lane);
+          store_nn<RT, 2>(acc, DU, ldu, K, ch * 32, lane, false);
+        }
+      } else if (FB_SW && p.sw_ok && j >= 1) {
         // du_j = dz_j . W_j over the fragment-major copy of W_j: 32-column chunks of K over the whole contraction M
         const int ntr = (M + 31) >> 5;
         const Src Wb = make_src(wt + FBF64(rv, FbPlan::WSB_OFF), (int64_t)round_up(M, 32) * round_up(K, 32));
@@ -2234,6 +2396,10 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
         wave_sum_n<2 * RPW>(red);
         const int64_t dzo = FBF64(rec_of(j - 1), FbPlan::DZ_OFF);
         float* dzg = ws + dzo;
+        float4 dzq[RPW][XC];  // H3: dz rows wait here for their scale
+        float amz[RPW];
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) amz[k] = 0.f;
 #pragma unroll
         for (int k = 0; k < RPW; ++k) {
           const int r = wave + NW * k;
@@ -2241,6 +2407,7 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
 #pragma unroll
           for (int u = 0; u < XC; ++u) {
             const int c = 4 * lane + 256 * u;
+            if constexpr (H3) dzq[k][u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (c < K) {
               const float4 x4 = xk[k][u], gx = gxk[k][u];
               float4 dz;
@@ -2248,7 +2415,12 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
               dz.y = rstd[k] * (gx.y - s1 - (x4.y - mean[k]) * rstd[k] * s2) * act_grad_from_out(x4.y, p.act);
               dz.z = rstd[k] * (gx.z - s1 - (x4.z - mean[k]) * rstd[k] * s2) * act_grad_from_out(x4.z, p.act);
               dz.w = rstd[k] * (gx.w - s1 - (x4.w - mean[k]) * rstd[k] * s2) * act_grad_from_out(x4.w, p.act);
-              st4(DZ + r * ldz + c, dz);
+              if constexpr (H3) {
+                dzq[k][u] = dz;
+                amz[k] = fmaxf(amz[k], fmaxf(fmaxf(fabsf(dz.x), fabsf(dz.y)), fmaxf(fabsf(dz.z), fabsf(dz.w))));
+              } else {
+                st4(DZ + r * ldz + c, dz);
+              }
 #if FB_WT == 2
               if (r < rows_valid) st4_stream(dzg + (n0 + r) * K + c, dz);
 #elif FB_WT
@@ -2258,7 +2430,29 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
 #endif
             }
           }
-          for (int c = K + lane; c < round_up(K, 32); c += 64) DZ[r * ldz + c] = 0.f;
+          if constexpr (!H3)
+            for (int c = K + lane; c < round_up(K, 32); c += 64) DZ[r * ldz + c] = 0.f;
+        }
+        if constexpr (H3) {
+          // dz_{j-1} as hi / lo planes for the dgrad product of the next iteration (K = M_{j-1} is a multiple of 32 here)
+          wave_max_n<RPW>(amz);
+#pragma unroll
+          for (int k = 0; k < RPW; ++k) {
+            const int r = wave + NW * k;
+            float rs, inv;
+            fb_h3_scale(amz[k], rs, inv);
+#pragma unroll
+            for (int u = 0; u < XC; ++u) {
+              const int c = 4 * lane + 256 * u;
+              if (c < K) {
+                fbh4 hi, lo;
+                fb_h3_split4(dzq[k][u], rs, hi, lo);
+                *reinterpret_cast<fbh4*>(AH + r * ldh + c) = hi;
+                *reinterpret_cast<fbh4*>(AL + r * ldh + c) = lo;
+              }
+            }
+            if (lane == 0) sm_os[r] = inv * (1.0f / ULTR_H3_WSCALE);
+          }
         }
       }
     }
@@ -2723,7 +2917,7 @@ __global__ __launch_bounds__(64) void grad_sumsq_kernel(int64_t P, const float* 
 // per knob per launch is host time on the critical path of a ~50 us step.  ultr_config_reload() re-reads them (tests and
 // the A/B tools flip knobs inside one process).
 struct Knobs {
-  int fwd_r, bwd_r, wgrad_wgs, fwd_nw, bwd_nw, no_vec, no_l0g, bwd_v1, no_fused_fb, fb_max_wg_per_cu, fwd_q4, big_fwd, big_bwd;
+  int fwd_r, bwd_r, wgrad_wgs, fwd_nw, bwd_nw, no_vec, no_l0g, bwd_v1, no_fused_fb, fb_max_wg_per_cu, fwd_q4, big_fwd, big_bwd, fb_h3;
   bool loaded;
 };
 static Knobs g_knobs = {};
@@ -2747,6 +2941,8 @@ static void knobs_load() {
   // the per-layer big-batch path (ultr_dnn_big.hip): 0 never, 1 by the measured rule (big_*_wanted), 2 whenever legal
   k.big_fwd = env_read("ULTR_BIG_FWD", 1);
   k.big_bwd = env_read("ULTR_BIG_BWD", 1);
+  // fused small-batch kernel: products as three fp16 MFMAs on hi / lo operand splits (1, default) or fp32 MFMAs (0)
+  k.fb_h3 = env_read("ULTR_FB_H3", 1);
   k.loaded = true;
   g_knobs = k;
 }
@@ -2841,6 +3037,21 @@ bool ultr_make_dnn_plan(const ultr_dnn_desc* d, int64_t N, DnnPlan* p) {
         if (j >= 1) {
           p->wsb_off[j] = o;
           o += n;
+        }
+      }
+      // split-half copies (DnnPlan::whf_off / whb_off): same element counts, two halves per float
+      bool h3 = true;
+      for (int j = 0; j < p->nl - 1; ++j) h3 = h3 && p->M[j] >= 256;
+      p->h3_ok = h3 ? 1 : 0;
+      if (h3) {
+        for (int j = 0; j < p->nl - 1; ++j) {
+          const int64_t n = (int64_t)round_up(p->K[j], 32) * round_up(p->M[j], 32);
+          p->whf_off[j] = o;
+          o += n;
+          if (j >= 1) {
+            p->whb_off[j] = o;
+            o += n;
+          }
         }
       }
       p->wt_total = o;
@@ -3097,6 +3308,18 @@ __global__ __launch_bounds__(256) void wt_build_kernel(DnnPlan p, const float* _
       if (p.sw_ok) {
         wt[p.wsf_off[j] + ultr_sw_index(m, k, (p.K[j] + 31) >> 5)] = v;
         if (j >= 1) wt[p.wsb_off[j] + ultr_sw_index(k, m, (p.M[j] + 31) >> 5)] = v;
+      }
+      if (p.h3_ok) {
+        const float sv = v * ULTR_H3_WSCALE;
+        const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
+        _Float16* hf = reinterpret_cast<_Float16*>(wt + p.whf_off[j]);
+        hf[ultr_h3_index(m, k, (p.K[j] + 31) >> 5, 0)] = hi;
+        hf[ultr_h3_index(m, k, (p.K[j] + 31) >> 5, 1)] = lo;
+        if (j >= 1) {
+          _Float16* hb = reinterpret_cast<_Float16*>(wt + p.whb_off[j]);
+          hb[ultr_h3_index(k, m, (p.M[j] + 31) >> 5, 0)] = hi;
+          hb[ultr_h3_index(k, m, (p.M[j] + 31) >> 5, 1)] = lo;
+        }
       }
       return;
     }
@@ -3422,21 +3645,28 @@ int ultr_fused_step_softmax(const ultr_dnn_desc* d, const float* params, const f
     put64(FbPlan::WSF_OFF, p.wsf_off[j]); put64(FbPlan::WSB_OFF, p.wsb_off[j]); put64(FbPlan::SV_X, p.sv_x[j]);
     put64(FbPlan::OFF_W, p.off_w[j]); put64(FbPlan::SV_MEAN, p.sv_mean[j]); put64(FbPlan::SV_RSTD, p.sv_rstd[j]);
     put64(FbPlan::DZ_OFF, j < p.nl - 1 ? bp.dz_off[j] : 0); put64(FbPlan::WT_OFF, p.wt_off[j]);
+    put64(FbPlan::WHF_OFF, p.whf_off[j]); put64(FbPlan::WHB_OFF, p.whb_off[j]);
   }
   hipError_t e;
   {
     UltrProfScope prof(ULTR_K_FUSED, st);
+#define LAUNCH_FB(XX, HH)                                                                                                      \
+  do {                                                                                                                         \
+    e = set_lds(dnn_fb_kernel<XX, HH>, lds);                                                                                   \
+    if (e != hipSuccess) return (int)e;                                                                                        \
+    ULTR_LAUNCH(prof, (dnn_fb_kernel<XX, HH>), dim3((unsigned)nblk), dim3(512), lds, st, p, bp, params, wt, features, n_docs,  \
+                docids, (int)batch, L, lpb, scores, (float*)saved, ws, fl, fp);                                                \
+  } while (0)
+    // products on the fp16 matrix cores with split operands where the plan has the split-half copies (ULTR_FB_H3=0: fp32 MFMAs)
+    const bool h3 = p.h3_ok != 0 && knobs().fb_h3 != 0;
     if (p.maxdim <= 256) {
-      e = set_lds(dnn_fb_kernel<1>, lds);
-      if (e != hipSuccess) return (int)e;
-      ULTR_LAUNCH(prof, dnn_fb_kernel<1>, dim3((unsigned)nblk), dim3(512), lds, st, p, bp, params, wt, features, n_docs, docids,
-                  (int)batch, L, lpb, scores, (float*)saved, ws, fl, fp);
+      if (h3) LAUNCH_FB(1, true);
+      else LAUNCH_FB(1, false);
     } else {
-      e = set_lds(dnn_fb_kernel<2>, lds);
-      if (e != hipSuccess) return (int)e;
-      ULTR_LAUNCH(prof, dnn_fb_kernel<2>, dim3((unsigned)nblk), dim3(512), lds, st, p, bp, params, wt, features, n_docs, docids,
-                  (int)batch, L, lpb, scores, (float*)saved, ws, fl, fp);
+      if (h3) LAUNCH_FB(2, true);
+      else LAUNCH_FB(2, false);
     }
+#undef LAUNCH_FB
   }
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;

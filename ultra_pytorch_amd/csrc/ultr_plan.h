@@ -40,6 +40,17 @@ struct DnnPlan {
   int64_t wsf_off[ULTR_MAXL], wsb_off[ULTR_MAXL];
   int64_t ws_begin;       // first float of the fragment-major region (zero-filled by ultr_dnn_build_wt: it is padded)
   int sw_ok;
+  // ... and the SPLIT-HALF fragment copies of the same matrices (h3_ok: every hidden width a multiple of 32 and >= 256), for
+  // the fused small-batch kernel's products on the fp16 matrix cores: every weight, scaled by 2^8, as hi = fp16(w) and
+  // lo = fp16(w - hi) (22 bits of mantissa between them; 4 bytes per weight, as fp32).  A product a . w is evaluated as
+  // ah.wh + ah.wl + al.wh with fp32 accumulation on v_mfma_f32_16x16x32_f16 (16x the fp32 MFMA rate, three products): the
+  // result differs from the fp32 MFMA chain by less than that chain's own rounding (measured on config 2's reference
+  // fixture: scores 8.3e-7 vs 7.5e-7 from the reference, gradients at 0.26 vs 0.24 of the parity tolerance).  Layout
+  // (ultr_h3_index): [chunk of 32 output columns][step of 32 along the contraction][4 loads: tile0 hi, tile0 lo, tile1 hi,
+  // tile1 lo][64 lanes = 16 q + j][8 halves: contraction 32 s + 8 q + e, column 32 c + 2 j + t] - the B-operand fragment
+  // order of the MFMA, 1 KiB contiguous per wave load.  Offsets in FLOATS into the same buffer (two halves per float).
+  int64_t whf_off[ULTR_MAXL], whb_off[ULTR_MAXL];
+  int h3_ok;
   int maxdim;             // max over all K_j (and M_j)
   // work map of the update kernel when it maintains the copies above: 16x16 tiles over every hidden W_j (a tile is
   // read row-major and written k-major through an LDS transpose: 64-byte segments both ways instead of a 4-byte
@@ -75,6 +86,15 @@ __host__ __device__ inline int64_t ultr_sw_index(int c, int k, int ntrips) {
   const int trip = k >> 5, kk = k & 31, h = kk >> 4, r = kk & 15, q = r >> 2, s = r & 3;
   const int u = 2 * h + (s >> 1), e_hi = s & 1;
   return ((((int64_t)chunk * ntrips + trip) * 4 + u) * 64 + (q * 16 + i)) * 4 + (e_hi * 2 + e_lo);
+}
+
+// HALF index (2-byte units) of element (output column c, contraction index k, plane hl = 0 hi / 1 lo) of a split-half
+// fragment matrix with `nks` = ceil(Kc / 32) steps per chunk
+#define ULTR_H3_WSCALE 256.0f  // weights are stored x 2^8: |w| up to 255, lo parts of typical weights stay normal fp16 numbers
+__host__ __device__ inline int64_t ultr_h3_index(int c, int k, int nks, int hl) {
+  const int chunk = c >> 5, t = c & 1, j = (c & 31) >> 1;  // the two column tiles of a chunk interleave: column 32 chunk + 2 j + t
+  const int s = k >> 5, q = (k & 31) >> 3, e = k & 7;      // (the accumulator layout the epilogues of the fp32 paths expect)
+  return ((((int64_t)chunk * nks + s) * 4 + (2 * t + hl)) * 64 + (q * 16 + j)) * 8 + e;
 }
 
 // position of parameter e inside the PV image (DnnPlan::pv_*), or -1 when e is a hidden Linear weight
@@ -139,7 +159,8 @@ struct BwdPlan {
 // load per thread at its start and reads a record with ONE ds_read per wave (lane = field), fields by v_readlane.
 struct FbPlan {
   enum { K = 0, M, PV_OFF, KSPLIT, KLEN, NCH, BWD_NCH, BWD_MSPLIT, BWD_MODE, BWD_MLEN, VOFF_G, VOFF_B,
-         WSF_OFF = 12, WSB_OFF = 14, SV_X = 16, OFF_W = 18, SV_MEAN = 20, SV_RSTD = 22, DZ_OFF = 24, WT_OFF = 26, NFIELD = 32 };
+         WSF_OFF = 12, WSB_OFF = 14, SV_X = 16, OFF_W = 18, SV_MEAN = 20, SV_RSTD = 22, DZ_OFF = 24, WT_OFF = 26, WHF_OFF = 28,
+         WHB_OFF = 30, NFIELD = 32 };
   int rec[ULTR_MAXL][NFIELD];
 };
 

@@ -333,6 +333,31 @@ __global__ __launch_bounds__(256) void update_tiled_kernel(ultr_update_desc u, D
       if (j < 0) continue;
       const int k = k0[q] + r, m = m0[q] + c;  // transposed ownership
       if (k < dp.K[j] && m < dp.M[j]) wt[dp.wt_off[j] + (int64_t)k * dp.M[j] + m] = tile[q][c][r];
+      if (dp.h3_ok && tid >= 128) {
+        // the split-half copies (DnnPlan::whf_off / whb_off, ultr_h3_index): the 16 x 16 tile is 64 pieces of 8 halves (16 bytes)
+        // of each: 2 planes x 2 quarter-steps x 2 column tiles x 8 lanes; threads 128..191 write the forward copy, 192..255 the
+        // dgrad copy
+        const int t6 = tid & 63, hl = t6 >> 5, qq = (t6 >> 4) & 1, tt = (t6 >> 3) & 1, jj = t6 & 7;
+        const bool fwd = tid < 192;
+        if (fwd || j >= 1) {
+          // forward: output column = m (tile row), contraction = k (tile column); dgrad: the other way round
+          const int c0 = fwd ? m0[q] : k0[q], z0 = fwd ? k0[q] : m0[q];
+          const int nks = ((fwd ? dp.K[j] : dp.M[j]) + 31) >> 5;
+          const int col = 2 * jj + tt;  // output column inside the tile
+          typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+          h8v piece;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float w = (fwd ? tile[q][col][8 * qq + e] : tile[q][8 * qq + e][col]) * ULTR_H3_WSCALE;
+            const _Float16 hi = (_Float16)w;
+            piece[e] = hl ? (_Float16)(w - (float)hi) : hi;
+          }
+          const int64_t pos = ((((int64_t)(c0 >> 5) * nks + (z0 >> 5)) * 4 + (2 * tt + hl)) * 64 +
+                               ((((z0 & 31) >> 3) + qq) * 16 + ((c0 & 31) >> 1) + jj)) * 8;
+          _Float16* dst = reinterpret_cast<_Float16*>(wt + (fwd ? dp.whf_off[j] : dp.whb_off[j]));
+          *reinterpret_cast<h8v*>(dst + pos) = piece;
+        }
+      }
       if (dp.sw_ok && tid < 128) {
         // the fragment-major copies (DnnPlan::wsf_off / wsb_off): the 16 x 16 tile is 64 float4 pieces of each, 8 pieces
         // (128 bytes) contiguous; threads 0..63 write the forward copy, 64..127 the dgrad copy (layers >= 1).  Elements
