@@ -38,6 +38,11 @@
 // forward buffers: float4 epilogue stores / float4 A reads of the generic path -> ld % 4 == 0; rows padded so that
 // the pipelined GEMM may read (masked) up to 31 columns past K
 __host__ __device__ static inline int fwd_ld(int maxdim) { return round_up(maxdim, 32) + ULTR_LD_PAD; }
+// dnn_fwd_kernel with split-half layers (DnnPlan::fwd_h3): the two fp16 planes of the A tile overlay the fp32 tile they were made
+// from, with a row stride of round_up(maxdim, 32) + 8 halves (16-byte reads, 4 banks per row apart) - they fit once the fp32 row
+// stride is that + 4 floats, which is odd in units of 4 floats just like the default (conflict-free float4 reads)
+__host__ __device__ static inline int fwd_ldh(int maxdim) { return round_up(maxdim, 32) + 8; }
+__host__ __device__ static inline int fwd_ld_of(int maxdim, int h3) { return h3 ? fwd_ldh(maxdim) + 4 : fwd_ld(maxdim); }
 // backward dz buffer: float4 A-fragment reads, rows zero-padded to a multiple of 32 (see gemm_nn)
 __host__ __device__ static inline int bwd_ldz(int maxdim) { return round_up(maxdim, 32) + ULTR_LD_PAD; }
 // backward du buffer: float4 epilogue stores -> ld % 4 == 0
@@ -707,10 +712,11 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int RT = R / 16;
   const int64_t N = (int64_t)B * L;
-  const int ld = fwd_ld(p.maxdim);
+  const int ld = fwd_ld_of(p.maxdim, p.fwd_h3);
   float* X = smem;
   float* Y = smem + R * ld;
   float* PV = smem + 2 * R * ld;  // every vector parameter of the model, staged once (see below)
+  __shared__ float sm_os[16];     // split-half layers: per-row output scale of the product
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave: SGPR
   const int64_t n0 = (int64_t)blockIdx.x * R;
   const int rows_valid = (int)((N - n0) < R ? (N - n0) : R);
@@ -843,7 +849,90 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
     }
     // ---- LayerNorm (biased variance, eps 1e-5, affine), in place; two-pass statistics -----------
     bool scored = false;
-    if (K <= 256) {
+    bool h3 = false;
+    if constexpr (VEC && RT == 1 && NW == 8) h3 = p.fwd_h3 != 0 && j < p.nl - 1 && p.h3f[j] != 0 && K16 <= 512;
+    if (h3) {
+      if constexpr (VEC && RT == 1 && NW == 8) {
+        // split-half layer (PipeH3): a lane owns columns 4 lane + 256 u; the wave's two rows stay in registers through
+        // both passes, and once every wave holds its rows (the barrier) the normalised rows go back over the tile as two
+        // fp16 planes, scaled per row by a power of two
+        constexpr int RPW = 2, XC = 2;
+        const float invK = 1.0f / (float)K;
+        const int ldh = fwd_ldh(p.maxdim);
+        _Float16* AH = reinterpret_cast<_Float16*>(X);
+        _Float16* AL = AH + R * ldh;
+        float4 xq[RPW][XC];
+        float s[RPW], v[RPW], am[RPW];
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+          const float* row = X + (wave + NW * q) * ld;
+          s[q] = 0.f;
+#pragma unroll
+          for (int u = 0; u < XC; ++u) {
+            const int c = 4 * lane + 256 * u;
+            xq[q][u] = (c < K) ? ld4(row + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            s[q] += (xq[q][u].x + xq[q][u].y) + (xq[q][u].z + xq[q][u].w);
+          }
+        }
+        wave_sum_n<RPW>(s);
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+          s[q] *= invK;
+          v[q] = 0.f;
+#pragma unroll
+          for (int u = 0; u < XC; ++u) {
+            const int c = 4 * lane + 256 * u;
+            float4& x = xq[q][u];
+            if (c < K) {
+              x.x -= s[q]; x.y -= s[q]; x.z -= s[q]; x.w -= s[q];
+            }
+            v[q] += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+          }
+        }
+        wave_sum_n<RPW>(v);
+        lds_barrier();  // every wave has read its rows: the planes may overwrite them
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+          const int r = wave + NW * q;
+          const float rstd = rsqrt_nr(v[q] * invK + ULTR_LN_EPS);
+          am[q] = 0.f;
+#pragma unroll
+          for (int u = 0; u < XC; ++u) {
+            const int c = 4 * lane + 256 * u;
+            float4& x = xq[q][u];
+            if (c < K) {
+              const float4 g = ld4(lnw + c), be = ld4(lnb + c);
+              const float4 xh = make_float4(x.x * rstd, x.y * rstd, x.z * rstd, x.w * rstd);
+              if (j == 0 && write_xhat0 && n0 + r < N) st4(saved + p.sv_x[0] + (n0 + r) * K + c, xh);
+              x = make_float4(xh.x * g.x + be.x, xh.y * g.y + be.y, xh.z * g.z + be.z, xh.w * g.w + be.w);
+              am[q] = fmaxf(am[q], fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w))));
+            }
+          }
+          if (lane == 0 && n0 + r < N && saved != nullptr) {
+            saved[lay.sv_mean + n0 + r] = s[q];
+            saved[lay.sv_rstd + n0 + r] = rstd;
+          }
+        }
+        wave_max_n<RPW>(am);
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+          const int r = wave + NW * q;
+          float rs, inv;
+          fb_h3_scale(am[q], rs, inv);
+#pragma unroll
+          for (int u = 0; u < XC; ++u) {
+            const int c = 4 * lane + 256 * u;
+            if (c < K16) {
+              fbh4 hi, lo;
+              fb_h3_split4(xq[q][u], rs, hi, lo);
+              *reinterpret_cast<fbh4*>(AH + r * ldh + c) = hi;
+              *reinterpret_cast<fbh4*>(AL + r * ldh + c) = lo;
+            }
+          }
+          if (lane == 0) sm_os[r] = inv * (1.0f / ULTR_H3_WSCALE);
+        }
+      }
+    } else if (K <= 256) {
       // fast path: a lane owns columns lane + 64k (k < 4); gamma/beta are fetched once per layer, the wave's
       // rows live in registers between the passes and their reductions are interleaved.  The scorer (last
       // layer, M = 1) is folded in:  score = rstd * sum_c (x_c - mean) gamma_c w_c + sum_c beta_c w_c + b
@@ -972,7 +1061,25 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
         }
         bool sw_done = false;
         if constexpr (RT == 1 && NW == 8) {
-          if (FWD_SW && p.sw_ok && M >= 32 * NW) {
+          if (h3) {
+            const int nks = K16 >> 5, ldh = fwd_ldh(p.maxdim);
+            const _Float16* AH = reinterpret_cast<const _Float16*>(X);
+            const _Float16* AL = AH + R * ldh;
+            const Src Wh = make_src(wt + p.whf_off[j], (int64_t)K16 * M);
+            PipeH3<FB_SWD> ph;
+            const int cs = wave * 32;
+            ph.begin(Wh, wave, nks, cs < M, lane);
+            for (int cc = cs; cc < M; cc += NW * 32) {
+              f32x4 acc[RT][2], accx[2];
+#pragma unroll
+              for (int t = 0; t < 2; ++t) acc[0][t] = accx[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+              ph.run(AH, AL, ldh, Wh, nks, acc[0], accx, lane);
+              if (cc + NW * 32 < M) ph.begin(Wh, (cc + NW * 32) >> 5, nks, true, lane);
+              fb_h3_finish(acc, accx, sm_os, lane);
+              finish_fwd_nn<RT, 2>(acc, Y, ld, M, cc, lane, bias, p.act, gout, rows_valid);
+            }
+            sw_done = true;
+          } else if (FWD_SW && p.sw_ok && M >= 32 * NW) {
             // fragment-major copy (DnnPlan::wsf_off): 32-column chunks, every wave over the whole contraction
             const int ntr = K16 >> 5;
             const Src Ws = make_src(wt + p.wsf_off[j], (int64_t)K16 * M);
@@ -2917,7 +3024,7 @@ __global__ __launch_bounds__(64) void grad_sumsq_kernel(int64_t P, const float* 
 // per knob per launch is host time on the critical path of a ~50 us step.  ultr_config_reload() re-reads them (tests and
 // the A/B tools flip knobs inside one process).
 struct Knobs {
-  int fwd_r, bwd_r, wgrad_wgs, fwd_nw, bwd_nw, no_vec, no_l0g, bwd_v1, no_fused_fb, fb_max_wg_per_cu, fwd_q4, big_fwd, big_bwd, fb_h3;
+  int fwd_r, bwd_r, wgrad_wgs, fwd_nw, bwd_nw, no_vec, no_l0g, bwd_v1, no_fused_fb, fb_max_wg_per_cu, fwd_q4, big_fwd, big_bwd, fb_h3, fwd_h3, bwd_h3;
   bool loaded;
 };
 static Knobs g_knobs = {};
@@ -2943,6 +3050,8 @@ static void knobs_load() {
   k.big_bwd = env_read("ULTR_BIG_BWD", 1);
   // fused small-batch kernel: products as three fp16 MFMAs on hi / lo operand splits (1, default) or fp32 MFMAs (0)
   k.fb_h3 = env_read("ULTR_FB_H3", 1);
+  k.fwd_h3 = env_read("ULTR_FWD_H3", 1);
+  k.bwd_h3 = env_read("ULTR_BWD_H3", 1);
   k.loaded = true;
   g_knobs = k;
 }
@@ -3039,21 +3148,27 @@ bool ultr_make_dnn_plan(const ultr_dnn_desc* d, int64_t N, DnnPlan* p) {
           o += n;
         }
       }
-      // split-half copies (DnnPlan::whf_off / whb_off): same element counts, two halves per float
+      // split-half copies (DnnPlan::whf_off / whb_off), per layer: same element counts, two halves per float
       bool h3 = true;
-      for (int j = 0; j < p->nl - 1; ++j) h3 = h3 && p->M[j] >= 256;
-      p->h3_ok = h3 ? 1 : 0;
-      if (h3) {
-        for (int j = 0; j < p->nl - 1; ++j) {
-          const int64_t n = (int64_t)round_up(p->K[j], 32) * round_up(p->M[j], 32);
+      for (int j = 0; j < p->nl - 1; ++j) {
+        const int64_t n = (int64_t)round_up(p->K[j], 32) * round_up(p->M[j], 32);
+        p->h3f[j] = (p->M[j] >= 256) ? 1 : 0;
+        p->h3b[j] = (j >= 1 && p->K[j] >= 256 && p->K[j] % 32 == 0) ? 1 : 0;
+        h3 = h3 && p->h3f[j] && (j == 0 || p->h3b[j]);
+        if (p->h3f[j]) {
           p->whf_off[j] = o;
           o += n;
-          if (j >= 1) {
-            p->whb_off[j] = o;
-            o += n;
-          }
+        }
+        if (p->h3b[j]) {
+          p->whb_off[j] = o;
+          o += n;
         }
       }
+      p->h3_ok = h3 ? 1 : 0;
+      p->fwd_h3 = 0;
+      if (knobs().fwd_h3)
+        for (int j = 0; j < p->nl - 1; ++j)
+          if (p->h3f[j] && round_up(p->K[j], 32) <= 512) p->fwd_h3 = 1;
       p->wt_total = o;
     }
   }
@@ -3108,7 +3223,9 @@ bool ultr_make_dnn_plan(const ultr_dnn_desc* d, int64_t N, DnnPlan* p) {
 }
 
 static size_t fwd_pv_floats(const DnnPlan& p) { return (size_t)p.pv_total; }
-static size_t fwd_lds_bytes(const DnnPlan& p, int R) { return ((size_t)2 * R * fwd_ld(p.maxdim) + fwd_pv_floats(p)) * sizeof(float); }
+static size_t fwd_lds_bytes(const DnnPlan& p, int R) {
+  return ((size_t)2 * R * fwd_ld_of(p.maxdim, p.fwd_h3) + fwd_pv_floats(p)) * sizeof(float);
+}
 static int fwd_rows_per_wg(const DnnPlan& p, int64_t N) {
   int r = knobs().fwd_r;
   if (r == 16 || r == 32) return r;
@@ -3309,13 +3426,15 @@ __global__ __launch_bounds__(256) void wt_build_kernel(DnnPlan p, const float* _
         wt[p.wsf_off[j] + ultr_sw_index(m, k, (p.K[j] + 31) >> 5)] = v;
         if (j >= 1) wt[p.wsb_off[j] + ultr_sw_index(k, m, (p.M[j] + 31) >> 5)] = v;
       }
-      if (p.h3_ok) {
+      if (p.h3f[j] || p.h3b[j]) {
         const float sv = v * ULTR_H3_WSCALE;
         const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
-        _Float16* hf = reinterpret_cast<_Float16*>(wt + p.whf_off[j]);
-        hf[ultr_h3_index(m, k, (p.K[j] + 31) >> 5, 0)] = hi;
-        hf[ultr_h3_index(m, k, (p.K[j] + 31) >> 5, 1)] = lo;
-        if (j >= 1) {
+        if (p.h3f[j]) {
+          _Float16* hf = reinterpret_cast<_Float16*>(wt + p.whf_off[j]);
+          hf[ultr_h3_index(m, k, (p.K[j] + 31) >> 5, 0)] = hi;
+          hf[ultr_h3_index(m, k, (p.K[j] + 31) >> 5, 1)] = lo;
+        }
+        if (p.h3b[j]) {
           _Float16* hb = reinterpret_cast<_Float16*>(wt + p.whb_off[j]);
           hb[ultr_h3_index(k, m, (p.M[j] + 31) >> 5, 0)] = hi;
           hb[ultr_h3_index(k, m, (p.M[j] + 31) >> 5, 1)] = lo;

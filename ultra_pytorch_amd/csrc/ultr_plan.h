@@ -50,7 +50,11 @@ struct DnnPlan {
   // tile1 lo][64 lanes = 16 q + j][8 halves: contraction 32 s + 8 q + e, column 32 c + 2 j + t] - the B-operand fragment
   // order of the MFMA, 1 KiB contiguous per wave load.  Offsets in FLOATS into the same buffer (two halves per float).
   int64_t whf_off[ULTR_MAXL], whb_off[ULTR_MAXL];
-  int h3_ok;
+  int h3_ok;              // every hidden layer has both copies (the fused kernel's condition)
+  // per layer: h3f[j] - the forward product of layer j has its split-half copy (M_j a multiple of 32, >= 256: eight 32-column
+  // chunks); h3b[j] - so has the dgrad product du_j = dz_j . W_j (j >= 1, K_j >= 256, both widths multiples of 32)
+  int h3f[ULTR_MAXL], h3b[ULTR_MAXL];
+  int fwd_h3;             // dnn_fwd_kernel runs at least one layer on the split-half copies (changes its LDS row stride)
   int maxdim;             // max over all K_j (and M_j)
   // work map of the update kernel when it maintains the copies above: 16x16 tiles over every hidden W_j (a tile is
   // read row-major and written k-major through an LDS transpose: 64-byte segments both ways instead of a 4-byte

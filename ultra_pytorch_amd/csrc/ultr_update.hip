@@ -333,13 +333,13 @@ __global__ __launch_bounds__(256) void update_tiled_kernel(ultr_update_desc u, D
       if (j < 0) continue;
       const int k = k0[q] + r, m = m0[q] + c;  // transposed ownership
       if (k < dp.K[j] && m < dp.M[j]) wt[dp.wt_off[j] + (int64_t)k * dp.M[j] + m] = tile[q][c][r];
-      if (dp.h3_ok && tid >= 128) {
+      if ((dp.h3f[j] | dp.h3b[j]) && tid >= 128) {
         // the split-half copies (DnnPlan::whf_off / whb_off, ultr_h3_index): the 16 x 16 tile is 64 pieces of 8 halves (16 bytes)
         // of each: 2 planes x 2 quarter-steps x 2 column tiles x 8 lanes; threads 128..191 write the forward copy, 192..255 the
         // dgrad copy
         const int t6 = tid & 63, hl = t6 >> 5, qq = (t6 >> 4) & 1, tt = (t6 >> 3) & 1, jj = t6 & 7;
         const bool fwd = tid < 192;
-        if (fwd || j >= 1) {
+        if (fwd ? dp.h3f[j] != 0 : dp.h3b[j] != 0) {
           // forward: output column = m (tile row), contraction = k (tile column); dgrad: the other way round
           const int c0 = fwd ? m0[q] : k0[q], z0 = fwd ? k0[q] : m0[q];
           const int nks = ((fwd ? dp.K[j] : dp.M[j]) + 31) >> 5;
