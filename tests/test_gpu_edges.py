@@ -222,13 +222,68 @@ def test_fused_step_shapes_match_oracle(F, hidden, B, L):
     assert abs(sc2[0] - ref2["loss"]) <= 1e-4 * max(1.0, abs(ref2["loss"]))
 
 
-def test_update_kernel_keeps_every_weight_copy_current():
-    """k-major copy, packed image and the fragment-major copies after ultr_apply_update == a fresh ultr_dnn_build_wt of the
-    updated parameters (bitwise), for a model that has the fragment-major copies (widths multiples of 32) and a ragged F."""
+def _softmax_case(F, hidden, B, L):
+    from oracle import ultr_oracle as O
+    rng = np.random.RandomState(F + B)
+    n_docs = B * L - 2
+    feats = rng.uniform(-1, 1, size=(n_docs, F)).astype(np.float32)
+    ids = rng.permutation(B * L)
+    ids = np.where(ids >= n_docs, n_docs, ids).astype(np.int32).reshape(L, B)  # two PAD documents
+    clicks = (rng.uniform(size=(L, B)) < 0.35).astype(np.float32)
+    clicks[0, :] = 1.0
+    params = O.init_params(F, hidden, seed=7)
+    for name, shape, off in O.param_layout(F, hidden):  # non-trivial LayerNorm affine parameters
+        if "layer_norm" in name:
+            n = int(np.prod(shape))
+            params[off:off + n] += rng.uniform(-0.3, 0.3, size=n).astype(np.float32)
+    state0 = (0.01 * rng.uniform(size=params.shape)).astype(np.float32)
+    return n_docs, feats, ids, clicks, params, state0
+
+
+@pytest.mark.parametrize("F,hidden,B,L", [(136, [256, 256], 33, 10),       # config 2's layers: both products of every layer on the split-half copies
+                                          (136, [512, 256, 128], 21, 20),  # config 3's layers: split-half where a layer has >= 256 outputs, fp32 elsewhere
+                                          (40, [512, 256], 7, 10),         # 512-wide rows
+                                          (24, [64, 32, 32], 20, 8)])      # no split-half copies at all
+def test_separate_kernel_step_shapes_match_oracle(F, hidden, B, L, monkeypatch):
+    """The same step through the SEPARATE forward / backward kernels (dnn_fwd_kernel, dnn_bwd2_kernel: what every batch too
+    large for the fused kernel runs, forced here with ULTR_NO_FUSED_FB=1) - including their split-half (fp16 hi/lo) products -
+    against the oracle: scores, loss, gradient, norm, updated parameters, and the scores of the step after."""
+    from oracle import ultr_oracle as O
+    from ultra_pytorch_amd import engine, hip_ops
+    monkeypatch.setenv("ULTR_NO_FUSED_FB", "1")
+    n_docs, feats, ids, clicks, params, state0 = _softmax_case(F, hidden, B, L)
+    ipw = np.linspace(1.0, 6.0, 24)
+    ref = O.train_step_softmax(params, state0, F, hidden, feats, ids, clicks, ipw_list=ipw)
+    shape = hip_ops.DnnShape(F, hidden, "elu")
+    try:
+        eng = engine.StepEngine(shape, B, L, torch.device("cuda"), algo="softmax")  # re-reads the knobs
+        p, st = dev(params), dev(state0)
+        eng.train_step(p, st, dev(feats), n_docs, dev(ids, torch.int32), dev(clicks), ipw_table=dev(ipw.astype(np.float32)))
+        sc = eng.read_scalars()
+        np.testing.assert_allclose(eng.scores.cpu().numpy(), ref["scores"], atol=1e-5, rtol=1e-5)
+        assert abs(sc[0] - ref["loss"]) <= 1e-5 * max(1.0, abs(ref["loss"]))
+        g = eng.grads[:shape.n_params].cpu().numpy() / sc[3]
+        np.testing.assert_allclose(g, ref["grads"], rtol=2e-5, atol=2e-6 * max(1.0, float(np.abs(ref["grads"]).max())))
+        assert abs(sc[1] - ref["norm"]) <= 1e-5 * max(1.0, ref["norm"])
+        eng.train_step(p, st, dev(feats), n_docs, dev(ids, torch.int32), dev(clicks), ipw_table=dev(ipw.astype(np.float32)))
+        sc2 = eng.read_scalars()
+        ref2 = O.train_step_softmax(ref["params"], ref["state"], F, hidden, feats, ids, clicks, ipw_list=ipw)
+        np.testing.assert_allclose(eng.scores.cpu().numpy(), ref2["scores"], atol=2e-4, rtol=2e-4)
+        assert abs(sc2[0] - ref2["loss"]) <= 1e-4 * max(1.0, abs(ref2["loss"]))
+    finally:
+        monkeypatch.delenv("ULTR_NO_FUSED_FB")
+        shape.lib.ultr_config_reload()
+
+
+@pytest.mark.parametrize("hidden", [[256, 64], [256, 256], [512, 256, 128]])
+def test_update_kernel_keeps_every_weight_copy_current(hidden):
+    """k-major copy, packed image, the fragment-major copies and the split-half (fp16 hi/lo) copies after ultr_apply_update ==
+    a fresh ultr_dnn_build_wt of the updated parameters (bitwise): a model with fragment-major copies only, config 2's layers
+    (split-half copies of every product) and config 3's (split-half copies of some layers); ragged F."""
     import ctypes
     from oracle import ultr_oracle as O
     from ultra_pytorch_amd import engine, hip_ops, synthetic
-    F, hidden, B, L = 136, [256, 64], 16, 10
+    F, B, L = 136, 16, 10
     rng = np.random.RandomState(1)
     shape = hip_ops.DnnShape(F, hidden, "elu")
     eng = engine.StepEngine(shape, B, L, torch.device("cuda"), algo="softmax")
@@ -247,3 +302,39 @@ def test_update_kernel_keeps_every_weight_copy_current():
     assert kept.numel() > shape.n_params  # copies + image + fragment-major region
     diff = (kept != fresh).nonzero().flatten()
     assert diff.numel() == 0, (diff[:8].tolist(), diff.numel(), kept.numel())
+
+
+@pytest.mark.parametrize("F,hidden,B,L,separate", [(136, [256, 256], 256, 10, False),     # config 2: the fused kernel
+                                                   (136, [256, 256], 256, 10, True),      # config 2 through the separate kernels
+                                                   (136, [512, 256, 128], 128, 20, True)])  # config 3's layers (too long lists for the fused kernel anyway)
+def test_repeated_launches_are_bitwise_identical(F, hidden, B, L, separate, monkeypatch):
+    """The same step from the same state, twenty times: scores, loss and every gradient bit must repeat.  (Round 3 found an
+    epilogue of the split-half dgrad product whose compiled form gave one row of one 16-column tile a different value in
+    a few launches out of ten - only on grids of >= ~20 workgroups, invisible to a single parity run; tools/h3_stress.py is
+    the long version of this test.)"""
+    from ultra_pytorch_amd import engine, hip_ops, synthetic
+    from ultra_pytorch_amd.ranking_model import init_flat_params
+    if separate:
+        monkeypatch.setenv("ULTR_NO_FUSED_FB", "1")
+    shape = hip_ops.DnnShape(F, hidden, "elu")
+    try:
+        feats, ids, y = synthetic.make_batch(np.random.RandomState(5), B, L, F)
+        ipw = np.asarray(synthetic.load_ipw(), np.float32)
+        p0 = init_flat_params(shape, seed=3).numpy()
+        eng = engine.StepEngine(shape, B, L, torch.device("cuda"), algo="softmax", learning_rate=0.05, max_gradient_norm=5.0)
+        f, i, yy, tab = dev(feats), dev(ids, torch.int32), dev(y), dev(ipw)
+        first = None
+        for rep in range(20):
+            params, state = dev(p0.copy()), dev(np.zeros_like(p0))
+            eng.train_step(params, state, f, feats.shape[0], i, yy, ipw_table=tab)
+            torch.cuda.synchronize()
+            got = (eng.grads[:shape.n_params].clone(), eng.scores.clone(), params.clone())
+            if first is None:
+                first = got
+                continue
+            for a, b, what in zip(got, first, ("gradients", "scores", "updated parameters")):
+                assert torch.equal(a, b), (rep, what, float((a - b).abs().max()))
+    finally:
+        if separate:
+            monkeypatch.delenv("ULTR_NO_FUSED_FB")
+            shape.lib.ultr_config_reload()

@@ -45,6 +45,8 @@ __host__ __device__ static inline int fwd_ldh(int maxdim) { return round_up(maxd
 __host__ __device__ static inline int fwd_ld_of(int maxdim, int h3) { return h3 ? fwd_ldh(maxdim) + 4 : fwd_ld(maxdim); }
 // backward dz buffer: float4 A-fragment reads, rows zero-padded to a multiple of 32 (see gemm_nn)
 __host__ __device__ static inline int bwd_ldz(int maxdim) { return round_up(maxdim, 32) + ULTR_LD_PAD; }
+// dnn_bwd2_kernel with split-half dgrad products (DnnPlan::bwd_h3): the dz tile holds two fp16 planes instead (see fwd_ld_of)
+__host__ __device__ static inline int bwd_ldz_of(int maxdim, int h3) { return h3 ? round_up(maxdim, 32) + 12 : bwd_ldz(maxdim); }
 // backward du buffer: float4 epilogue stores -> ld % 4 == 0
 __host__ __device__ static inline int bwd_ldu(int maxdim) { return round_up(maxdim, 16) + 4; }
 
@@ -524,16 +526,22 @@ struct PipeH3 {
     if constexpr (D > 2) fetch<1>(W);
     static_assert(D >= 2 && D <= 3, "pipeline depth");
   }
+  // Three accumulator sets per column tile (ah.wh | ah.wl | al.wh), each written ONCE per step: no MFMA reads an accumulator that
+  // one of the five MFMAs before it wrote.  With two sets (the cross terms chained: accx = ah.wl + accx; accx = al.wh + accx) hipcc
+  // may place the second product out of place (its SrcC = the first one's vDst, a different vDst of its own) one MFMA behind
+  // the first, and on gfx950 (ROCm 7.2) that v_mfma_f32_16x16x32_f16 pair then intermittently reads a stale SrcC for the rows
+  // the first product writes last - seen in dnn_bwd2_kernel as row 13 of one 16-column tile, ~1e-2 relative, a few launches in
+  // ten (tools/dbg_bwd_h3.py; profiles/r03_cfg2_attempts.md).
   template <int S>
   __device__ __forceinline__ void consume(const _Float16* __restrict__ ah_p, const _Float16* __restrict__ al_p, f32x4 (&acc)[2],
-                                          f32x4 (&accx)[2]) {
+                                          f32x4 (&accx)[2], f32x4 (&accy)[2]) {
     const fbh8 ah = *reinterpret_cast<const fbh8*>(ah_p), al = *reinterpret_cast<const fbh8*>(al_p);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const fbh8 wh = fb_as_h8(b[S][2 * t]), wl = fb_as_h8(b[S][2 * t + 1]);
       acc[t] = fb_mfma_h(ah, wh, acc[t]);
       accx[t] = fb_mfma_h(ah, wl, accx[t]);
-      accx[t] = fb_mfma_h(al, wh, accx[t]);
+      accy[t] = fb_mfma_h(al, wh, accy[t]);
     }
   }
   // Ah / Al: the two planes of the A tile, row stride ldh halves, zero beyond the real contraction length up to nks * 32
@@ -542,11 +550,12 @@ struct PipeH3 {
     const int i = lane & 15, q = lane >> 4;
     const _Float16* ph = Ah + i * ldh + 8 * q;
     const _Float16* pl = Al + i * ldh + 8 * q;
+    f32x4 accy[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     auto step = [&](auto uc) {
       constexpr int U = decltype(uc)::value;
       fetch<(U + D - 1) % D>(W);
       __builtin_amdgcn_sched_barrier(0);
-      consume<U>(ph, pl, acc, accx);
+      consume<U>(ph, pl, acc, accx, accy);
       ph += 32;
       pl += 32;
     };
@@ -556,8 +565,10 @@ struct PipeH3 {
       step(std::integral_constant<int, 1>());
       if constexpr (D > 2) step(std::integral_constant<int, 2>());
     }
-    if (t < nks) { consume<0>(ph, pl, acc, accx); ph += 32; pl += 32; }
-    if constexpr (D > 2) if (t + 1 < nks) { consume<1>(ph, pl, acc, accx); ph += 32; pl += 32; }
+    if (t < nks) { consume<0>(ph, pl, acc, accx, accy); ph += 32; pl += 32; }
+    if constexpr (D > 2) if (t + 1 < nks) { consume<1>(ph, pl, acc, accx, accy); ph += 32; pl += 32; }
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) accx[tt] += accy[tt];
   }
 };
 // rows 4 q + r of the accumulators times the per-row output scales (1 / (row scale x weight scale)), cross terms folded in
@@ -1537,7 +1548,7 @@ __host__ __device__ static inline int bwd2_cp_stride(const DnnPlan& p) {
   return cpw;
 }
 __host__ __device__ static inline size_t bwd2_lds_floats(const DnnPlan& p, int R, int NW) {
-  const size_t ldu = bwd_ldu(p.maxdim), ldz = bwd_ldz(p.maxdim);
+  const size_t ldu = bwd_ldu(p.maxdim), ldz = bwd_ldz_of(p.maxdim, R == 16 ? p.bwd_h3 : 0);
   return (size_t)R * (2 * ldu + ldz) + 5 * ldu + (size_t)NW * bwd2_cp_stride(p) + 5 * (size_t)R + 2 * (size_t)NW + 8;
 }
 
@@ -1552,7 +1563,10 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
   constexpr int RT = R / 16, NT = NW * 64, RPW = R / NW;
   static_assert(R % NW == 0, "a wave owns whole rows");
   const int64_t N = (int64_t)B * L;
-  const int ldz = bwd_ldz(p.maxdim), ldu = bwd_ldu(p.maxdim);
+  const bool h3on = (RT == 1) && p.bwd_h3 != 0 && wt != nullptr;  // dgrad products on the split-half copies where a layer has one (DnnPlan::h3b)
+  const int ldz = bwd_ldz_of(p.maxdim, h3on ? 1 : 0), ldu = bwd_ldu(p.maxdim);
+  const int ldh = round_up(p.maxdim, 32) + 8;    // row stride (halves) of the two fp16 planes that then live in DZ
+  __shared__ float sm_os[16];                    // their per-row output scales
   float* DU = smem;                    // [R][ldu]
   float* XS = DU + R * ldu;            // [R][ldu]  input of LayerNorm_j (rows written and read by their owner wave only)
   float* DZ = XS + R * ldu;            // [R][ldz]
@@ -1773,7 +1787,27 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
       const int nch = p.bwd_nch[j], msplit = p.bwd_msplit[j], mode = p.bwd_mode[j];
       bool sw_done = false;
       if constexpr (RT == 1) {
-        if (BWD_SW && wt != nullptr && p.sw_ok && j >= 1 && K >= 32 * NW) {
+        if (h3on && wt != nullptr && j >= 1 && p.h3b[j] != 0) {
+          // split-half copy of W_j (DnnPlan::whb_off) against the two planes of dz_j the row pass left in DZ
+          const int nks = M >> 5;
+          const _Float16* AH = reinterpret_cast<const _Float16*>(DZ);
+          const _Float16* AL = AH + R * ldh;
+          const Src Wh = make_src(wt + p.whb_off[j], (int64_t)M * K);
+          PipeH3<FB_SWD> ph;
+          ph.begin(Wh, wave, nks, wave * 32 < K, lane);
+          for (int ch = wave; ch * 32 < K; ch += NW) {
+            f32x4 acc[RT][2], accx[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[0][t] = accx[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            ph.run(AH, AL, ldh, Wh, nks, acc[0], accx, lane);
+            if ((ch + NW) * 32 < K) ph.begin(Wh, ch + NW, nks, true, lane);
+            // raw sums: the row pass below applies the per-row scale when it reads DU (its rows are the wave's own)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[0][t] += accx[t];
+            store_nn<RT, 2>(acc, DU, ldu, K, ch * 32, lane, false);
+          }
+          sw_done = true;
+        } else if (BWD_SW && wt != nullptr && p.sw_ok && j >= 1 && K >= 32 * NW) {
           // fragment-major copy of W_j (DnnPlan::wsb_off; M is a multiple of 32 there): 32-column chunks of K, whole contraction
           const int ntr = M >> 5;
           const Src Wb = make_src(wt + p.wsb_off[j], (int64_t)M * round_up(K, 32));
@@ -1841,13 +1875,16 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
       const float* gs = sm_g2 + par * ldu;
       const float* bs = sm_b2 + par * ldu;
       const float invK = 1.0f / (float)K;
-      float mean[RPW], rstd[RPW], dsr[RPW];
+      float mean[RPW], rstd[RPW], dsr[RPW], dus[RPW];
+      // du_j came out of the split-half product unscaled: its rows still carry the row scale of the dz planes
+      const bool du_scaled = h3on && !last && j >= 1 && p.h3b[j] != 0;
 #pragma unroll
       for (int k = 0; k < RPW; ++k) {
         const int r = wave + NW * k;
         mean[k] = sm_mean2[par * R + r];
         rstd[k] = sm_rstd2[par * R + r];
         dsr[k] = sm_ds[r];
+        dus[k] = du_scaled ? sm_os[r & 15] : 1.0f;
       }
       float4 xk[RPW][XC], gxk[RPW][XC];
       float red[2 * RPW];
@@ -1868,7 +1905,10 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
           const float4 x4 = act ? ld4(XS + r * ldu + c) : z4;
           float4 du4;
           if (last) du4 = make_float4(dsr[k] * w4.x, dsr[k] * w4.y, dsr[k] * w4.z, dsr[k] * w4.w);
-          else du4 = act ? ld4(DU + r * ldu + c) : z4;
+          else {
+            du4 = act ? ld4(DU + r * ldu + c) : z4;
+            du4.x *= dus[k]; du4.y *= dus[k]; du4.z *= dus[k]; du4.w *= dus[k];
+          }
           const float4 xh = make_float4((x4.x - mean[k]) * rstd[k], (x4.y - mean[k]) * rstd[k],
                                         (x4.z - mean[k]) * rstd[k], (x4.w - mean[k]) * rstd[k]);
           const float4 gx = make_float4(du4.x * g4.x, du4.y * g4.y, du4.z * g4.z, du4.w * g4.w);
@@ -1895,26 +1935,59 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
       if (j > 0) {
         wave_sum_n<2 * RPW>(red);
         float* dzg = ws + bp.dz_off[j - 1];
+        // dz_{j-1} feeds the dgrad product of layer j-1: as two fp16 planes when that layer has a split-half copy
+        const bool hz = h3on && j >= 2 && p.h3b[j - 1] != 0;
+        float amz[RPW];
 #pragma unroll
         for (int k = 0; k < RPW; ++k) {
           const int r = wave + NW * k;
           const int64_t n = n0 + r;
           const float s1 = red[k] * invK, s2 = red[RPW + k] * invK;
+          amz[k] = 0.f;
 #pragma unroll
           for (int u = 0; u < XC; ++u) {
             const int c = 4 * lane + 256 * u;
+            float4 dz = make_float4(0.f, 0.f, 0.f, 0.f);
             if (c < K) {
               const float4 x4 = xk[k][u], gx = gxk[k][u];
-              float4 dz;
               dz.x = rstd[k] * (gx.x - s1 - (x4.x - mean[k]) * rstd[k] * s2) * act_grad_from_out(x4.x, p.act);
               dz.y = rstd[k] * (gx.y - s1 - (x4.y - mean[k]) * rstd[k] * s2) * act_grad_from_out(x4.y, p.act);
               dz.z = rstd[k] * (gx.z - s1 - (x4.z - mean[k]) * rstd[k] * s2) * act_grad_from_out(x4.z, p.act);
               dz.w = rstd[k] * (gx.w - s1 - (x4.w - mean[k]) * rstd[k] * s2) * act_grad_from_out(x4.w, p.act);
-              st4(DZ + r * ldz + c, dz);
+              if (!hz) st4(DZ + r * ldz + c, dz);
               if (n < N) st4_out(dzg + n * K + c, dz);
             }
+            if constexpr (RT == 1) {
+              gxk[k][u] = dz;  // (gx is dead from here on)
+              amz[k] = fmaxf(amz[k], fmaxf(fmaxf(fabsf(dz.x), fabsf(dz.y)), fmaxf(fabsf(dz.z), fabsf(dz.w))));
+            }
           }
-          for (int c = K + lane; c < round_up(K, 32); c += 64) DZ[r * ldz + c] = 0.f;  // zero pad (gemm_nn reads it)
+          if (!hz)
+            for (int c = K + lane; c < round_up(K, 32); c += 64) DZ[r * ldz + c] = 0.f;  // zero pad (gemm_nn reads it)
+        }
+        if constexpr (RT == 1) {
+          if (hz) {
+            _Float16* AH = reinterpret_cast<_Float16*>(DZ);
+            _Float16* AL = AH + R * ldh;
+            wave_max_n<RPW>(amz);
+#pragma unroll
+            for (int k = 0; k < RPW; ++k) {
+              const int r = wave + NW * k;
+              float rs, inv;
+              fb_h3_scale(amz[k], rs, inv);
+#pragma unroll
+              for (int u = 0; u < XC; ++u) {
+                const int c = 4 * lane + 256 * u;
+                if (c < K) {  // K is a multiple of 32 here (DnnPlan::h3b)
+                  fbh4 hi, lo;
+                  fb_h3_split4(gxk[k][u], rs, hi, lo);
+                  *reinterpret_cast<fbh4*>(AH + r * ldh + c) = hi;
+                  *reinterpret_cast<fbh4*>(AL + r * ldh + c) = lo;
+                }
+              }
+              if (lane == 0) sm_os[r] = inv * (1.0f / ULTR_H3_WSCALE);
+            }
+          }
         }
       }
     }
@@ -2387,7 +2460,9 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
           for (int t = 0; t < 2; ++t) acc[0][t] = accx[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
           ph.run(AH, AL, ldh, Wh, nks, acc[0], accx, lane);
           if ((ch + NW) * 32 < K) ph.begin(Wh, ch + NW, nks, true, lane);
-          fb_h3_finish(acc, accx, sm_os, lane);
+          // raw sums: the row pass below applies the per-row scale when it reads DU (as dnn_bwd2_kernel)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) acc[0][t] += accx[t];
           store_nn<RT, 2>(acc, DU, ldu, K, ch * 32, lane, false);
         }
       } else if (FB_SW && p.sw_ok && j >= 1) {
@@ -2448,13 +2523,14 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
       const float* bs = gs + K;
       const float* wlp = PV + p.pv_wlast;
       const float invK = 1.0f / (float)K;
-      float mean[RPW], rstd[RPW], dsr[RPW];
+      float mean[RPW], rstd[RPW], dsr[RPW], dus[RPW];
 #pragma unroll
       for (int k = 0; k < RPW; ++k) {
         const int r = wave + NW * k;
         mean[k] = sm_mean[j * R + r];
         rstd[k] = sm_rstd[j * R + r];
         dsr[k] = sm_ds[r];
+        dus[k] = (H3 && !last && j >= 1) ? sm_os[r] : 1.0f;  // du_j of the split-half product is stored unscaled
       }
       float4 xk[RPW][XC], gxk[RPW][XC];
       float red[2 * RPW];
@@ -2475,7 +2551,10 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
           const float4 x4 = act ? ld4(XS + r * ld + c) : z4;
           float4 du4;
           if (last) du4 = make_float4(dsr[k] * w4.x, dsr[k] * w4.y, dsr[k] * w4.z, dsr[k] * w4.w);
-          else du4 = act ? ld4(DU + r * ldu + c) : z4;
+          else {
+            du4 = act ? ld4(DU + r * ldu + c) : z4;
+            if constexpr (H3) { du4.x *= dus[k]; du4.y *= dus[k]; du4.z *= dus[k]; du4.w *= dus[k]; }
+          }
           const float4 xh = make_float4((x4.x - mean[k]) * rstd[k], (x4.y - mean[k]) * rstd[k],
                                         (x4.z - mean[k]) * rstd[k], (x4.w - mean[k]) * rstd[k]);
           const float4 gx = make_float4(du4.x * g4.x, du4.y * g4.y, du4.z * g4.z, du4.w * g4.w);
@@ -3165,6 +3244,10 @@ bool ultr_make_dnn_plan(const ultr_dnn_desc* d, int64_t N, DnnPlan* p) {
         }
       }
       p->h3_ok = h3 ? 1 : 0;
+      p->bwd_h3 = 0;
+      if (knobs().bwd_h3)
+        for (int j = 1; j < p->nl - 1; ++j)
+          if (p->h3b[j]) p->bwd_h3 = 1;
       p->fwd_h3 = 0;
       if (knobs().fwd_h3)
         for (int j = 0; j < p->nl - 1; ++j)

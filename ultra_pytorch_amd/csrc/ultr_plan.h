@@ -54,6 +54,7 @@ struct DnnPlan {
   // per layer: h3f[j] - the forward product of layer j has its split-half copy (M_j a multiple of 32, >= 256: eight 32-column
   // chunks); h3b[j] - so has the dgrad product du_j = dz_j . W_j (j >= 1, K_j >= 256, both widths multiples of 32)
   int h3f[ULTR_MAXL], h3b[ULTR_MAXL];
+  int bwd_h3;             // dnn_bwd2_kernel runs at least one dgrad product on them (changes the row stride of its dz tile)
   int fwd_h3;             // dnn_fwd_kernel runs at least one layer on the split-half copies (changes its LDS row stride)
   int maxdim;             // max over all K_j (and M_j)
   // work map of the update kernel when it maintains the copies above: 16x16 tiles over every hidden W_j (a tile is
