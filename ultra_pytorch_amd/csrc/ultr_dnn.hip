@@ -861,13 +861,14 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
     // ---- LayerNorm (biased variance, eps 1e-5, affine), in place; two-pass statistics -----------
     bool scored = false;
     bool h3 = false;
-    if constexpr (VEC && RT == 1 && NW == 8) h3 = p.fwd_h3 != 0 && j < p.nl - 1 && p.h3f[j] != 0 && K16 <= 512;
+    if constexpr (VEC && RT == 1 && NW == 8) h3 = p.fwd_h3 != 0 && j < p.nl - 1 && p.h3f[j] != 0 && K16 <= 768;
     if (h3) {
       if constexpr (VEC && RT == 1 && NW == 8) {
+       auto ln_h3 = [&](auto xc_tag) {
         // split-half layer (PipeH3): a lane owns columns 4 lane + 256 u; the wave's two rows stay in registers through
         // both passes, and once every wave holds its rows (the barrier) the normalised rows go back over the tile as two
         // fp16 planes, scaled per row by a power of two
-        constexpr int RPW = 2, XC = 2;
+        constexpr int RPW = 2, XC = decltype(xc_tag)::value;  // rows up to 256 XC wide
         const float invK = 1.0f / (float)K;
         const int ldh = fwd_ldh(p.maxdim);
         _Float16* AH = reinterpret_cast<_Float16*>(X);
@@ -942,6 +943,9 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
           }
           if (lane == 0) sm_os[r] = inv * (1.0f / ULTR_H3_WSCALE);
         }
+       };
+       if (K16 <= 512) ln_h3(std::integral_constant<int, 2>());
+       else ln_h3(std::integral_constant<int, 3>());
       }
     } else if (K <= 256) {
       // fast path: a lane owns columns lane + 64k (k < 4); gamma/beta are fetched once per layer, the wave's
@@ -3251,7 +3255,7 @@ bool ultr_make_dnn_plan(const ultr_dnn_desc* d, int64_t N, DnnPlan* p) {
       p->fwd_h3 = 0;
       if (knobs().fwd_h3)
         for (int j = 0; j < p->nl - 1; ++j)
-          if (p->h3f[j] && round_up(p->K[j], 32) <= 512) p->fwd_h3 = 1;
+          if (p->h3f[j] && round_up(p->K[j], 32) <= 768) p->fwd_h3 = 1;
       p->wt_total = o;
     }
   }
@@ -3566,6 +3570,9 @@ static int dnn_device_cus() {
 static bool big_fwd_wanted(const DnnPlan& p, int64_t N, size_t row_tile_lds) {
   if (knobs().big_fwd != 1) return knobs().big_fwd >= 2;
   if (p.K[0] <= 512 || p.nl < 2) return false;
+  // round 3: with its first layer on the split-half copies the row-tile forward wins that case too (config 4, 800 tiles:
+  // 218 us per-layer, 225 row tiles in fp32, 151 row tiles with the split-half products)
+  if (p.fwd_h3 && p.h3f[0] && round_up(p.K[0], 32) <= 768) return false;
   const int cus = dnn_device_cus();
   const int per_cu = row_tile_lds > 80 * 1024 ? 1 : (row_tile_lds > 53 * 1024 ? 2 : 3);
   const int64_t slots = (int64_t)per_cu * cus, tiles = (N + 15) / 16, full = tiles / slots, rem = tiles % slots;
