@@ -734,7 +734,13 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
   // marker word behind the saved activations: does saved.x_0 hold xhat_0 for the weight-gradient launch?  (the LayerNorm fast
   // path below writes it for inputs up to 256 wide; the launch then contracts layer 0 with it instead of gathering by id and
   // normalising again)
-  const bool write_xhat0 = saved != nullptr && p.nl >= 2 && p.K[0] <= 256;
+#ifndef FWD_XHAT0_H3
+#define FWD_XHAT0_H3 1  // wider inputs too when layer 0 takes the split-half LayerNorm path (rows in registers there)
+#endif
+  bool write_xhat0 = saved != nullptr && p.nl >= 2 && p.K[0] <= 256;
+  if constexpr (VEC && R == 16 && NW == 8)
+    write_xhat0 = write_xhat0 || (FWD_XHAT0_H3 && saved != nullptr && p.nl >= 2 && p.fwd_h3 != 0 && p.h3f[0] != 0 &&
+                                  round_up(p.K[0], 32) <= 768);
   if (saved != nullptr && blockIdx.x == 0 && tid == 0) saved[p.sv_total] = write_xhat0 ? 1.f : 0.f;
   TRACE_STAMP(0);
 
