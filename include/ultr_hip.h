@@ -45,6 +45,11 @@ extern "C" {
 #define ULTR_E_UNSUPPORTED (-2)
 #define ULTR_E_WORKSPACE (-3)
 #define ULTR_E_COMM_TIMEOUT (-4) /* a peer did not arrive within the bounded wait of ultr_comm_allreduce */
+/* bit of the status word of the step report (ultr_update_desc::host_scalars[8]) that is NOT a communication failure: a hidden
+ * weight reached |w| >= 128, outside the range of the split-half (fp16 hi / lo, x 2^8) weight copies the wide layers' products
+ * read - results from then on are not to be trusted; run with ULTR_FB_H3=0 ULTR_FWD_H3=0 ULTR_BWD_H3=0 (fp32 matrix-core
+ * products).  Raised by ultr_dnn_build_wt / ultr_apply_update, reported with the step after the one that wrote the weight. */
+#define ULTR_STATUS_H3_RANGE 0x100u
 
 /* base_ranking_model.py:63-69 (ACT_FUNC_DIC): elu, relu, tanh, sigmoid.  ('selu' is listed there as a plain function and
  * nn.Sequential.add_module rejects it - TypeError at DNN.py:52-53 - so it is not an option of the reference.) */

@@ -338,3 +338,24 @@ def test_repeated_launches_are_bitwise_identical(F, hidden, B, L, separate, monk
         if separate:
             monkeypatch.delenv("ULTR_NO_FUSED_FB")
             shape.lib.ultr_config_reload()
+
+
+def test_weight_outside_the_split_half_range_raises():
+    """The wide layers' products read fp16 hi / lo copies of the weights x 2^8: a weight of magnitude >= 128 would overflow them.
+    The build / update kernels flag it and the host's read of the step report raises (ULTR_STATUS_H3_RANGE) instead of the
+    step silently computing with infinities; with the split-half products switched off the same model trains."""
+    from oracle import ultr_oracle as O
+    from ultra_pytorch_amd import _lib, engine, hip_ops, synthetic
+    F, hidden, B, L = 136, [256, 256], 16, 10
+    rng = np.random.RandomState(2)
+    shape = hip_ops.DnnShape(F, hidden, "elu")
+    p0 = O.init_params(F, hidden, seed=3)
+    for name, shp, off in O.param_layout(F, hidden):
+        if name.endswith("linear1.weight"):
+            p0[off + 5] = 200.0
+    feats, ids, y = synthetic.make_batch(rng, B, L, F)
+    eng = engine.StepEngine(shape, B, L, torch.device("cuda"), algo="softmax")
+    p, st = dev(p0), dev(np.zeros_like(p0))
+    eng.train_step(p, st, dev(feats), feats.shape[0], dev(ids, torch.int32), dev(y))
+    with pytest.raises(_lib.UltrHipError, match="split-half"):
+        eng.read_scalars()

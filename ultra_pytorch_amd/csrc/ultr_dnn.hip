@@ -3254,6 +3254,8 @@ bool ultr_make_dnn_plan(const ultr_dnn_desc* d, int64_t N, DnnPlan* p) {
         }
       }
       p->h3_ok = h3 ? 1 : 0;
+      p->h3_flag_off = o;  // (inside the region ultr_dnn_build_wt zeroes)
+      o += 4;
       p->bwd_h3 = 0;
       if (knobs().bwd_h3)
         for (int j = 1; j < p->nl - 1; ++j)
@@ -3521,6 +3523,8 @@ __global__ __launch_bounds__(256) void wt_build_kernel(DnnPlan p, const float* _
       }
       if (p.h3f[j] || p.h3b[j]) {
         const float sv = v * ULTR_H3_WSCALE;
+        if (!(fabsf(sv) < ULTR_H3_WMAX))
+          __hip_atomic_store(reinterpret_cast<uint32_t*>(wt + p.h3_flag_off), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
         if (p.h3f[j]) {
           _Float16* hf = reinterpret_cast<_Float16*>(wt + p.whf_off[j]);

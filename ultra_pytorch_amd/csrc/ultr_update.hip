@@ -101,7 +101,8 @@ __device__ __forceinline__ void update_body(const ultr_update_desc& u, const Dnn
                                             float* __restrict__ aux, float ss, const int64_t (&e_a)[EPT],
                                             const float (&g_raw_a)[EPT], const float (&p_old_a)[EPT],
                                             const float (&s_old_a)[EPT], float (&p_new_a)[EPT], float* sm,
-                                            float* __restrict__ scalars_out, const float* __restrict__ l2_sums) {
+                                            float* __restrict__ scalars_out, const float* __restrict__ l2_sums,
+                                            const uint32_t* __restrict__ h3flag = nullptr) {
   const int64_t P = u.n_params;
   const int L = u.list_size;
   const float loss_sum = tail[0], D = tail[1], loss2 = tail[2], D2 = tail[3];
@@ -228,7 +229,11 @@ __device__ __forceinline__ void update_body(const ultr_update_desc& u, const Dnn
   }
   if (threadIdx.x == 0 && u.host_scalars != nullptr) {
     const float v[8] = {loss, norm, coef, D, rank_loss, exam_loss, pnorm, ss};
-    host_report(u, v, 0u);
+    // a weight outside the range of the split-half copies (DnnPlan::h3_flag_off: raised by the build kernel or by an earlier
+    // update launch - this launch's own tiles report with the next step): the host's read of the loss raises
+    uint32_t st = 0u;
+    if (h3flag != nullptr && __hip_atomic_load(h3flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) st = ULTR_STATUS_H3_RANGE;
+    host_report(u, v, st);
   }
 }
 
@@ -321,7 +326,8 @@ __global__ __launch_bounds__(256) void update_tiled_kernel(ultr_update_desc u, D
   if (blockIdx.x != 0) {
     update_body<TPW>(u, dp, params, state, grads + P, aux, ss, ea, g_raw, p_old, s_old, pn, sm, nullptr, l2_sums);
   } else {
-    update_body<TPW>(u, dp, params, state, grads + P, aux, ss, ea, g_raw, p_old, s_old, pn, sm, scalars_out, l2_sums);
+    update_body<TPW>(u, dp, params, state, grads + P, aux, ss, ea, g_raw, p_old, s_old, pn, sm, scalars_out, l2_sums,
+                     dp.h3_flag_off > 0 ? reinterpret_cast<const uint32_t*>(wt + dp.h3_flag_off) : nullptr);
   }
   if (is_tile) {
 #pragma unroll
@@ -346,12 +352,15 @@ __global__ __launch_bounds__(256) void update_tiled_kernel(ultr_update_desc u, D
           const int col = 2 * jj + tt;  // output column inside the tile
           typedef _Float16 h8v __attribute__((ext_vector_type(8)));
           h8v piece;
+          bool big = false;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const float w = (fwd ? tile[q][col][8 * qq + e] : tile[q][8 * qq + e][col]) * ULTR_H3_WSCALE;
             const _Float16 hi = (_Float16)w;
             piece[e] = hl ? (_Float16)(w - (float)hi) : hi;
+            big = big || !(fabsf(w) < ULTR_H3_WMAX);
           }
+          if (big) __hip_atomic_store(reinterpret_cast<uint32_t*>(wt + dp.h3_flag_off), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const int64_t pos = ((((int64_t)(c0 >> 5) * nks + (z0 >> 5)) * 4 + (2 * tt + hl)) * 64 +
                                ((((z0 & 31) >> 3) + qq) * 16 + ((c0 & 31) >> 1) + jj)) * 8;
           _Float16* dst = reinterpret_cast<_Float16*>(wt + (fwd ? dp.whf_off[j] : dp.whb_off[j]));

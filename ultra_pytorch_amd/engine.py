@@ -176,10 +176,21 @@ class StepEngine:
                 t0 = now if t0 is None else t0
                 if now - t0 > timeout_s:
                     raise _lib.UltrHipError("no step report from the GPU within %.0f s (step %d)" % (timeout_s, seq))
-        if int(u[8]) != 0:
-            raise _lib.UltrHipError("data-parallel gradient exchange timed out on some rank (ULTR_E_COMM_TIMEOUT): this and all "
-                                    "later updates were NOT applied - restart from the last checkpoint")
+        self._raise_on_status(int(u[8]))
         return self._hs_f[:8].copy()
+
+    H3_RANGE = 0x100  # include/ultr_hip.h: ULTR_STATUS_H3_RANGE
+
+    @classmethod
+    def _raise_on_status(cls, st):
+        if st == 0:
+            return
+        if st & cls.H3_RANGE:
+            raise _lib.UltrHipError("a hidden weight reached |w| >= 128, outside the range of the split-half (fp16 hi / lo) weight copies "
+                                    "(ULTR_STATUS_H3_RANGE): results are not to be trusted from here on - run with ULTR_FB_H3=0 "
+                                    "ULTR_FWD_H3=0 ULTR_BWD_H3=0 (fp32 matrix-core products)")
+        raise _lib.UltrHipError("data-parallel gradient exchange timed out on some rank (ULTR_E_COMM_TIMEOUT): this and all "
+                                "later updates were NOT applied - restart from the last checkpoint")
 
     def read_loss(self, timeout_s=60.0):
         """The loss of the last queued step (the reference's `loss.item()`).  Returns as soon as the loss is FINAL: on one GPU
@@ -197,9 +208,8 @@ class StepEngine:
                 t0 = now if t0 is None else t0
                 if now - t0 > timeout_s:
                     raise _lib.UltrHipError("no loss report from the GPU within %.0f s (step %d)" % (timeout_s, seq))
-        if int(u[9]) == seq and int(u[8]) != 0:  # the full report is in as well and carries a communication failure
-            raise _lib.UltrHipError("data-parallel gradient exchange timed out on some rank (ULTR_E_COMM_TIMEOUT): this and all "
-                                    "later updates were NOT applied - restart from the last checkpoint")
+        if int(u[9]) == seq:  # the full report is in as well: it may carry a failure
+            self._raise_on_status(int(u[8]))
         return float(self._hs_f[0])
 
     def close(self):
