@@ -500,7 +500,7 @@ def main():
         for i in range(16):
             step(i)
         _lib.check(lib.ultr_prof_set_stride(stride), "ultr_prof_set_stride")
-        _lib.check(lib.ultr_prof_enable(1 << dom, args.steps // stride + 2), "ultr_prof_enable")
+        _lib.check(lib.ultr_prof_enable(1 << dom, 4 * (args.steps // stride + 2)), "ultr_prof_enable")  # x4: uncounted shadow samples
     # ---- data parallel: is the one-kernel exchange trustworthy on THIS node? --------------------------------------
     # (it has its own start-up self-test; here the product step's own vector is checked against the RCCL all-reduce of the same
     # local gradients, before anything is timed - a mismatch demotes the peer path and `value` is measured with RCCL)
@@ -583,7 +583,21 @@ def main():
         return 1e3 * e0.elapsed_time(e1) / nrep
 
     # the same loop without the per-step read of the loss (the host runs ahead of the GPU)
+    dom_stream_us = None
+    if dnn and (not args.no_extras or world > 1):
+        # the dominant kernel's dispatch timestamps in THIS loop too: back-to-back launches (what a rocprofv3 average over the
+        # whole process is dominated by) - the figure inside the timed region is higher because every step there starts on a
+        # GPU that idled while the host read the previous loss
+        _lib.check(lib.ultr_prof_set_stride(stride), "ultr_prof_set_stride")
+        _lib.check(lib.ultr_prof_enable(1 << dom, 4 * (max(100, min(args.steps, 2000)) // stride + 4)), "ultr_prof_enable")
     nosync = timed_loop(eng, max(100, min(args.steps, 2000)), False) if not args.no_extras or world > 1 else None
+    if dnn and nosync is not None:
+        tot2, cnt2 = (ctypes.c_double * 8)(), (ctypes.c_int64 * 8)()
+        _lib.check(lib.ultr_prof_collect(tot2, cnt2), "ultr_prof_collect")
+        lib.ultr_prof_enable(0, 0)
+        lib.ultr_prof_set_stride(1)
+        if cnt2[dom] > 0:
+            dom_stream_us = 1e3 * tot2[dom] / cnt2[dom]
 
     allreduce_us, dp_exchanges, rccl_ranks = None, None, None
     NAME_PEER = "ultr_comm_allreduce (one kernel, hipIpc peer reads over xGMI)"
@@ -725,6 +739,11 @@ def main():
                                                                 "they run as three f16 MFMAs on split operands") if (dnn and bound == "mfma" and h3_products_on()) else None,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "avg_launch_us": 1e6 * dom_s, "launches_timed": dom_samples, "algorithmic_per_launch": amount,
+                         "avg_launch_us_back_to_back": dom_stream_us,
+                         "avg_launch_us_note": ("avg_launch_us (and `achieved`) is measured INSIDE the timed region, where every step "
+                                                "starts on a GPU that idled while the host read the previous loss; "
+                                                "avg_launch_us_back_to_back = the same kernel in the loop without host reads, "
+                                                "which is what a rocprofv3 average over the whole process mostly sees") if dnn else None,
                          "stage_note": ("the forward / backward slots are STAGES: dnn_fwd_kernel / dnn_bwd2_kernel, or - where the "
                                         "launcher's measured rule sends the shape (config 4: both) - the per-layer launches of "
                                         "ultr_dnn_big.hip (statistics passes + tiled GEMMs), one sample = first launch's start to last "

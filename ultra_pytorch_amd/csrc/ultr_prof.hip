@@ -6,6 +6,7 @@
 #include "../../include/ultr_hip.h"
 
 uint32_t g_ultr_prof_mask = 0;
+uint32_t g_ultr_prof_shadow = 0;
 bool g_ultr_prof_live = false;
 
 namespace {
@@ -23,7 +24,22 @@ void ultr_prof_tick() {
   if (g_ultr_prof_mask == 0) return;
   // the sampled step sits in the MIDDLE of each stride window: the first step behind a host synchronisation (device just idle)
   // is not the one that gets timed
-  g_ultr_prof_live = (g_ticks++ % (uint64_t)g_stride) == (uint64_t)(g_stride / 2);
+  const uint64_t ph = g_ticks++ % (uint64_t)g_stride;
+  g_ultr_prof_live = ph == (uint64_t)(g_stride / 2);
+  g_ultr_prof_shadow = 0;
+  if (g_stride > 1) {
+    // launch order inside a step: fused | forward, loss, backward; weight gradients; reduction; update
+    static const int order[ULTR_K_COUNT] = {0, 1, 2, 3, 4, 5, 6, 0};
+    int first = 99;
+    for (int k = 0; k < ULTR_K_COUNT; ++k)
+      if (((g_ultr_prof_mask >> k) & 1u) && k != ULTR_K_NDCG && order[k] < first) first = order[k];
+    if (g_ultr_prof_live) {
+      for (int k = 0; k < ULTR_K_COUNT; ++k)
+        if (k != ULTR_K_NDCG && order[k] < first) g_ultr_prof_shadow |= 1u << k;
+    } else if (ph + 1 == (uint64_t)(g_stride / 2) && first == 0) {
+      g_ultr_prof_shadow = 1u << ULTR_K_UPDATE;  // the launch right in front of the next step's first kernel
+    }
+  }
 }
 
 bool ultr_prof_take(int kid, hipEvent_t* a, hipEvent_t* b) {
@@ -37,6 +53,7 @@ bool ultr_prof_take(int kid, hipEvent_t* a, hipEvent_t* b) {
 
 extern "C" int ultr_prof_enable(uint32_t kernel_mask, int32_t max_samples) {
   g_ultr_prof_mask = 0;
+  g_ultr_prof_shadow = 0;
   g_used = 0;
   g_ticks = 0;
   g_ultr_prof_live = false;
@@ -75,6 +92,7 @@ extern "C" int ultr_prof_collect(double* total_ms, int64_t* counts) {
     float ms = 0.f;
     e = hipEventElapsedTime(&ms, g_pool[i].a, g_pool[i].b);
     if (e != hipSuccess) return (int)e;
+    if (g_pool[i].kid < 0) continue;  // shadow sample: timed only to keep its tail out of the next launch's interval
     total_ms[g_pool[i].kid] += ms;
     counts[g_pool[i].kid] += 1;
   }
