@@ -599,6 +599,26 @@ def main():
         if cnt2[dom] > 0:
             dom_stream_us = 1e3 * tot2[dom] / cnt2[dom]
 
+    # the same synced loop with the wide layers' products on the fp32 matrix cores (round 2's arithmetic, bit for bit): the
+    # split-half fp16 products are fp32-accurate, this line is for a reader who wants the all-fp32-MFMA figure
+    fp32_mfma = None
+    if dnn and world == 1 and not args.no_extras and h3_products_on():
+        keep = {k: os.environ.get(k) for k in ("ULTR_FB_H3", "ULTR_FWD_H3", "ULTR_BWD_H3")}
+        try:
+            for k in keep:
+                os.environ[k] = "0"
+            e32 = engs["fp32_mfma"] = eng_cls(shape, B, L, device, algo=cfg["algo"], learning_rate=LR, max_gradient_norm=CLIP)  # re-reads the knobs
+            t32 = timed_loop(e32, max(100, min(args.steps, 1000)), True)
+            fp32_mfma = {"queries_per_sec": B / t32, "ms_per_step": 1e3 * t32,
+                         "what": "ULTR_FB_H3=0 ULTR_FWD_H3=0 ULTR_BWD_H3=0: every product on v_mfma_f32_16x16x4_f32; loss read on the host every step"}
+        finally:
+            for k, v in keep.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+            lib.ultr_config_reload()
+
     allreduce_us, dp_exchanges, rccl_ranks = None, None, None
     NAME_PEER = "ultr_comm_allreduce (one kernel, hipIpc peer reads over xGMI)"
     NAME_RCCL = "process-group all-reduce (RCCL) + ultr_grad_sumsq"
@@ -755,6 +775,8 @@ def main():
             "final_loss": final_loss,
         }
         out["value_definition"] = "every step followed by the host's read of its loss (the reference's loss.item(), SURVEY 8d)"
+        if fp32_mfma is not None:
+            out["fp32_mfma_products"] = fp32_mfma
         if nosync is not None:
             out["queries_per_sec_no_host_sync"] = B * world / nosync
             out["ms_per_step_no_host_sync"] = 1e3 * nosync
