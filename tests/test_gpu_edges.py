@@ -3,6 +3,7 @@ without any click under IPW (0/0 -> 0, base_algorithm.py:26-27), lists made of P
 batch, every document of the batch being the same row, and the longest lists the list-wise kernels take."""
 import numpy as np
 import pytest
+from tests import margins
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -359,3 +360,54 @@ def test_weight_outside_the_split_half_range_raises():
     eng.train_step(p, st, dev(feats), feats.shape[0], dev(ids, torch.int32), dev(y))
     with pytest.raises(_lib.UltrHipError, match="split-half"):
         eng.read_scalars()
+
+
+@pytest.mark.parametrize("separate", [False, True])
+def test_split_half_products_with_wide_dynamic_range(separate, monkeypatch):
+    """The error budget of the split-half (fp16 hi / lo) products at its edges: feature rows with a 1e4
+    outlier next to 1e-4 entries (LayerNorm_0 bounds what reaches the product, but the row's scale is set by its largest
+    element), all-zero rows, weights from 1e-7 to 60 in one layer, LayerNorm gains up to 30 - scores, loss and gradients against
+    the oracle at the standard 1e-5 bars."""
+    from oracle import ultr_oracle as O
+    from ultra_pytorch_amd import engine, hip_ops
+    if separate:
+        monkeypatch.setenv("ULTR_NO_FUSED_FB", "1")
+    F, hidden, B, L = 136, [256, 256], 24, 10
+    rng = np.random.RandomState(11)
+    n_docs = B * L
+    feats = rng.uniform(-1, 1, size=(n_docs, F)).astype(np.float32)
+    feats[::7, 3] = 1e4                      # outliers
+    feats[::5, 10:40] *= 1e-4                # tiny entries in the same rows as others of order 1
+    feats[13] = 0.0                          # an all-zero document
+    ids = rng.permutation(n_docs).astype(np.int32).reshape(L, B)
+    clicks = (rng.uniform(size=(L, B)) < 0.3).astype(np.float32)
+    clicks[0, :] = 1.0
+    params = O.init_params(F, hidden, seed=5)
+    for name, shape, off in O.param_layout(F, hidden):
+        n = int(np.prod(shape))
+        if name.endswith("linear1.weight"):
+            w = params[off:off + n]
+            w[::97] = 60.0 * np.sign(w[::97] + 1e-9)
+            w[1::89] *= 1e-6
+        if name.endswith("layer_norm1.weight"):
+            params[off:off + n:11] = 30.0
+    state0 = np.zeros_like(params)
+    ref = O.train_step_softmax(params, state0, F, hidden, feats, ids, clicks, ipw_list=None)
+    shape = hip_ops.DnnShape(F, hidden, "elu")
+    try:
+        eng = engine.StepEngine(shape, B, L, torch.device("cuda"), algo="softmax")
+        p, st = dev(params), dev(state0)
+        eng.train_step(p, st, dev(feats), n_docs, dev(ids, torch.int32), dev(clicks))
+        sc = eng.read_scalars()
+        smax = max(1.0, float(np.abs(ref["scores"]).max()))
+        np.testing.assert_allclose(eng.scores.cpu().numpy(), ref["scores"], atol=1e-5 * smax, rtol=1e-5)
+        assert abs(sc[0] - ref["loss"]) <= 1e-5 * max(1.0, abs(ref["loss"]))
+        g = eng.grads[:shape.n_params].cpu().numpy() / sc[3]
+        gmax = float(np.abs(ref["grads"]).max())
+        err = np.abs(g - ref["grads"]).max() / max(gmax, 1e-30)
+        margins.check("edges/split_half_dynamic_range" + ("_separate" if separate else ""), "grads_max_abs_diff_over_max_abs_g", err)
+        np.testing.assert_allclose(g, ref["grads"], rtol=1e-5, atol=1e-5 * max(1.0, gmax))
+    finally:
+        if separate:
+            monkeypatch.delenv("ULTR_NO_FUSED_FB")
+            shape.lib.ultr_config_reload()
