@@ -341,7 +341,7 @@ def test_repeated_launches_are_bitwise_identical(F, hidden, B, L, separate, monk
             shape.lib.ultr_config_reload()
 
 
-def test_weight_outside_the_split_half_range_raises():
+def test_weight_outside_the_split_half_range_raises(monkeypatch):
     """The wide layers' products read fp16 hi / lo copies of the weights x 2^8: a weight of magnitude >= 128 would overflow them.
     The build / update kernels flag it and the host's read of the step report raises (ULTR_STATUS_H3_RANGE) instead of the
     step silently computing with infinities; with the split-half products switched off the same model trains."""
@@ -360,6 +360,18 @@ def test_weight_outside_the_split_half_range_raises():
     eng.train_step(p, st, dev(feats), feats.shape[0], dev(ids, torch.int32), dev(y))
     with pytest.raises(_lib.UltrHipError, match="split-half"):
         eng.read_scalars()
+    # with the split-half products off nothing reads the copies: the same model trains
+    for k in ("ULTR_FB_H3", "ULTR_FWD_H3", "ULTR_BWD_H3"):
+        monkeypatch.setenv(k, "0")
+    try:
+        eng2 = engine.StepEngine(shape, B, L, torch.device("cuda"), algo="softmax")  # re-reads the knobs
+        p2, st2 = dev(p0), dev(np.zeros_like(p0))
+        eng2.train_step(p2, st2, dev(feats), feats.shape[0], dev(ids, torch.int32), dev(y))
+        assert np.isfinite(eng2.read_scalars()[0])
+    finally:
+        for k in ("ULTR_FB_H3", "ULTR_FWD_H3", "ULTR_BWD_H3"):
+            monkeypatch.delenv(k)
+        shape.lib.ultr_config_reload()
 
 
 @pytest.mark.parametrize("separate", [False, True])

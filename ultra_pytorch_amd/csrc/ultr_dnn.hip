@@ -3254,6 +3254,7 @@ bool ultr_make_dnn_plan(const ultr_dnn_desc* d, int64_t N, DnnPlan* p) {
         }
       }
       p->h3_ok = h3 ? 1 : 0;
+      p->fb_h3 = (h3 && knobs().fb_h3) ? 1 : 0;
       p->h3_flag_off = o;  // (inside the region ultr_dnn_build_wt zeroes)
       o += 4;
       p->bwd_h3 = 0;
@@ -3877,7 +3878,7 @@ int ultr_fused_step_softmax(const ultr_dnn_desc* d, const float* params, const f
                 docids, (int)batch, L, lpb, scores, (float*)saved, ws, fl, fp);                                                \
   } while (0)
     // products on the fp16 matrix cores with split operands where the plan has the split-half copies (ULTR_FB_H3=0: fp32 MFMAs)
-    const bool h3 = p.h3_ok != 0 && knobs().fb_h3 != 0;
+    const bool h3 = p.fb_h3 != 0;
     if (p.maxdim <= 256) {
       if (h3) LAUNCH_FB(1, true);
       else LAUNCH_FB(1, false);

@@ -54,6 +54,7 @@ struct DnnPlan {
   // per layer: h3f[j] - the forward product of layer j has its split-half copy (M_j a multiple of 32, >= 256: eight 32-column
   // chunks); h3b[j] - so has the dgrad product du_j = dz_j . W_j (j >= 1, K_j >= 256, both widths multiples of 32)
   int h3f[ULTR_MAXL], h3b[ULTR_MAXL];
+  int fb_h3;              // the fused kernel takes the split-half build (h3_ok and the ULTR_FB_H3 knob)
   int bwd_h3;             // dnn_bwd2_kernel runs at least one dgrad product on them (changes the row stride of its dz tile)
   int64_t h3_flag_off;    // one word behind the copies: != 0 once a weight left the copies' range (|w| x 2^8 >= 2^15): status ULTR_STATUS_H3_RANGE
   int fwd_h3;             // dnn_fwd_kernel runs at least one layer on the split-half copies (changes its LDS row stride)

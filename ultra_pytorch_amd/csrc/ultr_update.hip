@@ -327,7 +327,8 @@ __global__ __launch_bounds__(256) void update_tiled_kernel(ultr_update_desc u, D
     update_body<TPW>(u, dp, params, state, grads + P, aux, ss, ea, g_raw, p_old, s_old, pn, sm, nullptr, l2_sums);
   } else {
     update_body<TPW>(u, dp, params, state, grads + P, aux, ss, ea, g_raw, p_old, s_old, pn, sm, scalars_out, l2_sums,
-                     dp.h3_flag_off > 0 ? reinterpret_cast<const uint32_t*>(wt + dp.h3_flag_off) : nullptr);
+                     // (only a step that READS the copies reports: with all three knobs off a large weight is harmless)
+                     (dp.h3_flag_off > 0 && (dp.fb_h3 | dp.fwd_h3 | dp.bwd_h3)) ? reinterpret_cast<const uint32_t*>(wt + dp.h3_flag_off) : nullptr);
   }
   if (is_tile) {
 #pragma unroll
