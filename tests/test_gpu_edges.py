@@ -423,3 +423,33 @@ def test_split_half_products_with_wide_dynamic_range(separate, monkeypatch):
         if separate:
             monkeypatch.delenv("ULTR_NO_FUSED_FB")
             shape.lib.ultr_config_reload()
+
+
+@pytest.mark.parametrize("act", ["relu", "tanh", "sigmoid"])
+@pytest.mark.parametrize("separate", [False, True])
+def test_wide_layers_with_every_activation_match_oracle(act, separate, monkeypatch):
+    """The reference-fixture nets for relu / tanh / sigmoid are narrow (no split-half products, no fragment-major copies): the same
+    activations on config 2's layers - through the fused kernel and through the separate forward / backward kernels - against
+    the oracle: scores, loss, gradients at the standard bars."""
+    from oracle import ultr_oracle as O
+    from ultra_pytorch_amd import engine, hip_ops
+    if separate:
+        monkeypatch.setenv("ULTR_NO_FUSED_FB", "1")
+    F, hidden, B, L = 136, [256, 256], 40, 10
+    n_docs, feats, ids, clicks, params, state0 = _softmax_case(F, hidden, B, L)
+    ipw = np.linspace(1.0, 4.0, 10)
+    ref = O.train_step_softmax(params, state0, F, hidden, feats, ids, clicks, ipw_list=ipw, act=act)
+    shape = hip_ops.DnnShape(F, hidden, act)
+    try:
+        eng = engine.StepEngine(shape, B, L, torch.device("cuda"), algo="softmax")
+        p, st = dev(params), dev(state0)
+        eng.train_step(p, st, dev(feats), n_docs, dev(ids, torch.int32), dev(clicks), ipw_table=dev(ipw.astype(np.float32)))
+        sc = eng.read_scalars()
+        np.testing.assert_allclose(eng.scores.cpu().numpy(), ref["scores"], atol=1e-5, rtol=1e-5)
+        assert abs(sc[0] - ref["loss"]) <= 1e-5 * max(1.0, abs(ref["loss"]))
+        g = eng.grads[:shape.n_params].cpu().numpy() / sc[3]
+        np.testing.assert_allclose(g, ref["grads"], rtol=2e-5, atol=2e-6 * max(1.0, float(np.abs(ref["grads"]).max())))
+    finally:
+        if separate:
+            monkeypatch.delenv("ULTR_NO_FUSED_FB")
+            shape.lib.ultr_config_reload()
