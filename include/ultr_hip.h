@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ULTR_ABI_VERSION 4
+#define ULTR_ABI_VERSION 5
 #define ULTR_MAX_HIDDEN 7 /* hidden layers; Linear layers = hidden + 1 <= 8 */
 
 #define ULTR_E_BADARG (-1)
@@ -50,6 +50,11 @@ extern "C" {
  * read - results from then on are not to be trusted; run with ULTR_FB_H3=0 ULTR_FWD_H3=0 ULTR_BWD_H3=0 (fp32 matrix-core
  * products).  Raised by ultr_dnn_build_wt / ultr_apply_update, reported with the step after the one that wrote the weight. */
 #define ULTR_STATUS_H3_RANGE 0x100u
+/* ... and the early warning: a hidden weight reached |w| >= 64, half of that range, while every copy is still exact.  An optimizer
+ * step moves a weight by at most learning_rate x max_gradient_norm, so a host that reads the report every few steps has time to
+ * switch to the fp32 products (ULTR_*_H3=0 + ultr_config_reload) before anything overflows - engine.StepEngine does, with a
+ * warning: like the reference (base_algorithm.py:208-226) the library then trains any weight magnitude. */
+#define ULTR_STATUS_H3_NEAR 0x200u
 
 /* base_ranking_model.py:63-69 (ACT_FUNC_DIC): elu, relu, tanh, sigmoid.  ('selu' is listed there as a plain function and
  * nn.Sequential.add_module rejects it - TypeError at DNN.py:52-53 - so it is not an option of the reference.) */
@@ -98,6 +103,13 @@ int ultr_dnn_forward(const ultr_dnn_desc* d, const float* params, const float* w
  * Passing wt == NULL to ultr_dnn_forward selects the (slower) generic path that reads W directly. */
 int64_t ultr_dnn_wt_floats(const ultr_dnn_desc* d);
 int ultr_dnn_build_wt(const ultr_dnn_desc* d, const float* params, float* wt, void* stream);
+/* ABI 5.  Range state of the split-half (fp16 hi / lo) weight copies inside `wt` (ULTR_STATUS_H3_NEAR / _RANGE above):
+ * 0 = every hidden weight is below 64 in magnitude, 1 = near the edge (|w| >= 64, copies still exact), 2 = a copy overflowed
+ * (|w| >= 128).  SYNCHRONISES the stream (one 4-byte device-to-host copy): meant to be called once behind ultr_dnn_build_wt,
+ * i.e. after parameters arrived from outside (checkpoint, init) - the reference accepts any weight there (DNN.py:58-88 computes
+ * in fp32), so the caller switches to the fp32 products (ULTR_FB_H3=0 ULTR_FWD_H3=0 ULTR_BWD_H3=0 + ultr_config_reload) when
+ * this is not 0.  During training the same information arrives with the step report (host_scalars[8]). */
+int ultr_dnn_wt_range(const ultr_dnn_desc* d, const float* wt, void* stream);
 
 /* ---- a5 (backward half): what loss.backward() does for the DNN ----------------------
  * Replaces autograd through DNN.sequential (called from BaseAlgorithm.opt_step,

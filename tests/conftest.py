@@ -23,3 +23,27 @@ def golden_dir():
 def pytest_sessionfinish(session, exitstatus):
     from tests import margins
     margins.flush()
+
+
+H3_KNOBS = ("ULTR_FB_H3", "ULTR_FWD_H3", "ULTR_BWD_H3")
+
+
+@pytest.fixture(params=["split_half", "fp32_mfma"])
+def mfma_mode(request, monkeypatch):
+    """Both arithmetic plans of the wide layers' products under the same parity bars: the default (three v_mfma_f32_16x16x32_f16 on
+    split hi / lo fp16 operands) and every product on v_mfma_f32_16x16x4_f32 (ULTR_FB_H3=0 ULTR_FWD_H3=0 ULTR_BWD_H3=0 - what the
+    engine falls back to when a weight leaves the split-half copies' range, and bench.py's fp32_mfma_products figure).  The
+    knobs are read when an engine is built (ultr_config_reload), so tests build their engines AFTER taking this fixture."""
+    if request.param == "fp32_mfma":
+        for k in H3_KNOBS:
+            monkeypatch.setenv(k, "0")
+    else:
+        for k in H3_KNOBS:
+            monkeypatch.delenv(k, raising=False)
+    yield request.param
+    monkeypatch.undo()
+    try:
+        from ultra_pytorch_amd import _lib
+        _lib.load().ultr_config_reload()
+    except Exception:
+        pass

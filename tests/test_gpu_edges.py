@@ -181,7 +181,7 @@ def test_host_mapped_step_report_equals_device_scalars():
                                           (136, [128], 16, 16),         # one hidden layer, full 16-row tiles
                                           (32, [96, 64], 12, 5),        # three lists per 16-row tile
                                           (20, [48, 24], 9, 3)])        # widths not multiples of 32: no fragment-major copies
-def test_fused_step_shapes_match_oracle(F, hidden, B, L):
+def test_fused_step_shapes_match_oracle(F, hidden, B, L, mfma_mode):
     """The small-batch NA / IPW step (ONE fused forward + loss + backward launch, dnn_fb_kernel) through ultr_train_step at
     shapes that reach every path of the kernel - fragment-major and k-major weight streaming, one / two column chunks per
     lane, 1 - 5 lists per tile - against the oracle: scores, loss, gradient, norm, updated parameters."""
@@ -245,7 +245,7 @@ def _softmax_case(F, hidden, B, L):
                                           (136, [512, 256, 128], 21, 20),  # config 3's layers: split-half where a layer has >= 256 outputs, fp32 elsewhere
                                           (40, [512, 256], 7, 10),         # 512-wide rows
                                           (24, [64, 32, 32], 20, 8)])      # no split-half copies at all
-def test_separate_kernel_step_shapes_match_oracle(F, hidden, B, L, monkeypatch):
+def test_separate_kernel_step_shapes_match_oracle(F, hidden, B, L, mfma_mode, monkeypatch):
     """The same step through the SEPARATE forward / backward kernels (dnn_fwd_kernel, dnn_bwd2_kernel: what every batch too
     large for the fused kernel runs, forced here with ULTR_NO_FUSED_FB=1) - including their split-half (fp16 hi/lo) products -
     against the oracle: scores, loss, gradient, norm, updated parameters, and the scores of the step after."""
@@ -305,14 +305,16 @@ def test_update_kernel_keeps_every_weight_copy_current(hidden):
     assert diff.numel() == 0, (diff[:8].tolist(), diff.numel(), kept.numel())
 
 
-@pytest.mark.parametrize("F,hidden,B,L,separate", [(136, [256, 256], 256, 10, False),     # config 2: the fused kernel
-                                                   (136, [256, 256], 256, 10, True),      # config 2 through the separate kernels
-                                                   (136, [512, 256, 128], 128, 20, True)])  # config 3's layers (too long lists for the fused kernel anyway)
-def test_repeated_launches_are_bitwise_identical(F, hidden, B, L, separate, monkeypatch):
-    """The same step from the same state, twenty times: scores, loss and every gradient bit must repeat.  (Round 3 found an
-    epilogue of the split-half dgrad product whose compiled form gave one row of one 16-column tile a different value in
-    a few launches out of ten - only on grids of >= ~20 workgroups, invisible to a single parity run; tools/h3_stress.py is
-    the long version of this test.)"""
+@pytest.mark.parametrize("F,hidden,B,L,separate", [(136, [256, 256], 256, 10, False),      # config 2: the fused kernel
+                                                   (136, [256, 256], 256, 10, True),       # config 2 through the separate kernels
+                                                   (136, [512, 256, 128], 512, 20, True),  # config 3 (640 workgroups of the row-tile kernels)
+                                                   (700, [512, 256, 128], 256, 50, True)])  # config 4's grid (800 row tiles)
+def test_repeated_launches_are_bitwise_identical(F, hidden, B, L, separate, mfma_mode, monkeypatch):
+    """The same step from the same state, a hundred times: scores, loss and every gradient bit must repeat - with the split-half
+    products and with every product on the fp32 matrix cores.  (Round 3 met gradients that differed in a few launches out of
+    ten on grids of >= ~20 workgroups, invisible to a single parity run.  Round 4 found the cause - a gfx950 hazard of packed
+    fp32 instructions with op_sel next to another wave's f16 MFMAs, profiles/r04_h3_rootcause.md - and builds the library
+    without packed fp32 instructions; this test and its long version tools/h3_stress.py keep watch.)"""
     from ultra_pytorch_amd import engine, hip_ops, synthetic
     from ultra_pytorch_amd.ranking_model import init_flat_params
     if separate:
@@ -325,7 +327,7 @@ def test_repeated_launches_are_bitwise_identical(F, hidden, B, L, separate, monk
         eng = engine.StepEngine(shape, B, L, torch.device("cuda"), algo="softmax", learning_rate=0.05, max_gradient_norm=5.0)
         f, i, yy, tab = dev(feats), dev(ids, torch.int32), dev(y), dev(ipw)
         first = None
-        for rep in range(20):
+        for rep in range(100):
             params, state = dev(p0.copy()), dev(np.zeros_like(p0))
             eng.train_step(params, state, f, feats.shape[0], i, yy, ipw_table=tab)
             torch.cuda.synchronize()
@@ -341,36 +343,90 @@ def test_repeated_launches_are_bitwise_identical(F, hidden, B, L, separate, monk
             shape.lib.ultr_config_reload()
 
 
-def test_weight_outside_the_split_half_range_raises(monkeypatch):
-    """The wide layers' products read fp16 hi / lo copies of the weights x 2^8: a weight of magnitude >= 128 would overflow them.
-    The build / update kernels flag it and the host's read of the step report raises (ULTR_STATUS_H3_RANGE) instead of the
-    step silently computing with infinities; with the split-half products switched off the same model trains."""
+def _h3_case(weight, B=16):
     from oracle import ultr_oracle as O
-    from ultra_pytorch_amd import _lib, engine, hip_ops, synthetic
-    F, hidden, B, L = 136, [256, 256], 16, 10
-    rng = np.random.RandomState(2)
-    shape = hip_ops.DnnShape(F, hidden, "elu")
+    from ultra_pytorch_amd import synthetic
+    F, hidden, L = 136, [256, 256], 10
     p0 = O.init_params(F, hidden, seed=3)
     for name, shp, off in O.param_layout(F, hidden):
         if name.endswith("linear1.weight"):
-            p0[off + 5] = 200.0
-    feats, ids, y = synthetic.make_batch(rng, B, L, F)
-    eng = engine.StepEngine(shape, B, L, torch.device("cuda"), algo="softmax")
-    p, st = dev(p0), dev(np.zeros_like(p0))
-    eng.train_step(p, st, dev(feats), feats.shape[0], dev(ids, torch.int32), dev(y))
-    with pytest.raises(_lib.UltrHipError, match="split-half"):
-        eng.read_scalars()
-    # with the split-half products off nothing reads the copies: the same model trains
+            p0[off + 5] = weight
+    feats, ids, y = synthetic.make_batch(np.random.RandomState(2), B, L, F)
+    return F, hidden, L, p0, feats, ids, y
+
+
+@pytest.mark.parametrize("weight", [70.0, 200.0])
+@pytest.mark.parametrize("reader", ["read_loss", "read_scalars"])
+def test_weight_outside_the_split_half_range_falls_back_to_fp32(weight, reader, monkeypatch):
+    """The wide layers' products read fp16 hi / lo copies of the weights x 2^8 (|w| < 128).  The reference trains any weight
+    magnitude (base_algorithm.py:208-226): parameters that ARRIVE with a hidden weight >= 64 (near the edge) or >= 128 (beyond it)
+    make the engine switch to the fp32 matrix-core products - with a warning - before a kernel reads the copies, and the step
+    matches the oracle at the usual bars."""
+    from oracle import ultr_oracle as O
+    from ultra_pytorch_amd import engine, hip_ops
     for k in ("ULTR_FB_H3", "ULTR_FWD_H3", "ULTR_BWD_H3"):
-        monkeypatch.setenv(k, "0")
+        monkeypatch.setenv(k, "1")  # (the fallback writes os.environ: undo() then restores the caller's state)
+    F, hidden, L, p0, feats, ids, y = _h3_case(weight)
+    B = ids.shape[1]
+    shape = hip_ops.DnnShape(F, hidden, "elu")
     try:
-        eng2 = engine.StepEngine(shape, B, L, torch.device("cuda"), algo="softmax")  # re-reads the knobs
-        p2, st2 = dev(p0), dev(np.zeros_like(p0))
-        eng2.train_step(p2, st2, dev(feats), feats.shape[0], dev(ids, torch.int32), dev(y))
-        assert np.isfinite(eng2.read_scalars()[0])
+        eng = engine.StepEngine(shape, B, L, torch.device("cuda"), algo="softmax")
+        p, st = dev(p0), dev(np.zeros_like(p0))
+        with pytest.warns(RuntimeWarning, match="fp32 matrix cores"):
+            eng.train_step(p, st, dev(feats), feats.shape[0], dev(ids, torch.int32), dev(y))
+        loss = eng.read_loss() if reader == "read_loss" else float(eng.read_scalars()[0])
+        assert not hip_ops.split_half_enabled()
+        ref = O.train_step_softmax(p0, np.zeros_like(p0), F, hidden, feats, ids, y, ipw_list=None)
+        assert abs(loss - ref["loss"]) <= 1e-5 * max(1.0, abs(ref["loss"]))
+        np.testing.assert_allclose(eng.scores.cpu().numpy(), ref["scores"], atol=1e-5 * max(1.0, float(np.abs(ref["scores"]).max())), rtol=1e-5)
+        sc = eng.read_scalars()
+        g = eng.grads[:shape.n_params].cpu().numpy() / sc[3]
+        np.testing.assert_allclose(g, ref["grads"], rtol=2e-5, atol=2e-6 * max(1.0, float(np.abs(ref["grads"]).max())))
     finally:
-        for k in ("ULTR_FB_H3", "ULTR_FWD_H3", "ULTR_BWD_H3"):
-            monkeypatch.delenv(k)
+        monkeypatch.undo()
+        shape.lib.ultr_config_reload()
+
+
+@pytest.mark.parametrize("reader", ["read_loss", "read_scalars"])
+def test_weight_drifting_towards_the_split_half_range_switches_plans_in_time(reader, monkeypatch):
+    """Training drift: a hidden weight just below 64 is pushed over it by the optimizer.  The update kernel raises
+    ULTR_STATUS_H3_NEAR in the step report, the next read of the loss (read_loss: the ADVICE r03 path that never looked at the
+    status) switches the process to the fp32 products with a warning, nothing raises, and the trajectory goes on finite: every
+    copy was still exact when the switch happened (|w| < 128)."""
+    from ultra_pytorch_amd import engine, hip_ops
+    for k in ("ULTR_FB_H3", "ULTR_FWD_H3", "ULTR_BWD_H3"):
+        monkeypatch.setenv(k, "1")
+    F, hidden, L, p0, feats, ids, y = _h3_case(0.01)
+    B = ids.shape[1]
+    shape = hip_ops.DnnShape(F, hidden, "elu")
+    try:
+        # eight weights of layer 1 start a hair inside +-64 (different inputs k: their gradients' signs are unrelated); plain SGD
+        # moves each by lr x g per step, so within a few steps some of them cross
+        from oracle import ultr_oracle as O
+        for name, shp, off in O.param_layout(F, hidden):
+            if name.endswith("linear1.weight"):
+                for t in range(8):
+                    p0[off + 256 * (3 + t) + 11 * t] = (63.9999 if t % 2 == 0 else -63.9999)
+        assert float(np.abs(p0).max()) < 64.0
+        eng = engine.StepEngine(shape, B, L, torch.device("cuda"), algo="softmax", optimizer="sgd", learning_rate=2.0)
+        p, st = dev(p0), dev(np.zeros_like(p0))
+        args = (dev(feats), feats.shape[0], dev(ids, torch.int32), dev(y))
+        import warnings
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            seen = False
+            for step in range(6):
+                eng.train_step(p, st, *args)
+                loss = eng.read_loss() if reader == "read_loss" else float(eng.read_scalars()[0])
+                assert np.isfinite(loss)
+                seen = seen or any("fp32 matrix cores" in str(x.message) for x in w)
+            torch.cuda.synchronize()
+        wmax = float(p.abs().max())
+        assert wmax >= 64.0, "the planted weights did not cross 64: the test needs a larger learning rate (%.6f)" % wmax
+        assert seen and not hip_ops.split_half_enabled()
+        assert wmax < 128.0 and np.isfinite(p.cpu().numpy()).all()
+    finally:
+        monkeypatch.undo()
         shape.lib.ultr_config_reload()
 
 

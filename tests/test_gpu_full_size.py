@@ -102,6 +102,41 @@ def test_full_size_step_matches_oracle(name):
         np.testing.assert_allclose(aux2, ref["prop_params"], atol=2e-6)
 
 
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_full_size_product_step_matches_oracle(name, mfma_mode):
+    """The step the product issues (engine.StepEngine.train_step = ONE C call: fused kernel at config 2, row-tile forward /
+    backward with their split-half dgrad at config 3, per-layer backward at config 4) against the oracle at BASELINE's full
+    sizes, with the wide layers' products on the split-half copies and on the fp32 matrix cores.  The stage-by-stage test above
+    never reaches dnn_bwd2_kernel's split-half dgrad (the public ultr_dnn_backward has no weight-copy argument)."""
+    from oracle import ultr_oracle as O
+    from ultra_pytorch_amd import engine, hip_ops, synthetic
+    F, hidden, B, L, algo, lr = CONFIGS[name]
+    rng = np.random.RandomState(7)
+    feats, ids, y = make_inputs(F, B, L, algo)
+    params = O.init_params(F, hidden, seed=2)
+    aux = aux_for(name, rng)
+    ref = run_oracle(name, params, feats, ids, y, aux)
+    shape = hip_ops.DnnShape(F, hidden, "elu")
+    eng = engine.StepEngine(shape, B, L, torch.device("cuda"), algo=algo, learning_rate=lr)
+    p = dev(params)
+    st = None if algo == "dla" else dev(np.zeros_like(params))
+    a = None if aux is None else dev(aux)
+    tab = dev(np.asarray(synthetic.load_ipw(), np.float32)) if algo == "softmax" else None
+    eng.train_step(p, st, dev(feats), feats.shape[0], dev(ids, torch.int32), dev(y), aux=a, ipw_table=tab)
+    sc = eng.read_scalars()
+    scores = eng.scores.cpu().numpy()
+    np.testing.assert_allclose(scores, ref["scores"], atol=1e-5)
+    assert abs(sc[0] - ref["loss"]) <= 1e-5 * max(1.0, abs(ref["loss"]))
+    tail = eng.grads[shape.n_params:].cpu().numpy()
+    gs = 1.0 if algo == "pairdebias" else 1.0 / tail[1]
+    g, gref = eng.grads[:shape.n_params].cpu().numpy() * gs, ref["grads"]
+    key = "full_size_step_%s/%s" % (mfma_mode, name)
+    margins.check(key, "scores_max_abs_diff", np.abs(scores - ref["scores"]).max())
+    margins.check(key, "grads_max_abs_diff_over_max_abs_g", np.abs(g - gref).max() / np.abs(gref).max())
+    np.testing.assert_allclose(g, gref, rtol=1e-5, atol=1e-5 * float(np.abs(gref).max()))  # (the floor: see the stage test above)
+    assert abs(sc[1] - ref["norm"]) <= 1e-5 * ref["norm"]
+
+
 @pytest.mark.parametrize("name", ["cfg2_ipw", "cfg4_pairdebias"])
 def test_shard_sum_equals_full_batch(name):
     """The data-parallel identity at full size: [unscaled grads | tail] of the two half batches add up to the

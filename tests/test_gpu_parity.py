@@ -60,6 +60,16 @@ def gscale_and_loss(algo, tail, rw=1.0):
 
 @pytest.mark.parametrize("name", TRAIN_CASES)
 def test_golden_train_step(name):
+    _golden_train_step(name)
+
+
+def test_golden_train_step_on_the_fp32_mfma_plan(mfma_mode):
+    """The reference's config-2-shaped fixture (the only golden case whose layers are wide enough for the split-half products)
+    under BOTH arithmetic plans; test_golden_train_step above runs the default one for every fixture."""
+    _golden_train_step("ipw_cfg2")
+
+
+def _golden_train_step(name):
     d, m = load_golden(name)
     run = make_run(m, name)
     L = m["L"]

@@ -173,3 +173,34 @@ def test_regression_em_device_rng():
     p_r1 = c + (1 - c) * (0.1 * gamma / (1 - 0.9 * gamma))
     assert set(np.unique(ys[0])) <= {0.0, 1.0}
     assert abs(ys[0].mean() - p_r1.mean()) < 4 * np.sqrt(0.25 / (B * L))
+
+
+def test_plugin_trains_through_a_weight_outside_the_split_half_range(monkeypatch):
+    """IPWrank.train() the way main.py calls it, on a checkpoint whose hidden weight of 90 is outside what the split-half weight
+    copies serve exactly-with-margin (|w| < 64; they overflow at 128): the reference trains any weight (base_algorithm.py:
+    208-226), so the plugin must too - it switches to the fp32 matrix-core products with a warning and returns the reference's
+    loss (ipw_cfg2 fixture, one planted weight, against the oracle)."""
+    from oracle import ultr_oracle as O
+    from ultra_pytorch_amd import hip_ops
+    for k in hip_ops.H3_KNOBS:
+        monkeypatch.setenv(k, "1")
+    d, m = load_golden("ipw_cfg2")
+    algo = build(m)
+    flat = d["s0_pre_params"].copy()
+    for name, shape, off in O.param_layout(m["F"], m["hidden"]):
+        if name.endswith("linear1.weight"):
+            flat[off + 7] = 90.0
+    try:
+        load_flat(algo.model, flat)
+        feed = make_feed(algo, d["s0_features"], d["s0_docids"], d["s0_labels"])
+        with pytest.warns(RuntimeWarning, match="fp32 matrix cores"):
+            loss, _, _ = algo.train(feed)
+        ref = O.train_step_softmax(flat, d["s0_pre_adagrad"], m["F"], m["hidden"], d["s0_features"], d["s0_docids"].astype(np.int32),
+                                   d["s0_labels"], ipw_list=d["ipw_list"], lr=m["lr"], max_norm=m["max_gradient_norm"])
+        assert abs(loss - ref["loss"]) <= 1e-5 * max(1.0, abs(ref["loss"]))
+        assert not hip_ops.split_half_enabled()
+        loss2, _, _ = algo.train(feed)  # and keeps training
+        assert np.isfinite(loss2)
+    finally:
+        monkeypatch.undo()
+        algo.model.shape.lib.ultr_config_reload()

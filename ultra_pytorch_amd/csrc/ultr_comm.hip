@@ -155,8 +155,11 @@ __global__ __launch_bounds__(256) void comm_allreduce_kernel(CommDev c, uint32_t
         if (idx >= 0 && idx < 4) sm_head[idx] = sv[k];
       }
       __syncthreads();
+      // not after a timed-out wait in THIS slice - nor when another slice's wait, or a peer, already raised this rank's status
+      // word (the update behind this launch is then a no-op and reports NaN + the status: the loss must not look final)
       bool failed = false;
-      if constexpr (W > 1) failed = sm_fail != 0;
+      if constexpr (W > 1)
+        failed = sm_fail != 0 || __hip_atomic_load(c.status[c.rank], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
       if (tid == 0 && !failed) {
         const float loss_sum = sm_head[0], D = sm_head[1], loss2 = sm_head[2], D2 = sm_head[3];
         float loss = loss_sum / D;

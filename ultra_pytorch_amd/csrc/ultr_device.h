@@ -267,7 +267,11 @@ __device__ __forceinline__ float rsqrt_nr(float x) {
 // implements the fence as s_waitcnt vmcnt(0) lgkmcnt(0): every global store of an epilogue and every prefetched
 // global load would be drained at each phase boundary.  The kernels here never communicate through global memory
 // inside a launch, so waiting for the LDS queue is sufficient.
+#if ULTR_SYNC_BARRIER  // REPRO BUILDS ONLY (tools/h3_repro.sh): the full fence + barrier
+__device__ __forceinline__ void lds_barrier() { __syncthreads(); }
+#else
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 
 // Canonical order of every cross-workgroup partial sum (slabs, loss partials): part k belongs to group k & 3; a group
 // adds its parts in chunks of 8, ((v0+v1)+(v2+v3))+((v4+v5)+(v6+v7)) with missing parts = 0, chunks accumulate in
@@ -320,3 +324,6 @@ struct Philox {
 __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }  // [0, 1)
 
 __host__ __device__ __forceinline__ int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// raise bits of a status / flag word other workgroups and later launches read (rare path: relaxed, agent scope)
+__device__ __forceinline__ void flag_or(uint32_t* w, uint32_t bits) { __hip_atomic_fetch_or(w, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

@@ -11,7 +11,10 @@
 //                     the B operand on the fly, deterministic partial slabs (no atomics).
 //   grad_reduce_kernel  fixed-order slab reduction -> flat gradient (+ step tail + sum-of-squares partials).
 //
-// All matrix math is v_mfma_f32_16x16x4_f32 (exact fp32).  Wave = 64 lanes everywhere.
+// Matrix math: v_mfma_f32_16x16x4_f32 (exact fp32) - and, for layers with >= 256 outputs / inputs where the plan carries split-half
+// weight copies (DnnPlan::h3f / h3b; knobs ULTR_FB_H3 / ULTR_FWD_H3 / ULTR_BWD_H3, default on), three v_mfma_f32_16x16x32_f16 on
+// hi / lo fp16 halves of both operands with fp32 accumulation (PipeH3: fp32-grade results).  Wave = 64 lanes.
+// No packed fp32 VALU instructions anywhere (build.py NO_PACKED_FP32: a gfx950 hazard next to the f16 MFMAs).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -477,6 +480,27 @@ struct PipeSw {
 #define FB_SW 1   // dnn_fb_kernel streams the fragment-major copies when the plan has them (0: the k-major / row-major paths)
 #endif
 
+#ifndef BWD_H3_EPI
+#define BWD_H3_EPI 0  // REPRO BUILDS ONLY (tools/h3_repro.sh): dnn_bwd2_kernel's split-half dgrad epilogue applies the row scale itself
+#endif
+#ifndef H3_ACC2
+#define H3_ACC2 0     // REPRO BUILDS ONLY: PipeH3 chains both cross terms on one accumulator set
+#endif
+#ifndef H3_EPI_BAR
+#define H3_EPI_BAR 0        // REPRO BUILDS ONLY: a workgroup barrier between the products and the epilogue's read of the scales
+#endif
+#ifndef H3_EPI_OS_SCALAR
+#define H3_EPI_OS_SCALAR 0  // REPRO BUILDS ONLY: the epilogue reads its four scales with volatile 4-byte LDS reads
+#endif
+#ifndef H3_OS_DB
+#define H3_OS_DB 0          // REPRO BUILDS ONLY: the row scales double-buffered by layer parity
+#endif
+#ifndef H3_DBG_DUMP
+#define H3_DBG_DUMP 0
+#endif
+#ifndef H3_EPI_NOP
+#define H3_EPI_NOP 0  // REPRO BUILDS ONLY: 32 idle cycles between the last MFMA of a chunk and the epilogue
+#endif
 // Products on the fp16 matrix cores with SPLIT operands (DnnPlan::whf_off / whb_off, ultr_h3_index): the A tile lives in LDS as two
 // fp16 planes (hi, lo of the row-scaled activations), the weights arrive as hi / lo fragments, and a . w = ah.wh + (ah.wl + al.wh)
 // with fp32 accumulation on v_mfma_f32_16x16x32_f16 - 22 bits of operand mantissa, 6 MFMAs of 16 cycles per 32-deep step and
@@ -526,12 +550,11 @@ struct PipeH3 {
     if constexpr (D > 2) fetch<1>(W);
     static_assert(D >= 2 && D <= 3, "pipeline depth");
   }
-  // Three accumulator sets per column tile (ah.wh | ah.wl | al.wh), each written ONCE per step: no MFMA reads an accumulator that
-  // one of the five MFMAs before it wrote.  With two sets (the cross terms chained: accx = ah.wl + accx; accx = al.wh + accx) hipcc
-  // may place the second product out of place (its SrcC = the first one's vDst, a different vDst of its own) one MFMA behind
-  // the first, and on gfx950 (ROCm 7.2) that v_mfma_f32_16x16x32_f16 pair then intermittently reads a stale SrcC for the rows
-  // the first product writes last - seen in dnn_bwd2_kernel as row 13 of one 16-column tile, ~1e-2 relative, a few launches in
-  // ten (tools/dbg_bwd_h3.py; profiles/r03_cfg2_attempts.md).
+  // Three accumulator sets per column tile (ah.wh | ah.wl | al.wh): three independent MFMA chains, every accumulator written once per
+  // step.  (Round 3 presented this layout as the cure for an intermittent wrong result.  It was not: the cause was a packed fp32
+  // multiply in the EPILOGUE - v_pk_mul_f32 .. op_sel:[0,1] reads its operand as zero in lanes 48..63 while the SIMD's other wave
+  // is inside an MFMA loop - reproduced in isolation by tools/pkmul_coexec_test.hip; the library is built without packed fp32
+  // instructions since, build.py.  Two chained sets are deterministic too: tools/h3_repro.sh variant C; profiles/r04_h3_rootcause.md.)
   template <int S>
   __device__ __forceinline__ void consume(const _Float16* __restrict__ ah_p, const _Float16* __restrict__ al_p, f32x4 (&acc)[2],
                                           f32x4 (&accx)[2], f32x4 (&accy)[2]) {
@@ -541,7 +564,11 @@ struct PipeH3 {
       const fbh8 wh = fb_as_h8(b[S][2 * t]), wl = fb_as_h8(b[S][2 * t + 1]);
       acc[t] = fb_mfma_h(ah, wh, acc[t]);
       accx[t] = fb_mfma_h(ah, wl, accx[t]);
+#if H3_ACC2
+      accx[t] = fb_mfma_h(al, wh, accx[t]);  // repro build: the cross terms chained on one accumulator set
+#else
       accy[t] = fb_mfma_h(al, wh, accy[t]);
+#endif
     }
   }
   // Ah / Al: the two planes of the A tile, row stride ldh halves, zero beyond the real contraction length up to nks * 32
@@ -676,6 +703,12 @@ extern "C" int ultr_trace_read(unsigned long long* host_out) {
   } while (0)
 #endif
 
+#if H3_DBG_DUMP  // REPRO BUILDS ONLY (tools/dbg_bwd_h3.py): what dnn_bwd2_kernel's layer-1 row pass read from DU, and the scales its epilogue read
+__device__ float g_ultr_dbg[1 << 21];
+#define DBG_OS_OFF 700000
+#define DBG_EPI_OFF (1 << 20)
+extern "C" int ultr_dbg_read(float* host_out) { return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ultr_dbg), sizeof(float) * (1 << 21)); }
+#endif
 // ------------------------------------------------------------------------------------------------
 // Forward
 // ------------------------------------------------------------------------------------------------
@@ -1576,7 +1609,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
   const bool h3on = (RT == 1) && p.bwd_h3 != 0 && wt != nullptr;  // dgrad products on the split-half copies where a layer has one (DnnPlan::h3b)
   const int ldz = bwd_ldz_of(p.maxdim, h3on ? 1 : 0), ldu = bwd_ldu(p.maxdim);
   const int ldh = round_up(p.maxdim, 32) + 8;    // row stride (halves) of the two fp16 planes that then live in DZ
-  __shared__ float sm_os[16];                    // their per-row output scales
+  __shared__ __attribute__((aligned(16))) float sm_os[32];  // their per-row output scales ([16]; the second half only in the H3_OS_DB repro build)
   float* DU = smem;                    // [R][ldu]
   float* XS = DU + R * ldu;            // [R][ldu]  input of LayerNorm_j (rows written and read by their owner wave only)
   float* DZ = XS + R * ldu;            // [R][ldz]
@@ -1811,10 +1844,46 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
             for (int t = 0; t < 2; ++t) acc[0][t] = accx[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
             ph.run(AH, AL, ldh, Wh, nks, acc[0], accx, lane);
             if ((ch + NW) * 32 < K) ph.begin(Wh, ch + NW, nks, true, lane);
+#if BWD_H3_EPI
+            // repro build (tools/h3_repro.sh): round 3's first epilogue - scale by sm_os here, every wave reads all 16 scales
+#if H3_EPI_NOP
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+#if H3_EPI_BAR
+            lds_barrier();
+#endif
+#if H3_DBG_DUMP
+            if (j == 1 && (lane & 15) == 0 && ch == wave) {
+              const float4 o4d = ld4(sm_os + 4 * (lane >> 4));
+              float* dd = g_ultr_dbg + DBG_OS_OFF + ((int64_t)blockIdx.x * 8 + wave) * 16 + 4 * (lane >> 4);
+              dd[0] = o4d.x; dd[1] = o4d.y; dd[2] = o4d.z; dd[3] = o4d.w;
+            }
+#endif
+#if H3_EPI_OS_SCALAR
+            {
+              const volatile float* vos = sm_os + H3_OS_DB * 16 * (j & 1) + 4 * (lane >> 4);
+              const float o[4] = {vos[0], vos[1], vos[2], vos[3]};
+#pragma unroll
+              for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[0][t][r] = (acc[0][t][r] + accx[t][r]) * o[r];
+            }
+#else
+            fb_h3_finish(acc, accx, sm_os + H3_OS_DB * 16 * (j & 1), lane);
+#endif
+#else
             // raw sums: the row pass below applies the per-row scale when it reads DU (its rows are the wave's own)
 #pragma unroll
             for (int t = 0; t < 2; ++t) acc[0][t] += accx[t];
+#endif
             store_nn<RT, 2>(acc, DU, ldu, K, ch * 32, lane, false);
+#if H3_DBG_DUMP >= 2
+            if (j == 1 && ch == wave) {  // the epilogue's results straight from the registers
+              float* dd = g_ultr_dbg + DBG_EPI_OFF + (((int64_t)blockIdx.x * 8 + wave) * 64 + lane) * 8;
+              st4(dd, make_float4(acc[0][0][0], acc[0][0][1], acc[0][0][2], acc[0][0][3]));
+              st4(dd + 4, make_float4(acc[0][1][0], acc[0][1][1], acc[0][1][2], acc[0][1][3]));
+            }
+#endif
           }
           sw_done = true;
         } else if (BWD_SW && wt != nullptr && p.sw_ok && j >= 1 && K >= 32 * NW) {
@@ -1887,14 +1956,14 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
       const float invK = 1.0f / (float)K;
       float mean[RPW], rstd[RPW], dsr[RPW], dus[RPW];
       // du_j came out of the split-half product unscaled: its rows still carry the row scale of the dz planes
-      const bool du_scaled = h3on && !last && j >= 1 && p.h3b[j] != 0;
+      const bool du_scaled = !BWD_H3_EPI && h3on && !last && j >= 1 && p.h3b[j] != 0;
 #pragma unroll
       for (int k = 0; k < RPW; ++k) {
         const int r = wave + NW * k;
         mean[k] = sm_mean2[par * R + r];
         rstd[k] = sm_rstd2[par * R + r];
         dsr[k] = sm_ds[r];
-        dus[k] = du_scaled ? sm_os[r & 15] : 1.0f;
+        dus[k] = du_scaled ? sm_os[H3_OS_DB * 16 * (j & 1) + (r & 15)] : 1.0f;
       }
       float4 xk[RPW][XC], gxk[RPW][XC];
       float red[2 * RPW];
@@ -1918,6 +1987,9 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
           else {
             du4 = act ? ld4(DU + r * ldu + c) : z4;
             du4.x *= dus[k]; du4.y *= dus[k]; du4.z *= dus[k]; du4.w *= dus[k];
+#if H3_DBG_DUMP
+            if (j == 1 && act && n0 + r < N) st4(g_ultr_dbg + (n0 + r) * K + c, du4);
+#endif
           }
           const float4 xh = make_float4((x4.x - mean[k]) * rstd[k], (x4.y - mean[k]) * rstd[k],
                                         (x4.z - mean[k]) * rstd[k], (x4.w - mean[k]) * rstd[k]);
@@ -1995,7 +2067,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
                   *reinterpret_cast<fbh4*>(AL + r * ldh + c) = lo;
                 }
               }
-              if (lane == 0) sm_os[r] = inv * (1.0f / ULTR_H3_WSCALE);
+              if (lane == 0) sm_os[H3_OS_DB * 16 * ((j - 1) & 1) + r] = inv * (1.0f / ULTR_H3_WSCALE);
             }
           }
         }
@@ -3524,8 +3596,8 @@ __global__ __launch_bounds__(256) void wt_build_kernel(DnnPlan p, const float* _
       }
       if (p.h3f[j] || p.h3b[j]) {
         const float sv = v * ULTR_H3_WSCALE;
-        if (!(fabsf(sv) < ULTR_H3_WMAX))
-          __hip_atomic_store(reinterpret_cast<uint32_t*>(wt + p.h3_flag_off), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!(fabsf(sv) < ULTR_H3_WNEAR))
+          flag_or(reinterpret_cast<uint32_t*>(wt + p.h3_flag_off), !(fabsf(sv) < ULTR_H3_WMAX) ? (ULTR_H3_FLAG_OVER | ULTR_H3_FLAG_NEAR) : ULTR_H3_FLAG_NEAR);
         const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
         if (p.h3f[j]) {
           _Float16* hf = reinterpret_cast<_Float16*>(wt + p.whf_off[j]);
@@ -3553,6 +3625,17 @@ extern "C" int ultr_dnn_build_wt(const ultr_dnn_desc* d, const float* params, fl
   }
   hipLaunchKernelGGL(wt_build_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, params, wt);
   return (int)hipGetLastError();
+}
+
+extern "C" int ultr_dnn_wt_range(const ultr_dnn_desc* d, const float* wt, void* stream) {
+  DnnPlan p;
+  if (!wt || !ultr_make_dnn_plan(d, 0, &p)) return ULTR_E_BADARG;
+  if (p.h3_flag_off <= 0) return 0;  // this model has no split-half copies
+  uint32_t f = 0;
+  hipError_t e = hipMemcpyAsync(&f, wt + p.h3_flag_off, sizeof(f), hipMemcpyDeviceToHost, (hipStream_t)stream);
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  if (e != hipSuccess) return -(int)e - 100;
+  return (f & ULTR_H3_FLAG_OVER) ? 2 : ((f & ULTR_H3_FLAG_NEAR) ? 1 : 0);
 }
 
 // Which shapes take the per-layer path (ultr_dnn_big.hip) instead of the row-tile kernels below; mode = the knob (0 never,

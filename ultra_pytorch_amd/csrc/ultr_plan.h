@@ -56,7 +56,7 @@ struct DnnPlan {
   int h3f[ULTR_MAXL], h3b[ULTR_MAXL];
   int fb_h3;              // the fused kernel takes the split-half build (h3_ok and the ULTR_FB_H3 knob)
   int bwd_h3;             // dnn_bwd2_kernel runs at least one dgrad product on them (changes the row stride of its dz tile)
-  int64_t h3_flag_off;    // one word behind the copies: != 0 once a weight left the copies' range (|w| x 2^8 >= 2^15): status ULTR_STATUS_H3_RANGE
+  int64_t h3_flag_off;    // one word behind the copies: ULTR_H3_FLAG_OVER | ULTR_H3_FLAG_NEAR (status ULTR_STATUS_H3_RANGE / _NEAR)
   int fwd_h3;             // dnn_fwd_kernel runs at least one layer on the split-half copies (changes its LDS row stride)
   int maxdim;             // max over all K_j (and M_j)
   // work map of the update kernel when it maintains the copies above: 16x16 tiles over every hidden W_j (a tile is
@@ -99,6 +99,11 @@ __host__ __device__ inline int64_t ultr_sw_index(int c, int k, int ntrips) {
 // fragment matrix with `nks` = ceil(Kc / 32) steps per chunk
 #define ULTR_H3_WSCALE 256.0f  // weights are stored x 2^8: |w| up to 255, lo parts of typical weights stay normal fp16 numbers
 #define ULTR_H3_WMAX 32768.0f  // scaled weights must stay below this (fp16 overflows at 65504): |w| < 128, else ULTR_STATUS_H3_RANGE
+#define ULTR_H3_WNEAR 16384.0f // |w| >= 64: half of the range is used up - ULTR_STATUS_H3_NEAR, the host switches to the fp32 products
+                               // while the copies are still exact (an optimizer step moves a weight by at most lr x the clip norm)
+// the flag word behind the copies (DnnPlan::h3_flag_off): bit 0 = a copy overflowed, bit 1 = a weight is near the edge
+#define ULTR_H3_FLAG_OVER 1u
+#define ULTR_H3_FLAG_NEAR 2u
 __host__ __device__ inline int64_t ultr_h3_index(int c, int k, int nks, int hl) {
   const int chunk = c >> 5, t = c & 1, j = (c & 31) >> 1;  // the two column tiles of a chunk interleave: column 32 chunk + 2 j + t
   const int s = k >> 5, q = (k & 31) >> 3, e = k & 7;      // (the accumulator layout the epilogues of the fp32 paths expect)

@@ -232,7 +232,10 @@ __device__ __forceinline__ void update_body(const ultr_update_desc& u, const Dnn
     // a weight outside the range of the split-half copies (DnnPlan::h3_flag_off: raised by the build kernel or by an earlier
     // update launch - this launch's own tiles report with the next step): the host's read of the loss raises
     uint32_t st = 0u;
-    if (h3flag != nullptr && __hip_atomic_load(h3flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) st = ULTR_STATUS_H3_RANGE;
+    if (h3flag != nullptr) {
+      const uint32_t f = __hip_atomic_load(h3flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      st = ((f & ULTR_H3_FLAG_OVER) ? ULTR_STATUS_H3_RANGE : 0u) | ((f & ULTR_H3_FLAG_NEAR) ? ULTR_STATUS_H3_NEAR : 0u);
+    }
     host_report(u, v, st);
   }
 }
@@ -353,15 +356,16 @@ __global__ __launch_bounds__(256) void update_tiled_kernel(ultr_update_desc u, D
           const int col = 2 * jj + tt;  // output column inside the tile
           typedef _Float16 h8v __attribute__((ext_vector_type(8)));
           h8v piece;
-          bool big = false;
+          float wmax = 0.f;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const float w = (fwd ? tile[q][col][8 * qq + e] : tile[q][8 * qq + e][col]) * ULTR_H3_WSCALE;
             const _Float16 hi = (_Float16)w;
             piece[e] = hl ? (_Float16)(w - (float)hi) : hi;
-            big = big || !(fabsf(w) < ULTR_H3_WMAX);
+            wmax = fmaxf(wmax, !(fabsf(w) < ULTR_H3_WMAX) ? ULTR_H3_WMAX : fabsf(w));  // (NaN counts as out of range)
           }
-          if (big) __hip_atomic_store(reinterpret_cast<uint32_t*>(wt + dp.h3_flag_off), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (wmax >= ULTR_H3_WNEAR)
+            flag_or(reinterpret_cast<uint32_t*>(wt + dp.h3_flag_off), wmax >= ULTR_H3_WMAX ? (ULTR_H3_FLAG_OVER | ULTR_H3_FLAG_NEAR) : ULTR_H3_FLAG_NEAR);
           const int64_t pos = ((((int64_t)(c0 >> 5) * nks + (z0 >> 5)) * 4 + (2 * tt + hl)) * 64 +
                                ((((z0 & 31) >> 3) + qq) * 16 + ((c0 & 31) >> 1) + jj)) * 8;
           _Float16* dst = reinterpret_cast<_Float16*>(wt + (fwd ? dp.whf_off[j] : dp.whb_off[j]));

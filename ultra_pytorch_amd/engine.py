@@ -179,23 +179,36 @@ class StepEngine:
         self._raise_on_status(int(u[8]))
         return self._hs_f[:8].copy()
 
-    H3_RANGE = 0x100  # include/ultr_hip.h: ULTR_STATUS_H3_RANGE
+    H3_RANGE, H3_NEAR = 0x100, 0x200  # include/ultr_hip.h: ULTR_STATUS_H3_RANGE / ULTR_STATUS_H3_NEAR
 
-    @classmethod
-    def _raise_on_status(cls, st):
+    def _raise_on_status(self, st):
+        """Act on the status word of the latest full step report (host_scalars[8])."""
         if st == 0:
             return
-        if st & cls.H3_RANGE:
-            raise _lib.UltrHipError("a hidden weight reached |w| >= 128, outside the range of the split-half (fp16 hi / lo) weight copies "
-                                    "(ULTR_STATUS_H3_RANGE): results are not to be trusted from here on - run with ULTR_FB_H3=0 "
-                                    "ULTR_FWD_H3=0 ULTR_BWD_H3=0 (fp32 matrix-core products)")
+        if st & (self.H3_RANGE | self.H3_NEAR):
+            # a hidden weight is near (>= 64) or beyond (>= 128) the range of the split-half weight copies.  Near: every copy is
+            # still exact and one optimizer step moves a weight by at most lr x the clip norm - switch to the fp32 products now
+            # and go on, as the reference would (base_algorithm.py:208-226 trains any weight magnitude).  Beyond, with the
+            # split-half products still on: some step already read an overflowed copy.
+            switched = hip_ops.fall_back_to_fp32_products(self.shape.lib, "a hidden weight reached |w| >= 64 during training (the "
+                                                          "split-half weight copies cover |w| < 128)")
+            if (st & self.H3_RANGE) and switched:
+                raise _lib.UltrHipError("a hidden weight jumped to |w| >= 128 within the steps between two reads of the step report, "
+                                        "outside the range of the split-half (fp16 hi / lo) weight copies (ULTR_STATUS_H3_RANGE): the "
+                                        "last steps are not to be trusted - restart from the last checkpoint (the fp32 matrix-core "
+                                        "products are selected now: ULTR_FB_H3=0 ULTR_FWD_H3=0 ULTR_BWD_H3=0)")
+            st &= ~(self.H3_RANGE | self.H3_NEAR)
+            if st == 0:
+                return
         raise _lib.UltrHipError("data-parallel gradient exchange timed out on some rank (ULTR_E_COMM_TIMEOUT): this and all "
                                 "later updates were NOT applied - restart from the last checkpoint")
 
     def read_loss(self, timeout_s=60.0):
         """The loss of the last queued step (the reference's `loss.item()`).  Returns as soon as the loss is FINAL: on one GPU
         that is behind forward + loss (the weight-gradient launch reports it, include/ultr_hip.h: host_scalars[10]), while the
-        step's reduction and update are still running - later work simply queues behind them on the stream."""
+        step's reduction and update are still running - later work simply queues behind them on the stream.  The status word
+        of the LATEST full report is examined on every call (it is one or two launches older than the loss: a failure -
+        exchange timeout, split-half range - surfaces one step late at most; both conditions are sticky on the device)."""
         if not self._host_report:
             return float(self.read_scalars()[0])
         seq, u, spins, t0 = self._seq, self._hs_u, 0, None
@@ -208,8 +221,7 @@ class StepEngine:
                 t0 = now if t0 is None else t0
                 if now - t0 > timeout_s:
                     raise _lib.UltrHipError("no loss report from the GPU within %.0f s (step %d)" % (timeout_s, seq))
-        if int(u[9]) == seq:  # the full report is in as well: it may carry a failure
-            self._raise_on_status(int(u[8]))
+        self._raise_on_status(int(u[8]))
         return float(self._hs_f[0])
 
     def close(self):

@@ -5,6 +5,7 @@ HIP stream to libultr_hip.so and returns immediately (asynchronous w.r.t. the ho
 """
 import ctypes
 import os
+import warnings
 import weakref
 
 import torch
@@ -140,6 +141,27 @@ def loss_part_count(B):
     return int(_lib.load().ultr_loss_part_count(int(B)))
 
 
+H3_KNOBS = ("ULTR_FB_H3", "ULTR_FWD_H3", "ULTR_BWD_H3")
+
+
+def split_half_enabled():
+    return any(os.environ.get(k, "1") != "0" for k in H3_KNOBS)
+
+
+def fall_back_to_fp32_products(lib, why):
+    """Switch the wide layers' products from the split-half (fp16 hi / lo) copies to the fp32 matrix-core path for the rest of the
+    process (the knobs are process-wide) and say so once.  The reference computes in fp32 at any weight magnitude
+    (DNN.py:58-88, base_algorithm.py:208-226); the copies cover |w| < 128 only."""
+    if not split_half_enabled():
+        return False
+    for k in H3_KNOBS:
+        os.environ[k] = "0"
+    lib.ultr_config_reload()
+    warnings.warn("ultra_pytorch_amd: %s - the products of wide layers now run on the fp32 matrix cores (ULTR_FB_H3=0 ULTR_FWD_H3=0 "
+                  "ULTR_BWD_H3=0): same results to the 1e-5 parity bar, ~6 %% slower steps" % why, RuntimeWarning, stacklevel=3)
+    return True
+
+
 class WeightCopy:
     """The k-major copy of the hidden Linear weights the fast forward reads (ultr_dnn_build_wt).  Rebuilt whenever
     torch reports an in-place modification of `params` (load_state_dict, .copy_, init); ultr_apply_update keeps it
@@ -176,6 +198,16 @@ class WeightCopy:
             check(self.shape.lib.ultr_dnn_build_wt(ctypes.byref(self.shape.desc), _p(params), _p(self.wt), _stream()),
                   "ultr_dnn_build_wt")
             self.key, self.ref = key, weakref.ref(params)
+            # parameters that arrived from outside (checkpoint, init, a test) may be out of the split-half copies' range: look
+            # once (a stream synchronisation - this branch runs after external writes only) and switch to the fp32 products
+            # BEFORE a kernel reads the copies; training drift is caught by the step report instead (engine.StepEngine)
+            if split_half_enabled():
+                rng = int(self.shape.lib.ultr_dnn_wt_range(ctypes.byref(self.shape.desc), _p(self.wt), _stream()))
+                if rng < 0:
+                    check(rng, "ultr_dnn_wt_range")
+                if rng > 0:
+                    fall_back_to_fp32_products(self.shape.lib, "a hidden weight of magnitude >= 64 was loaded (the split-half weight "
+                                               "copies cover |w| < 128)")
         elif self.check:
             self._verify(params)
         return self.wt
