@@ -683,6 +683,55 @@ def err(labels: torch.Tensor, predictions: torch.Tensor, topn: Sequence[int], ma
     return torch.mean(torch.stack(outs, dim=0), dim=1).view(-1)
 
 
+def mean_average_precision(labels: torch.Tensor, predictions: torch.Tensor, topn: Sequence[int]) -> torch.Tensor:
+    """mean_average_precision (metrics.py:408-453), weights = 1: loops over lists and ranks (small cases only)."""
+    labels, predictions, topn = _prepare(labels, predictions, topn)
+    _, idx = predictions.sort(descending=True, dim=-1)
+    sl = torch.gather(labels, 1, idx).numpy()
+    vals = []
+    for row in sl:
+        hits, acc = 0, 0.0
+        for r, l in enumerate(row):
+            if l >= 1.0:
+                hits += 1
+                acc += np.float32(hits) / np.float32(r + 1)
+        vals.append(acc / hits if hits else 0.0)
+    return torch.tensor(np.mean(np.asarray(vals, np.float32)), dtype=torch.float32).repeat(len(topn))
+
+
+def ordered_pair_accuracy(labels: torch.Tensor, predictions: torch.Tensor, topn: Sequence[int]) -> torch.Tensor:
+    """ordered_pair_accuracy (metrics.py:531-568), weights = 1: correctly ordered valid pairs / (B * L * L)."""
+    clean, predictions, topn = _prepare(labels, predictions, topn)
+    y, c, s = labels.numpy(), clean.numpy(), predictions.numpy()
+    B, L = s.shape
+    n = 0
+    for b in range(B):
+        for i in range(L):
+            for j in range(L):
+                if y[b, i] == c[b, i] and y[b, j] == c[b, j] and c[b, i] > c[b, j] and s[b, i] > s[b, j]:
+                    n += 1
+    return torch.tensor(n / float(B * L * L), dtype=torch.float32).repeat(len(topn))
+
+
+def average_relevance_position(labels: torch.Tensor, predictions: torch.Tensor, topn: Sequence[int]) -> torch.Tensor:
+    """average_relevance_position (metrics.py:338-370), weights = 1 (topn only sets the length of the result)."""
+    labels, predictions, topn = _prepare(labels, predictions, topn)
+    _, idx = predictions.sort(descending=True, dim=-1)
+    sl = torch.gather(labels, 1, idx)
+    pos = torch.arange(1, sl.shape[1] + 1, dtype=torch.float)
+    return torch.mean(_safe_div(torch.sum(pos * sl, 1, keepdim=True), torch.sum(sl, 1, keepdim=True))).repeat(len(topn))
+
+
+def precision_whole_list(labels: torch.Tensor, predictions: torch.Tensor) -> torch.Tensor:
+    """precision (metrics.py:373-405), weights = 1: ONE scalar - the share of relevant documents in the whole list, 0 for lists
+    without one, batch mean (topn is not applied by the reference)."""
+    labels, predictions, _ = _prepare(labels, predictions, [1])
+    rel = torch.ge(labels, 1.0).float()
+    per_list = torch.sum(rel, 1, keepdim=True) / float(rel.shape[1])
+    has = _safe_div(torch.sum(rel, 1, keepdim=True), torch.sum(rel, 1, keepdim=True))
+    return torch.mean(per_list * has)
+
+
 def validation(params, F_, hidden, features, docids, labels_LB, topn=(1, 3, 5, 10), max_label=4.0, act="elu"):
     """*.validation (ipw_rank.py:184-211): returns UNMASKED scores + metrics on masked scores (Appendix A.10)."""
     with torch.no_grad():

@@ -484,7 +484,33 @@ def run_driver_case(ultra, name, seed=0):
     print("wrote", name, "steps", len(rec["losses"]), "checkpoints at", [s for s, _ in rec["saves"]], history)
 
 
+def run_metrics_case(ultra, name, seed=61):
+    """Every host metric the reference's factory registers (metrics.py:36-153), evaluated BY THE REFERENCE on seeded scores /
+    labels - two shapes, labels with invalid (-1) entries and PAD-masked scores, ties, an all-irrelevant list."""
+    from ultra.utils import metrics as RM
+    RM.RankingMetricKey.MAX_LABEL = 4.0
+    rng = np.random.RandomState(seed)
+    out = {"meta": json.dumps({"topn": [1, 3, 5, 10], "max_label": 4.0, "keys": ["ndcg", "mrr", "err", "precision", "arp", "map", "ordered_pair_accuracy"],
+                               "note": "dcg raises in the reference (gather on weights=None, metrics.py:191-221 called without "
+                                       "weights at :519-523); precision returns ONE scalar whatever topn is (metrics.py:373-405)"})}
+    for tag, (B, L) in (("a", (9, 12)), ("b", (5, 7))):
+        y = rng.randint(0, 5, size=(B, L)).astype(np.float32)
+        s = rng.normal(size=(B, L)).astype(np.float32)
+        y[1, :] = 0.0                      # a list without a relevant document
+        s[2, 3] = s[2, 4]                  # a tie
+        y[3, -2:] = -1.0                   # invalid labels (metrics.py:251-264)
+        s[4, -3:] = -100000.0              # PAD-masked scores (base_algorithm.py:88-116)
+        y[4, -3:] = 0.0
+        out[tag + "_labels"], out[tag + "_scores"] = y, s
+        for key in ("ndcg", "mrr", "err", "precision", "arp", "map", "ordered_pair_accuracy"):
+            fn = RM.make_ranking_metric_fn(key, [1, 3, 5, 10])
+            out["%s_%s" % (tag, key)] = np.asarray(fn(torch.from_numpy(y), torch.from_numpy(s), None).detach().cpu().numpy(), np.float64).reshape(-1)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, {k: v for k, v in out.items() if k.startswith("a_") and not k.endswith(("labels", "scores"))})
+
+
 CASES = {
+    "metrics_host": lambda u: run_metrics_case(u, "metrics_host"),
     "feeds_toy": lambda u: run_feed_case(u, "feeds_toy"),
     # the driver itself (main.py) on the toy dataset: losses, checkpoint schedule, printed metrics, saved tensors
     "driver_toy": lambda u: run_driver_case(u, "driver_toy"),

@@ -179,3 +179,27 @@ def test_softmax_closed_form():
     l2, g2, D = O.softmax_loss_closed_form(d["s0_scores"], d["s0_labels"].T, d["s0_pw"])
     assert abs(l2 - float(loss.detach())) < 1e-6
     np.testing.assert_allclose(g2, g.numpy(), atol=1e-7)
+
+
+def test_host_metrics_against_the_reference():
+    """Every metric key the reference's factory serves with weights=None (metrics.py:36-153), as the REFERENCE evaluated it
+    (tests/golden/metrics_host.npz: two shapes, invalid labels, PAD-masked scores, a tie, an all-irrelevant list): the oracle's
+    restatements and the product's host metrics must both reproduce them."""
+    import json
+    from oracle import ultr_oracle as O
+    from ultra_pytorch_amd.utils import metrics as M
+    d = np.load(os.path.join(GOLDEN, "metrics_host.npz"))
+    meta = json.loads(str(d["meta"]))
+    topn = meta["topn"]
+    M.RankingMetricKey.MAX_LABEL = meta["max_label"]
+    for tag in ("a", "b"):
+        y, s = torch.from_numpy(d[tag + "_labels"]), torch.from_numpy(d[tag + "_scores"])
+        oracle = {"ndcg": O.ndcg(y, s, topn), "mrr": O.mrr(y, s, topn), "err": O.err(y, s, topn, meta["max_label"]),
+                  "arp": O.average_relevance_position(y, s, topn), "map": O.mean_average_precision(y, s, topn),
+                  "ordered_pair_accuracy": O.ordered_pair_accuracy(y, s, topn), "precision": O.precision_whole_list(y, s)}
+        for key in meta["keys"]:
+            ref = d["%s_%s" % (tag, key)]
+            np.testing.assert_allclose(np.asarray(oracle[key]).reshape(-1), ref, atol=1e-6, err_msg="oracle " + key)
+            got = np.asarray(M.make_ranking_metric_fn(key, topn)(y, s, None)).reshape(-1)
+            assert got.shape == (len(topn),), key  # what validation() zips with metrics_topn
+            np.testing.assert_allclose(got, np.broadcast_to(ref, got.shape), atol=1e-6, err_msg="product " + key)

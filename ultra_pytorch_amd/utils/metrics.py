@@ -1,8 +1,12 @@
 """Host-side ranking metrics with the reference's factory interface (ultra/utils/metrics.py:36-153).
 
 NDCG on the validation path runs as a HIP kernel (ultr_ndcg); the other metrics that appear in the example
-settings (mrr, err, dcg, precision, arp) are evaluated here on host tensors — SURVEY.md §8 a13 marks them
-"host restatement suffices".  weights=None semantics only (what every validation() call passes).
+settings (mrr, err) and the rest of the reference's factory table (arp, precision, map, ordered_pair_accuracy, dcg) are
+evaluated here on host tensors — SURVEY.md §8 a13 marks them "host restatement suffices".  weights=None semantics only
+(what every validation() call passes).  Pinned to the reference's own outputs: tests/golden/metrics_host.npz.
+Two places where this module is usable and the reference is not: `dcg` (the reference's raises: it gathers a `weights` of None,
+metrics.py:519-523 -> :191-221) and `precision` (the reference returns ONE scalar whatever topn is, metrics.py:373-405, which
+validation()'s zip over metrics_topn cannot iterate; here the same value is repeated per cut-off).
 """
 import numpy as np
 import torch
@@ -10,6 +14,7 @@ import torch
 
 class RankingMetricKey(object):
     MRR, ERR, ARP, NDCG, DCG, PRECISION = "mrr", "err", "arp", "ndcg", "dcg", "precision"
+    MAP, ORDERED_PAIR_ACCURACY = "map", "ordered_pair_accuracy"  # metrics.py:56, 59
     MAX_LABEL = None  # set by the data loader from settings.json (data_utils.py:96)
 
 
@@ -70,23 +75,51 @@ def expected_reciprocal_rank(labels, predictions, weights=None, topn=None, name=
     return torch.stack(out)
 
 
+def _per_list_relevance_weight(labels):
+    """_per_example_weights_to_per_list_weights with unit weights (metrics.py:173-188): 1 for a list with a relevant document, else 0."""
+    rel = torch.ge(labels, 1.0).float()
+    return _safe_div(torch.sum(rel, 1, keepdim=True), torch.sum(rel, 1, keepdim=True))
+
+
 def precision(labels, predictions, weights=None, topn=None, name=None):
+    """metrics.py:373-405: the share of relevant documents in the WHOLE list (topn is not applied there), zero for lists
+    without one; a batch mean - repeated per cut-off here (module docstring)."""
     labels, predictions, topn = _prepare(labels, predictions, topn)
     rel = torch.ge(_sorted_labels(labels, predictions), 1.0).float()
-    return torch.stack([torch.mean(torch.sum(rel[:, :n], dim=1) / float(n)) for n in topn])
+    per_list = torch.sum(rel, 1, keepdim=True) / float(rel.shape[1])
+    return torch.mean(per_list * _per_list_relevance_weight(labels)).repeat(len(topn))
 
 
 def average_relevance_position(labels, predictions, weights=None, topn=None, name=None):
+    """metrics.py:338-370: mean over lists of sum(position x label) / sum(label) over the whole ranked list (0 for a list of
+    zeros); topn only sets the length of the (repeated) result."""
     labels, predictions, topn = _prepare(labels, predictions, topn)
     sl = _sorted_labels(labels, predictions).float()
-    L = sl.shape[-1]
-    pos = torch.arange(1, L + 1, dtype=torch.float32)
-    out = []
-    for n in topn:
-        m = (pos <= n).float()
-        out.append(torch.sum(_safe_div(torch.sum(pos * sl * m, 1), torch.sum(sl * m, 1)) * torch.sum(sl * m, 1)) /
-                   torch.clamp(torch.sum(sl * m), min=1e-12))
-    return torch.stack(out)
+    pos = torch.arange(1, sl.shape[-1] + 1, dtype=torch.float32)
+    per_list = _safe_div(torch.sum(pos * sl, dim=1, keepdim=True), torch.sum(sl, dim=1, keepdim=True))
+    return torch.mean(per_list).repeat(len(topn))
+
+
+def mean_average_precision(labels, predictions, weights=None, topn=None, name=None):
+    """metrics.py:408-453: per list, the mean over its relevant documents (label >= 1) of precision-at-their-rank; lists without a
+    relevant document count as 0; batch mean, repeated per cut-off."""
+    labels, predictions, topn = _prepare(labels, predictions, topn)
+    rel = torch.ge(_sorted_labels(labels, predictions), 1.0).float()
+    prec_at = torch.cumsum(rel, dim=1) / torch.arange(1, rel.shape[1] + 1, dtype=torch.float32)
+    per_list = torch.nan_to_num(torch.sum(prec_at * rel, 1, keepdim=True) / torch.sum(rel, 1, keepdim=True))
+    return torch.mean(per_list * _per_list_relevance_weight(labels)).repeat(len(topn))
+
+
+def ordered_pair_accuracy(labels, predictions, weights=None, topn=None, name=None):
+    """metrics.py:531-568: pairs (i, j) of valid documents with label_i > label_j AND score_i > score_j, as a MEAN OVER ALL
+    batch x L x L ordered pairs (not over the pairs that differ in label - the reference's normalisation); repeated per cut-off."""
+    clean, predictions, topn = _prepare(labels, predictions, topn)
+    valid = torch.eq(clean, labels)
+    vp = (valid.unsqueeze(2) & valid.unsqueeze(1)).float()
+    dl = clean.unsqueeze(2) - clean.unsqueeze(1)
+    dp = predictions.unsqueeze(2) - predictions.unsqueeze(1)
+    gt = torch.gt(dl, 0).float()
+    return torch.mean(gt * torch.gt(dp, 0).float() * gt * vp).repeat(len(topn))
 
 
 def make_ranking_metric_fn(metric_key, topn=None, name=None):
@@ -98,6 +131,8 @@ def make_ranking_metric_fn(metric_key, topn=None, name=None):
         RankingMetricKey.ERR: expected_reciprocal_rank,
         RankingMetricKey.PRECISION: precision,
         RankingMetricKey.ARP: average_relevance_position,
+        RankingMetricKey.MAP: mean_average_precision,
+        RankingMetricKey.ORDERED_PAIR_ACCURACY: ordered_pair_accuracy,
     }
     assert metric_key in table, "metric_key %s not supported." % metric_key
     fn = table[metric_key]
