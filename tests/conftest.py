@@ -47,3 +47,17 @@ def mfma_mode(request, monkeypatch):
         _lib.load().ultr_config_reload()
     except Exception:
         pass
+
+
+@pytest.fixture(params=["slabs", "direct"])
+def wgrad_path(request, monkeypatch):
+    """The two weight-gradient paths behind the fused small-batch kernel: 64 x 64 tiles x row splits + a reduction launch (the
+    default) and the direct one-launch kernel of ultr_wgd.hip (ULTR_WGD=1; not faster at config 2, kept under test)."""
+    monkeypatch.setenv("ULTR_WGD", "1" if request.param == "direct" else "0")
+    yield request.param
+    monkeypatch.undo()
+    try:
+        from ultra_pytorch_amd import _lib
+        _lib.load().ultr_config_reload()
+    except Exception:
+        pass

@@ -181,7 +181,7 @@ def test_host_mapped_step_report_equals_device_scalars():
                                           (136, [128], 16, 16),         # one hidden layer, full 16-row tiles
                                           (32, [96, 64], 12, 5),        # three lists per 16-row tile
                                           (20, [48, 24], 9, 3)])        # widths not multiples of 32: no fragment-major copies
-def test_fused_step_shapes_match_oracle(F, hidden, B, L, mfma_mode):
+def test_fused_step_shapes_match_oracle(F, hidden, B, L, mfma_mode, wgrad_path):
     """The small-batch NA / IPW step (ONE fused forward + loss + backward launch, dnn_fb_kernel) through ultr_train_step at
     shapes that reach every path of the kernel - fragment-major and k-major weight streaming, one / two column chunks per
     lane, 1 - 5 lists per tile - against the oracle: scores, loss, gradient, norm, updated parameters."""

@@ -3185,7 +3185,7 @@ __global__ __launch_bounds__(64) void grad_sumsq_kernel(int64_t P, const float* 
 // per knob per launch is host time on the critical path of a ~50 us step.  ultr_config_reload() re-reads them (tests and
 // the A/B tools flip knobs inside one process).
 struct Knobs {
-  int fwd_r, bwd_r, wgrad_wgs, fwd_nw, bwd_nw, no_vec, no_l0g, bwd_v1, no_fused_fb, fb_max_wg_per_cu, fwd_q4, big_fwd, big_bwd, fb_h3, fwd_h3, bwd_h3;
+  int fwd_r, bwd_r, wgrad_wgs, fwd_nw, bwd_nw, no_vec, no_l0g, bwd_v1, no_fused_fb, fb_max_wg_per_cu, fwd_q4, big_fwd, big_bwd, fb_h3, fwd_h3, bwd_h3, wgd, wgd_max_rows;
   bool loaded;
 };
 static Knobs g_knobs = {};
@@ -3213,6 +3213,11 @@ static void knobs_load() {
   k.fb_h3 = env_read("ULTR_FB_H3", 1);
   k.fwd_h3 = env_read("ULTR_FWD_H3", 1);
   k.bwd_h3 = env_read("ULTR_BWD_H3", 1);
+  // direct weight gradients (ultr_wgd.hip: final gradients from ONE launch, no slabs, no reduction launch) behind the fused
+  // small-batch kernel, for batches of at most this many rows.  OFF by default: measured at config 2 it ties with the slab path
+  // (17.7 us against 12.3 + 5.0 us + one launch gap; step 50.2 against 48.4 us - profiles/r04_cfg2_attempts.md)
+  k.wgd = env_read("ULTR_WGD", 0);
+  k.wgd_max_rows = env_read("ULTR_WGD_MAX_ROWS", 4096);
   k.loaded = true;
   g_knobs = k;
 }
@@ -3482,6 +3487,10 @@ bool ultr_make_bwd_plan(const DnnPlan& p, int64_t N, BwdPlan* bp) {
   bp->l0g = 0;
   bp->l0part_off = off;
   if (p.nl >= 2) off += ((int64_t)bp->wl[0].nmb * bp->wl[0].nsplit * 2 * p.K[0] + 3) & ~(int64_t)3;
+  {
+    const int64_t nmt0 = (p.M[0] + 15) / 16, nkt0 = (p.K[0] + 31) / 32;
+    bp->wgd_part_off = off; off += nkt0 * nmt0 * 96;
+  }
   bp->total = off;
   return true;
 }
@@ -3828,6 +3837,11 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
     len = len < 1024 ? 1024 : (len + 31) / 32 * 32;
     bp.lf_len = len;
     bp.lf_chunks = (nlp + len - 1) / len;
+  }
+  if (fused_rb > 0 && av && l0g_ok && knobs().wgd != 0 && N <= knobs().wgd_max_rows) {
+    // small batch behind the fused kernel: final gradients from one launch (ultr_wgd.hip)
+    const int rc = ultr_wgd_launch(p, bp, params, (const float*)saved, ws, grads, lp, nlp, tail, (int)ultr_red_blocks(p.P, tail), st);
+    if (rc != ULTR_E_UNSUPPORTED) return rc;
   }
   {
     UltrProfScope prof(ULTR_K_WGRAD, st);

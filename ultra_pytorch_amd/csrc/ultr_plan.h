@@ -161,10 +161,43 @@ struct BwdPlan {
   int64_t l0part_off;       // [nmb_0 * nsplit_0][2][K_0]
   int64_t lfold_off;        // [64][tail <= 4096]: first level of the loss-partial fold when there are more than 1024 partials
   int lf_chunks, lf_len;    // 0: one workgroup folds all; else lf_chunks workgroups x lf_len partials (set by the launcher)
+  int64_t wgd_part_off;     // direct weight gradients (WgdPlan): layer-0 column partials [ceil(K_0 / 32)][ceil(M_0 / 16)][96]
   int64_t sumsq_off;        // [n_red_blocks]
   int n_red_blocks;
   int64_t total;            // floats in bwd_ws
 };
+
+// Direct weight gradients (ultr_wgd.hip): small batches, where one workgroup can afford to contract ALL rows for its output tile.
+// A workgroup owns a 16 (m) x 32 (k) tile of ONE dW_j and sums over every row of the batch, so what it writes is the FINAL
+// gradient - no per-split slabs, no reduction launch (config 2: weight gradients + reduction 11.8 + 4.9 us -> one launch).
+// Consecutive block ids go round-robin to the 8 XCDs; tile (x = block % 8, t = block / 8) is laid out so that the tiles of one
+// XCD form a sub-grid of ONE layer's tile grid (every layer has its own group of gm x gk XCDs): an XCD's L2 then pulls (1 / gm)
+// of dz_j and (1 / gk) of u_j of that layer only.
+struct WgdLayer {
+  int M, K;
+  int nmt, nkt;     // tiles along m (16 wide) and k (32 wide)
+  int gm, gk;       // XCD grid: gm * gk = 8
+  int pm, pk;       // tiles per XCD along m / k (ceil)
+  int x0;           // first XCD of this layer's group (the group has gm * gk XCDs)
+  int pad_;
+  int64_t dz_off;   // dz_j in bwd_ws [N, M]
+  int64_t x_off;    // the ready-made operand in `saved` [N, K]
+  int64_t off_w, off_b;
+};
+struct WgdPlan {
+  int nl1;                 // hidden Linears
+  int tiles_per_xcd;       // max over the layers of pm * pk
+  int ntile_blocks;        // 8 * tiles_per_xcd
+  int nvec_blocks;         // ceil(vlen / 64): the per-row-block vector slabs folded into final gradients
+  int nsq_used;            // sum-of-squares slots this launch writes: tiles | layer-0 gamma / beta folds | vector folds
+  uint32_t seq;            // launch number (never repeats): the arrival flags of the layer-0 fold carry it
+  int64_t l0part_off;      // [nkt_0][nmt_0][24 pieces of (v0, v1, v2, launch number)]: per-tile column partials of d gamma_0 | d beta_0
+  WgdLayer l[ULTR_MAXL];
+};
+// library-internal, ultr_wgd.hip.  Returns ULTR_E_UNSUPPORTED when the shape does not qualify (the caller then runs the slab path).
+struct EarlyReport;
+int ultr_wgd_launch(const DnnPlan& p, const BwdPlan& bp, const float* params, const float* saved, float* ws, float* grads,
+                    const float* loss_part, int n_loss_part, int tail, int nsq, hipStream_t st);
 
 // Everything dnn_fb_kernel needs about layer j of BOTH loops, one 128-byte record per layer (32 ints; 64-bit offsets as lo, hi).
 // The plans travel as kernel arguments in HBM; runtime-indexed reads of them are scalar loads whose first touch of a cache
