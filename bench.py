@@ -113,6 +113,37 @@ def algorithmic_work(cfg, P):
     }
 
 
+PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16 matrix peak (v_mfma_f32_16x16x32_f16)
+L2_STREAM_PEAK_TBS = 8 * 2048 * 2.4e9 / 1e12  # eight XCD-private L2s x 2 KB / clk x 2.4 GHz = 39.3 TB/s (MI355X_MICROARCH.md)
+
+
+def issued_matrix_work(cfg, slot):
+    """What the matrix cores actually ISSUE for kernel slot `slot` under the current knobs (DnnPlan::h3f / h3b rules, ultr_dnn.hip
+    ultr_make_dnn_plan): flops on the f16 pipe (three v_mfma_f32_16x16x32_f16 per algorithmic product: x 3) and flops left on the
+    fp32 pipe.  Returns (f16_issued_flops, f32_flops)."""
+    N = cfg["B"] * cfg["L"]
+    dims = dnn_dims(cfg)  # [(K_j, M_j)], last = the scorer (a row dot product: no matrix-core work worth counting)
+    nl = len(dims)
+    on = lambda k: os.environ.get(k, "1") != "0"
+    knob_f = on("ULTR_FB_H3") if slot == 7 else on("ULTR_FWD_H3")
+    knob_b = on("ULTR_FB_H3") if slot == 7 else on("ULTR_BWD_H3")
+    fused_all = all(m >= 256 and m % 32 == 0 for _, m in dims[:-1])  # the fused kernel takes the split-half build only when every layer has its copies
+    f16 = f32 = 0.0
+    for j, (k, m) in enumerate(dims):
+        fl = 2.0 * N * k * m
+        if j < nl - 1 and slot in (0, 7):  # forward product of layer j
+            h3 = knob_f and m >= 256 and (fused_all if slot == 7 else True)
+            f16, f32 = (f16 + 3 * fl, f32) if h3 else (f16, f32 + fl)
+        elif j == nl - 1 and slot in (0, 7):
+            f32 += fl
+        if j >= 1 and slot in (2, 7):      # dgrad product du_j = dz_j . W_j (none for layer 0: the layer-0 shortcut)
+            h3 = knob_b and j < nl - 1 and k >= 256 and k % 32 == 0 and (fused_all if slot == 7 else True)
+            f16, f32 = (f16 + 3 * fl, f32) if h3 else (f16, f32 + fl)
+    if slot == 3:
+        f32 = 2.0 * N * sum(k * m for k, m in dims[:-1])  # weight gradients: fp32 MFMAs only
+    return f16, f32
+
+
 def make_pool(cfg, rng, device):
     from ultra_pytorch_amd import synthetic
     pool = []
@@ -749,14 +780,38 @@ def main():
         # `limited_by` says what the measurements show actually limits it
         limited_by = None
         if dnn and light and dom == 7:
-            limited_by = ("per-workgroup latency chain: one 10-document list per compute unit in a 16-row MFMA tile; 55 % of the kernel is "
-                          "row-wise phases (LayerNorms, loss, backward row passes), 45 % the three products, which run on the fp16 matrix "
-                          "cores (split hi/lo operands) and are bound by every workgroup streaming all 650 KB of weights through its "
-                          "XCD's L2 - not MFMA throughput, not HBM")
+            limited_by = ("a per-workgroup LATENCY CHAIN, nothing is at a bandwidth limit: one 10-document list per compute unit in a 16-row MFMA "
+                          "tile (8 waves); 55 % of the kernel is dependent row-wise phases (LayerNorms, loss, backward row passes), 45 % the "
+                          "three products, whose weight stream (l2_stream_frac below) runs ~2x off the L2's rate and whose matrix-core work "
+                          "(mfma_pipe_frac) is a few per cent of the launch")
         if bound == "mfma":
             achieved, peak, unit = amount / dom_s / 1e12, PEAK_FP32_MFMA_TFLOPS, "TFLOP/s"
         else:
             achieved, peak, unit = amount / dom_s / 1e9, PEAK_HBM_GBS, "GB/s"
+        # machine-readable honesty about the matrix-core dtype: what is issued, against the peak of what is issued
+        roofline_extras = {}
+        if dnn and bound == "mfma":
+            f16_issued, f32_issued = issued_matrix_work(cfg, dom)
+            pipe_s = f16_issued / (PEAK_F16_MFMA_TFLOPS * 1e12) + f32_issued / (PEAK_FP32_MFMA_TFLOPS * 1e12)
+            roofline_extras = {
+                "mfma_dtype": ("f16 x3 (split hi/lo operands, f32 accumulate)" if f32_issued == 0 else "f16 x3 (split hi/lo) + f32") if f16_issued > 0 else "f32",
+                "issued_f16_flops_per_launch": f16_issued, "issued_f32_flops_per_launch": f32_issued,
+                "frac_of_issued_dtype_peak": pipe_s / dom_s,
+                "frac_of_issued_dtype_peak_note": "time the matrix pipes need for what is ISSUED at their dense peaks (f16 2500, f32 157.3 TFLOP/s) "
+                                                  "/ launch duration; `frac` above prices the ALGORITHMIC fp32 flops against the fp32 peak instead "
+                                                  "(a comparison with a perfect fp32 implementation, not a ceiling of this kernel)"}
+            if dom == 7:
+                # every workgroup of the fused kernel streams every weight copy it multiplies with through its XCD's L2: 4 bytes per
+                # weight (fp32, or hi + lo halves) x [forward layers + dgrad layers >= 1] x workgroups; duration measured
+                dims = dnn_dims(cfg)
+                wbytes = 4.0 * (sum(k * m for k, m in dims[:-1]) + sum(k * m for k, m in dims[1:-1]))
+                lpb = max(1, 16 // cfg["L"])
+                nwg = (cfg["B"] + lpb - 1) // lpb
+                roofline_extras.update({"weight_stream_bytes_per_launch": wbytes * nwg, "weight_stream_tbps": wbytes * nwg / dom_s / 1e12,
+                                        "l2_stream_frac": wbytes * nwg / dom_s / 1e12 / L2_STREAM_PEAK_TBS,
+                                        "l2_stream_note": "workgroups x weight-copy bytes (computed) / measured launch duration, against "
+                                                          "8 L2s x 2 KB/clk x 2.4 GHz; the products are ~45 % of the launch, so inside them "
+                                                          "the stream runs at about twice this fraction"})
         traffic, traffic_source = None, None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes/launch from rocprofv3 PMC passes
         if os.path.exists(tfile) and light:
@@ -779,6 +834,7 @@ def main():
                          "frac": achieved / peak, "peak_note": ("fp32 MFMA dense peak; the kernel's products are counted as fp32 multiply-adds although "
                                                                 "they run as three f16 MFMAs on split operands") if (dnn and bound == "mfma" and h3_products_on()) else None,
                          "traffic": traffic, "traffic_source": traffic_source,
+                         **roofline_extras,
                          "avg_launch_us": 1e6 * dom_s, "launches_timed": dom_samples, "algorithmic_per_launch": amount,
                          "avg_launch_us_back_to_back": dom_stream_us,
                          "avg_launch_us_note": ("avg_launch_us (and `achieved`) is measured INSIDE the timed region, where every step "

@@ -7,7 +7,8 @@
 //
 //   * every rank owns an exchange buffer in FINE-GRAINED device memory, exported with hipIpcGetMemHandle and mapped by
 //     every peer (xGMI peer-to-peer loads/stores; one process per GPU, handles travel over the host process group);
-//   * a workgroup owns a 1024-float slice: it PUBLISHES its slice of the local vector into the local exchange slot with
+//   * a workgroup owns a 256-float slice (round 4; 1024 before - the slab-reduction launch that can run this exchange on its own
+//     output, grad_reduce_xchg_kernel in ultr_dnn.hip, works in blocks of 256): it PUBLISHES its slice of the local vector into the local exchange slot with
 //     system-scope write-through stores, waits for them (vmcnt), then raises its per-(slice, rank) flag in EVERY peer's
 //     flag array (one 4-byte posted store per peer); it then polls its OWN flag row until every peer's slice of the
 //     same step has landed and sums the W slices IN RANK ORDER with system-scope loads (bitwise identical on all
@@ -28,12 +29,7 @@
 #include <new>
 
 #include "../../include/ultr_hip.h"
-#include "ultr_device.h"
-#include "ultr_plan.h"
-
-#define ULTR_SYS 0x11  // cache policy sc0 | sc1: system scope (write-through stores, loads served from memory)
-#define COMM_SLICE 1024  // floats per workgroup (256 threads x float4)
-#define COMM_FLAG_STRIDE 1  // uint32 per (slice, rank) flag
+#include "ultr_comm.h"
 
 struct ultr_comm {
   int rank, world;
@@ -46,40 +42,18 @@ struct ultr_comm {
   int device;
 };
 
-struct CommDev {
-  int rank, world;
-  float* x_local;                          // local slot of this step
-  const float* x[ULTR_COMM_MAX_WORLD];     // every rank's slot of this step (x[rank] = x_local)
-  uint32_t* flags[ULTR_COMM_MAX_WORLD];    // every rank's flag array [nslice][world]
-  uint32_t* status[ULTR_COMM_MAX_WORLD];   // every rank's status word: != 0 after a timed-out wait on ANY rank (the rank
-                                           // that times out raises it everywhere, so no replica applies an update its
-                                           // peers did not)
-  long long timeout_ticks;                 // wall_clock64 ticks (100 MHz)
-};
-
 static inline size_t round4k(size_t v) { return (v + 4095) & ~(size_t)4095; }
 
-__device__ __forceinline__ void sys_st4(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, float4 v) {
-  const u32x4 d = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-  __builtin_amdgcn_raw_buffer_store_b128(d, rs, byte_off, 0, ULTR_SYS);
-}
-__device__ __forceinline__ float4 sys_ld4(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, ULTR_SYS);
-  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t sys_rsrc(const float* p, int64_t nfloats) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)(nfloats * 4), 0x00020000);
-}
-
-// src [n] local vector -> out [n] = sum over ranks; sumsq_part[k] = sum of out[e]^2 over e in [64k, 64k+64), e < n_params
+// src [n] local vector -> out [n] = sum over ranks; sumsq_part[k] = sum of out[e]^2 over e in [64k, 64k+64), e < n_params.
+// One wave per 256-float slice (float4 per lane).
 template <int W>
-__global__ __launch_bounds__(256) void comm_allreduce_kernel(CommDev c, uint32_t epoch, int64_t n, int64_t n_params, int64_t cap,
-                                                             const float* __restrict__ src, float* __restrict__ out,
-                                                             float* __restrict__ sumsq_part, int nsq, EarlyReport er) {
+__global__ __launch_bounds__(64) void comm_allreduce_kernel(CommDev c, int64_t n, int64_t n_params, const float* __restrict__ src,
+                                                            float* __restrict__ out, float* __restrict__ sumsq_part, int nsq,
+                                                            EarlyReport er) {
   __shared__ int sm_fail;
   __shared__ float sm_head[4];
   const int tid = threadIdx.x;
-  const int64_t e4 = ((int64_t)blockIdx.x * 256 + tid) * 4;
+  const int64_t e4 = ((int64_t)blockIdx.x * 64 + tid) * 4;
   if (tid == 0) sm_fail = 0;
   // ---- publish this workgroup's slice of the local vector (system-scope write-through) ------------------------------
   float4 mine = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -90,47 +64,22 @@ __global__ __launch_bounds__(256) void comm_allreduce_kernel(CommDev c, uint32_t
     if (e4 + 1 < n) mine.y = src[e4 + 1];
     if (e4 + 2 < n) mine.z = src[e4 + 2];
   }
+  bool landed = true;
   if constexpr (W > 1) {
-    sys_st4(sys_rsrc(c.x_local, cap), (unsigned)(e4 * 4), mine);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores are acknowledged at system scope
-    __syncthreads();
-    if (tid < W) {
-      // raise flag (slice, rank) in rank tid's array; then wait for rank tid's flag in ours
-      uint32_t* dst = c.flags[tid] + ((int64_t)blockIdx.x * W + c.rank) * COMM_FLAG_STRIDE;
-      __hip_atomic_store(dst, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      const uint32_t* mineflag = c.flags[c.rank] + ((int64_t)blockIdx.x * W + tid) * COMM_FLAG_STRIDE;
-      const long long t0 = wall_clock64();
-      bool ok = true;
-      // flags carry the step number; a peer may already be one step ahead (>=); the difference is taken modulo 2^32
-      while ((int32_t)(__hip_atomic_load(mineflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
-        __builtin_amdgcn_s_sleep(2);
-        if (wall_clock64() - t0 > c.timeout_ticks) {
-          ok = false;
-          break;
-        }
-      }
-      if (!ok) {
-        sm_fail = 1;
-        for (int p = 0; p < W; ++p) __hip_atomic_store(c.status[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-    }
-    __syncthreads();
-    // acquire at system scope behind the flag reads: nothing this workgroup cached before the peers published (L1 / non-local
-    // L2 lines) may serve the slice loads below.  (The publishing side needs no L2-wide release: its slice went out with
-    // write-through sc0|sc1 stores that were waited for - vmcnt(0) - before the flag stores were issued.)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    sys_st4(sys_rsrc(c.x_local, c.cap), (unsigned)(e4 * 4), mine);
+    landed = comm_flags_and_wait<W>(c, blockIdx.x, &sm_fail);
   }
   // ---- sum the W slices in rank order ---------------------------------------------------------------------------------
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if constexpr (W > 1) {
     float4 v[W];
 #pragma unroll
-    for (int p = 0; p < W; ++p) v[p] = sys_ld4(sys_rsrc(c.x[p], cap), (unsigned)(e4 * 4));
+    for (int p = 0; p < W; ++p) v[p] = sys_ld4(sys_rsrc(c.x[p], c.cap), (unsigned)(e4 * 4));
 #pragma unroll
     for (int p = 0; p < W; ++p) {
       s.x += v[p].x; s.y += v[p].y; s.z += v[p].z; s.w += v[p].w;
     }
-    if (sm_fail) s = mine;  // timed out: the local vector stays; the status word (raised on every rank) makes the update
+    if (!landed) s = mine;  // timed out: the local vector stays; the status word (raised on every rank) makes the update
                             // launches no-ops from here on and the host's next read of the loss raises
   } else {
     s = mine;
@@ -144,7 +93,7 @@ __global__ __launch_bounds__(256) void comm_allreduce_kernel(CommDev c, uint32_t
   }
   // ---- early loss report (EarlyReport, ultr_plan.h): the workgroup whose slice holds the head of the step tail
   // (loss_sum, D, loss2_sum, D2 at out[n_params .. n_params + 4)) now has the GLOBAL sums: the loss is final here, one
-  // launch before the update reports everything else.  Not after a timed-out wait (the guarded update reports that).
+  // launch before the update reports everything else.
   {
     const int64_t b0 = (int64_t)blockIdx.x * COMM_SLICE;
     if (er.host != nullptr && n_params >= b0 && n_params + 4 <= b0 + COMM_SLICE && n_params + 4 <= n) {  // block-uniform
@@ -159,16 +108,8 @@ __global__ __launch_bounds__(256) void comm_allreduce_kernel(CommDev c, uint32_t
       // word (the update behind this launch is then a no-op and reports NaN + the status: the loss must not look final)
       bool failed = false;
       if constexpr (W > 1)
-        failed = sm_fail != 0 || __hip_atomic_load(c.status[c.rank], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
-      if (tid == 0 && !failed) {
-        const float loss_sum = sm_head[0], D = sm_head[1], loss2 = sm_head[2], D2 = sm_head[3];
-        float loss = loss_sum / D;
-        if (er.algo == ULTR_ALGO_DLA) loss = loss2 / D2 + er.rlw * (loss_sum / D);
-        else if (er.algo == ULTR_ALGO_PAIRDEBIAS) loss = loss_sum;
-        __hip_atomic_store(er.host, loss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(reinterpret_cast<uint32_t*>(er.host) + 10, er.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
+        failed = !landed || __hip_atomic_load(c.status[c.rank], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+      if (tid == 0 && !failed) comm_early_report(er, sm_head[0], sm_head[1], sm_head[2], sm_head[3]);
     }
   }
   // ---- sum-of-squares partials of the reduced gradient (64 elements = 16 lanes) ---------------------------------------
@@ -196,7 +137,7 @@ extern "C" int ultr_comm_create(int32_t rank, int32_t world, int64_t n_floats, u
   c->world = world;
   c->cap = (n_floats + COMM_SLICE - 1) / COMM_SLICE * COMM_SLICE;
   c->nslice = (int)(c->cap / COMM_SLICE);
-  c->flag_bytes = round4k((size_t)c->nslice * world * COMM_FLAG_STRIDE * sizeof(uint32_t));
+  c->flag_bytes = round4k((size_t)c->nslice * world * sizeof(uint32_t));
   c->bytes = c->flag_bytes + 4096 + 2 * round4k((size_t)c->cap * sizeof(float));
   hipError_t e = hipGetDevice(&c->device);
   if (e == hipSuccess) e = hipExtMallocWithFlags(&c->base, c->bytes, hipDeviceMallocFinegrained);
@@ -254,27 +195,12 @@ int ultr_comm_allreduce_ex(ultr_comm* c, uint64_t step, const float* src, int64_
                            int32_t sumsq_parts, void* stream, EarlyReport er) {
   if (!c || !src || !out || !sumsq_ws || n <= 0 || n > c->cap || n_params < 0 || n_params > n || sumsq_parts < 0)
     return ULTR_E_BADARG;
-  if (!comm_ready(c)) return ULTR_E_UNSUPPORTED;
   CommDev d;
-  memset(&d, 0, sizeof(d));
-  d.rank = c->rank;
-  d.world = c->world;
-  const size_t slot_bytes = round4k((size_t)c->cap * sizeof(float));
-  const size_t slot_off = c->flag_bytes + 4096 + (size_t)(step & 1) * slot_bytes;
-  for (int p = 0; p < c->world; ++p) {
-    d.flags[p] = reinterpret_cast<uint32_t*>(c->peer_base[p]);
-    d.x[p] = reinterpret_cast<const float*>(reinterpret_cast<char*>(c->peer_base[p]) + slot_off);
-  }
-  d.x_local = reinterpret_cast<float*>(reinterpret_cast<char*>(c->base) + slot_off);
-  for (int p = 0; p < c->world; ++p)
-    d.status[p] = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(c->peer_base[p]) + c->flag_bytes);
-  d.timeout_ticks = 300000000LL;  // 3 s of the 100 MHz wall clock
-  const uint32_t epoch = (uint32_t)(step + 1);
+  if (!ultr_comm_dev(c, step, n, &d)) return ULTR_E_UNSUPPORTED;
   const int nblk = (int)((n + COMM_SLICE - 1) / COMM_SLICE);
   hipStream_t st = (hipStream_t)stream;
-#define COMM_LAUNCH(WW)                                                                                                      \
-  hipLaunchKernelGGL(comm_allreduce_kernel<WW>, dim3(nblk), dim3(256), 0, st, d, epoch, n, n_params, c->cap, src, out, \
-                     (float*)sumsq_ws, (int)sumsq_parts, er)
+#define COMM_LAUNCH(WW) \
+  hipLaunchKernelGGL(comm_allreduce_kernel<WW>, dim3(nblk), dim3(64), 0, st, d, n, n_params, src, out, (float*)sumsq_ws, (int)sumsq_parts, er)
   switch (c->world) {
     case 1: COMM_LAUNCH(1); break;
     case 2: COMM_LAUNCH(2); break;
@@ -287,6 +213,27 @@ int ultr_comm_allreduce_ex(ultr_comm* c, uint64_t step, const float* src, int64_
   }
 #undef COMM_LAUNCH
   return (int)hipGetLastError();
+}
+
+bool ultr_comm_dev(ultr_comm* c, uint64_t step, int64_t n, CommDev* out) {
+  if (!c || !out || n <= 0 || n > c->cap || !comm_ready(c)) return false;
+  CommDev& d = *out;
+  memset(&d, 0, sizeof(d));
+  d.rank = c->rank;
+  d.world = c->world;
+  const size_t slot_bytes = round4k((size_t)c->cap * sizeof(float));
+  const size_t slot_off = c->flag_bytes + 4096 + (size_t)(step & 1) * slot_bytes;
+  for (int p = 0; p < c->world; ++p) {
+    d.flags[p] = reinterpret_cast<uint32_t*>(c->peer_base[p]);
+    d.x[p] = reinterpret_cast<const float*>(reinterpret_cast<char*>(c->peer_base[p]) + slot_off);
+    d.status[p] = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(c->peer_base[p]) + c->flag_bytes);
+    d.early[p] = reinterpret_cast<float*>(reinterpret_cast<char*>(c->peer_base[p]) + c->flag_bytes + 256);  // 2 x 8 ranks x 32 bytes
+  }
+  d.x_local = reinterpret_cast<float*>(reinterpret_cast<char*>(c->base) + slot_off);
+  d.timeout_ticks = 300000000LL;  // 3 s of the 100 MHz wall clock
+  d.cap = c->cap;
+  d.epoch = (uint32_t)(step + 1);
+  return true;
 }
 
 // library-internal: the device address of this rank's status word (ultr_update_desc::guard of the update behind the exchange)

@@ -24,6 +24,7 @@
 #include <utility>
 
 #include "../../include/ultr_hip.h"
+#include "ultr_comm.h"
 #include "ultr_device.h"
 #include "ultr_plan.h"
 #include "ultr_prof.h"
@@ -2764,7 +2765,7 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
                                                         const float* __restrict__ saved, float* __restrict__ ws,
                                                         int vecf, float* __restrict__ grads,
                                                         const float* __restrict__ loss_part, int n_loss_part, int tail,
-                                                        EarlyReport er) {
+                                                        EarlyReport er, CommDev cd) {
   // ONE dynamic LDS array: [4][64*64] cross-wave reduction | [4][64] bias partials | [rows_per_split] doc ids
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float (*red)[64 * 64] = reinterpret_cast<float (*)[64 * 64]>(smem);
@@ -2807,11 +2808,18 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
     }
     if (er.host != nullptr && grp == 0 && loss_part != nullptr) {
       // early loss report (EarlyReport, ultr_plan.h): the same expressions as update_body, so the update kernel's later
-      // report of the same step carries the same bits
-      const float loss_sum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(head), 0));
-      const float D = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(head), 1));
-      const float loss2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(head), 2));
-      const float D2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(head), 3));
+      // report of the same step carries the same bits.  Data parallel (cd.world >= 1): the head of the tail is exchanged with
+      // the peers right here (comm_early_head, ultr_comm.h) - the loss needs the GLOBAL sums
+      float gh[4];
+      if (cd.world >= 1) {
+        if (!comm_early_head(cd, head, gh)) return;
+      } else {
+        gh[0] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(head), 0));
+        gh[1] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(head), 1));
+        gh[2] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(head), 2));
+        gh[3] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(head), 3));
+      }
+      const float loss_sum = gh[0], D = gh[1], loss2 = gh[2], D2 = gh[3];
       float loss = loss_sum / D;
       if (er.algo == ULTR_ALGO_DLA) loss = loss2 / D2 + er.rlw * (loss_sum / D);
       else if (er.algo == ULTR_ALGO_PAIRDEBIAS) loss = loss_sum;
@@ -3168,6 +3176,64 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(RedPlan rp, int64_t P,
     const float sq = wave_sum(gg);
     if (lane == 0) sumsq_part[blockIdx.x] = sq;
   }
+}
+
+// Data parallel (ultr_step_args::comm): the slab reduction EXCHANGES its own output - a workgroup folds its 256 elements, publishes
+// them into the rank's exchange slot, raises / awaits the slice's flags and adds the ranks' slots in rank order (ultr_comm.h: the
+// protocol, slots, flags and epochs of the stand-alone exchange kernel, so ranks may mix the two).  The exchange stops being a
+// launch: round 3's data-parallel step paid +8.4 us at world size 1 for comm_allreduce_kernel behind the reduction; here W = 1
+// is the plain reduction (same bits) and W > 1 adds one publish / flag / peer-read round trip inside a launch that ran anyway.
+// Elements P .. P + tail are the step tail the weight-gradient launch already folded (read from grads, exchanged like the rest).
+template <int W>
+__global__ __launch_bounds__(256) void grad_reduce_xchg_kernel(RedPlan rp, int64_t P, int tail, const float* __restrict__ ws,
+                                                               float* __restrict__ grads, float* __restrict__ sumsq_part, int nsq,
+                                                               CommDev c, EarlyReport er) {
+  __shared__ int sm_fail;
+  __shared__ float sm_head[4];
+  const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6;
+  const int64_t n = P + tail;
+  const int64_t e = (int64_t)blockIdx.x * 256 + tid;
+  if (tid == 0) sm_fail = 0;
+  float g = 0.f;
+  if (e < P) {
+    int s = 0;
+    while (s + 1 < rp.nseg && e >= rp.seg[s + 1].off) ++s;
+    const RedSeg sg = rp.seg[s];
+    g = full_sum(ws + sg.base + (e - sg.off), sg.stride, sg.nparts);
+  } else if (e < n) {
+    g = grads[e];
+  }
+  float s = g;
+  bool landed = true;
+  if constexpr (W > 1) {
+    sys_st1(sys_rsrc(c.x_local, c.cap), e < c.cap ? (unsigned)(e * 4) : ULTR_OOB, g);
+    landed = comm_flags_and_wait<W>(c, blockIdx.x, &sm_fail);
+    float v[W];
+#pragma unroll
+    for (int p = 0; p < W; ++p) v[p] = sys_ld1(sys_rsrc(c.x[p], c.cap), e < c.cap ? (unsigned)(e * 4) : ULTR_OOB);
+    s = 0.f;
+#pragma unroll
+    for (int p = 0; p < W; ++p) s += v[p];
+    if (!landed) s = g;  // timed out: the local value stays; the status word (raised on every rank) freezes the updates
+  }
+  if (e < n) grads[e] = s;
+  {
+    const int64_t b0 = (int64_t)blockIdx.x * 256;
+    if (er.host != nullptr && P >= b0 && P + 4 <= b0 + 256 && P + 4 <= n) {  // block-uniform: the head of the step tail is in this block
+      const int64_t idx = e - P;
+      if (idx >= 0 && idx < 4) sm_head[idx] = s;
+      __syncthreads();
+      bool failed = false;
+      if constexpr (W > 1)
+        failed = !landed || __hip_atomic_load(c.status[c.rank], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+      if (tid == 0 && !failed) comm_early_report(er, sm_head[0], sm_head[1], sm_head[2], sm_head[3]);
+    }
+  }
+  float gg = e < P ? s * s : 0.f;
+  asm volatile("" : "+v"(gg));  // (see grad_reduce_kernel: the product is rounded before the first cross-lane add)
+  const float sq = wave_sum(gg);
+  const int k = (int)blockIdx.x * 4 + grp;
+  if (lane == 0 && k < nsq) sumsq_part[k] = sq;
 }
 
 __global__ __launch_bounds__(64) void grad_sumsq_kernel(int64_t P, const float* __restrict__ grads,
@@ -3852,13 +3918,24 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
     if (e != hipSuccess) return (int)e;
     const dim3 wgrid(bp.wgrad_blocks + bp.vred_blocks + (bp.lf_chunks > 0 ? bp.lf_chunks : 1));
     EarlyReport er = g_ultr_early;
+    CommDev cd;
+    memset(&cd, 0, sizeof(cd));  // world 0: not a data-parallel step
+    if (g_ultr_step_xchg.comm != nullptr && g_ultr_step_xchg.er.host != nullptr && bp.lf_chunks == 0 &&
+        ultr_comm_dev(g_ultr_step_xchg.comm, g_ultr_step_xchg.step, p.P + tail, &cd)) {
+      // data-parallel step: the workgroup that folds the loss partials exchanges the head of the tail with the peers and reports
+      // the loss NOW; the gradient exchange behind this launch then has nothing to report
+      er = g_ultr_step_xchg.er;
+      g_ultr_step_xchg.er.host = nullptr;
+    } else {
+      cd.world = 0;
+    }
     if (bp.lf_chunks > 0) er.host = nullptr;  // two-level fold of > 1024 partials: the loss is only final in the reduction launch
     if (av)
       ULTR_LAUNCH(prof, dnn_wgrad_kernel<true>, wgrid, dim3(256), wlds, st, p, bp, params, features, n_docs,
-                         docids, (int)batch, (int)list_size, (const float*)saved, ws, (vm >> 31) & 1, grads, lp, nlp, tail, er);
+                         docids, (int)batch, (int)list_size, (const float*)saved, ws, (vm >> 31) & 1, grads, lp, nlp, tail, er, cd);
     else
       ULTR_LAUNCH(prof, dnn_wgrad_kernel<false>, wgrid, dim3(256), wlds, st, p, bp, params, features, n_docs,
-                         docids, (int)batch, (int)list_size, (const float*)saved, ws, (vm >> 31) & 1, grads, lp, nlp, tail, er);
+                         docids, (int)batch, (int)list_size, (const float*)saved, ws, (vm >> 31) & 1, grads, lp, nlp, tail, er, cd);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }
@@ -3868,6 +3945,28 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
   UltrProfScope prof(ULTR_K_REDUCE, st);
   int maxparts = 1;
   for (int k = 0; k < rp.nseg; ++k) maxparts = rp.seg[k].nparts > maxparts ? rp.seg[k].nparts : maxparts;
+  if (g_ultr_step_xchg.comm != nullptr && maxparts <= 32 && bp.lf_chunks == 0) {
+    // data-parallel step: this launch exchanges its own output (grad_reduce_xchg_kernel); ultr_train_step then skips the exchange kernel
+    CommDev cd;
+    if (ultr_comm_dev(g_ultr_step_xchg.comm, g_ultr_step_xchg.step, p.P + tail, &cd)) {
+      const dim3 xg((unsigned)((p.P + tail + 255) / 256));
+#define XCHG_LAUNCH(WW) \
+  ULTR_LAUNCH(prof, grad_reduce_xchg_kernel<WW>, xg, dim3(256), 0, st, rp, p.P, tail, (const float*)ws, grads, ws + bp.sumsq_off, nblk, cd, g_ultr_step_xchg.er)
+      switch (cd.world) {
+        case 1: XCHG_LAUNCH(1); break;
+        case 2: XCHG_LAUNCH(2); break;
+        case 3: XCHG_LAUNCH(3); break;
+        case 4: XCHG_LAUNCH(4); break;
+        case 5: XCHG_LAUNCH(5); break;
+        case 6: XCHG_LAUNCH(6); break;
+        case 7: XCHG_LAUNCH(7); break;
+        default: XCHG_LAUNCH(8); break;
+      }
+#undef XCHG_LAUNCH
+      g_ultr_step_xchg.done = true;
+      return (int)hipGetLastError();
+    }
+  }
   if (maxparts <= 32)
     ULTR_LAUNCH(prof, grad_reduce_kernel<true>, dim3((nblk + 3) / 4 + (bp.lf_chunks > 0 ? 1 : 0)), dim3(256), 0, st, rp, p.P, tail,
                 (const float*)ws, (const float*)(ws + bp.lfold_off), bp.lf_chunks, grads, ws + bp.sumsq_off, nblk);

@@ -268,6 +268,17 @@ struct ultr_comm;
 int ultr_comm_allreduce_ex(ultr_comm* c, uint64_t step, const float* src, int64_t n, int64_t n_params, float* out, void* sumsq_ws,
                            int32_t sumsq_parts, void* stream, EarlyReport er);
 
+// ... and the data-parallel step hands its communicator to the backward it launches: where the backward ends in the slab
+// reduction, that launch runs the exchange on its own output (grad_reduce_xchg_kernel) and says so (`done`); ultr_train_step then
+// goes straight to the guarded update.  nullptr everywhere else.
+struct StepXchg {
+  ultr_comm* comm;
+  uint64_t step;
+  EarlyReport er;
+  bool done;
+};
+extern thread_local StepXchg g_ultr_step_xchg;  // ultr_step.hip
+
 #define ULTR_TAIL_FIXED 4
 __host__ __device__ static inline int64_t ultr_tail_len(int L) { return ULTR_TAIL_FIXED + 2 * (int64_t)L; }
 

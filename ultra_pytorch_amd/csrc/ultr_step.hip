@@ -16,10 +16,12 @@ static int finish_step(const ultr_step_args* a, void* stream) {
     if (P <= 0) return ULTR_E_BADARG;
     const int64_t n = P + ultr_tail_len(a->list_size);
     const ultr_update_desc* u0 = a->upd;
-    const bool early = u0->host_scalars != nullptr && u0->l2_loss == 0.f;
-    const EarlyReport er = {early ? u0->host_scalars : nullptr, u0->seq, u0->algo, u0->ranker_loss_weight};
-    const int rc = ultr_comm_allreduce_ex(a->comm, a->comm_step, a->grads, n, P, a->grads, a->bwd_ws, (int32_t)((n + 63) / 64), stream, er);
-    if (rc) return rc;
+    // (er.host is null when the weight-gradient launch of this step already exchanged the head of the tail and reported the loss)
+    const EarlyReport er = g_ultr_step_xchg.er;
+    if (!g_ultr_step_xchg.done) {  // (the slab reduction of this step's backward did not run the exchange itself)
+      const int rc = ultr_comm_allreduce_ex(a->comm, a->comm_step, a->grads, n, P, a->grads, a->bwd_ws, (int32_t)((n + 63) / 64), stream, er);
+      if (rc) return rc;
+    }
     // the update behind the exchange is guarded by the communicator's status word: after a timed-out peer wait (here or on
     // any peer - the rank that times out raises the word everywhere) no replica moves its parameters again
     ultr_update_desc u = *a->upd;
@@ -33,6 +35,7 @@ static int finish_step(const ultr_step_args* a, void* stream) {
 
 thread_local EarlyReport g_ultr_early = {nullptr, 0u, 0, 1.0f};
 thread_local const float* g_ultr_step_wt = nullptr;
+thread_local StepXchg g_ultr_step_xchg = {nullptr, 0, {nullptr, 0u, 0, 1.0f}, false};
 
 namespace {
 // early loss report for the backward call(s) of this step (EarlyReport, ultr_plan.h): only where the local loss sums ARE the
@@ -43,10 +46,14 @@ struct EarlyScope {
     const bool ok = u->host_scalars != nullptr && a->comm == nullptr && !a->skip_update && u->l2_loss == 0.f;
     g_ultr_early = {ok ? u->host_scalars : nullptr, u->seq, u->algo, u->ranker_loss_weight};
     g_ultr_step_wt = a->wt;
+    const bool dp = a->comm != nullptr && !a->skip_update;
+    const bool early_dp = dp && u->host_scalars != nullptr && u->l2_loss == 0.f;
+    g_ultr_step_xchg = {dp ? a->comm : nullptr, a->comm_step, {early_dp ? u->host_scalars : nullptr, u->seq, u->algo, u->ranker_loss_weight}, false};
   }
   ~EarlyScope() {
     g_ultr_early.host = nullptr;
     g_ultr_step_wt = nullptr;
+    g_ultr_step_xchg.comm = nullptr;
   }
 };
 }  // namespace
