@@ -2150,8 +2150,9 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
   if (wave == 0) {
     const float* ka = (const float*)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr int KA_LINES = (int)((sizeof(DnnPlan) + sizeof(BwdPlan) + sizeof(FusedSoftmax) + sizeof(FbPlan) + 96 + 63) / 64);
-    static_assert(KA_LINES <= 64, "one lane per kernel-argument cache line");
+    static_assert(KA_LINES <= 128, "at most two kernel-argument cache lines per lane");
     ka_pf = ka[(lane < KA_LINES ? lane : 0) * 16];
+    if constexpr (KA_LINES > 64) ka_pf += ka[(lane + 64 < KA_LINES ? lane + 64 : 0) * 16];
   }
 #endif
 
@@ -3554,6 +3555,11 @@ bool ultr_make_bwd_plan(const DnnPlan& p, int64_t N, BwdPlan* bp) {
   bp->l0part_off = off;
   if (p.nl >= 2) off += ((int64_t)bp->wl[0].nmb * bp->wl[0].nsplit * 2 * p.K[0] + 3) & ~(int64_t)3;
   {
+    const int64_t h = ultr_dgp_layer(p, p.nl - 1);
+    off = (off + 7) & ~(int64_t)7;
+    bp->dgp_off = off; off += (h + 1) / 2; off = (off + 3) & ~(int64_t)3;
+  }
+  {
     const int64_t nmt0 = (p.M[0] + 15) / 16, nkt0 = (p.K[0] + 31) / 32;
     bp->wgd_part_off = off; off += nkt0 * nmt0 * 96;
   }
@@ -3626,7 +3632,7 @@ extern "C" int ultr_dnn_param_offsets(const ultr_dnn_desc* d, int64_t* offsets) 
 extern "C" int64_t ultr_dnn_saved_bytes(const ultr_dnn_desc* d, int64_t n_rows) {
   DnnPlan p;
   if (n_rows < 0 || !ultr_make_dnn_plan(d, n_rows, &p)) return 0;
-  return (p.sv_total + 4) * (int64_t)sizeof(float);
+  return (ultr_fwp_off(p) + (ultr_fwp_halves(p) + 1) / 2 + 4) * (int64_t)sizeof(float);
 }
 extern "C" int64_t ultr_dnn_bwd_workspace_bytes(const ultr_dnn_desc* d, int64_t n_rows) {
   DnnPlan p;
@@ -3785,7 +3791,7 @@ extern "C" int ultr_dnn_forward(const ultr_dnn_desc* d, const float* params, con
   if (saved != nullptr && wt != nullptr && av && ultr_dnn_big_ok(p, N, n_docs) &&
       knobs().big_fwd != 0 && (big_fwd_wanted(p, N, lds) || lds > 160 * 1024))
     return ultr_dnn_big_forward(p, params, wt, features, n_docs, docids, (int)batch, (int)list_size, scores, (float*)saved, st,
-                                prof.on ? prof.a : nullptr, prof.on ? prof.b : nullptr);
+                                prof.on ? prof.a : nullptr, prof.on ? prof.b : nullptr, knobs().fwd_h3 != 0);
   if (lds > 160 * 1024) return ULTR_E_UNSUPPORTED;
 #define LAUNCH_FWD(RR, NWW, VV)                                                                                     \
   do {                                                                                                              \
@@ -3874,7 +3880,7 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
     UltrProfScope prof(ULTR_K_BWD, st);
     bp.nrb = (int)((N + ULTR_BIG_ROWS - 1) / ULTR_BIG_ROWS);  // one vector slab per row block of the row kernels
     const int rc = ultr_dnn_big_backward(p, bp, params, (const float*)saved, dscores, ws, st, prof.on ? prof.a : nullptr,
-                                         prof.on ? prof.b : nullptr);
+                                         prof.on ? prof.b : nullptr, knobs().bwd_h3 != 0);
     if (rc) return rc;
   } else if (v2) {
     UltrProfScope prof(ULTR_K_BWD, st);

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "../../include/ultr_hip.h"
 #include "ultr_device.h"
@@ -254,6 +255,38 @@ hipError_t lnb_dispatch(const LnbArgs& a, unsigned blocks, hipStream_t st, hipEv
   return lnb_launch<4, TOP>(a, blocks, st, ea, eb);
 }
 
+// hi | lo fp16 planes of 2^8 W_j^T ([K_j][ldM_j], zero-padded) for the split-half dgrad GEMMs: blockIdx.y = layer j
+struct WtPlaneTable {
+  int64_t off_w[ULTR_MAXL], plane[ULTR_MAXL];
+  int M[ULTR_MAXL], K[ULTR_MAXL], ldM[ULTR_MAXL];
+};
+__global__ __launch_bounds__(256) void big_split_wT_kernel(WtPlaneTable tb, const float* __restrict__ params, _Float16* __restrict__ planes) {
+  const int j = blockIdx.y + 1;
+  const int K = tb.K[j], M = tb.M[j], ld = tb.ldM[j];
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)K * ld) return;
+  const int k = (int)(e / ld), m = (int)(e - (int64_t)k * ld);
+  const float w = m < M ? params[tb.off_w[j] + (int64_t)m * K + k] * UGEMM_H3_WSCALE : 0.f;
+  const _Float16 hi = (_Float16)w, lo = (_Float16)(w - (float)hi);  // (|w| >= 128 overflows to inf: NaN gradients, loud)
+  _Float16* dst = planes + tb.plane[j];
+  dst[e] = hi;
+  dst[(int64_t)K * ld + e] = lo;
+}
+
+// ... and of 2^8 W_j ([M_j][ldK_j]) for the split-half forward GEMMs: blockIdx.y = layer j
+__global__ __launch_bounds__(256) void big_split_w_kernel(WtPlaneTable tb, const float* __restrict__ params, _Float16* __restrict__ planes) {
+  const int j = blockIdx.y;
+  const int K = tb.K[j], M = tb.M[j], ld = tb.ldM[j];  // (ldM holds ldK here)
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)M * ld) return;
+  const int m = (int)(e / ld), k = (int)(e - (int64_t)m * ld);
+  const float w = k < K ? params[tb.off_w[j] + (int64_t)m * K + k] * UGEMM_H3_WSCALE : 0.f;
+  const _Float16 hi = (_Float16)w, lo = (_Float16)(w - (float)hi);
+  _Float16* dst = planes + tb.plane[j];
+  dst[e] = hi;
+  dst[(int64_t)M * ld + e] = lo;
+}
+
 }  // namespace
 
 // every layer must take the vector paths (rows a multiple of 4 floats wide, at most 1024; 32-bit buffer offsets)
@@ -270,10 +303,23 @@ bool ultr_dnn_big_ok(const DnnPlan& p, int64_t N, int64_t n_docs) {
 
 int ultr_dnn_big_forward(const DnnPlan& p, const float* params, const float* wt, const float* features, int64_t n_docs,
                          const int32_t* docids, int B, int L, float* scores, float* saved, hipStream_t st, hipEvent_t ev_start,
-                         hipEvent_t ev_stop) {
+                         hipEvent_t ev_stop, bool split_half) {
   const int64_t N = (int64_t)B * L;
   const unsigned rblocks = (unsigned)((N + BIG_ROWS - 1) / BIG_ROWS);
   const int top = p.nl - 1;
+  // split-half GEMMs (round 4, ultr_gemm.h run_h3): the planes of every W_j are rebuilt here, behind the saved activations
+  _Float16* planes = reinterpret_cast<_Float16*>(saved + ultr_fwp_off(p));
+  if (split_half) {
+    WtPlaneTable tb;
+    memset(&tb, 0, sizeof(tb));
+    int64_t maxe = 0;
+    for (int j = 0; j < top; ++j) {
+      tb.off_w[j] = p.off_w[j]; tb.plane[j] = ultr_fwp_layer(p, j); tb.M[j] = p.M[j]; tb.K[j] = p.K[j]; tb.ldM[j] = (p.K[j] + 31) / 32 * 32;
+      const int64_t e = (int64_t)p.M[j] * tb.ldM[j];
+      maxe = e > maxe ? e : maxe;
+    }
+    hipLaunchKernelGGL(big_split_w_kernel, dim3((unsigned)((maxe + 255) / 256), (unsigned)top), dim3(256), 0, st, tb, params, planes);
+  }
   for (int j = 0; j <= top; ++j) {
     const int K = p.K[j];
     const float* x = (j == 0) ? features : saved + p.sv_x[j];
@@ -297,7 +343,10 @@ int ultr_dnn_big_forward(const DnnPlan& p, const float* params, const float* wt,
       const ugemm::AAffine a{xhat0, params, N, p.P, p.off_lnw[j], p.off_lnb[j], K};
       const ugemm::Dims d0{N, M, K, M};
       const ugemm::EBiasAct e0{saved + p.sv_x[j + 1], params + p.off_b[j], M, p.act};
-      const hipError_t rc0 = ugemm::run<false>(d0, a, wt + p.wt_off[j], e0, st);
+      const int ldK = (K + 31) / 32 * 32;
+      const ugemm::Dims dh0{N, M, K, ldK};
+      const _Float16* hi0 = planes + ultr_fwp_layer(p, j);
+      const hipError_t rc0 = split_half ? ugemm::run_h3(dh0, a, hi0, hi0 + (int64_t)M * ldK, e0, st) : ugemm::run<false>(d0, a, wt + p.wt_off[j], e0, st);
       if (rc0 != hipSuccess) return (int)rc0;
       continue;
     }
@@ -318,7 +367,11 @@ int ultr_dnn_big_forward(const DnnPlan& p, const float* params, const float* wt,
     a.L = L;
     const ugemm::Dims d{N, M, K, M};
     const ugemm::EBiasAct e{saved + p.sv_x[j + 1], params + p.off_b[j], M, p.act};
-    const hipError_t rc = ugemm::run<false>(d, a, wt + p.wt_off[j], e, st);  // B = the k-major copy WT_j [K][M]
+    const int ldK = (K + 31) / 32 * 32;
+    const ugemm::Dims dh{N, M, K, ldK};
+    const _Float16* hi = planes + ultr_fwp_layer(p, j);
+    const hipError_t rc = split_half ? ugemm::run_h3(dh, a, hi, hi + (int64_t)M * ldK, e, st)
+                                     : ugemm::run<false>(d, a, wt + p.wt_off[j], e, st);  // B = the k-major copy WT_j [K][M]
     if (rc != hipSuccess) return (int)rc;
   }
   return (int)hipGetLastError();
@@ -327,12 +380,27 @@ int ultr_dnn_big_forward(const DnnPlan& p, const float* params, const float* wt,
 // the row-local half of the backward: dz_j for every hidden Linear + the vector slabs (one per BIG_ROWS rows); bp.nrb must be
 // ceil(N / BIG_ROWS) and bp.l0g == 1 (the caller's weight-gradient launch makes up for the missing layer-0 dgrad)
 int ultr_dnn_big_backward(const DnnPlan& p, const BwdPlan& bp, const float* params, const float* saved, const float* dscores, float* ws,
-                          hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                          hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, bool split_half) {
   const int64_t N = bp.N;
   const unsigned rblocks = (unsigned)((N + BIG_ROWS - 1) / BIG_ROWS);
   const int top = p.nl - 1;
   float* vslab = ws + bp.vslab_off;
   float* du = ws + bp.du_off;
+  // split-half dgrad GEMMs (round 4, ultr_gemm.h run_h3): the planes of every W_j^T are rebuilt here (the weights changed with the
+  // last update; ~1 MB, one small launch in front of the row kernel of the top layer, which does not read them)
+  _Float16* planes = reinterpret_cast<_Float16*>(ws + bp.dgp_off);
+  split_half = split_half && top >= 2;
+  if (split_half) {
+    WtPlaneTable tb;
+    memset(&tb, 0, sizeof(tb));
+    int64_t maxe = 0;
+    for (int j = 1; j < top; ++j) {
+      tb.off_w[j] = p.off_w[j]; tb.plane[j] = ultr_dgp_layer(p, j); tb.M[j] = p.M[j]; tb.K[j] = p.K[j]; tb.ldM[j] = (p.M[j] + 31) / 32 * 32;
+      const int64_t e = (int64_t)p.K[j] * tb.ldM[j];
+      maxe = e > maxe ? e : maxe;
+    }
+    hipLaunchKernelGGL(big_split_wT_kernel, dim3((unsigned)((maxe + 255) / 256), (unsigned)(top - 1)), dim3(256), 0, st, tb, params, planes);
+  }
   for (int j = top; j >= 1; --j) {
     const int K = p.K[j];
     LnbArgs la{du, dscores, saved + p.sv_x[j], saved + p.sv_mean[j], saved + p.sv_rstd[j], params + p.off_lnw[j], params + p.off_lnb[j],
@@ -346,7 +414,14 @@ int ultr_dnn_big_backward(const DnnPlan& p, const BwdPlan& bp, const float* para
       const ugemm::Dims d{N, K, M, K};
       const ugemm::APlain a{ws + bp.dz_off[j], N, M, M};
       const ugemm::EStore es{du, nullptr, K, 0};
-      e = ugemm::run<false>(d, a, params + p.off_w[j], es, st);
+      if (split_half) {
+        const int ldM = (M + 31) / 32 * 32;
+        const ugemm::Dims dh{N, K, M, ldM};
+        const _Float16* hi = planes + ultr_dgp_layer(p, j);
+        e = ugemm::run_h3(dh, a, hi, hi + (int64_t)K * ldM, es, st);
+      } else {
+        e = ugemm::run<false>(d, a, params + p.off_w[j], es, st);
+      }
       if (e != hipSuccess) return (int)e;
       e = lnb_dispatch<false>(la, rblocks, st, nullptr, j == 1 ? ev_stop : nullptr);
     }

@@ -545,6 +545,214 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(Dims d, AProd aprod,
   }
 }
 
+// ---- split-half mode (round 4): the same GEMM on the fp16 matrix cores with fp32-grade results -------------------------------------
+// C = epi(A' . W^T) with W given as TWO fp16 planes (hi = fp16(2^8 w), lo = fp16(2^8 w - hi); n-major [N][ldb halves], ldb a multiple of
+// 32, zero-padded - ultr_split_planes writes them once per step) and A split WHEN IT IS STAGED: the 32 contraction steps of a k-tile
+// of one row are scaled by a power of two that brings their largest magnitude just under 2^14, then written to LDS as hi / lo fp16
+// planes next to the row's inverse scale.  A k-tile is ONE 16x16x32 step: ah.wh + ah.wl + al.wh into a fresh accumulator (three
+// v_mfma_f32_16x16x32_f16, 48 cycles where the fp32 path issues eight v_mfma_f32_16x16x4_f32 = 256), which is then added to the
+// running fp32 sum with the row's scale (x 2^-8): per-TILE scaling, so the caller supplies no row statistics and rows whose
+// magnitude varies along k lose nothing.  Error budget as DESIGN section 4 (split-half products): 2^-22 relative per product term.
+// Same persistent schedule, staging pattern and LDS-transposed epilogue as the n-major fp32 kernel.
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+constexpr int LDH = BK + 8;  // halves per LDS row of a plane (80 bytes: 16 rows x b128 reads fall into distinct bank groups)
+#define UGEMM_H3_WSCALE 256.0f
+
+template <int BM, int BN, int WM, int WN, class AProd, class Epi>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_h3_kernel(Dims d, AProd aprod, const _Float16* __restrict__ Bhi,
+                                                               const _Float16* __restrict__ Blo, Epi epi) {
+  using C = Cfg<BM, BN, WM, WN, true>;
+  static_assert(C::STAGES == 2, "split-half mode: two LDS stages");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // per stage: A planes [2][BM][LDH] halves | B planes [2][BN][LDH] halves  (= the fp32 tiles' bytes); then the scales [2][BM]
+  _Float16* Ah = reinterpret_cast<_Float16*>(smem);
+  _Float16* Bh = reinterpret_cast<_Float16*>(smem + C::STAGES * C::A_FLOATS);
+  float* Sc = smem + C::STAGES * (C::A_FLOATS + C::B_FLOATS);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, q = lane >> 4;
+  const int wr = (wave / WN) * (BM / WM), wc = (wave % WN) * (BN / WN);
+  const int ncb = (d.N + BN - 1) / BN;
+  const int64_t nru = (d.R + 15) / 16;
+  const int64_t U = nru * ncb;
+  int64_t w = blockIdx.x;
+  const int64_t G = gridDim.x;
+  if ((G & 7) == 0) w = (w & 7) * (G >> 3) + (w >> 3);
+  int64_t u = w * U / G;
+  const int64_t u_end = (w + 1) * U / G;
+  if (u >= u_end) return;
+  const int64_t bplane = (int64_t)d.N * d.ldb;  // halves per plane
+  const __amdgpu_buffer_rsrc_t bhs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(Bhi), 0, (int)(bplane * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t bls = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(Blo), 0, (int)(bplane * 2), 0x00020000);
+  const int nk = (d.K + BK - 1) / BK;
+
+  int64_t r0 = 0, rend = 0;
+  int n0 = 0, m_units = 0;
+  constexpr int B_PIECES = BN * 4 / C::NT;  // 16-byte pieces (8 halves) per thread per plane per k-tile
+  static_assert(BN * 4 % C::NT == 0 && B_PIECES >= 1, "B staging divides evenly");
+  float4 areg[C::A_LOADS];
+  u32x4 bhr[B_PIECES], blr[B_PIECES];
+  const int k4 = (tid & 7) * 4;
+  typename AProd::Row arow[C::A_LOADS];
+  typename AProd::Cols acol;
+  auto begin_chunk = [&](int64_t uu) {
+    const int64_t cb = uu / nru, ru = uu - cb * nru;
+    int64_t m = u_end - uu;
+    if (m > BM / 16) m = BM / 16;
+    if (m > nru - ru) m = nru - ru;
+    m_units = (int)m;
+    r0 = ru * 16;
+    rend = r0 + 16 * m < d.R ? r0 + 16 * m : d.R;
+    n0 = (int)cb * BN;
+#pragma unroll
+    for (int j = 0; j < C::A_LOADS; ++j) arow[j] = aprod.row(r0 + ((tid + C::NT * j) >> 3), rend);
+  };
+  auto load_tile = [&](int k0) {
+    acol = aprod.cols(k0 + k4);
+#pragma unroll
+    for (int j = 0; j < C::A_LOADS; ++j) areg[j] = aprod.raw(arow[j], k0 + k4);
+#pragma unroll
+    for (int j = 0; j < B_PIECES; ++j) {
+      const int idx = tid + C::NT * j;
+      const int n = idx >> 2, kp = (idx & 3) * 8;
+      const bool ok = n0 + n < d.N && k0 + kp < d.ldb;
+      const unsigned off = ok ? (unsigned)(((int64_t)(n0 + n) * d.ldb + k0 + kp) * 2) : ULTR_OOB;
+      bhr[j] = __builtin_amdgcn_raw_buffer_load_b128(bhs, off, 0, 0);
+      blr[j] = __builtin_amdgcn_raw_buffer_load_b128(bls, off, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto store_tile = [&](int buf, int k0) {
+    _Float16* Ahb = Ah + (size_t)buf * (2 * C::A_FLOATS);          // (A_FLOATS floats = 2 * A_FLOATS halves per stage)
+    _Float16* Alb = Ahb + BM * LDH;
+    _Float16* Bhb = Bh + (size_t)buf * (2 * C::B_FLOATS);
+    _Float16* Blb = Bhb + BN * LDH;
+#pragma unroll
+    for (int j = 0; j < C::A_LOADS; ++j) {
+      const int idx = tid + C::NT * j, row = idx >> 3;
+      const float4 v = aprod.finish(arow[j], acol, k0 + k4, areg[j]);
+      // the largest magnitude of the row's 32 steps: the 8 threads of a row are 8 consecutive lanes
+      float am = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+      am = fmaxf(am, dpp_or<0xb1>(am, am));
+      am = fmaxf(am, dpp_or<0x4e>(am, am));
+      am = fmaxf(am, dpp_or<0x141>(am, am));  // row_half_mirror: lane i <-> 7 - i of its group of eight
+      int se = 267 - (int)((__float_as_uint(am) >> 23) & 0xffu);  // am * 2^(se - 127) < 2^14
+      se = se < 1 ? 1 : (se > 253 ? 253 : se);
+      const float rs = __uint_as_float((unsigned)se << 23);
+      const float a4[4] = {v.x * rs, v.y * rs, v.z * rs, v.w * rs};
+      h4v hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        hi[e] = (_Float16)a4[e];
+        lo[e] = (_Float16)(a4[e] - (float)hi[e]);
+      }
+      *reinterpret_cast<h4v*>(Ahb + row * LDH + k4) = hi;
+      *reinterpret_cast<h4v*>(Alb + row * LDH + k4) = lo;
+      if ((tid & 7) == 0) Sc[buf * BM + row] = __uint_as_float((unsigned)(254 - se) << 23) * (1.0f / UGEMM_H3_WSCALE);
+    }
+#pragma unroll
+    for (int j = 0; j < B_PIECES; ++j) {
+      const int idx = tid + C::NT * j;
+      const int n = idx >> 2, kp = (idx & 3) * 8;
+      *reinterpret_cast<u32x4*>(Bhb + n * LDH + kp) = bhr[j];
+      *reinterpret_cast<u32x4*>(Blb + n * LDH + kp) = blr[j];
+    }
+  };
+  f32x4 acc[C::RT][C::CT];
+
+  begin_chunk(u);
+  load_tile(0);
+  store_tile(0, 0);
+  lds_barrier();
+  for (;;) {
+#pragma unroll
+    for (int rt = 0; rt < C::RT; ++rt)
+#pragma unroll
+      for (int t = 0; t < C::CT; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int live_rt = (16 * m_units - wr + 15) / 16;
+    live_rt = live_rt < 0 ? 0 : (live_rt > C::RT ? C::RT : live_rt);
+    for (int t = 0; t < nk; ++t) {
+      if (t + 1 < nk) load_tile((t + 1) * BK);
+      if (live_rt > 0) {
+        const int buf = t & 1;
+        const _Float16* Ahb = Ah + (size_t)buf * (2 * C::A_FLOATS) + (wr + i) * LDH + 8 * q;
+        const _Float16* Bhb = Bh + (size_t)buf * (2 * C::B_FLOATS) + (wc + i) * LDH + 8 * q;
+        h8v bh[C::CT], bl[C::CT];
+#pragma unroll
+        for (int ct = 0; ct < C::CT; ++ct) {
+          bh[ct] = *reinterpret_cast<const h8v*>(Bhb + ct * 16 * LDH);
+          bl[ct] = *reinterpret_cast<const h8v*>(Bhb + BN * LDH + ct * 16 * LDH);
+        }
+#pragma unroll
+        for (int rt = 0; rt < C::RT; ++rt) {
+          if (rt < live_rt) {
+            const h8v ah = *reinterpret_cast<const h8v*>(Ahb + rt * 16 * LDH);
+            const h8v al = *reinterpret_cast<const h8v*>(Ahb + BM * LDH + rt * 16 * LDH);
+            const float4 sc = ld4(Sc + buf * BM + wr + 16 * rt + 4 * q);  // the scales of this lane's four output rows
+            const float scv[4] = {sc.x, sc.y, sc.z, sc.w};
+#pragma unroll
+            for (int ct = 0; ct < C::CT; ++ct) {
+              f32x4 tmp = {0.f, 0.f, 0.f, 0.f};
+              tmp = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ct], tmp, 0, 0, 0);
+              tmp = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ct], tmp, 0, 0, 0);
+              tmp = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ct], tmp, 0, 0, 0);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[rt][ct][r] = fmaf(tmp[r], scv[r], acc[rt][ct][r]);
+            }
+          }
+        }
+      }
+      if (t + 1 < nk) store_tile((t + 1) & 1, (t + 1) * BK);
+      lds_barrier();
+    }
+    // ---- the chunk's output through LDS (a lane holds one column of four tiles), as the n-major fp32 kernel ---------------
+    const int64_t e_r0 = r0, e_rend = rend;
+    const int e_n0 = n0;
+    const int64_t un = u + m_units;
+    const bool more = un < u_end;
+    if (more) begin_chunk(un);
+    float* Cs = smem;
+    constexpr int PIECES = BM * (BN / 4);
+    constexpr int PPT = PIECES / C::NT;
+    static_assert(PIECES % C::NT == 0, "epilogue pieces divide evenly");
+    typename Epi::Pre pre[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      const int idx = tid + C::NT * k;
+      const int row = idx / (BN / 4), c4 = (idx - row * (BN / 4)) * 4;
+      const int64_t r = e_r0 + row;
+      const int c = e_n0 + c4;
+      if (r < e_rend && c < d.N) pre[k] = epi.prefetch(r, c, d.N - c < 4 ? d.N - c : 4);
+    }
+#pragma unroll
+    for (int rt = 0; rt < C::RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wr + 16 * rt + 4 * q + r;
+#pragma unroll
+        for (int t = 0; t < C::CT; ++t) Cs[row * C::LDC + wc + 16 * t + i] = acc[rt][t][r];
+      }
+    lds_barrier();
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      const int idx = tid + C::NT * k;
+      const int row = idx / (BN / 4), c4 = (idx - row * (BN / 4)) * 4;
+      const int64_t r = e_r0 + row;
+      const int c = e_n0 + c4;
+      if (r < e_rend && c < d.N) {
+        const int nv = d.N - c < 4 ? d.N - c : 4;
+        epi(r, c, ld4(Cs + row * C::LDC + c4), nv, pre[k]);
+      }
+    }
+    if (!more) break;
+    lds_barrier();  // the tile in LDS has been read
+    load_tile(0);
+    store_tile(0, 0);
+    lds_barrier();
+    u = un;
+  }
+}
+
 #ifdef UGEMM_DEBUG_GRID
 static int g_ugemm_grid_mode = 0;
 #endif
@@ -614,6 +822,49 @@ inline hipError_t launch(const Dims& d, const AProd& aprod, const float* B, cons
     hipExtLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::NT), (uint32_t)lds, st, ev_start, ev_stop, 0, d, aprod, B, epi);
   else hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::NT), lds, st, d, aprod, B, epi);
   return hipGetLastError();
+}
+
+template <int BM, int BN, int WM, int WN, class AProd, class Epi>
+inline hipError_t launch_h3(const Dims& d, const AProd& aprod, const _Float16* Bhi, const _Float16* Blo, const Epi& epi, hipStream_t st) {
+  using C = Cfg<BM, BN, WM, WN, true>;
+  auto kern = gemm_h3_kernel<BM, BN, WM, WN, AProd, Epi>;
+  constexpr int stage_floats = C::STAGES * (C::A_FLOATS + C::B_FLOATS) + C::STAGES * BM;
+  const size_t lds = (size_t)(C::C_FLOATS > stage_floats ? C::C_FLOATS : stage_floats) * sizeof(float);
+  const int dev = current_device();
+  static std::atomic<bool> attr[UGEMM_MAX_DEV];
+  if (lds > 64 * 1024 && !attr[dev].load(std::memory_order_acquire)) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr[dev].store(true, std::memory_order_release);
+  }
+  static std::atomic<int> per_cu_dev[UGEMM_MAX_DEV];
+  int per_cu = per_cu_dev[dev].load(std::memory_order_relaxed);
+  if (per_cu == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), C::NT, lds) != hipSuccess || nb < 1) {
+      nb = (int)((160 * 1024) / lds);
+      const int by_waves = 32 / (WM * WN);
+      if (nb > by_waves) nb = by_waves;
+      if (nb < 1) nb = 1;
+    }
+    per_cu = nb;
+    per_cu_dev[dev].store(nb, std::memory_order_relaxed);
+  }
+  const int64_t slots = (int64_t)per_cu * device_cus();
+  const int64_t nru = (d.R + 15) / 16;
+  const int ncb = (d.N + BN - 1) / BN;
+  const int64_t chunks = ((nru + BM / 16 - 1) / (BM / 16)) * ncb;
+  const int64_t grid = chunks <= slots ? chunks : slots;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::NT), lds, st, d, aprod, Bhi, Blo, epi);
+  return hipGetLastError();
+}
+
+// split-half mode: C = epi(A' . W^T), W as hi / lo fp16 planes [N][d.ldb halves] (ldb a multiple of 32, zero-padded; d.K = the real
+// contraction length)
+template <class AProd, class Epi>
+inline hipError_t run_h3(const Dims& d, const AProd& aprod, const _Float16* Bhi, const _Float16* Blo, const Epi& epi, hipStream_t st) {
+  if (d.N > 64) return launch_h3<64, 128, 4, 2>(d, aprod, Bhi, Blo, epi, st);
+  return launch_h3<64, 64, 4, 1>(d, aprod, Bhi, Blo, epi, st);
 }
 
 // C = epi(A' . B).  Tile choice (tools/gemm_tile_ubench.hip): 64 x 128 with 8 waves (a wave = one 16-row tile x 64

@@ -86,6 +86,22 @@ struct DnnPlan {
   int64_t sv_rstd[ULTR_MAXL];  // [N]
   int64_t sv_total;
 };
+// per-layer forward with split-half GEMMs (ultr_dnn_big.hip): hi | lo planes of 2^8 W_j, [M_j][ldK_j] halves (ldK_j = K_j rounded up to 32,
+// zero-padded), rebuilt by every such forward behind the saved activations.  Host-side offsets (the plans travel as kernel arguments:
+// nothing a kernel does not read belongs in them): float offset of the region inside `saved`, layer j's planes in HALVES from there
+__host__ static inline int64_t ultr_fwp_off(const DnnPlan& p) { return (p.sv_total + 4 + 7) & ~(int64_t)7; }
+__host__ static inline int64_t ultr_fwp_layer(const DnnPlan& p, int j) {
+  int64_t h = 0;
+  for (int i = 0; i < j; ++i) h += 2 * (int64_t)p.M[i] * ((p.K[i] + 31) / 32 * 32);
+  return h;
+}
+__host__ static inline int64_t ultr_fwp_halves(const DnnPlan& p) { return ultr_fwp_layer(p, p.nl - 1); }
+// ... and of 2^8 W_j^T ([K_j][ldM_j], 1 <= j < nl-1) for the split-half dgrad GEMMs of the per-layer backward, at BwdPlan::dgp_off
+__host__ static inline int64_t ultr_dgp_layer(const DnnPlan& p, int j) {
+  int64_t h = 0;
+  for (int i = 1; i < j; ++i) h += 2 * (int64_t)p.K[i] * ((p.M[i] + 31) / 32 * 32);
+  return h;
+}
 
 // position of element (output column c, contraction index k) of a fragment-major matrix with `ntrips` = ceil(Kc / 32) trips
 __host__ __device__ inline int64_t ultr_sw_index(int c, int k, int ntrips) {
@@ -161,6 +177,7 @@ struct BwdPlan {
   int64_t l0part_off;       // [nmb_0 * nsplit_0][2][K_0]
   int64_t lfold_off;        // [64][tail <= 4096]: first level of the loss-partial fold when there are more than 1024 partials
   int lf_chunks, lf_len;    // 0: one workgroup folds all; else lf_chunks workgroups x lf_len partials (set by the launcher)
+  int64_t dgp_off;          // per-layer backward with split-half dgrad GEMMs (ultr_dnn_big.hip): the planes of W_j^T (ultr_dgp_layer)
   int64_t wgd_part_off;     // direct weight gradients (WgdPlan): layer-0 column partials [ceil(K_0 / 32)][ceil(M_0 / 16)][96]
   int64_t sumsq_off;        // [n_red_blocks]
   int n_red_blocks;
@@ -231,9 +248,9 @@ void ultr_make_red_plan(const DnnPlan& p, const BwdPlan& bp, RedPlan* rp); // ul
 bool ultr_dnn_big_ok(const DnnPlan& p, int64_t N, int64_t n_docs);
 int ultr_dnn_big_forward(const DnnPlan& p, const float* params, const float* wt, const float* features, int64_t n_docs,
                          const int32_t* docids, int B, int L, float* scores, float* saved, hipStream_t st, hipEvent_t ev_start,
-                         hipEvent_t ev_stop);
+                         hipEvent_t ev_stop, bool split_half);
 int ultr_dnn_big_backward(const DnnPlan& p, const BwdPlan& bp, const float* params, const float* saved, const float* dscores, float* ws,
-                          hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop);
+                          hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, bool split_half);
 
 // library-internal: the small-batch NA/IPW step as one fused forward+loss+backward launch (+ weight gradients +
 // reduction); ULTR_E_UNSUPPORTED = shape does not qualify, use the separate calls

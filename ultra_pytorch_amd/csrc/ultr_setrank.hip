@@ -46,6 +46,13 @@ struct SrPlan {
   int64_t sv_A[8], sv_s1[8], sv_m1[8], sv_r1[8], sv_out1[8], sv_f[8], sv_s2[8], sv_m2[8], sv_r2[8];
   int64_t sv_lse[8];  // [T, H] attention row statistic (log-sum-exp of the scaled scores)
   int64_t sv_total;
+  // split-half weight planes (round 4; ultr_gemm.h run_h3): behind the saved activations, rebuilt by every forward - for every
+  // weight matrix W[M][K] with M >= 16 the planes hi | lo of 2^8 W as [M][ldK] halves (forward: Y = X W^T) and of W^T as [K][ldM]
+  // halves (dgrad: dX = dY W), ldK / ldM = K / M rounded up to 32, zero-padded.  Offsets in HALVES from sv_planes (a float offset).
+  int64_t sv_planes, planes_halves;
+  struct SplitMat { int64_t off; int M, K, ldK, ldM; int64_t f_off, t_off; };
+  int n_split;
+  SplitMat split[32];
   // workspace (floats)
   int maxw;
   int64_t ws_g[3];   // three [T, maxw] gradient buffers
@@ -112,6 +119,20 @@ bool make_plan(const ultr_setrank_desc* c, int64_t T, SrPlan* p) {
   }
   p->sv_oh = take(T * dff);
   p->sv_total = s;
+  {
+    int64_t h = 0;
+    auto add = [&](int64_t off, int64_t M, int64_t K) {
+      SrPlan::SplitMat& m = p->split[p->n_split++];
+      m.off = off; m.M = (int)M; m.K = (int)K;
+      m.ldK = (int)((K + 31) / 32 * 32); m.ldM = (int)((M + 31) / 32 * 32);
+      m.f_off = h; h += 2 * M * m.ldK;
+      m.t_off = h; h += 2 * K * m.ldM;
+    };
+    add(p->w1, dff, F); add(p->w2, d, dff); add(p->wo1, dff, d);
+    for (int l = 0; l < p->nl; ++l) { add(p->lay[l].wd, d, d); add(p->lay[l].wf1, dff, d); add(p->lay[l].wf2, d, dff); }
+    p->sv_planes = (p->sv_total + 4 + 7) & ~(int64_t)7;
+    p->planes_halves = h;
+  }
   p->maxw = (int)(F > d ? F : d);
   if (dff > p->maxw) p->maxw = (int)dff;
   int64_t w = 0;
@@ -1509,6 +1530,51 @@ __global__ __launch_bounds__(256) void sr_head_bwd_kernel(const float* __restric
   if (threadIdx.x == 0) dst[K] = ((sm[0][256] + sm[1][256]) + sm[2][256]) + sm[3][256];
 }
 
+// ---- split-half weight planes ------------------------------------------------------------------------------------------------
+struct SrSplitTable {
+  int n;
+  SrPlan::SplitMat m[32];
+};
+// blockIdx.y = 2 * matrix + phase (0: the forward planes [M][ldK], 1: the transposed planes [K][ldM]); one element per thread
+__global__ __launch_bounds__(256) void sr_split_planes_kernel(SrSplitTable tb, const float* __restrict__ params, _Float16* __restrict__ planes) {
+  const SrPlan::SplitMat m = tb.m[blockIdx.y >> 1];
+  const int phase = blockIdx.y & 1;
+  const int rows = phase ? m.K : m.M, ld = phase ? m.ldM : m.ldK, cols = phase ? m.M : m.K;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)rows * ld) return;
+  const int r = (int)(e / ld), c = (int)(e - (int64_t)r * ld);
+  float w = 0.f;
+  if (c < cols) w = params[m.off + (phase ? ((int64_t)c * m.K + r) : ((int64_t)r * m.K + c))] * UGEMM_H3_WSCALE;
+  const _Float16 hi = (_Float16)w, lo = (_Float16)(w - (float)hi);  // |w| >= 128 overflows to inf: NaN results, loud
+  _Float16* dst = planes + (phase ? m.t_off : m.f_off);
+  dst[e] = hi;
+  dst[(int64_t)rows * ld + e] = lo;
+}
+// the planes of the step in flight (set by ultr_setrank_forward / _backward around their GEMM calls)
+struct SrH3Ctx {
+  const float* params;
+  const _Float16* planes;
+  const SrPlan* plan;
+};
+thread_local SrH3Ctx g_sr_h3 = {nullptr, nullptr, nullptr};
+int sr_h3_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("ULTR_SR_H3");
+    v = (e && *e) ? atoi(e) : 1;
+  }
+  return v;
+}
+const SrPlan::SplitMat* sr_find_split(const float* W, int M, int K) {
+  if (g_sr_h3.plan == nullptr || g_sr_h3.planes == nullptr || !sr_h3_enabled()) return nullptr;
+  const int64_t off = W - g_sr_h3.params;
+  for (int k = 0; k < g_sr_h3.plan->n_split; ++k) {
+    const SrPlan::SplitMat& m = g_sr_h3.plan->split[k];
+    if (m.off == off && m.M == M && m.K == K) return &m;
+  }
+  return nullptr;
+}
+
 bool vec_ok(const void* a, const void* w, const void* c, int K, int ld_out) {
   (void)w;
   return K % 4 == 0 && ld_out % 4 == 0 && ((((uintptr_t)a | (uintptr_t)c) & 15) == 0);
@@ -1516,9 +1582,14 @@ bool vec_ok(const void* a, const void* w, const void* c, int K, int ld_out) {
 // row-major  Y[T, M] = act(X[T, K] . W[M, K]^T + bias)      (bias may be NULL; relu 0 / 1)
 int gemm_xwT(const float* X, const float* W, const float* bias, float* Y, int64_t T, int K, int M, int relu, hipStream_t st) {
   if (M >= 16 && vec_ok(X, W, Y, K, M) && T * (K > M ? K : M) * 4 < ((int64_t)1 << 31)) {
-    const ugemm::Dims d{T, M, K, K};
     const ugemm::APlain a{X, T, K, K};
     const ugemm::EBiasAct e{Y, bias, M, relu ? 1 : -1};
+    if (const SrPlan::SplitMat* sm = sr_find_split(W, M, K)) {  // split-half planes of W: the product on the fp16 matrix cores
+      const ugemm::Dims dh{T, M, K, sm->ldK};
+      const _Float16* hi = g_sr_h3.planes + sm->f_off;
+      return ugemm::run_h3(dh, a, hi, hi + (int64_t)M * sm->ldK, e, st) == hipSuccess ? 0 : ULTR_E_UNSUPPORTED;
+    }
+    const ugemm::Dims d{T, M, K, K};
     return ugemm::run<true>(d, a, W, e, st) == hipSuccess ? 0 : ULTR_E_UNSUPPORTED;
   }
   if (M == 1 && !relu) {
@@ -1533,18 +1604,28 @@ int gemm_xwT(const float* X, const float* W, const float* bias, float* Y, int64_
 bool gemm_xwT_res(const float* X, const float* W, const float* bias, const float* res, float* S, int64_t T, int K, int M, hipStream_t st) {
   if (!(M >= 16 && M % 4 == 0 && vec_ok(X, W, S, K, M) && (((uintptr_t)res) & 15) == 0 && T * (K > M ? K : M) * 4 < ((int64_t)1 << 31)))
     return false;
-  const ugemm::Dims d{T, M, K, K};
   const ugemm::APlain a{X, T, K, K};
   const ugemm::EBiasRes e{S, bias, res, M};
+  if (const SrPlan::SplitMat* sm = sr_find_split(W, M, K)) {
+    const ugemm::Dims dh{T, M, K, sm->ldK};
+    const _Float16* hi = g_sr_h3.planes + sm->f_off;
+    return ugemm::run_h3(dh, a, hi, hi + (int64_t)M * sm->ldK, e, st) == hipSuccess;
+  }
+  const ugemm::Dims d{T, M, K, K};
   return ugemm::run<true>(d, a, W, e, st) == hipSuccess;
 }
 // row-major  dX[T, K] = (accumulate ? dX : 0) + dY[T, M] . W[M, K], then zeroed where mask <= 0 (mask may be NULL)
 int gemm_dyw(const float* dY, const float* W, float* dX, const float* mask, int64_t T, int K, int M, int accumulate, hipStream_t st) {
   if (M % 4 == 0 && K >= 16 && vec_ok(dY, W, dX, K, K) && (mask == nullptr || ((uintptr_t)mask & 15) == 0) &&
       T * (K > M ? K : M) * 4 < ((int64_t)1 << 31)) {
-    const ugemm::Dims d{T, K, M, K};
     const ugemm::APlain a{dY, T, M, M};
     const ugemm::EStore e{dX, mask, K, accumulate};
+    if (const SrPlan::SplitMat* sm = K >= 16 ? sr_find_split(W, M, K) : nullptr) {  // the planes of W^T: [K][ldM], contraction over M
+      const ugemm::Dims dh{T, K, M, sm->ldM};
+      const _Float16* hi = g_sr_h3.planes + sm->t_off;
+      return ugemm::run_h3(dh, a, hi, hi + (int64_t)K * sm->ldM, e, st) == hipSuccess ? 0 : ULTR_E_UNSUPPORTED;
+    }
+    const ugemm::Dims d{T, K, M, K};
     return ugemm::run<false>(d, a, W, e, st) == hipSuccess ? 0 : ULTR_E_UNSUPPORTED;
   }
   hipLaunchKernelGGL(sr_gemm_dyw_ref_kernel, dim3((unsigned)((T * K + 255) / 256)), dim3(256), 0, st, dY, W, dX, mask, T, K, M, accumulate);
@@ -1741,7 +1822,7 @@ extern "C" int64_t ultr_setrank_param_count(const ultr_setrank_desc* c) {
 }
 extern "C" int64_t ultr_setrank_saved_bytes(const ultr_setrank_desc* c, int64_t n_rows) {
   SrPlan p;
-  return (n_rows >= 0 && make_plan(c, n_rows, &p)) ? (p.sv_total + 4) * (int64_t)sizeof(float) : 0;
+  return (n_rows >= 0 && make_plan(c, n_rows, &p)) ? (p.sv_planes + (p.planes_halves + 1) / 2 + 4) * (int64_t)sizeof(float) : 0;
 }
 extern "C" int64_t ultr_setrank_workspace_bytes(const ultr_setrank_desc* c, int64_t n_rows) {
   SrPlan p;
@@ -1763,6 +1844,24 @@ extern "C" int ultr_setrank_forward(const ultr_setrank_desc* c, const float* par
   float* sv = (float*)saved;
   const unsigned rblk = (unsigned)((T + SR_ROWS - 1) / SR_ROWS);
   const int F = p.F, d = p.d, dff = p.dff;
+  // split-half planes of every weight matrix (the weights change with every update: rebuilt per forward, ~2 MB, one small launch)
+  struct H3Scope {
+    ~H3Scope() { g_sr_h3 = {nullptr, nullptr, nullptr}; }
+  } h3scope;
+  if (sr_h3_enabled()) {
+    _Float16* planes = reinterpret_cast<_Float16*>(sv + p.sv_planes);
+    SrSplitTable tb;
+    tb.n = p.n_split;
+    int64_t maxe = 0;
+    for (int k = 0; k < p.n_split; ++k) {
+      tb.m[k] = p.split[k];
+      const int64_t a = (int64_t)p.split[k].M * p.split[k].ldK, b = (int64_t)p.split[k].K * p.split[k].ldM;
+      maxe = a > maxe ? a : maxe;
+      maxe = b > maxe ? b : maxe;
+    }
+    hipLaunchKernelGGL(sr_split_planes_kernel, dim3((unsigned)((maxe + 255) / 256), (unsigned)(2 * p.n_split)), dim3(256), 0, st, tb, params, planes);
+    g_sr_h3 = {params, planes, &p};
+  }
   // input LayerNorm on the gathered rows, then the embedding FFN (SetRank.py:134-135, 146)
   if (F % 4 == 0 && F <= 1024 && ((uintptr_t)features & 15) == 0)
     hipLaunchKernelGGL(sr_ln_gather_v4_kernel, dim3(rblk), dim3(SR_ROWS * 64), 0, st, features, docids, n_docs, (int)batch, L, T, F,
@@ -1839,6 +1938,10 @@ extern "C" int ultr_setrank_backward(const ultr_setrank_desc* c, const float* pa
                             (int)lds_att) != hipSuccess)
       return ULTR_E_UNSUPPORTED;
   }
+  struct H3Scope {
+    ~H3Scope() { g_sr_h3 = {nullptr, nullptr, nullptr}; }
+  } h3scope;
+  if (sr_h3_enabled()) g_sr_h3 = {params, reinterpret_cast<const _Float16*>(sv + p.sv_planes), &p};  // built by this step's forward
   // ---- output FFN:  s = oh wo2^T + bo2,  oh = relu(x_nl Wo1^T + bo1) ----------------------------------------------
   FoldScope folds(ws + p.ws_arena, p.arena_floats);  // every fold below is queued; ONE launch at the end
   if (dff <= 256 && p.bo2 == p.wo2 + dff) {  // one pass: G1 = d oh [T, dff] (ReLU mask fused), d wo2 | d bo2 partials
