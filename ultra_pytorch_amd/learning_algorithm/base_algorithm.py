@@ -76,7 +76,11 @@ class BaseAlgorithm(object):
 
     def create_input_feed(self, input_feed, list_size):
         """numpy feed -> device tensors: features [n_docs,F] f32, docids [L,B] i32, labels [L,B] f32.
-        A feed from input_layer.DeviceClickFeed already holds device tensors (resident dataset): nothing to move."""
+        A feed from input_layer.DeviceClickFeed already holds device tensors (resident dataset): nothing to move.
+        LIFETIME: self.letor_features / docid_inputs / labels_LB are VIEWS of one reused device staging buffer and the returned
+        host labels a view of the reused pinned buffer - valid until the next create_input_feed() of this object (train() and
+        validation() consume them before they return; the reference allocates fresh tensors per batch, base_algorithm.py:169-186,
+        and nothing of it keeps them either).  Whoever wants to keep a batch must .clone() it."""
         if input_feed.get("device_feed", False):
             self.n_docs, self.batch_size = int(input_feed["n_docs"]), int(input_feed["batch_size"])
             self.letor_features = input_feed["features"]
@@ -143,7 +147,10 @@ class BaseAlgorithm(object):
             from .. import parallel
             from ..hip_ops import tail_floats
             self._dp_comm_tried = True
-            self._dp_comm = parallel.PeerComm.create(self.process_group, self.model.shape.n_params + tail_floats(L), self.cuda)
+            # sized for the LONGEST list this object can see (the step tail is 4 + 2 L floats): a later engine with a longer
+            # list - validation-shaped training batches, max_candidate_num > selection_bias_cutoff - must fit the same buffer
+            lmax = max(int(L), int(getattr(self, "max_candidate_num", L) or L), int(getattr(self, "rank_list_size", L) or L))
+            self._dp_comm = parallel.PeerComm.create(self.process_group, self.model.shape.n_params + tail_floats(lmax), self.cuda)
         key = (B, L)
         eng = self._train_engines.get(key)
         if eng is None:
