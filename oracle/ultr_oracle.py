@@ -140,11 +140,16 @@ def ranking_scores(params: torch.Tensor, feature_size: int, hidden: Sequence[int
 
 
 def dnn_backward_manual(params: np.ndarray, feature_size: int, hidden: Sequence[int], x: np.ndarray,
-                        dscore: np.ndarray, act: str = "elu") -> np.ndarray:
+                        dscore: np.ndarray, act: str = "elu", abs_terms: bool = False) -> np.ndarray:
     """Closed-form backward of dnn_forward (what autograd does for DNN.py:41-55) in numpy
     float64-free fp32 — this is the written-out spec the HIP backward kernels implement.
-    Returns the flat gradient."""
+    Returns the flat gradient.
+    abs_terms=True: the same walk in float64, returning per entry the SUM OF THE ABSOLUTE VALUES of the per-row terms the
+    entry is a sum of (|dz|^T |u| for a weight, sum |dz| for a bias, sum |du xhat| / sum |du| for the LayerNorm pair) - the
+    scale accumulation-order differences of an fp32 evaluation are proportional to (tests/test_gpu_full_size.py)."""
     assert act in ("elu", "relu", "tanh", "sigmoid")
+    if abs_terms:
+        return _dnn_backward_abs_terms(params, feature_size, hidden, x, dscore, act)
     x = np.asarray(x, np.float32)
     dims = layer_dims(feature_size, hidden)
     lay = {n: (s, o) for n, s, o in param_layout(feature_size, hidden)}
@@ -191,6 +196,49 @@ def dnn_backward_manual(params: np.ndarray, feature_size: int, hidden: Sequence[
                 "tanh": lambda: 1.0 - a * a, "sigmoid": lambda: a * (1.0 - a)}[act]()
         dz = (dx * dact).astype(np.float32)
     return grads
+
+
+def _dnn_backward_abs_terms(params, feature_size, hidden, x, dscore, act):
+    f8 = np.float64
+    params = np.asarray(params, f8)
+    dims = layer_dims(feature_size, hidden)
+    lay = {n: (s, o) for n, s, o in param_layout(feature_size, hidden)}
+    get = lambda n: params[lay[n][1]:lay[n][1] + int(np.prod(lay[n][0]))].reshape(lay[n][0])
+    xs, xhats, rstds, us = [], [], [], []
+    h = np.asarray(x, f8)
+    for j, (k, m) in enumerate(dims):
+        mu = h.mean(axis=1, keepdims=True)
+        r = 1.0 / np.sqrt(((h - mu) ** 2).mean(axis=1, keepdims=True) + LN_EPS)
+        xhat = (h - mu) * r
+        u = xhat * get("sequential.layer_norm%d.weight" % j) + get("sequential.layer_norm%d.bias" % j)
+        z = u @ get("sequential.linear%d.weight" % j).T + get("sequential.linear%d.bias" % j)
+        xs.append(h), xhats.append(xhat), rstds.append(r), us.append(u)
+        if j != len(dims) - 1:
+            h = {"elu": lambda: np.where(z > 0, z, np.expm1(np.minimum(z, 0))), "relu": lambda: np.maximum(z, 0),
+                 "tanh": lambda: np.tanh(z), "sigmoid": lambda: 1.0 / (1.0 + np.exp(-z))}[act]()
+    out = np.zeros(params.shape, f8)
+
+    def put(n, g):
+        s, o = lay[n]
+        out[o:o + int(np.prod(s))] = g.reshape(-1)
+
+    dz = np.asarray(dscore, f8).reshape(-1, 1)
+    for j in reversed(range(len(dims))):
+        W = get("sequential.linear%d.weight" % j)
+        put("sequential.linear%d.weight" % j, np.abs(dz).T @ np.abs(us[j]))
+        put("sequential.linear%d.bias" % j, np.abs(dz).sum(axis=0))
+        du = dz @ W
+        put("sequential.layer_norm%d.weight" % j, np.abs(du * xhats[j]).sum(axis=0))
+        put("sequential.layer_norm%d.bias" % j, np.abs(du).sum(axis=0))
+        if j == 0:
+            break
+        dxhat = du * get("sequential.layer_norm%d.weight" % j)
+        dx = rstds[j] * (dxhat - dxhat.mean(axis=1, keepdims=True) - xhats[j] * (dxhat * xhats[j]).mean(axis=1, keepdims=True))
+        a = xs[j]
+        dact = {"elu": lambda: np.where(a > 0, 1.0, a + 1.0), "relu": lambda: (a > 0).astype(f8),
+                "tanh": lambda: 1.0 - a * a, "sigmoid": lambda: a * (1.0 - a)}[act]()
+        dz = dx * dact
+    return out
 
 
 # --------------------------------------------------------------------------------------

@@ -176,3 +176,9 @@ def test_library_has_no_packed_fp32_instructions():
     if found is None:
         pytest.skip("no llvm-objdump on this box")
     assert found == [], found[:5]
+
+
+def test_graft_entry_build_passes():
+    """The driver's build check (round 4: its hard-coded ABI number went stale when the header moved on)."""
+    import __graft_entry__ as g
+    g.build()
