@@ -48,7 +48,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 den
 
 
 def h3_products_on():
-    return any(os.environ.get(k, "1") != "0" for k in ("ULTR_FB_H3", "ULTR_FWD_H3", "ULTR_BWD_H3"))
+    return any(os.environ.get(k, "1") != "0" for k in ("ULTR_FB_H3", "ULTR_FWD_H3", "ULTR_BWD_H3", "ULTR_WG_H3"))
 PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E spec peak
 # profiling slots of the library (ultr_prof.h); slot 7 = forward + loss + backward fused in one launch (small batches)
 KNAMES = ["dnn_fwd_kernel", "loss_kernel", "dnn_bwd_kernel", "dnn_wgrad_kernel", "grad_reduce_kernel", "update_kernel",
@@ -140,7 +140,11 @@ def issued_matrix_work(cfg, slot):
             h3 = knob_b and j < nl - 1 and k >= 256 and k % 32 == 0 and (fused_all if slot == 7 else True)
             f16, f32 = (f16 + 3 * fl, f32) if h3 else (f16, f32 + fl)
     if slot == 3:
-        f32 = 2.0 * N * sum(k * m for k, m in dims[:-1])  # weight gradients: fp32 MFMAs only
+        fl = 2.0 * N * sum(k * m for k, m in dims[:-1])
+        # weight gradients: the split-half launch (dnn_wgrad_h3_kernel) from ULTR_WG_H3_MIN_ROWS rows when every layer allows 16-byte paths
+        h3 = os.environ.get("ULTR_WG_H3", "1") != "0" and all(k % 4 == 0 and m % 4 == 0 for k, m in dims[:-1]) and \
+            (os.environ.get("ULTR_WG_H3", "1") == "2" or N >= int(os.environ.get("ULTR_WG_H3_MIN_ROWS", "4096")))
+        f16, f32 = (3 * fl, 0.0) if h3 else (0.0, fl)
     return f16, f32
 
 
@@ -655,14 +659,14 @@ def main():
     # split-half fp16 products are fp32-accurate, this line is for a reader who wants the all-fp32-MFMA figure
     fp32_mfma = None
     if dnn and world == 1 and not args.no_extras and h3_products_on():
-        keep = {k: os.environ.get(k) for k in ("ULTR_FB_H3", "ULTR_FWD_H3", "ULTR_BWD_H3")}
+        keep = {k: os.environ.get(k) for k in ("ULTR_FB_H3", "ULTR_FWD_H3", "ULTR_BWD_H3", "ULTR_WG_H3")}
         try:
             for k in keep:
                 os.environ[k] = "0"
             e32 = engs["fp32_mfma"] = eng_cls(shape, B, L, device, algo=cfg["algo"], learning_rate=LR, max_gradient_norm=CLIP)  # re-reads the knobs
             t32 = timed_loop(e32, max(100, min(args.steps, 1000)), True)
             fp32_mfma = {"queries_per_sec": B / t32, "ms_per_step": 1e3 * t32,
-                         "what": "ULTR_FB_H3=0 ULTR_FWD_H3=0 ULTR_BWD_H3=0: every product on v_mfma_f32_16x16x4_f32; loss read on the host every step"}
+                         "what": "ULTR_FB_H3=0 ULTR_FWD_H3=0 ULTR_BWD_H3=0 ULTR_WG_H3=0: every product on v_mfma_f32_16x16x4_f32; loss read on the host every step"}
         finally:
             for k, v in keep.items():
                 if v is None:

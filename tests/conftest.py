@@ -25,7 +25,7 @@ def pytest_sessionfinish(session, exitstatus):
     margins.flush()
 
 
-H3_KNOBS = ("ULTR_FB_H3", "ULTR_FWD_H3", "ULTR_BWD_H3")
+H3_KNOBS = ("ULTR_FB_H3", "ULTR_FWD_H3", "ULTR_BWD_H3", "ULTR_WG_H3")  # (the last one: the weight gradients of large batches)
 
 
 @pytest.fixture(params=["split_half", "fp32_mfma"])
@@ -49,11 +49,16 @@ def mfma_mode(request, monkeypatch):
         pass
 
 
-@pytest.fixture(params=["slabs", "direct"])
+@pytest.fixture(params=["slabs", "direct", "split_half"])
 def wgrad_path(request, monkeypatch):
-    """The two weight-gradient paths behind the fused small-batch kernel: 64 x 64 tiles x row splits + a reduction launch (the
-    default) and the direct one-launch kernel of ultr_wgd.hip (ULTR_WGD=1; not faster at config 2, kept under test)."""
+    """The weight-gradient paths: 64 x 64 register tiles x row splits + a reduction launch (the default below 4096 rows), the
+    direct one-launch kernel of ultr_wgd.hip behind the fused kernel (ULTR_WGD=1; not faster at config 2, kept under test), and
+    dnn_wgrad_h3_kernel - 128 x 128 LDS-staged blocks on the fp16 matrix cores with split operands, the default from 4096 rows,
+    forced onto these small shapes with ULTR_WG_H3=2.  (mfma_mode "fp32_mfma" sets ULTR_WG_H3=0 and wins: the combination
+    fp32_mfma x split_half runs the register kernel again.)"""
     monkeypatch.setenv("ULTR_WGD", "1" if request.param == "direct" else "0")
+    if request.param == "split_half" and os.environ.get("ULTR_WG_H3") != "0":
+        monkeypatch.setenv("ULTR_WG_H3", "2")
     yield request.param
     monkeypatch.undo()
     try:

@@ -245,7 +245,7 @@ def _softmax_case(F, hidden, B, L):
                                           (136, [512, 256, 128], 21, 20),  # config 3's layers: split-half where a layer has >= 256 outputs, fp32 elsewhere
                                           (40, [512, 256], 7, 10),         # 512-wide rows
                                           (24, [64, 32, 32], 20, 8)])      # no split-half copies at all
-def test_separate_kernel_step_shapes_match_oracle(F, hidden, B, L, mfma_mode, monkeypatch):
+def test_separate_kernel_step_shapes_match_oracle(F, hidden, B, L, mfma_mode, wgrad_path, monkeypatch):
     """The same step through the SEPARATE forward / backward kernels (dnn_fwd_kernel, dnn_bwd2_kernel: what every batch too
     large for the fused kernel runs, forced here with ULTR_NO_FUSED_FB=1) - including their split-half (fp16 hi/lo) products -
     against the oracle: scores, loss, gradient, norm, updated parameters, and the scores of the step after."""

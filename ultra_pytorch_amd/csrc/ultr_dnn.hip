@@ -2759,20 +2759,11 @@ template <int N, class F>
 __device__ __forceinline__ void wg_static_for(F&& f) {
   wg_static_for_impl<N>(f, std::make_integer_sequence<int, N>{});
 }
-template <bool VEC>
-__global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, const float* __restrict__ params,
-                                                        const float* __restrict__ features, int64_t n_docs,
-                                                        const int32_t* __restrict__ docids, int B, int L,
-                                                        const float* __restrict__ saved, float* __restrict__ ws,
-                                                        int vecf, float* __restrict__ grads,
-                                                        const float* __restrict__ loss_part, int n_loss_part, int tail,
-                                                        EarlyReport er, CommDev cd) {
-  // ONE dynamic LDS array: [4][64*64] cross-wave reduction | [4][64] bias partials | [rows_per_split] doc ids
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float (*red)[64 * 64] = reinterpret_cast<float (*)[64 * 64]>(smem);
-  float (*bred)[64] = reinterpret_cast<float (*)[64]>(smem + 4 * 64 * 64);
-  int* sm_ids = reinterpret_cast<int*>(smem + 4 * 64 * 64 + 4 * 64);
-  const int64_t N = bp.N;
+// The spare workgroups of the weight-gradient launch (blockIdx >= bp.wgrad_blocks): vector-slab fold, loss-partial fold + early
+// loss report.  Shared by dnn_wgrad_kernel and dnn_wgrad_h3_kernel; 256 threads, `smem` >= 256 floats.
+__device__ __forceinline__ void wg_spare_roles(const DnnPlan& p, const BwdPlan& bp, float* __restrict__ smem, float* __restrict__ ws,
+                                               float* __restrict__ grads, const float* __restrict__ loss_part, int n_loss_part,
+                                               int tail, const EarlyReport& er, const CommDev& cd) {
   if ((int)blockIdx.x >= bp.wgrad_blocks && (int)blockIdx.x < bp.wgrad_blocks + bp.vred_blocks) {
     // spare workgroups: fold the nrb per-row-block vector slabs (LayerNorm gamma/beta, scorer) into ONE slab while
     // the matrix blocks run, so that the reduction kernel's critical path is not a 160-deep serial sum
@@ -2785,7 +2776,7 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
       ws[bp.vred_off + e] = ((smem[lane] + smem[64 + lane]) + smem[128 + lane]) + smem[192 + lane];
     return;
   }
-  if ((int)blockIdx.x >= bp.wgrad_blocks + bp.vred_blocks) {
+  {
     // last spare workgroup(s): fold the loss partials into the step tail grads[P ..] (so the kernels after this one read
     // it with plain loads; the reduction launch then only folds gradient slabs).  More than 1024 partials (one per list
     // for the stand-alone loss stages): bp.lf_chunks workgroups fold bp.lf_len partials each into a scratch row and the
@@ -2830,6 +2821,26 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
         __hip_atomic_store(reinterpret_cast<uint32_t*>(er.host) + 10, er.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
+    return;
+  }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, const float* __restrict__ params,
+                                                        const float* __restrict__ features, int64_t n_docs,
+                                                        const int32_t* __restrict__ docids, int B, int L,
+                                                        const float* __restrict__ saved, float* __restrict__ ws,
+                                                        int vecf, float* __restrict__ grads,
+                                                        const float* __restrict__ loss_part, int n_loss_part, int tail,
+                                                        EarlyReport er, CommDev cd) {
+  // ONE dynamic LDS array: [4][64*64] cross-wave reduction | [4][64] bias partials | [rows_per_split] doc ids
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float (*red)[64 * 64] = reinterpret_cast<float (*)[64 * 64]>(smem);
+  float (*bred)[64] = reinterpret_cast<float (*)[64]>(smem + 4 * 64 * 64);
+  int* sm_ids = reinterpret_cast<int*>(smem + 4 * 64 * 64 + 4 * 64);
+  const int64_t N = bp.N;
+  if ((int)blockIdx.x >= bp.wgrad_blocks) {
+    wg_spare_roles(p, bp, smem, ws, grads, loss_part, n_loss_part, tail, er, cd);
     return;
   }
   TRACE_STAMP(8);
@@ -3103,6 +3114,311 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
 }
 
 // ------------------------------------------------------------------------------------------------
+// Weight gradients on the fp16 matrix cores with split (hi / lo) operands   (BwdPlan::wg_h3)
+// ------------------------------------------------------------------------------------------------
+// dnn_wgrad_kernel contracts on v_mfma_f32_16x16x4_f32 straight out of registers and sits at ~68 % of the fp32 matrix peak at
+// config 4 (profiles/r04_cfg4pair_pmc.md): nothing left but the instruction.  Here dW_j = dz_j^T u_j runs on
+// v_mfma_f32_16x16x32_f16 with both operands split, a.b = ah.bh + ah.bl + al.bh (22 bits of mantissa each, fp32 accumulation):
+// 3 x 16 cycles per 16 x 16 x 32 step where the fp32 instruction needs 8 x 32.  What has to be different from the forward / dgrad
+// products (PipeH3): the contraction index is the ROW here, so a per-row scale does not factor out of the sum.  The scale is per
+// (half-block, workgroup) instead - one power of two for a 32-row x 64-column block of an operand, chosen from the block's
+// largest magnitude (< 2^14 after scaling) and only ever lowered while the workgroup walks its rows: when a later block raises
+// the maximum the accumulators are multiplied by the (exact) ratio and the walk goes on.  An element keeps 1e-5 relative
+// accuracy down to 2^-22 of the largest element the workgroup has seen in its 64 columns; below that its error is 2^-25 on the
+// scale of that maximum, i.e. invisible in a sum that contains the large terms.
+// Workgroup = 4 waves on a 128 (m) x 128 (k) block of ONE dW_j and one row split.  Per 32-row step: wave w loads a 32 x 64 fp32
+// half-block (w = 0, 1: dz columns m0 + 64 w ..; w = 2, 3: u columns k0 + 64 (w - 2) ..) - each lane 8 rows x 4 columns, so the
+// transposition into the MFMA operand order (8 consecutive rows of one column = 16 bytes) happens in registers - applies
+// LayerNorm where `saved` holds x_j, finds the block maximum, splits and writes the two fp16 planes to LDS ([column][32 rows],
+// row stride WH_LDH halves); then wave (wm, wk) = (w >> 1, w & 1) multiplies its 64 x 64 sub-block: 16 ds_read_b128 + 48 MFMAs.
+// Operands go once from L2 to the CU per 128 x 128 block - a quarter of the L2 -> CU traffic of the 64 x 64 register kernel,
+// which re-reads every dz / u element once per 64 columns of the other operand.  Two workgroups share a CU (74 KB of LDS
+// each): one converts while the other multiplies.  The epilogue is dnn_wgrad_kernel's (slabs per row split, bias sums, layer-0
+// gamma / beta fold), so the reduction launch and everything behind it are unchanged.
+#define WH_LDH 40
+#ifndef WH_D
+#define WH_D 2  // steps in flight (register sets of 8 x 16 bytes per lane)
+#endif
+#define WH_RED_BYTES 65536
+#define WH_LDS_BYTES (WH_RED_BYTES + 32 + 2 * 64 * 4 + 2 * 16 * 64 * 4)
+struct WhStep {
+  float4 v[8];
+};
+__global__ __launch_bounds__(256, 2) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan bp, const float* __restrict__ params,
+                                                              const float* __restrict__ features, int64_t n_docs,
+                                                              const int32_t* __restrict__ docids, int B, int L,
+                                                              const float* __restrict__ saved, float* __restrict__ ws,
+                                                              float* __restrict__ grads, const float* __restrict__ loss_part,
+                                                              int n_loss_part, int tail, EarlyReport er, CommDev cd) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((int)blockIdx.x >= bp.wgrad_blocks) {
+    wg_spare_roles(p, bp, smem, ws, grads, loss_part, n_loss_part, tail, er, cd);
+    return;
+  }
+  int j = 0;
+  while (j + 1 < p.nl - 1 && (int)blockIdx.x >= bp.wl[j + 1].blk_begin) ++j;
+  const WgradLayer wl = bp.wl[j];
+  const int local = blockIdx.x - wl.blk_begin;
+  const int split = local % wl.nsplit;
+  const int tile = local / wl.nsplit;
+  const int mb2 = tile / wl.nkb2, kb2 = tile - mb2 * wl.nkb2;
+  const int M = wl.M, K = wl.K;
+  const int m0 = mb2 * 128, k0 = kb2 * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t N = bp.N;
+  const int rps = wl.rows_per_split;
+  const int64_t nbeg = (int64_t)split * rps;
+  const int rows = (int)((N - nbeg) < (int64_t)rps ? (N - nbeg) : (int64_t)rps);
+  const int nsteps = (rows + 31) >> 5;
+  const bool prenorm = bp.wg_prenorm != 0 || (j == 0 && bp.l0g != 0 && saved[p.sv_total] != 0.f);
+  const bool l0g = (j == 0) && bp.l0g != 0;
+  const bool gather = (j == 0) && !prenorm;
+  const bool xform = !prenorm;
+  // ---- LDS: planes [4 half-blocks][hi, lo][64 columns][WH_LDH] halves | per-row tables; the epilogue's four 64 x 64 fp32 blocks
+  // overlay both; behind them: exponents, bias sums, the layer-0 fold scratch
+  _Float16* planes = reinterpret_cast<_Float16*>(smem);
+  float2* sm_stat = reinterpret_cast<float2*>(smem + 10240);               // [rps] (mean, rstd)
+  int* sm_ids = reinterpret_cast<int*>(smem + 10240 + 2 * 2048);           // [rps]
+  int* sm_se = reinterpret_cast<int*>(smem + WH_RED_BYTES / 4);            // [4] final scale exponents
+  int* sm_bump = sm_se + 4;                                                // [4] exponent decrease of the step in LDS
+  float* sm_bsum = smem + WH_RED_BYTES / 4 + 8;                            // [2][64]
+  float* sm_fold = sm_bsum + 128;                                          // [2][16][64]
+  if (xform) {
+    const float* mp = saved + p.sv_mean[j];
+    const float* rp = saved + p.sv_rstd[j];
+    for (int r = tid; r < 32 * nsteps; r += 256) sm_stat[r] = (r < rows) ? make_float2(mp[nbeg + r], rp[nbeg + r]) : make_float2(0.f, 0.f);
+  }
+  if (gather) {
+    for (int r = tid; r < 32 * nsteps; r += 256) {
+      int id = -1;
+      if (r < rows) {
+        const int64_t n = nbeg + r;
+        const int b = (int)(n / L), l = (int)(n % L);
+        const int64_t d = docids[(int64_t)l * B + b];
+        if (d >= 0 && d < n_docs) id = (int)d;
+      }
+      sm_ids[r] = id;
+    }
+  }
+  // ---- staging role of this wave --------------------------------------------------------------------------------------------
+  const bool isA = wave < 2;
+  const int c16 = lane & 15, rg = lane >> 4;
+  const int ncols = isA ? M : K;
+  const int col = (isA ? m0 + 64 * wave : k0 + 64 * (wave - 2)) + 4 * c16;
+  const bool colok = col < ncols;
+  const Src src = isA ? make_src(ws + wl.dz_off, N * M)
+                      : (gather ? make_src(features, n_docs * K) : make_src(saved + p.sv_x[j], N * K));
+  float4 gam = make_float4(0.f, 0.f, 0.f, 0.f), bet = gam;
+  if (!isA && xform && colok) {
+    if (l0g) gam = make_float4(1.f, 1.f, 1.f, 1.f);
+    else {
+      gam = ld4(params + p.off_lnw[j] + col);
+      bet = ld4(params + p.off_lnb[j] + col);
+    }
+  }
+  _Float16* myplane = planes + (size_t)wave * 2 * 64 * WH_LDH + (4 * c16) * WH_LDH + 8 * rg;
+  auto load_step = [&](int t, WhStep& s) __attribute__((always_inline)) {
+    const int r0 = 32 * t + 8 * rg;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      unsigned off = ULTR_OOB;
+      if (gather && !isA) {
+        const int id = (r0 + r < 32 * nsteps) ? sm_ids[r0 + r] : -1;
+        if (id >= 0 && colok) off = (unsigned)(((int64_t)id * K + col) * 4);
+      } else if (r0 + r < rows && colok) {
+        off = (unsigned)(((nbeg + r0 + r) * ncols + col) * 4);
+      }
+      s.v[r] = buf_ld4(src, off);
+    }
+  };
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  int se_run = 253;  // biased exponent of the running scale 2^(se - 127)
+  fbh8 ch[4], cl[4];
+  int bump = 0;
+  auto convert = [&](int t, const WhStep& s) __attribute__((always_inline)) {
+    float v[8][4];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      v[r][0] = s.v[r].x; v[r][1] = s.v[r].y; v[r][2] = s.v[r].z; v[r][3] = s.v[r].w;
+    }
+    if (isA) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bsum[c] += v[r][c];
+    } else if (xform) {
+      const float g[4] = {gam.x, gam.y, gam.z, gam.w}, be[4] = {bet.x, bet.y, bet.z, bet.w};
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float2 st = sm_stat[32 * t + 8 * rg + r];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[r][c] = (v[r][c] - st.x) * st.y * g[c] + be[c];
+      }
+    }
+    float am = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) am = fmaxf(am, fabsf(v[r][c]));
+    am = wave_max(am);
+    int se = 267 - (int)((__float_as_uint(am) >> 23) & 0xffu);  // am * 2^(se - 127) < 2^14  (fb_h3_scale)
+    se = se < 1 ? 1 : (se > 253 ? 253 : se);
+    se = __builtin_amdgcn_readfirstlane(se);
+    bump = 0;
+    if (se < se_run) {
+      bump = se_run - se;
+      se_run = se;
+    }
+    const float rs = __uint_as_float((unsigned)se_run << 23);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float a = v[r][c] * rs;
+        const _Float16 hi = (_Float16)a;
+        ch[c][r] = hi;
+        cl[c][r] = (_Float16)(a - (float)hi);
+      }
+  };
+  auto publish = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      *reinterpret_cast<fbh8*>(myplane + c * WH_LDH) = ch[c];
+      *reinterpret_cast<fbh8*>(myplane + 64 * WH_LDH + c * WH_LDH) = cl[c];
+    }
+    if (lane == 0) sm_bump[wave] = bump;
+  };
+  // ---- compute role: the 64 x 64 sub-block (wm, wk) ---------------------------------------------------------------------------
+  const int wm = wave >> 1, wk = wave & 1;
+  const int i = lane & 15, q = lane >> 4;
+  const _Float16* pa = planes + (size_t)wm * 2 * 64 * WH_LDH + i * WH_LDH + 8 * q;
+  const _Float16* pb = planes + (size_t)(2 + wk) * 2 * 64 * WH_LDH + i * WH_LDH + 8 * q;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto multiply = [&]() __attribute__((always_inline)) {
+    const int d = __builtin_amdgcn_readfirstlane(sm_bump[wm] + sm_bump[2 + wk]);
+    if (d != 0) {  // an operand's scale went down by 2^d: bring the sums along (exact)
+      const float f = d > 126 ? 0.f : __uint_as_float((unsigned)(127 - d) << 23);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] *= f;
+    }
+    fbh8 bh[4], bl[4];
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) {
+      bh[tb] = *reinterpret_cast<const fbh8*>(pb + tb * 16 * WH_LDH);
+      bl[tb] = *reinterpret_cast<const fbh8*>(pb + 64 * WH_LDH + tb * 16 * WH_LDH);
+    }
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta) {
+      const fbh8 ah = *reinterpret_cast<const fbh8*>(pa + ta * 16 * WH_LDH);
+      const fbh8 al = *reinterpret_cast<const fbh8*>(pa + 64 * WH_LDH + ta * 16 * WH_LDH);
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = fb_mfma_h(ah, bh[tb], acc[ta][tb]);
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = fb_mfma_h(ah, bl[tb], acc[ta][tb]);
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = fb_mfma_h(al, bh[tb], acc[ta][tb]);
+    }
+  };
+  lds_barrier();  // tables
+  WhStep ring[WH_D];
+#pragma unroll
+  for (int d = 0; d < WH_D - 1; ++d) load_step(d, ring[d]);
+  auto step = [&](int t, WhStep& cur, WhStep& nxt) __attribute__((always_inline)) {
+    load_step(t + WH_D - 1, nxt);  // (past the last step: every offset is out of range - zeros, no traffic)
+    convert(t, cur);
+    lds_barrier();  // every wave is done with the planes of step t - 1
+    publish();
+    lds_barrier();
+    multiply();
+  };
+  int t = 0;
+  for (; t + WH_D <= nsteps; t += WH_D)
+    wg_static_for<WH_D>([&](auto I) { step(t + decltype(I)::value, ring[decltype(I)::value], ring[(decltype(I)::value + WH_D - 1) % WH_D]); });
+  wg_static_for<WH_D - 1>([&](auto I) {
+    if (t + decltype(I)::value < nsteps) step(t + decltype(I)::value, ring[decltype(I)::value], ring[(decltype(I)::value + WH_D - 1) % WH_D]);
+  });
+  // ---- epilogue ---------------------------------------------------------------------------------------------------------------
+  if (lane == 0) sm_se[wave] = se_run;
+  if (isA) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      bsum[c] += __shfl_xor(bsum[c], 16, 64);
+      bsum[c] += __shfl_xor(bsum[c], 32, 64);
+    }
+    if (rg == 0) st4(sm_bsum + 64 * wave + 4 * c16, make_float4(bsum[0], bsum[1], bsum[2], bsum[3]));
+  }
+  lds_barrier();  // last products read, exponents and bias sums visible: the planes may be overwritten
+  {
+    const float ia = __uint_as_float((unsigned)(254 - sm_se[wm]) << 23), ib = __uint_as_float((unsigned)(254 - sm_se[2 + wk]) << 23);
+    float* red = smem + wave * 4096;
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(16 * ta + 4 * q + r) * 64 + 16 * tb + i] = (acc[ta][tb][r] * ia) * ib;
+  }
+  lds_barrier();
+  float* slab = ws + wl.slab_off + (int64_t)split * ((int64_t)M * K + M);
+  for (int s = 0; s < 4; ++s) {
+    const int sm_ = s >> 1, sk = s & 1;
+    const int mB = m0 + 64 * sm_, kB = k0 + 64 * sk;
+    if (mB >= M || kB >= K) continue;  // (uniform)
+    const float* red = smem + s * 4096;
+    const int kq = kB + (tid & 15) * 4;
+    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = g4, l0pg = g4, l0pb = g4;
+    if (l0g && kq < K) {
+      g4 = ld4(params + p.off_lnw[0] + kq);
+      b4 = ld4(params + p.off_lnb[0] + kq);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int ml = (tid >> 4) + 16 * it;
+      const int m = mB + ml;
+      float4 v = ld4(red + ml * 64 + (tid & 15) * 4);
+      if (m < M && kq < K) {
+        if (l0g) {
+          // G -> dW_0 = gamma o G + S_m * beta;  partial column sums of W_0 o G and W_0 * S_m for d gamma_0 / d beta_0
+          const float Sm = sm_bsum[64 * sm_ + ml];
+          const float4 w4 = ld4(params + p.off_w[0] + (int64_t)m * K + kq);
+          l0pg.x += w4.x * v.x; l0pg.y += w4.y * v.y; l0pg.z += w4.z * v.z; l0pg.w += w4.w * v.w;
+          l0pb.x += w4.x * Sm; l0pb.y += w4.y * Sm; l0pb.z += w4.z * Sm; l0pb.w += w4.w * Sm;
+          v.x = g4.x * v.x + b4.x * Sm; v.y = g4.y * v.y + b4.y * Sm; v.z = g4.z * v.z + b4.z * Sm; v.w = g4.w * v.w + b4.w * Sm;
+        }
+#if WG_WT
+        st4_stream(slab + (int64_t)m * K + kq, v);
+#else
+        st4(slab + (int64_t)m * K + kq, v);
+#endif
+      }
+    }
+    if (kb2 == 0 && sk == 0 && tid < 64 && mB + tid < M) slab[(int64_t)M * K + mB + tid] = sm_bsum[64 * sm_ + tid];
+    if (l0g) {
+      float* pgs = sm_fold;            // [16][64]
+      float* pbs = sm_fold + 16 * 64;  // [16][64]
+      st4(pgs + (tid >> 4) * 64 + (tid & 15) * 4, l0pg);
+      st4(pbs + (tid >> 4) * 64 + (tid & 15) * 4, l0pb);
+      lds_barrier();
+      if (tid < 128) {
+        const int which = tid >> 6, c = tid & 63;
+        const float* srcp = which ? pbs : pgs;
+        float a = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) a += srcp[g * 64 + c];
+        if (kB + c < K) ws[bp.l0part_off + ((int64_t)((2 * mb2 + sm_) * wl.nsplit + split) * 2 + which) * K + kB + c] = a;
+      }
+      lds_barrier();
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Slab reduction -> flat gradient, step tail, sum-of-squares partials
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float block_sum_256(float v, float* sm) {
@@ -3252,7 +3568,7 @@ __global__ __launch_bounds__(64) void grad_sumsq_kernel(int64_t P, const float* 
 // per knob per launch is host time on the critical path of a ~50 us step.  ultr_config_reload() re-reads them (tests and
 // the A/B tools flip knobs inside one process).
 struct Knobs {
-  int fwd_r, bwd_r, wgrad_wgs, fwd_nw, bwd_nw, no_vec, no_l0g, bwd_v1, no_fused_fb, fb_max_wg_per_cu, fwd_q4, big_fwd, big_bwd, fb_h3, fwd_h3, bwd_h3, wgd, wgd_max_rows;
+  int fwd_r, bwd_r, wgrad_wgs, fwd_nw, bwd_nw, no_vec, no_l0g, bwd_v1, no_fused_fb, fb_max_wg_per_cu, fwd_q4, big_fwd, big_bwd, fb_h3, fwd_h3, bwd_h3, wgd, wgd_max_rows, wg_h3, wg_h3_min_rows, wg_h3_wgs;
   bool loaded;
 };
 static Knobs g_knobs = {};
@@ -3285,6 +3601,9 @@ static void knobs_load() {
   // (17.7 us against 12.3 + 5.0 us + one launch gap; step 50.2 against 48.4 us - profiles/r04_cfg2_attempts.md)
   k.wgd = env_read("ULTR_WGD", 0);
   k.wgd_max_rows = env_read("ULTR_WGD_MAX_ROWS", 4096);
+  k.wg_h3 = env_read("ULTR_WG_H3", 0);                    // weight gradients on the fp16 matrix cores (split-half operands); 2: any batch size
+  k.wg_h3_min_rows = env_read("ULTR_WG_H3_MIN_ROWS", 4096);
+  k.wg_h3_wgs = env_read("ULTR_WG_H3_WGS", 0);
   k.loaded = true;
   g_knobs = k;
 }
@@ -3483,7 +3802,7 @@ static int bwd_rows_per_wg(const DnnPlan& p, int64_t N) {
   return ((N + 15) / 16 > 512 && bwd_lds_bytes(p, 32) <= 160 * 1024) ? 32 : 16;
 }
 
-bool ultr_make_bwd_plan(const DnnPlan& p, int64_t N, BwdPlan* bp) {
+bool ultr_make_bwd_plan(const DnnPlan& p, int64_t N, BwdPlan* bp, int wg_mode) {
   memset(bp, 0, sizeof(*bp));
   bp->N = N;
   bp->rblk = bwd_rows_per_wg(p, N);
@@ -3515,36 +3834,47 @@ bool ultr_make_bwd_plan(const DnnPlan& p, int64_t N, BwdPlan* bp) {
     bp->du_off = off; off += N * kmax; off = (off + 3) & ~(int64_t)3;
   }
   // wgrad geometry
-  int tiles = 0;
-  for (int j = 0; j < p.nl - 1; ++j) tiles += ((p.M[j] + 63) / 64) * ((p.K[j] + 63) / 64);
+  int tiles = 0, tiles2 = 0;
+  bool h3w = wg_mode != 0 && knobs().wg_h3 != 0 && p.nl >= 2 && (knobs().wg_h3 >= 2 || N >= knobs().wg_h3_min_rows);
+  for (int j = 0; j < p.nl - 1; ++j) {
+    tiles += ((p.M[j] + 63) / 64) * ((p.K[j] + 63) / 64);
+    tiles2 += ((p.M[j] + 127) / 128) * ((p.K[j] + 127) / 128);
+    if (p.M[j] % 4 != 0 || p.K[j] % 4 != 0 || p.off_w[j] % 4 != 0) h3w = false;
+  }
+  bp->wg_h3 = h3w ? 1 : 0;
   // workgroups over all hidden Linears: about one per CU for a small batch (every workgroup is a chain of latencies and a
   // second one on the CU only slows both), about two per CU otherwise - measured (tools/sweep_wgrad.sh, bench_configs.py):
   // N = 2560 rows: 224 -> 12.3 us, 392 -> 12.7, 448 -> 13.0;  N = 10240: 224 -> 36, 392 -> 33, 448 -> 30 us
-  const int target = knobs().wgrad_wgs > 0 ? knobs().wgrad_wgs : (N < 4096 ? 224 : 448);
+  // Split-half launch (wg_h3): 128 x 128 blocks, a quarter of the tiles - every row split is one more slab of P floats to write and
+  // to fold, so the target stays near one workgroup per CU
+  const int target = h3w ? (knobs().wg_h3_wgs > 0 ? knobs().wg_h3_wgs : 320) : knobs().wgrad_wgs > 0 ? knobs().wgrad_wgs : (N < 4096 ? 224 : 448);
+  const int64_t rps_cap = h3w ? 2048 : 4096;  // the per-row tables of a split live in LDS
   int blk = 0;
   for (int j = 0; j < p.nl - 1; ++j) {
     WgradLayer& w = bp->wl[j];
     w.M = p.M[j]; w.K = p.K[j];
     w.nmb = (w.M + 63) / 64; w.nkb = (w.K + 63) / 64;
-    int nsplit = tiles > 0 ? (target + tiles - 1) / tiles : 1;
+    w.nmb2 = (w.M + 127) / 128; w.nkb2 = (w.K + 127) / 128;
+    const int tl = h3w ? tiles2 : tiles;
+    int nsplit = tl > 0 ? (target + tl - 1) / tl : 1;
     if (nsplit < 1) nsplit = 1;
-    const int by_cap = (int)((N + 4095) / 4096);  // the doc-id table of a split lives in LDS: at most 4096 rows
+    const int by_cap = (int)((N + rps_cap - 1) / rps_cap);  // the doc-id table of a split lives in LDS: at most 4096 rows
     if (nsplit < by_cap) nsplit = by_cap;
     // XCD-friendly split count.  Blocks are numbered split-fastest and consecutive block ids go round-robin to the 8 XCDs, so
     // with nsplit a divisor or a multiple of 8 each XCD works on ONE row chunk of a layer at a time and the blocks that
     // re-read the same dz / x rows (every 64 x 64 tile of that chunk) meet in one L2.  Misaligned counts fetch every operand
     // once per tile from HBM: config 4 (rocprofv3) 311 MB per launch at nsplit = 4, 115 us - nsplit 3 / 5: 154 / 158 us;
     // config 3 at nsplit = 7: 342 MB for 74 MB of operands, HBM-bound at 5.6 TB/s.
-    if (knobs().wgrad_wgs <= 0) nsplit = nsplit <= 1 ? 1 : nsplit <= 2 ? 2 : nsplit <= 5 ? 4 : nsplit <= 11 ? 8 : (nsplit + 4) / 8 * 8;
+    if (knobs().wgrad_wgs <= 0 || h3w) nsplit = nsplit <= 1 ? 1 : nsplit <= 2 ? 2 : nsplit <= 5 ? 4 : nsplit <= 11 ? 8 : (nsplit + 4) / 8 * 8;
     if (nsplit < by_cap) nsplit = (by_cap + 7) / 8 * 8;
     int64_t rps = (N + nsplit - 1) / nsplit;
     rps = (rps + 31) / 32 * 32;  // 8 rows per wave-trip
     if (rps < 64) rps = 64;
-    if (rps > 4096) rps = 4096;
+    if (rps > rps_cap) rps = rps_cap;
     w.rows_per_split = (int)rps;
     w.nsplit = (int)((N + rps - 1) / rps);
     w.blk_begin = blk;
-    blk += w.nmb * w.nkb * w.nsplit;
+    blk += (h3w ? w.nmb2 * w.nkb2 : w.nmb * w.nkb) * w.nsplit;
     w.vec = (w.M % 4 == 0 && w.K % 4 == 0) ? 1 : 0;
     w.dz_off = bp->dz_off[j];
     w.slab_off = off; off += (int64_t)w.nsplit * ((int64_t)w.M * w.K + w.M); off = (off + 3) & ~(int64_t)3;
@@ -3641,6 +3971,11 @@ extern "C" int64_t ultr_dnn_bwd_workspace_bytes(const ultr_dnn_desc* d, int64_t 
   // worst case over the env-tunable geometry: size for both row-block choices
   ultr_make_bwd_plan(p, n_rows, &bp);
   int64_t t = bp.total;
+  if (bp.wg_h3) {  // the launcher may fall back to the register kernel's geometry (unaligned pointers)
+    BwdPlan b0;
+    ultr_make_bwd_plan(p, n_rows, &b0, 0);
+    t = b0.total > t ? b0.total : t;
+  }
   const int64_t extra = ((n_rows + 15) / 16) * (int64_t)bp.vlen;  // if rblk were 16
   return (t + extra + 1024) * (int64_t)sizeof(float);
 }
@@ -3835,7 +4170,6 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
   DnnPlan p;
   BwdPlan bp;
   if (!ultr_make_dnn_plan(d, N, &p) || !ultr_make_bwd_plan(p, N, &bp)) return ULTR_E_BADARG;
-  if (fused_rb > 0) bp.nrb = (int)((N + fused_rb - 1) / fused_rb);  // vector slabs / loss partials: one per fused block
   const bool l0g_ok = p.nl >= 2 && knobs().no_l0g == 0;
   const int tail = (int)ultr_tail_len(list_size);
   if (tail > 4096) return ULTR_E_UNSUPPORTED;
@@ -3846,6 +4180,8 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
   hipError_t e = hipSuccess;
   float* ws = (float*)bwd_ws;
   const bool av = all_vec(p, vm, N, n_docs) && knobs().no_vec == 0;
+  if (bp.wg_h3 && !av) ultr_make_bwd_plan(p, N, &bp, 0);  // the split-half weight gradients take 16-byte paths only
+  if (fused_rb > 0) bp.nrb = (int)((N + fused_rb - 1) / fused_rb);  // vector slabs / loss partials: one per fused block
   const bool big = fused_rb == 0 && dscores != nullptr && av && l0g_ok && ultr_dnn_big_ok(p, N, n_docs) &&
                    knobs().big_bwd != 0 && (big_bwd_wanted(p, N) || lds > 160 * 1024);
   if (lds > 160 * 1024 && !big) return ULTR_E_UNSUPPORTED;
@@ -3915,7 +4251,27 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
     const int rc = ultr_wgd_launch(p, bp, params, (const float*)saved, ws, grads, lp, nlp, tail, (int)ultr_red_blocks(p.P, tail), st);
     if (rc != ULTR_E_UNSUPPORTED) return rc;
   }
-  {
+  if (bp.wg_h3) {
+    UltrProfScope prof(ULTR_K_WGRAD, st);
+    e = set_lds(dnn_wgrad_h3_kernel, (size_t)WH_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    const dim3 wgrid(bp.wgrad_blocks + bp.vred_blocks + (bp.lf_chunks > 0 ? bp.lf_chunks : 1));
+    EarlyReport er = g_ultr_early;
+    CommDev cd;
+    memset(&cd, 0, sizeof(cd));
+    if (g_ultr_step_xchg.comm != nullptr && g_ultr_step_xchg.er.host != nullptr && bp.lf_chunks == 0 &&
+        ultr_comm_dev(g_ultr_step_xchg.comm, g_ultr_step_xchg.step, p.P + tail, &cd)) {
+      er = g_ultr_step_xchg.er;  // (see the register kernel's launch below)
+      g_ultr_step_xchg.er.host = nullptr;
+    } else {
+      cd.world = 0;
+    }
+    if (bp.lf_chunks > 0) er.host = nullptr;
+    ULTR_LAUNCH(prof, dnn_wgrad_h3_kernel, wgrid, dim3(256), (size_t)WH_LDS_BYTES, st, p, bp, params, features, n_docs, docids, (int)batch,
+                (int)list_size, (const float*)saved, ws, grads, lp, nlp, tail, er, cd);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+  } else {
     UltrProfScope prof(ULTR_K_WGRAD, st);
     int maxrps = 0;
     for (int j = 0; j < p.nl - 1; ++j) maxrps = bp.wl[j].rows_per_split > maxrps ? bp.wl[j].rows_per_split : maxrps;

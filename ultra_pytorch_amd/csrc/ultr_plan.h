@@ -146,6 +146,8 @@ struct WgradLayer {
   int rows_per_split;  // multiple of 16; each of the 4 waves takes rows_per_split/4
   int blk_begin;       // first blockIdx of this layer
   int vec;             // 1: float4 path legal (M%4==0, K%4==0, aligned bases)
+  int nmb2, nkb2;      // BwdPlan::wg_h3: 128 x 128 output blocks of dnn_wgrad_h3_kernel (nmb / nkb keep counting 64 x 64 blocks:
+                       // the layer-0 column partials and the slab layout are indexed by those)
   int64_t dz_off;      // dz_j in bwd_ws  [N, M]
   int64_t slab_off;    // slabs in bwd_ws [nsplit][M*K + M]
 };
@@ -174,6 +176,10 @@ struct BwdPlan {
   // its copies in `saved` serve the weight gradients only): u_j = LayerNorm_j output for j >= 1, xhat_0 (l0g) or u_0 for j = 0.
   // The wgrad loop then issues two loads per 16 MFMAs instead of four and applies no transform.
   int wg_prenorm;
+  // 1: the geometry of wl[] (blocks, row splits, slabs) is the one of dnn_wgrad_h3_kernel - weight gradients on the fp16 matrix
+  // cores with split (hi / lo) operands, 128 x 128 blocks staged through LDS (ultr_dnn.hip).  Chosen by ultr_make_bwd_plan from
+  // the shapes and ULTR_WG_H3; the launcher re-plans with wg_mode 0 when the pointers do not allow the 16-byte paths.
+  int wg_h3;
   int64_t l0part_off;       // [nmb_0 * nsplit_0][2][K_0]
   int64_t lfold_off;        // [64][tail <= 4096]: first level of the loss-partial fold when there are more than 1024 partials
   int lf_chunks, lf_len;    // 0: one workgroup folds all; else lf_chunks workgroups x lf_len partials (set by the launcher)
@@ -240,7 +246,7 @@ struct RedPlan {
 
 struct ultr_dnn_desc;
 bool ultr_make_dnn_plan(const ultr_dnn_desc* d, int64_t N, DnnPlan* p);  // ultr_dnn.hip
-bool ultr_make_bwd_plan(const DnnPlan& p, int64_t N, BwdPlan* bp);         // ultr_dnn.hip
+bool ultr_make_bwd_plan(const DnnPlan& p, int64_t N, BwdPlan* bp, int wg_mode = -1);  // ultr_dnn.hip; wg_mode 0: never the split-half weight gradients
 void ultr_make_red_plan(const DnnPlan& p, const BwdPlan& bp, RedPlan* rp); // ultr_dnn.hip
 
 // library-internal, ultr_dnn_big.hip: the per-layer (un-fused) training forward / row-local backward for big batches
