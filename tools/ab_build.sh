@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 mkdir -p ultra_pytorch_amd/lib/variants
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-gpu-rdc $flags ultra_pytorch_amd/csrc/*.hip \
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-gpu-rdc -Xclang -target-feature -Xclang -packed-fp32-ops $flags ultra_pytorch_amd/csrc/*.hip \
     -o ultra_pytorch_amd/lib/variants/libultr_$name.so &
 done
 wait

@@ -3135,14 +3135,30 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
 // which re-reads every dz / u element once per 64 columns of the other operand.  Two workgroups share a CU (74 KB of LDS
 // each): one converts while the other multiplies.  The epilogue is dnn_wgrad_kernel's (slabs per row split, bias sums, layer-0
 // gamma / beta fold), so the reduction launch and everything behind it are unchanged.
-#define WH_LDH 40
-#ifndef WH_D
-#define WH_D 2  // steps in flight (register sets of 8 x 16 bytes per lane)
+#define WH_LDH 48  // halves per column of a plane: 32 contraction rows + 16 pad = 96 bytes; with the 16-byte slot index XORed with
+                   // (column >> 2) & 3 the operand reads (ds_read_b128, lane (i, q) -> column i, slot q) are conflict-free and the
+                   // staging writes (lane (c16, rg) -> column 4 c16 + c, slot rg) 2-way (13 -> 16 cycles): brute-forced over the
+                   // lane groups of MI355X_MICROARCH.md's LDS table; the first layout (80 bytes, no XOR: reads 2-way, writes 4-way)
+                   // spent 1 800 of 4 600 cycles per step between the two barriers around the plane writes
+#ifndef WH_NOLOAD
+#define WH_NOLOAD 0
 #endif
-#define WH_RED_BYTES 65536
-#define WH_LDS_BYTES (WH_RED_BYTES + 32 + 2 * 64 * 4 + 2 * 16 * 64 * 4)
+#ifndef WH_SCHED_SPLIT
+#define WH_SCHED_SPLIT 1
+#endif
+#ifndef WH_NOCONV
+#define WH_NOCONV 0
+#endif
+#ifndef WH_NOMFMA
+#define WH_NOMFMA 0
+#endif
+#define WH_ROWS_CAP 2048
+#define WH_PLANES_BYTES (4 * 2 * 64 * WH_LDH * 2)
+#define WH_TAB_ROWS (WH_ROWS_CAP + 64)
+#define WH_MAIN_BYTES (WH_PLANES_BYTES + WH_TAB_ROWS * 12)  // planes | (mean, rstd) per row | doc id per row; >= the epilogue's 4 x 16 KB
+#define WH_LDS_BYTES (WH_MAIN_BYTES + 32 + 2 * 64 * 4)
 struct WhStep {
-  float4 v[8];
+  u32x4 v[8];
 };
 __global__ __launch_bounds__(256, 2) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan bp, const float* __restrict__ params,
                                                               const float* __restrict__ features, int64_t n_docs,
@@ -3155,12 +3171,14 @@ __global__ __launch_bounds__(256, 2) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan
     wg_spare_roles(p, bp, smem, ws, grads, loss_part, n_loss_part, tail, er, cd);
     return;
   }
+  const int lin = ((int)blockIdx.x & 7) * bp.wg_chunk + ((int)blockIdx.x >> 3);  // BwdPlan::wg_chunk
+  if (lin >= bp.wg_live) return;
+  const int split = lin / bp.wg_tiles2;
+  const int tix = lin - split * bp.wg_tiles2;
   int j = 0;
-  while (j + 1 < p.nl - 1 && (int)blockIdx.x >= bp.wl[j + 1].blk_begin) ++j;
+  while (j + 1 < p.nl - 1 && tix >= bp.wl[j + 1].blk_begin) ++j;
   const WgradLayer wl = bp.wl[j];
-  const int local = blockIdx.x - wl.blk_begin;
-  const int split = local % wl.nsplit;
-  const int tile = local / wl.nsplit;
+  const int tile = tix - wl.blk_begin;
   const int mb2 = tile / wl.nkb2, kb2 = tile - mb2 * wl.nkb2;
   const int M = wl.M, K = wl.K;
   const int m0 = mb2 * 128, k0 = kb2 * 128;
@@ -3175,21 +3193,20 @@ __global__ __launch_bounds__(256, 2) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan
   const bool gather = (j == 0) && !prenorm;
   const bool xform = !prenorm;
   // ---- LDS: planes [4 half-blocks][hi, lo][64 columns][WH_LDH] halves | per-row tables; the epilogue's four 64 x 64 fp32 blocks
-  // overlay both; behind them: exponents, bias sums, the layer-0 fold scratch
+  // overlay both; behind them: exponents, bias sums
   _Float16* planes = reinterpret_cast<_Float16*>(smem);
-  float2* sm_stat = reinterpret_cast<float2*>(smem + 10240);               // [rps] (mean, rstd)
-  int* sm_ids = reinterpret_cast<int*>(smem + 10240 + 2 * 2048);           // [rps]
-  int* sm_se = reinterpret_cast<int*>(smem + WH_RED_BYTES / 4);            // [4] final scale exponents
-  int* sm_bump = sm_se + 4;                                                // [4] exponent decrease of the step in LDS
-  float* sm_bsum = smem + WH_RED_BYTES / 4 + 8;                            // [2][64]
-  float* sm_fold = sm_bsum + 128;                                          // [2][16][64]
+  float2* sm_stat = reinterpret_cast<float2*>(smem + WH_PLANES_BYTES / 4);                   // [WH_TAB_ROWS] (mean, rstd)
+  int* sm_ids = reinterpret_cast<int*>(smem + WH_PLANES_BYTES / 4 + 2 * WH_TAB_ROWS);        // [WH_TAB_ROWS]
+  int* sm_se = reinterpret_cast<int*>(smem + WH_MAIN_BYTES / 4);                             // [4] final scale exponents
+  int* sm_bump = sm_se + 4;                                                                  // [4] exponent decrease of the step in LDS
+  float* sm_bsum = smem + WH_MAIN_BYTES / 4 + 8;                                             // [2][64]
   if (xform) {
     const float* mp = saved + p.sv_mean[j];
     const float* rp = saved + p.sv_rstd[j];
-    for (int r = tid; r < 32 * nsteps; r += 256) sm_stat[r] = (r < rows) ? make_float2(mp[nbeg + r], rp[nbeg + r]) : make_float2(0.f, 0.f);
+    for (int r = tid; r < 32 * (nsteps + 1); r += 256) sm_stat[r] = (r < rows) ? make_float2(mp[nbeg + r], rp[nbeg + r]) : make_float2(0.f, 0.f);
   }
   if (gather) {
-    for (int r = tid; r < 32 * nsteps; r += 256) {
+    for (int r = tid; r < 32 * (nsteps + 2); r += 256) {
       int id = -1;
       if (r < rows) {
         const int64_t n = nbeg + r;
@@ -3200,14 +3217,18 @@ __global__ __launch_bounds__(256, 2) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan
       sm_ids[r] = id;
     }
   }
-  // ---- staging role of this wave --------------------------------------------------------------------------------------------
+  // ---- staging role of this wave: one 32-row x 64-column half-block per step --------------------------------------------------
   const bool isA = wave < 2;
   const int c16 = lane & 15, rg = lane >> 4;
   const int ncols = isA ? M : K;
   const int col = (isA ? m0 + 64 * wave : k0 + 64 * (wave - 2)) + 4 * c16;
   const bool colok = col < ncols;
-  const Src src = isA ? make_src(ws + wl.dz_off, N * M)
-                      : (gather ? make_src(features, n_docs * K) : make_src(saved + p.sv_x[j], N * K));
+  // the buffer ends with this split's last row: rows of the tail step beyond it read as zeros, no per-row predicate
+  const Src src = isA ? make_src(ws + wl.dz_off, (nbeg + rows) * M)
+                      : (gather ? make_src(features, n_docs * K) : make_src(saved + p.sv_x[j], (nbeg + rows) * K));
+  const unsigned stride = (unsigned)ncols * 4u;
+  unsigned vo = colok ? (unsigned)(((nbeg + 8 * rg) * ncols + col) * 4) : ULTR_OOB;  // advanced by 32 rows per load_step
+  int tl = 0;                                                                        // step the next load_step fetches
   float4 gam = make_float4(0.f, 0.f, 0.f, 0.f), bet = gam;
   if (!isA && xform && colok) {
     if (l0g) gam = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -3216,134 +3237,182 @@ __global__ __launch_bounds__(256, 2) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan
       bet = ld4(params + p.off_lnb[j] + col);
     }
   }
-  _Float16* myplane = planes + (size_t)wave * 2 * 64 * WH_LDH + (4 * c16) * WH_LDH + 8 * rg;
-  auto load_step = [&](int t, WhStep& s) __attribute__((always_inline)) {
-    const int r0 = 32 * t + 8 * rg;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      unsigned off = ULTR_OOB;
-      if (gather && !isA) {
-        const int id = (r0 + r < 32 * nsteps) ? sm_ids[r0 + r] : -1;
-        if (id >= 0 && colok) off = (unsigned)(((int64_t)id * K + col) * 4);
-      } else if (r0 + r < rows && colok) {
-        off = (unsigned)(((nbeg + r0 + r) * ncols + col) * 4);
-      }
-      s.v[r] = buf_ld4(src, off);
-    }
-  };
+  const int swz_w = c16 & 3;  // (column >> 2) & 3 of the lane's four columns
+  _Float16* myplane = planes + (size_t)wave * 2 * 64 * WH_LDH + (4 * c16) * WH_LDH + 8 * (rg ^ swz_w);
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
   int se_run = 253;  // biased exponent of the running scale 2^(se - 127)
   fbh8 ch[4], cl[4];
   int bump = 0;
-  auto convert = [&](int t, const WhStep& s) __attribute__((always_inline)) {
-    float v[8][4];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      v[r][0] = s.v[r].x; v[r][1] = s.v[r].y; v[r][2] = s.v[r].z; v[r][3] = s.v[r].w;
-    }
-    if (isA) {
-#pragma unroll
-      for (int r = 0; r < 8; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) bsum[c] += v[r][c];
-    } else if (xform) {
-      const float g[4] = {gam.x, gam.y, gam.z, gam.w}, be[4] = {bet.x, bet.y, bet.z, bet.w};
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const float2 st = sm_stat[32 * t + 8 * rg + r];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[r][c] = (v[r][c] - st.x) * st.y * g[c] + be[c];
-      }
-    }
-    float am = 0.f;
-#pragma unroll
-    for (int r = 0; r < 8; ++r)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) am = fmaxf(am, fabsf(v[r][c]));
-    am = wave_max(am);
-    int se = 267 - (int)((__float_as_uint(am) >> 23) & 0xffu);  // am * 2^(se - 127) < 2^14  (fb_h3_scale)
-    se = se < 1 ? 1 : (se > 253 ? 253 : se);
-    se = __builtin_amdgcn_readfirstlane(se);
-    bump = 0;
-    if (se < se_run) {
-      bump = se_run - se;
-      se_run = se;
-    }
-    const float rs = __uint_as_float((unsigned)se_run << 23);
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const float a = v[r][c] * rs;
-        const _Float16 hi = (_Float16)a;
-        ch[c][r] = hi;
-        cl[c][r] = (_Float16)(a - (float)hi);
-      }
-  };
-  auto publish = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      *reinterpret_cast<fbh8*>(myplane + c * WH_LDH) = ch[c];
-      *reinterpret_cast<fbh8*>(myplane + 64 * WH_LDH + c * WH_LDH) = cl[c];
-    }
-    if (lane == 0) sm_bump[wave] = bump;
-  };
   // ---- compute role: the 64 x 64 sub-block (wm, wk) ---------------------------------------------------------------------------
   const int wm = wave >> 1, wk = wave & 1;
   const int i = lane & 15, q = lane >> 4;
-  const _Float16* pa = planes + (size_t)wm * 2 * 64 * WH_LDH + i * WH_LDH + 8 * q;
-  const _Float16* pb = planes + (size_t)(2 + wk) * 2 * 64 * WH_LDH + i * WH_LDH + 8 * q;
+  const int swz_r = (i >> 2) & 3;
+  const _Float16* pa = planes + (size_t)wm * 2 * 64 * WH_LDH + i * WH_LDH + 8 * (q ^ swz_r);
+  const _Float16* pb = planes + (size_t)(2 + wk) * 2 * 64 * WH_LDH + i * WH_LDH + 8 * (q ^ swz_r);
   f32x4 acc[4][4];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  auto multiply = [&]() __attribute__((always_inline)) {
-    const int d = __builtin_amdgcn_readfirstlane(sm_bump[wm] + sm_bump[2 + wk]);
-    if (d != 0) {  // an operand's scale went down by 2^d: bring the sums along (exact)
-      const float f = d > 126 ? 0.f : __uint_as_float((unsigned)(127 - d) << 23);
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] *= f;
-    }
-    fbh8 bh[4], bl[4];
-#pragma unroll
-    for (int tb = 0; tb < 4; ++tb) {
-      bh[tb] = *reinterpret_cast<const fbh8*>(pb + tb * 16 * WH_LDH);
-      bl[tb] = *reinterpret_cast<const fbh8*>(pb + 64 * WH_LDH + tb * 16 * WH_LDH);
-    }
-#pragma unroll
-    for (int ta = 0; ta < 4; ++ta) {
-      const fbh8 ah = *reinterpret_cast<const fbh8*>(pa + ta * 16 * WH_LDH);
-      const fbh8 al = *reinterpret_cast<const fbh8*>(pa + 64 * WH_LDH + ta * 16 * WH_LDH);
-#pragma unroll
-      for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = fb_mfma_h(ah, bh[tb], acc[ta][tb]);
-#pragma unroll
-      for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = fb_mfma_h(ah, bl[tb], acc[ta][tb]);
-#pragma unroll
-      for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = fb_mfma_h(al, bh[tb], acc[ta][tb]);
-    }
-  };
+  TRACE_STAMP(0);
   lds_barrier();  // tables
-  WhStep ring[WH_D];
+  TRACE_STAMP(1);
+
+  auto mainloop = [&](auto isa_tag, auto xf_tag, auto ga_tag) __attribute__((always_inline)) {
+    constexpr bool ISA = decltype(isa_tag)::value, XFORM = decltype(xf_tag)::value, GATHER = decltype(ga_tag)::value;
+    auto load_step = [&](WhStep& s) __attribute__((always_inline)) {
+      if constexpr (GATHER) {
+        const int4 ia = *reinterpret_cast<const int4*>(sm_ids + 32 * tl + 8 * rg);
+        const int4 ib = *reinterpret_cast<const int4*>(sm_ids + 32 * tl + 8 * rg + 4);
+        const int id[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
 #pragma unroll
-  for (int d = 0; d < WH_D - 1; ++d) load_step(d, ring[d]);
-  auto step = [&](int t, WhStep& cur, WhStep& nxt) __attribute__((always_inline)) {
-    load_step(t + WH_D - 1, nxt);  // (past the last step: every offset is out of range - zeros, no traffic)
-    convert(t, cur);
-    lds_barrier();  // every wave is done with the planes of step t - 1
-    publish();
-    lds_barrier();
-    multiply();
+        for (int r = 0; r < 8; ++r) {
+          unsigned off = (id[r] >= 0 && colok) ? (unsigned)(((int64_t)id[r] * K + col) * 4) : ULTR_OOB;
+#if WH_NOLOAD
+          off = ULTR_OOB;
+#endif
+          s.v[r] = __builtin_amdgcn_raw_buffer_load_b128(src.rs, off, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+#if WH_NOLOAD
+          s.v[r] = __builtin_amdgcn_raw_buffer_load_b128(src.rs, ULTR_OOB, (unsigned)r * stride, 0);
+#else
+          s.v[r] = __builtin_amdgcn_raw_buffer_load_b128(src.rs, vo, (unsigned)r * stride, 0);
+#endif
+        }
+        vo += 32u * stride;
+      }
+      ++tl;
+    };
+    // scale + split of step t's half-block into ch / cl (held in registers until the planes are free); `bump` = how far the
+    // running scale went down
+    auto convert = [&](int t, const WhStep& s) __attribute__((always_inline)) {
+#if WH_NOCONV
+      if (t > 0) {  // timing variant: the loads are consumed, nothing is converted
+        unsigned x = 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) x |= s.v[r].x | s.v[r].y | s.v[r].z | s.v[r].w;
+        if (x == 0x7fc12345u) bump = 1;
+        return;
+      }
+#endif
+      float v[8][4];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        v[r][0] = __uint_as_float(s.v[r].x); v[r][1] = __uint_as_float(s.v[r].y);
+        v[r][2] = __uint_as_float(s.v[r].z); v[r][3] = __uint_as_float(s.v[r].w);
+      }
+      if constexpr (ISA) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) bsum[c] += v[r][c];
+      } else if constexpr (XFORM) {
+        const float g[4] = {gam.x, gam.y, gam.z, gam.w}, be[4] = {bet.x, bet.y, bet.z, bet.w};
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) {
+          const float4 st = *reinterpret_cast<const float4*>(sm_stat + 32 * t + 8 * rg + r);  // (mean, rstd) of two rows
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            v[r][c] = (v[r][c] - st.x) * (st.y * g[c]) + be[c];
+            v[r + 1][c] = (v[r + 1][c] - st.z) * (st.w * g[c]) + be[c];
+          }
+        }
+      }
+      float am = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) am = fmaxf(am, fabsf(v[r][c]));
+      am = wave_max(am);
+      int se = 267 - (int)((__float_as_uint(am) >> 23) & 0xffu);  // am * 2^(se - 127) < 2^14  (fb_h3_scale)
+      se = __builtin_amdgcn_readfirstlane(se);
+      se = se < 1 ? 1 : se;
+      const int lower = se < se_run ? se : se_run;
+      bump = se_run - lower;
+      se_run = lower;
+      const float rs = __uint_as_float((unsigned)se_run << 23);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const float a = v[r][c] * rs;
+          const _Float16 hi = (_Float16)a;
+          ch[c][r] = hi;
+          cl[c][r] = (_Float16)(a - (float)hi);
+        }
+    };
+    auto publish = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        *reinterpret_cast<fbh8*>(myplane + c * WH_LDH) = ch[c];
+        *reinterpret_cast<fbh8*>(myplane + 64 * WH_LDH + c * WH_LDH) = cl[c];
+      }
+      if (lane == 0) sm_bump[wave] = bump;
+    };
+    // the products of the step in LDS, with the conversion of the NEXT step's half-block (already in registers) in the same
+    // instruction stream: the VALU work rides in the matrix core's shadow
+    auto multiply_convert = [&](int tn, const WhStep& nx) __attribute__((always_inline)) {
+      const int d = __builtin_amdgcn_readfirstlane(sm_bump[wm] + sm_bump[2 + wk]);
+      if (d != 0) {  // an operand's scale went down by 2^d: bring the sums along (exact)
+        const float f = d > 126 ? 0.f : __uint_as_float((unsigned)(127 - d) << 23);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] *= f;
+      }
+      fbh8 bh[4], bl[4];
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb) {
+        bh[tb] = *reinterpret_cast<const fbh8*>(pb + tb * 16 * WH_LDH);
+        bl[tb] = *reinterpret_cast<const fbh8*>(pb + 64 * WH_LDH + tb * 16 * WH_LDH);
+      }
+#pragma unroll
+      for (int ta = 0; ta < (WH_NOMFMA ? 1 : 4); ++ta) {
+        const fbh8 ah = *reinterpret_cast<const fbh8*>(pa + ta * 16 * WH_LDH);
+        const fbh8 al = *reinterpret_cast<const fbh8*>(pa + 64 * WH_LDH + ta * 16 * WH_LDH);
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = fb_mfma_h(ah, bh[tb], acc[ta][tb]);
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = fb_mfma_h(ah, bl[tb], acc[ta][tb]);
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = fb_mfma_h(al, bh[tb], acc[ta][tb]);
+      }
+#if WH_SCHED_SPLIT
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      convert(tn, nx);
+    };
+    WhStep r0, r1;
+    load_step(r0);
+    load_step(r1);
+    convert(0, r0);
+    for (int t = 0; t < nsteps; t += 2) {
+      if (t < 6) TRACE_STAMP(2 + 4 * t);
+      lds_barrier();  // every wave is done with the planes of step t - 1
+      publish();
+      load_step(r0);  // step t + 2 (past the end: beyond the buffer - zeros, no traffic)
+      lds_barrier();
+      if (t < 6) TRACE_STAMP(3 + 4 * t);
+      multiply_convert(t + 1, r1);
+      if (t < 6) TRACE_STAMP(4 + 4 * t);
+      if (t + 1 >= nsteps) break;
+      lds_barrier();
+      publish();
+      load_step(r1);  // step t + 3
+      lds_barrier();
+      if (t < 6) TRACE_STAMP(5 + 4 * t);
+      multiply_convert(t + 2, r0);
+    }
   };
-  int t = 0;
-  for (; t + WH_D <= nsteps; t += WH_D)
-    wg_static_for<WH_D>([&](auto I) { step(t + decltype(I)::value, ring[decltype(I)::value], ring[(decltype(I)::value + WH_D - 1) % WH_D]); });
-  wg_static_for<WH_D - 1>([&](auto I) {
-    if (t + decltype(I)::value < nsteps) step(t + decltype(I)::value, ring[decltype(I)::value], ring[(decltype(I)::value + WH_D - 1) % WH_D]);
-  });
+  if (isA) mainloop(std::true_type{}, std::false_type{}, std::false_type{});
+  else if (!xform) mainloop(std::false_type{}, std::false_type{}, std::false_type{});
+  else if (!gather) mainloop(std::false_type{}, std::true_type{}, std::false_type{});
+  else mainloop(std::false_type{}, std::true_type{}, std::true_type{});
   // ---- epilogue ---------------------------------------------------------------------------------------------------------------
+  TRACE_STAMP(30);
   if (lane == 0) sm_se[wave] = se_run;
   if (isA) {
 #pragma unroll
@@ -3400,8 +3469,10 @@ __global__ __launch_bounds__(256, 2) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan
     }
     if (kb2 == 0 && sk == 0 && tid < 64 && mB + tid < M) slab[(int64_t)M * K + mB + tid] = sm_bsum[64 * sm_ + tid];
     if (l0g) {
-      float* pgs = sm_fold;            // [16][64]
-      float* pbs = sm_fold + 16 * 64;  // [16][64]
+      // fold scratch: sub-block 0's quarter of the overlay (s = 0 is never skipped and has been read by everyone past this barrier)
+      lds_barrier();
+      float* pgs = smem;            // [16][64]
+      float* pbs = smem + 16 * 64;  // [16][64]
       st4(pgs + (tid >> 4) * 64 + (tid & 15) * 4, l0pg);
       st4(pbs + (tid >> 4) * 64 + (tid & 15) * 4, l0pb);
       lds_barrier();
@@ -3416,6 +3487,7 @@ __global__ __launch_bounds__(256, 2) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan
       lds_barrier();
     }
   }
+  TRACE_STAMP(31);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3601,7 +3673,7 @@ static void knobs_load() {
   // (17.7 us against 12.3 + 5.0 us + one launch gap; step 50.2 against 48.4 us - profiles/r04_cfg2_attempts.md)
   k.wgd = env_read("ULTR_WGD", 0);
   k.wgd_max_rows = env_read("ULTR_WGD_MAX_ROWS", 4096);
-  k.wg_h3 = env_read("ULTR_WG_H3", 0);                    // weight gradients on the fp16 matrix cores (split-half operands); 2: any batch size
+  k.wg_h3 = env_read("ULTR_WG_H3", 1);                    // weight gradients on the fp16 matrix cores (split-half operands); 2: any batch size
   k.wg_h3_min_rows = env_read("ULTR_WG_H3_MIN_ROWS", 4096);
   k.wg_h3_wgs = env_read("ULTR_WG_H3_WGS", 0);
   k.loaded = true;
@@ -3847,7 +3919,7 @@ bool ultr_make_bwd_plan(const DnnPlan& p, int64_t N, BwdPlan* bp, int wg_mode) {
   // N = 2560 rows: 224 -> 12.3 us, 392 -> 12.7, 448 -> 13.0;  N = 10240: 224 -> 36, 392 -> 33, 448 -> 30 us
   // Split-half launch (wg_h3): 128 x 128 blocks, a quarter of the tiles - every row split is one more slab of P floats to write and
   // to fold, so the target stays near one workgroup per CU
-  const int target = h3w ? (knobs().wg_h3_wgs > 0 ? knobs().wg_h3_wgs : 320) : knobs().wgrad_wgs > 0 ? knobs().wgrad_wgs : (N < 4096 ? 224 : 448);
+  const int target = h3w ? (knobs().wg_h3_wgs > 0 ? knobs().wg_h3_wgs : 512) : knobs().wgrad_wgs > 0 ? knobs().wgrad_wgs : (N < 4096 ? 224 : 448);
   const int64_t rps_cap = h3w ? 2048 : 4096;  // the per-row tables of a split live in LDS
   int blk = 0;
   for (int j = 0; j < p.nl - 1; ++j) {
@@ -3856,7 +3928,7 @@ bool ultr_make_bwd_plan(const DnnPlan& p, int64_t N, BwdPlan* bp, int wg_mode) {
     w.nmb = (w.M + 63) / 64; w.nkb = (w.K + 63) / 64;
     w.nmb2 = (w.M + 127) / 128; w.nkb2 = (w.K + 127) / 128;
     const int tl = h3w ? tiles2 : tiles;
-    int nsplit = tl > 0 ? (target + tl - 1) / tl : 1;
+    int nsplit = tl > 0 ? (h3w ? target / tl : (target + tl - 1) / tl) : 1;
     if (nsplit < 1) nsplit = 1;
     const int by_cap = (int)((N + rps_cap - 1) / rps_cap);  // the doc-id table of a split lives in LDS: at most 4096 rows
     if (nsplit < by_cap) nsplit = by_cap;
@@ -3865,21 +3937,28 @@ bool ultr_make_bwd_plan(const DnnPlan& p, int64_t N, BwdPlan* bp, int wg_mode) {
     // re-read the same dz / x rows (every 64 x 64 tile of that chunk) meet in one L2.  Misaligned counts fetch every operand
     // once per tile from HBM: config 4 (rocprofv3) 311 MB per launch at nsplit = 4, 115 us - nsplit 3 / 5: 154 / 158 us;
     // config 3 at nsplit = 7: 342 MB for 74 MB of operands, HBM-bound at 5.6 TB/s.
-    if (knobs().wgrad_wgs <= 0 || h3w) nsplit = nsplit <= 1 ? 1 : nsplit <= 2 ? 2 : nsplit <= 5 ? 4 : nsplit <= 11 ? 8 : (nsplit + 4) / 8 * 8;
-    if (nsplit < by_cap) nsplit = (by_cap + 7) / 8 * 8;
+    if (knobs().wgrad_wgs <= 0 && !h3w) nsplit = nsplit <= 1 ? 1 : nsplit <= 2 ? 2 : nsplit <= 5 ? 4 : nsplit <= 11 ? 8 : (nsplit + 4) / 8 * 8;
+    if (nsplit < by_cap) nsplit = h3w ? by_cap : (by_cap + 7) / 8 * 8;
     int64_t rps = (N + nsplit - 1) / nsplit;
     rps = (rps + 31) / 32 * 32;  // 8 rows per wave-trip
     if (rps < 64) rps = 64;
     if (rps > rps_cap) rps = rps_cap;
     w.rows_per_split = (int)rps;
     w.nsplit = (int)((N + rps - 1) / rps);
-    w.blk_begin = blk;
-    blk += (h3w ? w.nmb2 * w.nkb2 : w.nmb * w.nkb) * w.nsplit;
+    w.blk_begin = blk;  // (wg_h3: the first TILE of the layer - see BwdPlan::wg_chunk)
+    blk += h3w ? w.nmb2 * w.nkb2 : w.nmb * w.nkb * w.nsplit;
     w.vec = (w.M % 4 == 0 && w.K % 4 == 0) ? 1 : 0;
     w.dz_off = bp->dz_off[j];
     w.slab_off = off; off += (int64_t)w.nsplit * ((int64_t)w.M * w.K + w.M); off = (off + 3) & ~(int64_t)3;
   }
   bp->wgrad_blocks = blk;
+  bp->wg_tiles2 = bp->wg_live = bp->wg_chunk = 0;
+  if (h3w) {
+    bp->wg_tiles2 = tiles2;
+    bp->wg_live = tiles2 * bp->wl[0].nsplit;  // (every layer got the same split count: one formula, one N)
+    bp->wg_chunk = (bp->wg_live + 7) / 8;
+    bp->wgrad_blocks = 8 * bp->wg_chunk;
+  }
   bp->lfold_off = off; off += 64 * tail_max;  // second level of the loss-partial fold (more than 1024 partials)
   bp->l0g = 0;
   bp->l0part_off = off;

@@ -180,6 +180,12 @@ struct BwdPlan {
   // cores with split (hi / lo) operands, 128 x 128 blocks staged through LDS (ultr_dnn.hip).  Chosen by ultr_make_bwd_plan from
   // the shapes and ULTR_WG_H3; the launcher re-plans with wg_mode 0 when the pointers do not allow the 16-byte paths.
   int wg_h3;
+  // wg_h3 block numbering: block b works on item  lin = (b % 8) * wg_chunk + b / 8  (consecutive block ids go round-robin to the 8
+  // XCDs, so every XCD owns ONE contiguous range of items), items ordered row split first: split = lin / wg_tiles2, tile of all
+  // layers = lin % wg_tiles2 (wl[j].blk_begin = first tile of layer j).  An XCD's L2 then serves ~nsplit / 8 row ranges of every
+  // layer whatever the split count is - which is chosen to fill the 2 x 256 workgroup slots ONCE (544 workgroups for 512 slots
+  // ran as two rounds: 113 us where 510 take 6x us at config 4).  Items >= wg_live are padding blocks.
+  int wg_tiles2, wg_live, wg_chunk;
   int64_t l0part_off;       // [nmb_0 * nsplit_0][2][K_0]
   int64_t lfold_off;        // [64][tail <= 4096]: first level of the loss-partial fold when there are more than 1024 partials
   int lf_chunks, lf_len;    // 0: one workgroup folds all; else lf_chunks workgroups x lf_len partials (set by the launcher)
