@@ -3116,25 +3116,30 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
 // ------------------------------------------------------------------------------------------------
 // Weight gradients on the fp16 matrix cores with split (hi / lo) operands   (BwdPlan::wg_h3)
 // ------------------------------------------------------------------------------------------------
-// dnn_wgrad_kernel contracts on v_mfma_f32_16x16x4_f32 straight out of registers and sits at ~68 % of the fp32 matrix peak at
-// config 4 (profiles/r04_cfg4pair_pmc.md): nothing left but the instruction.  Here dW_j = dz_j^T u_j runs on
-// v_mfma_f32_16x16x32_f16 with both operands split, a.b = ah.bh + ah.bl + al.bh (22 bits of mantissa each, fp32 accumulation):
-// 3 x 16 cycles per 16 x 16 x 32 step where the fp32 instruction needs 8 x 32.  What has to be different from the forward / dgrad
-// products (PipeH3): the contraction index is the ROW here, so a per-row scale does not factor out of the sum.  The scale is per
-// (half-block, workgroup) instead - one power of two for a 32-row x 64-column block of an operand, chosen from the block's
-// largest magnitude (< 2^14 after scaling) and only ever lowered while the workgroup walks its rows: when a later block raises
-// the maximum the accumulators are multiplied by the (exact) ratio and the walk goes on.  An element keeps 1e-5 relative
-// accuracy down to 2^-22 of the largest element the workgroup has seen in its 64 columns; below that its error is 2^-25 on the
-// scale of that maximum, i.e. invisible in a sum that contains the large terms.
-// Workgroup = 4 waves on a 128 (m) x 128 (k) block of ONE dW_j and one row split.  Per 32-row step: wave w loads a 32 x 64 fp32
-// half-block (w = 0, 1: dz columns m0 + 64 w ..; w = 2, 3: u columns k0 + 64 (w - 2) ..) - each lane 8 rows x 4 columns, so the
-// transposition into the MFMA operand order (8 consecutive rows of one column = 16 bytes) happens in registers - applies
-// LayerNorm where `saved` holds x_j, finds the block maximum, splits and writes the two fp16 planes to LDS ([column][32 rows],
-// row stride WH_LDH halves); then wave (wm, wk) = (w >> 1, w & 1) multiplies its 64 x 64 sub-block: 16 ds_read_b128 + 48 MFMAs.
-// Operands go once from L2 to the CU per 128 x 128 block - a quarter of the L2 -> CU traffic of the 64 x 64 register kernel,
-// which re-reads every dz / u element once per 64 columns of the other operand.  Two workgroups share a CU (74 KB of LDS
-// each): one converts while the other multiplies.  The epilogue is dnn_wgrad_kernel's (slabs per row split, bias sums, layer-0
-// gamma / beta fold), so the reduction launch and everything behind it are unchanged.
+// dnn_wgrad_kernel contracts on v_mfma_f32_16x16x4_f32 straight out of registers: 8 x 32 matrix-core cycles per 16 x 16 x 32 step
+// and every dz / u element fetched from L2 once per 64 columns of the other operand (config 4: 125 us, 68 % of the fp32 matrix
+// peak).  Here dW_j = dz_j^T u_j runs on v_mfma_f32_16x16x32_f16 with both operands split, a.b = ah.bh + ah.bl + al.bh (22 bits of
+// mantissa each, fp32 accumulation): 3 x 16 cycles for the same step, on 128 x 128 blocks staged through LDS (a quarter of the
+// L2 -> CU traffic).  What has to be different from the forward / dgrad products (PipeH3): the contraction index is the ROW here,
+// so a per-row scale does not factor out of the sum.  The scale is per (half-block, wave group) instead - one power of two for a
+// 32-row x 64-column block of an operand, chosen from the block's largest magnitude (< 2^14 after scaling) and only ever lowered
+// while the group walks its rows: when a later block raises the maximum the accumulators are multiplied by the (exact) ratio and
+// the walk goes on.  An element keeps 1e-5 relative accuracy down to 2^-22 of the largest element the group has seen in its 64
+// columns; below that its error is 2^-25 on the scale of that maximum, i.e. invisible in a sum that contains the large terms
+// (DESIGN.md section 4).
+// Workgroup = TWO groups of 4 waves on a 128 (m) x 128 (k) block of ONE dW_j and one row split; group g takes the 32-row steps
+// t = g, g + 2, ... with its own planes and its own accumulators (summed through LDS at the end: an in-workgroup row split that
+// costs no slab).  A step of a group is two phases, each closed by ONE workgroup barrier:
+//   stage:    wave w of the group takes the 32 x 64 fp32 half-block it loaded two steps earlier (w = 0, 1: dz columns
+//             m0 + 64 w ..; w = 2, 3: u columns k0 + 64 (w - 2) ..; a lane holds 8 rows x 4 columns, so the transposition into the
+//             MFMA operand order - 8 consecutive rows of one column = 16 bytes - happens in registers), applies LayerNorm where
+//             `saved` holds x_j, finds the block maximum, splits, writes the two fp16 planes ([column][32 rows]) and requests the
+//             half-block two steps ahead;
+//   multiply: wave (wm, wk) = (w >> 1, w & 1) multiplies its 64 x 64 sub-block: 16 ds_read_b128 + 48 MFMAs.
+// The groups run in ANTI-PHASE (group 1 starts one phase late): while one group's waves convert and write LDS the other group's
+// waves keep the matrix cores busy, by construction - two independent 4-wave workgroups per CU (the first version) drifted in
+// and out of phase and left the matrix cores 70 % idle.  The epilogue is dnn_wgrad_kernel's (slabs per row split, bias sums,
+// layer-0 gamma / beta fold), so the reduction launch and everything behind it are unchanged.
 #define WH_LDH 48  // halves per column of a plane: 32 contraction rows + 16 pad = 96 bytes; with the 16-byte slot index XORed with
                    // (column >> 2) & 3 the operand reads (ds_read_b128, lane (i, q) -> column i, slot q) are conflict-free and the
                    // staging writes (lane (c16, rg) -> column 4 c16 + c, slot rg) 2-way (13 -> 16 cycles): brute-forced over the
@@ -3143,8 +3148,8 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
 #ifndef WH_NOLOAD
 #define WH_NOLOAD 0
 #endif
-#ifndef WH_SCHED_SPLIT
-#define WH_SCHED_SPLIT 1
+#ifndef WH_LOAD_FIRST
+#define WH_LOAD_FIRST 0
 #endif
 #ifndef WH_NOCONV
 #define WH_NOCONV 0
@@ -3152,22 +3157,27 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
 #ifndef WH_NOMFMA
 #define WH_NOMFMA 0
 #endif
+#ifndef WH_NOPUB
+#define WH_NOPUB 0
+#endif
 #define WH_ROWS_CAP 2048
-#define WH_PLANES_BYTES (4 * 2 * 64 * WH_LDH * 2)
-#define WH_TAB_ROWS (WH_ROWS_CAP + 64)
-#define WH_MAIN_BYTES (WH_PLANES_BYTES + WH_TAB_ROWS * 12)  // planes | (mean, rstd) per row | doc id per row; >= the epilogue's 4 x 16 KB
-#define WH_LDS_BYTES (WH_MAIN_BYTES + 32 + 2 * 64 * 4)
+#define WH_GROUP_HALVES (4 * 2 * 64 * WH_LDH)
+#define WH_PLANES_BYTES (2 * WH_GROUP_HALVES * 2)
+#define WH_TAB_ROWS (WH_ROWS_CAP + 160)
+#define WH_MAIN_BYTES (WH_PLANES_BYTES + WH_TAB_ROWS * 12)  // planes of both groups | (mean, rstd) per row | doc id per row
+#define WH_LDS_BYTES (WH_MAIN_BYTES + 64 + 4 * 64 * 4)
 struct WhStep {
   u32x4 v[8];
 };
-__global__ __launch_bounds__(256, 2) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan bp, const float* __restrict__ params,
-                                                              const float* __restrict__ features, int64_t n_docs,
-                                                              const int32_t* __restrict__ docids, int B, int L,
-                                                              const float* __restrict__ saved, float* __restrict__ ws,
-                                                              float* __restrict__ grads, const float* __restrict__ loss_part,
-                                                              int n_loss_part, int tail, EarlyReport er, CommDev cd) {
+__global__ __launch_bounds__(512) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan bp, const float* __restrict__ params,
+                                                           const float* __restrict__ features, int64_t n_docs,
+                                                           const int32_t* __restrict__ docids, int B, int L,
+                                                           const float* __restrict__ saved, float* __restrict__ ws,
+                                                           float* __restrict__ grads, const float* __restrict__ loss_part,
+                                                           int n_loss_part, int tail, EarlyReport er, CommDev cd) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if ((int)blockIdx.x >= bp.wgrad_blocks) {
+    if (threadIdx.x >= 256) return;  // (the spare roles are written for four waves)
     wg_spare_roles(p, bp, smem, ws, grads, loss_part, n_loss_part, tail, er, cd);
     return;
   }
@@ -3183,6 +3193,7 @@ __global__ __launch_bounds__(256, 2) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan
   const int M = wl.M, K = wl.K;
   const int m0 = mb2 * 128, k0 = kb2 * 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wave >> 2, wv = wave & 3;  // wave group, wave of the group
   const int64_t N = bp.N;
   const int rps = wl.rows_per_split;
   const int64_t nbeg = (int64_t)split * rps;
@@ -3192,21 +3203,21 @@ __global__ __launch_bounds__(256, 2) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan
   const bool l0g = (j == 0) && bp.l0g != 0;
   const bool gather = (j == 0) && !prenorm;
   const bool xform = !prenorm;
-  // ---- LDS: planes [4 half-blocks][hi, lo][64 columns][WH_LDH] halves | per-row tables; the epilogue's four 64 x 64 fp32 blocks
-  // overlay both; behind them: exponents, bias sums
-  _Float16* planes = reinterpret_cast<_Float16*>(smem);
+  // ---- LDS: planes [2 groups][4 half-blocks][hi, lo][64 columns][WH_LDH] halves | per-row tables; the epilogue's four 64 x 64
+  // fp32 blocks overlay the planes; behind everything: exponents, bias sums
+  _Float16* planes = reinterpret_cast<_Float16*>(smem) + (size_t)g * WH_GROUP_HALVES;
   float2* sm_stat = reinterpret_cast<float2*>(smem + WH_PLANES_BYTES / 4);                   // [WH_TAB_ROWS] (mean, rstd)
   int* sm_ids = reinterpret_cast<int*>(smem + WH_PLANES_BYTES / 4 + 2 * WH_TAB_ROWS);        // [WH_TAB_ROWS]
-  int* sm_se = reinterpret_cast<int*>(smem + WH_MAIN_BYTES / 4);                             // [4] final scale exponents
-  int* sm_bump = sm_se + 4;                                                                  // [4] exponent decrease of the step in LDS
-  float* sm_bsum = smem + WH_MAIN_BYTES / 4 + 8;                                             // [2][64]
+  int* sm_se = reinterpret_cast<int*>(smem + WH_MAIN_BYTES / 4);                             // [8] final scale exponents
+  int* sm_bump = sm_se + 8;                                                                  // [8] exponent decrease of the step in LDS
+  float* sm_bsum = smem + WH_MAIN_BYTES / 4 + 16;                                            // [2 groups][2][64]
   if (xform) {
     const float* mp = saved + p.sv_mean[j];
     const float* rp = saved + p.sv_rstd[j];
-    for (int r = tid; r < 32 * (nsteps + 1); r += 256) sm_stat[r] = (r < rows) ? make_float2(mp[nbeg + r], rp[nbeg + r]) : make_float2(0.f, 0.f);
+    for (int r = tid; r < 32 * (nsteps + 2); r += 512) sm_stat[r] = (r < rows) ? make_float2(mp[nbeg + r], rp[nbeg + r]) : make_float2(0.f, 0.f);
   }
   if (gather) {
-    for (int r = tid; r < 32 * (nsteps + 2); r += 256) {
+    for (int r = tid; r < 32 * (nsteps + 5); r += 512) {
       int id = -1;
       if (r < rows) {
         const int64_t n = nbeg + r;
@@ -3217,18 +3228,19 @@ __global__ __launch_bounds__(256, 2) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan
       sm_ids[r] = id;
     }
   }
-  // ---- staging role of this wave: one 32-row x 64-column half-block per step --------------------------------------------------
-  const bool isA = wave < 2;
+  // ---- staging role of this wave: one 32-row x 64-column half-block per step of its group -------------------------------------
+  const bool isA = wv < 2;
   const int c16 = lane & 15, rg = lane >> 4;
   const int ncols = isA ? M : K;
-  const int col = (isA ? m0 + 64 * wave : k0 + 64 * (wave - 2)) + 4 * c16;
+  const int col = (isA ? m0 + 64 * wv : k0 + 64 * (wv - 2)) + 4 * c16;
   const bool colok = col < ncols;
   // the buffer ends with this split's last row: rows of the tail step beyond it read as zeros, no per-row predicate
   const Src src = isA ? make_src(ws + wl.dz_off, (nbeg + rows) * M)
                       : (gather ? make_src(features, n_docs * K) : make_src(saved + p.sv_x[j], (nbeg + rows) * K));
   const unsigned stride = (unsigned)ncols * 4u;
-  unsigned vo = colok ? (unsigned)(((nbeg + 8 * rg) * ncols + col) * 4) : ULTR_OOB;  // advanced by 32 rows per load_step
-  int tl = 0;                                                                        // step the next load_step fetches
+  unsigned vo = colok ? (unsigned)(((nbeg + 32 * g + 8 * rg) * ncols + col) * 4) : ULTR_OOB;  // advanced by 64 rows per load_step
+  int tl = g;  // step the next load_step fetches
+  int tc = g;  // step the next convert takes
   float4 gam = make_float4(0.f, 0.f, 0.f, 0.f), bet = gam;
   if (!isA && xform && colok) {
     if (l0g) gam = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -3238,13 +3250,13 @@ __global__ __launch_bounds__(256, 2) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan
     }
   }
   const int swz_w = c16 & 3;  // (column >> 2) & 3 of the lane's four columns
-  _Float16* myplane = planes + (size_t)wave * 2 * 64 * WH_LDH + (4 * c16) * WH_LDH + 8 * (rg ^ swz_w);
+  _Float16* myplane = planes + (size_t)wv * 2 * 64 * WH_LDH + (4 * c16) * WH_LDH + 8 * (rg ^ swz_w);
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
   int se_run = 253;  // biased exponent of the running scale 2^(se - 127)
   fbh8 ch[4], cl[4];
   int bump = 0;
   // ---- compute role: the 64 x 64 sub-block (wm, wk) ---------------------------------------------------------------------------
-  const int wm = wave >> 1, wk = wave & 1;
+  const int wm = wv >> 1, wk = wv & 1;
   const int i = lane & 15, q = lane >> 4;
   const int swz_r = (i >> 2) & 3;
   const _Float16* pa = planes + (size_t)wm * 2 * 64 * WH_LDH + i * WH_LDH + 8 * (q ^ swz_r);
@@ -3257,6 +3269,7 @@ __global__ __launch_bounds__(256, 2) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan
   TRACE_STAMP(0);
   lds_barrier();  // tables
   TRACE_STAMP(1);
+  const int S = (nsteps - g + 1) >> 1, S0 = (nsteps + 1) >> 1;  // steps of this group / of group 0
 
   auto mainloop = [&](auto isa_tag, auto xf_tag, auto ga_tag) __attribute__((always_inline)) {
     constexpr bool ISA = decltype(isa_tag)::value, XFORM = decltype(xf_tag)::value, GATHER = decltype(ga_tag)::value;
@@ -3282,19 +3295,19 @@ __global__ __launch_bounds__(256, 2) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan
           s.v[r] = __builtin_amdgcn_raw_buffer_load_b128(src.rs, vo, (unsigned)r * stride, 0);
 #endif
         }
-        vo += 32u * stride;
+        vo += 64u * stride;
       }
-      ++tl;
+      tl += 2;
     };
-    // scale + split of step t's half-block into ch / cl (held in registers until the planes are free); `bump` = how far the
-    // running scale went down
-    auto convert = [&](int t, const WhStep& s) __attribute__((always_inline)) {
+    // scale + split of a half-block into ch / cl; `bump` = how far the running scale went down
+    auto convert = [&](const WhStep& s) __attribute__((always_inline)) {
 #if WH_NOCONV
-      if (t > 0) {  // timing variant: the loads are consumed, nothing is converted
+      if (tc > 1) {  // timing variant: the loads are consumed, nothing is converted
         unsigned x = 0;
 #pragma unroll
         for (int r = 0; r < 8; ++r) x |= s.v[r].x | s.v[r].y | s.v[r].z | s.v[r].w;
         if (x == 0x7fc12345u) bump = 1;
+        tc += 2;
         return;
       }
 #endif
@@ -3310,17 +3323,18 @@ __global__ __launch_bounds__(256, 2) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan
 #pragma unroll
           for (int c = 0; c < 4; ++c) bsum[c] += v[r][c];
       } else if constexpr (XFORM) {
-        const float g[4] = {gam.x, gam.y, gam.z, gam.w}, be[4] = {bet.x, bet.y, bet.z, bet.w};
+        const float gg[4] = {gam.x, gam.y, gam.z, gam.w}, be[4] = {bet.x, bet.y, bet.z, bet.w};
 #pragma unroll
         for (int r = 0; r < 8; r += 2) {
-          const float4 st = *reinterpret_cast<const float4*>(sm_stat + 32 * t + 8 * rg + r);  // (mean, rstd) of two rows
+          const float4 st = *reinterpret_cast<const float4*>(sm_stat + 32 * tc + 8 * rg + r);  // (mean, rstd) of two rows
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            v[r][c] = (v[r][c] - st.x) * (st.y * g[c]) + be[c];
-            v[r + 1][c] = (v[r + 1][c] - st.z) * (st.w * g[c]) + be[c];
+            v[r][c] = (v[r][c] - st.x) * (st.y * gg[c]) + be[c];
+            v[r + 1][c] = (v[r + 1][c] - st.z) * (st.w * gg[c]) + be[c];
           }
         }
       }
+      tc += 2;
       float am = 0.f;
 #pragma unroll
       for (int r = 0; r < 8; ++r)
@@ -3344,18 +3358,23 @@ __global__ __launch_bounds__(256, 2) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan
           cl[c][r] = (_Float16)(a - (float)hi);
         }
     };
-    auto publish = [&]() __attribute__((always_inline)) {
+    auto stage = [&](WhStep& slot) __attribute__((always_inline)) {
+      convert(slot);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
+      for (int c = 0; c < (WH_NOPUB ? 1 : 4); ++c) {
         *reinterpret_cast<fbh8*>(myplane + c * WH_LDH) = ch[c];
         *reinterpret_cast<fbh8*>(myplane + 64 * WH_LDH + c * WH_LDH) = cl[c];
       }
       if (lane == 0) sm_bump[wave] = bump;
     };
-    // the products of the step in LDS, with the conversion of the NEXT step's half-block (already in registers) in the same
-    // instruction stream: the VALU work rides in the matrix core's shadow
-    auto multiply_convert = [&](int tn, const WhStep& nx) __attribute__((always_inline)) {
-      const int d = __builtin_amdgcn_readfirstlane(sm_bump[wm] + sm_bump[2 + wk]);
+    // ... and the request for the half-block two steps of the group ahead goes out of the MULTIPLY phase (the slot was converted in
+    // the phase before; past the end: beyond the buffer - zeros, no traffic): issuing 8 x 1 KiB per wave takes as long as the
+    // conversion, and in the stage phase it made that phase twice as long as the products it is meant to hide behind
+    auto multiply = [&](WhStep& slot) __attribute__((always_inline)) {
+#if WH_LOAD_FIRST
+      load_step(slot);
+#endif
+      const int d = __builtin_amdgcn_readfirstlane(sm_bump[4 * g + wm] + sm_bump[4 * g + 2 + wk]);
       if (d != 0) {  // an operand's scale went down by 2^d: bring the sums along (exact)
         const float f = d > 126 ? 0.f : __uint_as_float((unsigned)(127 - d) << 23);
 #pragma unroll
@@ -3380,37 +3399,36 @@ __global__ __launch_bounds__(256, 2) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan
 #pragma unroll
         for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = fb_mfma_h(al, bh[tb], acc[ta][tb]);
       }
-#if WH_SCHED_SPLIT
-      __builtin_amdgcn_sched_barrier(0);
+#if !WH_LOAD_FIRST
+      load_step(slot);
 #endif
-      convert(tn, nx);
     };
     WhStep r0, r1;
     load_step(r0);
     load_step(r1);
-    convert(0, r0);
-    for (int t = 0; t < nsteps; t += 2) {
-      if (t < 6) TRACE_STAMP(2 + 4 * t);
-      lds_barrier();  // every wave is done with the planes of step t - 1
-      publish();
-      load_step(r0);  // step t + 2 (past the end: beyond the buffer - zeros, no traffic)
+    if (g == 1) lds_barrier();  // group 1 runs one phase behind group 0
+    for (int s = 0; s < S; s += 2) {
+      if (s < 6) TRACE_STAMP(2 + 4 * s);
+      stage(r0);
       lds_barrier();
-      if (t < 6) TRACE_STAMP(3 + 4 * t);
-      multiply_convert(t + 1, r1);
-      if (t < 6) TRACE_STAMP(4 + 4 * t);
-      if (t + 1 >= nsteps) break;
+      if (s < 6) TRACE_STAMP(3 + 4 * s);
+      multiply(r0);
       lds_barrier();
-      publish();
-      load_step(r1);  // step t + 3
+      if (s < 6) TRACE_STAMP(4 + 4 * s);
+      if (s + 1 >= S) break;
+      stage(r1);
       lds_barrier();
-      if (t < 6) TRACE_STAMP(5 + 4 * t);
-      multiply_convert(t + 2, r0);
+      if (s < 6) TRACE_STAMP(5 + 4 * s);
+      multiply(r1);
+      lds_barrier();
     }
   };
   if (isA) mainloop(std::true_type{}, std::false_type{}, std::false_type{});
   else if (!xform) mainloop(std::false_type{}, std::false_type{}, std::false_type{});
   else if (!gather) mainloop(std::false_type{}, std::true_type{}, std::false_type{});
   else mainloop(std::false_type{}, std::true_type{}, std::true_type{});
+  // every wave passes 2 S0 + 1 barriers in the walk: group 0 is one short, group 1 two per step it has fewer than group 0
+  for (int n = (g == 0) ? 1 : 2 * (S0 - S); n > 0; --n) lds_barrier();
   // ---- epilogue ---------------------------------------------------------------------------------------------------------------
   TRACE_STAMP(30);
   if (lane == 0) sm_se[wave] = se_run;
@@ -3420,21 +3438,46 @@ __global__ __launch_bounds__(256, 2) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan
       bsum[c] += __shfl_xor(bsum[c], 16, 64);
       bsum[c] += __shfl_xor(bsum[c], 32, 64);
     }
-    if (rg == 0) st4(sm_bsum + 64 * wave + 4 * c16, make_float4(bsum[0], bsum[1], bsum[2], bsum[3]));
+    if (rg == 0) st4(sm_bsum + 128 * g + 64 * wv + 4 * c16, make_float4(bsum[0], bsum[1], bsum[2], bsum[3]));
+  }
+  // layer-0 fold: this thread's pieces of W_0 for the four sub-blocks, requested now (two per sub-block with 512 threads)
+  const int kq0 = k0 + (tid & 15) * 4;
+  float4 w4[4][2];
+  if (l0g) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int m = m0 + 64 * (s >> 1) + (tid >> 4) + 32 * it, kq = kq0 + 64 * (s & 1);
+        w4[s][it] = (m < M && kq < K) ? ld4(params + p.off_w[0] + (int64_t)m * K + kq) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
   }
   lds_barrier();  // last products read, exponents and bias sums visible: the planes may be overwritten
-  {
-    const float ia = __uint_as_float((unsigned)(254 - sm_se[wm]) << 23), ib = __uint_as_float((unsigned)(254 - sm_se[2 + wk]) << 23);
-    float* red = smem + wave * 4096;
+  const float ia = __uint_as_float((unsigned)(254 - sm_se[4 * g + wm]) << 23), ib = __uint_as_float((unsigned)(254 - sm_se[4 * g + 2 + wk]) << 23);
+  float* redw = smem + wv * 4096;
+  if (g == 1) {
 #pragma unroll
     for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
       for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[(16 * ta + 4 * q + r) * 64 + 16 * tb + i] = (acc[ta][tb][r] * ia) * ib;
+        for (int r = 0; r < 4; ++r) redw[(16 * ta + 4 * q + r) * 64 + 16 * tb + i] = (acc[ta][tb][r] * ia) * ib;
+  }
+  lds_barrier();
+  if (g == 0) {
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float* e = redw + (16 * ta + 4 * q + r) * 64 + 16 * tb + i;
+          *e = (acc[ta][tb][r] * ia) * ib + *e;
+        }
   }
   lds_barrier();
   float* slab = ws + wl.slab_off + (int64_t)split * ((int64_t)M * K + M);
+#pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int sm_ = s >> 1, sk = s & 1;
     const int mB = m0 + 64 * sm_, kB = k0 + 64 * sk;
@@ -3447,17 +3490,17 @@ __global__ __launch_bounds__(256, 2) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan
       b4 = ld4(params + p.off_lnb[0] + kq);
     }
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int ml = (tid >> 4) + 16 * it;
+    for (int it = 0; it < 2; ++it) {
+      const int ml = (tid >> 4) + 32 * it;
       const int m = mB + ml;
       float4 v = ld4(red + ml * 64 + (tid & 15) * 4);
       if (m < M && kq < K) {
         if (l0g) {
           // G -> dW_0 = gamma o G + S_m * beta;  partial column sums of W_0 o G and W_0 * S_m for d gamma_0 / d beta_0
-          const float Sm = sm_bsum[64 * sm_ + ml];
-          const float4 w4 = ld4(params + p.off_w[0] + (int64_t)m * K + kq);
-          l0pg.x += w4.x * v.x; l0pg.y += w4.y * v.y; l0pg.z += w4.z * v.z; l0pg.w += w4.w * v.w;
-          l0pb.x += w4.x * Sm; l0pb.y += w4.y * Sm; l0pb.z += w4.z * Sm; l0pb.w += w4.w * Sm;
+          const float Sm = sm_bsum[64 * sm_ + ml] + sm_bsum[128 + 64 * sm_ + ml];
+          const float4 w = w4[s][it];
+          l0pg.x += w.x * v.x; l0pg.y += w.y * v.y; l0pg.z += w.z * v.z; l0pg.w += w.w * v.w;
+          l0pb.x += w.x * Sm; l0pb.y += w.y * Sm; l0pb.z += w.z * Sm; l0pb.w += w.w * Sm;
           v.x = g4.x * v.x + b4.x * Sm; v.y = g4.y * v.y + b4.y * Sm; v.z = g4.z * v.z + b4.z * Sm; v.w = g4.w * v.w + b4.w * Sm;
         }
 #if WG_WT
@@ -3467,12 +3510,12 @@ __global__ __launch_bounds__(256, 2) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan
 #endif
       }
     }
-    if (kb2 == 0 && sk == 0 && tid < 64 && mB + tid < M) slab[(int64_t)M * K + mB + tid] = sm_bsum[64 * sm_ + tid];
+    if (kb2 == 0 && sk == 0 && tid < 64 && mB + tid < M) slab[(int64_t)M * K + mB + tid] = sm_bsum[64 * sm_ + tid] + sm_bsum[128 + 64 * sm_ + tid];
     if (l0g) {
       // fold scratch: sub-block 0's quarter of the overlay (s = 0 is never skipped and has been read by everyone past this barrier)
       lds_barrier();
-      float* pgs = smem;            // [16][64]
-      float* pbs = smem + 16 * 64;  // [16][64]
+      float* pgs = smem;            // [32][64]
+      float* pbs = smem + 32 * 64;  // [32][64]
       st4(pgs + (tid >> 4) * 64 + (tid & 15) * 4, l0pg);
       st4(pbs + (tid >> 4) * 64 + (tid & 15) * 4, l0pb);
       lds_barrier();
@@ -3481,7 +3524,7 @@ __global__ __launch_bounds__(256, 2) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan
         const float* srcp = which ? pbs : pgs;
         float a = 0.f;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) a += srcp[g * 64 + c];
+        for (int gr = 0; gr < 32; ++gr) a += srcp[gr * 64 + c];
         if (kB + c < K) ws[bp.l0part_off + ((int64_t)((2 * mb2 + sm_) * wl.nsplit + split) * 2 + which) * K + kB + c] = a;
       }
       lds_barrier();
@@ -3919,7 +3962,7 @@ bool ultr_make_bwd_plan(const DnnPlan& p, int64_t N, BwdPlan* bp, int wg_mode) {
   // N = 2560 rows: 224 -> 12.3 us, 392 -> 12.7, 448 -> 13.0;  N = 10240: 224 -> 36, 392 -> 33, 448 -> 30 us
   // Split-half launch (wg_h3): 128 x 128 blocks, a quarter of the tiles - every row split is one more slab of P floats to write and
   // to fold, so the target stays near one workgroup per CU
-  const int target = h3w ? (knobs().wg_h3_wgs > 0 ? knobs().wg_h3_wgs : 512) : knobs().wgrad_wgs > 0 ? knobs().wgrad_wgs : (N < 4096 ? 224 : 448);
+  const int target = h3w ? (knobs().wg_h3_wgs > 0 ? knobs().wg_h3_wgs : 256) : knobs().wgrad_wgs > 0 ? knobs().wgrad_wgs : (N < 4096 ? 224 : 448);
   const int64_t rps_cap = h3w ? 2048 : 4096;  // the per-row tables of a split live in LDS
   int blk = 0;
   for (int j = 0; j < p.nl - 1; ++j) {
@@ -4346,7 +4389,7 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
       cd.world = 0;
     }
     if (bp.lf_chunks > 0) er.host = nullptr;
-    ULTR_LAUNCH(prof, dnn_wgrad_h3_kernel, wgrid, dim3(256), (size_t)WH_LDS_BYTES, st, p, bp, params, features, n_docs, docids, (int)batch,
+    ULTR_LAUNCH(prof, dnn_wgrad_h3_kernel, wgrid, dim3(512), (size_t)WH_LDS_BYTES, st, p, bp, params, features, n_docs, docids, (int)batch,
                 (int)list_size, (const float*)saved, ws, grads, lp, nlp, tail, er, cd);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
