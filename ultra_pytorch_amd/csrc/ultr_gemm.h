@@ -861,8 +861,16 @@ inline hipError_t launch_h3(const Dims& d, const AProd& aprod, const _Float16* B
 
 // split-half mode: C = epi(A' . W^T), W as hi / lo fp16 planes [N][d.ldb halves] (ldb a multiple of 32, zero-padded; d.K = the real
 // contraction length)
+#ifndef UGEMM_H3_VARIANT
+#define UGEMM_H3_VARIANT 0
+#endif
 template <class AProd, class Epi>
 inline hipError_t run_h3(const Dims& d, const AProd& aprod, const _Float16* Bhi, const _Float16* Blo, const Epi& epi, hipStream_t st) {
+#if UGEMM_H3_VARIANT == 1  // experiments (tools/ab_build.sh): full-width chunks - every A tile split once / two row tiles per wave
+  if (d.N >= 256 && d.R >= 16384) return launch_h3<64, 256, 4, 2>(d, aprod, Bhi, Blo, epi, st);
+#elif UGEMM_H3_VARIANT == 2
+  if (d.N >= 128 && d.R >= 16384) return launch_h3<128, 128, 4, 2>(d, aprod, Bhi, Blo, epi, st);
+#endif
   if (d.N > 64) return launch_h3<64, 128, 4, 2>(d, aprod, Bhi, Blo, epi, st);
   return launch_h3<64, 64, 4, 1>(d, aprod, Bhi, Blo, epi, st);
 }
