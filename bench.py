@@ -253,8 +253,8 @@ def cpu_baseline(cfg, pool, params0, budget_s=10.0):
     Small GEMMs do not scale to every core of a big host and an oversubscribed baseline would flatter the GPU, so the thread
     count is CHOSEN BY MEASUREMENT - and by the same kind of measurement that is reported: for every candidate the threads are
     first pinned to that many distinct physical cores of ONE NUMA node, warmed up, then timed over three chunks of steps (the
-    median chunk = the candidate's sustained rate, `threads_candidates_sustained`); the smallest count within 5 % of the best
-    wins.  (Round 3 picked by a 12-step probe: 32 threads at 3.5 ms/step, which then sustained 8.2 ms on the driver's box.)
+    median chunk = the candidate's sustained rate, `threads_candidates_sustained`); a larger count has to win by 20 %, and a
+    choice whose long run does not sustain its figure hands over to the next smaller count (`long_runs`).  (Round 3 picked by a 12-step probe: 32 threads at 3.5 ms/step, which then sustained 8.2 ms on the driver's box.)
     `value` = the MEDIAN over chunks of the long run at that count; `sustained_over_probe` compares it with the candidate's own
     figure and anything beyond 1.3x is flagged.  `cores` = threads actually used."""
     ncpu = os.cpu_count() or 1
@@ -293,20 +293,41 @@ def cpu_baseline(cfg, pool, params0, budget_s=10.0):
                 i0 += per
                 ts.append(t / per)
             probe[th] = float(np.median(ts))
-            if best is None or probe[th] < 0.95 * probe[best]:  # ascending: a larger count must win by more than 5 %
+            if best is None or probe[th] < 0.80 * probe[best]:  # ascending: a larger count must win by more than 20 %
                 best = th
-        torch.set_num_threads(best)
-        st = cpu_state0(cfg, params0)
-        _, st = run(1, st, 0)
-        _pin_all_threads(node0[:best])
-        _, st = run(1 if heavy else 4, st, 1)
-        n, t_used, chunks = 0, 0.0, []
-        chunk = 1 if heavy else 10
-        while t_used < budget_s or n < (2 if heavy else 20):
-            t, st = run(chunk, st, 5 + n)
-            chunks.append(t / chunk)
-            n += chunk
-            t_used += t
+
+        def long_run(th):
+            torch.set_num_threads(th)
+            st = cpu_state0(cfg, params0)
+            _, st = run(1, st, 0)
+            _pin_all_threads(node0[:th])
+            _, st = run(1 if heavy else 4, st, 1)
+            n, t_used, chunks = 0, 0.0, []
+            chunk = 1 if heavy else 10
+            while t_used < budget_s or n < (2 if heavy else 20):
+                t, st = run(chunk, st, 5 + n)
+                chunks.append(t / chunk)
+                n += chunk
+                t_used += t
+            return n, t_used, chunks
+
+        # the long run at the chosen count; if it does not sustain what the candidate measurement promised (round 4, one box: 32
+        # threads 4.0 ms as a candidate, 9.4 ms over 770 steps) the next smaller counts get the same long run - the first stable
+        # one is reported, every attempt is listed
+        attempts = []
+        order = [best] + sorted((t for t in probe if t < best), key=lambda t: probe[t])[:2]
+        for th in order:
+            n, t_used, chunks = long_run(th)
+            ratio = float(np.median(chunks)) / probe[th]
+            attempts.append({"threads": th, "ms_per_step_median": round(1e3 * float(np.median(chunks)), 3), "sustained_over_probe": round(ratio, 3)})
+            if 1 / 1.3 <= ratio <= 1.3:
+                best = th
+                break
+        else:
+            th = min(attempts, key=lambda a: a["ms_per_step_median"])["threads"]
+            if th != order[-1]:
+                n, t_used, chunks = long_run(th)
+            best = th
     finally:
         _unpin(old_masks)
     med, mean = float(np.median(chunks)), t_used / n
@@ -318,9 +339,9 @@ def cpu_baseline(cfg, pool, params0, budget_s=10.0):
            "value_mean": B / mean, "ms_per_step_median": 1e3 * med, "ms_per_step_mean": 1e3 * mean,
            "threads_candidates_sustained": {str(k): round(1e3 * v, 3) for k, v in probe.items()},
            "threads_candidates_unit": "ms/step, median of 3 chunks, threads pinned to distinct physical cores of NUMA node 0 before timing",
-           "sustained_over_probe": ratio, "stable": bool(1 / 1.3 <= ratio <= 1.3),
+           "sustained_over_probe": ratio, "stable": bool(1 / 1.3 <= ratio <= 1.3), "long_runs": attempts,
            "sample": "%d steps (median of %d chunks) of the same workload after warm-up, oracle/ultr_oracle (vectorised torch-CPU "
-                     "restatement), %d threads (smallest count within 5 %% of the best sustained candidate) pinned to NUMA node 0 (%d of the host's %d CPUs)"
+                     "restatement), %d threads (a larger count has to beat a smaller one by 20 %%; the first count whose long run sustains its candidate figure) pinned to NUMA node 0 (%d of the host's %d CPUs)"
                      % (n, len(chunks), best, len(node0), ncpu)}
     if cfg["algo"] in ("dla", "pairdebias"):
         # the reference's own structure (per-step optimizer construction for DLA, the 2-level Python pair loop

@@ -4427,8 +4427,14 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
   ultr_make_red_plan(p, bp, &rp);
   const int nblk = (int)ultr_red_blocks(p.P, tail);
   UltrProfScope prof(ULTR_K_REDUCE, st);
+  // one thread per element (full_sum: any number of slabs, the same bits as the cooperating groups) as long as the BIG segments -
+  // the weight slabs - have at most 32 parts; the layer-0 gamma / beta partials (2 K_0 elements, one part per 64-row block of W_0
+  // and row split: 56 at config 4 with the split-half launch's 7 splits) may have up to 128
   int maxparts = 1;
-  for (int k = 0; k < rp.nseg; ++k) maxparts = rp.seg[k].nparts > maxparts ? rp.seg[k].nparts : maxparts;
+  for (int k = 0; k < rp.nseg; ++k) {
+    const int np = rp.seg[k].len > 4096 ? rp.seg[k].nparts : (rp.seg[k].nparts + 3) / 4;
+    maxparts = np > maxparts ? np : maxparts;
+  }
   if (g_ultr_step_xchg.comm != nullptr && maxparts <= 32 && bp.lf_chunks == 0) {
     // data-parallel step: this launch exchanges its own output (grad_reduce_xchg_kernel); ultr_train_step then skips the exchange kernel
     CommDev cd;
