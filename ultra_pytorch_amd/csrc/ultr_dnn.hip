@@ -3160,6 +3160,9 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
 #ifndef WH_NOPUB
 #define WH_NOPUB 0
 #endif
+#ifndef WH_CONV_IN_MUL
+#define WH_CONV_IN_MUL 0
+#endif
 #define WH_ROWS_CAP 2048
 #define WH_GROUP_HALVES (4 * 2 * 64 * WH_LDH)
 #define WH_PLANES_BYTES (2 * WH_GROUP_HALVES * 2)
@@ -3359,7 +3362,9 @@ __global__ __launch_bounds__(512) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan bp
         }
     };
     auto stage = [&](WhStep& slot) __attribute__((always_inline)) {
+#if !WH_CONV_IN_MUL
       convert(slot);
+#endif
 #pragma unroll
       for (int c = 0; c < (WH_NOPUB ? 1 : 4); ++c) {
         *reinterpret_cast<fbh8*>(myplane + c * WH_LDH) = ch[c];
@@ -3370,7 +3375,7 @@ __global__ __launch_bounds__(512) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan bp
     // ... and the request for the half-block two steps of the group ahead goes out of the MULTIPLY phase (the slot was converted in
     // the phase before; past the end: beyond the buffer - zeros, no traffic): issuing 8 x 1 KiB per wave takes as long as the
     // conversion, and in the stage phase it made that phase twice as long as the products it is meant to hide behind
-    auto multiply = [&](WhStep& slot) __attribute__((always_inline)) {
+    auto multiply = [&](WhStep& slot, const WhStep& other) __attribute__((always_inline)) {
 #if WH_LOAD_FIRST
       load_step(slot);
 #endif
@@ -3399,6 +3404,9 @@ __global__ __launch_bounds__(512) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan bp
 #pragma unroll
         for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = fb_mfma_h(al, bh[tb], acc[ta][tb]);
       }
+#if WH_CONV_IN_MUL
+      convert(other);  // the NEXT step's half-block (in registers since the phase before last): VALU work behind the products
+#endif
 #if !WH_LOAD_FIRST
       load_step(slot);
 #endif
@@ -3406,20 +3414,23 @@ __global__ __launch_bounds__(512) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan bp
     WhStep r0, r1;
     load_step(r0);
     load_step(r1);
+#if WH_CONV_IN_MUL
+    convert(r0);
+#endif
     if (g == 1) lds_barrier();  // group 1 runs one phase behind group 0
     for (int s = 0; s < S; s += 2) {
       if (s < 6) TRACE_STAMP(2 + 4 * s);
       stage(r0);
       lds_barrier();
       if (s < 6) TRACE_STAMP(3 + 4 * s);
-      multiply(r0);
+      multiply(r0, r1);
       lds_barrier();
       if (s < 6) TRACE_STAMP(4 + 4 * s);
       if (s + 1 >= S) break;
       stage(r1);
       lds_barrier();
       if (s < 6) TRACE_STAMP(5 + 4 * s);
-      multiply(r1);
+      multiply(r1, r0);
       lds_barrier();
     }
   };
