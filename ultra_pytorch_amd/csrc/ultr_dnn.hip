@@ -4291,6 +4291,56 @@ extern "C" int ultr_dnn_forward(const ultr_dnn_desc* d, const float* params, con
   return (int)hipGetLastError();
 }
 
+bool ultr_wgrad_h3_geometry(int64_t T, int M, int K, int* nsplit, int* rows_per_split) {
+  if (T <= 0 || M <= 0 || K <= 0 || M % 4 != 0 || K % 4 != 0) return false;
+  if (T * (int64_t)(M > K ? M : K) * 4 >= ((int64_t)1 << 31)) return false;  // 32-bit buffer offsets
+  const int tiles2 = ((M + 127) / 128) * ((K + 127) / 128);
+  int ns = 256 / tiles2;
+  if (ns < 1) ns = 1;
+  int64_t rps = (T + ns - 1) / ns;
+  rps = (rps + 31) / 32 * 32;
+  if (rps < 64) rps = 64;
+  *rows_per_split = (int)rps;
+  *nsplit = (int)((T + rps - 1) / rps);
+  return true;
+}
+int ultr_wgrad_h3_plain(const float* dY, const float* X, int64_t T, int M, int K, float* slabs, hipStream_t st) {
+  int ns = 0, rps = 0;
+  if (!dY || !X || !slabs || !ultr_wgrad_h3_geometry(T, M, K, &ns, &rps)) return ULTR_E_BADARG;
+  if ((((uintptr_t)dY | (uintptr_t)X | (uintptr_t)slabs) & 15) != 0) return ULTR_E_UNSUPPORTED;
+  // a one-layer plan around the operands: dz = ws + 0 with ws = dY, the ready-made operand = saved + 0 with saved = X (wg_prenorm),
+  // slabs at their distance from dY
+  DnnPlan p;
+  BwdPlan bp;
+  memset(&p, 0, sizeof(p));
+  memset(&bp, 0, sizeof(bp));
+  p.nl = 2;
+  p.M[0] = M; p.K[0] = K;
+  bp.N = T;
+  bp.wg_prenorm = 1;
+  bp.wg_h3 = 1;
+  WgradLayer& w = bp.wl[0];
+  w.M = M; w.K = K;
+  w.nmb = (M + 63) / 64; w.nkb = (K + 63) / 64;
+  w.nmb2 = (M + 127) / 128; w.nkb2 = (K + 127) / 128;
+  w.nsplit = ns; w.rows_per_split = rps; w.blk_begin = 0; w.vec = 1;
+  w.dz_off = 0;
+  w.slab_off = (int64_t)(slabs - dY);
+  bp.wg_tiles2 = w.nmb2 * w.nkb2;
+  bp.wg_live = bp.wg_tiles2 * ns;
+  bp.wg_chunk = (bp.wg_live + 7) / 8;
+  bp.wgrad_blocks = 8 * bp.wg_chunk;
+  hipError_t e = set_lds(dnn_wgrad_h3_kernel, (size_t)WH_LDS_BYTES);
+  if (e != hipSuccess) return (int)e;
+  EarlyReport er = {nullptr, 0u, 0, 1.0f};
+  CommDev cd;
+  memset(&cd, 0, sizeof(cd));
+  hipLaunchKernelGGL(dnn_wgrad_h3_kernel, dim3((unsigned)bp.wgrad_blocks), dim3(512), (size_t)WH_LDS_BYTES, st, p, bp, (const float*)nullptr,
+                     (const float*)nullptr, (int64_t)0, (const int32_t*)nullptr, 1, 1, X, const_cast<float*>(dY), (float*)nullptr,
+                     (const float*)nullptr, 0, 0, er, cd);
+  return (int)hipGetLastError();
+}
+
 static int backward_impl(const ultr_dnn_desc* d, const float* params, const float* features, int64_t n_docs,
                          const int32_t* docids, int32_t batch, int32_t list_size, const void* saved, const float* dscores,
                          const void* loss_ws, void* bwd_ws, float* grads, void* stream, FusedSoftmax fl,

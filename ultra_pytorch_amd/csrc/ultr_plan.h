@@ -225,6 +225,10 @@ struct WgdPlan {
 };
 // library-internal, ultr_wgd.hip.  Returns ULTR_E_UNSUPPORTED when the shape does not qualify (the caller then runs the slab path).
 struct EarlyReport;
+// ultr_dnn.hip: dnn_wgrad_h3_kernel for a PLAIN product (SetRank's Linears): slabs[nsplit][M*K + M] = per-row-split partials of
+// dW[M, K] = dY[T, M]^T X[T, K] and of the column sums of dY; the caller folds them (same layout as sr_wgrad_kernel's)
+bool ultr_wgrad_h3_geometry(int64_t T, int M, int K, int* nsplit, int* rows_per_split);
+int ultr_wgrad_h3_plain(const float* dY, const float* X, int64_t T, int M, int K, float* slabs, hipStream_t st);
 int ultr_wgd_launch(const DnnPlan& p, const BwdPlan& bp, const float* params, const float* saved, float* ws, float* grads,
                     const float* loss_part, int n_loss_part, int tail, int nsq, hipStream_t st);
 

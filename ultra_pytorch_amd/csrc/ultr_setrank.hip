@@ -1661,6 +1661,29 @@ int wgrad(const SrPlan& p, const float* dY, const float* X, float* dW, float* db
     if (db != nullptr) colsum(p, dY, nullptr, nullptr, nullptr, M, 0, ws, db, st);
     return 0;
   }
+  {
+    // square-ish products (d x d: 66 % matrix-core occupancy on the fp32 instruction) take the DNN's split-half weight-gradient
+    // kernel: same slab layout, so the fold below is the same.  The thin ones (dff = 64 wide) run at their HBM floor already.
+    static const int sr_wg_h3 = [] { const char* e = getenv("ULTR_SR_WG_H3"); return e ? atoi(e) : 1; }();
+    int S2 = 0, rps2 = 0;
+    if (sr_wg_h3 != 0 && sr_h3_enabled() && M >= 128 && K >= 128 && ultr_wgrad_h3_geometry(T, M, K, &S2, &rps2) &&
+        (int64_t)S2 * ((int64_t)M * K + M) <= p.wg_floats) {
+      float* part2 = part_scratch(ws + p.ws_wg, (int64_t)S2 * ((int64_t)M * K + M));
+      const int rc = ultr_wgrad_h3_plain(dY, X, T, M, K, part2, st);
+      if (rc == 0) {
+        const int64_t stride2 = (int64_t)M * K + M;
+        const int len2 = M * K;
+        if (db == dW + len2) {
+          fold(part2, stride2, S2, len2 + M, dW, st);
+        } else {
+          fold(part2, stride2, S2, len2, dW, st);
+          if (db != nullptr) fold(part2 + len2, stride2, S2, M, db, st);
+        }
+        return 0;
+      }
+      if (rc != ULTR_E_UNSUPPORTED) return rc;
+    }
+  }
   int rps = 0;
   const int S = wgrad_chunks(T, M, K, &rps);
   if ((int64_t)rps * (M > K ? M : K) * 4 >= ((int64_t)1 << 31)) return ULTR_E_UNSUPPORTED;
