@@ -3737,8 +3737,10 @@ static inline const Knobs& knobs() {
   if (!g_knobs.loaded) knobs_load();
   return g_knobs;
 }
+void ultr_setrank_knobs_reload();  // ultr_setrank.hip
 extern "C" int ultr_config_reload(void) {
   knobs_load();
+  ultr_setrank_knobs_reload();
   return 0;
 }
 

@@ -1309,6 +1309,387 @@ __global__ __launch_bounds__(SR_MAXT * 64) void sr_attn_bwd_f16_kernel(const flo
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Split-half attention (round 4, OPT-IN: ULTR_SR_ATTN_H3=1): the fp16-operand kernels above with every operand as hi (+ mid) + lo
+// fp16 planes and every product as three (S = x x^T and the forward's P V: six) f16 MFMAs with fp32 accumulation.  Scales are powers
+// of two per (list, head) slice: x to just below 2^10, dA to just below 2^4 (dS = P (dP - t) / sqrt(dh) stays far below fp16's 65504
+// for |x| up to several hundred), probabilities by 2^12; all are removed exactly in the epilogues.
+// WHY IT IS NOT THE DEFAULT.  The operands are exact to 2^-33 this way, but the instruction is not an fp32 dot product: inside
+// v_mfma_f32_16x16x32_f16 the 32 products are aligned to the LARGEST of them and truncated ~25 bits below it before they are added
+// (tools/mfma_f16_accum_test.hip: 2^20 + 31 x 0.111 comes out 0.44 low, 3.5 fp32 ulps, and the result depends on where the large
+// product sits).  A dot product with one dominant term therefore carries a biased error of up to ~2^-20 of that term.  The DNN's
+// products never notice (LayerNorm rows, 1e-6 on scores at every BASELINE config); attention does: a token with |x|^2 ~ 150 in a
+// head has a logit of ~26 and its softmax row is a difference of such logits - config 5 at full size: ONE score in each of ~14 of
+// 1024 lists moves by 5e-6 .. 3e-5 against the fp32 matrix-core kernels (everything else agrees to 5e-7), the permutation test
+// of tests/test_gpu_setrank.py (2e-5) fails, 3 075 -> 2 823 us per step.  Between the fp16 opt-in (1e-3) and the fp32 default.
+// ---------------------------------------------------------------------------------------------------------
+#ifndef SRS_NO_MIX
+#define SRS_NO_MIX 1
+#endif
+__device__ __forceinline__ float srs_pow2_scale(float amax, int target_exp) {  // amax * scale < 2^target_exp
+  int se = 253 + target_exp - (int)((__float_as_uint(amax) >> 23) & 0xffu);
+  se = se < 1 ? 1 : (se > 253 ? 253 : se);
+  return __uint_as_float((unsigned)se << 23);
+}
+template <int DH>
+__device__ __forceinline__ void srs_load(const float* __restrict__ src, int64_t base, int L, int d, int tid, int nthr, float4 (&v)[DH / 16],
+                                         float& amax) {
+#pragma unroll
+  for (int k = 0; k < DH / 16; ++k) {
+    const int e = tid + nthr * k;
+    const int r = e / (DH / 4), c4 = (e - r * (DH / 4)) * 4;
+    v[k] = r < L ? ld4(src + base + (int64_t)r * d + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[k].x), fabsf(v[k].y)), fmaxf(fabsf(v[k].z), fabsf(v[k].w))));
+  }
+}
+// row-major planes rh / rl [Lp][DH + 8] and transposed planes th / tl [DH][lt] of the scaled values
+// (r3 != nullptr: a THIRD row-major plane, the fp16 of what hi + lo leave - 33 bits for the operands of S = x x^T, whose error the
+// softmax exponentiates: with two pieces the scores of config 5 moved by up to 4e-5 under a permutation of the documents, 2e-7 with three)
+template <int DH>
+__device__ __forceinline__ void srs_store(const float4 (&v)[DH / 16], float scale, int tid, int nthr, _Float16* rh, _Float16* rl,
+                                          _Float16* th, _Float16* tl, int lt, _Float16* r3 = nullptr, _Float16* t3 = nullptr) {
+  constexpr int LDH = DH + 8;
+#pragma unroll
+  for (int k = 0; k < DH / 16; ++k) {
+    const int e = tid + nthr * k;
+    const int r = e / (DH / 4), c4 = (e - r * (DH / 4)) * 4;
+    const float a[4] = {v[k].x * scale, v[k].y * scale, v[k].z * scale, v[k].w * scale};
+    h4 hi, lo, l3;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      hi[j] = (_Float16)a[j];
+      float r1 = a[j] - (float)hi[j];
+#if SRS_NO_MIX
+      asm volatile("" : "+v"(r1));  // keeps hipcc from fusing the subtraction and the conversion into v_fma_mix*_f16
+#endif
+      lo[j] = (_Float16)r1;
+      float r2 = r1 - (float)lo[j];
+#if SRS_NO_MIX
+      asm volatile("" : "+v"(r2));
+#endif
+      l3[j] = (_Float16)r2;
+    }
+    *reinterpret_cast<h4*>(rh + r * LDH + c4) = hi;
+    *reinterpret_cast<h4*>(rl + r * LDH + c4) = lo;
+    if (r3 != nullptr) *reinterpret_cast<h4*>(r3 + r * LDH + c4) = l3;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      th[(c4 + j) * lt + r] = hi[j];
+      tl[(c4 + j) * lt + r] = lo[j];
+      if (t3 != nullptr) t3[(c4 + j) * lt + r] = l3[j];
+    }
+  }
+}
+__device__ __forceinline__ h8 srs_pair_b(const _Float16* tslice, int lt, int col, int t, int q) {
+  const _Float16* p = tslice + col * lt + 16 * t + 4 * q;
+  return join_h4(*reinterpret_cast<const h4*>(p), *reinterpret_cast<const h4*>(p + 16));
+}
+// the 4 + 4 values of a block pair times `scale` as hi / lo halves
+__device__ __forceinline__ void srs_pack(const f32x4& a, const f32x4& b, float scale, h8& hi, h8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = (j < 4 ? a[j & 3] : b[j & 3]) * scale;
+    const _Float16 h = (_Float16)v;
+    hi[j] = h;
+    float r1 = v - (float)h;
+#if SRS_NO_MIX
+    asm volatile("" : "+v"(r1));
+#endif
+    lo[j] = (_Float16)r1;
+  }
+}
+// ... as three pieces (the forward's P V product: an attention row that sits on ONE key with |x| ~ 16 carries that key's value
+// through - 2^-22 of 16 is 4e-6 on an activation, 3e-5 on a score of config 5; three pieces of P and of V are exact to fp32)
+__device__ __forceinline__ void srs_pack3(const f32x4& a, const f32x4& b, float scale, h8& hi, h8& mid, h8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = (j < 4 ? a[j & 3] : b[j & 3]) * scale;
+    const _Float16 h = (_Float16)v;
+    hi[j] = h;
+    float r1 = v - (float)h;
+#if SRS_NO_MIX
+    asm volatile("" : "+v"(r1));
+#endif
+    const _Float16 m = (_Float16)r1;
+    mid[j] = m;
+    float r2 = r1 - (float)m;
+#if SRS_NO_MIX
+    asm volatile("" : "+v"(r2));
+#endif
+    lo[j] = (_Float16)r2;
+  }
+}
+// NT tile over the head depth with split operands: sum_k a[k] b[k], a = row of the row-major planes, b = a held fragment
+template <int DH>
+__device__ __forceinline__ f32x4 srs_tile(const _Float16* ah_row, const _Float16* al_row, const h8 (&bh)[DH / 32], const h8 (&bl)[DH / 32]) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int f = 0; f < DH / 32; ++f) {
+    const h8 ah = *reinterpret_cast<const h8*>(ah_row + 32 * f), al = *reinterpret_cast<const h8*>(al_row + 32 * f);
+    acc = mfma_h(ah, bl[f], acc);
+    acc = mfma_h(al, bh[f], acc);
+    acc = mfma_h(ah, bh[f], acc);
+  }
+  return acc;
+}
+
+// the same with three pieces per operand (a = ah + am + al): every partial product down to 2^-22 of the largest
+template <int DH>
+__device__ __forceinline__ f32x4 srs_tile6(const _Float16* ah_row, const _Float16* am_row, const _Float16* al_row, const h8 (&bh)[DH / 32],
+                                           const h8 (&bm)[DH / 32], const h8 (&bl)[DH / 32]) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int f = 0; f < DH / 32; ++f) {
+    const h8 ah = *reinterpret_cast<const h8*>(ah_row + 32 * f), am = *reinterpret_cast<const h8*>(am_row + 32 * f),
+             al = *reinterpret_cast<const h8*>(al_row + 32 * f);
+    acc = mfma_h(ah, bl[f], acc);
+    acc = mfma_h(am, bm[f], acc);
+    acc = mfma_h(al, bh[f], acc);
+    acc = mfma_h(ah, bm[f], acc);
+    acc = mfma_h(am, bh[f], acc);
+    acc = mfma_h(ah, bh[f], acc);
+  }
+  return acc;
+}
+
+template <int DH>
+__global__ __launch_bounds__(SR_MAXT * 64) void sr_attn_fwd_h3_kernel(const float* __restrict__ x, int L, int d,
+                                                                     float* __restrict__ A, float* __restrict__ lse) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int LDH = DH + 8, NC = DH / 16, NF = DH / 32;
+  const int Lp = round_up(L, 16), NTL = Lp / 16, lt = 16 * NTL + 24;
+  _Float16* xh = reinterpret_cast<_Float16*>(smem);  // [Lp][LDH]
+  _Float16* xl = xh + Lp * LDH;
+  _Float16* x3 = xl + Lp * LDH;
+  _Float16* th = x3 + Lp * LDH;                      // [DH][lt]
+  _Float16* tl = th + DH * lt;
+  _Float16* t3 = tl + DH * lt;
+  float* red = reinterpret_cast<float*>(t3 + DH * lt);  // [SR_MAXT]
+  const int b = blockIdx.x, h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+  const int nthr = NTL * 64;
+  const int64_t base = (int64_t)b * L * d + h * DH;
+  for (int e = tid; e < 3 * DH * (lt / 8); e += nthr) {  // zero the transposed planes (padding columns are read)
+    const h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    *reinterpret_cast<h8*>(th + e * 8) = z;
+  }
+  float4 xv[DH / 16];
+  float am = 0.f;
+  srs_load<DH>(x, base, L, d, tid, nthr, xv, am);
+  am = wave_max(am);
+  if (lane == 0) red[wave] = am;
+  __syncthreads();
+  am = 0.f;
+  for (int w = 0; w < NTL; ++w) am = fmaxf(am, red[w]);
+  const float sx = srs_pow2_scale(am, 10), isx = 1.0f / sx;
+  srs_store<DH>(xv, sx, tid, nthr, xh, xl, th, tl, lt, x3, t3);
+  __syncthreads();
+  const float scale = 1.0f / sqrtf((float)DH);
+  h8 bqh[NF], bql[NF], bq3[NF];  // this wave's query block: lane (i, q) holds x'[query i][32 f + 8 q .. + 7]
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    bqh[f] = *reinterpret_cast<const h8*>(xh + (wave * 16 + i) * LDH + 32 * f + 8 * q);
+    bql[f] = *reinterpret_cast<const h8*>(xl + (wave * 16 + i) * LDH + 32 * f + 8 * q);
+    bq3[f] = *reinterpret_cast<const h8*>(x3 + (wave * 16 + i) * LDH + 32 * f + 8 * q);
+  }
+  f32x4 pr[SR_MAXT + 1];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t <= SR_MAXT; ++t) pr[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < SR_MAXT; ++t) {
+    if (t < NTL) {
+      pr[t] = srs_tile6<DH>(xh + (t * 16 + i) * LDH + 8 * q, xl + (t * 16 + i) * LDH + 8 * q, x3 + (t * 16 + i) * LDH + 8 * q, bqh, bql, bq3);  // sx^2 S
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, pr[t][r]);
+    }
+  }
+  mx = quad_max(mx);
+  const float sc2 = (scale * isx) * isx;  // logits = sc2 * (sx^2 S)
+  const float c1 = sc2 * 1.44269504088896341f, mx2 = mx * c1;
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < SR_MAXT; ++t) {
+    if (t < NTL) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pr[t][r] = __builtin_amdgcn_exp2f(fmaf(pr[t][r], c1, -mx2));
+      if (t == NTL - 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pr[t][r] = (t * 16 + 4 * q + r < L) ? pr[t][r] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sum += pr[t][r];
+    }
+  }
+  sum = quad_sum(sum);
+  const float inv = 1.0f / sum;
+  if (lse != nullptr && q == 0 && wave * 16 + i < L) lse[((int64_t)b * L + wave * 16 + i) * gridDim.y + h] = mx * sc2 + logf(sum);
+  f32x4 o[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) o[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float pscale = inv * 4096.0f;
+#pragma unroll
+  for (int t = 0; t < SR_MAXT; t += 2) {
+    if (t < NTL) {
+      h8 pah, pam, pal;
+      srs_pack3(pr[t], pr[t + 1], pscale, pah, pam, pal);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const h8 vh = srs_pair_b(th, lt, 16 * c + i, t, q), vm = srs_pair_b(tl, lt, 16 * c + i, t, q), vl = srs_pair_b(t3, lt, 16 * c + i, t, q);
+        o[c] = mfma_h(pah, vl, o[c]);
+        o[c] = mfma_h(pam, vm, o[c]);
+        o[c] = mfma_h(pal, vh, o[c]);
+        o[c] = mfma_h(pah, vm, o[c]);
+        o[c] = mfma_h(pam, vh, o[c]);
+        o[c] = mfma_h(pah, vh, o[c]);
+      }
+    }
+  }
+  const float oscale = isx * (1.0f / 4096.0f);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wave * 16 + 4 * q + r;
+      if (row < L) A[base + (int64_t)row * d + c * 16 + i] = o[c][r] * oscale;
+    }
+  }
+}
+
+template <int DH>
+__global__ __launch_bounds__(SR_MAXT * 64) void sr_attn_bwd_h3_kernel(const float* __restrict__ x, const float* __restrict__ dA,
+                                                                     const float* __restrict__ Aout, const float* __restrict__ lse,
+                                                                     int L, int d, float* __restrict__ dx) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int LDH = DH + 8, NC = DH / 16, NF = DH / 32, RT = DH / 4;
+  const int Lp = round_up(L, 16), NTL = Lp / 16, lt = 16 * NTL + 24;
+  _Float16* xh = reinterpret_cast<_Float16*>(smem);  // x: [Lp][LDH] hi, lo
+  _Float16* xl = xh + Lp * LDH;
+  _Float16* x3 = xl + Lp * LDH;
+  _Float16* gh = x3 + Lp * LDH;                      // dA
+  _Float16* gl = gh + Lp * LDH;
+  _Float16* xth = gl + Lp * LDH;                     // transposed [DH][lt]: x hi, lo, dA hi, lo
+  _Float16* xtl = xth + DH * lt;
+  _Float16* gth = xtl + DH * lt;
+  _Float16* gtl = gth + DH * lt;
+  float* st_l = reinterpret_cast<float*>(gtl + DH * lt);  // [16 (SR_MAXT + 1)] lse * log2(e) (+inf past L: P = 0)
+  float* st_t = st_l + 16 * (SR_MAXT + 1);                // [16 (SR_MAXT + 1)] t = dA . A
+  float* red = st_t + 16 * (SR_MAXT + 1);                 // [2][SR_MAXT]
+  const int b = blockIdx.x, h = blockIdx.y, H = gridDim.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+  const int nthr = NTL * 64;
+  const int64_t base = (int64_t)b * L * d + h * DH;
+  for (int e = tid; e < 4 * DH * (lt / 8); e += nthr) {  // zero the four transposed planes
+    const h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    *reinterpret_cast<h8*>(xth + e * 8) = z;
+  }
+  float4 xv[DH / 16], gv[DH / 16];
+  float amx = 0.f, amg = 0.f;
+  srs_load<DH>(x, base, L, d, tid, nthr, xv, amx);
+  srs_load<DH>(dA, base, L, d, tid, nthr, gv, amg);
+  amx = wave_max(amx);
+  amg = wave_max(amg);
+  if (lane == 0) {
+    red[wave] = amx;
+    red[SR_MAXT + wave] = amg;
+  }
+  for (int e = tid; e < 16 * (SR_MAXT + 1) * RT; e += nthr) {  // t = dA . A in fp32 from the fp32 inputs; lse
+    const int r = e / RT, c4 = (e - r * RT) * 4;
+    const bool ok = r < L;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 g4 = ok ? ld4(dA + base + (int64_t)r * d + c4) : z4;
+    const float4 av = ok ? ld4(Aout + base + (int64_t)r * d + c4) : z4;
+    float tt = g4.x * av.x + g4.y * av.y + g4.z * av.z + g4.w * av.w;
+#pragma unroll
+    for (int m = 1; m < RT; m <<= 1) tt += __shfl_xor(tt, m);
+    if ((e - r * RT) == 0) {
+      st_t[r] = tt;
+      st_l[r] = ok ? lse[((int64_t)b * L + r) * H + h] * 1.44269504088896341f : INFINITY;
+    }
+  }
+  __syncthreads();
+  amx = amg = 0.f;
+  for (int w = 0; w < NTL; ++w) {
+    amx = fmaxf(amx, red[w]);
+    amg = fmaxf(amg, red[SR_MAXT + w]);
+  }
+  const float sx = srs_pow2_scale(amx, 10), isx = 1.0f / sx;
+  const float sg = srs_pow2_scale(amg, 4), isg = 1.0f / sg;
+  srs_store<DH>(xv, sx, tid, nthr, xh, xl, xth, xtl, lt, x3);
+  srs_store<DH>(gv, sg, tid, nthr, gh, gl, gth, gtl, lt);
+  __syncthreads();
+  const float scale = 1.0f / sqrtf((float)DH);
+  h8 bxh[NF], bxl[NF], bx3[NF], bgh[NF], bgl[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    const int o = (wave * 16 + i) * LDH + 32 * f + 8 * q;
+    bxh[f] = *reinterpret_cast<const h8*>(xh + o);
+    bxl[f] = *reinterpret_cast<const h8*>(xl + o);
+    bx3[f] = *reinterpret_cast<const h8*>(x3 + o);
+    bgh[f] = *reinterpret_cast<const h8*>(gh + o);
+    bgl[f] = *reinterpret_cast<const h8*>(gl + o);
+  }
+  const float c1 = (scale * isx) * isx * 1.44269504088896341f;  // logits * log2(e) from sx^2 S
+  const float l_own = st_l[wave * 16 + i], t_own = st_t[wave * 16 + i] * sg;
+  f32x4 acc[NC], ack[NC], acv[NC];  // sx sg dq, sx sg dk, 4096 sg dv
+#pragma unroll
+  for (int c = 0; c < NC; ++c) acc[c] = ack[c] = acv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // one partner block: the three NT tiles and the element-wise dS algebra; results (sg dS[own][partner], sg dS[partner][own],
+  // P[partner][own]) for tokens 16 t + 4 q + r
+  auto block_vals = [&](int t, bool live, f32x4& dsa, f32x4& dsb, f32x4& pb) {
+    dsa = dsb = pb = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!live) return;
+    const int o = (t * 16 + i) * LDH + 8 * q;
+    const f32x4 sc = srs_tile6<DH>(xh + o, xl + o, x3 + o, bxh, bxl, bx3);   // sx^2 S[16 t + 4 q + r][own i]  (symmetric: both roles)
+    const f32x4 dpt = srs_tile<DH>(xh + o, xl + o, bgh, bgl);  // sx sg dP^T[key 16 t + 4 q + r][query own i] = x[key] . dA[query]
+    const f32x4 dpn = srs_tile<DH>(gh + o, gl + o, bxh, bxl);  // sx sg dP[query 16 t + 4 q + r][key own i]   = dA[query] . x[key]
+    const float4 l4 = ld4(st_l + t * 16 + 4 * q), t4 = ld4(st_t + t * 16 + 4 * q);
+    const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, tq[4] = {t4.x * sg, t4.y * sg, t4.z * sg, t4.w * sg};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int prt = t * 16 + 4 * q + r;
+      float pa = __builtin_amdgcn_exp2f(fmaf(sc[r], c1, -l_own));  // own token as query, partner as key
+      pa = (prt < L) ? pa : 0.f;                                    // padding keys (only the last block has any)
+      dsa[r] = (scale * pa) * (dpt[r] * isx - t_own);
+      const float pbv = __builtin_amdgcn_exp2f(fmaf(sc[r], c1, -lq[r]));  // own token as key, partner as query (lse = +inf past L)
+      pb[r] = pbv;
+      dsb[r] = (scale * pbv) * (dpn[r] * isx - tq[r]);
+    }
+  };
+  for (int t = 0; t < NTL; t += 2) {
+    f32x4 a0, b0, p0, a1, b1, p1;
+    block_vals(t, true, a0, b0, p0);
+    block_vals(t + 1, t + 1 < NTL, a1, b1, p1);
+    h8 hah, hal, hbh, hbl, hph, hpl;
+    srs_pack(a0, a1, 1.0f, hah, hal);
+    srs_pack(b0, b1, 1.0f, hbh, hbl);
+    srs_pack(p0, p1, 4096.0f, hph, hpl);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const h8 xbh = srs_pair_b(xth, lt, 16 * c + i, t, q), xbl = srs_pair_b(xtl, lt, 16 * c + i, t, q);
+      const h8 gbh = srs_pair_b(gth, lt, 16 * c + i, t, q), gbl = srs_pair_b(gtl, lt, 16 * c + i, t, q);
+      acc[c] = mfma_h(hah, xbl, acc[c]);  // dq: dS[own][partner] x[partner]
+      acc[c] = mfma_h(hal, xbh, acc[c]);
+      acc[c] = mfma_h(hah, xbh, acc[c]);
+      ack[c] = mfma_h(hbh, xbl, ack[c]);  // dk: dS[partner][own] x[partner]
+      ack[c] = mfma_h(hbl, xbh, ack[c]);
+      ack[c] = mfma_h(hbh, xbh, ack[c]);
+      acv[c] = mfma_h(hph, gbl, acv[c]);  // dv: P[partner][own] dA[partner]
+      acv[c] = mfma_h(hpl, gbh, acv[c]);
+      acv[c] = mfma_h(hph, gbh, acv[c]);
+    }
+  }
+  const float s1 = isx * isg, s2 = isg * (1.0f / 4096.0f);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wave * 16 + 4 * q + r;
+      if (row < L) dx[base + (int64_t)row * d + c * 16 + i] += (acc[c][r] + ack[c][r]) * s1 + acv[c][r] * s2;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // weight gradients of the plain Linears:  dW[M, K] = dY[T, M]^T X[T, K],  db[M] = column sums of dY
 // ---------------------------------------------------------------------------------------------------------
 // T is ~100k rows and the outputs are small (at most d x d), so the contraction is split over row chunks:
@@ -1557,13 +1938,22 @@ struct SrH3Ctx {
   const SrPlan* plan;
 };
 thread_local SrH3Ctx g_sr_h3 = {nullptr, nullptr, nullptr};
+// knobs of this file: read at first use, re-read after ultr_config_reload()
+int g_sr_knob_h3 = -1, g_sr_knob_attn_h3 = -1, g_sr_knob_attn_mask = 0, g_sr_knob_wg_h3 = -1;
+void sr_knobs_load() {
+  if (g_sr_knob_h3 >= 0) return;
+  const char* e = getenv("ULTR_SR_H3");
+  g_sr_knob_h3 = (e && *e) ? atoi(e) : 1;
+  e = getenv("ULTR_SR_ATTN_H3");
+  g_sr_knob_attn_h3 = (e && *e) ? atoi(e) : 0;
+  e = getenv("ULTR_SR_ATTN_H3_MASK");  // debug: bit (2 layer + dir), dir 0 forward / 1 backward
+  g_sr_knob_attn_mask = (e && *e) ? atoi(e) : -1;
+  e = getenv("ULTR_SR_WG_H3");
+  g_sr_knob_wg_h3 = (e && *e) ? atoi(e) : 1;
+}
 int sr_h3_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("ULTR_SR_H3");
-    v = (e && *e) ? atoi(e) : 1;
-  }
-  return v;
+  sr_knobs_load();
+  return g_sr_knob_h3;
 }
 const SrPlan::SplitMat* sr_find_split(const float* W, int M, int K) {
   if (g_sr_h3.plan == nullptr || g_sr_h3.planes == nullptr || !sr_h3_enabled()) return nullptr;
@@ -1664,9 +2054,8 @@ int wgrad(const SrPlan& p, const float* dY, const float* X, float* dW, float* db
   {
     // square-ish products (d x d: 66 % matrix-core occupancy on the fp32 instruction) take the DNN's split-half weight-gradient
     // kernel: same slab layout, so the fold below is the same.  The thin ones (dff = 64 wide) run at their HBM floor already.
-    static const int sr_wg_h3 = [] { const char* e = getenv("ULTR_SR_WG_H3"); return e ? atoi(e) : 1; }();
     int S2 = 0, rps2 = 0;
-    if (sr_wg_h3 != 0 && sr_h3_enabled() && M >= 128 && K >= 128 && ultr_wgrad_h3_geometry(T, M, K, &S2, &rps2) &&
+    if (sr_h3_enabled() && g_sr_knob_wg_h3 != 0 && M >= 128 && K >= 128 && ultr_wgrad_h3_geometry(T, M, K, &S2, &rps2) &&
         (int64_t)S2 * ((int64_t)M * K + M) <= p.wg_floats) {
       float* part2 = part_scratch(ws + p.ws_wg, (int64_t)S2 * ((int64_t)M * K + M));
       const int rc = ultr_wgrad_h3_plain(dY, X, T, M, K, part2, st);
@@ -1784,6 +2173,40 @@ int attn_bwd_f16(const SrPlan& p, const float* x, const float* dA, const float* 
   }
   return 0;
 }
+// split-half kernels: opt-in (ULTR_SR_ATTN_H3=1) for fp32 attention at head depth 32 / 64, list_size <= 128 - see the kernels' header for
+// why the fp32 matrix cores stay the default
+bool attn_h3_ok(const SrPlan& p, int L, int layer = 0, int dir = 0) {
+  sr_knobs_load();
+  return g_sr_knob_attn_h3 != 0 && ((g_sr_knob_attn_mask >> (2 * layer + dir)) & 1) && !p.att_f16 && attn_mfma_ok(p, L) && (p.dh == 32 || p.dh == 64);
+}
+int attn_fwd_h3(const SrPlan& p, const float* x, int batch, int L, float* A, float* lse, hipStream_t st) {
+  const int Lp = round_up(L, 16), lt = Lp + 24;
+  const size_t lds = ((size_t)3 * Lp * (p.dh + 8) + (size_t)3 * p.dh * lt) * sizeof(_Float16) + (size_t)SR_MAXT * sizeof(float);
+  const dim3 grid(batch, p.H), block(Lp * 4);
+  if (p.dh == 32) {
+    SR_CHECK(set_dyn_lds(sr_attn_fwd_h3_kernel<32>, lds));
+    hipLaunchKernelGGL(sr_attn_fwd_h3_kernel<32>, grid, block, lds, st, x, L, p.d, A, lse);
+  } else {
+    SR_CHECK(set_dyn_lds(sr_attn_fwd_h3_kernel<64>, lds));
+    hipLaunchKernelGGL(sr_attn_fwd_h3_kernel<64>, grid, block, lds, st, x, L, p.d, A, lse);
+  }
+  return 0;
+}
+int attn_bwd_h3(const SrPlan& p, const float* x, const float* dA, const float* Aout, const float* lse, int batch, int L, float* dx,
+                hipStream_t st) {
+  const int Lp = round_up(L, 16), lt = Lp + 24;
+  const size_t lds = ((size_t)5 * Lp * (p.dh + 8) + (size_t)4 * p.dh * lt) * sizeof(_Float16) +
+                     ((size_t)2 * 16 * (SR_MAXT + 1) + 2 * SR_MAXT) * sizeof(float);
+  const dim3 grid(batch, p.H), block(Lp * 4);
+  if (p.dh == 32) {
+    SR_CHECK(set_dyn_lds(sr_attn_bwd_h3_kernel<32>, lds));
+    hipLaunchKernelGGL(sr_attn_bwd_h3_kernel<32>, grid, block, lds, st, x, dA, Aout, lse, L, p.d, dx);
+  } else {
+    SR_CHECK(set_dyn_lds(sr_attn_bwd_h3_kernel<64>, lds));
+    hipLaunchKernelGGL(sr_attn_bwd_h3_kernel<64>, grid, block, lds, st, x, dA, Aout, lse, L, p.d, dx);
+  }
+  return 0;
+}
 int attn_bwd_mfma(const SrPlan& p, const float* x, const float* dA, const float* Aout, const float* lse, int batch, int L, float* dx,
                   hipStream_t st) {
   const int Lp = round_up(L, 16);
@@ -1838,6 +2261,8 @@ void colsum_ln(const SrPlan& p, const float* dy, const float* s, const float* me
 }
 
 }  // namespace
+
+void ultr_setrank_knobs_reload() { g_sr_knob_h3 = -1; }
 
 extern "C" int64_t ultr_setrank_param_count(const ultr_setrank_desc* c) {
   SrPlan p;
@@ -1906,6 +2331,7 @@ extern "C" int ultr_setrank_forward(const ultr_setrank_desc* c, const float* par
     const SrLayer& y = p.lay[l];
     const float* x = sv + p.sv_x[l];
     if (attn_f16_ok(p, L)) SR_CHECK(attn_fwd_f16(p, x, batch, L, sv + p.sv_A[l], sv + p.sv_lse[l], st));
+    else if (attn_h3_ok(p, L, l, 0)) SR_CHECK(attn_fwd_h3(p, x, batch, L, sv + p.sv_A[l], sv + p.sv_lse[l], st));
     else if (mfma_att) SR_CHECK(attn_fwd_mfma(p, x, batch, L, sv + p.sv_A[l], sv + p.sv_lse[l], st));
     else hipLaunchKernelGGL(sr_attn_fwd_kernel, dim3(batch, p.H), dim3(256), lds_att, st, x, L, d, p.dh, sv + p.sv_A[l]);
     // A Wd^T lands in out1's buffer, then out1 = LN1(x + (A Wd^T + bd)) in place (s1 keeps the pre-norm sum)
@@ -2009,6 +2435,8 @@ extern "C" int ultr_setrank_backward(const ultr_setrank_desc* c, const float* pa
     SR_CHECK(gemm_dyw(G0, params + y.wd, G1, nullptr, T, d, d, 0, st));      // G1 = d A  [T, d]
     if (attn_f16_ok(p, L))    // G0 += attention path -> d x_l
       SR_CHECK(attn_bwd_f16(p, sv + p.sv_x[l], G1, sv + p.sv_A[l], sv + p.sv_lse[l], batch, L, G0, st));
+    else if (attn_h3_ok(p, L, l, 1))
+      SR_CHECK(attn_bwd_h3(p, sv + p.sv_x[l], G1, sv + p.sv_A[l], sv + p.sv_lse[l], batch, L, G0, st));
     else if (attn_mfma_ok(p, L))
       SR_CHECK(attn_bwd_mfma(p, sv + p.sv_x[l], G1, sv + p.sv_A[l], sv + p.sv_lse[l], batch, L, G0, st));
     else hipLaunchKernelGGL(sr_attn_bwd_kernel, dim3(batch, p.H), dim3(256), lds_att, st, sv + p.sv_x[l], (const float*)G1, L, d,
