@@ -586,43 +586,80 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h3_kernel(Dims d, AProd apr
   const __amdgpu_buffer_rsrc_t bls = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(Blo), 0, (int)(bplane * 2), 0x00020000);
   const int nk = (d.K + BK - 1) / BK;
 
-  int64_t r0 = 0, rend = 0;
-  int n0 = 0, m_units = 0;
   constexpr int B_PIECES = BN * 4 / C::NT;  // 16-byte pieces (8 halves) per thread per plane per k-tile
   static_assert(BN * 4 % C::NT == 0 && B_PIECES >= 1, "B staging divides evenly");
-  float4 areg[C::A_LOADS];
-  u32x4 bhr[B_PIECES], blr[B_PIECES];
   const int k4 = (tid & 7) * 4;
-  typename AProd::Row arow[C::A_LOADS];
-  typename AProd::Cols acol;
-  auto begin_chunk = [&](int64_t uu) {
+  // The operand stream.  Tiles are requested TWO ahead of the one being multiplied and the stream runs on across chunk boundaries
+  // (the next chunk's first two tiles are in flight while this chunk's epilogue runs): with one tile of look-ahead inside a chunk
+  // and none across chunks every 32-deep contraction step waited for an HBM round trip - 2 800 cycles per step around 190 of MFMAs
+  // (profiles/r04: tools/prof_big_fwd.sh).  Two register slots; contraction tiles are walked in pairs so that the slot of a tile
+  // is static (an odd tile count is padded with one all-zero tile: its loads are out of range).
+  struct Chunk {
+    int64_t u, r0, rend;
+    int n0, m_units;
+  };
+  struct Slot {
+    float4 areg[C::A_LOADS];
+    typename AProd::Row arow[C::A_LOADS];
+    typename AProd::Cols acol;
+    u32x4 bhr[B_PIECES], blr[B_PIECES];
+  };
+  auto chunk_at = [&](int64_t uu) {
+    Chunk c;
     const int64_t cb = uu / nru, ru = uu - cb * nru;
     int64_t m = u_end - uu;
     if (m > BM / 16) m = BM / 16;
     if (m > nru - ru) m = nru - ru;
-    m_units = (int)m;
-    r0 = ru * 16;
-    rend = r0 + 16 * m < d.R ? r0 + 16 * m : d.R;
-    n0 = (int)cb * BN;
-#pragma unroll
-    for (int j = 0; j < C::A_LOADS; ++j) arow[j] = aprod.row(r0 + ((tid + C::NT * j) >> 3), rend);
+    c.u = uu;
+    c.m_units = (int)m;
+    c.r0 = ru * 16;
+    c.rend = c.r0 + 16 * m < d.R ? c.r0 + 16 * m : d.R;
+    c.n0 = (int)cb * BN;
+    return c;
   };
-  auto load_tile = [&](int k0) {
-    acol = aprod.cols(k0 + k4);
+  const int nkp = (nk + 1) & ~1;
+  // loader state: the chunk and tile the next request belongs to, the chunk's row descriptors (once per chunk: a producer's row()
+  // may read per-row statistics)
+  Chunk lc = chunk_at(u);
+  int lkt = 0;
+  bool lok = true;
+  typename AProd::Row lrow[C::A_LOADS];
+  auto loader_rows = [&]() {
 #pragma unroll
-    for (int j = 0; j < C::A_LOADS; ++j) areg[j] = aprod.raw(arow[j], k0 + k4);
+    for (int j = 0; j < C::A_LOADS; ++j) lrow[j] = aprod.row(lc.r0 + ((tid + C::NT * j) >> 3), lc.rend);
+  };
+  loader_rows();
+  auto load_next = [&](Slot& sl) {
+    if (lok) {
+      const int k0 = lkt * BK;
+      sl.acol = aprod.cols(k0 + k4);
 #pragma unroll
-    for (int j = 0; j < B_PIECES; ++j) {
-      const int idx = tid + C::NT * j;
-      const int n = idx >> 2, kp = (idx & 3) * 8;
-      const bool ok = n0 + n < d.N && k0 + kp < d.ldb;
-      const unsigned off = ok ? (unsigned)(((int64_t)(n0 + n) * d.ldb + k0 + kp) * 2) : ULTR_OOB;
-      bhr[j] = __builtin_amdgcn_raw_buffer_load_b128(bhs, off, 0, 0);
-      blr[j] = __builtin_amdgcn_raw_buffer_load_b128(bls, off, 0, 0);
+      for (int j = 0; j < C::A_LOADS; ++j) {
+        sl.arow[j] = lrow[j];
+        sl.areg[j] = aprod.raw(lrow[j], k0 + k4);
+      }
+#pragma unroll
+      for (int j = 0; j < B_PIECES; ++j) {
+        const int idx = tid + C::NT * j;
+        const int n = idx >> 2, kp = (idx & 3) * 8;
+        const bool ok = lc.n0 + n < d.N && k0 + kp < d.ldb;
+        const unsigned off = ok ? (unsigned)(((int64_t)(lc.n0 + n) * d.ldb + k0 + kp) * 2) : ULTR_OOB;
+        sl.bhr[j] = __builtin_amdgcn_raw_buffer_load_b128(bhs, off, 0, 0);
+        sl.blr[j] = __builtin_amdgcn_raw_buffer_load_b128(bls, off, 0, 0);
+      }
+      if (++lkt == nkp) {
+        lkt = 0;
+        const int64_t un = lc.u + lc.m_units;
+        if (un < u_end) {
+          lc = chunk_at(un);
+          loader_rows();
+        } else {
+          lok = false;
+        }
+      }
     }
-    __builtin_amdgcn_sched_barrier(0);
   };
-  auto store_tile = [&](int buf, int k0) {
+  auto store_tile = [&](const Slot& sl, int buf, int k0) {
     _Float16* Ahb = Ah + (size_t)buf * (2 * C::A_FLOATS);          // (A_FLOATS floats = 2 * A_FLOATS halves per stage)
     _Float16* Alb = Ahb + BM * LDH;
     _Float16* Bhb = Bh + (size_t)buf * (2 * C::B_FLOATS);
@@ -630,7 +667,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h3_kernel(Dims d, AProd apr
 #pragma unroll
     for (int j = 0; j < C::A_LOADS; ++j) {
       const int idx = tid + C::NT * j, row = idx >> 3;
-      const float4 v = aprod.finish(arow[j], acol, k0 + k4, areg[j]);
+      const float4 v = aprod.finish(sl.arow[j], sl.acol, k0 + k4, sl.areg[j]);
       // the largest magnitude of the row's 32 steps: the 8 threads of a row are 8 consecutive lanes
       float am = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
       am = fmaxf(am, dpp_or<0xb1>(am, am));
@@ -654,63 +691,75 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h3_kernel(Dims d, AProd apr
     for (int j = 0; j < B_PIECES; ++j) {
       const int idx = tid + C::NT * j;
       const int n = idx >> 2, kp = (idx & 3) * 8;
-      *reinterpret_cast<u32x4*>(Bhb + n * LDH + kp) = bhr[j];
-      *reinterpret_cast<u32x4*>(Blb + n * LDH + kp) = blr[j];
+      *reinterpret_cast<u32x4*>(Bhb + n * LDH + kp) = sl.bhr[j];
+      *reinterpret_cast<u32x4*>(Blb + n * LDH + kp) = sl.blr[j];
     }
   };
   f32x4 acc[C::RT][C::CT];
+  int live_rt = 0;
+  auto multiply = [&](int buf) {
+    if (live_rt > 0) {
+      const _Float16* Ahb = Ah + (size_t)buf * (2 * C::A_FLOATS) + (wr + i) * LDH + 8 * q;
+      const _Float16* Bhb = Bh + (size_t)buf * (2 * C::B_FLOATS) + (wc + i) * LDH + 8 * q;
+      h8v bh[C::CT], bl[C::CT];
+#pragma unroll
+      for (int ct = 0; ct < C::CT; ++ct) {
+        bh[ct] = *reinterpret_cast<const h8v*>(Bhb + ct * 16 * LDH);
+        bl[ct] = *reinterpret_cast<const h8v*>(Bhb + BN * LDH + ct * 16 * LDH);
+      }
+#pragma unroll
+      for (int rt = 0; rt < C::RT; ++rt) {
+        if (rt < live_rt) {
+          const h8v ah = *reinterpret_cast<const h8v*>(Ahb + rt * 16 * LDH);
+          const h8v al = *reinterpret_cast<const h8v*>(Ahb + BM * LDH + rt * 16 * LDH);
+          const float4 sc = ld4(Sc + buf * BM + wr + 16 * rt + 4 * q);  // the scales of this lane's four output rows
+          const float scv[4] = {sc.x, sc.y, sc.z, sc.w};
+#pragma unroll
+          for (int ct = 0; ct < C::CT; ++ct) {
+            f32x4 tmp = {0.f, 0.f, 0.f, 0.f};
+            tmp = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ct], tmp, 0, 0, 0);
+            tmp = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ct], tmp, 0, 0, 0);
+            tmp = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ct], tmp, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[rt][ct][r] = fmaf(tmp[r], scv[r], acc[rt][ct][r]);
+          }
+        }
+      }
+    }
+  };
 
-  begin_chunk(u);
-  load_tile(0);
-  store_tile(0, 0);
-  lds_barrier();
+  Slot s0, s1;
+  load_next(s0);
+  load_next(s1);
+  Chunk cur = chunk_at(u);
   for (;;) {
 #pragma unroll
     for (int rt = 0; rt < C::RT; ++rt)
 #pragma unroll
       for (int t = 0; t < C::CT; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    int live_rt = (16 * m_units - wr + 15) / 16;
+    live_rt = (16 * cur.m_units - wr + 15) / 16;
     live_rt = live_rt < 0 ? 0 : (live_rt > C::RT ? C::RT : live_rt);
-    for (int t = 0; t < nk; ++t) {
-      if (t + 1 < nk) load_tile((t + 1) * BK);
-      if (live_rt > 0) {
-        const int buf = t & 1;
-        const _Float16* Ahb = Ah + (size_t)buf * (2 * C::A_FLOATS) + (wr + i) * LDH + 8 * q;
-        const _Float16* Bhb = Bh + (size_t)buf * (2 * C::B_FLOATS) + (wc + i) * LDH + 8 * q;
-        h8v bh[C::CT], bl[C::CT];
-#pragma unroll
-        for (int ct = 0; ct < C::CT; ++ct) {
-          bh[ct] = *reinterpret_cast<const h8v*>(Bhb + ct * 16 * LDH);
-          bl[ct] = *reinterpret_cast<const h8v*>(Bhb + BN * LDH + ct * 16 * LDH);
-        }
-#pragma unroll
-        for (int rt = 0; rt < C::RT; ++rt) {
-          if (rt < live_rt) {
-            const h8v ah = *reinterpret_cast<const h8v*>(Ahb + rt * 16 * LDH);
-            const h8v al = *reinterpret_cast<const h8v*>(Ahb + BM * LDH + rt * 16 * LDH);
-            const float4 sc = ld4(Sc + buf * BM + wr + 16 * rt + 4 * q);  // the scales of this lane's four output rows
-            const float scv[4] = {sc.x, sc.y, sc.z, sc.w};
-#pragma unroll
-            for (int ct = 0; ct < C::CT; ++ct) {
-              f32x4 tmp = {0.f, 0.f, 0.f, 0.f};
-              tmp = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ct], tmp, 0, 0, 0);
-              tmp = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ct], tmp, 0, 0, 0);
-              tmp = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ct], tmp, 0, 0, 0);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) acc[rt][ct][r] = fmaf(tmp[r], scv[r], acc[rt][ct][r]);
-            }
-          }
-        }
+    store_tile(s0, 0, 0);
+    load_next(s0);
+    lds_barrier();
+    for (int t = 0; t < nkp; t += 2) {
+      multiply(0);
+      store_tile(s1, 1, (t + 1) * BK);
+      load_next(s1);
+      lds_barrier();
+      multiply(1);
+      if (t + 2 < nkp) {
+        store_tile(s0, 0, (t + 2) * BK);
+        load_next(s0);
       }
-      if (t + 1 < nk) store_tile((t + 1) & 1, (t + 1) * BK);
       lds_barrier();
     }
     // ---- the chunk's output through LDS (a lane holds one column of four tiles), as the n-major fp32 kernel ---------------
-    const int64_t e_r0 = r0, e_rend = rend;
-    const int e_n0 = n0;
-    const int64_t un = u + m_units;
+    // (s0 / s1 now hold the next chunk's first two tiles, in flight)
+    const int64_t e_r0 = cur.r0, e_rend = cur.rend;
+    const int e_n0 = cur.n0;
+    const int64_t un = cur.u + cur.m_units;
     const bool more = un < u_end;
-    if (more) begin_chunk(un);
     float* Cs = smem;
     constexpr int PIECES = BM * (BN / 4);
     constexpr int PPT = PIECES / C::NT;
@@ -746,10 +795,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h3_kernel(Dims d, AProd apr
     }
     if (!more) break;
     lds_barrier();  // the tile in LDS has been read
-    load_tile(0);
-    store_tile(0, 0);
-    lds_barrier();
-    u = un;
+    cur = chunk_at(un);
   }
 }
 
