@@ -556,6 +556,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(Dims d, AProd aprod,
 // Same persistent schedule, staging pattern and LDS-transposed epilogue as the n-major fp32 kernel.
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+#ifndef UGEMM_H3_ABLATE
+#define UGEMM_H3_ABLATE 0
+#endif
 constexpr int LDH = BK + 8;  // halves per LDS row of a plane (80 bytes: 16 rows x b128 reads fall into distinct bank groups)
 #define UGEMM_H3_WSCALE 256.0f
 
@@ -636,7 +639,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h3_kernel(Dims d, AProd apr
 #pragma unroll
       for (int j = 0; j < C::A_LOADS; ++j) {
         sl.arow[j] = lrow[j];
+#if UGEMM_H3_ABLATE == 1  // timing variant: no A traffic
+        sl.areg[j] = aprod.raw(lrow[j], 0x40000000);
+#else
         sl.areg[j] = aprod.raw(lrow[j], k0 + k4);
+#endif
       }
 #pragma unroll
       for (int j = 0; j < B_PIECES; ++j) {
@@ -717,8 +724,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h3_kernel(Dims d, AProd apr
 #pragma unroll
           for (int ct = 0; ct < C::CT; ++ct) {
             f32x4 tmp = {0.f, 0.f, 0.f, 0.f};
+#if UGEMM_H3_ABLATE != 3  // (3: timing variant without the cross terms)
             tmp = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ct], tmp, 0, 0, 0);
             tmp = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ct], tmp, 0, 0, 0);
+#endif
             tmp = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ct], tmp, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[rt][ct][r] = fmaf(tmp[r], scv[r], acc[rt][ct][r]);
@@ -788,7 +797,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h3_kernel(Dims d, AProd apr
       const int row = idx / (BN / 4), c4 = (idx - row * (BN / 4)) * 4;
       const int64_t r = e_r0 + row;
       const int c = e_n0 + c4;
+#if UGEMM_H3_ABLATE == 2  // timing variant: one row in 64 is stored
+      if (r < e_rend && c < d.N && (r & 63) == 0) {
+#else
       if (r < e_rend && c < d.N) {
+#endif
         const int nv = d.N - c < 4 ? d.N - c : 4;
         epi(r, c, ld4(Cs + row * C::LDC + c4), nv, pre[k]);
       }
