@@ -559,6 +559,9 @@ typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 #ifndef UGEMM_H3_ABLATE
 #define UGEMM_H3_ABLATE 0
 #endif
+#ifndef UGEMM_TRACE_STAMP  // phase tracing (-DULTR_TRACE builds of ultr_setrank.hip define it): s_memtime of wave 0 of every 32nd workgroup
+#define UGEMM_TRACE_STAMP(slot) do {} while (0)
+#endif
 constexpr int LDH = BK + 8;  // halves per LDS row of a plane (80 bytes: 16 rows x b128 reads fall into distinct bank groups)
 #define UGEMM_H3_WSCALE 256.0f
 
@@ -632,37 +635,39 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h3_kernel(Dims d, AProd apr
     for (int j = 0; j < C::A_LOADS; ++j) lrow[j] = aprod.row(lc.r0 + ((tid + C::NT * j) >> 3), lc.rend);
   };
   loader_rows();
+  // (no control flow around the loads: a load behind a branch makes hipcc's wait-count pass drain vmcnt(0) at every use - seen in this
+  // kernel's ISA as vmcnt(2) / (1) / (0) in front of EVERY tile, i.e. no look-ahead at all; past the end of the stream the offsets
+  // are out of range instead)
   auto load_next = [&](Slot& sl) {
-    if (lok) {
-      const int k0 = lkt * BK;
-      sl.acol = aprod.cols(k0 + k4);
+    const int k0 = lkt * BK;
+    const int ka = lok ? k0 + k4 : 0x40000000;
+    sl.acol = aprod.cols(k0 + k4);
 #pragma unroll
-      for (int j = 0; j < C::A_LOADS; ++j) {
-        sl.arow[j] = lrow[j];
+    for (int j = 0; j < C::A_LOADS; ++j) {
+      sl.arow[j] = lrow[j];
 #if UGEMM_H3_ABLATE == 1  // timing variant: no A traffic
-        sl.areg[j] = aprod.raw(lrow[j], 0x40000000);
+      sl.areg[j] = aprod.raw(lrow[j], 0x40000000);
 #else
-        sl.areg[j] = aprod.raw(lrow[j], k0 + k4);
+      sl.areg[j] = aprod.raw(lrow[j], ka);
 #endif
-      }
+    }
 #pragma unroll
-      for (int j = 0; j < B_PIECES; ++j) {
-        const int idx = tid + C::NT * j;
-        const int n = idx >> 2, kp = (idx & 3) * 8;
-        const bool ok = lc.n0 + n < d.N && k0 + kp < d.ldb;
-        const unsigned off = ok ? (unsigned)(((int64_t)(lc.n0 + n) * d.ldb + k0 + kp) * 2) : ULTR_OOB;
-        sl.bhr[j] = __builtin_amdgcn_raw_buffer_load_b128(bhs, off, 0, 0);
-        sl.blr[j] = __builtin_amdgcn_raw_buffer_load_b128(bls, off, 0, 0);
-      }
-      if (++lkt == nkp) {
-        lkt = 0;
-        const int64_t un = lc.u + lc.m_units;
-        if (un < u_end) {
-          lc = chunk_at(un);
-          loader_rows();
-        } else {
-          lok = false;
-        }
+    for (int j = 0; j < B_PIECES; ++j) {
+      const int idx = tid + C::NT * j;
+      const int n = idx >> 2, kp = (idx & 3) * 8;
+      const bool ok = lok && lc.n0 + n < d.N && k0 + kp < d.ldb;
+      const unsigned off = ok ? (unsigned)(((int64_t)(lc.n0 + n) * d.ldb + k0 + kp) * 2) : ULTR_OOB;
+      sl.bhr[j] = __builtin_amdgcn_raw_buffer_load_b128(bhs, off, 0, 0);
+      sl.blr[j] = __builtin_amdgcn_raw_buffer_load_b128(bls, off, 0, 0);
+    }
+    if (lok && ++lkt == nkp) {
+      lkt = 0;
+      const int64_t un = lc.u + lc.m_units;
+      if (un < u_end) {
+        lc = chunk_at(un);
+        loader_rows();
+      } else {
+        lok = false;
       }
     }
   };
@@ -748,21 +753,30 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h3_kernel(Dims d, AProd apr
       for (int t = 0; t < C::CT; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     live_rt = (16 * cur.m_units - wr + 15) / 16;
     live_rt = live_rt < 0 ? 0 : (live_rt > C::RT ? C::RT : live_rt);
+    UGEMM_TRACE_STAMP(0);
     store_tile(s0, 0, 0);
     load_next(s0);
     lds_barrier();
+    UGEMM_TRACE_STAMP(1);
     for (int t = 0; t < nkp; t += 2) {
+      if (t < 4) UGEMM_TRACE_STAMP(2 + 3 * t);
       multiply(0);
+      if (t < 4) UGEMM_TRACE_STAMP(3 + 3 * t);
       store_tile(s1, 1, (t + 1) * BK);
       load_next(s1);
+      if (t < 4) UGEMM_TRACE_STAMP(4 + 3 * t);
       lds_barrier();
+      if (t < 4) UGEMM_TRACE_STAMP(5 + 3 * t);
       multiply(1);
       if (t + 2 < nkp) {
         store_tile(s0, 0, (t + 2) * BK);
         load_next(s0);
       }
+      if (t < 4) UGEMM_TRACE_STAMP(6 + 3 * t);
       lds_barrier();
+      if (t < 4) UGEMM_TRACE_STAMP(7 + 3 * t);
     }
+    UGEMM_TRACE_STAMP(20);
     // ---- the chunk's output through LDS (a lane holds one column of four tiles), as the n-major fp32 kernel ---------------
     // (s0 / s1 now hold the next chunk's first two tiles, in flight)
     const int64_t e_r0 = cur.r0, e_rend = cur.rend;
@@ -806,6 +820,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h3_kernel(Dims d, AProd apr
         epi(r, c, ld4(Cs + row * C::LDC + c4), nv, pre[k]);
       }
     }
+    UGEMM_TRACE_STAMP(21);
     if (!more) break;
     lds_barrier();  // the tile in LDS has been read
     cur = chunk_at(un);
@@ -929,6 +944,11 @@ inline hipError_t run_h3(const Dims& d, const AProd& aprod, const _Float16* Bhi,
   if (d.N >= 256 && d.R >= 16384) return launch_h3<64, 256, 4, 2>(d, aprod, Bhi, Blo, epi, st);
 #elif UGEMM_H3_VARIANT == 2
   if (d.N >= 128 && d.R >= 16384) return launch_h3<128, 128, 4, 2>(d, aprod, Bhi, Blo, epi, st);
+#elif UGEMM_H3_VARIANT == 3  // four waves of 32 x 64 per 64 x 128 chunk: twice the MFMAs per staged byte and per loop overhead of a wave
+  if (d.N > 64) return launch_h3<64, 128, 2, 2>(d, aprod, Bhi, Blo, epi, st);
+  return launch_h3<64, 64, 2, 1>(d, aprod, Bhi, Blo, epi, st);
+#elif UGEMM_H3_VARIANT == 4
+  if (d.N > 64) return launch_h3<64, 128, 2, 2>(d, aprod, Bhi, Blo, epi, st);
 #endif
   if (d.N > 64) return launch_h3<64, 128, 4, 2>(d, aprod, Bhi, Blo, epi, st);
   return launch_h3<64, 64, 4, 1>(d, aprod, Bhi, Blo, epi, st);

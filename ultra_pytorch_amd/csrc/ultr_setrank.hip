@@ -20,6 +20,22 @@
 
 #include "../../include/ultr_hip.h"
 #include "ultr_device.h"
+#ifdef ULTR_TRACE
+__device__ unsigned long long g_ugemm_trace[64 * 32];
+#define UGEMM_TRACE_STAMP(slot)                                                                    \
+  do {                                                                                             \
+    if (threadIdx.x == 0 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 64 && g_ugemm_trace[(blockIdx.x >> 3) * 32 + 31] == 0ull) \
+      g_ugemm_trace[(blockIdx.x >> 3) * 32 + (slot)] = __builtin_amdgcn_s_memtime();              \
+  } while (0)
+extern "C" int ultr_gemm_trace_read(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ugemm_trace), sizeof(unsigned long long) * 64 * 32);
+}
+extern "C" int ultr_gemm_trace_arm(int on) {  // slot 31 != 0: frozen
+  unsigned long long z[64 * 32];
+  for (int k = 0; k < 64 * 32; ++k) z[k] = (on || (k & 31) != 31) ? 0ull : 1ull;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ugemm_trace), z, sizeof(z));
+}
+#endif
 #include "ultr_gemm.h"
 #include "ultr_plan.h"
 
