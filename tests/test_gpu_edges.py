@@ -431,7 +431,7 @@ def test_weight_drifting_towards_the_split_half_range_switches_plans_in_time(rea
 
 
 @pytest.mark.parametrize("separate", [False, True])
-def test_split_half_products_with_wide_dynamic_range(separate, monkeypatch):
+def test_split_half_products_with_wide_dynamic_range(separate, wgrad_path, monkeypatch):
     """The error budget of the split-half (fp16 hi / lo) products at its edges: feature rows with a 1e4
     outlier next to 1e-4 entries (LayerNorm_0 bounds what reaches the product, but the row's scale is set by its largest
     element), all-zero rows, weights from 1e-7 to 60 in one layer, LayerNorm gains up to 30 - scores, loss and gradients against
@@ -473,7 +473,8 @@ def test_split_half_products_with_wide_dynamic_range(separate, monkeypatch):
         g = eng.grads[:shape.n_params].cpu().numpy() / sc[3]
         gmax = float(np.abs(ref["grads"]).max())
         err = np.abs(g - ref["grads"]).max() / max(gmax, 1e-30)
-        margins.check("edges/split_half_dynamic_range" + ("_separate" if separate else ""), "grads_max_abs_diff_over_max_abs_g", err)
+        margins.check("edges/split_half_dynamic_range" + ("_separate" if separate else "") + ("" if wgrad_path == "slabs" else "_wgrad_" + wgrad_path),
+                      "grads_max_abs_diff_over_max_abs_g", err)
         np.testing.assert_allclose(g, ref["grads"], rtol=1e-5, atol=1e-5 * max(1.0, gmax))
     finally:
         if separate:
@@ -509,3 +510,40 @@ def test_wide_layers_with_every_activation_match_oracle(act, separate, monkeypat
         if separate:
             monkeypatch.delenv("ULTR_NO_FUSED_FB")
             shape.lib.ultr_config_reload()
+
+
+def test_split_half_weight_gradients_across_a_wide_range_of_dz(monkeypatch):
+    """dnn_wgrad_h3_kernel's scale is ONE power of two per 64 columns of an operand and wave group: rows of dz that differ by
+    2^20 inside a workgroup's walk (the scale is lowered on the way and the sums follow exactly) and a block of columns 2^16 below its neighbours.
+    Every entry of dW_1 against an fp64 product of the same dz and u within 1e-5 x (|entry| + sum of |terms|) - the bar of the full-size tests -
+    through the stage API with hand-made dscores-free inputs: forward, then ultr_dnn_backward on a crafted dscores vector."""
+    from oracle import ultr_oracle as O
+    from tests.hipref import HipRun
+    monkeypatch.setenv("ULTR_WG_H3", "2")
+    monkeypatch.setenv("ULTR_NO_FUSED_FB", "1")
+    F, hidden, B, L = 136, [256, 128], 40, 10
+    rng = np.random.RandomState(3)
+    n_docs = B * L
+    feats = rng.uniform(-1, 1, size=(n_docs, F)).astype(np.float32)
+    ids = rng.permutation(n_docs).astype(np.int32).reshape(L, B)
+    params = O.init_params(F, hidden, seed=2)
+    for name, shape, off in O.param_layout(F, hidden):
+        if name.endswith("linear1.weight"):  # output units 0..31 of layer 1 see 2^-16 of the gradient of the others
+            w = params[off:off + int(np.prod(shape))].reshape(shape)
+            w[:32] *= 2.0 ** -16
+    try:
+        run = HipRun(F, hidden, B, L, algo="softmax")
+        run.set_inputs(feats, ids, np.zeros((L, B), np.float32))
+        run.forward(params)
+        ds = rng.normal(size=(B, L)).astype(np.float32)
+        ds[: B // 2] *= 2.0 ** -20  # the first half of the lists: gradients a million times smaller
+        g, _ = run.backward(dscores=ds)
+        x = O.gather_rows(feats, ids).numpy()
+        ref = O.dnn_backward_manual(params, F, hidden, x, ds.T.reshape(-1))
+        terms = O.dnn_backward_manual(params, F, hidden, x, ds.T.reshape(-1), abs_terms=True)
+        bad = np.abs(g - ref) > 1e-5 * (np.abs(ref) + terms)
+        assert not bad.any(), (int(bad.sum()), float((np.abs(g - ref) / np.maximum(terms, 1e-30)).max()))
+    finally:
+        monkeypatch.undo()
+        from ultra_pytorch_amd import _lib
+        _lib.load().ultr_config_reload()
