@@ -268,9 +268,9 @@ def test_fp16_attention_against_the_oracle_directly(shape):
 
 @pytest.fixture
 def split_attention(monkeypatch):
-    """ULTR_SR_ATTN_H3=1: the opt-in split-half attention kernels (sr_attn_fwd_h3_kernel / sr_attn_bwd_h3_kernel)."""
+    """ULTR_SR_ATTN_H3=2: the split-half attention kernels in BOTH directions (the backward one is the default, the forward one opt-in)."""
     from ultra_pytorch_amd import _lib
-    monkeypatch.setenv("ULTR_SR_ATTN_H3", "1")
+    monkeypatch.setenv("ULTR_SR_ATTN_H3", "2")
     _lib.load().ultr_config_reload()
     yield
     monkeypatch.undo()
@@ -315,17 +315,22 @@ def test_split_half_attention_at_full_size(monkeypatch):
     kw = dict(learning_rate=0.05, max_gradient_norm=5.0)
     out = {}
     try:
-        for mode in ("0", "1"):
+        for mode in ("0", "1", "2"):
             monkeypatch.setenv("ULTR_SR_ATTN_H3", mode)
             _lib.load().ultr_config_reload()
             out[mode] = run_step(shape, B, L, kw, p0, np.zeros_like(p0), feats, ids, y, None)
     finally:
         monkeypatch.undo()
         _lib.load().ultr_config_reload()
-    s32, s3 = out["0"][0], out["1"][0]
+    s32, s3 = out["0"][0], out["2"][0]
     assert not np.array_equal(s32, s3), "the split-half attention did not run"
+    # the default (= "1": split-half BACKWARD kernel only): every score bit for bit, gradients within 1e-6 of the largest entry
+    assert np.array_equal(out["1"][0], s32)
+    n1 = shape.n_params
+    gd = np.abs(out["1"][1][:n1] - out["0"][1][:n1]).max()
+    assert 0.0 < gd <= 1e-6 * np.abs(out["0"][1][:n1]).max(), gd
     dd = np.abs(s3 - s32)
     assert np.quantile(dd, 0.99) <= 1e-6 and dd.max() <= 6e-5, (np.quantile(dd, 0.99), dd.max())
     n = shape.n_params
-    g32, g3 = out["0"][1][:n], out["1"][1][:n]
+    g32, g3 = out["0"][1][:n], out["2"][1][:n]
     assert np.abs(g3 - g32).max() <= 3e-5 * np.abs(g32).max()

@@ -1325,18 +1325,21 @@ __global__ __launch_bounds__(SR_MAXT * 64) void sr_attn_bwd_f16_kernel(const flo
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Split-half attention (round 4, OPT-IN: ULTR_SR_ATTN_H3=1): the fp16-operand kernels above with every operand as hi (+ mid) + lo
+// Split-half attention (round 4; backward: default, forward: OPT-IN ULTR_SR_ATTN_H3=2): the fp16-operand kernels above with every operand as hi (+ mid) + lo
 // fp16 planes and every product as three (S = x x^T and the forward's P V: six) f16 MFMAs with fp32 accumulation.  Scales are powers
 // of two per (list, head) slice: x to just below 2^10, dA to just below 2^4 (dS = P (dP - t) / sqrt(dh) stays far below fp16's 65504
 // for |x| up to several hundred), probabilities by 2^12; all are removed exactly in the epilogues.
-// WHY IT IS NOT THE DEFAULT.  The operands are exact to 2^-33 this way, but the instruction is not an fp32 dot product: inside
+// WHY THE FORWARD KERNEL IS NOT THE DEFAULT.  The operands are exact to 2^-33 this way, but the instruction is not an fp32 dot product: inside
 // v_mfma_f32_16x16x32_f16 the 32 products are aligned to the LARGEST of them and truncated ~25 bits below it before they are added
 // (tools/mfma_f16_accum_test.hip: 2^20 + 31 x 0.111 comes out 0.44 low, 3.5 fp32 ulps, and the result depends on where the large
 // product sits).  A dot product with one dominant term therefore carries a biased error of up to ~2^-20 of that term.  The DNN's
 // products never notice (LayerNorm rows, 1e-6 on scores at every BASELINE config); attention does: a token with |x|^2 ~ 150 in a
 // head has a logit of ~26 and its softmax row is a difference of such logits - config 5 at full size: ONE score in each of ~14 of
 // 1024 lists moves by 5e-6 .. 3e-5 against the fp32 matrix-core kernels (everything else agrees to 5e-7), the permutation test
-// of tests/test_gpu_setrank.py (2e-5) fails, 3 075 -> 2 823 us per step.  Between the fp16 opt-in (1e-3) and the fp32 default.
+// of tests/test_gpu_setrank.py (2e-5) fails.  The BACKWARD kernel has no such amplifier behind it: its P is recomputed from the same
+// truncated S, but the error enters dS, dq, dk, dv linearly and is summed over 102 400 tokens into the weight gradients - 1.8e-7 of
+// the largest gradient entry at config 5 (bar: 1e-5 relative + 2e-6 of the largest), scores bit for bit those of the fp32 forward.
+// Config 5: 3 020 -> 2 866 us with the backward kernel alone (383 -> 309 us per launch), 2 845 with both.
 // ---------------------------------------------------------------------------------------------------------
 #ifndef SRS_NO_MIX
 #define SRS_NO_MIX 1
@@ -1960,8 +1963,8 @@ void sr_knobs_load() {
   if (g_sr_knob_h3 >= 0) return;
   const char* e = getenv("ULTR_SR_H3");
   g_sr_knob_h3 = (e && *e) ? atoi(e) : 1;
-  e = getenv("ULTR_SR_ATTN_H3");
-  g_sr_knob_attn_h3 = (e && *e) ? atoi(e) : 0;
+  e = getenv("ULTR_SR_ATTN_H3");  // 0: fp32 matrix cores; 1 (default): split-half BACKWARD kernel; 2: split-half forward too (opt-in)
+  g_sr_knob_attn_h3 = (e && *e) ? atoi(e) : 1;
   e = getenv("ULTR_SR_ATTN_H3_MASK");  // debug: bit (2 layer + dir), dir 0 forward / 1 backward
   g_sr_knob_attn_mask = (e && *e) ? atoi(e) : -1;
   e = getenv("ULTR_SR_WG_H3");
@@ -2189,11 +2192,17 @@ int attn_bwd_f16(const SrPlan& p, const float* x, const float* dA, const float* 
   }
   return 0;
 }
-// split-half kernels: opt-in (ULTR_SR_ATTN_H3=1) for fp32 attention at head depth 32 / 64, list_size <= 128 - see the kernels' header for
-// why the fp32 matrix cores stay the default
+// split-half kernels for fp32 attention at head depth 32 / 64, list_size <= 128: the BACKWARD kernel by default (ULTR_SR_ATTN_H3=1: the
+// forward and therefore every score stays on the fp32 matrix cores bit for bit; gradients move by 1.8e-7 of the largest entry at config 5),
+// the forward kernel only as an opt-in (=2) - see the kernels' header for why; =0: fp32 matrix cores everywhere
 bool attn_h3_ok(const SrPlan& p, int L, int layer = 0, int dir = 0) {
   sr_knobs_load();
-  return g_sr_knob_attn_h3 != 0 && ((g_sr_knob_attn_mask >> (2 * layer + dir)) & 1) && !p.att_f16 && attn_mfma_ok(p, L) && (p.dh == 32 || p.dh == 64);
+  const bool want = dir == 1 ? g_sr_knob_attn_h3 >= 1 : g_sr_knob_attn_h3 >= 2;
+  // the planes of a slice must leave room for two workgroups per CU (head depth 64 at list sizes > ~50 does not: fp32 matrix cores there)
+  const int Lp = round_up(L, 16), lt = Lp + 24;
+  const size_t lds = ((size_t)(dir == 1 ? 5 : 3) * Lp * (p.dh + 8) + (size_t)(dir == 1 ? 4 : 3) * p.dh * lt) * sizeof(_Float16) + 1400;
+  if (lds > 82 * 1024) return false;
+  return want && ((g_sr_knob_attn_mask >> (2 * layer + dir)) & 1) && !p.att_f16 && attn_mfma_ok(p, L) && (p.dh == 32 || p.dh == 64);
 }
 int attn_fwd_h3(const SrPlan& p, const float* x, int batch, int L, float* A, float* lse, hipStream_t st) {
   const int Lp = round_up(L, 16), lt = Lp + 24;
