@@ -1583,8 +1583,7 @@ __global__ __launch_bounds__(SR_MAXT * 64) void sr_attn_bwd_h3_kernel(const floa
   const int Lp = round_up(L, 16), NTL = Lp / 16, lt = 16 * NTL + 24;
   _Float16* xh = reinterpret_cast<_Float16*>(smem);  // x: [Lp][LDH] hi, lo
   _Float16* xl = xh + Lp * LDH;
-  _Float16* x3 = xl + Lp * LDH;
-  _Float16* gh = x3 + Lp * LDH;                      // dA
+  _Float16* gh = xl + Lp * LDH;                      // dA
   _Float16* gl = gh + Lp * LDH;
   _Float16* xth = gl + Lp * LDH;                     // transposed [DH][lt]: x hi, lo, dA hi, lo
   _Float16* xtl = xth + DH * lt;
@@ -1611,15 +1610,19 @@ __global__ __launch_bounds__(SR_MAXT * 64) void sr_attn_bwd_h3_kernel(const floa
     red[wave] = amx;
     red[SR_MAXT + wave] = amg;
   }
-  for (int e = tid; e < 16 * (SR_MAXT + 1) * RT; e += nthr) {  // t = dA . A in fp32 from the fp32 inputs; lse
+  // t = dA . A in fp32 from the fp32 inputs (the dA values this thread holds for the planes; the 8 (16) threads of a row are consecutive
+  // lanes), and the forward's lse; rows past L: P = 0 through lse = +inf
+#pragma unroll
+  for (int k = 0; k < DH / 16; ++k) {
+    const int e = tid + nthr * k;
     const int r = e / RT, c4 = (e - r * RT) * 4;
     const bool ok = r < L;
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 g4 = ok ? ld4(dA + base + (int64_t)r * d + c4) : z4;
-    const float4 av = ok ? ld4(Aout + base + (int64_t)r * d + c4) : z4;
-    float tt = g4.x * av.x + g4.y * av.y + g4.z * av.z + g4.w * av.w;
-#pragma unroll
-    for (int m = 1; m < RT; m <<= 1) tt += __shfl_xor(tt, m);
+    const float4 av = ok ? ld4(Aout + base + (int64_t)r * d + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float tt = gv[k].x * av.x + gv[k].y * av.y + gv[k].z * av.z + gv[k].w * av.w;
+    tt += dpp_or<0xb1>(0.f, tt);
+    tt += dpp_or<0x4e>(0.f, tt);
+    tt += dpp_or<0x141>(0.f, tt);  // row_half_mirror: the other four lanes of the group of eight
+    if (RT == 16) tt += dpp_or<0x140>(0.f, tt);  // row_mirror: the other eight of sixteen
     if ((e - r * RT) == 0) {
       st_t[r] = tt;
       st_l[r] = ok ? lse[((int64_t)b * L + r) * H + h] * 1.44269504088896341f : INFINITY;
@@ -1633,17 +1636,16 @@ __global__ __launch_bounds__(SR_MAXT * 64) void sr_attn_bwd_h3_kernel(const floa
   }
   const float sx = srs_pow2_scale(amx, 10), isx = 1.0f / sx;
   const float sg = srs_pow2_scale(amg, 4), isg = 1.0f / sg;
-  srs_store<DH>(xv, sx, tid, nthr, xh, xl, xth, xtl, lt, x3);
+  srs_store<DH>(xv, sx, tid, nthr, xh, xl, xth, xtl, lt);
   srs_store<DH>(gv, sg, tid, nthr, gh, gl, gth, gtl, lt);
   __syncthreads();
   const float scale = 1.0f / sqrtf((float)DH);
-  h8 bxh[NF], bxl[NF], bx3[NF], bgh[NF], bgl[NF];
+  h8 bxh[NF], bxl[NF], bgh[NF], bgl[NF];
 #pragma unroll
   for (int f = 0; f < NF; ++f) {
     const int o = (wave * 16 + i) * LDH + 32 * f + 8 * q;
     bxh[f] = *reinterpret_cast<const h8*>(xh + o);
     bxl[f] = *reinterpret_cast<const h8*>(xl + o);
-    bx3[f] = *reinterpret_cast<const h8*>(x3 + o);
     bgh[f] = *reinterpret_cast<const h8*>(gh + o);
     bgl[f] = *reinterpret_cast<const h8*>(gl + o);
   }
@@ -1658,7 +1660,7 @@ __global__ __launch_bounds__(SR_MAXT * 64) void sr_attn_bwd_h3_kernel(const floa
     dsa = dsb = pb = f32x4{0.f, 0.f, 0.f, 0.f};
     if (!live) return;
     const int o = (t * 16 + i) * LDH + 8 * q;
-    const f32x4 sc = srs_tile6<DH>(xh + o, xl + o, x3 + o, bxh, bxl, bx3);   // sx^2 S[16 t + 4 q + r][own i]  (symmetric: both roles)
+    const f32x4 sc = srs_tile<DH>(xh + o, xl + o, bxh, bxl);   // sx^2 S[16 t + 4 q + r][own i]  (symmetric: both roles; two pieces: a third changes nothing measurable)
     const f32x4 dpt = srs_tile<DH>(xh + o, xl + o, bgh, bgl);  // sx sg dP^T[key 16 t + 4 q + r][query own i] = x[key] . dA[query]
     const f32x4 dpn = srs_tile<DH>(gh + o, gl + o, bxh, bxl);  // sx sg dP[query 16 t + 4 q + r][key own i]   = dA[query] . x[key]
     const float4 l4 = ld4(st_l + t * 16 + 4 * q), t4 = ld4(st_t + t * 16 + 4 * q);
@@ -2200,7 +2202,7 @@ bool attn_h3_ok(const SrPlan& p, int L, int layer = 0, int dir = 0) {
   const bool want = dir == 1 ? g_sr_knob_attn_h3 >= 1 : g_sr_knob_attn_h3 >= 2;
   // the planes of a slice must leave room for two workgroups per CU (head depth 64 at list sizes > ~50 does not: fp32 matrix cores there)
   const int Lp = round_up(L, 16), lt = Lp + 24;
-  const size_t lds = ((size_t)(dir == 1 ? 5 : 3) * Lp * (p.dh + 8) + (size_t)(dir == 1 ? 4 : 3) * p.dh * lt) * sizeof(_Float16) + 1400;
+  const size_t lds = ((size_t)(dir == 1 ? 4 : 3) * Lp * (p.dh + 8) + (size_t)(dir == 1 ? 4 : 3) * p.dh * lt) * sizeof(_Float16) + 1400;
   if (lds > 82 * 1024) return false;
   return want && ((g_sr_knob_attn_mask >> (2 * layer + dir)) & 1) && !p.att_f16 && attn_mfma_ok(p, L) && (p.dh == 32 || p.dh == 64);
 }
@@ -2220,7 +2222,7 @@ int attn_fwd_h3(const SrPlan& p, const float* x, int batch, int L, float* A, flo
 int attn_bwd_h3(const SrPlan& p, const float* x, const float* dA, const float* Aout, const float* lse, int batch, int L, float* dx,
                 hipStream_t st) {
   const int Lp = round_up(L, 16), lt = Lp + 24;
-  const size_t lds = ((size_t)5 * Lp * (p.dh + 8) + (size_t)4 * p.dh * lt) * sizeof(_Float16) +
+  const size_t lds = ((size_t)4 * Lp * (p.dh + 8) + (size_t)4 * p.dh * lt) * sizeof(_Float16) +
                      ((size_t)2 * 16 * (SR_MAXT + 1) + 2 * SR_MAXT) * sizeof(float);
   const dim3 grid(batch, p.H), block(Lp * 4);
   if (p.dh == 32) {
