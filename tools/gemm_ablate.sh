@@ -2,7 +2,7 @@
 # (tools/ab_build.sh g_noa "-DUGEMM_H3_ABLATE=1" g_nostore "-DUGEMM_H3_ABLATE=2" g_nocross "-DUGEMM_H3_ABLATE=3")
 REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-for v in product g_noa g_nostore g_nocross; do
+for v in product g_noa g_nostore g_nocross g_norescale g_noconv; do
 if [ $v = product ]; then unset ULTR_HIP_LIB; else export ULTR_HIP_LIB=$REPO/ultra_pytorch_amd/lib/variants/libultr_$v.so; fi
 rm -rf /tmp/ga_$v
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ga_$v -o s -- python $REPO/bench.py --config 5 --no-cpu-baseline --no-extras --steps 20 > /tmp/ga_$v.log 2>&1
