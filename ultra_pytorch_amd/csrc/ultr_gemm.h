@@ -851,12 +851,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h3_kernel(Dims d, AProd apr
 // and leaves the per-element work (conversion, LDS traffic) as it is.  One LDS stage (the planes of a 64 x 64 A tile and a
 // BN x 64 B tile: 55 KB, two workgroups per CU) and the two register slots of the stream: a tile is written after the barrier that
 // ends the products of the tile before it.  Scales: per row and 64-deep tile (16 lanes per row).
-constexpr int BKW = 64;
-constexpr int LDW = BKW + 8;  // halves per LDS row of a plane (144 bytes: the 16 rows of a b128 read fall into distinct bank groups)
-template <int BM, int BN, int WM, int WN, class AProd, class Epi>
+// (BKW = 32: the same single-stage structure with 32-deep tiles - 31 KB of LDS, four workgroups per CU)
+template <int BM, int BN, int WM, int WN, int BKW, class AProd, class Epi>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_h3w_kernel(Dims d, AProd aprod, const _Float16* __restrict__ Bhi,
                                                                 const _Float16* __restrict__ Blo, Epi epi) {
-  constexpr int NT = WM * WN * 64, RT = BM / WM / 16, CT = BN / WN / 16, LDC = BN + 4;
+  constexpr int NT = WM * WN * 64, RT = BM / WM / 16, CT = BN / WN / 16, LDC = BN + 4, LDW = BKW + 8, TPR = BKW / 4, PPR = BKW / 8;
   static_assert(CT == 4, "a wave owns 64 output columns");
   constexpr int A_LOADS = BM * (BKW / 4) / NT;     // float4 per thread per tile
   constexpr int B_PIECES = BN * (BKW / 8) / NT;    // 16-byte pieces (8 halves) per thread per plane per tile
@@ -882,7 +881,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h3w_kernel(Dims d, AProd ap
   const __amdgpu_buffer_rsrc_t bls = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(Blo), 0, (int)(bplane * 2), 0x00020000);
   const int nk = (d.K + BKW - 1) / BKW;
   const int nkp = (nk + 1) & ~1;
-  const int k4 = (tid & 15) * 4;
+  const int k4 = (tid & (TPR - 1)) * 4;
   struct Chunk {
     int64_t u, r0, rend;
     int n0, m_units;
@@ -913,11 +912,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h3w_kernel(Dims d, AProd ap
   unsigned lboff[B_PIECES];  // byte offset of this thread's pieces in the planes at k-tile 0 of the loader's chunk (out of range: n >= N)
   auto loader_rows = [&]() {
 #pragma unroll
-    for (int j = 0; j < A_LOADS; ++j) lrow[j] = aprod.row(lc.r0 + ((tid + NT * j) >> 4), lc.rend);
+    for (int j = 0; j < A_LOADS; ++j) lrow[j] = aprod.row(lc.r0 + ((tid + NT * j) / TPR), lc.rend);
 #pragma unroll
     for (int j = 0; j < B_PIECES; ++j) {
       const int idx = tid + NT * j;
-      const int n = idx >> 3, kp = (idx & 7) * 8;
+      const int n = idx / PPR, kp = (idx % PPR) * 8;
       lboff[j] = (lc.n0 + n < d.N) ? (unsigned)(((int64_t)(lc.n0 + n) * d.ldb + kp) * 2) : ULTR_OOB;
     }
   };
@@ -933,7 +932,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h3w_kernel(Dims d, AProd ap
     }
 #pragma unroll
     for (int j = 0; j < B_PIECES; ++j) {
-      const int kp = ((tid + NT * j) & 7) * 8;
+      const int kp = ((tid + NT * j) % PPR) * 8;
       const bool ok = lok && lboff[j] != ULTR_OOB && k0 + kp < d.ldb;
       const unsigned off = ok ? lboff[j] + (unsigned)k0 * 2u : ULTR_OOB;
       sl.bhr[j] = __builtin_amdgcn_raw_buffer_load_b128(bhs, off, 0, 0);
@@ -955,14 +954,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h3w_kernel(Dims d, AProd ap
     _Float16* Bl = Bh + BN * LDW;
 #pragma unroll
     for (int j = 0; j < A_LOADS; ++j) {
-      const int idx = tid + NT * j, row = idx >> 4;
+      const int idx = tid + NT * j, row = idx / TPR;
       const float4 v = aprod.finish(sl.arow[j], sl.acol, k0 + k4, sl.areg[j]);
       // the largest magnitude of the row's 64 steps: the 16 threads of a row are one DPP row
       float am = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
       am = fmaxf(am, dpp_or<0xb1>(am, am));
       am = fmaxf(am, dpp_or<0x4e>(am, am));
       am = fmaxf(am, dpp_or<0x141>(am, am));  // row_half_mirror
-      am = fmaxf(am, dpp_or<0x140>(am, am));  // row_mirror
+      if constexpr (TPR == 16) am = fmaxf(am, dpp_or<0x140>(am, am));  // row_mirror
       int se = 267 - (int)((__float_as_uint(am) >> 23) & 0xffu);  // am * 2^(se - 127) < 2^14
       se = se < 1 ? 1 : (se > 253 ? 253 : se);
       const float rs = __uint_as_float((unsigned)se << 23);
@@ -975,12 +974,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h3w_kernel(Dims d, AProd ap
       }
       *reinterpret_cast<h4v*>(Ah + row * LDW + k4) = hi;
       *reinterpret_cast<h4v*>(Al + row * LDW + k4) = lo;
-      if ((tid & 15) == 0) Sc[row] = __uint_as_float((unsigned)(254 - se) << 23) * (1.0f / UGEMM_H3_WSCALE);
+      if ((tid & (TPR - 1)) == 0) Sc[row] = __uint_as_float((unsigned)(254 - se) << 23) * (1.0f / UGEMM_H3_WSCALE);
     }
 #pragma unroll
     for (int j = 0; j < B_PIECES; ++j) {
       const int idx = tid + NT * j;
-      const int n = idx >> 3, kp = (idx & 7) * 8;
+      const int n = idx / PPR, kp = (idx % PPR) * 8;
       *reinterpret_cast<u32x4*>(Bh + n * LDW + kp) = sl.bhr[j];
       *reinterpret_cast<u32x4*>(Bl + n * LDW + kp) = sl.blr[j];
     }
@@ -1205,10 +1204,10 @@ inline hipError_t launch_h3(const Dims& d, const AProd& aprod, const _Float16* B
   return hipGetLastError();
 }
 
-template <int BM, int BN, int WM, int WN, class AProd, class Epi>
+template <int BM, int BN, int WM, int WN, int BKW, class AProd, class Epi>
 inline hipError_t launch_h3w(const Dims& d, const AProd& aprod, const _Float16* Bhi, const _Float16* Blo, const Epi& epi, hipStream_t st) {
-  auto kern = gemm_h3w_kernel<BM, BN, WM, WN, AProd, Epi>;
-  constexpr int NT = WM * WN * 64;
+  auto kern = gemm_h3w_kernel<BM, BN, WM, WN, BKW, AProd, Epi>;
+  constexpr int NT = WM * WN * 64, LDW = BKW + 8;
   constexpr size_t stage = (size_t)(2 * BM * LDW + 2 * BN * LDW) * sizeof(_Float16) + BM * sizeof(float);
   constexpr size_t cbytes = (size_t)BM * (BN + 4) * sizeof(float);
   const size_t lds = cbytes > stage ? cbytes : stage;
@@ -1261,11 +1260,14 @@ inline hipError_t run_h3(const Dims& d, const AProd& aprod, const _Float16* Bhi,
 #elif UGEMM_H3_VARIANT == 4
   if (d.N > 64) return launch_h3<64, 128, 2, 2>(d, aprod, Bhi, Blo, epi, st);
 #endif
-#if UGEMM_H3_WIDE  // 64-deep contraction tiles (gemm_h3w_kernel)
+#if UGEMM_H3_WIDE == 1  // 64-deep contraction tiles on one LDS stage (gemm_h3w_kernel)
   if (d.K >= 64) {
-    if (d.N > 64) return launch_h3w<64, 128, 4, 2>(d, aprod, Bhi, Blo, epi, st);
-    return launch_h3w<64, 64, 4, 1>(d, aprod, Bhi, Blo, epi, st);
+    if (d.N > 64) return launch_h3w<64, 128, 4, 2, 64>(d, aprod, Bhi, Blo, epi, st);
+    return launch_h3w<64, 64, 4, 1, 64>(d, aprod, Bhi, Blo, epi, st);
   }
+#elif UGEMM_H3_WIDE == 2  // 32-deep tiles on one LDS stage: half the LDS, twice the workgroups per CU
+  if (d.N > 64) return launch_h3w<64, 128, 4, 2, 32>(d, aprod, Bhi, Blo, epi, st);
+  return launch_h3w<64, 64, 4, 1, 32>(d, aprod, Bhi, Blo, epi, st);
 #endif
   if (d.N > 64) return launch_h3<64, 128, 4, 2>(d, aprod, Bhi, Blo, epi, st);
   return launch_h3<64, 64, 4, 1>(d, aprod, Bhi, Blo, epi, st);
