@@ -572,6 +572,55 @@ struct PipeH3 {
 #endif
     }
   }
+  // RT row tiles of 16 rows behind ONE weight stream (dnn_fwd_kernel with 32-row tiles: every weight fragment feeds 2 x 6 MFMAs) - the same
+  // accumulator layout per row tile
+  template <int S, int RT>
+  __device__ __forceinline__ void consume_rt(const _Float16* __restrict__ ah_p, const _Float16* __restrict__ al_p, int ldh, f32x4 (&acc)[RT][2],
+                                             f32x4 (&accx)[RT][2], f32x4 (&accy)[RT][2]) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const fbh8 ah = *reinterpret_cast<const fbh8*>(ah_p + rt * 16 * ldh), al = *reinterpret_cast<const fbh8*>(al_p + rt * 16 * ldh);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const fbh8 wh = fb_as_h8(b[S][2 * t]), wl = fb_as_h8(b[S][2 * t + 1]);
+        acc[rt][t] = fb_mfma_h(ah, wh, acc[rt][t]);
+        accx[rt][t] = fb_mfma_h(ah, wl, accx[rt][t]);
+        accy[rt][t] = fb_mfma_h(al, wh, accy[rt][t]);
+      }
+    }
+  }
+  template <int RT>
+  __device__ __forceinline__ void run_rt(const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al, int ldh, const Src& W, int nks,
+                                         f32x4 (&acc)[RT][2], f32x4 (&accx)[RT][2], int lane) {
+    const int i = lane & 15, q = lane >> 4;
+    const _Float16* ph = Ah + i * ldh + 8 * q;
+    const _Float16* pl = Al + i * ldh + 8 * q;
+    f32x4 accy[RT][2];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) accy[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto step = [&](auto uc) {
+      constexpr int U = decltype(uc)::value;
+      fetch<(U + D - 1) % D>(W);
+      __builtin_amdgcn_sched_barrier(0);
+      consume_rt<U, RT>(ph, pl, ldh, acc, accx, accy);
+      ph += 32;
+      pl += 32;
+    };
+    int t = 0;
+    for (; t + D <= nks; t += D) {
+      step(std::integral_constant<int, 0>());
+      step(std::integral_constant<int, 1>());
+      if constexpr (D > 2) step(std::integral_constant<int, 2>());
+    }
+    if (t < nks) { consume_rt<0, RT>(ph, pl, ldh, acc, accx, accy); ph += 32; pl += 32; }
+    if constexpr (D > 2) if (t + 1 < nks) { consume_rt<1, RT>(ph, pl, ldh, acc, accx, accy); ph += 32; pl += 32; }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) accx[rt][tt] += accy[rt][tt];
+  }
   // Ah / Al: the two planes of the A tile, row stride ldh halves, zero beyond the real contraction length up to nks * 32
   __device__ __forceinline__ void run(const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al, int ldh, const Src& W, int nks,
                                       f32x4 (&acc)[2], f32x4 (&accx)[2], int lane) {
@@ -607,6 +656,19 @@ __device__ __forceinline__ void fb_h3_finish(f32x4 (&acc)[1][2], const f32x4 (&a
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[0][t][r] = (acc[0][t][r] + accx[t][r]) * o[r];
+}
+
+template <int RT>
+__device__ __forceinline__ void fb_h3_finish_rt(f32x4 (&acc)[RT][2], const f32x4 (&accx)[RT][2], const float* __restrict__ os, int lane) {
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const float4 o4 = ld4(os + 16 * rt + 4 * (lane >> 4));
+    const float o[4] = {o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[rt][t][r] = (acc[rt][t][r] + accx[rt][t][r]) * o[r];
+  }
 }
 
 // forward epilogue of the last contraction slice: (+ partial sums of earlier slices) + bias, activation; to LDS
@@ -761,7 +823,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
   float* X = smem;
   float* Y = smem + R * ld;
   float* PV = smem + 2 * R * ld;  // every vector parameter of the model, staged once (see below)
-  __shared__ float sm_os[16];     // split-half layers: per-row output scale of the product
+  __shared__ __attribute__((aligned(16))) float sm_os[R];  // split-half layers: per-row output scale of the product
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave: SGPR
   const int64_t n0 = (int64_t)blockIdx.x * R;
   const int rows_valid = (int)((N - n0) < R ? (N - n0) : R);
@@ -772,7 +834,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
 #define FWD_XHAT0_H3 1  // wider inputs too when layer 0 takes the split-half LayerNorm path (rows in registers there)
 #endif
   bool write_xhat0 = saved != nullptr && p.nl >= 2 && p.K[0] <= 256;
-  if constexpr (VEC && R == 16 && NW == 8)
+  if constexpr (VEC && (R == 16 || R == 32) && NW == 8)
     write_xhat0 = write_xhat0 || (FWD_XHAT0_H3 && saved != nullptr && p.nl >= 2 && p.fwd_h3 != 0 && p.h3f[0] != 0 &&
                                   round_up(p.K[0], 32) <= 768);
   if (saved != nullptr && blockIdx.x == 0 && tid == 0) saved[p.sv_total] = write_xhat0 ? 1.f : 0.f;
@@ -901,14 +963,14 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
     // ---- LayerNorm (biased variance, eps 1e-5, affine), in place; two-pass statistics -----------
     bool scored = false;
     bool h3 = false;
-    if constexpr (VEC && RT == 1 && NW == 8) h3 = p.fwd_h3 != 0 && j < p.nl - 1 && p.h3f[j] != 0 && K16 <= 768;
+    if constexpr (VEC && RT <= 2 && NW == 8) h3 = p.fwd_h3 != 0 && j < p.nl - 1 && p.h3f[j] != 0 && K16 <= (RT == 1 ? 768 : 512);
     if (h3) {
-      if constexpr (VEC && RT == 1 && NW == 8) {
+      if constexpr (VEC && RT <= 2 && NW == 8) {
        auto ln_h3 = [&](auto xc_tag) {
         // split-half layer (PipeH3): a lane owns columns 4 lane + 256 u; the wave's two rows stay in registers through
         // both passes, and once every wave holds its rows (the barrier) the normalised rows go back over the tile as two
         // fp16 planes, scaled per row by a power of two
-        constexpr int RPW = 2, XC = decltype(xc_tag)::value;  // rows up to 256 XC wide
+        constexpr int RPW = R / NW, XC = decltype(xc_tag)::value;  // rows up to 256 XC wide (32-row tiles: four rows of a wave in registers)
         const float invK = 1.0f / (float)K;
         const int ldh = fwd_ldh(p.maxdim);
         _Float16* AH = reinterpret_cast<_Float16*>(X);
@@ -984,8 +1046,13 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
           if (lane == 0) sm_os[r] = inv * (1.0f / ULTR_H3_WSCALE);
         }
        };
-       if (K16 <= 512) ln_h3(std::integral_constant<int, 2>());
-       else ln_h3(std::integral_constant<int, 3>());
+       if constexpr (RT == 1) {
+         if (K16 <= 512) ln_h3(std::integral_constant<int, 2>());
+         else ln_h3(std::integral_constant<int, 3>());
+       } else {
+         if (K16 <= 256) ln_h3(std::integral_constant<int, 1>());
+         else ln_h3(std::integral_constant<int, 2>());
+       }
       }
     } else if (K <= 256) {
       // fast path: a lane owns columns lane + 64k (k < 4); gamma/beta are fetched once per layer, the wave's
@@ -1115,6 +1182,29 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
           }
         }
         bool sw_done = false;
+        if constexpr (RT == 2 && NW == 8) {
+          if (h3) {  // 32-row tiles: two row tiles behind every weight fragment (half the weight stream per row)
+            const int nks = K16 >> 5, ldh = fwd_ldh(p.maxdim);
+            const _Float16* AH = reinterpret_cast<const _Float16*>(X);
+            const _Float16* AL = AH + R * ldh;
+            const Src Wh = make_src(wt + p.whf_off[j], (int64_t)K16 * M);
+            PipeH3<FB_SWD> ph;
+            const int cs = wave * 32;
+            ph.begin(Wh, wave, nks, cs < M, lane);
+            for (int cc = cs; cc < M; cc += NW * 32) {
+              f32x4 acc[RT][2], accx[RT][2];
+#pragma unroll
+              for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[rt][t] = accx[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+              ph.template run_rt<RT>(AH, AL, ldh, Wh, nks, acc, accx, lane);
+              if (cc + NW * 32 < M) ph.begin(Wh, (cc + NW * 32) >> 5, nks, true, lane);
+              fb_h3_finish_rt<RT>(acc, accx, sm_os, lane);
+              finish_fwd_nn<RT, 2>(acc, Y, ld, M, cc, lane, bias, p.act, gout, rows_valid);
+            }
+            sw_done = true;
+          }
+        }
         if constexpr (RT == 1 && NW == 8) {
           if (h3) {
             const int nks = K16 >> 5, ldh = fwd_ldh(p.maxdim);
