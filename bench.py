@@ -448,6 +448,200 @@ def torch_rocm_baseline(cfg, pool, params0, device, budget_s=4.0):
                     "fp32, loss.item() each step): the reference's step with device='cuda' - context, not the target"}
 
 
+class Workload:
+    """Everything one BASELINE config needs on one rank: model shape, replicated parameters / optimizer state, a pool of
+    pre-staged batches resident in HBM, the step engine."""
+
+    def __init__(self, key, device, rank=0, pg=None, attention_dtype="fp32"):
+        from ultra_pytorch_amd import engine, hip_ops, synthetic
+        cfg = self.cfg = CONFIGS[key]
+        F, L, B = cfg["F"], cfg["L"], cfg["B"]
+        self.key, self.device, self.attention_dtype = key, device, attention_dtype
+        if cfg["model"] == "setrank":
+            from ultra_pytorch_amd.ranking_model.SetRank import init_setrank_params
+            self.shape = hip_ops.SetRankShape(F, 256, 8, 2, 64, attention_dtype=attention_dtype)
+            self.params0 = init_setrank_params(self.shape, seed=0).numpy()
+            self.eng_cls = engine.SetRankStepEngine
+        else:
+            from ultra_pytorch_amd.ranking_model import init_flat_params
+            self.shape = hip_ops.DnnShape(F, cfg["hidden"], "elu")
+            self.params0 = init_flat_params(self.shape, seed=0).numpy()
+            self.eng_cls = engine.StepEngine
+        self.P = self.shape.n_params
+        self.params = torch.from_numpy(self.params0.copy()).to(device)  # identical replicas on every rank
+        self.state = None if cfg["algo"] == "dla" else torch.zeros_like(self.params)
+        self.aux = None
+        if cfg["algo"] == "dla":
+            self.aux = torch.zeros(L + 1, device=device)
+        elif cfg["algo"] in ("pairdebias", "lambdarank"):
+            self.aux = torch.ones(2 * L, device=device)
+        self.ipw = torch.tensor(synthetic.load_ipw(), dtype=torch.float32, device=device) if cfg["algo"] == "softmax" else None
+        self.pool = make_pool(cfg, np.random.RandomState(1234 + rank), device)
+        self.pg = pg
+        self.eng = self.make_engine()
+
+    def make_engine(self, **kw):
+        cfg = self.cfg
+        return self.eng_cls(self.shape, cfg["B"], cfg["L"], self.device, algo=cfg["algo"], learning_rate=cfg["lr"],
+                            max_gradient_norm=CLIP, process_group=self.pg, **kw)
+
+    def step(self, i, e=None):
+        f, nd, ids, y, _ = self.pool[i % len(self.pool)]
+        return (e or self.eng).train_step(self.params, self.state, f, nd, ids, y, aux=self.aux, ipw_table=self.ipw)
+
+
+def dtype_label(cfg, attention_dtype="fp32"):
+    """The arithmetic the step ISSUES under the current knobs (values, accumulation and every row-wise phase are f32 everywhere)."""
+    if cfg["model"] == "dnn":
+        return (("f32 (products of layers with >= 256 outputs: three f16 MFMAs on split hi/lo f16 operands, f32 accumulate - "
+                 "f32-accurate, same 1e-5 parity bar; ULTR_FB_H3 / ULTR_FWD_H3 / ULTR_BWD_H3 = 0 for f32 MFMAs)") if h3_products_on()
+                else "f32")
+    on = lambda k: os.environ.get(k, "1") != "0"
+    parts = []
+    if on("ULTR_SR_H3"):
+        parts.append("Linear forward / dgrad GEMMs")
+    if on("ULTR_SR_WG_H3"):
+        parts.append("d x d weight gradients")
+    if attention_dtype == "fp32" and on("ULTR_SR_ATTN_H3"):
+        parts.append("attention backward")
+    s = "f32"
+    if parts:
+        s += (" (%s: three f16 MFMAs on split hi/lo f16 operands, f32 accumulate - f32-accurate, 1e-5 parity bar; attention forward, "
+              "LayerNorms, softmax, loss: f32; ULTR_SR_H3 / ULTR_SR_WG_H3 / ULTR_SR_ATTN_H3 = 0 for f32 MFMAs)" % ", ".join(parts))
+    if attention_dtype != "fp32":
+        s += " (self-attention operands plain f16, f32 accumulate: ordering-level parity)"
+    return s
+
+
+def short_config_run(key, device, lib, steps, warmup):
+    """One of the OTHER BASELINE configs on the driver's line: a short synced run - `steps` steps, each
+    followed by the host's read of its loss - after `warmup` steps and (DNN) a calibration pass with every kernel timer armed."""
+    from ultra_pytorch_amd import _lib
+    t_setup = time.perf_counter()
+    W = Workload(key, device)
+    cfg = W.cfg
+    for i in range(warmup):
+        W.step(i)
+    torch.cuda.synchronize()
+    rec = {"workload": cfg["workload"]}
+    dnn = cfg["model"] == "dnn"
+    if dnn:
+        tot, cnt = (ctypes.c_double * 8)(), (ctypes.c_int64 * 8)()
+        ncal = 6
+        _lib.check(lib.ultr_prof_enable(0xBF, 8 * ncal), "ultr_prof_enable")
+        for i in range(ncal):
+            W.step(i)
+        torch.cuda.synchronize()
+        _lib.check(lib.ultr_prof_collect(tot, cnt), "ultr_prof_collect")
+        lib.ultr_prof_enable(0, 0)
+        kus = {k: 1e3 * tot[k] / cnt[k] for k in KSLOTS if cnt[k] > 0}
+        for i in range(4):
+            W.step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        W.step(i)
+        W.eng.read_loss()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    loss = W.eng.read_loss()
+    flops = step_flops(cfg)
+    rec.update({"ms_per_step": 1e3 * dt, "queries_per_sec": cfg["B"] / dt, "steps": steps, "warmup": warmup,
+                "step_tflops": flops / dt / 1e12, "step_frac_of_fp32_mfma_peak": flops / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                "dtype": dtype_label(cfg), "final_loss": loss, "finite": bool(np.isfinite(loss))})
+    if dnn:
+        dom = max(kus, key=kus.get)
+        bound, amount = algorithmic_work(cfg, W.P)[dom]
+        ach = amount / (1e-6 * kus[dom]) / (1e12 if bound == "mfma" else 1e9)
+        rec["dominant_kernel"] = {"kernel": KNAMES[dom], "avg_launch_us": kus[dom], "bound": bound, "achieved": ach,
+                                  "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+                                  "frac": ach / (PEAK_FP32_MFMA_TFLOPS if bound == "mfma" else PEAK_HBM_GBS),
+                                  "source": "calibration pass of %d steps in front of the timed steps, every kernel timer armed" % ncal}
+        rec["kernel_us"] = {KNAMES[k]: round(v, 2) for k, v in kus.items()}
+    else:
+        rec["dominant_kernel"] = {"kernel": "whole step (47 launches, none dominant: profiles/r05_cfg5_pmc.md)", "bound": "mfma",
+                                  "achieved": rec["step_tflops"], "unit": "TFLOP/s", "frac": rec["step_frac_of_fp32_mfma_peak"]}
+    W.eng.close()
+    del W
+    torch.cuda.empty_cache()
+    rec["wall_s"] = round(time.perf_counter() - t_setup, 2)
+    return rec
+
+
+def eval_leg(cfg, device, lib, params0):
+    """validation() on the device (SURVEY 8 a12 / a13, 8d "Validation-only: 2 S per document"): DNN forward at the evaluated list
+    length + pad mask + NDCG@{1,3,5,10}, the metric vector read on the host after every batch (the reference's .item() per
+    metric, ipw_rank.py:204-210).  Two shapes: config 2's own (list_size 10) and max_candidate_num = 100 with ragged lists."""
+    from ultra_pytorch_amd import _lib, engine, hip_ops, synthetic
+    F, B = cfg["F"], cfg["B"]
+    shape = hip_ops.DnnShape(F, cfg["hidden"], "elu")
+    params = torch.from_numpy(params0.copy()).to(device)
+    dims = dnn_dims(cfg)
+    s_all = sum(k * m for k, m in dims)
+    out = {}
+    for L in (cfg["L"], 100):
+        rng = np.random.RandomState(77 + L)
+        ev = engine.EvalEngine(shape, B, L, device)
+        batches = []
+        for _ in range(4):
+            feats, ids, y = synthetic.make_batch(rng, B, L, F, clicks=False)
+            if L > cfg["L"]:  # ragged lists: a random tail of every list is PAD (id == n_docs), as data_utils.pad leaves them
+                n_docs = feats.shape[0]
+                lens = rng.randint(L // 2, L + 1, size=B)
+                padm = np.arange(L)[:, None] >= lens[None, :]
+                ids = np.where(padm, n_docs, ids).astype(np.int32)
+                y = np.where(padm, 0.0, y).astype(np.float32)
+            batches.append((torch.from_numpy(feats).to(device), feats.shape[0], torch.from_numpy(ids).to(device), torch.from_numpy(y).to(device)))
+        live = float(np.mean([(b[2] < b[1]).sum().item() for b in batches]))
+
+        def run(i):
+            f, nd, ids, y = batches[i % len(batches)]
+            return ev.run(params, f, nd, ids, y)
+        for i in range(10):
+            run(i)
+        torch.cuda.synchronize()
+        tot, cnt = (ctypes.c_double * 8)(), (ctypes.c_int64 * 8)()
+        ncal = 20
+        _lib.check(lib.ultr_prof_enable((1 << 0) | (1 << 6), 4 * ncal), "ultr_prof_enable")
+        for i in range(ncal):
+            run(i)
+        torch.cuda.synchronize()
+        _lib.check(lib.ultr_prof_collect(tot, cnt), "ultr_prof_collect")
+        lib.ultr_prof_enable(0, 0)
+        assert cnt[0] > 0 and cnt[6] > 0, "the eval kernels were not timed"
+        fwd_us = 1e3 * tot[0] / cnt[0]
+        ndcg_us = 1e3 * tot[6] / cnt[6]
+        n = 200
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            _, nd_t = run(i)
+            nd_host = nd_t.cpu()
+        dt = (time.perf_counter() - t0) / n
+        t0 = time.perf_counter()
+        for i in range(n):
+            run(i)
+        torch.cuda.synchronize()
+        dt_ns = (time.perf_counter() - t0) / n
+        N = B * L
+        ndcg_bytes = 12.0 * N  # scores + labels + doc ids in (DESIGN section 3)
+        fwd_flops = 2.0 * N * s_all
+        out["list_size_%d" % L] = {
+            "batch": B, "list_size": L, "live_documents_per_batch": live,
+            "queries_per_sec": B / dt, "ms_per_batch": 1e3 * dt, "queries_per_sec_no_host_sync": B / dt_ns,
+            "forward": {"kernel": "dnn_fwd_kernel", "avg_launch_us": fwd_us, "bound": "mfma", "achieved": fwd_flops / (1e-6 * fwd_us) / 1e12,
+                        "unit": "TFLOP/s", "frac": fwd_flops / (1e-6 * fwd_us) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                        "algorithmic_per_launch": fwd_flops},
+            "ndcg": {"kernel": "ndcg_list_kernel", "avg_launch_us": ndcg_us, "bound": "hbm", "achieved": ndcg_bytes / (1e-6 * ndcg_us) / 1e9,
+                     "unit": "GB/s", "frac": ndcg_bytes / (1e-6 * ndcg_us) / 1e9 / PEAK_HBM_GBS, "algorithmic_per_launch": ndcg_bytes,
+                     "limited_by": "launch latency: one wavefront-sorted list per workgroup, %d KB per launch" % int(ndcg_bytes / 1024)},
+            "ndcg_at_1_3_5_10": [float(v) for v in nd_host.tolist()],
+            "what": "EvalEngine.run = ultr_dnn_forward + ultr_ndcg (pad mask, label validation, rank sort, DCG / IDCG at the cut-offs), "
+                    "ndcg vector copied to the host after every batch",
+        }
+    return out
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` outside torchrun: launch N ranks of this script (one per GPU) and pass rank 0's line on."""
     import socket
@@ -475,6 +669,10 @@ def main():
                          "ordering-level parity; fp32 = the 1e-5 parity path, default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures (plugin API, device feed)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of configs 3 / 4pair / 4lambda / 5 and the eval leg")
+    ap.add_argument("--spinup-ms", type=float, default=None,
+                    help="untimed steps for this many ms in front of the W warm-up steps (shader clocks settle; default 300 for config 2)")
+    ap.add_argument("--timer-stride", type=int, default=None, help="the dominant kernel is timed on every stride-th step of the timed region")
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)  # does not return
@@ -509,28 +707,11 @@ def main():
 
     from ultra_pytorch_amd import _lib, engine, hip_ops, synthetic
     lib = _lib.load()
-    if cfg["model"] == "setrank":
-        from ultra_pytorch_amd.ranking_model.SetRank import init_setrank_params
-        shape = hip_ops.SetRankShape(F, 256, 8, 2, 64, attention_dtype=args.attention_dtype)
-        params0 = init_setrank_params(shape, seed=0).numpy()
-        eng_cls = engine.SetRankStepEngine
-    else:
-        from ultra_pytorch_amd.ranking_model import init_flat_params
-        shape = hip_ops.DnnShape(F, HIDDEN, "elu")
-        params0 = init_flat_params(shape, seed=0).numpy()
-        eng_cls = engine.StepEngine
-    P = shape.n_params
-    params = torch.from_numpy(params0.copy()).to(device)  # identical replicas on every rank
-    state = None if cfg["algo"] == "dla" else torch.zeros_like(params)
-    aux = None
-    if cfg["algo"] == "dla":
-        aux = torch.zeros(L + 1, device=device)
-    elif cfg["algo"] in ("pairdebias", "lambdarank"):
-        aux = torch.ones(2 * L, device=device)
-    ipw = torch.tensor(synthetic.load_ipw(), dtype=torch.float32, device=device) if cfg["algo"] == "softmax" else None
-    pool = make_pool(cfg, np.random.RandomState(1234 + rank), device)
+    W = Workload(args.config, device, rank=rank, pg=pg, attention_dtype=args.attention_dtype)
+    shape, params0, eng_cls, P = W.shape, W.params0, W.eng_cls, W.P
+    params, state, aux, ipw, pool = W.params, W.state, W.aux, W.ipw, W.pool
     npool = len(pool)
-    eng = eng_cls(shape, B, L, device, algo=cfg["algo"], learning_rate=LR, max_gradient_norm=CLIP, process_group=pg)
+    eng = W.eng
     engs = {"main": eng}
 
     def step(i, e=None):
@@ -547,6 +728,20 @@ def main():
             torch.distributed.all_reduce(_flag, group=pg)
         torch.cuda.synchronize()
 
+    # ---- spin-up: the shader clock needs tens of milliseconds of load to reach its sustained level; the driver's form
+    # (--warmup 5 --steps 20) is 1.3 ms of work in all, so without this a short timed region measures the clock ramp
+    # (round 5, same box: 51.5 us/step at --steps 20 against 48.3 at --steps 2000).  Untimed, in front of the W warm-up steps,
+    # reported on the line as `spinup_ms`.
+    spinup_ms = (300.0 if light else 0.0) if args.spinup_ms is None else args.spinup_ms
+    spun = 0
+    if spinup_ms > 0:
+        t_sp = time.perf_counter()
+        while 1e3 * (time.perf_counter() - t_sp) < spinup_ms:
+            for i in range(32):
+                step(spun + i)
+            eng.read_loss()
+            spun += 32
+        barrier()
     # ---- warm-up (untimed) + pick the dominant kernel with all timers armed ------------------------
     for i in range(args.warmup):
         step(i)
@@ -559,7 +754,8 @@ def main():
     # short_region.py: all kernels timed at stride 8 cost 2.3 us per step of the headline, 20 us per timed step), so the other
     # kernels' averages come from the calibration pass in front of the timed region (`kernel_us`, all timers armed; the
     # dominant kernel's figure there and inside the region agree to 1 %).
-    stride = (8 if args.steps < 256 else 32) if light else 4
+    # at least five timed launches inside the timed region whatever its length (two were thin)
+    stride = args.timer_stride or max(1, min((8 if args.steps < 256 else 32) if light else 4, args.steps // 5))
     cal_us = [0.0] * 8
     cal_cnt = [0] * 8
     if dnn:
@@ -793,6 +989,16 @@ def main():
         except Exception as ex:  # a baseline must never take the headline down
             trb = {"value": None, "error": repr(ex)}
 
+    other, evalleg = None, None
+    if world == 1 and light and not args.no_other_configs:
+        # the other BASELINE configs and the validation path on the SAME line: short synced runs
+        evalleg = eval_leg(cfg, device, lib, params0)
+        other = {}
+        for key, (n_st, n_wu) in (("3", (50, 10)), ("4pair", (30, 6)), ("4lambda", (30, 6)), ("5", (20, 3))):
+            try:
+                other[key] = short_config_run(key, device, lib, n_st, n_wu)
+            except Exception as ex:  # a secondary figure must never take the headline down
+                other[key] = {"error": repr(ex)}
     if rank == 0:
         flops = step_flops(cfg)
         ms_step = 1e3 * elapsed / args.steps
@@ -804,6 +1010,10 @@ def main():
         # `bound` names the PEAK the kernel is priced against (its work is a dense contraction -> the fp32 matrix cores);
         # `limited_by` says what the measurements show actually limits it
         limited_by = None
+        if not dnn:
+            limited_by = ("HBM traffic + instruction issue, not the matrix pipes: ~9.9 GB cross HBM per step (profiles/r04_cfg5_pmc.md: 3.5 TB/s average; "
+                          "at the ~6.3 TB/s this part sustains that alone is 55 % of the step), the split-half GEMMs sit at 7-11 % matrix-core "
+                          "occupancy (~250 issued instructions per 12 MFMAs), the attention backward is VALU-bound")
         if dnn and light and dom == 7:
             limited_by = ("a per-workgroup LATENCY CHAIN, nothing is at a bandwidth limit: one 10-document list per compute unit in a 16-row MFMA "
                           "tile (8 waves); 55 % of the kernel is dependent row-wise phases (LayerNorms, loss, backward row passes), 45 % the "
@@ -839,19 +1049,16 @@ def main():
                                                           "the stream runs at about twice this fraction"})
         traffic, traffic_source = None, None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes/launch from rocprofv3 PMC passes
-        if os.path.exists(tfile) and light:
+        if os.path.exists(tfile) and (light or not dnn):
             tj = json.load(open(tfile))
-            traffic = tj.get(kname)
+            traffic = tj.get(kname if dnn else "setrank_whole_step")
             traffic_source = "file profiles/traffic.json (%s): rocprofv3 FETCH_SIZE/WRITE_SIZE passes of an earlier run of this " \
                              "command, NOT measured in this process" % tj.get("_source", "tools/profile_round.sh")
         out = {
             "metric": "queries/sec (training step)", "value": world * B * args.steps / elapsed, "unit": "queries/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": (("f32 (products of layers with >= 256 outputs: three f16 MFMAs on split hi/lo f16 operands, f32 accumulate - "
-                       "f32-accurate, same 1e-5 parity bar; ULTR_FB_H3 / ULTR_FWD_H3 / ULTR_BWD_H3 = 0 for f32 MFMAs)") if h3_products_on()
-                      else "f32") if dnn else
-                     ("f32" if args.attention_dtype == "fp32" else "f32 (self-attention operands f16, f32 accumulate)"),
+            "dtype": dtype_label(cfg, args.attention_dtype),
             "data": "synthetic",
             "config": {"workload": cfg["workload"], "baseline_config": args.config, "global_batch": world * B, "list_size": L,
                        "feature_size": F, "hidden": HIDDEN, "parallelism": "dp%d" % world, "params": P},
@@ -877,6 +1084,14 @@ def main():
             "final_loss": final_loss,
         }
         out["value_definition"] = "every step followed by the host's read of its loss (the reference's loss.item(), SURVEY 8d)"
+        out["spinup_ms"] = spinup_ms
+        out["spinup_steps"] = spun
+        out["spinup_note"] = ("untimed steps in front of the W warm-up steps so that the shader clock is at its sustained level when a "
+                              "SHORT timed region starts (--steps 20 is 1 ms of GPU work); --spinup-ms 0 switches it off")
+        if other is not None:
+            out["other_configs"] = other
+        if evalleg is not None:
+            out["eval"] = evalleg
         if fp32_mfma is not None:
             out["fp32_mfma_products"] = fp32_mfma
         if nosync is not None:

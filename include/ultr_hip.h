@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ULTR_ABI_VERSION 5
+#define ULTR_ABI_VERSION 6
 #define ULTR_MAX_HIDDEN 7 /* hidden layers; Linear layers = hidden + 1 <= 8 */
 
 #define ULTR_E_BADARG (-1)
@@ -52,9 +52,12 @@ extern "C" {
 #define ULTR_STATUS_H3_RANGE 0x100u
 /* ... and the early warning: a hidden weight reached |w| >= 64, half of that range, while every copy is still exact.  An optimizer
  * step moves a weight by at most learning_rate x max_gradient_norm, so a host that reads the report every few steps has time to
- * switch to the fp32 products (ULTR_*_H3=0 + ultr_config_reload) before anything overflows - engine.StepEngine does, with a
+ * switch THIS model to the fp32 products (ultr_dnn_desc::flags |= ULTR_MODEL_FP32_PRODUCTS) before anything overflows - engine.StepEngine does, with a
  * warning: like the reference (base_algorithm.py:208-226) the library then trains any weight magnitude. */
 #define ULTR_STATUS_H3_NEAR 0x200u
+/* bits of a range-flag word (ultr_update_desc::range_flag, the word inside `wt`): a scaled weight overflowed / is near the edge */
+#define ULTR_H3_FLAG_OVER 1u
+#define ULTR_H3_FLAG_NEAR 2u
 
 /* base_ranking_model.py:63-69 (ACT_FUNC_DIC): elu, relu, tanh, sigmoid.  ('selu' is listed there as a plain function and
  * nn.Sequential.add_module rejects it - TypeError at DNN.py:52-53 - so it is not an option of the reference.) */
@@ -67,7 +70,12 @@ typedef struct ultr_dnn_desc {
   int32_t n_hidden;                /* k; 0 reproduces ultra.ranking_model.Linear */
   int32_t hidden[ULTR_MAX_HIDDEN]; /* hidden_layer_sizes */
   int32_t activation;              /* ultr_activation */
+  /* ABI 6: per-MODEL switches (0 = defaults).  ULTR_MODEL_FP32_PRODUCTS: every product of this model on the fp32 matrix cores
+   * (v_mfma_f32_16x16x4_f32), whatever the process-wide ULTR_*_H3 knobs say - what a caller sets when a hidden weight of THIS
+   * model approaches the range of the split-half weight copies (ULTR_STATUS_H3_NEAR); other models of the process keep their plan. */
+  int32_t flags;
 } ultr_dnn_desc;
+#define ULTR_MODEL_FP32_PRODUCTS 1
 
 /* ---- host-only queries ------------------------------------------------------------- */
 int ultr_abi_version(void);
@@ -205,10 +213,14 @@ typedef struct ultr_setrank_desc {
    * config 5 names); scores / softmax / gradients algebra stay fp32; parity is ORDERING-level (~1e-3 relative), so it is
    * opt-in.  Needs head depth 32 or 64 and list_size <= 128, otherwise the fp32 kernels run. */
   int32_t attention_dtype;
+  int32_t flags;  /* ABI 6: ULTR_MODEL_FP32_PRODUCTS - the Linear products and d x d weight gradients of this model on the fp32 matrix cores */
 } ultr_setrank_desc;
 int64_t ultr_setrank_param_count(const ultr_setrank_desc* c);
 int64_t ultr_setrank_saved_bytes(const ultr_setrank_desc* c, int64_t n_rows);
 int64_t ultr_setrank_workspace_bytes(const ultr_setrank_desc* c, int64_t n_rows);
+/* ABI 6: float offset into `saved` of the word ultr_setrank_forward raises ULTR_H3_FLAG_* bits in when it builds the split-half
+ * planes of the weights (zeroed by every forward; ultr_update_desc::range_flag); -1 on a bad desc */
+int64_t ultr_setrank_range_flag_offset(const ultr_setrank_desc* c, int64_t n_rows);
 int ultr_setrank_forward(const ultr_setrank_desc* c, const float* params, const float* features, int64_t n_docs,
                          const int32_t* docids, int32_t batch, int32_t list_size, float* scores, void* saved, void* stream);
 int ultr_setrank_backward(const ultr_setrank_desc* c, const float* params, int32_t batch, int32_t list_size, const void* saved,
@@ -256,6 +268,11 @@ typedef struct ultr_update_desc {
   float* host_scalars;
   uint32_t seq;
   uint32_t pad_;
+  /* ABI 6 - range_flag: optional device word of ULTR_H3_FLAG_* bits raised by whatever builds split-half (fp16 hi / lo) weight
+   *   planes for the caller's model; block 0 of the update reports them in host_scalars[8] as ULTR_STATUS_H3_NEAR / _RANGE.
+   *   ultr_train_step / ultr_apply_update with `wt` find the DNN's own word themselves (NULL is fine); a SetRank caller passes
+   *   saved + ultr_setrank_range_flag_offset(). */
+  const uint32_t* range_flag;
 } ultr_update_desc;
 
 /* params/state [P] updated in place; grads = the buffer ultr_dnn_backward filled (possibly

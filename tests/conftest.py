@@ -49,14 +49,12 @@ def mfma_mode(request, monkeypatch):
         pass
 
 
-@pytest.fixture(params=["slabs", "direct", "split_half"])
+@pytest.fixture(params=["slabs", "split_half"])
 def wgrad_path(request, monkeypatch):
-    """The weight-gradient paths: 64 x 64 register tiles x row splits + a reduction launch (the default below 4096 rows), the
-    direct one-launch kernel of ultr_wgd.hip behind the fused kernel (ULTR_WGD=1; not faster at config 2, kept under test), and
+    """The weight-gradient paths: 64 x 64 register tiles x row splits + a reduction launch (the default below 4096 rows) and
     dnn_wgrad_h3_kernel - 128 x 128 LDS-staged blocks on the fp16 matrix cores with split operands, the default from 4096 rows,
     forced onto these small shapes with ULTR_WG_H3=2.  (mfma_mode "fp32_mfma" sets ULTR_WG_H3=0 and wins: the combination
     fp32_mfma x split_half runs the register kernel again.)"""
-    monkeypatch.setenv("ULTR_WGD", "1" if request.param == "direct" else "0")
     if request.param == "split_half" and os.environ.get("ULTR_WG_H3") != "0":
         monkeypatch.setenv("ULTR_WG_H3", "2")
     yield request.param

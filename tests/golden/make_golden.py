@@ -457,20 +457,7 @@ def run_driver_case(ultra, name, seed=0):
     finally:
         sys.argv = old_argv
         cls.train, torch.save = orig_train, orig_save
-    # parse what the driver printed at each checkpoint
-    history, cur = [], None
-    for line in buf.getvalue().splitlines():
-        if line.startswith("global step "):
-            tok = line.split()
-            cur = {"global_step": int(tok[2]), "loss": float(tok[-1]), "metrics": {}}
-            history.append(cur)
-        elif cur is not None:
-            tok = line.split()
-            if len(tok) == 2 and tok[0].rsplit("_", 1)[-1].isdigit() and ":" not in tok[0]:
-                try:
-                    cur["metrics"][tok[0]] = float(tok[1])
-                except ValueError:
-                    pass
+    history = parse_driver_stdout(buf.getvalue())  # what the driver printed at each checkpoint
     out = {"meta": json.dumps({"name": name, "seed": seed, "argv": argv[6:], "settings": settings, "history": history,
                                "save_steps": [s for s, _ in rec["saves"]], "n_steps": len(rec["losses"]),
                                "param_keys": list(rec["init"].keys())})}
@@ -482,6 +469,140 @@ def run_driver_case(ultra, name, seed=0):
             out["save%d_%s" % (i, k)] = v
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print("wrote", name, "steps", len(rec["losses"]), "checkpoints at", [s for s, _ in rec["saves"]], history)
+
+
+def parse_driver_stdout(text):
+    """What main.py printed at each checkpoint: (global step, averaged loss, merged validation metrics)."""
+    history, cur = [], None
+    for line in text.splitlines():
+        if line.startswith("global step "):
+            tok = line.split()
+            cur = {"global_step": int(tok[2]), "loss": float(tok[-1]), "metrics": {}}
+            history.append(cur)
+        elif cur is not None:
+            tok = line.split()
+            if len(tok) == 2 and tok[0].rsplit("_", 1)[-1].isdigit() and ":" not in tok[0]:
+                try:
+                    cur["metrics"][tok[0]] = float(tok[1])
+                except ValueError:
+                    pass
+    return history
+
+
+CONV_ALGOS = {"ipw": "IPWrank", "dla": "DLA", "pairdebias": "PairDebias"}
+CONV_SEEDS = (0, 1, 2, 3, 4)
+CONV_TOPN = (1, 3, 5, 10)
+
+
+def feed_checksum(algo, input_feed, L):
+    """Two numbers per batch that pin WHICH documents sit where and WHICH of them were clicked (position-weighted sums)."""
+    w = np.arange(1, L + 1, dtype=np.float64)[:, None]
+    ids = np.stack([np.asarray(input_feed[algo.docid_inputs_name[l]], np.float64) for l in range(L)])
+    lab = np.stack([np.asarray(input_feed[algo.labels_name[l]], np.float64) for l in range(L)])
+    col = np.arange(1, ids.shape[1] + 1, dtype=np.float64)[None, :]
+    return float((ids * w * col).sum()), float((lab * w * col).sum())
+
+
+def run_convergence_case(ultra, name, algo_key, n_iter=300, ckpt_every=50, batch=64, n_ulp=1):
+    """End-of-training NDCG@10 of the reference's own main.py (main.py:85-227) on the toy ULTRA dataset for a click-feed
+    algorithm (ipw_rank.py:102-182, dla.py:179-266, pairwise_debias.py:106-174): ClickSimulationFeed (PBM), DNN[32,16],
+    batch 64, a checkpoint every 50 steps, --max_train_iteration 300 (the stop test runs at checkpoint boundaries: 350 steps,
+    7 checkpoints), 5 seeds.  Per seed THREE runs of the reference: 1 thread, 8 threads, and 1 thread with the initial weights
+    moved by one fp32 rounding (x (1 +- 2^-23)): the spread between them is the reference's own sensitivity to summation
+    order / rounding, the band a counterpart with different fp32 summation order is held to.  Stores arrays only: initial
+    weights (and DLA's propensity parameters), per-step batch checksums and losses of the 1-thread run, validation
+    ndcg_{1,3,5,10} at every checkpoint of every variant."""
+    import runpy
+    import tempfile
+    data_dir = os.path.join(HERE, "ultra_toy_data") + "/"
+    cls_name = CONV_ALGOS[algo_key]
+    settings = {
+        "train_input_feed": "ultra.input_layer.ClickSimulationFeed", "train_input_hparams": "",
+        "valid_input_feed": "ultra.input_layer.DirectLabelFeed", "valid_input_hparams": "",
+        "test_input_feed": "ultra.input_layer.DirectLabelFeed", "test_input_hparams": "",
+        "ranking_model": "ultra.ranking_model.DNN", "ranking_model_hparams": "hidden_layer_sizes=[32, 16]",
+        "learning_algorithm": "ultra.learning_algorithm." + cls_name, "learning_algorithm_hparams": "",
+        "metrics": ["ndcg"], "metrics_topn": list(CONV_TOPN), "objective_metric": "ndcg_10",
+    }
+    cls = getattr(ultra.learning_algorithm, cls_name)
+    out, meta_runs = {}, {}
+    # (DLA: n_ulp = 6 - its stateless sign-like updates turn one rounding into a different trajectory, three variants understate the band)
+    variants = (("t1", 1, None), ("t8", 8, None)) + tuple(("ulp" if k == 0 else "ulp%d" % (k + 1), 1, k + 1) for k in range(n_ulp))
+    for seed in CONV_SEEDS:
+        init_sd, init_prop = None, None
+        for vname, threads, perturb in variants:
+            tmp = tempfile.mkdtemp(prefix="ultr_conv_")
+            sf = os.path.join(tmp, "settings.json")
+            json.dump(settings, open(sf, "w"))
+            os.makedirs(tmp + "/model/", exist_ok=True)
+            argv = ["--data_dir", data_dir, "--setting_file", sf, "--model_dir", tmp + "/model/", "--output_dir", tmp + "/out/",
+                    "--batch_size", str(batch), "--max_train_iteration", str(n_iter), "--steps_per_checkpoint", str(ckpt_every)]
+            torch.set_num_threads(threads)
+            torch.manual_seed(seed)
+            random.seed(seed)
+            np.random.seed(seed)
+            rec = {"first": True, "losses": [], "sums": []}
+            orig_train = cls.train
+
+            def train(self, input_feed, rec=rec, perturb=perturb, vname=vname):
+                nonlocal init_sd, init_prop
+                if rec["first"]:
+                    rec["first"] = False
+                    if init_sd is None:  # first variant of the seed: what torch.manual_seed(seed) initialised
+                        init_sd = flat_state(self.model)
+                        if hasattr(self, "propensity_model"):
+                            init_prop = flat_state(self.propensity_model)
+                    else:                # later variants start from the SAME weights (whatever the thread count did to the init)
+                        self.model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in init_sd.items()})
+                        if init_prop is not None:
+                            self.propensity_model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in init_prop.items()})
+                    if perturb:
+                        g = torch.Generator().manual_seed(1000 * perturb + seed)
+                        with torch.no_grad():
+                            for p in self.model.parameters():
+                                sign = (torch.randint(0, 2, p.shape, generator=g).to(p.dtype) * 2 - 1)
+                                p.mul_(1.0 + sign * 2.0 ** -23)
+                L = self.exp_settings["selection_bias_cutoff"]
+                rec["sums"].append(feed_checksum(self, input_feed, L))
+                o = orig_train(self, input_feed)
+                rec["losses"].append(float(o[0]))
+                return o
+
+            cls.train = train
+            buf = io.StringIO()
+            old_argv = sys.argv
+            try:
+                sys.argv = ["main.py"] + argv
+                with contextlib.redirect_stdout(buf):
+                    runpy.run_path(os.path.join(REF, "main.py"), run_name="__main__")
+            finally:
+                sys.argv = old_argv
+                cls.train = orig_train
+                torch.set_num_threads(1)
+            hist = parse_driver_stdout(buf.getvalue())
+            nd = np.asarray([[h["metrics"]["ndcg_%d" % n] for n in CONV_TOPN] for h in hist], np.float64)
+            out["s%d_%s_ndcg" % (seed, vname)] = nd
+            out["s%d_%s_ckpt_loss" % (seed, vname)] = np.asarray([h["loss"] for h in hist], np.float64)
+            out["s%d_%s_losses" % (seed, vname)] = np.asarray(rec["losses"], np.float64)
+            if vname == "t1":
+                out["s%d_losses" % seed] = np.asarray(rec["losses"], np.float64)
+                out["s%d_feed_sums" % seed] = np.asarray(rec["sums"], np.float64)
+                for k, v in init_sd.items():
+                    out["s%d_init_%s" % (seed, k)] = v
+                if init_prop is not None:
+                    for k, v in init_prop.items():
+                        out["s%d_prop_%s" % (seed, k)] = v
+                meta_runs[str(seed)] = {"n_steps": len(rec["losses"]), "ckpt_steps": [h["global_step"] for h in hist]}
+            print(name, "seed", seed, vname, "final ndcg@10 %.4f" % nd[-1, -1], "steps", len(rec["losses"]))
+    out["meta"] = json.dumps({"name": name, "algo": algo_key, "class": cls_name, "seeds": list(CONV_SEEDS), "topn": list(CONV_TOPN),
+                              "variants": [v[0] for v in variants], "settings": settings,
+                              "argv": ["--batch_size", str(batch), "--max_train_iteration", str(n_iter),
+                                       "--steps_per_checkpoint", str(ckpt_every)],
+                              "param_keys": list(init_sd.keys()), "prop_keys": list(init_prop.keys()) if init_prop else [],
+                              "runs": meta_runs})
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    fin = np.asarray([[out["s%d_%s_ndcg" % (s, v[0])][-1, -1] for v in variants] for s in CONV_SEEDS])
+    print("wrote", name, "final ndcg@10 per seed x variant:\n", np.round(fin, 4), "\nmean", fin.mean(0), "max spread", np.ptp(fin, axis=1).max())
 
 
 def run_metrics_case(ultra, name, seed=61):
@@ -514,6 +635,10 @@ CASES = {
     "feeds_toy": lambda u: run_feed_case(u, "feeds_toy"),
     # the driver itself (main.py) on the toy dataset: losses, checkpoint schedule, printed metrics, saved tensors
     "driver_toy": lambda u: run_driver_case(u, "driver_toy"),
+    # end-of-training NDCG@10 of the reference's main.py with a click feed, 5 seeds x {1 thread, 8 threads, one-rounding init}
+    "conv_ipw": lambda u: run_convergence_case(u, "conv_ipw", "ipw"),
+    "conv_dla": lambda u: run_convergence_case(u, "conv_dla", "dla", n_ulp=6),
+    "conv_pairdebias": lambda u: run_convergence_case(u, "conv_pairdebias", "pairdebias"),
     # tiny, two teacher-forced steps each
     "na_tiny": lambda u: run_train_case(u, "na_tiny", "na", 136, 10, 8, [32, 16], 2, 11),
     "ipw_tiny": lambda u: run_train_case(u, "ipw_tiny", "ipw", 136, 10, 8, [32, 16], 2, 12),

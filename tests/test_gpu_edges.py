@@ -1,6 +1,8 @@
 """Edge cases of the hot path on the GPU against the oracle: degenerate shapes (one list, one document), lists
 without any click under IPW (0/0 -> 0, base_algorithm.py:26-27), lists made of PAD documents only, an all-zero label
 batch, every document of the batch being the same row, and the longest lists the list-wise kernels take."""
+import os
+
 import numpy as np
 import pytest
 from tests import margins
@@ -365,7 +367,7 @@ def test_weight_outside_the_split_half_range_falls_back_to_fp32(weight, reader, 
     from oracle import ultr_oracle as O
     from ultra_pytorch_amd import engine, hip_ops
     for k in ("ULTR_FB_H3", "ULTR_FWD_H3", "ULTR_BWD_H3"):
-        monkeypatch.setenv(k, "1")  # (the fallback writes os.environ: undo() then restores the caller's state)
+        monkeypatch.setenv(k, "1")
     F, hidden, L, p0, feats, ids, y = _h3_case(weight)
     B = ids.shape[1]
     shape = hip_ops.DnnShape(F, hidden, "elu")
@@ -375,7 +377,11 @@ def test_weight_outside_the_split_half_range_falls_back_to_fp32(weight, reader, 
         with pytest.warns(RuntimeWarning, match="fp32 matrix cores"):
             eng.train_step(p, st, dev(feats), feats.shape[0], dev(ids, torch.int32), dev(y))
         loss = eng.read_loss() if reader == "read_loss" else float(eng.read_scalars()[0])
-        assert not hip_ops.split_half_enabled()
+        # THIS model is on the fp32 products now; the process-wide knobs and the environment are untouched, and a second model
+        # of the same process keeps the split-half plan
+        assert not hip_ops.split_half_enabled(shape) and hip_ops.split_half_enabled()
+        assert all(os.environ.get(k) == "1" for k in ("ULTR_FB_H3", "ULTR_FWD_H3", "ULTR_BWD_H3"))
+        assert hip_ops.split_half_enabled(hip_ops.DnnShape(F, hidden, "elu"))
         ref = O.train_step_softmax(p0, np.zeros_like(p0), F, hidden, feats, ids, y, ipw_list=None)
         assert abs(loss - ref["loss"]) <= 1e-5 * max(1.0, abs(ref["loss"]))
         np.testing.assert_allclose(eng.scores.cpu().numpy(), ref["scores"], atol=1e-5 * max(1.0, float(np.abs(ref["scores"]).max())), rtol=1e-5)
@@ -391,7 +397,7 @@ def test_weight_outside_the_split_half_range_falls_back_to_fp32(weight, reader, 
 def test_weight_drifting_towards_the_split_half_range_switches_plans_in_time(reader, monkeypatch):
     """Training drift: a hidden weight just below 64 is pushed over it by the optimizer.  The update kernel raises
     ULTR_STATUS_H3_NEAR in the step report, the next read of the loss (read_loss: the ADVICE r03 path that never looked at the
-    status) switches the process to the fp32 products with a warning, nothing raises, and the trajectory goes on finite: every
+    status) switches THIS MODEL to the fp32 products with a warning, nothing raises, and the trajectory goes on finite: every
     copy was still exact when the switch happened (|w| < 128)."""
     from ultra_pytorch_amd import engine, hip_ops
     for k in ("ULTR_FB_H3", "ULTR_FWD_H3", "ULTR_BWD_H3"):
@@ -423,8 +429,84 @@ def test_weight_drifting_towards_the_split_half_range_switches_plans_in_time(rea
             torch.cuda.synchronize()
         wmax = float(p.abs().max())
         assert wmax >= 64.0, "the planted weights did not cross 64: the test needs a larger learning rate (%.6f)" % wmax
-        assert seen and not hip_ops.split_half_enabled()
+        assert seen and not hip_ops.split_half_enabled(shape) and hip_ops.split_half_enabled()
         assert wmax < 128.0 and np.isfinite(p.cpu().numpy()).all()
+    finally:
+        monkeypatch.undo()
+        shape.lib.ultr_config_reload()
+
+
+def test_fp32_fallback_of_one_model_leaves_a_second_engine_consistent(monkeypatch):
+    """VERDICT r04 item 5: the automatic fp32 fallback is per MODEL (ultr_dnn_desc::flags), not a process-wide knob flip.  Two
+    engines in one process: model A arrives with a hidden weight of 200 (falls back), model B is ordinary.  B's step before and
+    after A's fallback is bit-identical (same plan, same kernels), B still reports split-half products, and A matches the oracle."""
+    from oracle import ultr_oracle as O
+    from ultra_pytorch_amd import engine, hip_ops
+    for k in ("ULTR_FB_H3", "ULTR_FWD_H3", "ULTR_BWD_H3"):
+        monkeypatch.setenv(k, "1")
+    F, hidden, L, pA, feats, ids, y = _h3_case(200.0)
+    _, _, _, pB, _, _, _ = _h3_case(0.01)
+    B = ids.shape[1]
+    shA, shB = hip_ops.DnnShape(F, hidden, "elu"), hip_ops.DnnShape(F, hidden, "elu")
+    try:
+        engA = engine.StepEngine(shA, B, L, torch.device("cuda"), algo="softmax")
+        engB = engine.StepEngine(shB, B, L, torch.device("cuda"), algo="softmax")
+        args = (dev(feats), feats.shape[0], dev(ids, torch.int32), dev(y))
+
+        def step_b():
+            p, st = dev(pB), dev(np.zeros_like(pB))
+            engB.train_step(p, st, *args)
+            engB.read_scalars()
+            return engB.scores.cpu().numpy().copy(), engB.grads.cpu().numpy().copy(), p.cpu().numpy().copy()
+
+        before = step_b()
+        pa, sa = dev(pA), dev(np.zeros_like(pA))
+        with pytest.warns(RuntimeWarning, match="fp32 matrix cores"):
+            engA.train_step(pa, sa, *args)
+        lossA = engA.read_loss()
+        assert not hip_ops.split_half_enabled(shA) and hip_ops.split_half_enabled(shB)
+        after = step_b()
+        for a, b in zip(before, after):
+            assert np.array_equal(a, b)
+        ref = O.train_step_softmax(pA, np.zeros_like(pA), F, hidden, feats, ids, y, ipw_list=None)
+        assert abs(lossA - ref["loss"]) <= 1e-5 * max(1.0, abs(ref["loss"]))
+    finally:
+        monkeypatch.undo()
+        shA.lib.ultr_config_reload()
+
+
+@pytest.mark.parametrize("hidden", [[128, 64], [256, 100]])
+def test_big_path_planes_of_narrow_layers_are_range_checked(hidden, monkeypatch):
+    """the per-layer big-batch path builds split-half planes of EVERY hidden layer - also of layers without
+    fragment copies (fewer than 256 outputs, or a width that is no multiple of 32) - so the range of every hidden weight is
+    tracked: a model of such widths that arrives with a weight of 200 is switched to the fp32 products before a kernel reads a
+    plane, and the forced per-layer step matches the oracle (it used to run on overflowed planes: NaN gradients, silently)."""
+    from oracle import ultr_oracle as O
+    from ultra_pytorch_amd import engine, hip_ops, synthetic
+    for k in ("ULTR_FB_H3", "ULTR_FWD_H3", "ULTR_BWD_H3"):
+        monkeypatch.setenv(k, "1")
+    monkeypatch.setenv("ULTR_BIG_FWD", "2")
+    monkeypatch.setenv("ULTR_BIG_BWD", "2")
+    F, L, B = 136, 10, 64
+    p0 = O.init_params(F, hidden, seed=4)
+    for name, shp, off in O.param_layout(F, hidden):
+        if name.endswith("linear1.weight"):
+            p0[off + 3] = 200.0
+    feats, ids, y = synthetic.make_batch(np.random.RandomState(6), B, L, F)
+    shape = hip_ops.DnnShape(F, hidden, "elu")
+    try:
+        eng = engine.StepEngine(shape, B, L, torch.device("cuda"), algo="softmax")
+        p, st = dev(p0), dev(np.zeros_like(p0))
+        with pytest.warns(RuntimeWarning, match="fp32 matrix cores"):
+            eng.train_step(p, st, dev(feats), feats.shape[0], dev(ids, torch.int32), dev(y))
+        sc = eng.read_scalars()
+        assert not hip_ops.split_half_enabled(shape)
+        ref = O.train_step_softmax(p0, np.zeros_like(p0), F, hidden, feats, ids, y, ipw_list=None)
+        assert abs(float(sc[0]) - ref["loss"]) <= 1e-5 * max(1.0, abs(ref["loss"]))
+        g = eng.grads[:shape.n_params].cpu().numpy() / sc[3]
+        assert np.isfinite(g).all()
+        # (a weight of 200 in front of a LayerNorm: the bar of the full-size tests, 1e-5 relative + 1e-5 of the largest entry)
+        np.testing.assert_allclose(g, ref["grads"], rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(ref["grads"]).max())))
     finally:
         monkeypatch.undo()
         shape.lib.ultr_config_reload()

@@ -198,7 +198,7 @@ def test_plugin_trains_through_a_weight_outside_the_split_half_range(monkeypatch
         ref = O.train_step_softmax(flat, d["s0_pre_adagrad"], m["F"], m["hidden"], d["s0_features"], d["s0_docids"].astype(np.int32),
                                    d["s0_labels"], ipw_list=d["ipw_list"], lr=m["lr"], max_norm=m["max_gradient_norm"])
         assert abs(loss - ref["loss"]) <= 1e-5 * max(1.0, abs(ref["loss"]))
-        assert not hip_ops.split_half_enabled()
+        assert not hip_ops.split_half_enabled(algo.model.shape) and hip_ops.split_half_enabled()
         loss2, _, _ = algo.train(feed)  # and keeps training
         assert np.isfinite(loss2)
     finally:

@@ -20,7 +20,11 @@ c_i32, c_i64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctyp
 
 
 class DnnDesc(ctypes.Structure):
-    _fields_ = [("feature_size", c_i32), ("n_hidden", c_i32), ("hidden", c_i32 * ULTR_MAX_HIDDEN), ("activation", c_i32)]
+    _fields_ = [("feature_size", c_i32), ("n_hidden", c_i32), ("hidden", c_i32 * ULTR_MAX_HIDDEN), ("activation", c_i32),
+                ("flags", c_i32)]
+
+
+MODEL_FP32_PRODUCTS = 1  # ultr_dnn_desc / ultr_setrank_desc ::flags (include/ultr_hip.h, ABI 6)
 
 
 class UpdateDesc(ctypes.Structure):
@@ -28,12 +32,12 @@ class UpdateDesc(ctypes.Structure):
                 ("n_params", c_i64), ("learning_rate", c_f32), ("max_gradient_norm", c_f32), ("adagrad_eps", c_f32),
                 ("ranker_loss_weight", c_f32), ("propensity_learning_rate", c_f32), ("em_step_size", c_f32),
                 ("regulation_p", c_f32), ("l2_loss", c_f32), ("guard", c_vp), ("host_scalars", c_vp),
-                ("seq", ctypes.c_uint32), ("pad_", ctypes.c_uint32)]
+                ("seq", ctypes.c_uint32), ("pad_", ctypes.c_uint32), ("range_flag", c_vp)]
 
 
 class SetRankDesc(ctypes.Structure):
     _fields_ = [("feature_size", c_i32), ("d_model", c_i32), ("num_heads", c_i32), ("num_layers", c_i32), ("dff", c_i32),
-                ("attention_dtype", c_i32)]
+                ("attention_dtype", c_i32), ("flags", c_i32)]
 
 
 class StepArgs(ctypes.Structure):
@@ -73,6 +77,7 @@ SIGNATURES = {
     "ultr_setrank_param_count": (c_i64, [ctypes.POINTER(SetRankDesc)]),
     "ultr_setrank_saved_bytes": (c_i64, [ctypes.POINTER(SetRankDesc), c_i64]),
     "ultr_setrank_workspace_bytes": (c_i64, [ctypes.POINTER(SetRankDesc), c_i64]),
+    "ultr_setrank_range_flag_offset": (c_i64, [ctypes.POINTER(SetRankDesc), c_i64]),
     "ultr_setrank_forward": (c_i32, [ctypes.POINTER(SetRankDesc), c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "ultr_setrank_backward": (c_i32, [ctypes.POINTER(SetRankDesc), c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp,
                                       c_vp]),

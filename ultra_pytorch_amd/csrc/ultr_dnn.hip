@@ -481,27 +481,6 @@ struct PipeSw {
 #define FB_SW 1   // dnn_fb_kernel streams the fragment-major copies when the plan has them (0: the k-major / row-major paths)
 #endif
 
-#ifndef BWD_H3_EPI
-#define BWD_H3_EPI 0  // REPRO BUILDS ONLY (tools/h3_repro.sh): dnn_bwd2_kernel's split-half dgrad epilogue applies the row scale itself
-#endif
-#ifndef H3_ACC2
-#define H3_ACC2 0     // REPRO BUILDS ONLY: PipeH3 chains both cross terms on one accumulator set
-#endif
-#ifndef H3_EPI_BAR
-#define H3_EPI_BAR 0        // REPRO BUILDS ONLY: a workgroup barrier between the products and the epilogue's read of the scales
-#endif
-#ifndef H3_EPI_OS_SCALAR
-#define H3_EPI_OS_SCALAR 0  // REPRO BUILDS ONLY: the epilogue reads its four scales with volatile 4-byte LDS reads
-#endif
-#ifndef H3_OS_DB
-#define H3_OS_DB 0          // REPRO BUILDS ONLY: the row scales double-buffered by layer parity
-#endif
-#ifndef H3_DBG_DUMP
-#define H3_DBG_DUMP 0
-#endif
-#ifndef H3_EPI_NOP
-#define H3_EPI_NOP 0  // REPRO BUILDS ONLY: 32 idle cycles between the last MFMA of a chunk and the epilogue
-#endif
 // Products on the fp16 matrix cores with SPLIT operands (DnnPlan::whf_off / whb_off, ultr_h3_index): the A tile lives in LDS as two
 // fp16 planes (hi, lo of the row-scaled activations), the weights arrive as hi / lo fragments, and a . w = ah.wh + (ah.wl + al.wh)
 // with fp32 accumulation on v_mfma_f32_16x16x32_f16 - 22 bits of operand mantissa, 6 MFMAs of 16 cycles per 32-deep step and
@@ -565,61 +544,8 @@ struct PipeH3 {
       const fbh8 wh = fb_as_h8(b[S][2 * t]), wl = fb_as_h8(b[S][2 * t + 1]);
       acc[t] = fb_mfma_h(ah, wh, acc[t]);
       accx[t] = fb_mfma_h(ah, wl, accx[t]);
-#if H3_ACC2
-      accx[t] = fb_mfma_h(al, wh, accx[t]);  // repro build: the cross terms chained on one accumulator set
-#else
       accy[t] = fb_mfma_h(al, wh, accy[t]);
-#endif
     }
-  }
-  // RT row tiles of 16 rows behind ONE weight stream (dnn_fwd_kernel with 32-row tiles: every weight fragment feeds 2 x 6 MFMAs) - the same
-  // accumulator layout per row tile
-  template <int S, int RT>
-  __device__ __forceinline__ void consume_rt(const _Float16* __restrict__ ah_p, const _Float16* __restrict__ al_p, int ldh, f32x4 (&acc)[RT][2],
-                                             f32x4 (&accx)[RT][2], f32x4 (&accy)[RT][2]) {
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      const fbh8 ah = *reinterpret_cast<const fbh8*>(ah_p + rt * 16 * ldh), al = *reinterpret_cast<const fbh8*>(al_p + rt * 16 * ldh);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const fbh8 wh = fb_as_h8(b[S][2 * t]), wl = fb_as_h8(b[S][2 * t + 1]);
-        acc[rt][t] = fb_mfma_h(ah, wh, acc[rt][t]);
-        accx[rt][t] = fb_mfma_h(ah, wl, accx[rt][t]);
-        accy[rt][t] = fb_mfma_h(al, wh, accy[rt][t]);
-      }
-    }
-  }
-  template <int RT>
-  __device__ __forceinline__ void run_rt(const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al, int ldh, const Src& W, int nks,
-                                         f32x4 (&acc)[RT][2], f32x4 (&accx)[RT][2], int lane) {
-    const int i = lane & 15, q = lane >> 4;
-    const _Float16* ph = Ah + i * ldh + 8 * q;
-    const _Float16* pl = Al + i * ldh + 8 * q;
-    f32x4 accy[RT][2];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int t = 0; t < 2; ++t) accy[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    auto step = [&](auto uc) {
-      constexpr int U = decltype(uc)::value;
-      fetch<(U + D - 1) % D>(W);
-      __builtin_amdgcn_sched_barrier(0);
-      consume_rt<U, RT>(ph, pl, ldh, acc, accx, accy);
-      ph += 32;
-      pl += 32;
-    };
-    int t = 0;
-    for (; t + D <= nks; t += D) {
-      step(std::integral_constant<int, 0>());
-      step(std::integral_constant<int, 1>());
-      if constexpr (D > 2) step(std::integral_constant<int, 2>());
-    }
-    if (t < nks) { consume_rt<0, RT>(ph, pl, ldh, acc, accx, accy); ph += 32; pl += 32; }
-    if constexpr (D > 2) if (t + 1 < nks) { consume_rt<1, RT>(ph, pl, ldh, acc, accx, accy); ph += 32; pl += 32; }
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) accx[rt][tt] += accy[rt][tt];
   }
   // Ah / Al: the two planes of the A tile, row stride ldh halves, zero beyond the real contraction length up to nks * 32
   __device__ __forceinline__ void run(const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al, int ldh, const Src& W, int nks,
@@ -656,19 +582,6 @@ __device__ __forceinline__ void fb_h3_finish(f32x4 (&acc)[1][2], const f32x4 (&a
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[0][t][r] = (acc[0][t][r] + accx[t][r]) * o[r];
-}
-
-template <int RT>
-__device__ __forceinline__ void fb_h3_finish_rt(f32x4 (&acc)[RT][2], const f32x4 (&accx)[RT][2], const float* __restrict__ os, int lane) {
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    const float4 o4 = ld4(os + 16 * rt + 4 * (lane >> 4));
-    const float o[4] = {o4.x, o4.y, o4.z, o4.w};
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[rt][t][r] = (acc[rt][t][r] + accx[rt][t][r]) * o[r];
-  }
 }
 
 // forward epilogue of the last contraction slice: (+ partial sums of earlier slices) + bias, activation; to LDS
@@ -766,12 +679,6 @@ extern "C" int ultr_trace_read(unsigned long long* host_out) {
   } while (0)
 #endif
 
-#if H3_DBG_DUMP  // REPRO BUILDS ONLY (tools/dbg_bwd_h3.py): what dnn_bwd2_kernel's layer-1 row pass read from DU, and the scales its epilogue read
-__device__ float g_ultr_dbg[1 << 21];
-#define DBG_OS_OFF 700000
-#define DBG_EPI_OFF (1 << 20)
-extern "C" int ultr_dbg_read(float* host_out) { return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ultr_dbg), sizeof(float) * (1 << 21)); }
-#endif
 // ------------------------------------------------------------------------------------------------
 // Forward
 // ------------------------------------------------------------------------------------------------
@@ -781,11 +688,6 @@ extern "C" int ultr_dbg_read(float* host_out) { return (int)hipMemcpyFromSymbol(
 #endif
 #ifndef BWD_SW
 #define BWD_SW 1  // dnn_bwd2_kernel: the dgrad products of layers >= 1 with >= 8 chunks stream the fragment-major copy of W_j
-#endif
-#ifndef WG_ATOMIC
-#define WG_ATOMIC 0  // TIMING EXPERIMENT: the weight-gradient epilogue adds its 64 x 64 partial into ONE slab
-                     // with hardware fp32 atomics (all row splits of a block hit the same 16 KB) instead of writing its own slab;
-                     // results are not consumed correctly in this mode - it measures what an atomic epilogue would cost
 #endif
 #ifndef WG_WT
 #define WG_WT 1   // dnn_wgrad_kernel: slabs leave with streaming stores (config 2: step 53.6 -> 53.1 us)
@@ -799,9 +701,6 @@ extern "C" int ultr_dbg_read(float* host_out) { return (int)hipMemcpyFromSymbol(
 #ifndef FB_WT
 #define FB_WT 1  // dnn_fb_kernel: operands for the weight-gradient launch (u_j / xhat_0, dz_j) leave with write-through stores
                  // (1: sc1 buffer stores, 2: nt; 0: plain) - config 2: step 55.4 -> 53.4 (sc1) / 53.6 (nt) us
-#endif
-#ifndef FB_L2PF
-#define FB_L2PF 0  // dnn_fb_kernel: warm the XCD's L2 with the weights from the prologue (A/B: tools/ab_build.sh)
 #endif
 #ifndef FWD_D
 #define FWD_D 2
@@ -963,14 +862,14 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
     // ---- LayerNorm (biased variance, eps 1e-5, affine), in place; two-pass statistics -----------
     bool scored = false;
     bool h3 = false;
-    if constexpr (VEC && RT <= 2 && NW == 8) h3 = p.fwd_h3 != 0 && j < p.nl - 1 && p.h3f[j] != 0 && K16 <= (RT == 1 ? 768 : 512);
+    if constexpr (VEC && RT == 1 && NW == 8) h3 = p.fwd_h3 != 0 && j < p.nl - 1 && p.h3f[j] != 0 && K16 <= 768;  // (32-row tiles behind one split-half stream were built and lost: profiles/r04_cfg2_attempts.md)
     if (h3) {
-      if constexpr (VEC && RT <= 2 && NW == 8) {
+      if constexpr (VEC && RT == 1 && NW == 8) {
        auto ln_h3 = [&](auto xc_tag) {
         // split-half layer (PipeH3): a lane owns columns 4 lane + 256 u; the wave's two rows stay in registers through
         // both passes, and once every wave holds its rows (the barrier) the normalised rows go back over the tile as two
         // fp16 planes, scaled per row by a power of two
-        constexpr int RPW = R / NW, XC = decltype(xc_tag)::value;  // rows up to 256 XC wide (32-row tiles: four rows of a wave in registers)
+        constexpr int RPW = R / NW, XC = decltype(xc_tag)::value;  // rows up to 256 XC wide
         const float invK = 1.0f / (float)K;
         const int ldh = fwd_ldh(p.maxdim);
         _Float16* AH = reinterpret_cast<_Float16*>(X);
@@ -1046,13 +945,8 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
           if (lane == 0) sm_os[r] = inv * (1.0f / ULTR_H3_WSCALE);
         }
        };
-       if constexpr (RT == 1) {
-         if (K16 <= 512) ln_h3(std::integral_constant<int, 2>());
-         else ln_h3(std::integral_constant<int, 3>());
-       } else {
-         if (K16 <= 256) ln_h3(std::integral_constant<int, 1>());
-         else ln_h3(std::integral_constant<int, 2>());
-       }
+       if (K16 <= 512) ln_h3(std::integral_constant<int, 2>());
+       else ln_h3(std::integral_constant<int, 3>());
       }
     } else if (K <= 256) {
       // fast path: a lane owns columns lane + 64k (k < 4); gamma/beta are fetched once per layer, the wave's
@@ -1182,29 +1076,6 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
           }
         }
         bool sw_done = false;
-        if constexpr (RT == 2 && NW == 8) {
-          if (h3) {  // 32-row tiles: two row tiles behind every weight fragment (half the weight stream per row)
-            const int nks = K16 >> 5, ldh = fwd_ldh(p.maxdim);
-            const _Float16* AH = reinterpret_cast<const _Float16*>(X);
-            const _Float16* AL = AH + R * ldh;
-            const Src Wh = make_src(wt + p.whf_off[j], (int64_t)K16 * M);
-            PipeH3<FB_SWD> ph;
-            const int cs = wave * 32;
-            ph.begin(Wh, wave, nks, cs < M, lane);
-            for (int cc = cs; cc < M; cc += NW * 32) {
-              f32x4 acc[RT][2], accx[RT][2];
-#pragma unroll
-              for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) acc[rt][t] = accx[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-              ph.template run_rt<RT>(AH, AL, ldh, Wh, nks, acc, accx, lane);
-              if (cc + NW * 32 < M) ph.begin(Wh, (cc + NW * 32) >> 5, nks, true, lane);
-              fb_h3_finish_rt<RT>(acc, accx, sm_os, lane);
-              finish_fwd_nn<RT, 2>(acc, Y, ld, M, cc, lane, bias, p.act, gout, rows_valid);
-            }
-            sw_done = true;
-          }
-        }
         if constexpr (RT == 1 && NW == 8) {
           if (h3) {
             const int nks = K16 >> 5, ldh = fwd_ldh(p.maxdim);
@@ -1700,7 +1571,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
   const bool h3on = (RT == 1) && p.bwd_h3 != 0 && wt != nullptr;  // dgrad products on the split-half copies where a layer has one (DnnPlan::h3b)
   const int ldz = bwd_ldz_of(p.maxdim, h3on ? 1 : 0), ldu = bwd_ldu(p.maxdim);
   const int ldh = round_up(p.maxdim, 32) + 8;    // row stride (halves) of the two fp16 planes that then live in DZ
-  __shared__ __attribute__((aligned(16))) float sm_os[32];  // their per-row output scales ([16]; the second half only in the H3_OS_DB repro build)
+  __shared__ __attribute__((aligned(16))) float sm_os[16];  // their per-row output scales
   float* DU = smem;                    // [R][ldu]
   float* XS = DU + R * ldu;            // [R][ldu]  input of LayerNorm_j (rows written and read by their owner wave only)
   float* DZ = XS + R * ldu;            // [R][ldz]
@@ -1935,46 +1806,10 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
             for (int t = 0; t < 2; ++t) acc[0][t] = accx[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
             ph.run(AH, AL, ldh, Wh, nks, acc[0], accx, lane);
             if ((ch + NW) * 32 < K) ph.begin(Wh, ch + NW, nks, true, lane);
-#if BWD_H3_EPI
-            // repro build (tools/h3_repro.sh): round 3's first epilogue - scale by sm_os here, every wave reads all 16 scales
-#if H3_EPI_NOP
-            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-#endif
-#if H3_EPI_BAR
-            lds_barrier();
-#endif
-#if H3_DBG_DUMP
-            if (j == 1 && (lane & 15) == 0 && ch == wave) {
-              const float4 o4d = ld4(sm_os + 4 * (lane >> 4));
-              float* dd = g_ultr_dbg + DBG_OS_OFF + ((int64_t)blockIdx.x * 8 + wave) * 16 + 4 * (lane >> 4);
-              dd[0] = o4d.x; dd[1] = o4d.y; dd[2] = o4d.z; dd[3] = o4d.w;
-            }
-#endif
-#if H3_EPI_OS_SCALAR
-            {
-              const volatile float* vos = sm_os + H3_OS_DB * 16 * (j & 1) + 4 * (lane >> 4);
-              const float o[4] = {vos[0], vos[1], vos[2], vos[3]};
-#pragma unroll
-              for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[0][t][r] = (acc[0][t][r] + accx[t][r]) * o[r];
-            }
-#else
-            fb_h3_finish(acc, accx, sm_os + H3_OS_DB * 16 * (j & 1), lane);
-#endif
-#else
             // raw sums: the row pass below applies the per-row scale when it reads DU (its rows are the wave's own)
 #pragma unroll
             for (int t = 0; t < 2; ++t) acc[0][t] += accx[t];
-#endif
             store_nn<RT, 2>(acc, DU, ldu, K, ch * 32, lane, false);
-#if H3_DBG_DUMP >= 2
-            if (j == 1 && ch == wave) {  // the epilogue's results straight from the registers
-              float* dd = g_ultr_dbg + DBG_EPI_OFF + (((int64_t)blockIdx.x * 8 + wave) * 64 + lane) * 8;
-              st4(dd, make_float4(acc[0][0][0], acc[0][0][1], acc[0][0][2], acc[0][0][3]));
-              st4(dd + 4, make_float4(acc[0][1][0], acc[0][1][1], acc[0][1][2], acc[0][1][3]));
-            }
-#endif
           }
           sw_done = true;
         } else if (BWD_SW && wt != nullptr && p.sw_ok && j >= 1 && K >= 32 * NW) {
@@ -2047,14 +1882,14 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
       const float invK = 1.0f / (float)K;
       float mean[RPW], rstd[RPW], dsr[RPW], dus[RPW];
       // du_j came out of the split-half product unscaled: its rows still carry the row scale of the dz planes
-      const bool du_scaled = !BWD_H3_EPI && h3on && !last && j >= 1 && p.h3b[j] != 0;
+      const bool du_scaled = h3on && !last && j >= 1 && p.h3b[j] != 0;
 #pragma unroll
       for (int k = 0; k < RPW; ++k) {
         const int r = wave + NW * k;
         mean[k] = sm_mean2[par * R + r];
         rstd[k] = sm_rstd2[par * R + r];
         dsr[k] = sm_ds[r];
-        dus[k] = du_scaled ? sm_os[H3_OS_DB * 16 * (j & 1) + (r & 15)] : 1.0f;
+        dus[k] = du_scaled ? sm_os[r & 15] : 1.0f;
       }
       float4 xk[RPW][XC], gxk[RPW][XC];
       float red[2 * RPW];
@@ -2078,9 +1913,6 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
           else {
             du4 = act ? ld4(DU + r * ldu + c) : z4;
             du4.x *= dus[k]; du4.y *= dus[k]; du4.z *= dus[k]; du4.w *= dus[k];
-#if H3_DBG_DUMP
-            if (j == 1 && act && n0 + r < N) st4(g_ultr_dbg + (n0 + r) * K + c, du4);
-#endif
           }
           const float4 xh = make_float4((x4.x - mean[k]) * rstd[k], (x4.y - mean[k]) * rstd[k],
                                         (x4.z - mean[k]) * rstd[k], (x4.w - mean[k]) * rstd[k]);
@@ -2158,7 +1990,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
                   *reinterpret_cast<fbh4*>(AL + r * ldh + c) = lo;
                 }
               }
-              if (lane == 0) sm_os[H3_OS_DB * 16 * ((j - 1) & 1) + r] = inv * (1.0f / ULTR_H3_WSCALE);
+              if (lane == 0) sm_os[r] = inv * (1.0f / ULTR_H3_WSCALE);
             }
           }
         }
@@ -2287,25 +2119,6 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
     if (tid < R) sm_ds[tid] = 0.f;
     if (lane < 2) sm_lt[wave * 2 + lane] = 0.f;
   }
-#if FB_L2PF
-  // Warm THIS XCD's L2 with the weights: a launch starts with cold L2s (they are invalidated at every kernel boundary;
-  // the weights sit in the memory-side cache), and the workgroups of an XCD stream the same matrices in lockstep, so
-  // without this every trip of every GEMM phase waits for a first touch beyond L2.  Workgroup b runs on XCD b % 8: the
-  // gridDim / 8 workgroups of an XCD each touch a different 1 / (gridDim / 8) of [k-major copy | parameters], one 4-byte
-  // load per 128-byte line (64 lines per wave instruction), issued behind the prologue's own loads and never waited for
-  // before the end of the kernel.
-  float pf0, pf1;
-  {
-    const int nslot = ((int)gridDim.x + 7) >> 3, slot = (int)blockIdx.x >> 3;
-    const int l_wt = (int)((p.wt_total * 4 + 127) >> 7), l_p = (int)((p.P * 4 + 127) >> 7);
-    const int per_wt = (l_wt + nslot - 1) / nslot, per_p = (l_p + nslot - 1) / nslot;
-    const int e = wave * 64 + lane;
-    const int lw = slot * per_wt + e, lp = slot * per_p + e;
-    const Src s_wt = make_src(wt, p.wt_total), s_p = make_src(params, p.P);
-    pf0 = buf_ld1(s_wt, (e < per_wt && lw < l_wt) ? (unsigned)lw * 128u : ULTR_OOB);
-    pf1 = buf_ld1(s_p, (e < per_p && lp < l_p) ? (unsigned)lp * 128u : ULTR_OOB);
-  }
-#endif
   // loss inputs of the wave's first list (lane = position), in flight during the whole forward
   const int li0 = wave;  // list index inside the block handled by this wave (then + NW)
   const bool lact0 = li0 < LPB && b_first + li0 < B && lane < L;
@@ -2824,9 +2637,6 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
 #if FB_KAPF
   asm volatile("" ::"v"(ka_pf));
 #endif
-#if FB_L2PF
-  asm volatile("" ::"v"(pf0), "v"(pf1));  // the warming loads are only "used" here
-#endif
 #undef FBF
 #undef FBF64
 }
@@ -3133,11 +2943,7 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
   }
   lds_barrier();
   TRACE_STAMP(11);
-#if WG_ATOMIC
-  float* slab = ws + wl.slab_off;  // every split of a block into the same slab
-#else
   float* slab = ws + wl.slab_off + (int64_t)split * ((int64_t)M * K + M);
-#endif
   float4 l0pg = make_float4(0.f, 0.f, 0.f, 0.f), l0pb = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
@@ -3162,12 +2968,7 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
     if (m < M && k < K) {
       float* dst = slab + (int64_t)m * K + k;
       if (vec && k + 3 < K) {
-#if WG_ATOMIC
-        unsafeAtomicAdd(dst + 0, s.x);
-        unsafeAtomicAdd(dst + 1, s.y);
-        unsafeAtomicAdd(dst + 2, s.z);
-        unsafeAtomicAdd(dst + 3, s.w);
-#elif WG_WT
+#if WG_WT
         st4_stream(dst, s);
 #else
         st4(dst, s);
@@ -3235,24 +3036,6 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
                    // staging writes (lane (c16, rg) -> column 4 c16 + c, slot rg) 2-way (13 -> 16 cycles): brute-forced over the
                    // lane groups of MI355X_MICROARCH.md's LDS table; the first layout (80 bytes, no XOR: reads 2-way, writes 4-way)
                    // spent 1 800 of 4 600 cycles per step between the two barriers around the plane writes
-#ifndef WH_NOLOAD
-#define WH_NOLOAD 0
-#endif
-#ifndef WH_LOAD_FIRST
-#define WH_LOAD_FIRST 0
-#endif
-#ifndef WH_NOCONV
-#define WH_NOCONV 0
-#endif
-#ifndef WH_NOMFMA
-#define WH_NOMFMA 0
-#endif
-#ifndef WH_NOPUB
-#define WH_NOPUB 0
-#endif
-#ifndef WH_CONV_IN_MUL
-#define WH_CONV_IN_MUL 0
-#endif
 #define WH_ROWS_CAP 2048
 #define WH_GROUP_HALVES (4 * 2 * 64 * WH_LDH)
 #define WH_PLANES_BYTES (2 * WH_GROUP_HALVES * 2)
@@ -3374,19 +3157,12 @@ __global__ __launch_bounds__(512) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan bp
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
           unsigned off = (id[r] >= 0 && colok) ? (unsigned)(((int64_t)id[r] * K + col) * 4) : ULTR_OOB;
-#if WH_NOLOAD
-          off = ULTR_OOB;
-#endif
           s.v[r] = __builtin_amdgcn_raw_buffer_load_b128(src.rs, off, 0, 0);
         }
       } else {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-#if WH_NOLOAD
-          s.v[r] = __builtin_amdgcn_raw_buffer_load_b128(src.rs, ULTR_OOB, (unsigned)r * stride, 0);
-#else
           s.v[r] = __builtin_amdgcn_raw_buffer_load_b128(src.rs, vo, (unsigned)r * stride, 0);
-#endif
         }
         vo += 64u * stride;
       }
@@ -3394,16 +3170,6 @@ __global__ __launch_bounds__(512) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan bp
     };
     // scale + split of a half-block into ch / cl; `bump` = how far the running scale went down
     auto convert = [&](const WhStep& s) __attribute__((always_inline)) {
-#if WH_NOCONV
-      if (tc > 1) {  // timing variant: the loads are consumed, nothing is converted
-        unsigned x = 0;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) x |= s.v[r].x | s.v[r].y | s.v[r].z | s.v[r].w;
-        if (x == 0x7fc12345u) bump = 1;
-        tc += 2;
-        return;
-      }
-#endif
       float v[8][4];
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
@@ -3452,11 +3218,9 @@ __global__ __launch_bounds__(512) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan bp
         }
     };
     auto stage = [&](WhStep& slot) __attribute__((always_inline)) {
-#if !WH_CONV_IN_MUL
       convert(slot);
-#endif
 #pragma unroll
-      for (int c = 0; c < (WH_NOPUB ? 1 : 4); ++c) {
+      for (int c = 0; c < 4; ++c) {
         *reinterpret_cast<fbh8*>(myplane + c * WH_LDH) = ch[c];
         *reinterpret_cast<fbh8*>(myplane + 64 * WH_LDH + c * WH_LDH) = cl[c];
       }
@@ -3466,9 +3230,6 @@ __global__ __launch_bounds__(512) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan bp
     // the phase before; past the end: beyond the buffer - zeros, no traffic): issuing 8 x 1 KiB per wave takes as long as the
     // conversion, and in the stage phase it made that phase twice as long as the products it is meant to hide behind
     auto multiply = [&](WhStep& slot, const WhStep& other) __attribute__((always_inline)) {
-#if WH_LOAD_FIRST
-      load_step(slot);
-#endif
       const int d = __builtin_amdgcn_readfirstlane(sm_bump[4 * g + wm] + sm_bump[4 * g + 2 + wk]);
       if (d != 0) {  // an operand's scale went down by 2^d: bring the sums along (exact)
         const float f = d > 126 ? 0.f : __uint_as_float((unsigned)(127 - d) << 23);
@@ -3484,7 +3245,7 @@ __global__ __launch_bounds__(512) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan bp
         bl[tb] = *reinterpret_cast<const fbh8*>(pb + 64 * WH_LDH + tb * 16 * WH_LDH);
       }
 #pragma unroll
-      for (int ta = 0; ta < (WH_NOMFMA ? 1 : 4); ++ta) {
+      for (int ta = 0; ta < 4; ++ta) {
         const fbh8 ah = *reinterpret_cast<const fbh8*>(pa + ta * 16 * WH_LDH);
         const fbh8 al = *reinterpret_cast<const fbh8*>(pa + 64 * WH_LDH + ta * 16 * WH_LDH);
 #pragma unroll
@@ -3494,19 +3255,11 @@ __global__ __launch_bounds__(512) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan bp
 #pragma unroll
         for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = fb_mfma_h(al, bh[tb], acc[ta][tb]);
       }
-#if WH_CONV_IN_MUL
-      convert(other);  // the NEXT step's half-block (in registers since the phase before last): VALU work behind the products
-#endif
-#if !WH_LOAD_FIRST
       load_step(slot);
-#endif
     };
     WhStep r0, r1;
     load_step(r0);
     load_step(r1);
-#if WH_CONV_IN_MUL
-    convert(r0);
-#endif
     if (g == 1) lds_barrier();  // group 1 runs one phase behind group 0
     for (int s = 0; s < S; s += 2) {
       if (s < 6) TRACE_STAMP(2 + 4 * s);
@@ -3784,7 +3537,7 @@ __global__ __launch_bounds__(64) void grad_sumsq_kernel(int64_t P, const float* 
 // per knob per launch is host time on the critical path of a ~50 us step.  ultr_config_reload() re-reads them (tests and
 // the A/B tools flip knobs inside one process).
 struct Knobs {
-  int fwd_r, bwd_r, wgrad_wgs, fwd_nw, bwd_nw, no_vec, no_l0g, bwd_v1, no_fused_fb, fb_max_wg_per_cu, fwd_q4, big_fwd, big_bwd, fb_h3, fwd_h3, bwd_h3, wgd, wgd_max_rows, wg_h3, wg_h3_min_rows, wg_h3_wgs;
+  int fwd_r, bwd_r, wgrad_wgs, fwd_nw, bwd_nw, no_vec, no_l0g, no_fused_fb, fb_max_wg_per_cu, fwd_q4, big_fwd, big_bwd, fb_h3, fwd_h3, bwd_h3, wg_h3, wg_h3_min_rows, wg_h3_wgs;
   bool loaded;
 };
 static Knobs g_knobs = {};
@@ -3801,7 +3554,6 @@ static void knobs_load() {
   k.bwd_nw = env_read("ULTR_BWD_NW", 8);
   k.no_vec = env_read("ULTR_NO_VEC", 0);
   k.no_l0g = env_read("ULTR_NO_L0G", 0);
-  k.bwd_v1 = env_read("ULTR_BWD_V1", 0);
   k.no_fused_fb = env_read("ULTR_NO_FUSED_FB", 0);
   k.fb_max_wg_per_cu = env_read("ULTR_FB_MAX_WG_PER_CU", 1);
   k.fwd_q4 = env_read("ULTR_FWD_Q4", 1);
@@ -3812,11 +3564,6 @@ static void knobs_load() {
   k.fb_h3 = env_read("ULTR_FB_H3", 1);
   k.fwd_h3 = env_read("ULTR_FWD_H3", 1);
   k.bwd_h3 = env_read("ULTR_BWD_H3", 1);
-  // direct weight gradients (ultr_wgd.hip: final gradients from ONE launch, no slabs, no reduction launch) behind the fused
-  // small-batch kernel, for batches of at most this many rows.  OFF by default: measured at config 2 it ties with the slab path
-  // (17.7 us against 12.3 + 5.0 us + one launch gap; step 50.2 against 48.4 us - profiles/r04_cfg2_attempts.md)
-  k.wgd = env_read("ULTR_WGD", 0);
-  k.wgd_max_rows = env_read("ULTR_WGD_MAX_ROWS", 4096);
   k.wg_h3 = env_read("ULTR_WG_H3", 1);                    // weight gradients on the fp16 matrix cores (split-half operands); 2: any batch size
   k.wg_h3_min_rows = env_read("ULTR_WG_H3_MIN_ROWS", 4096);
   k.wg_h3_wgs = env_read("ULTR_WG_H3_WGS", 0);
@@ -3848,6 +3595,8 @@ bool ultr_make_dnn_plan(const ultr_dnn_desc* d, int64_t N, DnnPlan* p) {
   memset(p, 0, sizeof(*p));
   p->nl = d->n_hidden + 1;
   p->act = d->activation;
+  p->no_h3 = (d->flags & ULTR_MODEL_FP32_PRODUCTS) ? 1 : 0;
+  p->h3_watch = (!p->no_h3 && (knobs().fb_h3 != 0 || knobs().fwd_h3 != 0 || knobs().bwd_h3 != 0)) ? 1 : 0;
   int k = d->feature_size;
   int64_t off = 0;
   p->maxdim = k;
@@ -3935,17 +3684,21 @@ bool ultr_make_dnn_plan(const ultr_dnn_desc* d, int64_t N, DnnPlan* p) {
         }
       }
       p->h3_ok = h3 ? 1 : 0;
-      p->fb_h3 = (h3 && knobs().fb_h3) ? 1 : 0;
-      p->h3_flag_off = o;  // (inside the region ultr_dnn_build_wt zeroes)
-      o += 4;
+      p->fb_h3 = (h3 && knobs().fb_h3 && !p->no_h3) ? 1 : 0;
       p->bwd_h3 = 0;
-      if (knobs().bwd_h3)
+      if (knobs().bwd_h3 && !p->no_h3)
         for (int j = 1; j < p->nl - 1; ++j)
           if (p->h3b[j]) p->bwd_h3 = 1;
       p->fwd_h3 = 0;
-      if (knobs().fwd_h3)
+      if (knobs().fwd_h3 && !p->no_h3)
         for (int j = 0; j < p->nl - 1; ++j)
           if (p->h3f[j] && round_up(p->K[j], 32) <= 768) p->fwd_h3 = 1;
+    }
+    // the range word of the hidden weights (every model with a hidden layer: the per-layer big-batch path builds split-half planes of
+    // ANY hidden layer, ultr_dnn_big.hip); zeroed by ultr_dnn_build_wt
+    if (p->nl >= 2) {
+      p->h3_flag_off = o;
+      o += 4;
       p->wt_total = o;
     }
   }
@@ -4114,10 +3867,6 @@ bool ultr_make_bwd_plan(const DnnPlan& p, int64_t N, BwdPlan* bp, int wg_mode) {
     off = (off + 7) & ~(int64_t)7;
     bp->dgp_off = off; off += (h + 1) / 2; off = (off + 3) & ~(int64_t)3;
   }
-  {
-    const int64_t nmt0 = (p.M[0] + 15) / 16, nkt0 = (p.K[0] + 31) / 32;
-    bp->wgd_part_off = off; off += nkt0 * nmt0 * 96;
-  }
   bp->total = off;
   return true;
 }
@@ -4235,10 +3984,10 @@ __global__ __launch_bounds__(256) void wt_build_kernel(DnnPlan p, const float* _
         wt[p.wsf_off[j] + ultr_sw_index(m, k, (p.K[j] + 31) >> 5)] = v;
         if (j >= 1) wt[p.wsb_off[j] + ultr_sw_index(k, m, (p.M[j] + 31) >> 5)] = v;
       }
+      const float sv = v * ULTR_H3_WSCALE;
+      if (!(fabsf(sv) < ULTR_H3_WNEAR))  // every hidden weight is watched: the per-layer path builds planes of any layer (NaN counts as out of range)
+        flag_or(reinterpret_cast<uint32_t*>(wt + p.h3_flag_off), !(fabsf(sv) < ULTR_H3_WMAX) ? (ULTR_H3_FLAG_OVER | ULTR_H3_FLAG_NEAR) : ULTR_H3_FLAG_NEAR);
       if (p.h3f[j] || p.h3b[j]) {
-        const float sv = v * ULTR_H3_WSCALE;
-        if (!(fabsf(sv) < ULTR_H3_WNEAR))
-          flag_or(reinterpret_cast<uint32_t*>(wt + p.h3_flag_off), !(fabsf(sv) < ULTR_H3_WMAX) ? (ULTR_H3_FLAG_OVER | ULTR_H3_FLAG_NEAR) : ULTR_H3_FLAG_NEAR);
         const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
         if (p.h3f[j]) {
           _Float16* hf = reinterpret_cast<_Float16*>(wt + p.whf_off[j]);
@@ -4260,7 +4009,7 @@ extern "C" int ultr_dnn_build_wt(const ultr_dnn_desc* d, const float* params, fl
   DnnPlan p;
   if (!params || !wt || !ultr_make_dnn_plan(d, 0, &p)) return ULTR_E_BADARG;
   const int64_t n = p.P + 4;
-  if (p.sw_ok && p.wt_total > p.ws_begin) {  // the fragment-major copies are padded to whole 32 x 32 blocks: zeros there
+  if (p.wt_total > p.ws_begin) {  // the fragment-major copies are padded to whole 32 x 32 blocks: zeros there (and the range word)
     const hipError_t e = hipMemsetAsync(wt + p.ws_begin, 0, (size_t)(p.wt_total - p.ws_begin) * sizeof(float), (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
   }
@@ -4271,7 +4020,7 @@ extern "C" int ultr_dnn_build_wt(const ultr_dnn_desc* d, const float* params, fl
 extern "C" int ultr_dnn_wt_range(const ultr_dnn_desc* d, const float* wt, void* stream) {
   DnnPlan p;
   if (!wt || !ultr_make_dnn_plan(d, 0, &p)) return ULTR_E_BADARG;
-  if (p.h3_flag_off <= 0) return 0;  // this model has no split-half copies
+  if (p.h3_flag_off <= 0) return 0;  // no hidden layer: nothing is ever split
   uint32_t f = 0;
   hipError_t e = hipMemcpyAsync(&f, wt + p.h3_flag_off, sizeof(f), hipMemcpyDeviceToHost, (hipStream_t)stream);
   if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
@@ -4317,7 +4066,7 @@ static bool big_fwd_wanted(const DnnPlan& p, int64_t N, size_t row_tile_lds) {
 static bool big_bwd_wanted(const DnnPlan& p, int64_t N) {
   const int mode = knobs().big_bwd;
   if (mode != 1) return mode >= 2;
-  const bool v2 = knobs().bwd_nw == 8 && knobs().bwd_v1 == 0 && p.maxdim <= 512 &&
+  const bool v2 = knobs().bwd_nw == 8 && p.maxdim <= 512 &&
                   bwd2_lds_floats(p, bwd_rows_per_wg(p, N), 8) * sizeof(float) <= 160 * 1024;
   return N >= (v2 ? 16384 : 4096);
 }
@@ -4351,7 +4100,7 @@ extern "C" int ultr_dnn_forward(const ultr_dnn_desc* d, const float* params, con
   if (saved != nullptr && wt != nullptr && av && ultr_dnn_big_ok(p, N, n_docs) &&
       knobs().big_fwd != 0 && (big_fwd_wanted(p, N, lds) || lds > 160 * 1024))
     return ultr_dnn_big_forward(p, params, wt, features, n_docs, docids, (int)batch, (int)list_size, scores, (float*)saved, st,
-                                prof.on ? prof.a : nullptr, prof.on ? prof.b : nullptr, knobs().fwd_h3 != 0);
+                                prof.on ? prof.a : nullptr, prof.on ? prof.b : nullptr, knobs().fwd_h3 != 0 && !p.no_h3 && wt != nullptr);
   if (lds > 160 * 1024) return ULTR_E_UNSUPPORTED;
 #define LAUNCH_FWD(RR, NWW, VV)                                                                                     \
   do {                                                                                                              \
@@ -4475,7 +4224,7 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
   // fast variant: aligned shapes, K_j <= 512, 8 waves, LDS budget (see dnn_bwd2_kernel)
   const size_t lds2 = bwd2_lds_floats(p, bp.rblk, 8) * sizeof(float);
   const bool v2 = av && nw == 8 && p.maxdim <= 512 && lds2 <= 160 * 1024 && p.sv_total * 4 < ((int64_t)1 << 31) &&
-                  p.P * 4 < ((int64_t)1 << 31) && knobs().bwd_v1 == 0;
+                  p.P * 4 < ((int64_t)1 << 31);
 #define LAUNCH_BWDV2(RR, XX)                                                                                           \
   do {                                                                                                                 \
     e = set_lds(dnn_bwd2_kernel<RR, 8, XX>, lds2);                                                                     \
@@ -4491,7 +4240,7 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
     UltrProfScope prof(ULTR_K_BWD, st);
     bp.nrb = (int)((N + ULTR_BIG_ROWS - 1) / ULTR_BIG_ROWS);  // one vector slab per row block of the row kernels
     const int rc = ultr_dnn_big_backward(p, bp, params, (const float*)saved, dscores, ws, st, prof.on ? prof.a : nullptr,
-                                         prof.on ? prof.b : nullptr, knobs().bwd_h3 != 0);
+                                         prof.on ? prof.b : nullptr, knobs().bwd_h3 != 0 && !p.no_h3 && g_ultr_step_wt != nullptr);
     if (rc) return rc;
   } else if (v2) {
     UltrProfScope prof(ULTR_K_BWD, st);
@@ -4520,11 +4269,6 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
     len = len < 1024 ? 1024 : (len + 31) / 32 * 32;
     bp.lf_len = len;
     bp.lf_chunks = (nlp + len - 1) / len;
-  }
-  if (fused_rb > 0 && av && l0g_ok && knobs().wgd != 0 && N <= knobs().wgd_max_rows) {
-    // small batch behind the fused kernel: final gradients from one launch (ultr_wgd.hip)
-    const int rc = ultr_wgd_launch(p, bp, params, (const float*)saved, ws, grads, lp, nlp, tail, (int)ultr_red_blocks(p.P, tail), st);
-    if (rc != ULTR_E_UNSUPPORTED) return rc;
   }
   if (bp.wg_h3) {
     UltrProfScope prof(ULTR_K_WGRAD, st);

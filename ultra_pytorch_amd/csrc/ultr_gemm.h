@@ -28,9 +28,6 @@
 //     are masked: any R, N, K (K % 4 == 0 and 16-byte aligned rows for the vector loads; checked by the launcher).
 #pragma once
 #include <atomic>
-#ifndef UGEMM_BM128
-#define UGEMM_BM128 0
-#endif
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
@@ -55,9 +52,6 @@ __device__ unsigned long long g_ugemm_cyc[4096], g_ugemm_xcc[4096];
 // 1 = all ten fragment reads of a k-tile in front of its MFMAs (counted lgkmcnt waits) instead of hipcc's own order (two
 // reads, wait, eight MFMAs - four LDS round trips per k-tile but 52 registers).  Measured: 102 registers -> two workgroups
 // per CU instead of three, 101 -> 91 TFLOP/s at 12288 x 704 x 512: occupancy beats the shorter dependency chain.  Default 0.
-#ifndef UGEMM_FRAG_SCHED
-#define UGEMM_FRAG_SCHED 0
-#endif
 constexpr int BK = 32;        // contraction steps per k-tile
 constexpr int LDA = BK + 8;   // LDS row stride of k-contiguous tiles (A, n-major B): stride = 8 (mod 16) floats is the
                               // conflict-free one for ds_read_b128 with 16 rows x 4 k-groups per wave (its 4 x 16 lane groups)
@@ -449,15 +443,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(Dims d, AProd aprod,
           float4 fa0[C::RT], fb0[4], fa1[C::RT], fb1[4];
           read_frags(t & 1, 0, fa0, fb0);
           read_frags(t & 1, 1, fa1, fb1);
-#if UGEMM_FRAG_SCHED
-          // left alone, hipcc issues two fragment reads at a time and waits for each pair in front of its eight MFMAs: four
-          // exposed LDS round trips per k-tile.  All ten reads first, then the MFMAs behind counted lgkmcnt waits
-          __builtin_amdgcn_sched_barrier(0);
-#endif
           mfma_half(fa0, fb0, live_rt);
-#if UGEMM_FRAG_SCHED
-          __builtin_amdgcn_sched_barrier(0);
-#endif
           mfma_half(fa1, fb1, live_rt);
         }
         if (t + 1 < nk) store_tile((t + 1) & 1, (t + 1) * BK, S0);
@@ -556,9 +542,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(Dims d, AProd aprod,
 // Same persistent schedule, staging pattern and LDS-transposed epilogue as the n-major fp32 kernel.
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
-#ifndef UGEMM_H3_ABLATE
-#define UGEMM_H3_ABLATE 0
-#endif
 #ifndef UGEMM_TRACE_STAMP  // phase tracing (-DULTR_TRACE builds of ultr_setrank.hip define it): s_memtime of wave 0 of every 32nd workgroup
 #define UGEMM_TRACE_STAMP(slot) do {} while (0)
 #endif
@@ -645,11 +628,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h3_kernel(Dims d, AProd apr
 #pragma unroll
     for (int j = 0; j < C::A_LOADS; ++j) {
       sl.arow[j] = lrow[j];
-#if UGEMM_H3_ABLATE == 1  // timing variant: no A traffic
-      sl.areg[j] = aprod.raw(lrow[j], 0x40000000);
-#else
       sl.areg[j] = aprod.raw(lrow[j], ka);
-#endif
     }
 #pragma unroll
     for (int j = 0; j < B_PIECES; ++j) {
@@ -680,16 +659,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h3_kernel(Dims d, AProd apr
     for (int j = 0; j < C::A_LOADS; ++j) {
       const int idx = tid + C::NT * j, row = idx >> 3;
       const float4 v = aprod.finish(sl.arow[j], sl.acol, k0 + k4, sl.areg[j]);
-#if UGEMM_H3_ABLATE == 5  // timing variant: no scale search, no split (the raw bits go to LDS)
-      {
-        union { float4 f; h4v h[2]; } u;
-        u.f = v;
-        *reinterpret_cast<h4v*>(Ahb + row * LDH + k4) = u.h[0];
-        *reinterpret_cast<h4v*>(Alb + row * LDH + k4) = u.h[1];
-        if ((tid & 7) == 0) Sc[buf * BM + row] = 1.0f;
-        continue;
-      }
-#endif
       // the largest magnitude of the row's 32 steps: the 8 threads of a row are 8 consecutive lanes
       float am = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
       am = fmaxf(am, dpp_or<0xb1>(am, am));
@@ -738,18 +707,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h3_kernel(Dims d, AProd apr
           const float scv[4] = {sc.x, sc.y, sc.z, sc.w};
 #pragma unroll
           for (int ct = 0; ct < C::CT; ++ct) {
-#if UGEMM_H3_ABLATE == 4  // timing variant: no per-tile rescale (the three products accumulate straight into acc)
-            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ct], acc[rt][ct], 0, 0, 0);
-            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ct], acc[rt][ct], 0, 0, 0);
-            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ct], acc[rt][ct], 0, 0, 0);
-            if (scv[0] == 12345.f) acc[rt][ct][0] += 1.f;
-            continue;
-#endif
             f32x4 tmp = {0.f, 0.f, 0.f, 0.f};
-#if UGEMM_H3_ABLATE != 3  // (3: timing variant without the cross terms)
             tmp = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ct], tmp, 0, 0, 0);
             tmp = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ct], tmp, 0, 0, 0);
-#endif
             tmp = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ct], tmp, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[rt][ct][r] = fmaf(tmp[r], scv[r], acc[rt][ct][r]);
@@ -828,270 +788,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h3_kernel(Dims d, AProd apr
       const int row = idx / (BN / 4), c4 = (idx - row * (BN / 4)) * 4;
       const int64_t r = e_r0 + row;
       const int c = e_n0 + c4;
-#if UGEMM_H3_ABLATE == 2  // timing variant: one row in 64 is stored
-      if (r < e_rend && c < d.N && (r & 63) == 0) {
-#else
       if (r < e_rend && c < d.N) {
-#endif
         const int nv = d.N - c < 4 ? d.N - c : 4;
         epi(r, c, ld4(Cs + row * C::LDC + c4), nv, pre[k]);
       }
     }
     UGEMM_TRACE_STAMP(21);
-    if (!more) break;
-    lds_barrier();  // the tile in LDS has been read
-    cur = chunk_at(un);
-  }
-}
-
-// ---- split-half mode, 64-deep contraction tiles ---------------------------------------------------------------------------
-// gemm_h3_kernel issues ~150 instructions per wave and 32-deep tile around its 12 MFMAs (tools/gemm_ablate.sh: no A traffic,
-// no cross products, no rescale - each -2 .. -5 %: nothing but the instruction count is left), four waves per SIMD.  Twice the
-// contraction depth per tile halves what is paid per tile - the rescale, the offsets of the requests, the barriers, the loop -
-// and leaves the per-element work (conversion, LDS traffic) as it is.  One LDS stage (the planes of a 64 x 64 A tile and a
-// BN x 64 B tile: 55 KB, two workgroups per CU) and the two register slots of the stream: a tile is written after the barrier that
-// ends the products of the tile before it.  Scales: per row and 64-deep tile (16 lanes per row).
-// (BKW = 32: the same single-stage structure with 32-deep tiles - 31 KB of LDS, four workgroups per CU)
-template <int BM, int BN, int WM, int WN, int BKW, class AProd, class Epi>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_h3w_kernel(Dims d, AProd aprod, const _Float16* __restrict__ Bhi,
-                                                                const _Float16* __restrict__ Blo, Epi epi) {
-  constexpr int NT = WM * WN * 64, RT = BM / WM / 16, CT = BN / WN / 16, LDC = BN + 4, LDW = BKW + 8, TPR = BKW / 4, PPR = BKW / 8;
-  static_assert(CT == 4, "a wave owns 64 output columns");
-  constexpr int A_LOADS = BM * (BKW / 4) / NT;     // float4 per thread per tile
-  constexpr int B_PIECES = BN * (BKW / 8) / NT;    // 16-byte pieces (8 halves) per thread per plane per tile
-  static_assert(BM * (BKW / 4) % NT == 0 && BN * (BKW / 8) % NT == 0 && A_LOADS >= 1 && B_PIECES >= 1, "staging divides evenly");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  _Float16* Ah = reinterpret_cast<_Float16*>(smem);  // [2][BM][LDW]
-  _Float16* Bh = Ah + 2 * BM * LDW;                  // [2][BN][LDW]
-  float* Sc = reinterpret_cast<float*>(Bh + 2 * BN * LDW);  // [BM]
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int i = lane & 15, q = lane >> 4;
-  const int wr = (wave / WN) * (BM / WM), wc = (wave % WN) * (BN / WN);
-  const int ncb = (d.N + BN - 1) / BN;
-  const int64_t nru = (d.R + 15) / 16;
-  const int64_t U = nru * ncb;
-  int64_t w = blockIdx.x;
-  const int64_t G = gridDim.x;
-  if ((G & 7) == 0) w = (w & 7) * (G >> 3) + (w >> 3);
-  const int64_t u = w * U / G;
-  const int64_t u_end = (w + 1) * U / G;
-  if (u >= u_end) return;
-  const int64_t bplane = (int64_t)d.N * d.ldb;  // halves per plane
-  const __amdgpu_buffer_rsrc_t bhs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(Bhi), 0, (int)(bplane * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t bls = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(Blo), 0, (int)(bplane * 2), 0x00020000);
-  const int nk = (d.K + BKW - 1) / BKW;
-  const int nkp = (nk + 1) & ~1;
-  const int k4 = (tid & (TPR - 1)) * 4;
-  struct Chunk {
-    int64_t u, r0, rend;
-    int n0, m_units;
-  };
-  struct Slot {
-    float4 areg[A_LOADS];
-    typename AProd::Row arow[A_LOADS];
-    typename AProd::Cols acol;
-    u32x4 bhr[B_PIECES], blr[B_PIECES];
-  };
-  auto chunk_at = [&](int64_t uu) {
-    Chunk c;
-    const int64_t cb = uu / nru, ru = uu - cb * nru;
-    int64_t m = u_end - uu;
-    if (m > BM / 16) m = BM / 16;
-    if (m > nru - ru) m = nru - ru;
-    c.u = uu;
-    c.m_units = (int)m;
-    c.r0 = ru * 16;
-    c.rend = c.r0 + 16 * m < d.R ? c.r0 + 16 * m : d.R;
-    c.n0 = (int)cb * BN;
-    return c;
-  };
-  Chunk lc = chunk_at(u);
-  int lkt = 0;
-  bool lok = true;
-  typename AProd::Row lrow[A_LOADS];
-  unsigned lboff[B_PIECES];  // byte offset of this thread's pieces in the planes at k-tile 0 of the loader's chunk (out of range: n >= N)
-  auto loader_rows = [&]() {
-#pragma unroll
-    for (int j = 0; j < A_LOADS; ++j) lrow[j] = aprod.row(lc.r0 + ((tid + NT * j) / TPR), lc.rend);
-#pragma unroll
-    for (int j = 0; j < B_PIECES; ++j) {
-      const int idx = tid + NT * j;
-      const int n = idx / PPR, kp = (idx % PPR) * 8;
-      lboff[j] = (lc.n0 + n < d.N) ? (unsigned)(((int64_t)(lc.n0 + n) * d.ldb + kp) * 2) : ULTR_OOB;
-    }
-  };
-  loader_rows();
-  auto load_next = [&](Slot& sl) {  // (no control flow around the loads - see gemm_h3_kernel)
-    const int k0 = lkt * BKW;
-    const int ka = lok ? k0 + k4 : 0x40000000;
-    sl.acol = aprod.cols(k0 + k4);
-#pragma unroll
-    for (int j = 0; j < A_LOADS; ++j) {
-      sl.arow[j] = lrow[j];
-      sl.areg[j] = aprod.raw(lrow[j], ka);
-    }
-#pragma unroll
-    for (int j = 0; j < B_PIECES; ++j) {
-      const int kp = ((tid + NT * j) % PPR) * 8;
-      const bool ok = lok && lboff[j] != ULTR_OOB && k0 + kp < d.ldb;
-      const unsigned off = ok ? lboff[j] + (unsigned)k0 * 2u : ULTR_OOB;
-      sl.bhr[j] = __builtin_amdgcn_raw_buffer_load_b128(bhs, off, 0, 0);
-      sl.blr[j] = __builtin_amdgcn_raw_buffer_load_b128(bls, off, 0, 0);
-    }
-    if (lok && ++lkt == nkp) {
-      lkt = 0;
-      const int64_t un = lc.u + lc.m_units;
-      if (un < u_end) {
-        lc = chunk_at(un);
-        loader_rows();
-      } else {
-        lok = false;
-      }
-    }
-  };
-  auto store_tile = [&](const Slot& sl, int k0) {
-    _Float16* Al = Ah + BM * LDW;
-    _Float16* Bl = Bh + BN * LDW;
-#pragma unroll
-    for (int j = 0; j < A_LOADS; ++j) {
-      const int idx = tid + NT * j, row = idx / TPR;
-      const float4 v = aprod.finish(sl.arow[j], sl.acol, k0 + k4, sl.areg[j]);
-      // the largest magnitude of the row's 64 steps: the 16 threads of a row are one DPP row
-      float am = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-      am = fmaxf(am, dpp_or<0xb1>(am, am));
-      am = fmaxf(am, dpp_or<0x4e>(am, am));
-      am = fmaxf(am, dpp_or<0x141>(am, am));  // row_half_mirror
-      if constexpr (TPR == 16) am = fmaxf(am, dpp_or<0x140>(am, am));  // row_mirror
-      int se = 267 - (int)((__float_as_uint(am) >> 23) & 0xffu);  // am * 2^(se - 127) < 2^14
-      se = se < 1 ? 1 : (se > 253 ? 253 : se);
-      const float rs = __uint_as_float((unsigned)se << 23);
-      const float a4[4] = {v.x * rs, v.y * rs, v.z * rs, v.w * rs};
-      h4v hi, lo;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        hi[e] = (_Float16)a4[e];
-        lo[e] = (_Float16)(a4[e] - (float)hi[e]);
-      }
-      *reinterpret_cast<h4v*>(Ah + row * LDW + k4) = hi;
-      *reinterpret_cast<h4v*>(Al + row * LDW + k4) = lo;
-      if ((tid & (TPR - 1)) == 0) Sc[row] = __uint_as_float((unsigned)(254 - se) << 23) * (1.0f / UGEMM_H3_WSCALE);
-    }
-#pragma unroll
-    for (int j = 0; j < B_PIECES; ++j) {
-      const int idx = tid + NT * j;
-      const int n = idx / PPR, kp = (idx % PPR) * 8;
-      *reinterpret_cast<u32x4*>(Bh + n * LDW + kp) = sl.bhr[j];
-      *reinterpret_cast<u32x4*>(Bl + n * LDW + kp) = sl.blr[j];
-    }
-  };
-  f32x4 acc[RT][CT];
-  int live_rt = 0;
-  auto multiply = [&]() {
-    if (live_rt > 0) {
-      const _Float16* Ar = Ah + (wr + i) * LDW + 8 * q;
-      const _Float16* Br = Bh + (wc + i) * LDW + 8 * q;
-      f32x4 tmp[RT][CT];
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) tmp[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kk = 0; kk < BKW / 32; ++kk) {
-        h8v bh[CT], bl[CT];
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          bh[ct] = *reinterpret_cast<const h8v*>(Br + ct * 16 * LDW + 32 * kk);
-          bl[ct] = *reinterpret_cast<const h8v*>(Br + BN * LDW + ct * 16 * LDW + 32 * kk);
-        }
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          if (rt < live_rt) {
-            const h8v ah = *reinterpret_cast<const h8v*>(Ar + rt * 16 * LDW + 32 * kk);
-            const h8v al = *reinterpret_cast<const h8v*>(Ar + BM * LDW + rt * 16 * LDW + 32 * kk);
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-              tmp[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ct], tmp[rt][ct], 0, 0, 0);
-              tmp[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ct], tmp[rt][ct], 0, 0, 0);
-              tmp[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ct], tmp[rt][ct], 0, 0, 0);
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        if (rt < live_rt) {
-          const float4 sc = ld4(Sc + wr + 16 * rt + 4 * q);  // the scales of this lane's four output rows
-          const float scv[4] = {sc.x, sc.y, sc.z, sc.w};
-#pragma unroll
-          for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[rt][ct][r] = fmaf(tmp[rt][ct][r], scv[r], acc[rt][ct][r]);
-        }
-      }
-    }
-  };
-
-  Slot s0, s1;
-  load_next(s0);
-  load_next(s1);
-  Chunk cur = chunk_at(u);
-  for (;;) {
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int t = 0; t < CT; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    live_rt = (16 * cur.m_units - wr + 15) / 16;
-    live_rt = live_rt < 0 ? 0 : (live_rt > RT ? RT : live_rt);
-    for (int t = 0; t < nkp; t += 2) {
-      store_tile(s0, t * BKW);
-      load_next(s0);
-      lds_barrier();
-      multiply();
-      lds_barrier();
-      store_tile(s1, (t + 1) * BKW);
-      load_next(s1);
-      lds_barrier();
-      multiply();
-      lds_barrier();
-    }
-    // ---- the chunk's output through LDS, as gemm_h3_kernel (s0 / s1 hold the next chunk's first two tiles, in flight) ----------
-    const int64_t e_r0 = cur.r0, e_rend = cur.rend;
-    const int e_n0 = cur.n0;
-    const int64_t un = cur.u + cur.m_units;
-    const bool more = un < u_end;
-    float* Cs = smem;
-    constexpr int PIECES = BM * (BN / 4);
-    constexpr int PPT = PIECES / NT;
-    static_assert(PIECES % NT == 0, "epilogue pieces divide evenly");
-    typename Epi::Pre pre[PPT];
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-      const int idx = tid + NT * k;
-      const int row = idx / (BN / 4), c4 = (idx - row * (BN / 4)) * 4;
-      const int64_t r = e_r0 + row;
-      const int c = e_n0 + c4;
-      if (r < e_rend && c < d.N) pre[k] = epi.prefetch(r, c, d.N - c < 4 ? d.N - c : 4);
-    }
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = wr + 16 * rt + 4 * q + r;
-#pragma unroll
-        for (int t = 0; t < CT; ++t) Cs[row * LDC + wc + 16 * t + i] = acc[rt][t][r];
-      }
-    lds_barrier();
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-      const int idx = tid + NT * k;
-      const int row = idx / (BN / 4), c4 = (idx - row * (BN / 4)) * 4;
-      const int64_t r = e_r0 + row;
-      const int c = e_n0 + c4;
-      if (r < e_rend && c < d.N) {
-        const int nv = d.N - c < 4 ? d.N - c : 4;
-        epi(r, c, ld4(Cs + row * LDC + c4), nv, pre[k]);
-      }
-    }
     if (!more) break;
     lds_barrier();  // the tile in LDS has been read
     cur = chunk_at(un);
@@ -1204,71 +906,8 @@ inline hipError_t launch_h3(const Dims& d, const AProd& aprod, const _Float16* B
   return hipGetLastError();
 }
 
-template <int BM, int BN, int WM, int WN, int BKW, class AProd, class Epi>
-inline hipError_t launch_h3w(const Dims& d, const AProd& aprod, const _Float16* Bhi, const _Float16* Blo, const Epi& epi, hipStream_t st) {
-  auto kern = gemm_h3w_kernel<BM, BN, WM, WN, BKW, AProd, Epi>;
-  constexpr int NT = WM * WN * 64, LDW = BKW + 8;
-  constexpr size_t stage = (size_t)(2 * BM * LDW + 2 * BN * LDW) * sizeof(_Float16) + BM * sizeof(float);
-  constexpr size_t cbytes = (size_t)BM * (BN + 4) * sizeof(float);
-  const size_t lds = cbytes > stage ? cbytes : stage;
-  const int dev = current_device();
-  static std::atomic<bool> attr[UGEMM_MAX_DEV];
-  if (lds > 64 * 1024 && !attr[dev].load(std::memory_order_acquire)) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr[dev].store(true, std::memory_order_release);
-  }
-  static std::atomic<int> per_cu_dev[UGEMM_MAX_DEV];
-  int per_cu = per_cu_dev[dev].load(std::memory_order_relaxed);
-  if (per_cu == 0) {
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), NT, lds) != hipSuccess || nb < 1) {
-      nb = (int)((160 * 1024) / lds);
-      const int by_waves = 32 / (WM * WN);
-      if (nb > by_waves) nb = by_waves;
-      if (nb < 1) nb = 1;
-    }
-    per_cu = nb;
-    per_cu_dev[dev].store(nb, std::memory_order_relaxed);
-  }
-  const int64_t slots = (int64_t)per_cu * device_cus();
-  const int64_t nru = (d.R + 15) / 16;
-  const int ncb = (d.N + BN - 1) / BN;
-  const int64_t chunks = ((nru + BM / 16 - 1) / (BM / 16)) * ncb;
-  const int64_t grid = chunks <= slots ? chunks : slots;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, st, d, aprod, Bhi, Blo, epi);
-  return hipGetLastError();
-}
-
-// split-half mode: C = epi(A' . W^T), W as hi / lo fp16 planes [N][d.ldb halves] (ldb a multiple of 32, zero-padded; d.K = the real
-// contraction length)
-#ifndef UGEMM_H3_VARIANT
-#define UGEMM_H3_VARIANT 0
-#endif
-#ifndef UGEMM_H3_WIDE
-#define UGEMM_H3_WIDE 0
-#endif
 template <class AProd, class Epi>
 inline hipError_t run_h3(const Dims& d, const AProd& aprod, const _Float16* Bhi, const _Float16* Blo, const Epi& epi, hipStream_t st) {
-#if UGEMM_H3_VARIANT == 1  // experiments (tools/ab_build.sh): full-width chunks - every A tile split once / two row tiles per wave
-  if (d.N >= 256 && d.R >= 16384) return launch_h3<64, 256, 4, 2>(d, aprod, Bhi, Blo, epi, st);
-#elif UGEMM_H3_VARIANT == 2
-  if (d.N >= 128 && d.R >= 16384) return launch_h3<128, 128, 4, 2>(d, aprod, Bhi, Blo, epi, st);
-#elif UGEMM_H3_VARIANT == 3  // four waves of 32 x 64 per 64 x 128 chunk: twice the MFMAs per staged byte and per loop overhead of a wave
-  if (d.N > 64) return launch_h3<64, 128, 2, 2>(d, aprod, Bhi, Blo, epi, st);
-  return launch_h3<64, 64, 2, 1>(d, aprod, Bhi, Blo, epi, st);
-#elif UGEMM_H3_VARIANT == 4
-  if (d.N > 64) return launch_h3<64, 128, 2, 2>(d, aprod, Bhi, Blo, epi, st);
-#endif
-#if UGEMM_H3_WIDE == 1  // 64-deep contraction tiles on one LDS stage (gemm_h3w_kernel)
-  if (d.K >= 64) {
-    if (d.N > 64) return launch_h3w<64, 128, 4, 2, 64>(d, aprod, Bhi, Blo, epi, st);
-    return launch_h3w<64, 64, 4, 1, 64>(d, aprod, Bhi, Blo, epi, st);
-  }
-#elif UGEMM_H3_WIDE == 2  // 32-deep tiles on one LDS stage: half the LDS, twice the workgroups per CU
-  if (d.N > 64) return launch_h3w<64, 128, 4, 2, 32>(d, aprod, Bhi, Blo, epi, st);
-  return launch_h3w<64, 64, 4, 1, 32>(d, aprod, Bhi, Blo, epi, st);
-#endif
   if (d.N > 64) return launch_h3<64, 128, 4, 2>(d, aprod, Bhi, Blo, epi, st);
   return launch_h3<64, 64, 4, 1>(d, aprod, Bhi, Blo, epi, st);
 }
@@ -1280,10 +919,6 @@ inline hipError_t run_h3(const Dims& d, const AProd& aprod, const _Float16* Bhi,
 template <bool B_NMAJOR, class AProd, class Epi>
 inline hipError_t run(const Dims& d, const AProd& aprod, const float* B, const Epi& epi, hipStream_t st, hipEvent_t ev_start = nullptr,
                       hipEvent_t ev_stop = nullptr) {
-#if UGEMM_BM128
-  // experiment: 128 x 128 chunks (a wave = two 16-row tiles x 64 columns: twice the MFMAs per fragment read and per barrier)
-  if (d.N > 64 && d.R >= 16384) return launch<128, 128, 4, 2, B_NMAJOR>(d, aprod, B, epi, st, ev_start, ev_stop);
-#endif
   if (d.N > 64) return launch<64, 128, 4, 2, B_NMAJOR>(d, aprod, B, epi, st, ev_start, ev_stop);
   return launch<64, 64, 4, 1, B_NMAJOR>(d, aprod, B, epi, st, ev_start, ev_stop);
 }

@@ -10,6 +10,7 @@
 #include "../../include/ultr_hip.h"
 #include "ultr_device.h"
 #include "ultr_plan.h"
+#include "ultr_prof.h"
 
 #define NDCG_LPW 4
 #define NDCG_MAX_TOPN 16
@@ -109,8 +110,11 @@ extern "C" int ultr_ndcg(const float* scores, const float* labels, const int32_t
   const size_t lds = (size_t)NDCG_LPW * 4 * list_size * sizeof(float);
   if (lds > 64 * 1024) return ULTR_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(ndcg_list_kernel, dim3((batch + NDCG_LPW - 1) / NDCG_LPW), dim3(NDCG_LPW * 64), lds, st, scores,
-                     labels, docids, n_docs, (int)batch, (int)list_size, t, ndcg_ws, order_out, masked_out);
+  {
+    UltrProfScope prof(ULTR_K_NDCG, st);
+    ULTR_LAUNCH(prof, ndcg_list_kernel, dim3((batch + NDCG_LPW - 1) / NDCG_LPW), dim3(NDCG_LPW * 64), lds, st, scores, labels, docids,
+                n_docs, (int)batch, (int)list_size, t, ndcg_ws, order_out, masked_out);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(ndcg_mean_kernel, dim3(n_topn), dim3(64), 0, st, (const float*)ndcg_ws, (int)batch, (int)n_topn,

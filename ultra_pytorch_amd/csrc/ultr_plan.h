@@ -56,7 +56,10 @@ struct DnnPlan {
   int h3f[ULTR_MAXL], h3b[ULTR_MAXL];
   int fb_h3;              // the fused kernel takes the split-half build (h3_ok and the ULTR_FB_H3 knob)
   int bwd_h3;             // dnn_bwd2_kernel runs at least one dgrad product on them (changes the row stride of its dz tile)
-  int64_t h3_flag_off;    // one word behind the copies: ULTR_H3_FLAG_OVER | ULTR_H3_FLAG_NEAR (status ULTR_STATUS_H3_RANGE / _NEAR)
+  int64_t h3_flag_off;    // one word behind the copies (every model with a hidden layer has it): ULTR_H3_FLAG_OVER | ULTR_H3_FLAG_NEAR
+                          // over ALL hidden weights (status ULTR_STATUS_H3_RANGE / _NEAR)
+  int no_h3;              // ultr_dnn_desc::flags & ULTR_MODEL_FP32_PRODUCTS: no split-half products for this model
+  int h3_watch;           // some split-half product may read this model's weights (a ULTR_*_H3 knob is on and !no_h3): the range is reported
   int fwd_h3;             // dnn_fwd_kernel runs at least one layer on the split-half copies (changes its LDS row stride)
   int maxdim;             // max over all K_j (and M_j)
   // work map of the update kernel when it maintains the copies above: 16x16 tiles over every hidden W_j (a tile is
@@ -117,9 +120,8 @@ __host__ __device__ inline int64_t ultr_sw_index(int c, int k, int ntrips) {
 #define ULTR_H3_WMAX 32768.0f  // scaled weights must stay below this (fp16 overflows at 65504): |w| < 128, else ULTR_STATUS_H3_RANGE
 #define ULTR_H3_WNEAR 16384.0f // |w| >= 64: half of the range is used up - ULTR_STATUS_H3_NEAR, the host switches to the fp32 products
                                // while the copies are still exact (an optimizer step moves a weight by at most lr x the clip norm)
-// the flag word behind the copies (DnnPlan::h3_flag_off): bit 0 = a copy overflowed, bit 1 = a weight is near the edge
-#define ULTR_H3_FLAG_OVER 1u
-#define ULTR_H3_FLAG_NEAR 2u
+// the flag word behind the copies (DnnPlan::h3_flag_off): ULTR_H3_FLAG_OVER = a copy overflowed, ULTR_H3_FLAG_NEAR = a weight is
+// near the edge (include/ultr_hip.h)
 __host__ __device__ inline int64_t ultr_h3_index(int c, int k, int nks, int hl) {
   const int chunk = c >> 5, t = c & 1, j = (c & 31) >> 1;  // the two column tiles of a chunk interleave: column 32 chunk + 2 j + t
   const int s = k >> 5, q = (k & 31) >> 3, e = k & 7;      // (the accumulator layout the epilogues of the fp32 paths expect)
@@ -190,47 +192,16 @@ struct BwdPlan {
   int64_t lfold_off;        // [64][tail <= 4096]: first level of the loss-partial fold when there are more than 1024 partials
   int lf_chunks, lf_len;    // 0: one workgroup folds all; else lf_chunks workgroups x lf_len partials (set by the launcher)
   int64_t dgp_off;          // per-layer backward with split-half dgrad GEMMs (ultr_dnn_big.hip): the planes of W_j^T (ultr_dgp_layer)
-  int64_t wgd_part_off;     // direct weight gradients (WgdPlan): layer-0 column partials [ceil(K_0 / 32)][ceil(M_0 / 16)][96]
   int64_t sumsq_off;        // [n_red_blocks]
   int n_red_blocks;
   int64_t total;            // floats in bwd_ws
 };
 
-// Direct weight gradients (ultr_wgd.hip): small batches, where one workgroup can afford to contract ALL rows for its output tile.
-// A workgroup owns a 16 (m) x 32 (k) tile of ONE dW_j and sums over every row of the batch, so what it writes is the FINAL
-// gradient - no per-split slabs, no reduction launch (config 2: weight gradients + reduction 11.8 + 4.9 us -> one launch).
-// Consecutive block ids go round-robin to the 8 XCDs; tile (x = block % 8, t = block / 8) is laid out so that the tiles of one
-// XCD form a sub-grid of ONE layer's tile grid (every layer has its own group of gm x gk XCDs): an XCD's L2 then pulls (1 / gm)
-// of dz_j and (1 / gk) of u_j of that layer only.
-struct WgdLayer {
-  int M, K;
-  int nmt, nkt;     // tiles along m (16 wide) and k (32 wide)
-  int gm, gk;       // XCD grid: gm * gk = 8
-  int pm, pk;       // tiles per XCD along m / k (ceil)
-  int x0;           // first XCD of this layer's group (the group has gm * gk XCDs)
-  int pad_;
-  int64_t dz_off;   // dz_j in bwd_ws [N, M]
-  int64_t x_off;    // the ready-made operand in `saved` [N, K]
-  int64_t off_w, off_b;
-};
-struct WgdPlan {
-  int nl1;                 // hidden Linears
-  int tiles_per_xcd;       // max over the layers of pm * pk
-  int ntile_blocks;        // 8 * tiles_per_xcd
-  int nvec_blocks;         // ceil(vlen / 64): the per-row-block vector slabs folded into final gradients
-  int nsq_used;            // sum-of-squares slots this launch writes: tiles | layer-0 gamma / beta folds | vector folds
-  uint32_t seq;            // launch number (never repeats): the arrival flags of the layer-0 fold carry it
-  int64_t l0part_off;      // [nkt_0][nmt_0][24 pieces of (v0, v1, v2, launch number)]: per-tile column partials of d gamma_0 | d beta_0
-  WgdLayer l[ULTR_MAXL];
-};
-// library-internal, ultr_wgd.hip.  Returns ULTR_E_UNSUPPORTED when the shape does not qualify (the caller then runs the slab path).
 struct EarlyReport;
 // ultr_dnn.hip: dnn_wgrad_h3_kernel for a PLAIN product (SetRank's Linears): slabs[nsplit][M*K + M] = per-row-split partials of
 // dW[M, K] = dY[T, M]^T X[T, K] and of the column sums of dY; the caller folds them (same layout as sr_wgrad_kernel's)
 bool ultr_wgrad_h3_geometry(int64_t T, int M, int K, int* nsplit, int* rows_per_split);
 int ultr_wgrad_h3_plain(const float* dY, const float* X, int64_t T, int M, int K, float* slabs, hipStream_t st);
-int ultr_wgd_launch(const DnnPlan& p, const BwdPlan& bp, const float* params, const float* saved, float* ws, float* grads,
-                    const float* loss_part, int n_loss_part, int tail, int nsq, hipStream_t st);
 
 // Everything dnn_fb_kernel needs about layer j of BOTH loops, one 128-byte record per layer (32 ints; 64-bit offsets as lo, hi).
 // The plans travel as kernel arguments in HBM; runtime-indexed reads of them are scalar loads whose first touch of a cache

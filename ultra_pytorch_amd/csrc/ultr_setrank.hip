@@ -66,6 +66,8 @@ struct SrPlan {
   // weight matrix W[M][K] with M >= 16 the planes hi | lo of 2^8 W as [M][ldK] halves (forward: Y = X W^T) and of W^T as [K][ldM]
   // halves (dgrad: dX = dY W), ldK / ldM = K / M rounded up to 32, zero-padded.  Offsets in HALVES from sv_planes (a float offset).
   int64_t sv_planes, planes_halves;
+  int64_t sv_flag;   // float offset in `saved` of the range word behind the planes (ULTR_H3_FLAG_*: raised by sr_split_planes_kernel)
+  int no_h3;         // ultr_setrank_desc::flags & ULTR_MODEL_FP32_PRODUCTS
   struct SplitMat { int64_t off; int M, K, ldK, ldM; int64_t f_off, t_off; };
   int n_split;
   SplitMat split[32];
@@ -105,6 +107,7 @@ bool make_plan(const ultr_setrank_desc* c, int64_t T, SrPlan* p) {
   p->F = c->feature_size; p->d = c->d_model; p->H = c->num_heads; p->nl = c->num_layers; p->dff = c->dff;
   p->dh = p->d / p->H;
   p->att_f16 = (c->attention_dtype == ULTR_ATTN_FP16) ? 1 : 0;
+  p->no_h3 = (c->flags & ULTR_MODEL_FP32_PRODUCTS) ? 1 : 0;
   p->T = T;
   const int64_t F = p->F, d = p->d, dff = p->dff;
   int64_t o = 0;
@@ -148,6 +151,7 @@ bool make_plan(const ultr_setrank_desc* c, int64_t T, SrPlan* p) {
     for (int l = 0; l < p->nl; ++l) { add(p->lay[l].wd, d, d); add(p->lay[l].wf1, dff, d); add(p->lay[l].wf2, d, dff); }
     p->sv_planes = (p->sv_total + 4 + 7) & ~(int64_t)7;
     p->planes_halves = h;
+    p->sv_flag = p->sv_planes + (h + 1) / 2;  // (ultr_setrank_saved_bytes leaves four floats behind the planes)
   }
   p->maxw = (int)(F > d ? F : d);
   if (dff > p->maxw) p->maxw = (int)dff;
@@ -1325,11 +1329,11 @@ __global__ __launch_bounds__(SR_MAXT * 64) void sr_attn_bwd_f16_kernel(const flo
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Split-half attention (round 4; backward: default, forward: OPT-IN ULTR_SR_ATTN_H3=2): the fp16-operand kernels above with every operand as hi (+ mid) + lo
-// fp16 planes and every product as three (S = x x^T and the forward's P V: six) f16 MFMAs with fp32 accumulation.  Scales are powers
+// Split-half attention BACKWARD (round 4; default, ULTR_SR_ATTN_H3=0 for the fp32 matrix cores): the fp16-operand kernel above with every operand as hi + lo
+// fp16 planes and every product as three f16 MFMAs with fp32 accumulation.  Scales are powers
 // of two per (list, head) slice: x to just below 2^10, dA to just below 2^4 (dS = P (dP - t) / sqrt(dh) stays far below fp16's 65504
 // for |x| up to several hundred), probabilities by 2^12; all are removed exactly in the epilogues.
-// WHY THE FORWARD KERNEL IS NOT THE DEFAULT.  The operands are exact to 2^-33 this way, but the instruction is not an fp32 dot product: inside
+// WHY THERE IS NO SPLIT-HALF FORWARD KERNEL (one was written and measured in round 4, removed in round 5; git 9876d59 has it).  The operands are exact to 2^-33 this way, but the instruction is not an fp32 dot product: inside
 // v_mfma_f32_16x16x32_f16 the 32 products are aligned to the LARGEST of them and truncated ~25 bits below it before they are added
 // (tools/mfma_f16_accum_test.hip: 2^20 + 31 x 0.111 comes out 0.44 low, 3.5 fp32 ulps, and the result depends on where the large
 // product sits).  A dot product with one dominant term therefore carries a biased error of up to ~2^-20 of that term.  The DNN's
@@ -1339,7 +1343,7 @@ __global__ __launch_bounds__(SR_MAXT * 64) void sr_attn_bwd_f16_kernel(const flo
 // of tests/test_gpu_setrank.py (2e-5) fails.  The BACKWARD kernel has no such amplifier behind it: its P is recomputed from the same
 // truncated S, but the error enters dS, dq, dk, dv linearly and is summed over 102 400 tokens into the weight gradients - 1.8e-7 of
 // the largest gradient entry at config 5 (bar: 1e-5 relative + 2e-6 of the largest), scores bit for bit those of the fp32 forward.
-// Config 5: 3 020 -> 2 866 us with the backward kernel alone (383 -> 309 us per launch), 2 845 with both.
+// Config 5: 3 020 -> 2 866 us with the backward kernel (383 -> 309 us per launch); a forward kernel on top gave 2 845 and failed the bar above.
 // ---------------------------------------------------------------------------------------------------------
 #ifndef SRS_NO_MIX
 #define SRS_NO_MIX 1
@@ -1416,27 +1420,6 @@ __device__ __forceinline__ void srs_pack(const f32x4& a, const f32x4& b, float s
     lo[j] = (_Float16)r1;
   }
 }
-// ... as three pieces (the forward's P V product: an attention row that sits on ONE key with |x| ~ 16 carries that key's value
-// through - 2^-22 of 16 is 4e-6 on an activation, 3e-5 on a score of config 5; three pieces of P and of V are exact to fp32)
-__device__ __forceinline__ void srs_pack3(const f32x4& a, const f32x4& b, float scale, h8& hi, h8& mid, h8& lo) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float v = (j < 4 ? a[j & 3] : b[j & 3]) * scale;
-    const _Float16 h = (_Float16)v;
-    hi[j] = h;
-    float r1 = v - (float)h;
-#if SRS_NO_MIX
-    asm volatile("" : "+v"(r1));
-#endif
-    const _Float16 m = (_Float16)r1;
-    mid[j] = m;
-    float r2 = r1 - (float)m;
-#if SRS_NO_MIX
-    asm volatile("" : "+v"(r2));
-#endif
-    lo[j] = (_Float16)r2;
-  }
-}
 // NT tile over the head depth with split operands: sum_k a[k] b[k], a = row of the row-major planes, b = a held fragment
 template <int DH>
 __device__ __forceinline__ f32x4 srs_tile(const _Float16* ah_row, const _Float16* al_row, const h8 (&bh)[DH / 32], const h8 (&bl)[DH / 32]) {
@@ -1451,128 +1434,7 @@ __device__ __forceinline__ f32x4 srs_tile(const _Float16* ah_row, const _Float16
   return acc;
 }
 
-// the same with three pieces per operand (a = ah + am + al): every partial product down to 2^-22 of the largest
-template <int DH>
-__device__ __forceinline__ f32x4 srs_tile6(const _Float16* ah_row, const _Float16* am_row, const _Float16* al_row, const h8 (&bh)[DH / 32],
-                                           const h8 (&bm)[DH / 32], const h8 (&bl)[DH / 32]) {
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int f = 0; f < DH / 32; ++f) {
-    const h8 ah = *reinterpret_cast<const h8*>(ah_row + 32 * f), am = *reinterpret_cast<const h8*>(am_row + 32 * f),
-             al = *reinterpret_cast<const h8*>(al_row + 32 * f);
-    acc = mfma_h(ah, bl[f], acc);
-    acc = mfma_h(am, bm[f], acc);
-    acc = mfma_h(al, bh[f], acc);
-    acc = mfma_h(ah, bm[f], acc);
-    acc = mfma_h(am, bh[f], acc);
-    acc = mfma_h(ah, bh[f], acc);
-  }
-  return acc;
-}
 
-template <int DH>
-__global__ __launch_bounds__(SR_MAXT * 64) void sr_attn_fwd_h3_kernel(const float* __restrict__ x, int L, int d,
-                                                                     float* __restrict__ A, float* __restrict__ lse) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int LDH = DH + 8, NC = DH / 16, NF = DH / 32;
-  const int Lp = round_up(L, 16), NTL = Lp / 16, lt = 16 * NTL + 24;
-  _Float16* xh = reinterpret_cast<_Float16*>(smem);  // [Lp][LDH]
-  _Float16* xl = xh + Lp * LDH;
-  _Float16* x3 = xl + Lp * LDH;
-  _Float16* th = x3 + Lp * LDH;                      // [DH][lt]
-  _Float16* tl = th + DH * lt;
-  _Float16* t3 = tl + DH * lt;
-  float* red = reinterpret_cast<float*>(t3 + DH * lt);  // [SR_MAXT]
-  const int b = blockIdx.x, h = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
-  const int nthr = NTL * 64;
-  const int64_t base = (int64_t)b * L * d + h * DH;
-  for (int e = tid; e < 3 * DH * (lt / 8); e += nthr) {  // zero the transposed planes (padding columns are read)
-    const h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-    *reinterpret_cast<h8*>(th + e * 8) = z;
-  }
-  float4 xv[DH / 16];
-  float am = 0.f;
-  srs_load<DH>(x, base, L, d, tid, nthr, xv, am);
-  am = wave_max(am);
-  if (lane == 0) red[wave] = am;
-  __syncthreads();
-  am = 0.f;
-  for (int w = 0; w < NTL; ++w) am = fmaxf(am, red[w]);
-  const float sx = srs_pow2_scale(am, 10), isx = 1.0f / sx;
-  srs_store<DH>(xv, sx, tid, nthr, xh, xl, th, tl, lt, x3, t3);
-  __syncthreads();
-  const float scale = 1.0f / sqrtf((float)DH);
-  h8 bqh[NF], bql[NF], bq3[NF];  // this wave's query block: lane (i, q) holds x'[query i][32 f + 8 q .. + 7]
-#pragma unroll
-  for (int f = 0; f < NF; ++f) {
-    bqh[f] = *reinterpret_cast<const h8*>(xh + (wave * 16 + i) * LDH + 32 * f + 8 * q);
-    bql[f] = *reinterpret_cast<const h8*>(xl + (wave * 16 + i) * LDH + 32 * f + 8 * q);
-    bq3[f] = *reinterpret_cast<const h8*>(x3 + (wave * 16 + i) * LDH + 32 * f + 8 * q);
-  }
-  f32x4 pr[SR_MAXT + 1];
-  float mx = -INFINITY;
-#pragma unroll
-  for (int t = 0; t <= SR_MAXT; ++t) pr[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int t = 0; t < SR_MAXT; ++t) {
-    if (t < NTL) {
-      pr[t] = srs_tile6<DH>(xh + (t * 16 + i) * LDH + 8 * q, xl + (t * 16 + i) * LDH + 8 * q, x3 + (t * 16 + i) * LDH + 8 * q, bqh, bql, bq3);  // sx^2 S
-#pragma unroll
-      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, pr[t][r]);
-    }
-  }
-  mx = quad_max(mx);
-  const float sc2 = (scale * isx) * isx;  // logits = sc2 * (sx^2 S)
-  const float c1 = sc2 * 1.44269504088896341f, mx2 = mx * c1;
-  float sum = 0.f;
-#pragma unroll
-  for (int t = 0; t < SR_MAXT; ++t) {
-    if (t < NTL) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) pr[t][r] = __builtin_amdgcn_exp2f(fmaf(pr[t][r], c1, -mx2));
-      if (t == NTL - 1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) pr[t][r] = (t * 16 + 4 * q + r < L) ? pr[t][r] : 0.f;
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sum += pr[t][r];
-    }
-  }
-  sum = quad_sum(sum);
-  const float inv = 1.0f / sum;
-  if (lse != nullptr && q == 0 && wave * 16 + i < L) lse[((int64_t)b * L + wave * 16 + i) * gridDim.y + h] = mx * sc2 + logf(sum);
-  f32x4 o[NC];
-#pragma unroll
-  for (int c = 0; c < NC; ++c) o[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const float pscale = inv * 4096.0f;
-#pragma unroll
-  for (int t = 0; t < SR_MAXT; t += 2) {
-    if (t < NTL) {
-      h8 pah, pam, pal;
-      srs_pack3(pr[t], pr[t + 1], pscale, pah, pam, pal);
-#pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        const h8 vh = srs_pair_b(th, lt, 16 * c + i, t, q), vm = srs_pair_b(tl, lt, 16 * c + i, t, q), vl = srs_pair_b(t3, lt, 16 * c + i, t, q);
-        o[c] = mfma_h(pah, vl, o[c]);
-        o[c] = mfma_h(pam, vm, o[c]);
-        o[c] = mfma_h(pal, vh, o[c]);
-        o[c] = mfma_h(pah, vm, o[c]);
-        o[c] = mfma_h(pam, vh, o[c]);
-        o[c] = mfma_h(pah, vh, o[c]);
-      }
-    }
-  }
-  const float oscale = isx * (1.0f / 4096.0f);
-#pragma unroll
-  for (int c = 0; c < NC; ++c) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = wave * 16 + 4 * q + r;
-      if (row < L) A[base + (int64_t)row * d + c * 16 + i] = o[c][r] * oscale;
-    }
-  }
-}
 
 template <int DH>
 __global__ __launch_bounds__(SR_MAXT * 64) void sr_attn_bwd_h3_kernel(const float* __restrict__ x, const float* __restrict__ dA,
@@ -1938,7 +1800,8 @@ struct SrSplitTable {
   SrPlan::SplitMat m[32];
 };
 // blockIdx.y = 2 * matrix + phase (0: the forward planes [M][ldK], 1: the transposed planes [K][ldM]); one element per thread
-__global__ __launch_bounds__(256) void sr_split_planes_kernel(SrSplitTable tb, const float* __restrict__ params, _Float16* __restrict__ planes) {
+__global__ __launch_bounds__(256) void sr_split_planes_kernel(SrSplitTable tb, const float* __restrict__ params, _Float16* __restrict__ planes,
+                                                              uint32_t* __restrict__ range_flag) {
   const SrPlan::SplitMat m = tb.m[blockIdx.y >> 1];
   const int phase = blockIdx.y & 1;
   const int rows = phase ? m.K : m.M, ld = phase ? m.ldM : m.ldK, cols = phase ? m.M : m.K;
@@ -1947,7 +1810,10 @@ __global__ __launch_bounds__(256) void sr_split_planes_kernel(SrSplitTable tb, c
   const int r = (int)(e / ld), c = (int)(e - (int64_t)r * ld);
   float w = 0.f;
   if (c < cols) w = params[m.off + (phase ? ((int64_t)c * m.K + r) : ((int64_t)r * m.K + c))] * UGEMM_H3_WSCALE;
-  const _Float16 hi = (_Float16)w, lo = (_Float16)(w - (float)hi);  // |w| >= 128 overflows to inf: NaN results, loud
+  // |w| >= 64 raises ULTR_H3_FLAG_NEAR, >= 128 (or NaN: the planes overflow) ULTR_H3_FLAG_OVER - the step's update launch reports the word
+  // (ultr_update_desc::range_flag) and the engine switches this model to the fp32 products
+  if (!(fabsf(w) < 16384.0f)) flag_or(range_flag, !(fabsf(w) < 32768.0f) ? (ULTR_H3_FLAG_OVER | ULTR_H3_FLAG_NEAR) : ULTR_H3_FLAG_NEAR);
+  const _Float16 hi = (_Float16)w, lo = (_Float16)(w - (float)hi);
   _Float16* dst = planes + (phase ? m.t_off : m.f_off);
   dst[e] = hi;
   dst[(int64_t)rows * ld + e] = lo;
@@ -1965,7 +1831,7 @@ void sr_knobs_load() {
   if (g_sr_knob_h3 >= 0) return;
   const char* e = getenv("ULTR_SR_H3");
   g_sr_knob_h3 = (e && *e) ? atoi(e) : 1;
-  e = getenv("ULTR_SR_ATTN_H3");  // 0: fp32 matrix cores; 1 (default): split-half BACKWARD kernel; 2: split-half forward too (opt-in)
+  e = getenv("ULTR_SR_ATTN_H3");  // 0: fp32 matrix cores; 1 (default): split-half BACKWARD kernel (the forward always runs on the fp32 matrix cores)
   g_sr_knob_attn_h3 = (e && *e) ? atoi(e) : 1;
   e = getenv("ULTR_SR_ATTN_H3_MASK");  // debug: bit (2 layer + dir), dir 0 forward / 1 backward
   g_sr_knob_attn_mask = (e && *e) ? atoi(e) : -1;
@@ -2076,7 +1942,7 @@ int wgrad(const SrPlan& p, const float* dY, const float* X, float* dW, float* db
     // square-ish products (d x d: 66 % matrix-core occupancy on the fp32 instruction) take the DNN's split-half weight-gradient
     // kernel: same slab layout, so the fold below is the same.  The thin ones (dff = 64 wide) run at their HBM floor already.
     int S2 = 0, rps2 = 0;
-    if (sr_h3_enabled() && g_sr_knob_wg_h3 != 0 && M >= 128 && K >= 128 && ultr_wgrad_h3_geometry(T, M, K, &S2, &rps2) &&
+    if (sr_h3_enabled() && !p.no_h3 && g_sr_knob_wg_h3 != 0 && M >= 128 && K >= 128 && ultr_wgrad_h3_geometry(T, M, K, &S2, &rps2) &&
         (int64_t)S2 * ((int64_t)M * K + M) <= p.wg_floats) {
       float* part2 = part_scratch(ws + p.ws_wg, (int64_t)S2 * ((int64_t)M * K + M));
       const int rc = ultr_wgrad_h3_plain(dY, X, T, M, K, part2, st);
@@ -2194,36 +2060,25 @@ int attn_bwd_f16(const SrPlan& p, const float* x, const float* dA, const float* 
   }
   return 0;
 }
-// split-half kernels for fp32 attention at head depth 32 / 64, list_size <= 128: the BACKWARD kernel by default (ULTR_SR_ATTN_H3=1: the
-// forward and therefore every score stays on the fp32 matrix cores bit for bit; gradients move by 1.8e-7 of the largest entry at config 5),
-// the forward kernel only as an opt-in (=2) - see the kernels' header for why; =0: fp32 matrix cores everywhere
+// split-half BACKWARD kernel for fp32 attention at head depth 32 / 64, list_size <= 128 (ULTR_SR_ATTN_H3=1, default: the forward and
+// therefore every score stays on the fp32 matrix cores bit for bit; gradients move by 1.8e-7 of the largest entry at config 5); =0: fp32
+// matrix cores everywhere.  LDS of a launch = four hi / lo plane pairs of the (list, head) slice + the per-wave dS scratch:
+size_t attn_bwd_h3_lds(const SrPlan& p, int L) {
+  const int Lp = round_up(L, 16), lt = Lp + 24;
+  return ((size_t)4 * Lp * (p.dh + 8) + (size_t)4 * p.dh * lt) * sizeof(_Float16) + ((size_t)2 * 16 * (SR_MAXT + 1) + 2 * SR_MAXT) * sizeof(float);
+}
 bool attn_h3_ok(const SrPlan& p, int L, int layer = 0, int dir = 0) {
   sr_knobs_load();
-  const bool want = dir == 1 ? g_sr_knob_attn_h3 >= 1 : g_sr_knob_attn_h3 >= 2;
-  // the planes of a slice must leave room for two workgroups per CU (head depth 64 at list sizes > ~50 does not: fp32 matrix cores there)
-  const int Lp = round_up(L, 16), lt = Lp + 24;
-  const size_t lds = ((size_t)(dir == 1 ? 4 : 3) * Lp * (p.dh + 8) + (size_t)(dir == 1 ? 4 : 3) * p.dh * lt) * sizeof(_Float16) + 1400;
-  if (lds > 82 * 1024) return false;
-  return want && ((g_sr_knob_attn_mask >> (2 * layer + dir)) & 1) && !p.att_f16 && attn_mfma_ok(p, L) && (p.dh == 32 || p.dh == 64);
-}
-int attn_fwd_h3(const SrPlan& p, const float* x, int batch, int L, float* A, float* lse, hipStream_t st) {
-  const int Lp = round_up(L, 16), lt = Lp + 24;
-  const size_t lds = ((size_t)3 * Lp * (p.dh + 8) + (size_t)3 * p.dh * lt) * sizeof(_Float16) + (size_t)SR_MAXT * sizeof(float);
-  const dim3 grid(batch, p.H), block(Lp * 4);
-  if (p.dh == 32) {
-    SR_CHECK(set_dyn_lds(sr_attn_fwd_h3_kernel<32>, lds));
-    hipLaunchKernelGGL(sr_attn_fwd_h3_kernel<32>, grid, block, lds, st, x, L, p.d, A, lse);
-  } else {
-    SR_CHECK(set_dyn_lds(sr_attn_fwd_h3_kernel<64>, lds));
-    hipLaunchKernelGGL(sr_attn_fwd_h3_kernel<64>, grid, block, lds, st, x, L, p.d, A, lse);
-  }
-  return 0;
+  if (dir != 1 || g_sr_knob_attn_h3 < 1) return false;
+  // measured rule (round 4): the kernel wins while its launch fits 100 KB (config 5: 88 KB = one workgroup of 7 waves per CU, 289 us
+  // against 383 on the fp32 matrix cores); head depth 64 at list sizes > ~50 needs more and loses to the fp32 kernel's two per CU
+  if (attn_bwd_h3_lds(p, L) > 100 * 1024) return false;
+  return ((g_sr_knob_attn_mask >> (2 * layer + dir)) & 1) && !p.att_f16 && attn_mfma_ok(p, L) && (p.dh == 32 || p.dh == 64);
 }
 int attn_bwd_h3(const SrPlan& p, const float* x, const float* dA, const float* Aout, const float* lse, int batch, int L, float* dx,
                 hipStream_t st) {
-  const int Lp = round_up(L, 16), lt = Lp + 24;
-  const size_t lds = ((size_t)4 * Lp * (p.dh + 8) + (size_t)4 * p.dh * lt) * sizeof(_Float16) +
-                     ((size_t)2 * 16 * (SR_MAXT + 1) + 2 * SR_MAXT) * sizeof(float);
+  const int Lp = round_up(L, 16);
+  const size_t lds = attn_bwd_h3_lds(p, L);
   const dim3 grid(batch, p.H), block(Lp * 4);
   if (p.dh == 32) {
     SR_CHECK(set_dyn_lds(sr_attn_bwd_h3_kernel<32>, lds));
@@ -2299,6 +2154,10 @@ extern "C" int64_t ultr_setrank_saved_bytes(const ultr_setrank_desc* c, int64_t 
   SrPlan p;
   return (n_rows >= 0 && make_plan(c, n_rows, &p)) ? (p.sv_planes + (p.planes_halves + 1) / 2 + 4) * (int64_t)sizeof(float) : 0;
 }
+extern "C" int64_t ultr_setrank_range_flag_offset(const ultr_setrank_desc* c, int64_t n_rows) {
+  SrPlan p;
+  return (n_rows >= 0 && make_plan(c, n_rows, &p)) ? p.sv_flag : -1;
+}
 extern "C" int64_t ultr_setrank_workspace_bytes(const ultr_setrank_desc* c, int64_t n_rows) {
   SrPlan p;
   return (n_rows >= 0 && make_plan(c, n_rows, &p)) ? (p.ws_total + 4) * (int64_t)sizeof(float) : 0;
@@ -2323,7 +2182,8 @@ extern "C" int ultr_setrank_forward(const ultr_setrank_desc* c, const float* par
   struct H3Scope {
     ~H3Scope() { g_sr_h3 = {nullptr, nullptr, nullptr}; }
   } h3scope;
-  if (sr_h3_enabled()) {
+  SR_CHECK((int)hipMemsetAsync(sv + p.sv_flag, 0, sizeof(uint32_t), st));  // this step's range word
+  if (sr_h3_enabled() && !p.no_h3) {
     _Float16* planes = reinterpret_cast<_Float16*>(sv + p.sv_planes);
     SrSplitTable tb;
     tb.n = p.n_split;
@@ -2334,7 +2194,8 @@ extern "C" int ultr_setrank_forward(const ultr_setrank_desc* c, const float* par
       maxe = a > maxe ? a : maxe;
       maxe = b > maxe ? b : maxe;
     }
-    hipLaunchKernelGGL(sr_split_planes_kernel, dim3((unsigned)((maxe + 255) / 256), (unsigned)(2 * p.n_split)), dim3(256), 0, st, tb, params, planes);
+    hipLaunchKernelGGL(sr_split_planes_kernel, dim3((unsigned)((maxe + 255) / 256), (unsigned)(2 * p.n_split)), dim3(256), 0, st, tb, params, planes,
+                       reinterpret_cast<uint32_t*>(sv + p.sv_flag));
     g_sr_h3 = {params, planes, &p};
   }
   // input LayerNorm on the gathered rows, then the embedding FFN (SetRank.py:134-135, 146)
@@ -2358,7 +2219,6 @@ extern "C" int ultr_setrank_forward(const ultr_setrank_desc* c, const float* par
     const SrLayer& y = p.lay[l];
     const float* x = sv + p.sv_x[l];
     if (attn_f16_ok(p, L)) SR_CHECK(attn_fwd_f16(p, x, batch, L, sv + p.sv_A[l], sv + p.sv_lse[l], st));
-    else if (attn_h3_ok(p, L, l, 0)) SR_CHECK(attn_fwd_h3(p, x, batch, L, sv + p.sv_A[l], sv + p.sv_lse[l], st));
     else if (mfma_att) SR_CHECK(attn_fwd_mfma(p, x, batch, L, sv + p.sv_A[l], sv + p.sv_lse[l], st));
     else hipLaunchKernelGGL(sr_attn_fwd_kernel, dim3(batch, p.H), dim3(256), lds_att, st, x, L, d, p.dh, sv + p.sv_A[l]);
     // A Wd^T lands in out1's buffer, then out1 = LN1(x + (A Wd^T + bd)) in place (s1 keeps the pre-norm sum)
@@ -2417,7 +2277,7 @@ extern "C" int ultr_setrank_backward(const ultr_setrank_desc* c, const float* pa
   struct H3Scope {
     ~H3Scope() { g_sr_h3 = {nullptr, nullptr, nullptr}; }
   } h3scope;
-  if (sr_h3_enabled()) g_sr_h3 = {params, reinterpret_cast<const _Float16*>(sv + p.sv_planes), &p};  // built by this step's forward
+  if (sr_h3_enabled() && !p.no_h3) g_sr_h3 = {params, reinterpret_cast<const _Float16*>(sv + p.sv_planes), &p};  // built by this step's forward
   // ---- output FFN:  s = oh wo2^T + bo2,  oh = relu(x_nl Wo1^T + bo1) ----------------------------------------------
   FoldScope folds(ws + p.ws_arena, p.arena_floats);  // every fold below is queued; ONE launch at the end
   if (dff <= 256 && p.bo2 == p.wo2 + dff) {  // one pass: G1 = d oh [T, dff] (ReLU mask fused), d wo2 | d bo2 partials

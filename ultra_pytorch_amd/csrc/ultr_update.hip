@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void update_kernel(ultr_update_desc u, DnnPlan
   for (int k = threadIdx.x; k < nsq; k += 256) ss += sumsq_part[k];
   ss = block_sum256(ss, sm);
   float pn[1];
-  update_body<1>(u, dp, params, state, grads + P, aux, ss, ea, g_raw, p_old, s_old, pn, sm, scalars_out, l2_sums);
+  update_body<1>(u, dp, params, state, grads + P, aux, ss, ea, g_raw, p_old, s_old, pn, sm, scalars_out, l2_sums, u.range_flag);
 }
 
 // Variant that keeps the k-major weight copy and the vector-parameter image current (DnnPlan::wt_*).  Workgroups
@@ -330,10 +330,21 @@ __global__ __launch_bounds__(256) void update_tiled_kernel(ultr_update_desc u, D
     update_body<TPW>(u, dp, params, state, grads + P, aux, ss, ea, g_raw, p_old, s_old, pn, sm, nullptr, l2_sums);
   } else {
     update_body<TPW>(u, dp, params, state, grads + P, aux, ss, ea, g_raw, p_old, s_old, pn, sm, scalars_out, l2_sums,
-                     // (only a step that READS the copies reports: with all three knobs off a large weight is harmless)
-                     (dp.h3_flag_off > 0 && (dp.fb_h3 | dp.fwd_h3 | dp.bwd_h3)) ? reinterpret_cast<const uint32_t*>(wt + dp.h3_flag_off) : nullptr);
+                     // (only a model whose weights some split-half product may READ reports: with the knobs off, or for a model
+                     // switched to the fp32 products, a large weight is harmless)
+                     (dp.h3_flag_off > 0 && dp.h3_watch) ? reinterpret_cast<const uint32_t*>(wt + dp.h3_flag_off) : u.range_flag);
   }
   if (is_tile) {
+    // range of EVERY hidden weight (not only of the layers with fragment copies: the per-layer big-batch path builds split-half planes
+    // of any hidden layer): |w| >= 64 raises NEAR, >= 128 (or NaN) OVER - reported with the next step
+    if (dp.h3_flag_off > 0) {
+#pragma unroll
+      for (int q = 0; q < TPW; ++q) {
+        const float aw = fabsf(pn[q]) * ULTR_H3_WSCALE;
+        if (ea[q] >= 0 && !(aw < ULTR_H3_WNEAR))
+          flag_or(reinterpret_cast<uint32_t*>(wt + dp.h3_flag_off), !(aw < ULTR_H3_WMAX) ? (ULTR_H3_FLAG_OVER | ULTR_H3_FLAG_NEAR) : ULTR_H3_FLAG_NEAR);
+      }
+    }
 #pragma unroll
     for (int q = 0; q < TPW; ++q) tile[q][r][c] = pn[q];
     __syncthreads();
@@ -356,16 +367,12 @@ __global__ __launch_bounds__(256) void update_tiled_kernel(ultr_update_desc u, D
           const int col = 2 * jj + tt;  // output column inside the tile
           typedef _Float16 h8v __attribute__((ext_vector_type(8)));
           h8v piece;
-          float wmax = 0.f;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const float w = (fwd ? tile[q][col][8 * qq + e] : tile[q][8 * qq + e][col]) * ULTR_H3_WSCALE;
             const _Float16 hi = (_Float16)w;
             piece[e] = hl ? (_Float16)(w - (float)hi) : hi;
-            wmax = fmaxf(wmax, !(fabsf(w) < ULTR_H3_WMAX) ? ULTR_H3_WMAX : fabsf(w));  // (NaN counts as out of range)
           }
-          if (wmax >= ULTR_H3_WNEAR)
-            flag_or(reinterpret_cast<uint32_t*>(wt + dp.h3_flag_off), wmax >= ULTR_H3_WMAX ? (ULTR_H3_FLAG_OVER | ULTR_H3_FLAG_NEAR) : ULTR_H3_FLAG_NEAR);
           const int64_t pos = ((((int64_t)(c0 >> 5) * nks + (z0 >> 5)) * 4 + (2 * tt + hl)) * 64 +
                                ((((z0 & 31) >> 3) + qq) * 16 + ((c0 & 31) >> 1) + jj)) * 8;
           _Float16* dst = reinterpret_cast<_Float16*>(wt + (fwd ? dp.whf_off[j] : dp.whb_off[j]));

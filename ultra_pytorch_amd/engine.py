@@ -99,6 +99,7 @@ class StepEngine:
         u.regulation_p = float(regulation_p)
         u.l2_loss = float(l2_loss)
         u.guard = None
+        u.range_flag = None
         u.host_scalars = self._hs.data_ptr() if self._host_report else None
         u.seq = 0
         self.udesc = u
@@ -190,13 +191,13 @@ class StepEngine:
             # still exact and one optimizer step moves a weight by at most lr x the clip norm - switch to the fp32 products now
             # and go on, as the reference would (base_algorithm.py:208-226 trains any weight magnitude).  Beyond, with the
             # split-half products still on: some step already read an overflowed copy.
-            switched = hip_ops.fall_back_to_fp32_products(self.shape.lib, "a hidden weight reached |w| >= 64 during training (the "
+            switched = hip_ops.fall_back_to_fp32_products(self.shape, "a hidden weight reached |w| >= 64 during training (the "
                                                           "split-half weight copies cover |w| < 128)")
             if (st & self.H3_RANGE) and switched:
                 raise _lib.UltrHipError("a hidden weight jumped to |w| >= 128 within the steps between two reads of the step report, "
                                         "outside the range of the split-half (fp16 hi / lo) weight copies (ULTR_STATUS_H3_RANGE): the "
-                                        "last steps are not to be trusted - restart from the last checkpoint (the fp32 matrix-core "
-                                        "products are selected now: ULTR_FB_H3=0 ULTR_FWD_H3=0 ULTR_BWD_H3=0)")
+                                        "last steps are not to be trusted - restart from the last checkpoint (this model is on the fp32 "
+                                        "matrix-core products now: ULTR_MODEL_FP32_PRODUCTS)")
             st &= ~(self.H3_RANGE | self.H3_NEAR)
             if st == 0:
                 return
@@ -315,6 +316,8 @@ class SetRankStepEngine(StepEngine):
         self.sr_ws = _f32(shape.workspace_bytes(self.N) // 4, device)
         # sum-of-squares partials of ultr_grad_sumsq / ultr_apply_update
         self.bwd_ws = _f32((self.P + self.tail + 63) // 64 + self.P // 4096 + 16, device)
+        self._flag_off = shape.range_flag_offset(self.N)
+        self.saved[self._flag_off].zero_()  # (every forward zeroes it again: this is for a report before the first forward)
 
     def forward(self, params, features, n_docs, docids, scores=None, train=False):
         scores = self.scores if scores is None else scores
@@ -332,6 +335,8 @@ class SetRankStepEngine(StepEngine):
 
     def update(self, params, state, aux=None):
         check = _lib.check
+        # the range word of this step's split-half planes (raised by ultr_setrank_forward) travels in the step report
+        self.udesc.range_flag = self.saved.data_ptr() + 4 * self._flag_off
         check(self.shape.lib.ultr_apply_update(ctypes.byref(self.udesc), None, ctypes.c_void_p(params.data_ptr()), None,
                                                ctypes.c_void_p(state.data_ptr()) if state is not None else None,
                                                ctypes.c_void_p(self.grads.data_ptr()),
@@ -355,10 +360,17 @@ class SetRankEvalEngine(EvalEngine):
     def __init__(self, shape, batch, list_size, device, topn=(1, 3, 5, 10)):
         super().__init__(shape, batch, list_size, device, topn=topn)
         self.saved = _f32(shape.saved_bytes(self.B * self.L) // 4, device)
+        self._flag = self.saved[shape.range_flag_offset(self.B * self.L):][:1].view(torch.int32)
 
     def run(self, params, features, n_docs, docids, labels):
         _setrank_draw(self.L)
         hip_ops.setrank_forward(self.shape, params, features, n_docs, docids, self.B, self.L, self.scores, self.saved)
+        # the split-half planes of a loaded checkpoint may be out of range (|w| >= 64 / 128): the forward raised the word - look
+        # (validation reads its metrics on the host anyway), switch this model to the fp32 products and score again
+        if hip_ops.split_half_enabled(self.shape) and int(self._flag.item()) != 0:
+            hip_ops.fall_back_to_fp32_products(self.shape, "a SetRank weight of magnitude >= 64 was loaded (the split-half weight planes "
+                                                           "cover |w| < 128)")
+            hip_ops.setrank_forward(self.shape, params, features, n_docs, docids, self.B, self.L, self.scores, self.saved)
         hip_ops.ndcg(self.scores, labels, docids, n_docs, self.B, self.L, self.topn, self.ndcg, self.ndcg_ws,
                      order_out=self.order, masked_out=self.masked)
         return self.scores, self.ndcg

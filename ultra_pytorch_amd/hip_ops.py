@@ -117,6 +117,10 @@ class SetRankShape:
     def workspace_bytes(self, n_rows):
         return int(self.lib.ultr_setrank_workspace_bytes(ctypes.byref(self.desc), n_rows))
 
+    def range_flag_offset(self, n_rows):
+        """Float offset in `saved` of the range word of the split-half planes (ultr_update_desc::range_flag)."""
+        return int(self.lib.ultr_setrank_range_flag_offset(ctypes.byref(self.desc), n_rows))
+
 
 def setrank_forward(shape, params, features, n_docs, docids, B, L, scores, saved):
     check(shape.lib.ultr_setrank_forward(ctypes.byref(shape.desc), _p(params), _p(features), int(n_docs), _p(docids), int(B),
@@ -142,23 +146,46 @@ def loss_part_count(B):
 
 
 H3_KNOBS = ("ULTR_FB_H3", "ULTR_FWD_H3", "ULTR_BWD_H3")
+SR_H3_KNOBS = ("ULTR_SR_H3",)
 
 
-def split_half_enabled():
-    return any(os.environ.get(k, "1") != "0" for k in H3_KNOBS)
+def knob_on(name, default=1):
+    """An integer knob as the LIBRARY reads it (csrc: atoi of the environment string - 'false' or 'off' parse as 0 there, so they
+    do here; an unset or empty variable is the default)."""
+    v = os.environ.get(name, "")
+    if v == "":
+        return default != 0
+    v = v.strip()
+    sign = -1 if v.startswith("-") else 1
+    digits = ""
+    for ch in v.lstrip("+-"):
+        if not ch.isdigit():
+            break
+        digits += ch
+    return (sign * int(digits) if digits else 0) != 0
 
 
-def fall_back_to_fp32_products(lib, why):
-    """Switch the wide layers' products from the split-half (fp16 hi / lo) copies to the fp32 matrix-core path for the rest of the
-    process (the knobs are process-wide) and say so once.  The reference computes in fp32 at any weight magnitude
-    (DNN.py:58-88, base_algorithm.py:208-226); the copies cover |w| < 128 only."""
-    if not split_half_enabled():
+def split_half_enabled(shape=None):
+    """Does any split-half (fp16 hi / lo) product read THIS model's weights?  Process-wide knobs AND the model's own switch
+    (ultr_dnn_desc / ultr_setrank_desc ::flags)."""
+    if shape is not None and (int(shape.desc.flags) & _lib.MODEL_FP32_PRODUCTS):
         return False
-    for k in H3_KNOBS:
-        os.environ[k] = "0"
-    lib.ultr_config_reload()
-    warnings.warn("ultra_pytorch_amd: %s - the products of wide layers now run on the fp32 matrix cores (ULTR_FB_H3=0 ULTR_FWD_H3=0 "
-                  "ULTR_BWD_H3=0): same results to the 1e-5 parity bar, ~6 %% slower steps" % why, RuntimeWarning, stacklevel=3)
+    knobs = SR_H3_KNOBS if isinstance(shape, SetRankShape) else H3_KNOBS
+    return any(knob_on(k) for k in knobs)
+
+
+def fall_back_to_fp32_products(shape, why):
+    """Switch THIS model's products from the split-half (fp16 hi / lo) weight copies to the fp32 matrix cores - a flag in the
+    model's descriptor (ULTR_MODEL_FP32_PRODUCTS), read by every later call that takes the descriptor; other models of the
+    process keep their plan and nothing is written to the environment.  The reference computes in fp32 at any weight
+    magnitude (DNN.py:58-88, base_algorithm.py:208-226); the copies cover |w| < 128 only.  In a data-parallel run the replicas
+    are bit-identical and read their step reports in lockstep, so every rank switches at the same step.  Returns True when
+    the model was on the split-half plan until now."""
+    if not split_half_enabled(shape):
+        return False
+    shape.desc.flags = int(shape.desc.flags) | _lib.MODEL_FP32_PRODUCTS
+    warnings.warn("ultra_pytorch_amd: %s - the products of this model now run on the fp32 matrix cores (ULTR_MODEL_FP32_PRODUCTS): "
+                  "same results to the 1e-5 parity bar, a few per cent slower steps" % why, RuntimeWarning, stacklevel=3)
     return True
 
 
@@ -201,12 +228,12 @@ class WeightCopy:
             # parameters that arrived from outside (checkpoint, init, a test) may be out of the split-half copies' range: look
             # once (a stream synchronisation - this branch runs after external writes only) and switch to the fp32 products
             # BEFORE a kernel reads the copies; training drift is caught by the step report instead (engine.StepEngine)
-            if split_half_enabled():
+            if split_half_enabled(self.shape):
                 rng = int(self.shape.lib.ultr_dnn_wt_range(ctypes.byref(self.shape.desc), _p(self.wt), _stream()))
                 if rng < 0:
                     check(rng, "ultr_dnn_wt_range")
                 if rng > 0:
-                    fall_back_to_fp32_products(self.shape.lib, "a hidden weight of magnitude >= 64 was loaded (the split-half weight "
+                    fall_back_to_fp32_products(self.shape, "a hidden weight of magnitude >= 64 was loaded (the split-half weight "
                                                "copies cover |w| < 128)")
         elif self.check:
             self._verify(params)
