@@ -968,7 +968,7 @@ def main():
 
         def e2e_step(i):
             _lib.check(lib.ultr_click_batch(vp(rlists), vp(rlab), nq, L, nq * L, vp(exam), int(exam.numel()), vp(cprob),
-                                            int(cprob.numel()), 1234, i, B, L, 100, vp(dids), vp(dclk), None,
+                                            int(cprob.numel()), 0, 1234, i, B, L, 100, vp(dids), vp(dclk), None,
                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ultr_click_batch")
             return eng.train_step(params, state, rfeat, nq * L, dids, dclk, ipw_table=ipw)
 

@@ -346,11 +346,16 @@ int ultr_ndcg(const float* scores, const float* labels, const int32_t* docids, i
  * (exam_prob[min(l, n_exam-1)] * click_prob[min(label, n_rel-1)]), redraws lists without a click (up to
  * max_tries), and writes docids [L, B] (global doc ids, PAD = n_docs) + clicks [L, B] ready for ultr_train_step
  * with features = the resident matrix.  query_idx (may be NULL) [B] = the sampled queries.  Counter-based RNG:
- * the batch is a pure function of (seed, step).  Parity with the Python feed is distributional. */
+ * the batch is a pure function of (seed, step).  Parity with the Python feed is distributional.
+ * ABI 6: click_model = ULTR_CLICK_PBM (click_models.py:68-110) or ULTR_CLICK_CASCADE (:187-236: the same draw per position, every
+ * position behind the first click reports no click).  A changing bias severity (dynamic_bias_eta_change, click_simulation_feed.py:
+ * 165-172) is the caller's new exam_prob table. */
+#define ULTR_CLICK_PBM 0
+#define ULTR_CLICK_CASCADE 1
 int ultr_click_batch(const int32_t* lists, const float* labels, int64_t n_queries, int32_t lmax, int64_t n_docs,
-                     const float* exam_prob, int32_t n_exam, const float* click_prob, int32_t n_rel, uint64_t seed,
-                     uint64_t step, int32_t batch, int32_t list_size, int32_t max_tries, int32_t* docids, float* clicks,
-                     int32_t* query_idx, void* stream);
+                     const float* exam_prob, int32_t n_exam, const float* click_prob, int32_t n_rel, int32_t click_model,
+                     uint64_t seed, uint64_t step, int32_t batch, int32_t list_size, int32_t max_tries, int32_t* docids,
+                     float* clicks, int32_t* query_idx, void* stream);
 
 /* ---- e: data-parallel gradient exchange over xGMI -----------------------------
  * No reference counterpart: the reference is single-process.  One process per GPU; queries shard across ranks,

@@ -605,6 +605,34 @@ def run_convergence_case(ultra, name, algo_key, n_iter=300, ckpt_every=50, batch
     print("wrote", name, "final ndcg@10 per seed x variant:\n", np.round(fin, 4), "\nmean", fin.mean(0), "max spread", np.ptp(fin, axis=1).max())
 
 
+def run_click_models_case(ultra, name, seed=71):
+    """The reference's three click simulators (click_models.py:68-110 PBM, 113-186 UBM, 187-236 cascade) loaded from its own
+    example JSONs, on seeded label lists of 5 / 10 / 17 documents (the last beyond the 10-entry examination tables): clicks,
+    examination and click probabilities per position, and estimatePropensityWeightsForOneList on the sampled clicks - all
+    drawn from Python's `random` stream after random.seed(seed)."""
+    from ultra.utils import click_models as RCM
+    files = {"pbm": "pbm_0.1_1.0_4_1.0.json", "ubm": "ubm_0.1_1_4_1.0.json", "cascade": "cascade_0.1_1.0_4_1.0.json"}
+    rng = np.random.RandomState(seed)
+    lists = [rng.randint(0, 5, size=n).tolist() for n in (5, 10, 17, 10, 17, 12)]
+    out = {"meta": json.dumps({"seed": seed, "models": list(files), "files": files, "n_lists": len(lists)})}
+    for i, lab in enumerate(lists):
+        out["labels%d" % i] = np.asarray(lab, np.int64)
+    for key, fn in files.items():
+        model = RCM.loadModelFromJson(json.load(open(os.path.join(REF, "example", "ClickModel", fn))))
+        random.seed(seed)
+        for i, lab in enumerate(lists):
+            c, e, p = model.sampleClicksForOneList(list(lab))
+            out["%s_clicks%d" % (key, i)] = np.asarray(c, np.float64)
+            out["%s_exam%d" % (key, i)] = np.asarray(e, np.float64)
+            out["%s_cprob%d" % (key, i)] = np.asarray(p, np.float64)
+            for flag in (False, True):
+                # (integer clicks: the reference's `use_non_clicked_data | click_list[r] > 0` raises on the cascade model's 0.0 floats)
+                out["%s_pw%d_%d" % (key, i, int(flag))] = np.asarray(model.estimatePropensityWeightsForOneList([int(x) for x in c], flag), np.float64)
+        out["%s_next_uniform" % key] = np.float64(random.random())  # where the stream stands afterwards
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, {k: int(out[k + "_clicks2"].sum()) for k in files})
+
+
 def run_metrics_case(ultra, name, seed=61):
     """Every host metric the reference's factory registers (metrics.py:36-153), evaluated BY THE REFERENCE on seeded scores /
     labels - two shapes, labels with invalid (-1) entries and PAD-masked scores, ties, an all-irrelevant list."""
@@ -633,6 +661,7 @@ def run_metrics_case(ultra, name, seed=61):
 CASES = {
     "metrics_host": lambda u: run_metrics_case(u, "metrics_host"),
     "feeds_toy": lambda u: run_feed_case(u, "feeds_toy"),
+    "click_models": lambda u: run_click_models_case(u, "click_models"),
     # the driver itself (main.py) on the toy dataset: losses, checkpoint schedule, printed metrics, saved tensors
     "driver_toy": lambda u: run_driver_case(u, "driver_toy"),
     # end-of-training NDCG@10 of the reference's main.py with a click feed, 5 seeds x {1 thread, 8 threads, one-rounding init}

@@ -47,6 +47,33 @@ def local_vector(algo, params, feed, names_d, names_l, aux, batch_total):
         loss_sum = -(w * torch.log_softmax(scores, -1)).sum()
         tail[0], tail[1] = loss_sum.detach(), w.sum()
         obj = loss_sum
+    elif algo == "lambdarank":
+        # every term carries 1 / IDCG_batch (lambda_rank.py:247-266, 280-282: ONE scalar over the whole batch): a shard emits the
+        # IDCG-free sums (its own loss x its own IDCG) and its IDCG share in tail[1]; the update divides by the reduced IDCG
+        tp, tm = torch.tensor(aux[:L]), torch.tensor(aux[L:])
+        y = torch.tensor(y_LB.T.copy())
+        loss, PL, tpl, tml = O.lambdarank_loss(scores, y, tp, tm)
+        ideal, _ = torch.sort(y, dim=1, descending=True)
+        idcg = torch.sum(O._safe_div(torch.pow(torch.tensor(2.0), ideal) - 1.0, torch.log(torch.arange(1, L + 1, dtype=torch.float32) + 1)))
+        obj = loss * idcg
+        tail[0], tail[1] = obj.detach(), idcg
+        tail[4:4 + L], tail[4 + L:] = tpl.detach() * idcg, tml.detach() * idcg
+    elif algo == "dla":
+        # two coupled softmax losses (dla.py:196-237), each with its own batch-global normaliser: [X_rank, D_rank, X_exam, D_exam]
+        # and, per position, the un-normalised gradient of the exam loss with respect to the (batch-independent) propensity
+        y = torch.tensor(y_LB.T.copy())
+        q = torch.tensor(aux[:L + 1])
+        prop = O.denoising_net(q, scores.shape[0], L).clone().requires_grad_(True)
+        with torch.no_grad():
+            pw = O.normalized_weights(O.logits_to_prob(prop))
+            rw = O.normalized_weights(O.logits_to_prob(scores))
+        w1, w2 = (y + 1e-7) * pw, (y + 1e-7) * rw
+        x_rank = -(w1 * torch.log_softmax(scores, -1)).sum()
+        x_exam = -(w2 * torch.log_softmax(prop, -1)).sum()
+        (gprop,) = torch.autograd.grad(x_exam, prop)
+        tail[0], tail[1], tail[2], tail[3] = x_rank.detach(), w1.sum(), x_exam.detach(), w2.sum()
+        tail[4:4 + L] = gprop.sum(0)
+        obj = x_rank
     else:  # pairdebias: linear in the pair sums; the xB factor uses the GLOBAL batch
         tp, tm = torch.tensor(aux[:L]), torch.tensor(aux[L:])
         loss, PL, tpl, tml = O.pairdebias_loss(scores, torch.tensor(y_LB), tp, tm)
@@ -78,11 +105,11 @@ def worker(rank, world, port, algo, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("algo", ["softmax", "pairdebias"])
+@pytest.mark.parametrize("algo", ["softmax", "pairdebias", "lambdarank", "dla"])
 def test_sharded_allreduce_equals_single_process(algo):
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    port = 29611 + (0 if algo == "softmax" else 1)
+    port = 29611 + ["softmax", "pairdebias", "lambdarank", "dla"].index(algo)
     procs = [ctx.Process(target=worker, args=(r, 2, port, algo, out)) for r in range(2)]
     [p.start() for p in procs]
     vec = out.get(timeout=120)
@@ -100,6 +127,27 @@ def test_sharded_allreduce_equals_single_process(algo):
         D = vec[P + 1]
         np.testing.assert_allclose(vec[:P] / D, ref["grads"], rtol=1e-4, atol=1e-6)
         assert abs(vec[P] / D - ref["loss"]) < 1e-5
+    elif algo == "lambdarank":
+        aux = np.linspace(0.9, 1.1, 2 * L).astype(np.float32)
+        ref = O.lambdarank_step(params, np.zeros_like(params), aux[:L], aux[L:], F, HIDDEN, feed["letor_features"], ids, y_LB)
+        D = vec[P + 1]  # the batch-global IDCG, summed over the shards
+        np.testing.assert_allclose(vec[:P] / D, ref["grads"], rtol=1e-4, atol=1e-5 * np.abs(ref["grads"]).max())
+        assert abs(vec[P] / D - ref["loss"]) <= 1e-5 * max(1.0, abs(ref["loss"]))
+        tpl, tml = torch.tensor(vec[P + 4:P + 4 + L] / D), torch.tensor(vec[P + 4 + L:] / D)
+        np.testing.assert_allclose(O.em_update(torch.tensor(aux[:L]), tpl, 0.05, 1, safe=True).numpy(), ref["t_plus"].ravel(), atol=1e-6)
+        np.testing.assert_allclose(O.em_update(torch.tensor(aux[L:]), tml, 0.05, 1, safe=True).numpy(), ref["t_minus"].ravel(), atol=1e-6)
+    elif algo == "dla":
+        aux = np.linspace(0.9, 1.1, 2 * L).astype(np.float32)
+        q = aux[:L + 1]
+        ref = O.dla_step(params, q, F, HIDDEN, feed["letor_features"], ids, y_LB)
+        d1, d2 = vec[P + 1], vec[P + 3]
+        np.testing.assert_allclose(vec[:P] / d1, ref["grads"], rtol=1e-4, atol=1e-6)
+        assert abs(vec[P] / d1 - ref["rank_loss"]) < 1e-5 and abs(vec[P + 2] / d2 - ref["exam_loss"]) < 1e-5
+        assert abs(vec[P + 2] / d2 + vec[P] / d1 - ref["loss"]) < 1e-5
+        # DenoisingNet backward from the reduced per-position sums (what update_kernel's block 0 does): dW_l = ELU'(W_l + b) s_l / D2
+        z = q[:L] + q[L]
+        gw = (vec[P + 4:P + 4 + L] / d2) * np.where(z > 0, 1.0, np.exp(z))
+        np.testing.assert_allclose(np.concatenate([gw, [gw.sum()]]), ref["prop_grads"], rtol=1e-4, atol=1e-6)
     else:
         aux = np.linspace(0.9, 1.1, 2 * L).astype(np.float32)
         ref = O.pairdebias_step(params, np.zeros_like(params), aux[:L], aux[L:], F, HIDDEN, feed["letor_features"], ids, y_LB)

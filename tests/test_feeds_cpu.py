@@ -104,8 +104,30 @@ def test_click_models_and_estimator():
     est = RandomizedPropensityEstimator(synthetic.IPW_JSON)
     w = est.getPropensityForOneList([1, 0, 1] + [0] * 40 + [1])
     assert w[0] == est.IPW_list[0] and w[1] == 0.0 and w[2] == est.IPW_list[2] and w[-1] == est.IPW_list[-1]
-    with pytest.raises(NotImplementedError):
-        cm.loadModelFromJson({"model_name": "user_browsing_model", "eta": 1, "click_prob": [], "exam_prob": []})
+
+
+def test_click_models_draw_the_reference_stream():
+    """PBM, the user-browsing model and the cascade model against the reference's own simulators (tests/golden/click_models.npz:
+    click_models.py:68-110, 113-186, 187-236 run on its example JSONs): same `random` seed -> the same clicks, examination and
+    click probabilities at every position, the same propensity weights, and the stream stands at the same place afterwards."""
+    from ultra_pytorch_amd import synthetic
+    from ultra_pytorch_amd.utils import click_models as cm
+    d = np.load(os.path.join(GOLDEN, "click_models.npz"))
+    m = json.loads(str(d["meta"]))
+    data = os.path.dirname(synthetic.PBM_JSON)
+    for key in m["models"]:
+        model = cm.loadModelFromJson(json.load(open(os.path.join(data, m["files"][key]))))
+        assert model.model_name == {"pbm": "position_biased_model", "ubm": "user_browsing_model", "cascade": "cascade_model"}[key]
+        random.seed(m["seed"])
+        for i in range(m["n_lists"]):
+            c, e, p = model.sampleClicksForOneList(d["labels%d" % i].tolist())
+            np.testing.assert_array_equal(np.asarray(c, np.float64), d["%s_clicks%d" % (key, i)])
+            np.testing.assert_array_equal(np.asarray(e, np.float64), d["%s_exam%d" % (key, i)])
+            np.testing.assert_array_equal(np.asarray(p, np.float64), d["%s_cprob%d" % (key, i)])
+            for flag in (False, True):
+                np.testing.assert_array_equal(np.asarray(model.estimatePropensityWeightsForOneList([int(x) for x in c], flag), np.float64),
+                                              d["%s_pw%d_%d" % (key, i, int(flag))])
+        assert random.random() == float(d["%s_next_uniform" % key])
 
 
 def test_dataset_roundtrip_merge_and_ranklist(tmp_path):

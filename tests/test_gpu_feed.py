@@ -102,3 +102,59 @@ def test_training_with_resident_dataset():
         loss, _, _ = algo.train(input_feed)
         losses.append(loss)
     assert all(np.isfinite(losses)) and np.mean(losses[-10:]) < np.mean(losses[:10])
+
+
+def _rates(feed, ds, model, L, n_batches, host):
+    out = []
+    for _ in range(n_batches):
+        f, _ = feed.get_batch(ds, check_validation=True)
+        out.append(np.stack([f[model.labels_name[l]] for l in range(L)]) if host else f["labels"].cpu().numpy().copy())
+    return np.concatenate(out, axis=1)
+
+
+def test_cascade_model_on_the_device():
+    """The cascade click model (click_models.py:187-236) through ultr_click_batch: at most ONE click per list, and it sits where
+    the host feed (bit-exact with the reference's) puts it - the distribution of the clicked position agrees to 5 sigma."""
+    import os
+    from ultra_pytorch_amd import synthetic
+    from ultra_pytorch_amd.input_layer import ClickSimulationFeed, DeviceClickFeed
+    F, L, B = 8, 12, 4096
+    ds = DS(300, (4, 12), F, seed=3)
+    ds.pad(L)
+    model = Model(F, L)
+    hp = "click_model_json=%s" % os.path.join(os.path.dirname(synthetic.PBM_JSON), "cascade_0.1_1.0_4_1.0.json")
+    dev_clicks = _rates(DeviceClickFeed(model, B, hp, seed=11), ds, model, L, 8, host=False)
+    assert set(np.unique(dev_clicks)) <= {0.0, 1.0}
+    assert (dev_clicks.sum(0) == 1.0).all()  # exactly one click: lists without one are redrawn, everything behind the first is dropped
+    random.seed(9)
+    host_clicks = _rates(ClickSimulationFeed(model, B, hp), ds, model, L, 8, host=True)
+    assert (host_clicks.sum(0) == 1.0).all()
+    n = dev_clicks.shape[1]
+    dr, hr = dev_clicks.mean(1), host_clicks.mean(1)
+    sigma = np.sqrt(np.maximum(hr * (1 - hr), 1e-4) * 2 / n)
+    assert np.all(np.abs(dr - hr) < 5 * sigma + 1e-3), (dr, hr)
+
+
+def test_dynamic_bias_eta_change_on_the_device():
+    """dynamic_bias_eta_change / dynamic_bias_step_interval (click_simulation_feed.py:165-172): every `interval` batches eta moves
+    and the examination table becomes ORIGINAL ** eta.  The device feed follows the host feed: same eta after the same number
+    of batches, and the per-position click rates of the batches drawn under the NEW eta agree to 5 sigma (and differ from
+    the rates under the old eta, so the change is visible)."""
+    from ultra_pytorch_amd.input_layer import ClickSimulationFeed, DeviceClickFeed
+    F, L, B = 8, 10, 4096
+    ds = DS(300, (10, 10), F, seed=4)
+    ds.pad(L)
+    model = Model(F, L)
+    hp = "dynamic_bias_eta_change=1.5,dynamic_bias_step_interval=4"
+    dfeed = DeviceClickFeed(model, B, hp, seed=5)
+    random.seed(6)
+    hfeed = ClickSimulationFeed(model, B, hp)
+    d_old, h_old = _rates(dfeed, ds, model, L, 4, host=False), _rates(hfeed, ds, model, L, 4, host=True)
+    assert abs(dfeed.click_model.eta - 2.5) < 1e-12 and abs(hfeed.click_model.eta - 2.5) < 1e-12
+    np.testing.assert_allclose(dfeed.exam.cpu().numpy(), np.asarray(hfeed.click_model.exam_prob, np.float32), rtol=1e-6)
+    d_new, h_new = _rates(dfeed, ds, model, L, 3, host=False), _rates(hfeed, ds, model, L, 3, host=True)
+    for dv, hv in ((d_old, h_old), (d_new, h_new)):
+        dr, hr = dv.mean(1), hv.mean(1)
+        sigma = np.sqrt(np.maximum(hr * (1 - hr), 1e-4) * 2 / dv.shape[1])
+        assert np.all(np.abs(dr - hr) < 5 * sigma + 1e-3), (dr, hr)
+    assert np.abs(d_new.mean(1) - d_old.mean(1)).max() > 0.02  # a steeper position bias

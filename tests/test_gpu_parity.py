@@ -28,9 +28,10 @@ def gtol(g, name=""):
     """1e-5 relative + 1e-6*max|g| absolute.  The *_odd fixtures have LayerNorms over 3-6 units (rstd up to 54):
     fp32 evaluation-order noise in their inputs is amplified ~10x, for torch-CPU and for the HIP path alike
     (tools/diag_precision.py: every stage is individually as accurate as torch fp32 against an fp64 evaluation),
-    so those ill-conditioned toy nets get 1e-4 / 1e-5*max|g|."""
+    so those ill-conditioned toy nets get 2e-5 / 1e-5*max|g| (round 5: closed from 1e-4 - measured <= 6.2e-6 x max|g|,
+    profiles/r04_parity_margins.json)."""
     if name.endswith("_odd"):
-        return dict(rtol=1e-4, atol=1e-5 * max(1.0, float(np.abs(g).max())))
+        return dict(rtol=2e-5, atol=1e-5 * max(1.0, float(np.abs(g).max())))
     return dict(rtol=1e-5, atol=1e-6 * max(1.0, float(np.abs(g).max())))
 
 
@@ -137,8 +138,8 @@ def _golden_train_step(name):
         if state is not None and "sgd" not in name:
             ref_state = d[p + "post_adagrad"]
             # s' = s + g^2 with g at the 1e-5 bar: 2e-5 relative (+ 2e-6 * max for elements with g ~ 0); the ill-conditioned
-            # *_odd nets carry their 1e-4 gradient bar (gtol) into the accumulator
-            np.testing.assert_allclose(state2, ref_state, rtol=2e-4 if name.endswith("_odd") else 2e-5,
+            # *_odd nets carry their 2e-5 gradient bar (gtol) into the accumulator
+            np.testing.assert_allclose(state2, ref_state, rtol=4e-5 if name.endswith("_odd") else 2e-5,
                                        atol=2e-6 * float(ref_state.max()))
 
 

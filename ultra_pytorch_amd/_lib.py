@@ -84,7 +84,7 @@ SIGNATURES = {
     "ultr_apply_update": (c_i32, [ctypes.POINTER(UpdateDesc), ctypes.POINTER(DnnDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                   c_vp, c_vp]),
     "ultr_train_step": (c_i32, [ctypes.POINTER(StepArgs), c_vp]),
-    "ultr_click_batch": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_i32, ctypes.c_uint64, ctypes.c_uint64,
+    "ultr_click_batch": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_i32, c_i32, ctypes.c_uint64, ctypes.c_uint64,
                                  c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "ultr_comm_create": (c_i32, [c_i32, c_i32, c_i64, ctypes.POINTER(c_vp)]),
     "ultr_comm_export": (c_i32, [c_vp, c_vp]),

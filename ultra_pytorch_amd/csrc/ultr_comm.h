@@ -3,7 +3,7 @@
 // Protocol (see ultr_comm.hip): a workgroup owns a slice of COMM_SLICE floats of the vector; it publishes the slice into the
 // rank's exchange slot with system-scope write-through stores, waits for them, raises flag (slice, rank) = epoch in EVERY rank's
 // flag array, polls its OWN flag row until every rank's flag carries the epoch, and adds the W slots IN RANK ORDER.  Both kernels
-// use the same slice geometry, flags, slots and epochs: ranks may mix them freely within one step.
+// use the same slice geometry, flags, slots and epochs: ranks may mix them freely within one step (the sum-of-squares partials they emit are bit-identical: same tree, tests/test_gpu_dp.py).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

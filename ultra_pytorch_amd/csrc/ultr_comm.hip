@@ -113,17 +113,22 @@ __global__ __launch_bounds__(64) void comm_allreduce_kernel(CommDev c, int64_t n
     }
   }
   // ---- sum-of-squares partials of the reduced gradient (64 elements = 16 lanes) ---------------------------------------
-  float q = 0.f;
-  if (e4 < n_params) q += s.x * s.x;
-  if (e4 + 1 < n_params) q += s.y * s.y;
-  if (e4 + 2 < n_params) q += s.z * s.z;
-  if (e4 + 3 < n_params) q += s.w * s.w;
+  // The SAME bits as grad_reduce_kernel / grad_reduce_xchg_kernel / grad_sumsq_kernel produce for this partial (ranks may
+  // take different exchange paths within one step - unequal local batches - and a one-ulp difference in a partial is a different
+  // clip coefficient, i.e. diverging replicas).  Those kernels hold ONE element per lane and run wave_sum: a balanced binary tree over
+  // the 64 elements in index order (xor 1, xor 2, row_ror 4 / 8 read from the row's last lane, then the rows).  Here a lane
+  // holds four consecutive elements = the two lowest levels of that tree, and the 16 lanes of a row finish it: read from lane 15.
+  // Every square is rounded before it is added (no fma contraction - the empty asm, as in grad_reduce_kernel).
+  float qx = (e4 < n_params) ? s.x * s.x : 0.f, qy = (e4 + 1 < n_params) ? s.y * s.y : 0.f;
+  float qz = (e4 + 2 < n_params) ? s.z * s.z : 0.f, qw = (e4 + 3 < n_params) ? s.w * s.w : 0.f;
+  asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz), "+v"(qw));
+  float q = (qx + qy) + (qz + qw);
   q += dpp_or<0xb1>(0.f, q);
   q += dpp_or<0x4e>(0.f, q);
   q += dpp_or<0x124>(0.f, q);
   q += dpp_or<0x128>(0.f, q);
   const int64_t k = e4 >> 6;
-  if ((tid & 15) == 0 && k < nsq) sumsq_part[k] = q;
+  if ((tid & 15) == 15 && k < nsq) sumsq_part[k] = q;
 }
 
 extern "C" int ultr_comm_create(int32_t rank, int32_t world, int64_t n_floats, ultr_comm** out) {

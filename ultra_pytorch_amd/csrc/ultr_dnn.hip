@@ -3526,7 +3526,9 @@ __global__ __launch_bounds__(64) void grad_sumsq_kernel(int64_t P, const float* 
                                                         float* __restrict__ sumsq_part) {
   const int64_t e = (int64_t)blockIdx.x * 64 + threadIdx.x;
   const float g = (e < P) ? grads[e] : 0.f;
-  const float sq = wave_sum(g * g);
+  float gg = g * g;
+  asm volatile("" : "+v"(gg));  // rounded before the first cross-lane add, as in grad_reduce_kernel / comm_allreduce_kernel: same bits
+  const float sq = wave_sum(gg);
   if (threadIdx.x == 0) sumsq_part[blockIdx.x] = sq;
 }
 

@@ -8,7 +8,8 @@
 //
 // Per batch slot (one wavefront): pick a query uniformly, sample position-biased clicks
 //   click_l ~ Bernoulli(exam_prob[min(l, n_exam-1)] * click_prob[min(label_l, n_rel-1)])      (click_models.py:68-110)
-// and, as the reference feed does with check_validation, redraw the whole list while it has no click.
+// - the cascade model (click_models.py:187-236) draws the same way and reports only the FIRST click of a list (a ballot over
+// the wavefront's positions) - and, as the reference feed does with check_validation, redraw the whole list while it has no click.
 // Randomness: a counter-based generator (Philox-4x32-10 keyed by (seed, step); counter = slot, attempt, position), so a
 // batch is a pure function of (seed, step) - reproducible and independent of launch geometry.  It is NOT the
 // Python Mersenne-Twister stream: parity with the reference feed is distributional (tests/test_gpu_feed.py).
@@ -21,7 +22,7 @@
 __global__ __launch_bounds__(256) void click_batch_kernel(const int32_t* __restrict__ lists, const float* __restrict__ rel,
                                                           int64_t n_queries, int Lmax, int64_t n_docs,
                                                           const float* __restrict__ exam, int n_exam,
-                                                          const float* __restrict__ cprob, int n_rel, uint64_t seed,
+                                                          const float* __restrict__ cprob, int n_rel, int cascade, uint64_t seed,
                                                           uint64_t step, int B, int L, int max_tries,
                                                           int32_t* __restrict__ docids, float* __restrict__ clicks,
                                                           int32_t* __restrict__ qidx) {
@@ -36,6 +37,7 @@ __global__ __launch_bounds__(256) void click_batch_kernel(const int32_t* __restr
     q = (int64_t)((double)u01(c[0]) * (double)n_queries);  // uniform query pick (click_simulation_feed.py:126)
     if (q >= n_queries) q = n_queries - 1;
     float any = 0.f;
+    bool clicked_before = false;  // cascade: a click in an earlier chunk of 64 positions
     for (int l0 = 0; l0 < L; l0 += 64) {
       const int l = l0 + lane;
       float ck = 0.f;
@@ -54,6 +56,14 @@ __global__ __launch_bounds__(256) void click_batch_kernel(const int32_t* __restr
         rng(r);
         const float p = exam[l < n_exam ? l : n_exam - 1] * cprob[lab < n_rel ? lab : n_rel - 1];
         ck = (u01(r[l & 3]) < p) ? 1.f : 0.f;
+      }
+      if (cascade) {  // only the first click of the list counts (the draws behind it are made and ignored, as in the reference)
+        const uint64_t hit = __ballot(ck > 0.f);
+        const int first = hit ? (int)__builtin_ctzll(hit) : 64;
+        if (clicked_before || lane > first) ck = 0.f;
+        clicked_before = clicked_before || hit != 0;
+      }
+      if (l < L) {
         docids[(int64_t)l * B + b] = id;
         clicks[(int64_t)l * B + b] = ck;
       }
@@ -65,14 +75,14 @@ __global__ __launch_bounds__(256) void click_batch_kernel(const int32_t* __restr
 }
 
 extern "C" int ultr_click_batch(const int32_t* lists, const float* labels, int64_t n_queries, int32_t lmax, int64_t n_docs,
-                                const float* exam_prob, int32_t n_exam, const float* click_prob, int32_t n_rel,
+                                const float* exam_prob, int32_t n_exam, const float* click_prob, int32_t n_rel, int32_t click_model,
                                 uint64_t seed, uint64_t step, int32_t batch, int32_t list_size, int32_t max_tries,
                                 int32_t* docids, float* clicks, int32_t* query_idx, void* stream) {
   if (!lists || !labels || !exam_prob || !click_prob || !docids || !clicks || n_queries <= 0 || lmax <= 0 || batch <= 0 ||
-      list_size <= 0 || n_exam <= 0 || n_rel <= 0 || max_tries <= 0 || n_docs < 0 || n_docs >= ((int64_t)1 << 31))
+      list_size <= 0 || n_exam <= 0 || n_rel <= 0 || max_tries <= 0 || (click_model != ULTR_CLICK_PBM && click_model != ULTR_CLICK_CASCADE) || n_docs < 0 || n_docs >= ((int64_t)1 << 31))
     return ULTR_E_BADARG;
   hipLaunchKernelGGL(click_batch_kernel, dim3((batch + 3) / 4), dim3(256), 0, (hipStream_t)stream, lists, labels, n_queries,
-                     (int)lmax, n_docs, exam_prob, (int)n_exam, click_prob, (int)n_rel, seed, step, (int)batch,
+                     (int)lmax, n_docs, exam_prob, (int)n_exam, click_prob, (int)n_rel, (int)(click_model == ULTR_CLICK_CASCADE), seed, step, (int)batch,
                      (int)list_size, (int)max_tries, docids, clicks, query_idx);
   return (int)hipGetLastError();
 }

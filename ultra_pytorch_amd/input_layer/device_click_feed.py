@@ -2,8 +2,9 @@
 
 Replaces the per-step Python batch construction of ClickSimulationFeed (reference click_simulation_feed.py:101-174,
 ~15 ms at config 2) by one kernel launch (ultr_click_batch): features never move again after the one-time upload, a
-batch is B x L global document ids + clicks.  Same distribution as the reference feed (uniform queries, PBM clicks,
-click-less lists redrawn); not the same random stream.  `get_batch` returns a feed of DEVICE tensors that the
+batch is B x L global document ids + clicks.  Same distribution as the reference feed (uniform queries, position-biased or
+cascade clicks, click-less lists redrawn, the bias severity eta drifting every `dynamic_bias_step_interval` batches when
+`dynamic_bias_eta_change` is set - click_simulation_feed.py:165-172); not the same random stream.  `get_batch` returns a feed of DEVICE tensors that the
 plugin algorithms recognise (`device_feed` key) and pass straight to the step kernels."""
 import ctypes
 import json
@@ -14,6 +15,7 @@ import torch
 
 from .. import _lib
 from ..utils import HParams
+from ..utils import click_models
 
 
 class ResidentDataset(object):
@@ -41,19 +43,24 @@ class ResidentDataset(object):
 
 class DeviceClickFeed(object):
     def __init__(self, model, batch_size, hparam_str, seed=0):
-        self.hparams = HParams(click_model_json="./example/ClickModel/pbm_0.1_1.0_4_1.0.json", max_tries=100)
+        self.hparams = HParams(click_model_json="./example/ClickModel/pbm_0.1_1.0_4_1.0.json", max_tries=100,
+                               dynamic_bias_eta_change=0.0, dynamic_bias_step_interval=1000)
         self.hparams.parse(hparam_str)
         path = self.hparams.click_model_json
         if not os.path.exists(path):
             alt = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", os.path.basename(path))
             path = alt if os.path.exists(alt) else path
         desc = json.load(open(path))
-        if desc["model_name"] != "position_biased_model":
-            raise NotImplementedError("DeviceClickFeed simulates the position-biased model")
+        if desc["model_name"] not in ("position_biased_model", "cascade_model"):
+            raise NotImplementedError("DeviceClickFeed simulates the position-biased and the cascade model (the user-browsing model "
+                                      "is served by the host feed, input_layer.ClickSimulationFeed)")
+        self.click_model = click_models.loadModelFromJson(desc)  # host twin: owns eta and the examination table
+        self.model_id = 1 if desc["model_name"] == "cascade_model" else 0
         self.model, self.batch_size = model, int(batch_size)
         self.rank_list_size = model.rank_list_size
         self.device = model.cuda
-        self.exam = torch.tensor([pow(x, 1.0) for x in desc["exam_prob"]], dtype=torch.float32, device=self.device)
+        self.exam = torch.tensor(self.click_model.exam_prob, dtype=torch.float32, device=self.device)
+        self.global_batch_count = 0
         self.cprob = torch.tensor(desc["click_prob"], dtype=torch.float32, device=self.device)
         self.seed, self.step = int(seed), 0
         self.lib = _lib.load()
@@ -77,12 +84,19 @@ class DeviceClickFeed(object):
         rd = self.resident(data_set)
         vp = lambda t: ctypes.c_void_p(t.data_ptr())
         rc = self.lib.ultr_click_batch(vp(rd.lists), vp(rd.labels), rd.n_queries, rd.lmax, rd.n_docs, vp(self.exam),
-                                       int(self.exam.numel()), vp(self.cprob), int(self.cprob.numel()), self.seed, self.step,
+                                       int(self.exam.numel()), vp(self.cprob), int(self.cprob.numel()), self.model_id, self.seed, self.step,
                                        self.batch_size, self.rank_list_size, int(self.hparams.max_tries) if check_validation else 1,
                                        vp(self.docids), vp(self.clicks), vp(self.qidx),
                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         _lib.check(rc, "ultr_click_batch")
         self.step += 1
+        self.global_batch_count += 1
+        # drifting bias severity (click_simulation_feed.py:165-172): eta moves, the examination table is rebuilt from the model's
+        # ORIGINAL table to the new power (click_models.py:77-81) and uploaded - 10 floats every `interval` batches
+        if self.hparams.dynamic_bias_eta_change != 0 and self.global_batch_count % self.hparams.dynamic_bias_step_interval == 0:
+            self.click_model.eta += self.hparams.dynamic_bias_eta_change
+            self.click_model.setExamProb(self.click_model.eta)
+            self.exam = torch.tensor(self.click_model.exam_prob, dtype=torch.float32, device=self.device)
         feed = {"device_feed": True, "features": rd.features, "n_docs": rd.n_docs, "docids": self.docids,
                 "labels": self.clicks, "batch_size": self.batch_size}
         return feed, {"rank_list_idxs": self.qidx}
