@@ -10,7 +10,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 500 --warmup 50 --no-cpu-baseline --no-extras"
+CMD="python $REPO/bench.py --steps 500 --warmup 50 --no-cpu-baseline --no-extras --no-other-configs --spinup-ms 0"
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- $CMD > "$OUT/stats.log" 2>&1
 echo "stats rc=$?"
 timeout 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -o f -- $CMD > "$OUT/fetch.log" 2>&1

@@ -4,8 +4,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 src = sorted(os.path.join(ROOT, "ultra_pytorch_amd/csrc", f) for f in os.listdir(os.path.join(ROOT, "ultra_pytorch_amd/csrc")) if f.endswith(".hip"))
-out = "/tmp/libultr_trace.so"
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DULTR_TRACE"] + src + ["-o", out])
+out = os.environ.get("ULTR_TRACE_LIB", "/tmp/libultr_trace.so")  # a variant prebuilt with tools/ab_build.sh trace "-DULTR_TRACE", or built here
+if not os.path.exists(out):
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-Xclang", "-target-feature",
+                           "-Xclang", "-packed-fp32-ops", "-DULTR_TRACE"] + src + ["-o", out])
 from ultra_pytorch_amd import _lib
 lib = _lib.load(out)
 _lib._LIB = lib

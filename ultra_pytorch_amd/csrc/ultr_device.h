@@ -52,31 +52,32 @@ __device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
 #pragma unroll
   for (int k = 0; k < N; ++k) v[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[k]), 63));
 }
+// wave maximum: ONE instruction per step (v_max_f32_dpp).  Written as asm because the compiler cannot fold a maximum into the DPP move
+// (fmaxf(v, dpp(v)) became v_mov + s_nop + v_mov_dpp + a canonicalising v_max + v_max: five issue slots per step, 60 instead of
+// 12 for the two interleaved chains of a LayerNorm - on kernels that are instruction-issue bound with two waves per SIMD).  The
+// s_nop supplies the two wait states a DPP read of a just-written VGPR needs; lanes without a source (row_bcast) keep their value.
+#define ULTR_DPP_MAX(x, ctrl) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " ctrl " bank_mask:0xf" : "+v"(x))
 template <int N>
 __device__ __forceinline__ void wave_max_n(float (&v)[N]) {
 #pragma unroll
-  for (int k = 0; k < N; ++k) v[k] = fmaxf(v[k], dpp_or<0xb1>(v[k], v[k]));
+  for (int k = 0; k < N; ++k) ULTR_DPP_MAX(v[k], "quad_perm:[1,0,3,2] row_mask:0xf");
 #pragma unroll
-  for (int k = 0; k < N; ++k) v[k] = fmaxf(v[k], dpp_or<0x4e>(v[k], v[k]));
+  for (int k = 0; k < N; ++k) ULTR_DPP_MAX(v[k], "quad_perm:[2,3,0,1] row_mask:0xf");
 #pragma unroll
-  for (int k = 0; k < N; ++k) v[k] = fmaxf(v[k], dpp_or<0x124>(v[k], v[k]));
+  for (int k = 0; k < N; ++k) ULTR_DPP_MAX(v[k], "row_ror:4 row_mask:0xf");
 #pragma unroll
-  for (int k = 0; k < N; ++k) v[k] = fmaxf(v[k], dpp_or<0x128>(v[k], v[k]));
+  for (int k = 0; k < N; ++k) ULTR_DPP_MAX(v[k], "row_ror:8 row_mask:0xf");
 #pragma unroll
-  for (int k = 0; k < N; ++k) v[k] = fmaxf(v[k], dpp_or<0x142>(v[k], v[k]));
+  for (int k = 0; k < N; ++k) ULTR_DPP_MAX(v[k], "row_bcast:15 row_mask:0xa");
 #pragma unroll
-  for (int k = 0; k < N; ++k) v[k] = fmaxf(v[k], dpp_or<0x143>(v[k], v[k]));
+  for (int k = 0; k < N; ++k) ULTR_DPP_MAX(v[k], "row_bcast:31 row_mask:0xc");
 #pragma unroll
   for (int k = 0; k < N; ++k) v[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[k]), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-  v = fmaxf(v, dpp_or<0xb1>(v, v));
-  v = fmaxf(v, dpp_or<0x4e>(v, v));
-  v = fmaxf(v, dpp_or<0x124>(v, v));
-  v = fmaxf(v, dpp_or<0x128>(v, v));
-  v = fmaxf(v, dpp_or<0x142>(v, v));
-  v = fmaxf(v, dpp_or<0x143>(v, v));
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+  float a[1] = {v};
+  wave_max_n<1>(a);
+  return a[0];
 }
 
 // activation and its derivative expressed through the activation OUTPUT a = act(z)
