@@ -3406,7 +3406,8 @@ __device__ __forceinline__ float block_sum_256(float v, float* sm) {
 template <bool ONE>
 __global__ __launch_bounds__(256) void grad_reduce_kernel(RedPlan rp, int64_t P, int tail, const float* __restrict__ ws,
                                                           const float* __restrict__ loss_part, int n_loss_part,
-                                                          float* __restrict__ grads, float* __restrict__ sumsq_part, int nsq) {
+                                                          float* __restrict__ grads, float* __restrict__ sumsq_part, int nsq,
+                                                          float* __restrict__ sumsq2) {
   __shared__ float sm[4][64];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   if (n_loss_part > 0 && blockIdx.x == gridDim.x - 1) {
@@ -3442,6 +3443,11 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(RedPlan rp, int64_t P,
     const float sq = wave_sum(gg);
     const int k = (int)blockIdx.x * 4 + grp;
     if (lane == 0 && k < nsq) sumsq_part[k] = sq;
+    if (sumsq2 != nullptr) {  // level 2: the block's four partials in order (partials beyond nsq are sums of zeros)
+      if (lane == 0) sm[0][grp] = sq;
+      __syncthreads();
+      if (threadIdx.x == 0) sumsq2[blockIdx.x] = ((sm[0][0] + sm[0][1]) + sm[0][2]) + sm[0][3];
+    }
     return;
   }
   const int64_t e = (int64_t)blockIdx.x * 64 + lane;
@@ -3473,9 +3479,10 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(RedPlan rp, int64_t P,
 template <int W>
 __global__ __launch_bounds__(256) void grad_reduce_xchg_kernel(RedPlan rp, int64_t P, int tail, const float* __restrict__ ws,
                                                                float* __restrict__ grads, float* __restrict__ sumsq_part, int nsq,
-                                                               CommDev c, EarlyReport er) {
+                                                               CommDev c, EarlyReport er, float* __restrict__ sumsq2) {
   __shared__ int sm_fail;
   __shared__ float sm_head[4];
+  __shared__ float sm_sq[4];
   const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6;
   const int64_t n = P + tail;
   const int64_t e = (int64_t)blockIdx.x * 256 + tid;
@@ -3520,6 +3527,11 @@ __global__ __launch_bounds__(256) void grad_reduce_xchg_kernel(RedPlan rp, int64
   const float sq = wave_sum(gg);
   const int k = (int)blockIdx.x * 4 + grp;
   if (lane == 0 && k < nsq) sumsq_part[k] = sq;
+  if (sumsq2 != nullptr) {  // level 2, as grad_reduce_kernel: the same bits on one GPU and on every rank
+    if (lane == 0) sm_sq[grp] = sq;
+    __syncthreads();
+    if (tid == 0) sumsq2[blockIdx.x] = ((sm_sq[0] + sm_sq[1]) + sm_sq[2]) + sm_sq[3];
+  }
 }
 
 __global__ __launch_bounds__(64) void grad_sumsq_kernel(int64_t P, const float* __restrict__ grads,
@@ -3793,6 +3805,8 @@ bool ultr_make_bwd_plan(const DnnPlan& p, int64_t N, BwdPlan* bp, int wg_mode) {
   const int64_t tail_max = 4096;  // generous: tail is 4 + 2L floats
   bp->n_red_blocks = (int)ultr_red_blocks(p.P, (int)tail_max);
   bp->sumsq_off = off; off += bp->n_red_blocks; off = (off + 3) & ~(int64_t)3;
+  off += ultr_sumsq2_len(p.P);  // level-2 partials at ultr_sumsq2_off(P) (= here: sumsq_off is 0)
+  off = (off + 3) & ~(int64_t)3;
   // sized for the finest row blocking any kernel uses (the fused forward+backward kernel owns >= 9 live rows per block)
   const int64_t nrb_alloc = (N + 8) / 9 + 1 > bp->nrb ? (N + 8) / 9 + 1 : bp->nrb;
   bp->vslab_off = off; off += nrb_alloc * bp->vlen; off = (off + 3) & ~(int64_t)3;
@@ -4340,7 +4354,7 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
     if (ultr_comm_dev(g_ultr_step_xchg.comm, g_ultr_step_xchg.step, p.P + tail, &cd)) {
       const dim3 xg((unsigned)((p.P + tail + 255) / 256));
 #define XCHG_LAUNCH(WW) \
-  ULTR_LAUNCH(prof, grad_reduce_xchg_kernel<WW>, xg, dim3(256), 0, st, rp, p.P, tail, (const float*)ws, grads, ws + bp.sumsq_off, nblk, cd, g_ultr_step_xchg.er)
+  ULTR_LAUNCH(prof, grad_reduce_xchg_kernel<WW>, xg, dim3(256), 0, st, rp, p.P, tail, (const float*)ws, grads, ws + bp.sumsq_off, nblk, cd, g_ultr_step_xchg.er, ws + ultr_sumsq2_off(p.P))
       switch (cd.world) {
         case 1: XCHG_LAUNCH(1); break;
         case 2: XCHG_LAUNCH(2); break;
@@ -4353,15 +4367,20 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
       }
 #undef XCHG_LAUNCH
       g_ultr_step_xchg.done = true;
+      g_ultr_step_nsq2 = (int)xg.x;
       return (int)hipGetLastError();
     }
   }
-  if (maxparts <= 32)
+  if (maxparts <= 32) {
+    // (level-2 partials only without the extra loss-fold workgroup: its index would be a level-2 slot)
+    float* s2 = bp.lf_chunks == 0 ? ws + ultr_sumsq2_off(p.P) : nullptr;
     ULTR_LAUNCH(prof, grad_reduce_kernel<true>, dim3((nblk + 3) / 4 + (bp.lf_chunks > 0 ? 1 : 0)), dim3(256), 0, st, rp, p.P, tail,
-                (const float*)ws, (const float*)(ws + bp.lfold_off), bp.lf_chunks, grads, ws + bp.sumsq_off, nblk);
-  else
+                (const float*)ws, (const float*)(ws + bp.lfold_off), bp.lf_chunks, grads, ws + bp.sumsq_off, nblk, s2);
+    if (s2 != nullptr) g_ultr_step_nsq2 = (nblk + 3) / 4;
+  } else {
     ULTR_LAUNCH(prof, grad_reduce_kernel<false>, dim3(nblk + (bp.lf_chunks > 0 ? 1 : 0)), dim3(256), 0, st, rp, p.P, tail,
-                (const float*)ws, (const float*)(ws + bp.lfold_off), bp.lf_chunks, grads, ws + bp.sumsq_off, nblk);
+                (const float*)ws, (const float*)(ws + bp.lfold_off), bp.lf_chunks, grads, ws + bp.sumsq_off, nblk, (float*)nullptr);
+  }
   return (int)hipGetLastError();
 }
 

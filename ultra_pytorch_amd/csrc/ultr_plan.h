@@ -282,12 +282,21 @@ struct StepXchg {
   bool done;
 };
 extern thread_local StepXchg g_ultr_step_xchg;  // ultr_step.hip
+extern thread_local int g_ultr_step_nsq2;       // ultr_step.hip: level-2 sum-of-squares partials this step's reduction launch wrote (0: none)
+int ultr_apply_update_ex(const ultr_update_desc* u, const ultr_dnn_desc* d, float* params, float* wt, float* state, const float* grads,
+                         float* aux, const void* bwd_ws, float* scalars_out, int nsq2, void* stream);  // ultr_update.hip
 
 #define ULTR_TAIL_FIXED 4
 __host__ __device__ static inline int64_t ultr_tail_len(int L) { return ULTR_TAIL_FIXED + 2 * (int64_t)L; }
 
 // sum-of-squares partials: one per 64 gradient elements (grad_reduce_kernel / grad_sumsq_kernel geometry)
 __host__ __device__ static inline int64_t ultr_red_blocks(int64_t P, int tail) { return (P + tail + 63) / 64; }
+// ... and their sums per 256 elements ("level 2": ((p0 + p1) + p2) + p3 of the four partials of a 256-element block), written by the
+// slab-reduction launches of ultr_train_step behind the level-1 partials at a fixed offset of bwd_ws.  The update sums THESE when
+// the step's reduction wrote them (a quarter of the words: every update workgroup reads all of them - 401 workgroups x 1601 words
+// on 50 cache lines was a hot spot at the top of the launch, config 2: update 6.9 -> 6.3 us without it)
+__host__ __device__ static inline int64_t ultr_sumsq2_off(int64_t P) { return (ultr_red_blocks(P, 4096) + 3) & ~(int64_t)3; }
+__host__ __device__ static inline int64_t ultr_sumsq2_len(int64_t P) { return (ultr_red_blocks(P, 4096) + 3) / 4 + 4; }
 
 // loss workspace: [0] int n_partials (as float bits unused) ; partials [MAXPART][tail]
 #define ULTR_LOSS_LISTS_PER_WG 1  // one list per workgroup: a step has only `batch` lists, spread them over the CUs

@@ -26,16 +26,19 @@ static int finish_step(const ultr_step_args* a, void* stream) {
     // any peer - the rank that times out raises the word everywhere) no replica moves its parameters again
     ultr_update_desc u = *a->upd;
     u.guard = ultr_comm_status_word(a->comm);
-    return ultr_apply_update(&u, a->desc, a->params, a->wt, a->state, a->grads, a->aux, a->bwd_ws, a->scalars, stream);
+    // (level-2 partials: only when the slab-reduction launch exchanged the vector itself - the stand-alone exchange kernel writes level 1)
+    return ultr_apply_update_ex(&u, a->desc, a->params, a->wt, a->state, a->grads, a->aux, a->bwd_ws, a->scalars,
+                                g_ultr_step_xchg.done ? g_ultr_step_nsq2 : 0, stream);
   } else if (a->skip_update) {
     return 0;
   }
-  return ultr_apply_update(a->upd, a->desc, a->params, a->wt, a->state, a->grads, a->aux, a->bwd_ws, a->scalars, stream);
+  return ultr_apply_update_ex(a->upd, a->desc, a->params, a->wt, a->state, a->grads, a->aux, a->bwd_ws, a->scalars, g_ultr_step_nsq2, stream);
 }
 
 thread_local EarlyReport g_ultr_early = {nullptr, 0u, 0, 1.0f};
 thread_local const float* g_ultr_step_wt = nullptr;
 thread_local StepXchg g_ultr_step_xchg = {nullptr, 0, {nullptr, 0u, 0, 1.0f}, false};
+thread_local int g_ultr_step_nsq2 = 0;
 
 namespace {
 // early loss report for the backward call(s) of this step (EarlyReport, ultr_plan.h): only where the local loss sums ARE the
@@ -46,6 +49,7 @@ struct EarlyScope {
     const bool ok = u->host_scalars != nullptr && a->comm == nullptr && !a->skip_update && u->l2_loss == 0.f;
     g_ultr_early = {ok ? u->host_scalars : nullptr, u->seq, u->algo, u->ranker_loss_weight};
     g_ultr_step_wt = a->wt;
+    g_ultr_step_nsq2 = 0;
     const bool dp = a->comm != nullptr && !a->skip_update;
     const bool early_dp = dp && u->host_scalars != nullptr && u->l2_loss == 0.f;
     g_ultr_step_xchg = {dp ? a->comm : nullptr, a->comm_step, {early_dp ? u->host_scalars : nullptr, u->seq, u->algo, u->ranker_loss_weight}, false};
@@ -54,6 +58,7 @@ struct EarlyScope {
     g_ultr_early.host = nullptr;
     g_ultr_step_wt = nullptr;
     g_ultr_step_xchg.comm = nullptr;
+    g_ultr_step_nsq2 = 0;
   }
 };
 }  // namespace

@@ -243,7 +243,7 @@ __device__ __forceinline__ void update_body(const ultr_update_desc& u, const Dnn
 __global__ __launch_bounds__(256) void update_kernel(ultr_update_desc u, DnnPlan dp, float* __restrict__ params,
                                                      float* __restrict__ state, const float* __restrict__ grads,
                                                      float* __restrict__ aux, const float* __restrict__ sumsq_part, int nsq,
-                                                     float* __restrict__ scalars_out, const float* __restrict__ l2_sums) {
+                                                     float* __restrict__ scalars_out, const float* __restrict__ l2_sums, int nsq2) {
   if (update_guarded(u)) return;
   // flat variant (no k-major copy to maintain): one element per thread, loads issued BEFORE the norm reduction so
   // that the two memory round trips overlap
@@ -256,8 +256,13 @@ __global__ __launch_bounds__(256) void update_kernel(ultr_update_desc u, DnnPlan
   const float p_old[1] = {live ? params[e] : 0.f};
   const float s_old[1] = {(live && state != nullptr) ? state[e] : 0.f};
   float ss = 0.f;
+  if (nsq2 > 0) {  // level-2 partials of this step's reduction launch (ultr_sumsq2_off)
+    const float* s2 = sumsq_part + ultr_sumsq2_off(P);
+    for (int k = threadIdx.x; k < nsq2; k += 256) ss += s2[k];
+  } else {
 #pragma unroll 8
-  for (int k = threadIdx.x; k < nsq; k += 256) ss += sumsq_part[k];
+    for (int k = threadIdx.x; k < nsq; k += 256) ss += sumsq_part[k];
+  }
   ss = block_sum256(ss, sm);
   float pn[1];
   update_body<1>(u, dp, params, state, grads + P, aux, ss, ea, g_raw, p_old, s_old, pn, sm, scalars_out, l2_sums, u.range_flag);
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(256) void update_tiled_kernel(ultr_update_desc u, D
                                                            float* __restrict__ aux, float* __restrict__ wt,
                                                            const float* __restrict__ sumsq_part, int nsq,
                                                            float* __restrict__ scalars_out, int n_tile_blocks,
-                                                           const float* __restrict__ l2_sums) {
+                                                           const float* __restrict__ l2_sums, int nsq2) {
   __shared__ float sm[4];
   __shared__ float tile[TPW][16][17];
   if (update_guarded(u)) return;
@@ -321,8 +326,13 @@ __global__ __launch_bounds__(256) void update_tiled_kernel(ultr_update_desc u, D
     s_old[q] = (live && state != nullptr) ? state[ea[q]] : 0.f;
   }
   float ss = 0.f;
+  if (nsq2 > 0) {  // level-2 partials of this step's reduction launch (ultr_sumsq2_off): a quarter of the words every workgroup reads
+    const float* s2 = sumsq_part + ultr_sumsq2_off(P);
+    for (int k = tid; k < nsq2; k += 256) ss += s2[k];
+  } else {
 #pragma unroll 8
-  for (int k = tid; k < nsq; k += 256) ss += sumsq_part[k];
+    for (int k = tid; k < nsq; k += 256) ss += sumsq_part[k];
+  }
   ss = block_sum256(ss, sm);
   float pn[TPW];
   // block 0's extra duties (EM / propensity updates, step scalars) run inside update_body and need all 256 threads
@@ -407,6 +417,11 @@ __global__ __launch_bounds__(256) void update_tiled_kernel(ultr_update_desc u, D
 
 extern "C" int ultr_apply_update(const ultr_update_desc* u, const ultr_dnn_desc* d, float* params, float* wt, float* state,
                                  const float* grads, float* aux, const void* bwd_ws, float* scalars_out, void* stream) {
+  return ultr_apply_update_ex(u, d, params, wt, state, grads, aux, bwd_ws, scalars_out, 0, stream);
+}
+// nsq2 > 0: the step's slab-reduction launch left level-2 sum-of-squares partials (ultr_plan.h) - library-internal (ultr_train_step)
+int ultr_apply_update_ex(const ultr_update_desc* u, const ultr_dnn_desc* d, float* params, float* wt, float* state, const float* grads,
+                         float* aux, const void* bwd_ws, float* scalars_out, int nsq2, void* stream) {
   if (!u || !params || !grads || !bwd_ws || u->n_params <= 0 || u->list_size <= 0) return ULTR_E_BADARG;
   DnnPlan dp;
   memset(&dp, 0, sizeof(dp));
@@ -433,16 +448,16 @@ extern "C" int ultr_apply_update(const ultr_update_desc* u, const ultr_dnn_desc*
     if (n_tiles + (n_vec + 255) / 256 < 1536) {  // one unit per workgroup keeps the launch wide (config 2: 401 units, config 3: 940 -
                                                  // four per workgroup left 235 workgroups for 256 CUs: 7.0 -> 9.0 us)
       ULTR_LAUNCH(prof, update_tiled_kernel<1>, dim3(n_tiles + (n_vec + 255) / 256), dim3(256), 0, (hipStream_t)stream, *u, dp, params, state,
-                  grads, aux, wt, (const float*)bwd_ws, nsq, scalars_out, n_tiles, l2_sums);
+                  grads, aux, wt, (const float*)bwd_ws, nsq, scalars_out, n_tiles, l2_sums, nsq2);
     } else {
       const int tb = (n_tiles + 3) / 4;
       ULTR_LAUNCH(prof, update_tiled_kernel<4>, dim3(tb + (n_vec + 1023) / 1024), dim3(256), 0, (hipStream_t)stream, *u, dp, params, state,
-                  grads, aux, wt, (const float*)bwd_ws, nsq, scalars_out, tb, l2_sums);
+                  grads, aux, wt, (const float*)bwd_ws, nsq, scalars_out, tb, l2_sums, nsq2);
     }
   } else {
     const int nblk = (int)((u->n_params + 255) / 256);
     ULTR_LAUNCH(prof, update_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *u, dp, params, state, grads, aux,
-                (const float*)bwd_ws, nsq, scalars_out, l2_sums);
+                (const float*)bwd_ws, nsq, scalars_out, l2_sums, nsq2);
   }
   return (int)hipGetLastError();
 }
