@@ -947,6 +947,27 @@ def main():
                                            if os.environ.get("ULTR_DP_COMM", "peer") == "peer" else "ULTR_DP_COMM=pg"}
         dp_checks["replicas_bit_identical_after_run"] = replicas_identical()
         assert dp_checks["replicas_bit_identical_after_run"] or not main_ok, "data-parallel replicas diverged"
+        # the SAME step without the exchange, in this run, on every rank at once (its own copies of the parameters: the replicas are
+        # not disturbed): what one GPU does alone on this node right now - the denominator of the weak-scaling efficiency
+        solo_params, solo_state = params.clone(), None if state is None else state.clone()
+        solo_aux = None if aux is None else aux.clone()
+        e1 = engs["solo"] = eng_cls(shape, B, L, device, algo=cfg["algo"], learning_rate=LR, max_gradient_norm=CLIP)
+
+        def solo_step(i):
+            f, nd, ids, y, _ = pool[i % npool]
+            return e1.train_step(solo_params, solo_state, f, nd, ids, y, aux=solo_aux, ipw_table=ipw)
+        for i in range(20):
+            solo_step(i)
+        barrier()
+        n_solo = max(100, min(args.steps, 1000))
+        ta = time.perf_counter()
+        for i in range(n_solo):
+            solo_step(i)
+            e1.read_loss()
+        torch.cuda.synchronize()
+        tsolo = torch.tensor([(time.perf_counter() - ta) / n_solo], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(tsolo, op=torch.distributed.ReduceOp.MAX)
+        solo_ms = 1e3 * float(tsolo.item())
 
     e2e, plugin = None, None
     if world == 1 and not args.no_extras and light:
@@ -1103,6 +1124,10 @@ def main():
             out["rccl_ranks"] = rccl_ranks  # world size of the RCCL communicator that all-reduced `grads` in THIS run
             out["allreduce_us"] = allreduce_us
             out["dp_checks"] = dp_checks
+            out["single_gpu_in_run"] = {"ms_per_step": solo_ms, "queries_per_sec": B / (1e-3 * solo_ms),
+                                        "what": "the same synced step WITHOUT the exchange on every rank at once, in this run (slowest rank)"}
+            out["weak_scaling_efficiency"] = (world * B * args.steps / elapsed) / (world * B / (1e-3 * solo_ms))
+            out["exchange_exposed_us"] = 1e3 * (1e3 * elapsed / args.steps - solo_ms)
         if trb is not None:
             out["torch_rocm_baseline"] = trb
         if e2e is not None:

@@ -163,3 +163,5 @@ def test_bench_multi_rank_logic_on_one_gpu():
     assert len(d["dp_exchanges"]) == 2 and all("ms_per_step" in v for v in d["dp_exchanges"].values())
     assert d["dp_checks"]["replicas_bit_identical_after_run"] and d["dp_checks"]["peer_exchange_matches_rccl_allreduce"]
     assert d["rccl_ranks"] == 2 and d["value"] > 0
+    # the in-run single-GPU figure and what the driver's scaling run is read against (two ranks SHARE one GPU here: no bar on the value)
+    assert d["single_gpu_in_run"]["ms_per_step"] > 0 and 0.0 < d["weak_scaling_efficiency"] < 1.5 and "exchange_exposed_us" in d

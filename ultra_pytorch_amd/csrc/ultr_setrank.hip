@@ -2070,9 +2070,10 @@ size_t attn_bwd_h3_lds(const SrPlan& p, int L) {
 bool attn_h3_ok(const SrPlan& p, int L, int layer = 0, int dir = 0) {
   sr_knobs_load();
   if (dir != 1 || g_sr_knob_attn_h3 < 1) return false;
-  // measured rule (round 4): the kernel wins while its launch fits 100 KB (config 5: 88 KB = one workgroup of 7 waves per CU, 289 us
-  // against 383 on the fp32 matrix cores); head depth 64 at list sizes > ~50 needs more and loses to the fp32 kernel's two per CU
-  if (attn_bwd_h3_lds(p, L) > 100 * 1024) return false;
+  // the launch must leave room for two workgroups per CU, give or take (config 5, head depth 32 at list size 100: 72 KB - two of 7 waves
+  // each; head depth 64 up to list size 64: 83 KB - one, still ahead of the fp32 kernel; beyond that, 100 KB and more, the fp32
+  // matrix-core kernel wins).  ONE expression for the gate and the launch.
+  if (attn_bwd_h3_lds(p, L) > 84 * 1024) return false;
   return ((g_sr_knob_attn_mask >> (2 * layer + dir)) & 1) && !p.att_f16 && attn_mfma_ok(p, L) && (p.dh == 32 || p.dh == 64);
 }
 int attn_bwd_h3(const SrPlan& p, const float* x, const float* dA, const float* Aout, const float* lse, int batch, int L, float* dx,
