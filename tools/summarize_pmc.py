@@ -64,4 +64,17 @@ with open(out, "w") as fh:
         occ = 100.0 * busy[k] / (act[k] / 8.0 * 1024.0) if k in busy and act.get(k, 0) > 0 else float("nan")
         fh.write("| `%s` | %.1f | %.1f | %.1f %% | %.1f | %.2f | %s |\n" % (k, calls[k] / steps, us, 100.0 * dur[k] / total, b / 1e6, b / us / 1e6,
                                                                        ("%.0f %%" % occ) if occ == occ else "-"))
+if cfg.startswith("5"):
+    # the whole step's HBM bytes (sum over its launches) -> profiles/traffic.json, read by bench.py for config 5's roofline.traffic
+    import json
+    tot_b = sum((2.0 * fetch.get(k, 0.0) + write.get(k, 0.0)) * 1024.0 * calls[k] / steps for k in dur if calls[k] >= steps // 2)
+    tj_path = os.path.join(ROOT, "profiles", "traffic.json")
+    tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
+    if cfg == "5":
+        tj["setrank_whole_step"] = tot_b
+        tj["_source_setrank"] = "profiles/%s_cfg5_pmc.md (SetRank: sum over the launches of one step)" % tag
+        json.dump(tj, open(tj_path, "w"), indent=1)
+    with open(out, "a") as fh:
+        fh.write("\nWhole step: **%.2f GB** of HBM traffic over %d launches, %.0f us of kernels.\n"
+                 % (tot_b / 1e9, round(sum(calls[k] / steps for k in dur if calls[k] >= steps // 2)), sum(dur[k] / steps for k in dur if calls[k] >= steps // 2)))
 print(open(out).read())

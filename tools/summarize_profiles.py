@@ -55,7 +55,12 @@ def counter(pattern, cname):
 fetch = counter("fetch/**/*counter_collection.csv", "FETCH_SIZE")
 write = counter("write/**/*counter_collection.csv", "WRITE_SIZE")
 traffic = {k: (2.0 * fetch.get(k, 0.0) + write.get(k, 0.0)) * 1024.0 for k in OURS if k in fetch or k in write}
-json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+tj_path = os.path.join(ROOT, "profiles", "traffic.json")
+tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
+tj.update(traffic)  # (keys this pass did not measure - e.g. SetRank's whole-step sum from tools/summarize_pmc.py - stay)
+tj["_source"] = "profiles/%s_hbm_traffic.md (config 2 kernels: tools/profile_round.sh %s)%s" % (
+    tag, tag, "; " + tj["_source_setrank"] if "_source_setrank" in tj else "")
+json.dump(tj, open(tj_path, "w"), indent=1)
 with open(os.path.join(ROOT, "profiles", tag + "_hbm_traffic.md"), "w") as fh:
     fh.write("# %s - HBM traffic per launch (rocprofv3 PMC, separate passes), bench.py workload (cfg2: F136 L10 B256 DNN[256,256] IPW)\n\n" % tag)
     fh.write("Collected by `tools/profile_round.sh %s` (`rocprofv3 --pmc FETCH_SIZE --kernel-trace`, then `--pmc WRITE_SIZE\n"
@@ -67,6 +72,8 @@ with open(os.path.join(ROOT, "profiles", tag + "_hbm_traffic.md"), "w") as fh:
     for k in OURS:
         if k in traffic:
             fh.write("| %s | %.2f | %.1f | %.1f | %d |\n" % (k, avg_us.get(k, float("nan")), fetch.get(k, 0), write.get(k, 0), traffic[k]))
+    step_kernels = [k for k in ("dnn_fb_kernel", "dnn_wgrad_kernel", "grad_reduce_kernel", "update_kernel") if k in traffic]
+    fh.write("\nPer step (%s): **%.1f MB** against 3.06 MB algorithmic (SURVEY 8d).\n" % (" + ".join(step_kernels), sum(traffic[k] for k in step_kernels) / 1e6))
 # matrix-core occupancy (optional 4th pass): SQ_VALU_MFMA_BUSY_CYCLES sums, over all SIMDs, the cycles an MFMA occupies its pipe
 # (32 per v_mfma_f32_16x16x4_f32); GRBM_GUI_ACTIVE = GPU-busy cycles of the dispatch SUMMED over the 8 XCDs (checked: 8 x the
 # kernel duration in shader cycles).  util = busy / (active / 8 * 1024 SIMDs).

@@ -106,10 +106,6 @@ __device__ __forceinline__ float expm1_neg(float z) {
 //   sigmoid       : a = 1 / (1 + e^{-z}); act' = a (1 - a)
 // `act` is a kernel argument (wave-uniform): the chain below is scalar branches, elu first.
 __device__ __forceinline__ float act_fwd(float z, int act) {
-#ifdef ULTR_ACT2
-  if (act == 0) return z > 0.0f ? z : expm1_neg(z);
-  return fmaxf(z, 0.0f);
-#endif
   if (act <= 1) {  // elu / relu share one select: the negative branch is expm1(z) or 0 (wave-uniform factor)
     const float neg = expm1_neg(z) * (act == 0 ? 1.0f : 0.0f);
     return z > 0.0f ? z : neg;
@@ -132,16 +128,11 @@ __device__ __forceinline__ float act_fwd(float z, int act) {
 // the constants are scalar selects hoisted out of every loop, the per-element cost is two fmas, a compare and a select
 // (an if-chain over four formulas in the backward row passes cost config 3 8 us per step).
 __device__ __forceinline__ float act_grad_from_out(float a, int act) {
-#ifdef ULTR_ACT2
-  if (act == 0) return a > 0.0f ? 1.0f : (a + 1.0f);
-  return a > 0.0f ? 1.0f : 0.0f;
-#else
   const float thr = act < 2 ? 0.0f : __builtin_huge_valf();
   const float c0 = (act == 0 || act == 2) ? 1.0f : 0.0f;
   const float c1 = (act == 0 || act == 3) ? 1.0f : 0.0f;
   const float c2 = act >= 2 ? -1.0f : 0.0f;
   return a > thr ? 1.0f : fmaf(a, fmaf(a, c2, c1), c0);
-#endif
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -155,24 +146,13 @@ __device__ __forceinline__ void st4_stream(float* p, float4 v) {
   __builtin_nontemporal_store(x, reinterpret_cast<f32x4*>(p));
 }
 __device__ __forceinline__ void st1_stream(float* p, float v) { __builtin_nontemporal_store(v, p); }
-// bulk kernel OUTPUTS that only later launches read (saved activations, dz, GEMM results): streaming when ULTR_STREAM_OUT
-#ifndef ULTR_STREAM_OUT
-#define ULTR_STREAM_OUT 0
-#endif
+// bulk kernel OUTPUTS that only later launches read (saved activations, dz, GEMM results): plain stores (streaming stores lose at the
+// larger configs: config 4 437 -> 454 us, config 5 3.32 -> 3.34 ms - the consumer wants them in L2 / the memory-side cache)
 __device__ __forceinline__ void st2_out(float* p, float2 v) {
-#if ULTR_STREAM_OUT
-  const f32x2 x = {v.x, v.y};
-  __builtin_nontemporal_store(x, reinterpret_cast<f32x2*>(p));
-#else
   *reinterpret_cast<float2*>(p) = v;
-#endif
 }
 __device__ __forceinline__ void st4_out(float* p, float4 v) {
-#if ULTR_STREAM_OUT
-  st4_stream(p, v);
-#else
   st4(p, v);
-#endif
 }
 
 // masked 4-wide row load: elements [c, c+4) of a row of length `len`; vec => 16-byte aligned fast path
@@ -268,11 +248,7 @@ __device__ __forceinline__ float rsqrt_nr(float x) {
 // implements the fence as s_waitcnt vmcnt(0) lgkmcnt(0): every global store of an epilogue and every prefetched
 // global load would be drained at each phase boundary.  The kernels here never communicate through global memory
 // inside a launch, so waiting for the LDS queue is sufficient.
-#if ULTR_SYNC_BARRIER  // REPRO BUILDS ONLY (tools/h3_repro.sh): the full fence + barrier
-__device__ __forceinline__ void lds_barrier() { __syncthreads(); }
-#else
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-#endif
 
 // Canonical order of every cross-workgroup partial sum (slabs, loss partials): part k belongs to group k & 3; a group
 // adds its parts in chunks of 8, ((v0+v1)+(v2+v3))+((v4+v5)+(v6+v7)) with missing parts = 0, chunks accumulate in

@@ -689,19 +689,6 @@ extern "C" int ultr_trace_read(unsigned long long* host_out) {
 #ifndef BWD_SW
 #define BWD_SW 1  // dnn_bwd2_kernel: the dgrad products of layers >= 1 with >= 8 chunks stream the fragment-major copy of W_j
 #endif
-#ifndef WG_WT
-#define WG_WT 1   // dnn_wgrad_kernel: slabs leave with streaming stores (config 2: step 53.6 -> 53.1 us)
-#endif
-#ifndef RED_WT
-#define RED_WT 0  // grad_reduce_kernel: the flat gradient leaves with streaming stores
-#endif
-#ifndef FB_KAPF
-#define FB_KAPF 1  // dnn_fb_kernel: pull the kernel-argument segment into L2 with one vector load at the top (-0.2 us)
-#endif
-#ifndef FB_WT
-#define FB_WT 1  // dnn_fb_kernel: operands for the weight-gradient launch (u_j / xhat_0, dz_j) leave with write-through stores
-                 // (1: sc1 buffer stores, 2: nt; 0: plain) - config 2: step 55.4 -> 53.4 (sc1) / 53.6 (nt) us
-#endif
 #ifndef FWD_D
 #define FWD_D 2
 #endif
@@ -729,12 +716,9 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
   // marker word behind the saved activations: does saved.x_0 hold xhat_0 for the weight-gradient launch?  (the LayerNorm fast
   // path below writes it for inputs up to 256 wide; the launch then contracts layer 0 with it instead of gathering by id and
   // normalising again)
-#ifndef FWD_XHAT0_H3
-#define FWD_XHAT0_H3 1  // wider inputs too when layer 0 takes the split-half LayerNorm path (rows in registers there)
-#endif
   bool write_xhat0 = saved != nullptr && p.nl >= 2 && p.K[0] <= 256;
   if constexpr (VEC && (R == 16 || R == 32) && NW == 8)
-    write_xhat0 = write_xhat0 || (FWD_XHAT0_H3 && saved != nullptr && p.nl >= 2 && p.fwd_h3 != 0 && p.h3f[0] != 0 &&
+    write_xhat0 = write_xhat0 || (saved != nullptr && p.nl >= 2 && p.fwd_h3 != 0 && p.h3f[0] != 0 &&
                                   round_up(p.K[0], 32) <= 768);
   if (saved != nullptr && blockIdx.x == 0 && tid == 0) saved[p.sv_total] = write_xhat0 ? 1.f : 0.f;
   TRACE_STAMP(0);
@@ -2063,7 +2047,6 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
   auto rec_of = [&](int jj) { return sm_plan[jj * FbPlan::NFIELD + (lane & (FbPlan::NFIELD - 1))]; };  // lane = field
 #define FBF(rv, k) __builtin_amdgcn_readlane((rv), (k))
 #define FBF64(rv, k) ((int64_t)(((uint64_t)(uint32_t)FBF(rv, (k) + 1) << 32) | (uint64_t)(uint32_t)FBF(rv, (k))))
-#if FB_KAPF
   // The plans travel as kernel arguments (~2.7 KB = 43 cache lines in HBM) and are read with scalar loads at the top of every
   // layer of both loops (runtime-indexed records): each first touch of a line was a ~2k-cycle miss on the critical path of
   // every workgroup.  One vector load per workgroup (lane = line) pulls the whole segment into the XCD's L2 from the first
@@ -2076,7 +2059,6 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
     ka_pf = ka[(lane < KA_LINES ? lane : 0) * 16];
     if constexpr (KA_LINES > 64) ka_pf += ka[(lane + 64 < KA_LINES ? lane + 64 : 0) * 16];
   }
-#endif
 
   // ---- prologue: ids, loss inputs of this wave's list, parameter image, feature rows - all issued back to back -----
   {
@@ -2210,10 +2192,8 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
           // the weight gradients' operand goes to HBM from here: u_j, or xhat_0 for the layer-0 shortcut
           const int64_t svx = FBF64(rv, FbPlan::SV_X);
           float* wop = saved + svx + (n0 + r) * K;
-#if FB_WT == 1
           const Src svs = make_src(saved, p.sv_total);
           const unsigned wop_b = (unsigned)((svx + (n0 + r) * K) * 4);
-#endif
           const bool xhat_only = (j == 0) && bp.l0g != 0;
 #pragma unroll
           for (int u = 0; u < XC; ++u) {
@@ -2229,13 +2209,7 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
               } else {
                 st4(UZ + r * ld + c, uu);
               }
-#if FB_WT == 2
-              if (c < K && r < rows_valid) st4_stream(wop + c, xhat_only ? xh : uu);
-#elif FB_WT
               if (c < K && r < rows_valid) coh_st4(svs, wop_b + (unsigned)c * 4u, xhat_only ? xh : uu);
-#else
-              if (c < K && r < rows_valid) st4(wop + c, xhat_only ? xh : uu);
-#endif
             }
           }
         }
@@ -2594,13 +2568,7 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
               } else {
                 st4(DZ + r * ldz + c, dz);
               }
-#if FB_WT == 2
-              if (r < rows_valid) st4_stream(dzg + (n0 + r) * K + c, dz);
-#elif FB_WT
               if (r < rows_valid) coh_st4(make_src(ws, bp.total), (unsigned)((dzo + (n0 + r) * K + c) * 4), dz);
-#else
-              if (r < rows_valid) st4(dzg + (n0 + r) * K + c, dz);
-#endif
             }
           }
           if constexpr (!H3)
@@ -2634,9 +2602,7 @@ __global__ __launch_bounds__(512) void dnn_fb_kernel(DnnPlan p, BwdPlan bp, cons
   }
   finalize(jlow);
   TRACE_STAMP(13);
-#if FB_KAPF
   asm volatile("" ::"v"(ka_pf));
-#endif
 #undef FBF
 #undef FBF64
 }
@@ -2968,11 +2934,7 @@ __global__ __launch_bounds__(256) void dnn_wgrad_kernel(DnnPlan p, BwdPlan bp, c
     if (m < M && k < K) {
       float* dst = slab + (int64_t)m * K + k;
       if (vec && k + 3 < K) {
-#if WG_WT
         st4_stream(dst, s);
-#else
-        st4(dst, s);
-#endif
       } else {
         dst[0] = s.x;
         if (k + 1 < K) dst[1] = s.y;
@@ -3357,11 +3319,7 @@ __global__ __launch_bounds__(512) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan bp
           l0pb.x += w.x * Sm; l0pb.y += w.y * Sm; l0pb.z += w.z * Sm; l0pb.w += w.w * Sm;
           v.x = g4.x * v.x + b4.x * Sm; v.y = g4.y * v.y + b4.y * Sm; v.z = g4.z * v.z + b4.z * Sm; v.w = g4.w * v.w + b4.w * Sm;
         }
-#if WG_WT
         st4_stream(slab + (int64_t)m * K + kq, v);
-#else
-        st4(slab + (int64_t)m * K + kq, v);
-#endif
       }
     }
     if (kb2 == 0 && sk == 0 && tid < 64 && mB + tid < M) slab[(int64_t)M * K + mB + tid] = sm_bsum[64 * sm_ + tid] + sm_bsum[128 + 64 * sm_ + tid];
@@ -3429,11 +3387,7 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(RedPlan rp, int64_t P,
       while (s + 1 < rp.nseg && e >= rp.seg[s + 1].off) ++s;
       const RedSeg sg = rp.seg[s];
       g = full_sum(ws + sg.base + (e - sg.off), sg.stride, sg.nparts);
-#if RED_WT
-      st1_stream(grads + e, g);
-#else
       grads[e] = g;
-#endif
     }
     // the product must be ROUNDED before the first cross-lane add: left alone (and with __fmul_rn as well) hipcc turns
     // `g * g + shuffled(g * g)` into an fma in this variant and not in the other - one-ulp different partials, a different clip

@@ -1345,9 +1345,6 @@ __global__ __launch_bounds__(SR_MAXT * 64) void sr_attn_bwd_f16_kernel(const flo
 // the largest gradient entry at config 5 (bar: 1e-5 relative + 2e-6 of the largest), scores bit for bit those of the fp32 forward.
 // Config 5: 3 020 -> 2 866 us with the backward kernel (383 -> 309 us per launch); a forward kernel on top gave 2 845 and failed the bar above.
 // ---------------------------------------------------------------------------------------------------------
-#ifndef SRS_NO_MIX
-#define SRS_NO_MIX 1
-#endif
 __device__ __forceinline__ float srs_pow2_scale(float amax, int target_exp) {  // amax * scale < 2^target_exp
   int se = 253 + target_exp - (int)((__float_as_uint(amax) >> 23) & 0xffu);
   se = se < 1 ? 1 : (se > 253 ? 253 : se);
@@ -1381,14 +1378,10 @@ __device__ __forceinline__ void srs_store(const float4 (&v)[DH / 16], float scal
     for (int j = 0; j < 4; ++j) {
       hi[j] = (_Float16)a[j];
       float r1 = a[j] - (float)hi[j];
-#if SRS_NO_MIX
       asm volatile("" : "+v"(r1));  // keeps hipcc from fusing the subtraction and the conversion into v_fma_mix*_f16
-#endif
       lo[j] = (_Float16)r1;
       float r2 = r1 - (float)lo[j];
-#if SRS_NO_MIX
       asm volatile("" : "+v"(r2));
-#endif
       l3[j] = (_Float16)r2;
     }
     *reinterpret_cast<h4*>(rh + r * LDH + c4) = hi;
@@ -1414,9 +1407,7 @@ __device__ __forceinline__ void srs_pack(const f32x4& a, const f32x4& b, float s
     const _Float16 h = (_Float16)v;
     hi[j] = h;
     float r1 = v - (float)h;
-#if SRS_NO_MIX
     asm volatile("" : "+v"(r1));
-#endif
     lo[j] = (_Float16)r1;
   }
 }

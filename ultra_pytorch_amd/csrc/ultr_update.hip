@@ -14,9 +14,6 @@
 #include "ultr_plan.h"
 #include "ultr_prof.h"
 
-#ifndef UPD_WT
-#define UPD_WT 0  // parameters / optimizer state / weight copies leave with streaming stores
-#endif
 __device__ __forceinline__ float block_sum256(float v, float* sm) {
   v = wave_sum(v);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -163,13 +160,8 @@ __device__ __forceinline__ void update_body(const ultr_update_desc& u, const Dnn
       g *= coef;
       float s_new = s_old;
       const float pn = opt_step(p_old, g, &s_new, u.optimizer, stateless || state == nullptr, u.learning_rate, u.adagrad_eps);
-#if UPD_WT
-      st1_stream(params + e, pn);
-      if (state != nullptr && !stateless && u.optimizer != ULTR_OPT_SGD) st1_stream(state + e, s_new);
-#else
       params[e] = pn;
       if (state != nullptr && !stateless && u.optimizer != ULTR_OPT_SGD) state[e] = s_new;
-#endif
       p_new_a[k] = pn;
     }
   }
