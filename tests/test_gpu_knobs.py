@@ -25,7 +25,6 @@ KNOB_SETS = [
     ("ULTR_FWD_NW=4 ULTR_BWD_NW=4", "cfg3_dla"),       # general-shape kernels with 4 waves
     ("ULTR_FWD_NW=16 ULTR_BWD_NW=16", "cfg3_dla"),
     ("ULTR_NO_VEC=1", "cfg3_dla"),                     # the unaligned-shape (scalar load) builds on aligned shapes
-    ("ULTR_NO_L0G=1", "cfg3_dla"),                     # layer-0 dgrad computed instead of the shortcut
     ("ULTR_FWD_Q4=0", "cfg4_pairdebias"),
     ("ULTR_WGRAD_WGS=300", "cfg3_dla"),
     ("ULTR_FB_H3=0 ULTR_FWD_H3=0 ULTR_BWD_H3=0 ULTR_WG_H3=0", "cfg4_pairdebias"),  # every product on the fp32 matrix cores

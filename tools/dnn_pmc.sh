@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: SQ counter passes over bench.py's workload, summed per kernel -> stdout
 R=$GRAFT_REPO_ROOT; cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extras --no-other-configs --spinup-ms 0"
+CMD="python $R/bench.py ${DNN_PMC_ARGS:---steps 200 --warmup 20} --no-cpu-baseline --no-extras --no-other-configs --spinup-ms 0"
 i=0
 for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS" \
            "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM"; do

@@ -3505,7 +3505,7 @@ __global__ __launch_bounds__(64) void grad_sumsq_kernel(int64_t P, const float* 
 // per knob per launch is host time on the critical path of a ~50 us step.  ultr_config_reload() re-reads them (tests and
 // the A/B tools flip knobs inside one process).
 struct Knobs {
-  int fwd_r, bwd_r, wgrad_wgs, fwd_nw, bwd_nw, no_vec, no_l0g, no_fused_fb, fb_max_wg_per_cu, fwd_q4, big_fwd, big_bwd, fb_h3, fwd_h3, bwd_h3, wg_h3, wg_h3_min_rows, wg_h3_wgs;
+  int fwd_r, bwd_r, wgrad_wgs, fwd_nw, bwd_nw, no_vec, no_fused_fb, fb_max_wg_per_cu, fwd_q4, big_fwd, big_bwd, fb_h3, fwd_h3, bwd_h3, wg_h3, wg_h3_min_rows, wg_h3_wgs;
   bool loaded;
 };
 static Knobs g_knobs = {};
@@ -3521,7 +3521,6 @@ static void knobs_load() {
   k.fwd_nw = env_read("ULTR_FWD_NW", 8);
   k.bwd_nw = env_read("ULTR_BWD_NW", 8);
   k.no_vec = env_read("ULTR_NO_VEC", 0);
-  k.no_l0g = env_read("ULTR_NO_L0G", 0);
   k.no_fused_fb = env_read("ULTR_NO_FUSED_FB", 0);
   k.fb_max_wg_per_cu = env_read("ULTR_FB_MAX_WG_PER_CU", 1);
   k.fwd_q4 = env_read("ULTR_FWD_Q4", 1);
@@ -4164,7 +4163,7 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
   DnnPlan p;
   BwdPlan bp;
   if (!ultr_make_dnn_plan(d, N, &p) || !ultr_make_bwd_plan(p, N, &bp)) return ULTR_E_BADARG;
-  const bool l0g_ok = p.nl >= 2 && knobs().no_l0g == 0;
+  const bool l0g_ok = p.nl >= 2;  // the layer-0 shortcut whenever there is a hidden layer (its A/B knob of round 1 is gone: the explicit du_0 path had rotted)
   const int tail = (int)ultr_tail_len(list_size);
   if (tail > 4096) return ULTR_E_UNSUPPORTED;
   const size_t lds = bwd_lds_bytes(p, bp.rblk);
@@ -4360,7 +4359,7 @@ extern "C" int ultr_dnn_backward_softmax(const ultr_dnn_desc* d, const float* pa
     BwdPlan bp0;
     const bool planned = dscores_out && batch > 0 && list_size > 0 && ultr_make_dnn_plan(d, N, &p) && ultr_make_bwd_plan(p, N, &bp0);
     if (planned && (big_bwd_wanted(p, N) || bwd_lds_bytes(p, bp0.rblk) > 160 * 1024) && knobs().big_bwd != 0 &&
-        knobs().no_l0g == 0 && knobs().no_vec == 0 && ultr_dnn_big_ok(p, N, n_docs)) {
+        knobs().no_vec == 0 && ultr_dnn_big_ok(p, N, n_docs)) {
       const int rc = ultr_softmax_ce(scores, labels, pw, ipw_table, n_ipw, batch, list_size, dscores_out, loss_ws, stream);
       if (rc) return rc;
       FusedSoftmax none = {nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
@@ -4406,7 +4405,7 @@ int ultr_fused_step_softmax(const ultr_dnn_desc* d, const float* params, const f
                   p.sv_total * 4 < ((int64_t)1 << 31) && p.P * 4 < ((int64_t)1 << 31);
   if (!ok) return ULTR_E_UNSUPPORTED;
   bp.nrb = (int)nblk;
-  bp.l0g = (p.nl >= 2 && knobs().no_l0g == 0) ? 1 : 0;  // must match backward_impl's choice
+  bp.l0g = p.nl >= 2 ? 1 : 0;  // must match backward_impl's choice
   bp.wg_prenorm = 1;
   hipStream_t st = (hipStream_t)stream;
   FusedSoftmax fl = {nullptr, labels, pw, ipw_table, (int)n_ipw, dscores_out, (float*)loss_ws};
