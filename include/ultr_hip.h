@@ -348,10 +348,12 @@ int ultr_ndcg(const float* scores, const float* labels, const int32_t* docids, i
  * with features = the resident matrix.  query_idx (may be NULL) [B] = the sampled queries.  Counter-based RNG:
  * the batch is a pure function of (seed, step).  Parity with the Python feed is distributional.
  * ABI 6: click_model = ULTR_CLICK_PBM (click_models.py:68-110) or ULTR_CLICK_CASCADE (:187-236: the same draw per position, every
- * position behind the first click reports no click).  A changing bias severity (dynamic_bias_eta_change, click_simulation_feed.py:
+ * position behind the first click reports no click) or ULTR_CLICK_UBM.  A changing bias severity (dynamic_bias_eta_change, click_simulation_feed.py:
  * 165-172) is the caller's new exam_prob table. */
 #define ULTR_CLICK_PBM 0
 #define ULTR_CLICK_CASCADE 1
+#define ULTR_CLICK_UBM 2 /* user-browsing model (click_models.py:113-186): exam_prob = dense [n_exam][n_exam] image of the triangular
+                          * table exam[rank][distance - 1] (distance to the last click; entries beyond the diagonal unused) */
 int ultr_click_batch(const int32_t* lists, const float* labels, int64_t n_queries, int32_t lmax, int64_t n_docs,
                      const float* exam_prob, int32_t n_exam, const float* click_prob, int32_t n_rel, int32_t click_model,
                      uint64_t seed, uint64_t step, int32_t batch, int32_t list_size, int32_t max_tries, int32_t* docids,

@@ -158,3 +158,38 @@ def test_dynamic_bias_eta_change_on_the_device():
         sigma = np.sqrt(np.maximum(hr * (1 - hr), 1e-4) * 2 / dv.shape[1])
         assert np.all(np.abs(dr - hr) < 5 * sigma + 1e-3), (dr, hr)
     assert np.abs(d_new.mean(1) - d_old.mean(1)).max() > 0.02  # a steeper position bias
+
+
+def test_user_browsing_model_on_the_device():
+    """The user-browsing model (click_models.py:113-186: examination depends on the rank AND the distance to the last click)
+    through ultr_click_batch: per-position click rates and the distribution of the GAP between consecutive clicks (what the
+    rank x distance table shapes) agree with the host feed - bit-exact with the reference's - to 5 sigma; lists of 14 documents
+    reach beyond the 10-row table (its last row is reused)."""
+    import os
+    from ultra_pytorch_amd import synthetic
+    from ultra_pytorch_amd.input_layer import ClickSimulationFeed, DeviceClickFeed
+    F, L, B = 8, 14, 4096
+    ds = DS(300, (8, 14), F, seed=8)
+    ds.pad(L)
+    model = Model(F, L)
+    hp = "click_model_json=%s" % os.path.join(os.path.dirname(synthetic.PBM_JSON), "ubm_0.1_1_4_1.0.json")
+    dev_clicks = _rates(DeviceClickFeed(model, B, hp, seed=21), ds, model, L, 8, host=False)
+    random.seed(13)
+    host_clicks = _rates(ClickSimulationFeed(model, B, hp), ds, model, L, 8, host=True)
+    assert set(np.unique(dev_clicks)) <= {0.0, 1.0} and (dev_clicks.sum(0) > 0).all()
+    n = dev_clicks.shape[1]
+
+    def close(a, b, what):
+        sigma = np.sqrt(np.maximum(b * (1 - b), 1e-4) * 2 / n)
+        assert np.all(np.abs(a - b) < 5 * sigma + 1e-3), (what, a, b)
+
+    close(dev_clicks.mean(1), host_clicks.mean(1), "per-position click rates")
+
+    def gap_hist(c):  # P(gap = g) over lists, gap = distance between the first two clicks (0: fewer than two)
+        out = np.zeros(L)
+        for col in c.T:
+            pos = np.flatnonzero(col)
+            out[pos[1] - pos[0] if len(pos) >= 2 else 0] += 1
+        return out / c.shape[1]
+
+    close(gap_hist(dev_clicks), gap_hist(host_clicks), "gap between the first two clicks")

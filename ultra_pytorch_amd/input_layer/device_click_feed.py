@@ -51,15 +51,14 @@ class DeviceClickFeed(object):
             alt = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", os.path.basename(path))
             path = alt if os.path.exists(alt) else path
         desc = json.load(open(path))
-        if desc["model_name"] not in ("position_biased_model", "cascade_model"):
-            raise NotImplementedError("DeviceClickFeed simulates the position-biased and the cascade model (the user-browsing model "
-                                      "is served by the host feed, input_layer.ClickSimulationFeed)")
+        if desc["model_name"] not in ("position_biased_model", "cascade_model", "user_browsing_model"):
+            raise NotImplementedError("DeviceClickFeed simulates the position-biased, the cascade and the user-browsing model")
         self.click_model = click_models.loadModelFromJson(desc)  # host twin: owns eta and the examination table
-        self.model_id = 1 if desc["model_name"] == "cascade_model" else 0
+        self.model_id = {"position_biased_model": 0, "cascade_model": 1, "user_browsing_model": 2}[desc["model_name"]]
         self.model, self.batch_size = model, int(batch_size)
         self.rank_list_size = model.rank_list_size
         self.device = model.cuda
-        self.exam = torch.tensor(self.click_model.exam_prob, dtype=torch.float32, device=self.device)
+        self.exam, self.n_exam = self._exam_tensor()
         self.global_batch_count = 0
         self.cprob = torch.tensor(desc["click_prob"], dtype=torch.float32, device=self.device)
         self.seed, self.step = int(seed), 0
@@ -69,6 +68,16 @@ class DeviceClickFeed(object):
         self.docids = torch.empty(L, B, dtype=torch.int32, device=self.device)
         self.clicks = torch.empty(L, B, dtype=torch.float32, device=self.device)
         self.qidx = torch.empty(B, dtype=torch.int32, device=self.device)
+
+    def _exam_tensor(self):
+        """The examination table on the device: [n] for PBM / cascade, a dense [n][n] image of the triangular rank x distance table
+        for the user-browsing model (ULTR_CLICK_UBM)."""
+        ep = self.click_model.exam_prob
+        if self.model_id == 2:
+            n = len(ep)
+            dense = [[(row[c] if c < len(row) else 0.0) for c in range(n)] for row in ep]
+            return torch.tensor(dense, dtype=torch.float32, device=self.device).contiguous(), n
+        return torch.tensor(ep, dtype=torch.float32, device=self.device), len(ep)
 
     @staticmethod
     def preprocess_data(data_set, hparam_str, exp_settings):
@@ -84,7 +93,7 @@ class DeviceClickFeed(object):
         rd = self.resident(data_set)
         vp = lambda t: ctypes.c_void_p(t.data_ptr())
         rc = self.lib.ultr_click_batch(vp(rd.lists), vp(rd.labels), rd.n_queries, rd.lmax, rd.n_docs, vp(self.exam),
-                                       int(self.exam.numel()), vp(self.cprob), int(self.cprob.numel()), self.model_id, self.seed, self.step,
+                                       self.n_exam, vp(self.cprob), int(self.cprob.numel()), self.model_id, self.seed, self.step,
                                        self.batch_size, self.rank_list_size, int(self.hparams.max_tries) if check_validation else 1,
                                        vp(self.docids), vp(self.clicks), vp(self.qidx),
                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
@@ -96,7 +105,7 @@ class DeviceClickFeed(object):
         if self.hparams.dynamic_bias_eta_change != 0 and self.global_batch_count % self.hparams.dynamic_bias_step_interval == 0:
             self.click_model.eta += self.hparams.dynamic_bias_eta_change
             self.click_model.setExamProb(self.click_model.eta)
-            self.exam = torch.tensor(self.click_model.exam_prob, dtype=torch.float32, device=self.device)
+            self.exam, self.n_exam = self._exam_tensor()
         feed = {"device_feed": True, "features": rd.features, "n_docs": rd.n_docs, "docids": self.docids,
                 "labels": self.clicks, "batch_size": self.batch_size}
         return feed, {"rank_list_idxs": self.qidx}
