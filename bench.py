@@ -1074,7 +1074,7 @@ def main():
             tj = json.load(open(tfile))
             traffic = tj.get(kname if dnn else "setrank_whole_step")
             traffic_source = "file profiles/traffic.json (%s): rocprofv3 FETCH_SIZE/WRITE_SIZE passes of an earlier run of this " \
-                             "command, NOT measured in this process" % tj.get("_source", "tools/profile_round.sh")
+                             "command, NOT measured in this process" % tj.get("_source" if dnn else "_source_setrank", "tools/profile_round.sh")
         out = {
             "metric": "queries/sec (training step)", "value": world * B * args.steps / elapsed, "unit": "queries/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
