@@ -118,6 +118,11 @@ int ultr_dnn_build_wt(const ultr_dnn_desc* d, const float* params, float* wt, vo
  * in fp32), so the caller switches to the fp32 products (ULTR_FB_H3=0 ULTR_FWD_H3=0 ULTR_BWD_H3=0 + ultr_config_reload) when
  * this is not 0.  During training the same information arrives with the step report (host_scalars[8]). */
 int ultr_dnn_wt_range(const ultr_dnn_desc* d, const float* wt, void* stream);
+/* Which forward kernel ultr_dnn_forward launches for n_rows = batch x list_size rows when it is given aligned operands and the
+ * weight copies (host-only, for tests and the bench line): 16 / 32 = dnn_fwd_kernel with that many rows per workgroup,
+ * 1000 + R = the wide-tile kernel dnn_fwdw_kernel with R = 17 .. 48 rows per workgroup (round 5), 0 = the per-layer path
+ * (training forward only), < 0 = bad descriptor. */
+int32_t ultr_dnn_forward_tile_rows(const ultr_dnn_desc* d, int64_t n_rows, int32_t training);
 
 /* ---- a5 (backward half): what loss.backward() does for the DNN ----------------------
  * Replaces autograd through DNN.sequential (called from BaseAlgorithm.opt_step,

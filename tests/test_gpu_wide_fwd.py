@@ -1,0 +1,106 @@
+"""dnn_fwdw_kernel - the wide-tile forward (17 .. 48 rows per workgroup behind one split-half weight stream, round 5) - against the
+oracle's DNN forward (DNN.py:41-88, base_algorithm.py:118-154): scores at 1e-5, and through the saved activations / statistics it
+leaves for the backward, the gradients of a whole softmax step at the bar of tests/test_gpu_full_size.py.  Shapes pick every
+code path: two and three MFMA row tiles, a ragged last workgroup, chunks x slices of the contraction (fewer than sixteen
+32-column chunks, odd slice counts), more chunks than waves, one / two / three float4 per lane in the LayerNorms, PAD documents,
+evaluation (nothing saved), every activation."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.hipref import HipRun  # noqa: E402
+
+SHAPES = {
+    # name: (F, hidden, B, L, act, n_pad)
+    "cfg3_three_tiles": (136, [512, 256, 128], 512, 20, "elu", 0),        # 40 rows x 256 workgroups
+    "two_tiles_ragged": (136, [256, 256], 300, 23, "elu", 2),             # 27 rows, the last workgroup holds 15
+    "cfg4_wide_input": (700, [512, 256, 128], 256, 50, "elu", 0),         # 25 rows x 512 workgroups, three float4 per lane
+    "odd_slices": (220, [96, 64], 200, 40, "relu", 3),                    # 3 and 2 chunks: 4 and 3 slices of the contraction
+    "chunks_beyond_waves": (136, [768, 32], 256, 40, "tanh", 0),          # 24 chunks on 16 waves; then ONE chunk in 12 slices
+    "sigmoid_narrow": (48, [64, 64, 32], 128, 60, "sigmoid", 5),
+}
+
+
+def tile_rows(F, hidden, act, n_rows, training=True):
+    from ultra_pytorch_amd import _lib, hip_ops
+    shape = hip_ops.DnnShape(F, hidden, act)
+    return _lib.load().ultr_dnn_forward_tile_rows(shape.desc, n_rows, 1 if training else 0)
+
+
+def inputs(name):
+    from oracle import ultr_oracle as O
+    from ultra_pytorch_amd import synthetic
+    F, hidden, B, L, act, n_pad = SHAPES[name]
+    rng = np.random.RandomState(11)
+    feats, ids, y = synthetic.make_batch(rng, B, L, F, clicks=True, n_pad=n_pad)
+    params = O.init_params(F, hidden, seed=5)
+    # LayerNorm affine parameters away from their (1, 0) initial values, a few weights large
+    lay = O.param_layout(F, hidden)
+    for n, s, o in lay:
+        k = int(np.prod(s))
+        if "layer_norm" in n:
+            params[o:o + k] += rng.normal(scale=0.2, size=k).astype(np.float32)
+    return feats, ids, y, params
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+@pytest.mark.parametrize("train", [True, False], ids=["train", "eval"])
+def test_wide_forward_scores_match_oracle(name, train):
+    from oracle import ultr_oracle as O
+    F, hidden, B, L, act, n_pad = SHAPES[name]
+    R = tile_rows(F, hidden, act, B * L, train)
+    assert R > 1000, "shape does not take the wide-tile kernel (ultr_dnn_forward_tile_rows = %d)" % R
+    R -= 1000
+    feats, ids, y, params = inputs(name)
+    run = HipRun(F, hidden, B, L, algo="softmax", act=act)
+    run.set_inputs(feats, ids, y)
+    scores = run.forward(params, train=train)
+    ref = O.ranking_scores(torch.from_numpy(params), F, hidden, feats, ids, act).numpy()
+    print("%s: %d rows per workgroup, max |score diff| %.2e" % (name, R, np.abs(scores - ref).max()))
+    np.testing.assert_allclose(scores, ref, atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+def test_wide_forward_feeds_the_backward(name):
+    """forward (wide tiles) -> softmax loss -> backward: the gradients come out of what the forward saved (xhat_0, the
+    activations, the LayerNorm statistics of every layer)"""
+    from oracle import ultr_oracle as O
+    F, hidden, B, L, act, n_pad = SHAPES[name]
+    assert tile_rows(F, hidden, act, B * L) > 1000
+    feats, ids, y, params = inputs(name)
+    run = HipRun(F, hidden, B, L, algo="softmax", act=act)
+    run.set_inputs(feats, ids, y)
+    run.forward(params)
+    ds, tail = run.loss()
+    g, tail2 = run.backward()
+    gs = 1.0 / tail2[1]
+    x = O.gather_rows(feats, ids).numpy()
+    dsc = (ds * gs).T.reshape(-1)
+    gref = O.dnn_backward_manual(params, F, hidden, x, dsc, act)
+    terms = O.dnn_backward_manual(params, F, hidden, x, dsc, act, abs_terms=True)
+    d = np.abs(g * gs - gref)
+    print("%s: max |g - g_ref| / (|g_ref| + terms) = %.2e" % (name, (d / np.maximum(np.abs(gref) + terms, 1e-30)).max()))
+    assert (d <= 1e-5 * (np.abs(gref) + terms)).all()
+
+
+def test_wide_forward_is_deterministic_and_knob_switches_it_off(monkeypatch):
+    from ultra_pytorch_amd import _lib
+    F, hidden, B, L, act, n_pad = SHAPES["cfg3_three_tiles"]
+    feats, ids, y, params = inputs("cfg3_three_tiles")
+    run = HipRun(F, hidden, B, L, algo="softmax", act=act)
+    run.set_inputs(feats, ids, y)
+    a = run.forward(params)
+    b = run.forward(params)
+    assert np.array_equal(a, b)
+    monkeypatch.setenv("ULTR_FWD_WIDE", "0")
+    _lib.load().ultr_config_reload()
+    try:
+        assert tile_rows(F, hidden, act, B * L) == 16
+        c = run.forward(params)
+    finally:
+        monkeypatch.undo()
+        _lib.load().ultr_config_reload()
+    # the 16-row kernel sums the same products in another order (no slices of the contraction, other tile shapes)
+    np.testing.assert_allclose(a, c, atol=2e-6)

@@ -670,12 +670,21 @@ __device__ unsigned long long g_ultr_trace[64 * 32];
     if (threadIdx.x == 0 && (blockIdx.x & 31) == 0 && (slot) < 32 && (blockIdx.x >> 5) < 64)        \
       g_ultr_trace[(blockIdx.x >> 5) * 32 + (slot)] = __builtin_amdgcn_s_memtime();                 \
   } while (0)
+// the same with the constant 100 MHz counter every XCD shares (s_memrealtime): when did the workgroup start / end inside the launch
+#define TRACE_REAL(slot)                                                                            \
+  do {                                                                                              \
+    if (threadIdx.x == 0 && (blockIdx.x & 31) == 0 && (slot) < 32 && (blockIdx.x >> 5) < 64)        \
+      g_ultr_trace[(blockIdx.x >> 5) * 32 + (slot)] = __builtin_amdgcn_s_memrealtime();             \
+  } while (0)
 extern "C" int ultr_trace_read(unsigned long long* host_out) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ultr_trace), sizeof(unsigned long long) * 64 * 32);
 }
 #else
 #define TRACE_STAMP(slot) \
   do {                    \
+  } while (0)
+#define TRACE_REAL(slot) \
+  do {                   \
   } while (0)
 #endif
 
@@ -718,7 +727,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
   // normalising again)
   bool write_xhat0 = saved != nullptr && p.nl >= 2 && p.K[0] <= 256;
   if constexpr (VEC && (R == 16 || R == 32) && NW == 8)
-    write_xhat0 = write_xhat0 || (saved != nullptr && p.nl >= 2 && p.fwd_h3 != 0 && p.h3f[0] != 0 &&
+    write_xhat0 = write_xhat0 || (saved != nullptr && p.nl >= 2 && p.fwd_h3 != 0 && p.h3f[0] == 1 &&
                                   round_up(p.K[0], 32) <= 768);
   if (saved != nullptr && blockIdx.x == 0 && tid == 0) saved[p.sv_total] = write_xhat0 ? 1.f : 0.f;
   TRACE_STAMP(0);
@@ -846,7 +855,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
     // ---- LayerNorm (biased variance, eps 1e-5, affine), in place; two-pass statistics -----------
     bool scored = false;
     bool h3 = false;
-    if constexpr (VEC && RT == 1 && NW == 8) h3 = p.fwd_h3 != 0 && j < p.nl - 1 && p.h3f[j] != 0 && K16 <= 768;  // (32-row tiles behind one split-half stream were built and lost: profiles/r04_cfg2_attempts.md)
+    if constexpr (VEC && RT == 1 && NW == 8) h3 = p.fwd_h3 != 0 && j < p.nl - 1 && p.h3f[j] == 1 && K16 <= 768;  // (32-row tiles behind one split-half stream were built and lost: profiles/r04_cfg2_attempts.md)
     if (h3) {
       if constexpr (VEC && RT == 1 && NW == 8) {
        auto ln_h3 = [&](auto xc_tag) {
@@ -1214,6 +1223,443 @@ __global__ __launch_bounds__(NW * 64) void dnn_fwd_kernel(DnnPlan p, const float
       }
       TRACE_STAMP(3 + 3 * j);
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward, wide row tiles (round 5)
+// ------------------------------------------------------------------------------------------------
+// dnn_fwd_kernel streams every weight once per 16 rows and is bound by exactly that stream (31 - 32 B/clk per CU through the
+// L2 -> L1 path, the matrix cores a third busy) - and its 16-row tiles quantise badly: config 3 = 640 tiles on 512 slots, config 4 =
+// 800 on 256.  This kernel gives a workgroup R = 17 .. 64 rows, chosen by the host so that the grid is a whole number of rounds
+// (config 3: 40 rows x 256 workgroups), as RT = ceil(R / 16) MFMA row tiles behind ONE weight stream: every B fragment feeds RT
+// row tiles (6 RT MFMAs of 16 cycles per 4 KiB of weights).  Sixteen waves; every hidden layer on the split-half copies
+// (DnnPlan::h3f, value 2 = fewer than eight chunks: chunks x slices of the contraction, partial tiles summed in fixed order);
+// the activations ping-pong between two LDS buffers sized per layer PARITY (not 2 x the widest layer), a LayerNorm turns the
+// fp32 rows of its input buffer into the two fp16 planes in place; the gathered feature rows go from HBM through registers
+// straight into LayerNorm_0 (no fp32 staging tile).
+struct WidePlan {
+  int R;                   // rows per workgroup
+  int buf[2];              // float offsets of the two activation buffers in dynamic LDS (layer j reads buf[j & 1])
+  int pv;                  // float offset of the vector-parameter image, followed by the 64 per-row output scales
+  int ksplit[ULTR_MAXL];   // slices of layer j's contraction (waves = chunks x slices)
+  int kslen[ULTR_MAXL];    // 32-deep steps per slice
+};
+
+#ifndef FWDW_DEPTH
+#define FWDW_DEPTH 2  // weight steps (4 KiB per wave) in flight per wave
+#endif
+template <int RT, int D>
+struct PipeH3W {
+  float4 b[D][4];
+  unsigned of;
+  int left;
+  template <int S>
+  __device__ __forceinline__ void fetch(const Src& W) {
+    const bool ok = left > 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) b[S][u] = buf_ld4(W, ok ? (of + (unsigned)u * 1024u) : ULTR_OOB);
+    --left;
+    of += 4096u;
+  }
+  // steps [ks0, ks0 + cnt) of chunk `chunk` (nks steps per chunk in the copy)
+  __device__ __forceinline__ void begin(const Src& W, int chunk, int nks, int ks0, int cnt, bool valid, int lane) {
+    of = (((unsigned)chunk * (unsigned)nks + (unsigned)ks0) * 256u + (unsigned)lane) * 16u;
+    left = valid ? cnt : 0;
+    fetch<0>(W);
+    if constexpr (D > 2) fetch<1>(W);
+    static_assert(D >= 2 && D <= 3, "pipeline depth");
+  }
+  // pa[rt]: this lane's A row of row tile rt in the hi plane (+ lo_off halves: the lo plane), at the current step.
+  // ONE accumulator per output tile: ah.wh, ah.wl and al.wh are added into it in three sweeps over the RT x 2 tiles (a dependent
+  // MFMA is 2 .. 4 instructions behind its predecessor).  The 8-wave kernels keep the cross terms in their own accumulators; here
+  // 16 waves share the register file (128 per wave) and a second accumulator set is what spilled (each reload a memory round trip
+  // in the middle of the stream).  The sum is the same three products in fp32; scores move by < 1e-6 (tests/test_gpu_wide_fwd.py).
+  template <int S>
+  __device__ __forceinline__ void consume(const _Float16* const (&pa)[RT], int lo_off, int kofs, f32x4 (&acc)[RT][2]) {
+#pragma unroll
+    for (int r0 = 0; r0 < RT; r0 += 2) {
+      constexpr int NP = 2;
+      fbh8 ah[NP], al[NP];
+#pragma unroll
+      for (int d = 0; d < NP; ++d)
+        if (r0 + d < RT) {
+          ah[d] = *reinterpret_cast<const fbh8*>(pa[r0 + d] + kofs);
+          al[d] = *reinterpret_cast<const fbh8*>(pa[r0 + d] + lo_off + kofs);
+        }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int d = 0; d < NP; ++d)
+          if (r0 + d < RT) acc[r0 + d][t] = fb_mfma_h(al[d], fb_as_h8(b[S][2 * t]), acc[r0 + d][t]);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int d = 0; d < NP; ++d)
+          if (r0 + d < RT) acc[r0 + d][t] = fb_mfma_h(ah[d], fb_as_h8(b[S][2 * t + 1]), acc[r0 + d][t]);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int d = 0; d < NP; ++d)
+          if (r0 + d < RT) acc[r0 + d][t] = fb_mfma_h(ah[d], fb_as_h8(b[S][2 * t]), acc[r0 + d][t]);
+    }
+  }
+  __device__ __forceinline__ void run(const _Float16* const (&pa)[RT], int lo_off, const Src& W, int cnt, f32x4 (&acc)[RT][2]) {
+    int kofs = 0;
+    auto step = [&](auto uc) {
+      constexpr int U = decltype(uc)::value;
+      fetch<(U + D - 1) % D>(W);
+      __builtin_amdgcn_sched_barrier(0);
+      consume<U>(pa, lo_off, kofs, acc);
+      kofs += 32;
+    };
+    int t = 0;
+    for (; t + D <= cnt; t += D) {
+      step(std::integral_constant<int, 0>());
+      step(std::integral_constant<int, 1>());
+      if constexpr (D > 2) step(std::integral_constant<int, 2>());
+    }
+    if (t < cnt) { consume<0>(pa, lo_off, kofs, acc); kofs += 32; }
+    if constexpr (D > 2) if (t + 1 < cnt) { consume<1>(pa, lo_off, kofs, acc); kofs += 32; }
+  }
+};
+
+// stores through a buffer resource: the address is (wave-uniform descriptor) + a 32-bit lane offset + a scalar offset, and rows past
+// the end of the described extent are dropped by the hardware range check - no 64-bit address per unrolled store, no branches
+// around the stores of a ragged tile (per-store 64-bit addresses + their spill reloads were 36k of this kernel's first 147k cycles)
+struct Dst {
+  __amdgpu_buffer_rsrc_t rs;
+};
+__device__ __forceinline__ Dst make_dst(float* base, int64_t nfloats) {
+  Dst d;
+  d.rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(nfloats * 4), 0x00020000);
+  return d;
+}
+__device__ __forceinline__ void buf_st4(const Dst& d, unsigned voff, unsigned soff, float4 v) {
+  const u32x4 x = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(x, d.rs, voff, soff, 0);
+}
+__device__ __forceinline__ void buf_st2(const Dst& d, unsigned voff, unsigned soff, float2 v) {
+  const u32x2 x = {__float_as_uint(v.x), __float_as_uint(v.y)};
+  __builtin_amdgcn_raw_buffer_store_b64(x, d.rs, voff, soff, 0);
+}
+__device__ __forceinline__ void buf_st1(const Dst& d, unsigned voff, unsigned soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), d.rs, voff, soff, 0);
+}
+
+template <int RT>
+__global__ __launch_bounds__(1024) void dnn_fwdw_kernel(DnnPlan p, WidePlan wp, const float* __restrict__ features, int64_t n_docs,
+                                                        const int32_t* __restrict__ docids, int B, int L,
+                                                        float* __restrict__ scores, float* __restrict__ saved,
+                                                        const float* __restrict__ wt) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NW = 16, NT = NW * 64, PVR = 2;
+  const int R = wp.R;  // the buffers hold R + 1 rows: row R takes whatever the rows R .. 16 RT - 1 of the last MFMA tile produce
+  const int64_t N = (int64_t)B * L;
+  float* PV = smem + wp.pv;
+  float* OS = PV + p.pv_total;  // per-row output scale of the current product (64 floats)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t n0 = (int64_t)blockIdx.x * R;
+  const int vr = (int)((N - n0) < R ? (N - n0) : R);  // rows of this workgroup that exist
+  const bool train = saved != nullptr;
+  const int64_t tr = train ? 1 : 0;  // evaluation: every descriptor of `saved` has zero extent
+  float* sbase = train ? saved : scores;
+  if (train && blockIdx.x == 0 && tid == 0) saved[p.sv_total] = 1.f;  // saved.x_0 holds xhat_0 (see dnn_fwd_kernel)
+  TRACE_STAMP(0);
+  TRACE_REAL(30);
+
+  // ---- prologue: ids -> packed vector-parameter image -> feature rows, all in flight before anything is written to LDS ------
+  // lane q < RT of a wave holds the id of its row  wave + 16 q; the rows go to buffer 0 as fp32 (LayerNorm_0 reads them like
+  // every later LayerNorm reads its input)
+  {
+    const int rme = wave + NW * (lane < RT ? lane : 0);
+    const bool idok = lane < RT && rme < vr;
+    const uint32_t nme = idok ? (uint32_t)(n0 + rme) : 0u;
+    const int bb = (int)(nme / (uint32_t)L), ll = (int)(nme % (uint32_t)L);
+    const int myid_raw = docids[(int64_t)ll * B + bb];
+    const Src pvs = make_src(wt + p.wt_pv_off, p.pv_total);
+    float4 pvr[PVR];
+#pragma unroll
+    for (int u = 0; u < PVR; ++u) pvr[u] = buf_ld4(pvs, (unsigned)(tid + u * NT) * 16u);
+    const int myid = (idok && myid_raw >= 0 && myid_raw < n_docs) ? myid_raw : -1;
+    const int F = p.K[0], F16 = round_up(F, 32), ld0 = F16 + 8;
+    const Src fs = make_src(features, n_docs * F);
+    float4 fr[RT][3];
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+      const int id = __builtin_amdgcn_readlane(myid, q);
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int c = 4 * lane + 256 * u;
+        fr[q][u] = buf_ld4(fs, (id >= 0 && c < F) ? (unsigned)(((int64_t)id * F + c) * 4) : ULTR_OOB);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PVR; ++u) {
+      const int o = (tid + u * NT) * 4;
+      if (o < p.pv_total) st4(PV + o, pvr[u]);
+    }
+    float* X0 = smem + wp.buf[0];
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+      const int r = wave + NW * q, rc = r < R ? r : R;
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int c = 4 * lane + 256 * u;
+        if (c < F16) st4(X0 + rc * ld0 + c, fr[q][u]);
+      }
+    }
+  }
+  lds_barrier();
+  TRACE_STAMP(1);
+
+  int pv_off = 0;
+  for (int j = 0; j < p.nl; ++j) {
+    const DnnPlan::FwdLayer lay = p.fl[j];
+    const int K = lay.K, M = lay.M;
+    const int K16 = round_up(K, 32);
+    const int ldh = K16 + 8;  // halves per plane row = floats per fp32 row of the same buffer
+    const float* lnw = PV + pv_off;
+    const float* lnb = PV + pv_off + K;
+    const float* bias = PV + pv_off + 2 * K;
+    pv_off += 2 * K + M;
+    float* Bin = smem + wp.buf[j & 1];
+    float* Bout = smem + wp.buf[(j + 1) & 1];
+    const bool last = j == p.nl - 1;
+    const float invK = 1.0f / (float)K;
+    const Dst d_mean = make_dst(sbase + tr * (lay.sv_mean + n0), tr * vr), d_rstd = make_dst(sbase + tr * (lay.sv_rstd + n0), tr * vr);
+
+    // ---- LayerNorm_j: the wave's rows in registers (a lane owns columns 4 lane + 256 u); hidden layers: the normalised rows
+    // go back over the buffer as two fp16 planes scaled per row by a power of two; last layer: the scorer is folded in
+    auto ln = [&](auto xc_tag) {
+      constexpr int XC = decltype(xc_tag)::value;
+      float4 xq[RT][XC];
+      float s[RT], v[RT];
+#pragma unroll
+      for (int q = 0; q < RT; ++q) {
+        const int r = wave + NW * q;
+        const float* row = Bin + (r < R ? r : R) * ldh;
+#pragma unroll
+        for (int u = 0; u < XC; ++u) {
+          const int c = 4 * lane + 256 * u;
+          xq[q][u] = (c < K) ? ld4(row + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < RT; ++q) {
+        s[q] = 0.f;
+#pragma unroll
+        for (int u = 0; u < XC; ++u) s[q] += (xq[q][u].x + xq[q][u].y) + (xq[q][u].z + xq[q][u].w);
+      }
+      wave_sum_n<RT>(s);
+#pragma unroll
+      for (int q = 0; q < RT; ++q) {
+        s[q] *= invK;
+        v[q] = 0.f;
+#pragma unroll
+        for (int u = 0; u < XC; ++u) {
+          const int c = 4 * lane + 256 * u;
+          float4& x = xq[q][u];
+          if (c < K) {
+            x.x -= s[q]; x.y -= s[q]; x.z -= s[q]; x.w -= s[q];
+          }
+          v[q] += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+        }
+      }
+      wave_sum_n<RT>(v);
+      lds_barrier();  // every wave holds its rows: the planes may overwrite them
+      const unsigned l0 = lane == 0 ? 0u : ULTR_OOB;
+      if (!last) {
+        _Float16* AH = reinterpret_cast<_Float16*>(Bin);
+        _Float16* AL = AH + (R + 1) * ldh;
+        const Dst d_x0 = make_dst(sbase + tr * (p.sv_x[0] + n0 * K), (j == 0 ? tr : 0) * (int64_t)vr * K);
+        float am[RT];
+#pragma unroll
+        for (int q = 0; q < RT; ++q) {
+          const int r = wave + NW * q;
+          const float rstd = rsqrt_nr(v[q] * invK + ULTR_LN_EPS);
+          am[q] = 0.f;
+#pragma unroll
+          for (int u = 0; u < XC; ++u) {
+            const int c = 4 * lane + 256 * u;
+            float4& x = xq[q][u];
+            if (c < K) {
+              const float4 g = ld4(lnw + c), be = ld4(lnb + c);
+              const float4 xh = make_float4(x.x * rstd, x.y * rstd, x.z * rstd, x.w * rstd);
+              buf_st4(d_x0, (unsigned)c * 4u, (unsigned)(r * K) * 4u, xh);  // layer 0, training: xhat_0 for the weight gradients
+              x = make_float4(xh.x * g.x + be.x, xh.y * g.y + be.y, xh.z * g.z + be.z, xh.w * g.w + be.w);
+              am[q] = fmaxf(am[q], fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w))));
+            }
+          }
+          buf_st1(d_mean, l0, (unsigned)r * 4u, s[q]);
+          buf_st1(d_rstd, l0, (unsigned)r * 4u, rstd);
+        }
+        wave_max_n<RT>(am);
+#pragma unroll
+        for (int q = 0; q < RT; ++q) {
+          const int r = wave + NW * q, rc = r < R ? r : R;
+          float rs, inv;
+          fb_h3_scale(am[q], rs, inv);
+#pragma unroll
+          for (int u = 0; u < XC; ++u) {
+            const int c = 4 * lane + 256 * u;
+            if (c < K16) {
+              fbh4 hi, lo;
+              fb_h3_split4(xq[q][u], rs, hi, lo);
+              *reinterpret_cast<fbh4*>(AH + rc * ldh + c) = hi;
+              *reinterpret_cast<fbh4*>(AL + rc * ldh + c) = lo;
+            }
+          }
+          if (lane == 0) OS[r] = inv * (1.0f / ULTR_H3_WSCALE);
+        }
+      } else {
+        // score = rstd * sum_c (x_c - mean) gamma_c w_c + sum_c beta_c w_c + b
+        const float* wl = PV + pv_off;  // the scorer's weight row
+        const Dst d_sc = make_dst(scores + n0, vr);
+        float t[RT + 1];
+        t[RT] = 0.f;
+#pragma unroll
+        for (int q = 0; q < RT; ++q) t[q] = 0.f;
+#pragma unroll
+        for (int u = 0; u < XC; ++u) {
+          const int c = 4 * lane + 256 * u;
+          if (c < K) {
+            const float4 g = ld4(lnw + c), be = ld4(lnb + c), w = ld4(wl + c);
+            t[RT] += (be.x * w.x + be.y * w.y) + (be.z * w.z + be.w * w.w);
+#pragma unroll
+            for (int q = 0; q < RT; ++q) {
+              const float4 x = xq[q][u];
+              t[q] += (x.x * (g.x * w.x) + x.y * (g.y * w.y)) + (x.z * (g.z * w.z) + x.w * (g.w * w.w));
+            }
+          }
+        }
+        wave_sum_n<RT + 1>(t);
+#pragma unroll
+        for (int q = 0; q < RT; ++q) {
+          const int r = wave + NW * q;
+          const float rstd = rsqrt_nr(v[q] * invK + ULTR_LN_EPS);
+          buf_st1(d_mean, l0, (unsigned)r * 4u, s[q]);
+          buf_st1(d_rstd, l0, (unsigned)r * 4u, rstd);
+          buf_st1(d_sc, l0, (unsigned)r * 4u, rstd * t[q] + t[RT] + bias[0]);
+        }
+      }
+    };
+    if (K16 <= 256) ln(std::integral_constant<int, 1>());
+    else if (K16 <= 512) ln(std::integral_constant<int, 2>());
+    else ln(std::integral_constant<int, 3>());
+    TRACE_STAMP(2 + 3 * j);
+    if (last) {
+      TRACE_REAL(31);
+      break;
+    }
+    lds_barrier();
+    TRACE_STAMP(3 + 3 * j);
+
+    // ---- Linear_j + activation: Y = act((Ah + Al) . (Wh + Wl) x scales + b), 32-column chunks ----------------------------------
+    {
+      const int nks = K16 >> 5, nch = M >> 5;
+      const int ldy = round_up(M, 32) + 8;
+      const _Float16* AH = reinterpret_cast<const _Float16*>(Bin);
+      const int lo_off = (R + 1) * ldh;
+      const Src Wh = make_src(wt + p.whf_off[j], (int64_t)K16 * M);
+      const Dst d_y = make_dst(sbase + tr * (lay.sv_x_next + n0 * M), tr * (int64_t)vr * M);  // saved x_{j+1} rows of this workgroup
+      const int i = lane & 15, q = lane >> 4;
+      const _Float16* pa[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const int row = 16 * rt + i;
+        pa[rt] = AH + (row < R ? row : R) * ldh + 8 * q;
+      }
+      // this lane's rows 16 rt + 4 q + r of the output tile: LDS row (the rows beyond R collapse onto row R), byte offset in `saved`
+      int yrow[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) yrow[rt] = 16 * rt + 4 * q;
+      const unsigned gv = (unsigned)(4 * q * M + 2 * i) * 4u;
+      const int ksplit = wp.ksplit[j];
+      PipeH3W<RT, FWDW_DEPTH> ph;
+      if (ksplit == 1) {
+        ph.begin(Wh, wave, nks, 0, nks, wave < nch, lane);
+        for (int ch = wave; ch < nch; ch += NW) {
+          f32x4 acc[RT][2];
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          ph.run(pa, lo_off, Wh, nks, acc);
+          if (ch + NW < nch) ph.begin(Wh, ch + NW, nks, 0, nks, true, lane);
+          const int col = 32 * ch + 2 * i;
+          const float2 bv = *reinterpret_cast<const float2*>(bias + col);
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            const float4 o4 = ld4(OS + 16 * rt + 4 * q);
+            const float o[4] = {o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = yrow[rt] + r;
+              const int rc = (rt < RT - 1 || row < R) ? row : R;
+              const float2 y = make_float2(act_fwd(acc[rt][0][r] * o[r] + bv.x, p.act), act_fwd(acc[rt][1][r] * o[r] + bv.y, p.act));
+              *reinterpret_cast<float2*>(Bout + rc * ldy + col) = y;
+              buf_st2(d_y, gv, (unsigned)((16 * rt + r) * M + 32 * ch) * 4u, y);
+            }
+          }
+        }
+      } else {
+        // chunks x slices of the contraction: wave = slice * nch + chunk; the raw partial tiles are summed into the output buffer
+        // slice by slice (fixed order), then every thread applies scale, bias and activation
+        int ks = 0, ch = wave;
+        while (ch >= nch) { ch -= nch; ++ks; }
+        const bool has = ks < ksplit;
+        const int k0 = ks * wp.kslen[j];
+        const int cnt = has ? ((k0 + wp.kslen[j] < nks) ? wp.kslen[j] : (nks - k0)) : 0;
+        f32x4 acc[RT][2];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) pa[rt] += 32 * k0;
+        ph.begin(Wh, ch, nks, k0, cnt, has, lane);
+        ph.run(pa, lo_off, Wh, cnt, acc);
+        const int col = 32 * ch + 2 * i;
+        for (int sl = 0; sl < ksplit; ++sl) {
+          if (has && ks == sl) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int row = yrow[rt] + r;
+                const int rc = (rt < RT - 1 || row < R) ? row : R;
+                float2* dst = reinterpret_cast<float2*>(Bout + rc * ldy + col);
+                float2 y = make_float2(acc[rt][0][r], acc[rt][1][r]);
+                if (sl > 0) {
+                  const float2 o = *dst;
+                  y.x += o.x;
+                  y.y += o.y;
+                }
+                *dst = y;
+              }
+          }
+          lds_barrier();
+        }
+#pragma unroll
+        for (int qq = 0; qq < RT; ++qq) {
+          const int row = wave + NW * qq, rc = row < R ? row : R;
+          const float os = OS[row];
+          for (int c = 4 * lane; c < M; c += 256) {
+            float4 y = ld4(Bout + rc * ldy + c);
+            const float4 b4 = ld4(bias + c);
+            y.x = act_fwd(y.x * os + b4.x, p.act);
+            y.y = act_fwd(y.y * os + b4.y, p.act);
+            y.z = act_fwd(y.z * os + b4.z, p.act);
+            y.w = act_fwd(y.w * os + b4.w, p.act);
+            st4(Bout + rc * ldy + c, y);
+            buf_st4(d_y, (unsigned)c * 4u, (unsigned)(row * M) * 4u, y);
+          }
+        }
+      }
+    }
+    TRACE_STAMP(4 + 3 * j);
+    lds_barrier();
   }
 }
 
@@ -3505,7 +3951,7 @@ __global__ __launch_bounds__(64) void grad_sumsq_kernel(int64_t P, const float* 
 // per knob per launch is host time on the critical path of a ~50 us step.  ultr_config_reload() re-reads them (tests and
 // the A/B tools flip knobs inside one process).
 struct Knobs {
-  int fwd_r, bwd_r, wgrad_wgs, fwd_nw, bwd_nw, no_vec, no_fused_fb, fb_max_wg_per_cu, fwd_q4, big_fwd, big_bwd, fb_h3, fwd_h3, bwd_h3, wg_h3, wg_h3_min_rows, wg_h3_wgs;
+  int fwd_r, bwd_r, wgrad_wgs, fwd_nw, bwd_nw, no_vec, no_fused_fb, fb_max_wg_per_cu, fwd_q4, big_fwd, big_bwd, fb_h3, fwd_h3, bwd_h3, wg_h3, wg_h3_min_rows, wg_h3_wgs, fwd_wide;
   bool loaded;
 };
 static Knobs g_knobs = {};
@@ -3534,6 +3980,7 @@ static void knobs_load() {
   k.wg_h3 = env_read("ULTR_WG_H3", 1);                    // weight gradients on the fp16 matrix cores (split-half operands); 2: any batch size
   k.wg_h3_min_rows = env_read("ULTR_WG_H3_MIN_ROWS", 4096);
   k.wg_h3_wgs = env_read("ULTR_WG_H3_WGS", 0);
+  k.fwd_wide = env_read("ULTR_FWD_WIDE", 1);  // dnn_fwdw_kernel (17 .. 64 rows per workgroup) where the 16-row tiles would need more than one round; 0: never
   k.loaded = true;
   g_knobs = k;
 }
@@ -3638,9 +4085,11 @@ bool ultr_make_dnn_plan(const ultr_dnn_desc* d, int64_t N, DnnPlan* p) {
       bool h3 = true;
       for (int j = 0; j < p->nl - 1; ++j) {
         const int64_t n = (int64_t)round_up(p->K[j], 32) * round_up(p->M[j], 32);
-        p->h3f[j] = (p->M[j] >= 256) ? 1 : 0;
+        // 1: eight or more 32-column chunks (the 8-wave kernels take the layer on the split-half stream); 2: fewer - only the wide-tile
+        // forward (dnn_fwdw_kernel: 16 waves, chunks x slices of the contraction) reads that copy
+        p->h3f[j] = (p->M[j] >= 256) ? 1 : 2;
         p->h3b[j] = (j >= 1 && p->K[j] >= 256 && p->K[j] % 32 == 0) ? 1 : 0;
-        h3 = h3 && p->h3f[j] && (j == 0 || p->h3b[j]);
+        h3 = h3 && p->h3f[j] == 1 && (j == 0 || p->h3b[j]);
         if (p->h3f[j]) {
           p->whf_off[j] = o;
           o += n;
@@ -3659,7 +4108,7 @@ bool ultr_make_dnn_plan(const ultr_dnn_desc* d, int64_t N, DnnPlan* p) {
       p->fwd_h3 = 0;
       if (knobs().fwd_h3 && !p->no_h3)
         for (int j = 0; j < p->nl - 1; ++j)
-          if (p->h3f[j] && round_up(p->K[j], 32) <= 768) p->fwd_h3 = 1;
+          if (p->h3f[j] == 1 && round_up(p->K[j], 32) <= 768) p->fwd_h3 = 1;
     }
     // the range word of the hidden weights (every model with a hidden layer: the per-layer big-batch path builds split-half planes of
     // ANY hidden layer, ultr_dnn_big.hip); zeroed by ultr_dnn_build_wt
@@ -4025,7 +4474,7 @@ static bool big_fwd_wanted(const DnnPlan& p, int64_t N, size_t row_tile_lds) {
   if (p.K[0] <= 512 || p.nl < 2) return false;
   // round 3: with its first layer on the split-half copies the row-tile forward wins that case too (config 4, 800 tiles:
   // 218 us per-layer, 225 row tiles in fp32, 151 row tiles with the split-half products)
-  if (p.fwd_h3 && p.h3f[0] && round_up(p.K[0], 32) <= 768) return false;
+  if (p.fwd_h3 && p.h3f[0] == 1 && round_up(p.K[0], 32) <= 768) return false;
   const int cus = dnn_device_cus();
   const int per_cu = row_tile_lds > 80 * 1024 ? 1 : (row_tile_lds > 53 * 1024 ? 2 : 3);
   const int64_t slots = (int64_t)per_cu * cus, tiles = (N + 15) / 16, full = tiles / slots, rem = tiles % slots;
@@ -4038,6 +4487,44 @@ static bool big_bwd_wanted(const DnnPlan& p, int64_t N) {
   const bool v2 = knobs().bwd_nw == 8 && p.maxdim <= 512 &&
                   bwd2_lds_floats(p, bwd_rows_per_wg(p, N), 8) * sizeof(float) <= 160 * 1024;
   return N >= (v2 ? 16384 : 4096);
+}
+
+// dnn_fwdw_kernel: which shapes take it, and with how many rows per workgroup.  Legal: every hidden layer has its split-half
+// forward copy (widths multiples of 32) and no LayerNorm is wider than 768 (three float4 per lane).  Rows: as many as the LDS holds
+// (two buffers sized per layer parity + the parameter image), at most 64; then the smallest R that still covers the batch in the
+// same number of rounds of one workgroup per CU.  Taken when that is more than the 16 rows of dnn_fwd_kernel.
+static bool fwd_wide_plan(const DnnPlan& p, int64_t N, WidePlan* wp, size_t* lds_bytes) {
+  if (knobs().fwd_wide == 0 || knobs().fwd_h3 == 0 || p.no_h3 || p.nl < 2 || !p.sw_ok || p.pv_total > 2 * 1024 * 4) return false;
+  if (knobs().fwd_r != 0 || knobs().fwd_nw != 8) return false;  // an explicit tile geometry of the row-tile kernel was asked for
+  int w[2] = {0, 0};
+  for (int j = 0; j < p.nl; ++j) {
+    const int k16 = round_up(p.K[j], 32);
+    if (k16 > 768 || (j < p.nl - 1 && p.h3f[j] == 0)) return false;
+    if (k16 + 8 > w[j & 1]) w[j & 1] = k16 + 8;
+  }
+  const int64_t fixed = ((int64_t)p.pv_total + 64) * 4, per_row = (int64_t)(w[0] + w[1]) * 4;
+  int64_t rmax = (160 * 1024 - fixed) / per_row - 1;  // the buffers hold R + 1 rows (dnn_fwdw_kernel: the rows of the last MFMA tile beyond R land in row R)
+  if (rmax > 48) rmax = 48;  // three MFMA row tiles (four: 29 spilled registers at sixteen waves)
+  if (rmax < 17) return false;
+  const int64_t cus = dnn_device_cus();
+  const int64_t rounds = (N + cus * rmax - 1) / (cus * rmax);
+  const int64_t R = (N + cus * rounds - 1) / (cus * rounds);
+  if (R <= 16) return false;
+  memset(wp, 0, sizeof(*wp));
+  wp->R = (int)R;
+  wp->buf[0] = 0;
+  wp->buf[1] = (int)(R + 1) * w[0];
+  wp->pv = (int)(R + 1) * (w[0] + w[1]);
+  for (int j = 0; j < p.nl - 1; ++j) {
+    const int nks = round_up(p.K[j], 32) / 32, nch = p.M[j] / 32;
+    int ks = nch >= 16 ? 1 : 16 / nch;
+    if (ks > nks) ks = nks;
+    const int len = (nks + ks - 1) / ks;
+    wp->kslen[j] = len;
+    wp->ksplit[j] = (nks + len - 1) / len;
+  }
+  *lds_bytes = (size_t)(wp->pv + p.pv_total + 64) * sizeof(float);
+  return true;
 }
 
 template <typename KernelT>
@@ -4070,6 +4557,25 @@ extern "C" int ultr_dnn_forward(const ultr_dnn_desc* d, const float* params, con
       knobs().big_fwd != 0 && (big_fwd_wanted(p, N, lds) || lds > 160 * 1024))
     return ultr_dnn_big_forward(p, params, wt, features, n_docs, docids, (int)batch, (int)list_size, scores, (float*)saved, st,
                                 prof.on ? prof.a : nullptr, prof.on ? prof.b : nullptr, knobs().fwd_h3 != 0 && !p.no_h3 && wt != nullptr);
+  {
+    WidePlan wp;
+    size_t wlds = 0;
+    if (av && wt != nullptr && fwd_wide_plan(p, N, &wp, &wlds)) {
+      const int rt = (wp.R + 15) / 16;
+      const dim3 wgrid((unsigned)((N + wp.R - 1) / wp.R));
+#define LAUNCH_FWDW(RTT)                                                                                                        \
+  do {                                                                                                                          \
+    e = set_lds(dnn_fwdw_kernel<RTT>, wlds);                                                                                    \
+    if (e != hipSuccess) return (int)e;                                                                                         \
+    ULTR_LAUNCH(prof, (dnn_fwdw_kernel<RTT>), wgrid, dim3(1024), wlds, st, p, wp, features, n_docs, docids, (int)batch,         \
+                (int)list_size, scores, (float*)saved, wt);                                                                     \
+  } while (0)
+      if (rt == 2) LAUNCH_FWDW(2);
+      else LAUNCH_FWDW(3);
+#undef LAUNCH_FWDW
+      return (int)hipGetLastError();
+    }
+  }
   if (lds > 160 * 1024) return ULTR_E_UNSUPPORTED;
 #define LAUNCH_FWD(RR, NWW, VV)                                                                                     \
   do {                                                                                                              \
@@ -4099,6 +4605,18 @@ extern "C" int ultr_dnn_forward(const ultr_dnn_desc* d, const float* params, con
 #undef LAUNCH_FWD2
 #undef LAUNCH_FWD
   return (int)hipGetLastError();
+}
+
+extern "C" int32_t ultr_dnn_forward_tile_rows(const ultr_dnn_desc* d, int64_t n_rows, int32_t training) {
+  DnnPlan p;
+  if (n_rows <= 0 || !ultr_make_dnn_plan(d, n_rows, &p)) return -1;
+  const int R = fwd_rows_per_wg(p, n_rows);
+  const size_t lds = fwd_lds_bytes(p, R);
+  if (training && ultr_dnn_big_ok(p, n_rows, n_rows) && knobs().big_fwd != 0 && (big_fwd_wanted(p, n_rows, lds) || lds > 160 * 1024)) return 0;
+  WidePlan wp;
+  size_t wlds = 0;
+  if (knobs().no_vec == 0 && fwd_wide_plan(p, n_rows, &wp, &wlds)) return 1000 + wp.R;
+  return R;
 }
 
 bool ultr_wgrad_h3_geometry(int64_t T, int M, int K, int* nsplit, int* rows_per_split) {
