@@ -123,6 +123,9 @@ int ultr_dnn_wt_range(const ultr_dnn_desc* d, const float* wt, void* stream);
  * 1000 + R = the wide-tile kernel dnn_fwdw_kernel with R = 17 .. 48 rows per workgroup (round 5), 0 = the per-layer path
  * (training forward only), < 0 = bad descriptor. */
 int32_t ultr_dnn_forward_tile_rows(const ultr_dnn_desc* d, int64_t n_rows, int32_t training);
+/* ... and the row-local backward kernel of ultr_train_step (aligned operands, dscores from a loss kernel): 16 / 32 = dnn_bwd2_kernel /
+ * dnn_bwd_kernel, 1000 + R = the wide-tile kernel dnn_bwdw_kernel, 0 = the per-layer path. */
+int32_t ultr_dnn_backward_tile_rows(const ultr_dnn_desc* d, int64_t n_rows);
 
 /* ---- a5 (backward half): what loss.backward() does for the DNN ----------------------
  * Replaces autograd through DNN.sequential (called from BaseAlgorithm.opt_step,

@@ -1,9 +1,11 @@
-"""dnn_fwdw_kernel - the wide-tile forward (17 .. 48 rows per workgroup behind one split-half weight stream, round 5) - against the
+"""dnn_fwdw_kernel / dnn_bwdw_kernel - the wide-tile forward and row-local backward (17 .. 48 rows per workgroup behind one
+split-half weight stream, round 5).  The forward against the
 oracle's DNN forward (DNN.py:41-88, base_algorithm.py:118-154): scores at 1e-5, and through the saved activations / statistics it
 leaves for the backward, the gradients of a whole softmax step at the bar of tests/test_gpu_full_size.py.  Shapes pick every
 code path: two and three MFMA row tiles, a ragged last workgroup, chunks x slices of the contraction (fewer than sixteen
 32-column chunks, odd slice counts), more chunks than waves, one / two / three float4 per lane in the LayerNorms, PAD documents,
-evaluation (nothing saved), every activation."""
+evaluation (nothing saved), every activation.  The backward runs inside ultr_train_step (it needs the weight copies): one whole step
+(IPW softmax, whose loss then runs as its own launch, and DLA) against the oracle's step (ipw_rank.py:102-182, dla.py:179-266)."""
 import numpy as np
 import pytest
 import torch
@@ -104,3 +106,48 @@ def test_wide_forward_is_deterministic_and_knob_switches_it_off(monkeypatch):
         _lib.load().ultr_config_reload()
     # the 16-row kernel sums the same products in another order (no slices of the contraction, other tile shapes)
     np.testing.assert_allclose(a, c, atol=2e-6)
+
+
+def backward_tile_rows(F, hidden, act, n_rows):
+    from ultra_pytorch_amd import _lib, hip_ops
+    return _lib.load().ultr_dnn_backward_tile_rows(hip_ops.DnnShape(F, hidden, act).desc, n_rows)
+
+
+@pytest.mark.parametrize("name", [k for k in SHAPES if k != "chunks_beyond_waves"])  # (a 768-wide LayerNorm: the per-layer backward)
+@pytest.mark.parametrize("algo", ["softmax", "dla"])
+def test_wide_backward_step_matches_oracle(name, algo):
+    from oracle import ultr_oracle as O
+    from ultra_pytorch_amd import engine, hip_ops, synthetic
+    from tests.hipref import dev
+    F, hidden, B, L, act, n_pad = SHAPES[name]
+    R = backward_tile_rows(F, hidden, act, B * L)
+    assert R > 1000, "shape does not take the wide-tile backward (ultr_dnn_backward_tile_rows = %d)" % R
+    feats, ids, y, params = inputs(name)
+    rng = np.random.RandomState(3)
+    lr = 0.05
+    if algo == "softmax":
+        aux = None
+        ref = O.train_step_softmax(params, np.zeros_like(params), F, hidden, feats, ids, y, ipw_list=synthetic.load_ipw(), lr=lr, act=act)
+    else:
+        aux = rng.normal(scale=0.2, size=L + 1).astype(np.float32)
+        ref = O.dla_step(params, aux, F, hidden, feats, ids, y, lr=lr, act=act)
+    shape = hip_ops.DnnShape(F, hidden, act)
+    eng = engine.StepEngine(shape, B, L, torch.device("cuda"), algo=algo, learning_rate=lr)
+    p = dev(params)
+    st = None if algo == "dla" else dev(np.zeros_like(params))
+    a = None if aux is None else dev(aux)
+    tab = dev(np.asarray(synthetic.load_ipw(), np.float32)) if algo == "softmax" else None
+    eng.train_step(p, st, dev(feats), feats.shape[0], dev(ids, torch.int32), dev(y), aux=a, ipw_table=tab)
+    sc = eng.read_scalars()
+    scores = eng.scores.cpu().numpy()
+    np.testing.assert_allclose(scores, ref["scores"], atol=1e-5, rtol=1e-5)
+    assert abs(sc[0] - ref["loss"]) <= 1e-5 * max(1.0, abs(ref["loss"]))
+    n = shape.n_params
+    tail = eng.grads[n:].cpu().numpy()
+    gs = 1.0 / tail[1]
+    g, gref = eng.grads[:n].cpu().numpy() * gs, ref["grads"]
+    d = np.abs(g - gref)
+    print("%s / %s: %d rows per workgroup, max |g - g_ref| / max|g_ref| = %.2e" % (name, algo, R - 1000, d.max() / np.abs(gref).max()))
+    np.testing.assert_allclose(g, gref, rtol=1e-5, atol=1e-5 * float(np.abs(gref).max()))  # (the bar of tests/test_gpu_knobs.py)
+    assert abs(sc[1] - ref["norm"]) <= 1e-5 * ref["norm"]
+    eng.close()

@@ -65,6 +65,7 @@ SIGNATURES = {
     "ultr_dnn_build_wt": (c_i32, [ctypes.POINTER(DnnDesc), c_vp, c_vp, c_vp]),
     "ultr_dnn_wt_range": (c_i32, [ctypes.POINTER(DnnDesc), c_vp, c_vp]),
     "ultr_dnn_forward_tile_rows": (c_i32, [ctypes.POINTER(DnnDesc), c_i64, c_i32]),
+    "ultr_dnn_backward_tile_rows": (c_i32, [ctypes.POINTER(DnnDesc), c_i64]),
     "ultr_dnn_backward": (c_i32, [ctypes.POINTER(DnnDesc), c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp,
                                   c_vp, c_vp]),
     "ultr_dnn_backward_softmax": (c_i32, [ctypes.POINTER(DnnDesc), c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp,

@@ -2222,7 +2222,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
       const int nch = p.bwd_nch[j], msplit = p.bwd_msplit[j], mode = p.bwd_mode[j];
       bool sw_done = false;
       if constexpr (RT == 1) {
-        if (h3on && wt != nullptr && j >= 1 && p.h3b[j] != 0) {
+        if (h3on && wt != nullptr && j >= 1 && p.h3b[j] == 1) {
           // split-half copy of W_j (DnnPlan::whb_off) against the two planes of dz_j the row pass left in DZ
           const int nks = M >> 5;
           const _Float16* AH = reinterpret_cast<const _Float16*>(DZ);
@@ -2312,7 +2312,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
       const float invK = 1.0f / (float)K;
       float mean[RPW], rstd[RPW], dsr[RPW], dus[RPW];
       // du_j came out of the split-half product unscaled: its rows still carry the row scale of the dz planes
-      const bool du_scaled = h3on && !last && j >= 1 && p.h3b[j] != 0;
+      const bool du_scaled = h3on && !last && j >= 1 && p.h3b[j] == 1;
 #pragma unroll
       for (int k = 0; k < RPW; ++k) {
         const int r = wave + NW * k;
@@ -2371,7 +2371,7 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
         wave_sum_n<2 * RPW>(red);
         float* dzg = ws + bp.dz_off[j - 1];
         // dz_{j-1} feeds the dgrad product of layer j-1: as two fp16 planes when that layer has a split-half copy
-        const bool hz = h3on && j >= 2 && p.h3b[j - 1] != 0;
+        const bool hz = h3on && j >= 2 && p.h3b[j - 1] == 1;
         float amz[RPW];
 #pragma unroll
         for (int k = 0; k < RPW; ++k) {
@@ -2431,6 +2431,306 @@ __global__ __launch_bounds__(NW * 64) void dnn_bwd2_kernel(DnnPlan p, BwdPlan bp
     lds_barrier();
   }
   finalize(jlow);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward, row-local half - wide row tiles (round 5)
+// ------------------------------------------------------------------------------------------------
+// The counterpart of dnn_fwdw_kernel for the training step (ultr_train_step hands over the weight copies): R = 17 .. 48 rows per
+// workgroup so that the grid is whole rounds of one workgroup per CU (config 3: 40 rows x 256 workgroups where dnn_bwd2_kernel ran
+// 640 16-row tiles as three rounds), sixteen waves, every dgrad product du_j = dz_j . W_j on the split-half copies (DnnPlan::whb_off)
+// with RT = ceil(R / 16) row tiles behind one weight stream.  Same outputs as dnn_bwd2_kernel: dz_j in HBM for the weight-gradient
+// launch, one vector slab (d gamma_j, d beta_j, the scorer's dW / db) per workgroup.  Needs the layer-0 shortcut (BwdPlan::l0g: du_0
+// is never formed), dscores from a loss kernel, and LayerNorms of layers >= 1 at most 512 wide.
+//   row pass j (top .. 1): a wave owns rows wave + 16 q; x_j, the statistics and gamma_j come straight from `saved` / the
+//     parameter image into registers (no LDS tile), du_j from the product's LDS tile (or ds x w for the scorer); dz_{j-1} goes to
+//     HBM and - as two fp16 planes scaled per row - to LDS for the next product; the per-wave column partials of d gamma / d beta
+//     overlay the du tile once every wave has read its rows, and are folded in wave order.
+//   product j (top-1 .. 1): 32-column chunks of K_j x slices of the contraction M_j when there are fewer than sixteen chunks.
+struct WideBwd {
+  int R;
+  int dz, du, ds;         // float offsets in dynamic LDS: dz planes [(R + 1)][M_j + 8] x 2 halves; du tile [(R + 1)][K_j + 8] (and the
+                          // column partials [16][2 or 3][K_j]); ds[64] followed by the per-row plane scales [64]
+  int ksplit[ULTR_MAXL];  // product j: slices of its contraction
+  int kslen[ULTR_MAXL];   // 32-deep steps per slice
+};
+
+template <int RT>
+__global__ __launch_bounds__(1024) void dnn_bwdw_kernel(DnnPlan p, BwdPlan bp, WideBwd wb, const float* __restrict__ saved,
+                                                        const float* __restrict__ dscores, float* __restrict__ ws,
+                                                        const float* __restrict__ wt) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NW = 16, NT = NW * 64;
+  const int R = wb.R;
+  const int64_t N = bp.N;
+  float* DZ = smem + wb.dz;
+  float* DU = smem + wb.du;
+  float* CP = DU;
+  float* DS = smem + wb.ds;
+  float* OS = DS + 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t n0 = (int64_t)blockIdx.x * R;
+  const int vr = (int)((N - n0) < R ? (N - n0) : R);
+  float* vslab = ws + bp.vslab_off + (int64_t)blockIdx.x * bp.vlen;
+  const Src svs = make_src(saved, p.sv_total);
+  const Src pvs = make_src(wt + p.wt_pv_off, p.pv_total);
+  const int top = p.nl - 1;
+  TRACE_STAMP(0);
+  TRACE_REAL(30);
+  // lane q < RT of a wave speaks for its row  wave + 16 q
+  const int rme = wave + NW * (lane < RT ? lane : 0);
+  const bool rowok_l = lane < RT && rme < vr;
+  const Src dss = make_src(dscores + n0, vr);
+  const float ds_l = buf_ld1(dss, rowok_l ? (unsigned)rme * 4u : ULTR_OOB);
+  if (lane < RT) DS[rme] = ds_l;
+
+  for (int j = top; j >= 1; --j) {
+    const int K = p.K[j];
+    const bool last = j == top;
+    const int ldu = K + 8;
+    const int cpw = (last ? 3 : 2) * K;
+    const float invK = 1.0f / (float)K;
+    const float mean_l = buf_ld1(svs, rowok_l ? (unsigned)((p.sv_mean[j] + n0 + rme) * 4) : ULTR_OOB);
+    const float rstd_l = buf_ld1(svs, rowok_l ? (unsigned)((p.sv_rstd[j] + n0 + rme) * 4) : ULTR_OOB);
+    const Dst d_dz = make_dst(ws + bp.dz_off[j - 1] + n0 * K, (int64_t)vr * K);
+    const bool planes = j >= 2;  // a product follows: dz_{j-1} also as the two fp16 planes of its A operand
+    const int ldh = K + 8;       // (K = M_{j-1}: a multiple of 32)
+
+    auto rowpass = [&](auto xc_tag, auto last_tag) {
+      constexpr int XC = decltype(xc_tag)::value;
+      constexpr bool LAST = decltype(last_tag)::value;  // the scorer's layer: du = ds x w, its dW on the side
+      float4 xk[RT][XC], g4[XC];  // (du is read from its LDS tile twice rather than kept: 24 registers at three row tiles x 512 columns)
+      // ---- loads: x_j rows, gamma_j (beta, scorer row for the top layer)
+#pragma unroll
+      for (int q = 0; q < RT; ++q) {
+        const int r = wave + NW * q;
+#pragma unroll
+        for (int u = 0; u < XC; ++u) {
+          const int c = 4 * lane + 256 * u;
+          xk[q][u] = buf_ld4(svs, (r < vr && c < K) ? (unsigned)((p.sv_x[j] + (n0 + r) * K + c) * 4) : ULTR_OOB);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < XC; ++u) {
+        const int c = 4 * lane + 256 * u;
+        g4[u] = buf_ld4(pvs, c < K ? (unsigned)(p.pv_off[j] + c) * 4u : ULTR_OOB);
+      }
+      float mean[RT], rstd[RT], dsr[RT], dus[RT];
+#pragma unroll
+      for (int q = 0; q < RT; ++q) {
+        const int r = wave + NW * q;
+        mean[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mean_l), q));
+        rstd[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rstd_l), q));
+        dsr[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ds_l), q));
+        dus[q] = (!LAST && r < vr) ? OS[r] : 0.f;  // du_j came out of the product unscaled
+      }
+      float red[2 * RT];
+#pragma unroll
+      for (int k = 0; k < 2 * RT; ++k) red[k] = 0.f;
+      float4 pg[XC], pb[XC], pw[LAST ? XC : 1], wk[LAST ? XC : 1];
+#pragma unroll
+      for (int u = 0; u < XC; ++u) {
+        const int c = 4 * lane + 256 * u;
+        const bool act = c < K;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 be4 = z4, w4 = z4;
+        if constexpr (LAST) {
+          be4 = buf_ld4(pvs, act ? (unsigned)(p.pv_off[j] + K + c) * 4u : ULTR_OOB);
+          w4 = buf_ld4(pvs, act ? (unsigned)(p.pv_wlast + c) * 4u : ULTR_OOB);
+          wk[u] = w4;
+          pw[u] = z4;
+        }
+        pg[u] = pb[u] = z4;
+#pragma unroll
+        for (int q = 0; q < RT; ++q) {
+          const int r = wave + NW * q;
+          const float4 x4 = xk[q][u];
+          float4 du4;
+          if constexpr (LAST) du4 = make_float4(dsr[q] * w4.x, dsr[q] * w4.y, dsr[q] * w4.z, dsr[q] * w4.w);
+          else {
+            du4 = (act && r < vr) ? ld4(DU + r * ldu + c) : z4;  // (rows that do not exist contribute nothing)
+            du4.x *= dus[q]; du4.y *= dus[q]; du4.z *= dus[q]; du4.w *= dus[q];
+          }
+          const float4 xh = make_float4((x4.x - mean[q]) * rstd[q], (x4.y - mean[q]) * rstd[q], (x4.z - mean[q]) * rstd[q],
+                                        (x4.w - mean[q]) * rstd[q]);
+          const float4 gx = make_float4(du4.x * g4[u].x, du4.y * g4[u].y, du4.z * g4[u].z, du4.w * g4[u].w);
+          red[q] += (gx.x + gx.y) + (gx.z + gx.w);
+          red[RT + q] += (gx.x * xh.x + gx.y * xh.y) + (gx.z * xh.z + gx.w * xh.w);
+          // (padded lanes: x = gamma = du = 0 -> xh = -mean rstd, but every product with it carries a zero factor)
+          pg[u].x += du4.x * xh.x; pg[u].y += du4.y * xh.y; pg[u].z += du4.z * xh.z; pg[u].w += du4.w * xh.w;
+          pb[u].x += du4.x; pb[u].y += du4.y; pb[u].z += du4.z; pb[u].w += du4.w;
+          if constexpr (LAST) {
+            pw[u].x += dsr[q] * (g4[u].x * xh.x + be4.x); pw[u].y += dsr[q] * (g4[u].y * xh.y + be4.y);
+            pw[u].z += dsr[q] * (g4[u].z * xh.z + be4.z); pw[u].w += dsr[q] * (g4[u].w * xh.w + be4.w);
+          }
+        }
+      }
+      wave_sum_n<2 * RT>(red);
+      float amz[RT];
+#pragma unroll
+      for (int q = 0; q < RT; ++q) {
+        const int r = wave + NW * q;
+        const float s1 = red[q] * invK, s2 = red[RT + q] * invK;
+        amz[q] = 0.f;
+#pragma unroll
+        for (int u = 0; u < XC; ++u) {
+          const int c = 4 * lane + 256 * u;
+          float4 dz = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (c < K) {
+            const float4 x4 = xk[q][u];
+            float4 du4;
+            if constexpr (LAST) du4 = make_float4(dsr[q] * wk[u].x, dsr[q] * wk[u].y, dsr[q] * wk[u].z, dsr[q] * wk[u].w);
+            else {
+              du4 = r < vr ? ld4(DU + r * ldu + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+              du4.x *= dus[q]; du4.y *= dus[q]; du4.z *= dus[q]; du4.w *= dus[q];
+            }
+            const float4 gx = make_float4(du4.x * g4[u].x, du4.y * g4[u].y, du4.z * g4[u].z, du4.w * g4[u].w);
+            dz.x = rstd[q] * (gx.x - s1 - (x4.x - mean[q]) * rstd[q] * s2) * act_grad_from_out(x4.x, p.act);
+            dz.y = rstd[q] * (gx.y - s1 - (x4.y - mean[q]) * rstd[q] * s2) * act_grad_from_out(x4.y, p.act);
+            dz.z = rstd[q] * (gx.z - s1 - (x4.z - mean[q]) * rstd[q] * s2) * act_grad_from_out(x4.z, p.act);
+            dz.w = rstd[q] * (gx.w - s1 - (x4.w - mean[q]) * rstd[q] * s2) * act_grad_from_out(x4.w, p.act);
+            buf_st4(d_dz, (unsigned)c * 4u, (unsigned)(r * K) * 4u, dz);
+          }
+          xk[q][u] = dz;  // (x is dead from here on)
+          amz[q] = fmaxf(amz[q], fmaxf(fmaxf(fabsf(dz.x), fabsf(dz.y)), fmaxf(fabsf(dz.z), fabsf(dz.w))));
+        }
+      }
+      if (planes) {
+        _Float16* AH = reinterpret_cast<_Float16*>(DZ);
+        _Float16* AL = AH + (R + 1) * ldh;
+        wave_max_n<RT>(amz);
+#pragma unroll
+        for (int q = 0; q < RT; ++q) {
+          const int r = wave + NW * q, rc = r < R ? r : R;
+          float rs, inv;
+          fb_h3_scale(amz[q], rs, inv);
+#pragma unroll
+          for (int u = 0; u < XC; ++u) {
+            const int c = 4 * lane + 256 * u;
+            if (c < K) {
+              fbh4 hi, lo;
+              fb_h3_split4(xk[q][u], rs, hi, lo);
+              *reinterpret_cast<fbh4*>(AH + rc * ldh + c) = hi;
+              *reinterpret_cast<fbh4*>(AL + rc * ldh + c) = lo;
+            }
+          }
+          if (lane == 0) OS[r] = inv * (1.0f / ULTR_H3_WSCALE);
+        }
+      }
+      lds_barrier();  // every wave has read its rows of the du tile: the column partials may overlay it
+#pragma unroll
+      for (int u = 0; u < XC; ++u) {
+        const int c = 4 * lane + 256 * u;
+        if (c < K) {
+          st4(CP + wave * cpw + c, pg[u]);
+          st4(CP + wave * cpw + K + c, pb[u]);
+          if constexpr (LAST) st4(CP + wave * cpw + 2 * K + c, pw[u]);
+        }
+      }
+    };
+    if (last) {
+      if (K <= 256) rowpass(std::integral_constant<int, 1>(), std::true_type());
+      else rowpass(std::integral_constant<int, 2>(), std::true_type());
+    } else {
+      if (K <= 256) rowpass(std::integral_constant<int, 1>(), std::false_type());
+      else rowpass(std::integral_constant<int, 2>(), std::false_type());
+    }
+    TRACE_STAMP(1 + 3 * (top - j));
+    lds_barrier();
+    // ---- column sums of layer j: the per-wave partials in wave order
+    for (int e = tid; e < cpw; e += NT) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s += CP[w * cpw + e];
+      const int which = e >= 2 * K ? 2 : (e >= K ? 1 : 0), c = e - which * K;
+      vslab[(which == 0 ? bp.voff_g[j] : which == 1 ? bp.voff_b[j] : bp.voff_wk) + c] = s;
+    }
+    if (last && tid == 0) {
+      float sds = 0.f;
+      for (int r = 0; r < R; ++r) sds += DS[r];
+      vslab[bp.voff_bk] = sds;
+    }
+    TRACE_STAMP(2 + 3 * (top - j));
+    if (j == 1) break;
+    lds_barrier();  // the partials are folded: the product may write the du tile
+    // ---- du_{j-1} = dz_{j-1} . W_{j-1}: the planes against the split-half copy of W_{j-1} (contraction over its M = K_j outputs)
+    {
+      const int jj = j - 1;
+      const int Ko = p.K[jj], nks = K >> 5, nch = Ko >> 5, ldo = Ko + 8;
+      const _Float16* AH = reinterpret_cast<const _Float16*>(DZ);
+      const int lo_off = (R + 1) * ldh;
+      const Src Wh = make_src(wt + p.whb_off[jj], (int64_t)K * Ko);
+      const int i = lane & 15, q = lane >> 4;
+      const _Float16* pa[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const int row = 16 * rt + i;
+        pa[rt] = AH + (row < R ? row : R) * ldh + 8 * q;
+      }
+      const int ksplit = wb.ksplit[jj];
+      PipeH3W<RT, FWDW_DEPTH> ph;
+      if (ksplit == 1) {
+        ph.begin(Wh, wave, nks, 0, nks, wave < nch, lane);
+        for (int ch = wave; ch < nch; ch += NW) {
+          f32x4 acc[RT][2];
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          ph.run(pa, lo_off, Wh, nks, acc);
+          if (ch + NW < nch) ph.begin(Wh, ch + NW, nks, 0, nks, true, lane);
+          const int col = 32 * ch + 2 * i;
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = 16 * rt + 4 * q + r;
+              const int rc = (rt < RT - 1 || row < R) ? row : R;
+              *reinterpret_cast<float2*>(DU + rc * ldo + col) = make_float2(acc[rt][0][r], acc[rt][1][r]);
+            }
+        }
+      } else {
+        int ks = 0, ch = wave;
+        while (ch >= nch) { ch -= nch; ++ks; }
+        const bool has = ks < ksplit;
+        const int k0 = ks * wb.kslen[jj];
+        const int cnt = has ? ((k0 + wb.kslen[jj] < nks) ? wb.kslen[jj] : (nks - k0)) : 0;
+        f32x4 acc[RT][2];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) pa[rt] += 32 * k0;
+        ph.begin(Wh, ch, nks, k0, cnt, has, lane);
+        ph.run(pa, lo_off, Wh, cnt, acc);
+        const int col = 32 * ch + 2 * i;
+        for (int sl = 0; sl < ksplit; ++sl) {
+          if (has && ks == sl) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int row = 16 * rt + 4 * q + r;
+                const int rc = (rt < RT - 1 || row < R) ? row : R;
+                float2* dst = reinterpret_cast<float2*>(DU + rc * ldo + col);
+                float2 y = make_float2(acc[rt][0][r], acc[rt][1][r]);
+                if (sl > 0) {
+                  const float2 o = *dst;
+                  y.x += o.x;
+                  y.y += o.y;
+                }
+                *dst = y;
+              }
+          }
+          if (sl + 1 < ksplit) lds_barrier();
+        }
+      }
+    }
+    TRACE_STAMP(3 + 3 * (top - j));
+    lds_barrier();
+  }
+  TRACE_REAL(31);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3951,7 +4251,7 @@ __global__ __launch_bounds__(64) void grad_sumsq_kernel(int64_t P, const float* 
 // per knob per launch is host time on the critical path of a ~50 us step.  ultr_config_reload() re-reads them (tests and
 // the A/B tools flip knobs inside one process).
 struct Knobs {
-  int fwd_r, bwd_r, wgrad_wgs, fwd_nw, bwd_nw, no_vec, no_fused_fb, fb_max_wg_per_cu, fwd_q4, big_fwd, big_bwd, fb_h3, fwd_h3, bwd_h3, wg_h3, wg_h3_min_rows, wg_h3_wgs, fwd_wide;
+  int fwd_r, bwd_r, wgrad_wgs, fwd_nw, bwd_nw, no_vec, no_fused_fb, fb_max_wg_per_cu, fwd_q4, big_fwd, big_bwd, fb_h3, fwd_h3, bwd_h3, wg_h3, wg_h3_min_rows, wg_h3_wgs, fwd_wide, bwd_wide;
   bool loaded;
 };
 static Knobs g_knobs = {};
@@ -3980,6 +4280,7 @@ static void knobs_load() {
   k.wg_h3 = env_read("ULTR_WG_H3", 1);                    // weight gradients on the fp16 matrix cores (split-half operands); 2: any batch size
   k.wg_h3_min_rows = env_read("ULTR_WG_H3_MIN_ROWS", 4096);
   k.wg_h3_wgs = env_read("ULTR_WG_H3_WGS", 0);
+  k.bwd_wide = env_read("ULTR_BWD_WIDE", 1);  // dnn_bwdw_kernel, the same for the row-local backward of ultr_train_step
   k.fwd_wide = env_read("ULTR_FWD_WIDE", 1);  // dnn_fwdw_kernel (17 .. 64 rows per workgroup) where the 16-row tiles would need more than one round; 0: never
   k.loaded = true;
   g_knobs = k;
@@ -4088,8 +4389,8 @@ bool ultr_make_dnn_plan(const ultr_dnn_desc* d, int64_t N, DnnPlan* p) {
         // 1: eight or more 32-column chunks (the 8-wave kernels take the layer on the split-half stream); 2: fewer - only the wide-tile
         // forward (dnn_fwdw_kernel: 16 waves, chunks x slices of the contraction) reads that copy
         p->h3f[j] = (p->M[j] >= 256) ? 1 : 2;
-        p->h3b[j] = (j >= 1 && p->K[j] >= 256 && p->K[j] % 32 == 0) ? 1 : 0;
-        h3 = h3 && p->h3f[j] == 1 && (j == 0 || p->h3b[j]);
+        p->h3b[j] = (j >= 1 && p->K[j] % 32 == 0) ? (p->K[j] >= 256 ? 1 : 2) : 0;  // (2: only dnn_bwdw_kernel reads that copy)
+        h3 = h3 && p->h3f[j] == 1 && (j == 0 || p->h3b[j] == 1);
         if (p->h3f[j]) {
           p->whf_off[j] = o;
           o += n;
@@ -4104,7 +4405,7 @@ bool ultr_make_dnn_plan(const ultr_dnn_desc* d, int64_t N, DnnPlan* p) {
       p->bwd_h3 = 0;
       if (knobs().bwd_h3 && !p->no_h3)
         for (int j = 1; j < p->nl - 1; ++j)
-          if (p->h3b[j]) p->bwd_h3 = 1;
+          if (p->h3b[j] == 1) p->bwd_h3 = 1;
       p->fwd_h3 = 0;
       if (knobs().fwd_h3 && !p->no_h3)
         for (int j = 0; j < p->nl - 1; ++j)
@@ -4527,6 +4828,52 @@ static bool fwd_wide_plan(const DnnPlan& p, int64_t N, WidePlan* wp, size_t* lds
   return true;
 }
 
+// dnn_bwdw_kernel: legal when the layer-0 shortcut is on, every LayerNorm of the layers >= 1 is at most 512 wide and every dgrad
+// product has its split-half copy; rows per workgroup as in fwd_wide_plan (LDS: the dz planes, the du tile that also holds the
+// column partials of sixteen waves, 128 floats of per-row scalars)
+static bool bwd_wide_plan(const DnnPlan& p, int64_t N, WideBwd* wb, size_t* lds_bytes) {
+  if (knobs().bwd_wide == 0 || knobs().bwd_h3 == 0 || p.no_h3 || p.nl < 2 || !p.sw_ok) return false;
+  if (knobs().bwd_r != 0 || knobs().bwd_nw != 8 || knobs().big_bwd >= 2) return false;  // another kernel was asked for explicitly
+  if (p.sv_total * 4 >= ((int64_t)1 << 31)) return false;
+  const int top = p.nl - 1;
+  int wdz = 0, wdu = 0, cpmax = 16 * 3 * p.K[top];
+  for (int j = 1; j <= top; ++j) {
+    if (p.K[j] > 512 || p.K[j] % 32 != 0) return false;
+    if (j < top) {
+      if (p.h3b[j] == 0) return false;
+      if (p.K[j] + 8 > wdu) wdu = p.K[j] + 8;
+      if (p.M[j] + 8 > wdz) wdz = p.M[j] + 8;
+      if (16 * 2 * p.K[j] > cpmax) cpmax = 16 * 2 * p.K[j];
+    }
+  }
+  auto floats = [&](int64_t R) {
+    const int64_t du = (R + 1) * wdu > cpmax ? (R + 1) * wdu : cpmax;
+    return (R + 1) * wdz + du + 128;
+  };
+  int64_t rmax = 48;
+  while (rmax > 16 && floats(rmax) * 4 > 160 * 1024) --rmax;
+  if (rmax < 17) return false;
+  const int64_t cus = dnn_device_cus();
+  const int64_t rounds = (N + cus * rmax - 1) / (cus * rmax);
+  const int64_t R = (N + cus * rounds - 1) / (cus * rounds);
+  if (R <= 16) return false;
+  memset(wb, 0, sizeof(*wb));
+  wb->R = (int)R;
+  wb->dz = 0;
+  wb->du = (int)((R + 1) * wdz);
+  wb->ds = (int)(floats(R) - 128);
+  for (int j = 1; j < top; ++j) {
+    const int nks = p.M[j] / 32, nch = p.K[j] / 32;
+    int ks = nch >= 16 ? 1 : 16 / nch;
+    if (ks > nks) ks = nks;
+    const int len = (nks + ks - 1) / ks;
+    wb->kslen[j] = len;
+    wb->ksplit[j] = (nks + len - 1) / len;
+  }
+  *lds_bytes = (size_t)floats(R) * sizeof(float);
+  return true;
+}
+
 template <typename KernelT>
 static hipError_t set_lds(KernelT k, size_t bytes) {
   if (bytes <= 64 * 1024) return hipSuccess;
@@ -4617,6 +4964,17 @@ extern "C" int32_t ultr_dnn_forward_tile_rows(const ultr_dnn_desc* d, int64_t n_
   size_t wlds = 0;
   if (knobs().no_vec == 0 && fwd_wide_plan(p, n_rows, &wp, &wlds)) return 1000 + wp.R;
   return R;
+}
+
+extern "C" int32_t ultr_dnn_backward_tile_rows(const ultr_dnn_desc* d, int64_t n_rows) {
+  DnnPlan p;
+  BwdPlan bp;
+  if (n_rows <= 0 || !ultr_make_dnn_plan(d, n_rows, &p) || !ultr_make_bwd_plan(p, n_rows, &bp)) return -1;
+  WideBwd wb;
+  size_t wl = 0;
+  if (knobs().no_vec == 0 && bwd_wide_plan(p, n_rows, &wb, &wl)) return 1000 + wb.R;
+  if (knobs().big_bwd != 0 && ultr_dnn_big_ok(p, n_rows, n_rows) && (big_bwd_wanted(p, n_rows) || bwd_lds_bytes(p, bp.rblk) > 160 * 1024)) return 0;
+  return bp.rblk;
 }
 
 bool ultr_wgrad_h3_geometry(int64_t T, int M, int K, int* nsplit, int* rows_per_split) {
@@ -4721,8 +5079,26 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
   } while (0)
   bp.l0g = l0g_ok ? 1 : 0;  // every backward kernel skips du_0; the wgrad launch makes up for it
   bp.wg_prenorm = (fused_rb > 0) ? 1 : 0;  // the fused kernel left the ready-made wgrad operands in `saved`
+  WideBwd wb;
+  size_t wblds = 0;
+  const bool wide = fused_rb == 0 && dscores != nullptr && av && l0g_ok && g_ultr_step_wt != nullptr && ((uintptr_t)g_ultr_step_wt & 15) == 0 &&
+                    bwd_wide_plan(p, N, &wb, &wblds);
   if (fused_rb > 0) {
     // the row-local half already ran inside dnn_fb_kernel
+  } else if (wide) {
+    UltrProfScope prof(ULTR_K_BWD, st);
+    bp.rblk = wb.R;
+    bp.nrb = (int)((N + wb.R - 1) / wb.R);  // one vector slab per workgroup
+#define LAUNCH_BWDW(RTT)                                                                                                      \
+  do {                                                                                                                        \
+    e = set_lds(dnn_bwdw_kernel<RTT>, wblds);                                                                                 \
+    if (e != hipSuccess) return (int)e;                                                                                       \
+    ULTR_LAUNCH(prof, (dnn_bwdw_kernel<RTT>), dim3(bp.nrb), dim3(1024), wblds, st, p, bp, wb, (const float*)saved, dscores, ws, \
+                g_ultr_step_wt);                                                                                              \
+  } while (0)
+    if (wb.R <= 32) LAUNCH_BWDW(2);
+    else LAUNCH_BWDW(3);
+#undef LAUNCH_BWDW
   } else if (big) {
     UltrProfScope prof(ULTR_K_BWD, st);
     bp.nrb = (int)((N + ULTR_BIG_ROWS - 1) / ULTR_BIG_ROWS);  // one vector slab per row block of the row kernels
@@ -4876,8 +5252,12 @@ extern "C" int ultr_dnn_backward_softmax(const ultr_dnn_desc* d, const float* pa
     // backward_impl applies to the other algorithms - without it this entry point returned ULTR_E_UNSUPPORTED there
     BwdPlan bp0;
     const bool planned = dscores_out && batch > 0 && list_size > 0 && ultr_make_dnn_plan(d, N, &p) && ultr_make_bwd_plan(p, N, &bp0);
-    if (planned && (big_bwd_wanted(p, N) || bwd_lds_bytes(p, bp0.rblk) > 160 * 1024) && knobs().big_bwd != 0 &&
-        knobs().no_vec == 0 && ultr_dnn_big_ok(p, N, n_docs)) {
+    // ... and the wide-tile backward of ultr_train_step (dnn_bwdw_kernel), which takes dscores too
+    WideBwd wb0;
+    size_t wl0 = 0;
+    const bool wide = planned && g_ultr_step_wt != nullptr && knobs().no_vec == 0 && bwd_wide_plan(p, N, &wb0, &wl0);
+    if (planned && (wide || ((big_bwd_wanted(p, N) || bwd_lds_bytes(p, bp0.rblk) > 160 * 1024) && knobs().big_bwd != 0 &&
+        knobs().no_vec == 0 && ultr_dnn_big_ok(p, N, n_docs)))) {
       const int rc = ultr_softmax_ce(scores, labels, pw, ipw_table, n_ipw, batch, list_size, dscores_out, loss_ws, stream);
       if (rc) return rc;
       FusedSoftmax none = {nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
