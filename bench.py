@@ -558,6 +558,7 @@ def short_config_run(key, device, lib, steps, warmup):
                                   "frac": ach / (PEAK_FP32_MFMA_TFLOPS if bound == "mfma" else PEAK_HBM_GBS),
                                   "source": "calibration pass of %d steps in front of the timed steps, every kernel timer armed" % ncal}
         rec["kernel_us"] = {KNAMES[k]: round(v, 2) for k, v in kus.items()}
+        rec["stage_kernels"] = stage_kernels(lib, cfg)
     else:
         rec["dominant_kernel"] = {"kernel": "whole step (47 launches, none dominant: profiles/r05_cfg5_pmc.md)", "bound": "mfma",
                                   "achieved": rec["step_tflops"], "unit": "TFLOP/s", "frac": rec["step_frac_of_fp32_mfma_peak"]}
@@ -566,6 +567,30 @@ def short_config_run(key, device, lib, steps, warmup):
     torch.cuda.empty_cache()
     rec["wall_s"] = round(time.perf_counter() - t_setup, 2)
     return rec
+
+
+def stage_kernels(lib, cfg):
+    """Which kernels the forward / backward STAGES of this config's training step launch (ultr_dnn_forward_tile_rows /
+    ultr_dnn_backward_tile_rows: host-only planners of the library) - the kernel_us slots are named after the stage."""
+    from ultra_pytorch_amd import hip_ops
+    if cfg["model"] != "dnn":
+        return None
+    shape = hip_ops.DnnShape(cfg["F"], cfg["hidden"], "elu")
+    n = cfg["B"] * cfg["L"]
+
+    def name(code, wide, tile, per_layer):
+        if code >= 1000:
+            return "%s<%d> (%d rows per workgroup, %d workgroups)" % (wide, (code - 1000 + 15) // 16, code - 1000, -(-n // (code - 1000)))
+        if code == 0:
+            return per_layer
+        return "%s (%d rows per workgroup)" % (tile, code)
+    fwd = lib.ultr_dnn_forward_tile_rows(shape.desc, n, 1)
+    bwd = lib.ultr_dnn_backward_tile_rows(shape.desc, n)
+    fused = n <= 16 * 256 and cfg["algo"] == "softmax" and os.environ.get("ULTR_NO_FUSED_FB", "0") != "1"
+    if fused:
+        return {"forward+loss+backward": "dnn_fb_kernel (16 rows per workgroup)"}
+    return {"forward": name(fwd, "dnn_fwdw_kernel", "dnn_fwd_kernel", "per-layer launches (ultr_dnn_big.hip)"),
+            "backward": name(bwd, "dnn_bwdw_kernel", "dnn_bwd2_kernel", "per-layer launches (ultr_dnn_big.hip)")}
 
 
 def eval_leg(cfg, device, lib, params0):
@@ -1094,12 +1119,13 @@ def main():
                                                 "starts on a GPU that idled while the host read the previous loss; "
                                                 "avg_launch_us_back_to_back = the same kernel in the loop without host reads, "
                                                 "which is what a rocprofv3 average over the whole process mostly sees") if dnn else None,
-                         "stage_note": ("the forward / backward slots are STAGES: dnn_fwd_kernel / dnn_bwd2_kernel, or - where the "
-                                        "launcher's measured rule sends the shape (config 4: both) - the per-layer launches of "
-                                        "ultr_dnn_big.hip (statistics passes + tiled GEMMs), one sample = first launch's start to last "
-                                        "launch's stop") if dnn else None},
+                         "stage_note": ("the forward / backward slots are STAGES (`stage_kernels` names what they launch for this shape): "
+                                        "the wide-tile kernels dnn_fwdw_kernel / dnn_bwdw_kernel (round 5: configs 3 and 4), the 16-row tiles "
+                                        "dnn_fwd_kernel / dnn_bwd2_kernel, or the per-layer launches of ultr_dnn_big.hip (one sample = first "
+                                        "launch's start to last launch's stop)") if dnn else None},
             "step_tflops": flops / (1e-3 * ms_step) / 1e12, "step_frac_of_fp32_mfma_peak": flops / (1e-3 * ms_step) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
             "kernel_us": {KNAMES[k]: round(cal_us[k], 3) for k in KSLOTS if cal_cnt[k] > 0} if dnn else {},
+            "stage_kernels": stage_kernels(lib, cfg),
             "kernel_us_source": "calibration pass in front of the timed region (all kernel timers armed); roofline.avg_launch_us is "
                                 "the dominant kernel INSIDE the timed region",
             "final_loss": final_loss,

@@ -23,10 +23,10 @@ print("tile rows:", lib.ultr_dnn_forward_tile_rows(shape.desc, B * L, 1))
 for _ in range(20):
     eng.forward(p, f, feats.shape[0], i_, train=True)
 torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * (64 * 32))()
+buf = (ctypes.c_ulonglong * (3 * 64 * 32))()
 lib.ultr_trace_read.argtypes = [ctypes.c_void_p]
 lib.ultr_trace_read(buf)
-a = np.array(buf[:], dtype=np.uint64).reshape(64, 32).astype(np.int64)
+a = np.array(buf[:], dtype=np.uint64).reshape(3, 64, 32).astype(np.int64)[1]  # bank 1
 nl = len(H) + 1
 t0 = a[:8, 30].min()
 print("100 MHz counter: start / end of the sampled workgroups relative to the first start (us):",

@@ -25,10 +25,10 @@ st = torch.zeros_like(p)
 for _ in range(20):
     eng.train_step(p, st, f, feats.shape[0], i_, y_, ipw_table=ipw)
 torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * (64 * 32))()
+buf = (ctypes.c_ulonglong * (3 * 64 * 32))()
 lib.ultr_trace_read.argtypes = [ctypes.c_void_p]
 lib.ultr_trace_read(buf)
-a = np.array(buf[:], dtype=np.uint64).reshape(64, 32)
+a = np.array(buf[:], dtype=np.uint64).reshape(3, 64, 32)[0]  # bank 0: the 8-wave kernels
 # fused forward+loss+backward kernel (dnn_fb_kernel): 0 start, 1 prologue done, 2+2j LayerNorm_j done, 3+2j GEMM_j done,
 # 16 loss done, then the backward stamps of dnn_bwd2_kernel (18+4jj row pass start, 19+4jj row pass done, 17+4jj GEMM done)
 if os.environ.get("ULTR_NO_FUSED_FB", "0") != "1":

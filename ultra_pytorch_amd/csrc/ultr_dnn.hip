@@ -664,29 +664,32 @@ __device__ __forceinline__ int pick_ct(int width, int nw) {
 // Optional phase tracing (build with -DULTR_TRACE): wave 0 of every 32nd workgroup stamps s_memtime at phase
 // boundaries into g_ultr_trace; tools/trace_phases.py prints the deltas.  Compiled out by default.
 #ifdef ULTR_TRACE
-__device__ unsigned long long g_ultr_trace[64 * 32];
-#define TRACE_STAMP(slot)                                                                           \
+// three banks: 0 = the 8-wave kernels (their slot numbers overlap each other: trace one kernel at a time), 1 = dnn_fwdw_kernel,
+// 2 = dnn_bwdw_kernel (a training step runs all of them)
+__device__ unsigned long long g_ultr_trace[3 * 64 * 32];
+#define TRACE_STAMP_B(bank, slot)                                                                   \
   do {                                                                                              \
     if (threadIdx.x == 0 && (blockIdx.x & 31) == 0 && (slot) < 32 && (blockIdx.x >> 5) < 64)        \
-      g_ultr_trace[(blockIdx.x >> 5) * 32 + (slot)] = __builtin_amdgcn_s_memtime();                 \
+      g_ultr_trace[(bank) * 2048 + (blockIdx.x >> 5) * 32 + (slot)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 // the same with the constant 100 MHz counter every XCD shares (s_memrealtime): when did the workgroup start / end inside the launch
-#define TRACE_REAL(slot)                                                                            \
+#define TRACE_REAL_B(bank, slot)                                                                    \
   do {                                                                                              \
     if (threadIdx.x == 0 && (blockIdx.x & 31) == 0 && (slot) < 32 && (blockIdx.x >> 5) < 64)        \
-      g_ultr_trace[(blockIdx.x >> 5) * 32 + (slot)] = __builtin_amdgcn_s_memrealtime();             \
+      g_ultr_trace[(bank) * 2048 + (blockIdx.x >> 5) * 32 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
 extern "C" int ultr_trace_read(unsigned long long* host_out) {
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ultr_trace), sizeof(unsigned long long) * 64 * 32);
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ultr_trace), sizeof(unsigned long long) * 3 * 64 * 32);
 }
 #else
-#define TRACE_STAMP(slot) \
-  do {                    \
+#define TRACE_STAMP_B(bank, slot) \
+  do {                            \
   } while (0)
-#define TRACE_REAL(slot) \
-  do {                   \
+#define TRACE_REAL_B(bank, slot) \
+  do {                           \
   } while (0)
 #endif
+#define TRACE_STAMP(slot) TRACE_STAMP_B(0, slot)
 
 // ------------------------------------------------------------------------------------------------
 // Forward
@@ -1246,6 +1249,10 @@ struct WidePlan {
   int kslen[ULTR_MAXL];    // 32-deep steps per slice
 };
 
+#ifndef FWDW_PREFETCH
+#define FWDW_PREFETCH 0  // dnn_fwdw_kernel: 1 = the first weight step of a product is requested in front of the LayerNorm (measured: no change,
+                         // config 3 forward 43.4 / 43.7 us against 43.2 / 46.0 on the same box, and 7 spilled registers at three row tiles)
+#endif
 #ifndef FWDW_DEPTH
 #define FWDW_DEPTH 2  // weight steps (4 KiB per wave) in flight per wave
 #endif
@@ -1365,8 +1372,8 @@ __global__ __launch_bounds__(1024) void dnn_fwdw_kernel(DnnPlan p, WidePlan wp, 
   const int64_t tr = train ? 1 : 0;  // evaluation: every descriptor of `saved` has zero extent
   float* sbase = train ? saved : scores;
   if (train && blockIdx.x == 0 && tid == 0) saved[p.sv_total] = 1.f;  // saved.x_0 holds xhat_0 (see dnn_fwd_kernel)
-  TRACE_STAMP(0);
-  TRACE_REAL(30);
+  TRACE_STAMP_B(1, 0);
+  TRACE_REAL_B(1, 30);
 
   // ---- prologue: ids -> packed vector-parameter image -> feature rows, all in flight before anything is written to LDS ------
   // lane q < RT of a wave holds the id of its row  wave + 16 q; the rows go to buffer 0 as fp32 (LayerNorm_0 reads them like
@@ -1411,7 +1418,7 @@ __global__ __launch_bounds__(1024) void dnn_fwdw_kernel(DnnPlan p, WidePlan wp, 
     }
   }
   lds_barrier();
-  TRACE_STAMP(1);
+  TRACE_STAMP_B(1, 1);
 
   int pv_off = 0;
   for (int j = 0; j < p.nl; ++j) {
@@ -1544,24 +1551,38 @@ __global__ __launch_bounds__(1024) void dnn_fwdw_kernel(DnnPlan p, WidePlan wp, 
         }
       }
     };
+    // this wave's share of the product behind the LayerNorm - 32-column chunk(s) x a slice of the contraction - and, with
+    // FWDW_PREFETCH, its first weight step requested NOW: it lands while the LayerNorm runs (which issues stores but waits for
+    // no load), instead of heading the product with an exposed L2 round trip
+    const int nks = K16 >> 5, nch = M >> 5;
+    const int ksplit = last ? 1 : wp.ksplit[j];
+    int ks = 0, ch0 = wave;
+    if (ksplit > 1)
+      while (ch0 >= nch) { ch0 -= nch; ++ks; }
+    const bool has = ksplit > 1 ? ks < ksplit : wave < nch;
+    const int k0 = ksplit > 1 ? ks * wp.kslen[j] : 0;
+    const int cnt = !has ? 0 : ksplit == 1 ? nks : ((k0 + wp.kslen[j] < nks) ? wp.kslen[j] : (nks - k0));
+    const Src Wh = make_src(wt + (last ? 0 : p.whf_off[j]), last ? 0 : (int64_t)K16 * M);
+    PipeH3W<RT, FWDW_DEPTH> ph;
+#if FWDW_PREFETCH
+    if (!last) ph.begin(Wh, ch0, nks, k0, cnt, has, lane);
+#endif
     if (K16 <= 256) ln(std::integral_constant<int, 1>());
     else if (K16 <= 512) ln(std::integral_constant<int, 2>());
     else ln(std::integral_constant<int, 3>());
-    TRACE_STAMP(2 + 3 * j);
+    TRACE_STAMP_B(1, 2 + 3 * j);
     if (last) {
-      TRACE_REAL(31);
+      TRACE_REAL_B(1, 31);
       break;
     }
     lds_barrier();
-    TRACE_STAMP(3 + 3 * j);
+    TRACE_STAMP_B(1, 3 + 3 * j);
 
     // ---- Linear_j + activation: Y = act((Ah + Al) . (Wh + Wl) x scales + b), 32-column chunks ----------------------------------
     {
-      const int nks = K16 >> 5, nch = M >> 5;
       const int ldy = round_up(M, 32) + 8;
       const _Float16* AH = reinterpret_cast<const _Float16*>(Bin);
       const int lo_off = (R + 1) * ldh;
-      const Src Wh = make_src(wt + p.whf_off[j], (int64_t)K16 * M);
       const Dst d_y = make_dst(sbase + tr * (lay.sv_x_next + n0 * M), tr * (int64_t)vr * M);  // saved x_{j+1} rows of this workgroup
       const int i = lane & 15, q = lane >> 4;
       const _Float16* pa[RT];
@@ -1575,10 +1596,10 @@ __global__ __launch_bounds__(1024) void dnn_fwdw_kernel(DnnPlan p, WidePlan wp, 
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) yrow[rt] = 16 * rt + 4 * q;
       const unsigned gv = (unsigned)(4 * q * M + 2 * i) * 4u;
-      const int ksplit = wp.ksplit[j];
-      PipeH3W<RT, FWDW_DEPTH> ph;
+#if !FWDW_PREFETCH
+      ph.begin(Wh, ch0, nks, k0, cnt, has, lane);
+#endif
       if (ksplit == 1) {
-        ph.begin(Wh, wave, nks, 0, nks, wave < nch, lane);
         for (int ch = wave; ch < nch; ch += NW) {
           f32x4 acc[RT][2];
 #pragma unroll
@@ -1606,11 +1627,7 @@ __global__ __launch_bounds__(1024) void dnn_fwdw_kernel(DnnPlan p, WidePlan wp, 
       } else {
         // chunks x slices of the contraction: wave = slice * nch + chunk; the raw partial tiles are summed into the output buffer
         // slice by slice (fixed order), then every thread applies scale, bias and activation
-        int ks = 0, ch = wave;
-        while (ch >= nch) { ch -= nch; ++ks; }
-        const bool has = ks < ksplit;
-        const int k0 = ks * wp.kslen[j];
-        const int cnt = has ? ((k0 + wp.kslen[j] < nks) ? wp.kslen[j] : (nks - k0)) : 0;
+        const int ch = ch0;
         f32x4 acc[RT][2];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -1618,7 +1635,6 @@ __global__ __launch_bounds__(1024) void dnn_fwdw_kernel(DnnPlan p, WidePlan wp, 
           for (int t = 0; t < 2; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) pa[rt] += 32 * k0;
-        ph.begin(Wh, ch, nks, k0, cnt, has, lane);
         ph.run(pa, lo_off, Wh, cnt, acc);
         const int col = 32 * ch + 2 * i;
         for (int sl = 0; sl < ksplit; ++sl) {
@@ -1658,7 +1674,7 @@ __global__ __launch_bounds__(1024) void dnn_fwdw_kernel(DnnPlan p, WidePlan wp, 
         }
       }
     }
-    TRACE_STAMP(4 + 3 * j);
+    TRACE_STAMP_B(1, 4 + 3 * j);
     lds_barrier();
   }
 }
@@ -2475,8 +2491,8 @@ __global__ __launch_bounds__(1024) void dnn_bwdw_kernel(DnnPlan p, BwdPlan bp, W
   const Src svs = make_src(saved, p.sv_total);
   const Src pvs = make_src(wt + p.wt_pv_off, p.pv_total);
   const int top = p.nl - 1;
-  TRACE_STAMP(0);
-  TRACE_REAL(30);
+  TRACE_STAMP_B(2, 0);
+  TRACE_REAL_B(2, 30);
   // lane q < RT of a wave speaks for its row  wave + 16 q
   const int rme = wave + NW * (lane < RT ? lane : 0);
   const bool rowok_l = lane < RT && rme < vr;
@@ -2500,7 +2516,8 @@ __global__ __launch_bounds__(1024) void dnn_bwdw_kernel(DnnPlan p, BwdPlan bp, W
       constexpr int XC = decltype(xc_tag)::value;
       constexpr bool LAST = decltype(last_tag)::value;  // the scorer's layer: du = ds x w, its dW on the side
       float4 xk[RT][XC], g4[XC];  // (du is read from its LDS tile twice rather than kept: 24 registers at three row tiles x 512 columns)
-      // ---- loads: x_j rows, gamma_j (beta, scorer row for the top layer)
+      // ---- loads: x_j rows, gamma_j (beta, scorer row for the top layer).  (Requested one product ahead and kept in registers
+      // they cost more than the exposed round trip: 80 spilled registers at three row tiles, 63 us instead of 45 at config 3.)
 #pragma unroll
       for (int q = 0; q < RT; ++q) {
         const int r = wave + NW * q;
@@ -2527,6 +2544,7 @@ __global__ __launch_bounds__(1024) void dnn_bwdw_kernel(DnnPlan p, BwdPlan bp, W
       float red[2 * RT];
 #pragma unroll
       for (int k = 0; k < 2 * RT; ++k) red[k] = 0.f;
+      if (j == 1) TRACE_STAMP_B(2, 12);
       float4 pg[XC], pb[XC], pw[LAST ? XC : 1], wk[LAST ? XC : 1];
 #pragma unroll
       for (int u = 0; u < XC; ++u) {
@@ -2565,7 +2583,9 @@ __global__ __launch_bounds__(1024) void dnn_bwdw_kernel(DnnPlan p, BwdPlan bp, W
           }
         }
       }
+      if (j == 1) TRACE_STAMP_B(2, 13);
       wave_sum_n<2 * RT>(red);
+      if (j == 1) TRACE_STAMP_B(2, 14);
       float amz[RT];
 #pragma unroll
       for (int q = 0; q < RT; ++q) {
@@ -2617,7 +2637,9 @@ __global__ __launch_bounds__(1024) void dnn_bwdw_kernel(DnnPlan p, BwdPlan bp, W
           if (lane == 0) OS[r] = inv * (1.0f / ULTR_H3_WSCALE);
         }
       }
+      if (j == 1) TRACE_STAMP_B(2, 15);
       lds_barrier();  // every wave has read its rows of the du tile: the column partials may overlay it
+      if (j == 1) TRACE_STAMP_B(2, 16);
 #pragma unroll
       for (int u = 0; u < XC; ++u) {
         const int c = 4 * lane + 256 * u;
@@ -2635,7 +2657,7 @@ __global__ __launch_bounds__(1024) void dnn_bwdw_kernel(DnnPlan p, BwdPlan bp, W
       if (K <= 256) rowpass(std::integral_constant<int, 1>(), std::false_type());
       else rowpass(std::integral_constant<int, 2>(), std::false_type());
     }
-    TRACE_STAMP(1 + 3 * (top - j));
+    TRACE_STAMP_B(2, 1 + 3 * (top - j));
     lds_barrier();
     // ---- column sums of layer j: the per-wave partials in wave order
     for (int e = tid; e < cpw; e += NT) {
@@ -2650,7 +2672,7 @@ __global__ __launch_bounds__(1024) void dnn_bwdw_kernel(DnnPlan p, BwdPlan bp, W
       for (int r = 0; r < R; ++r) sds += DS[r];
       vslab[bp.voff_bk] = sds;
     }
-    TRACE_STAMP(2 + 3 * (top - j));
+    TRACE_STAMP_B(2, 2 + 3 * (top - j));
     if (j == 1) break;
     lds_barrier();  // the partials are folded: the product may write the du tile
     // ---- du_{j-1} = dz_{j-1} . W_{j-1}: the planes against the split-half copy of W_{j-1} (contraction over its M = K_j outputs)
@@ -2727,10 +2749,10 @@ __global__ __launch_bounds__(1024) void dnn_bwdw_kernel(DnnPlan p, BwdPlan bp, W
         }
       }
     }
-    TRACE_STAMP(3 + 3 * (top - j));
+    TRACE_STAMP_B(2, 3 + 3 * (top - j));
     lds_barrier();
   }
-  TRACE_REAL(31);
+  TRACE_REAL_B(2, 31);
 }
 
 // ------------------------------------------------------------------------------------------------
