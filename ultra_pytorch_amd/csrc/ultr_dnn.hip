@@ -1249,10 +1249,6 @@ struct WidePlan {
   int kslen[ULTR_MAXL];    // 32-deep steps per slice
 };
 
-#ifndef FWDW_PREFETCH
-#define FWDW_PREFETCH 0  // dnn_fwdw_kernel: 1 = the first weight step of a product is requested in front of the LayerNorm (measured: no change,
-                         // config 3 forward 43.4 / 43.7 us against 43.2 / 46.0 on the same box, and 7 spilled registers at three row tiles)
-#endif
 #ifndef FWDW_DEPTH
 #define FWDW_DEPTH 2  // weight steps (4 KiB per wave) in flight per wave
 #endif
@@ -1551,22 +1547,6 @@ __global__ __launch_bounds__(1024) void dnn_fwdw_kernel(DnnPlan p, WidePlan wp, 
         }
       }
     };
-    // this wave's share of the product behind the LayerNorm - 32-column chunk(s) x a slice of the contraction - and, with
-    // FWDW_PREFETCH, its first weight step requested NOW: it lands while the LayerNorm runs (which issues stores but waits for
-    // no load), instead of heading the product with an exposed L2 round trip
-    const int nks = K16 >> 5, nch = M >> 5;
-    const int ksplit = last ? 1 : wp.ksplit[j];
-    int ks = 0, ch0 = wave;
-    if (ksplit > 1)
-      while (ch0 >= nch) { ch0 -= nch; ++ks; }
-    const bool has = ksplit > 1 ? ks < ksplit : wave < nch;
-    const int k0 = ksplit > 1 ? ks * wp.kslen[j] : 0;
-    const int cnt = !has ? 0 : ksplit == 1 ? nks : ((k0 + wp.kslen[j] < nks) ? wp.kslen[j] : (nks - k0));
-    const Src Wh = make_src(wt + (last ? 0 : p.whf_off[j]), last ? 0 : (int64_t)K16 * M);
-    PipeH3W<RT, FWDW_DEPTH> ph;
-#if FWDW_PREFETCH
-    if (!last) ph.begin(Wh, ch0, nks, k0, cnt, has, lane);
-#endif
     if (K16 <= 256) ln(std::integral_constant<int, 1>());
     else if (K16 <= 512) ln(std::integral_constant<int, 2>());
     else ln(std::integral_constant<int, 3>());
@@ -1577,6 +1557,19 @@ __global__ __launch_bounds__(1024) void dnn_fwdw_kernel(DnnPlan p, WidePlan wp, 
     }
     lds_barrier();
     TRACE_STAMP_B(1, 3 + 3 * j);
+    // this wave's share of the product: 32-column chunk(s) x a slice of the contraction.  (Requesting its first weight step in
+    // front of the LayerNorm was measured: no change - config 3 forward 43.4 / 43.7 us against 43.2 / 46.0 on the same box.)
+    const int nks = K16 >> 5, nch = M >> 5;
+    const int ksplit = wp.ksplit[j];
+    int ks = 0, ch0 = wave;
+    if (ksplit > 1)
+      while (ch0 >= nch) { ch0 -= nch; ++ks; }
+    const bool has = ksplit > 1 ? ks < ksplit : wave < nch;
+    const int k0 = ksplit > 1 ? ks * wp.kslen[j] : 0;
+    const int cnt = !has ? 0 : ksplit == 1 ? nks : ((k0 + wp.kslen[j] < nks) ? wp.kslen[j] : (nks - k0));
+    const Src Wh = make_src(wt + p.whf_off[j], (int64_t)K16 * M);
+    PipeH3W<RT, FWDW_DEPTH> ph;
+    ph.begin(Wh, ch0, nks, k0, cnt, has, lane);
 
     // ---- Linear_j + activation: Y = act((Ah + Al) . (Wh + Wl) x scales + b), 32-column chunks ----------------------------------
     {
@@ -1596,9 +1589,6 @@ __global__ __launch_bounds__(1024) void dnn_fwdw_kernel(DnnPlan p, WidePlan wp, 
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) yrow[rt] = 16 * rt + 4 * q;
       const unsigned gv = (unsigned)(4 * q * M + 2 * i) * 4u;
-#if !FWDW_PREFETCH
-      ph.begin(Wh, ch0, nks, k0, cnt, has, lane);
-#endif
       if (ksplit == 1) {
         for (int ch = wave; ch < nch; ch += NW) {
           f32x4 acc[RT][2];
