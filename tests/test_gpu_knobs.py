@@ -28,6 +28,12 @@ KNOB_SETS = [
     ("ULTR_FWD_Q4=0", "cfg4_pairdebias"),
     ("ULTR_WGRAD_WGS=300", "cfg3_dla"),
     ("ULTR_FB_H3=0 ULTR_FWD_H3=0 ULTR_BWD_H3=0 ULTR_WG_H3=0", "cfg4_pairdebias"),  # every product on the fp32 matrix cores
+    # round 5: configs 3 / 4 take the wide-tile kernels by default - the 16-row tiles (dnn_fwd_kernel, dnn_bwd2_kernel) and the
+    # per-layer backward they replaced stay under the same bars
+    ("ULTR_FWD_WIDE=0 ULTR_BWD_WIDE=0", "cfg3_dla"),
+    ("ULTR_FWD_WIDE=0 ULTR_BWD_WIDE=0", "cfg4_pairdebias"),
+    ("ULTR_FWD_WIDE=0", "cfg4_pairdebias"),            # 16-row forward in front of the wide backward (and the other way round below)
+    ("ULTR_BWD_WIDE=0", "cfg3_dla"),
 ]
 
 
