@@ -1361,7 +1361,8 @@ __global__ __launch_bounds__(1024) void dnn_fwdw_kernel(DnnPlan p, WidePlan wp, 
   const int64_t N = (int64_t)B * L;
   float* PV = smem + wp.pv;
   float* OS = PV + p.pv_total;  // per-row output scale of the current product (64 floats)
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = threadIdx.x, lane_id = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = lane_id;
   const int64_t n0 = (int64_t)blockIdx.x * R;
   const int vr = (int)((N - n0) < R ? (N - n0) : R);  // rows of this workgroup that exist
   const bool train = saved != nullptr;
@@ -1418,6 +1419,11 @@ __global__ __launch_bounds__(1024) void dnn_fwdw_kernel(DnnPlan p, WidePlan wp, 
 
   int pv_off = 0;
   for (int j = 0; j < p.nl; ++j) {
+    // (the lane id goes through an opaque move per layer: hipcc otherwise hoists the lane-derived indices and predicates of every
+    // phase out of this loop and keeps - or spills - them across all of it)
+    int lane_j = lane_id;
+    asm volatile("" : "+v"(lane_j));
+    const int lane = lane_j;
     const DnnPlan::FwdLayer lay = p.fl[j];
     const int K = lay.K, M = lay.M;
     const int K16 = round_up(K, 32);
@@ -2474,7 +2480,8 @@ __global__ __launch_bounds__(1024) void dnn_bwdw_kernel(DnnPlan p, BwdPlan bp, W
   float* CP = DU;
   float* DS = smem + wb.ds;
   float* OS = DS + 64;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = threadIdx.x, lane_id = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = lane_id;
   const int64_t n0 = (int64_t)blockIdx.x * R;
   const int vr = (int)((N - n0) < R ? (N - n0) : R);
   float* vslab = ws + bp.vslab_off + (int64_t)blockIdx.x * bp.vlen;
@@ -2491,6 +2498,11 @@ __global__ __launch_bounds__(1024) void dnn_bwdw_kernel(DnnPlan p, BwdPlan bp, W
   if (lane < RT) DS[rme] = ds_l;
 
   for (int j = top; j >= 1; --j) {
+    // (the lane id goes through an opaque move per layer: hipcc otherwise hoists every lane-derived index and predicate of all
+    // phases out of this loop and spills them - 22 registers at three row tiles, each reload a memory round trip)
+    int ln = lane_id;
+    asm volatile("" : "+v"(ln));
+    const int lane = ln;
     const int K = p.K[j];
     const bool last = j == top;
     const int ldu = K + 8;
@@ -4817,7 +4829,7 @@ static bool fwd_wide_plan(const DnnPlan& p, int64_t N, WidePlan* wp, size_t* lds
   }
   const int64_t fixed = ((int64_t)p.pv_total + 64) * 4, per_row = (int64_t)(w[0] + w[1]) * 4;
   int64_t rmax = (160 * 1024 - fixed) / per_row - 1;  // the buffers hold R + 1 rows (dnn_fwdw_kernel: the rows of the last MFMA tile beyond R land in row R)
-  if (rmax > 48) rmax = 48;  // three MFMA row tiles (four: 29 spilled registers at sixteen waves)
+  if (rmax > 64) rmax = 64;  // four MFMA row tiles
   if (rmax < 17) return false;
   const int64_t cus = dnn_device_cus();
   const int64_t rounds = (N + cus * rmax - 1) / (cus * rmax);
@@ -4930,7 +4942,8 @@ extern "C" int ultr_dnn_forward(const ultr_dnn_desc* d, const float* params, con
                 (int)list_size, scores, (float*)saved, wt);                                                                     \
   } while (0)
       if (rt == 2) LAUNCH_FWDW(2);
-      else LAUNCH_FWDW(3);
+      else if (rt == 3) LAUNCH_FWDW(3);
+      else LAUNCH_FWDW(4);
 #undef LAUNCH_FWDW
       return (int)hipGetLastError();
     }
