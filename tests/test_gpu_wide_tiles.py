@@ -14,6 +14,20 @@ pytestmark = pytest.mark.gpu
 
 from tests.hipref import HipRun  # noqa: E402
 
+
+
+@pytest.fixture(autouse=True)
+def wide_whenever_legal(monkeypatch):
+    """ULTR_FWD_WIDE=2: the wide-tile forward wherever it is legal (the default takes it by a measured rule, which sends some of the
+    small shapes below to the 16-row kernel)"""
+    from ultra_pytorch_amd import _lib
+    monkeypatch.setenv("ULTR_FWD_WIDE", "2")
+    _lib.load().ultr_config_reload()
+    yield
+    monkeypatch.undo()
+    _lib.load().ultr_config_reload()
+
+
 SHAPES = {
     # name: (F, hidden, B, L, act, n_pad)
     "cfg3_three_tiles": (136, [512, 256, 128], 512, 20, "elu", 0),        # 40 rows x 256 workgroups
@@ -98,12 +112,8 @@ def test_wide_forward_is_deterministic_and_knob_switches_it_off(monkeypatch):
     assert np.array_equal(a, b)
     monkeypatch.setenv("ULTR_FWD_WIDE", "0")
     _lib.load().ultr_config_reload()
-    try:
-        assert tile_rows(F, hidden, act, B * L) == 16
-        c = run.forward(params)
-    finally:
-        monkeypatch.undo()
-        _lib.load().ultr_config_reload()
+    assert tile_rows(F, hidden, act, B * L) == 16
+    c = run.forward(params)
     # the 16-row kernel sums the same products in another order (no slices of the contraction, other tile shapes)
     np.testing.assert_allclose(a, c, atol=2e-6)
 

@@ -254,13 +254,25 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // adds its parts in chunks of 8, ((v0+v1)+(v2+v3))+((v4+v5)+(v6+v7)) with missing parts = 0, chunks accumulate in
 // order; total = ((S0+S1)+S2)+S3.  strided_sum = ONE group (4 cooperating threads + an LDS combine), full_sum = all four
 // groups by one thread with 32 loads in flight: both produce the same bits.
+// NC chunks (8 NC loads) are requested per trip and added in chunk order: the same bits for every NC.  The spare workgroups of the
+// weight-gradient launch use NC = 4 - a quarter of the dependent round trips (their folds of 256 - 1024 partials ended after the
+// launch's matrix blocks: config 3 wgrad 43.7 -> 41.7 us, config 4 84 -> 81, 10 240 rows x [256,256] 36 -> 31); the reduction kernels
+// keep NC = 1 (the 32 live registers of NC = 4 cost them occupancy: config 4's reduction 10.1 -> 13.7 us).
+template <int NC = 1>
 __device__ __forceinline__ float strided_sum(const float* __restrict__ src, int64_t stride, int nparts, int grp) {
   float part = 0.f;
-  for (int k = grp; k < nparts; k += 32) {
-    float v[8];
+  for (int k = grp; k < nparts; k += 32 * NC) {
+    float v[NC][8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = (k + 4 * i < nparts) ? src[(int64_t)(k + 4 * i) * stride] : 0.f;
-    part += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int kk = k + 32 * c + 4 * i;
+        v[c][i] = (kk < nparts) ? src[(int64_t)kk * stride] : 0.f;
+      }
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+      if (k + 32 * c < nparts) part += ((v[c][0] + v[c][1]) + (v[c][2] + v[c][3])) + ((v[c][4] + v[c][5]) + (v[c][6] + v[c][7]));
   }
   return part;
 }

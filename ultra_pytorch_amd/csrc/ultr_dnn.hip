@@ -3405,7 +3405,7 @@ __device__ __forceinline__ void wg_spare_roles(const DnnPlan& p, const BwdPlan& 
     // the matrix blocks run, so that the reduction kernel's critical path is not a 160-deep serial sum
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int e = ((int)blockIdx.x - bp.wgrad_blocks) * 64 + lane;
-    const float part = (e < bp.vlen) ? strided_sum(ws + bp.vslab_off + e, bp.vlen, bp.nrb, grp) : 0.f;
+    const float part = (e < bp.vlen) ? strided_sum<4>(ws + bp.vslab_off + e, bp.vlen, bp.nrb, grp) : 0.f;
     smem[grp * 64 + lane] = part;
     lds_barrier();
     if (grp == 0 && e < bp.vlen)
@@ -3425,7 +3425,7 @@ __device__ __forceinline__ void wg_spare_roles(const DnnPlan& p, const BwdPlan& 
     float head = 0.f;  // group 0, lanes 0..3: loss_sum, D, loss2_sum, D2 of the whole batch
     for (int t0 = 0; t0 < tail; t0 += 64) {
       const int t = t0 + lane;
-      smem[grp * 64 + lane] = (t < tail && loss_part != nullptr) ? strided_sum(loss_part + (int64_t)beg * tail + t, tail, cnt, grp) : 0.f;
+      smem[grp * 64 + lane] = (t < tail && loss_part != nullptr) ? strided_sum<4>(loss_part + (int64_t)beg * tail + t, tail, cnt, grp) : 0.f;
       lds_barrier();
       if (grp == 0 && t < tail && loss_part != nullptr) {
         const float v = ((smem[lane] + smem[64 + lane]) + smem[128 + lane]) + smem[192 + lane];
@@ -4275,7 +4275,7 @@ __global__ __launch_bounds__(64) void grad_sumsq_kernel(int64_t P, const float* 
 // per knob per launch is host time on the critical path of a ~50 us step.  ultr_config_reload() re-reads them (tests and
 // the A/B tools flip knobs inside one process).
 struct Knobs {
-  int fwd_r, bwd_r, wgrad_wgs, fwd_nw, bwd_nw, no_vec, no_fused_fb, fb_max_wg_per_cu, fwd_q4, big_fwd, big_bwd, fb_h3, fwd_h3, bwd_h3, wg_h3, wg_h3_min_rows, wg_h3_wgs, fwd_wide, bwd_wide;
+  int fwd_r, bwd_r, wgrad_wgs, fwd_nw, bwd_nw, no_vec, no_fused_fb, fb_max_wg_per_cu, fwd_q4, big_fwd, big_bwd, fb_h3, fwd_h3, bwd_h3, wg_h3, wg_h3_min_rows, wg_h3_wgs, fwd_wide, bwd_wide, fwd_wide_rmax;
   bool loaded;
 };
 static Knobs g_knobs = {};
@@ -4305,7 +4305,8 @@ static void knobs_load() {
   k.wg_h3_min_rows = env_read("ULTR_WG_H3_MIN_ROWS", 4096);
   k.wg_h3_wgs = env_read("ULTR_WG_H3_WGS", 0);
   k.bwd_wide = env_read("ULTR_BWD_WIDE", 1);  // dnn_bwdw_kernel, the same for the row-local backward of ultr_train_step
-  k.fwd_wide = env_read("ULTR_FWD_WIDE", 1);  // dnn_fwdw_kernel (17 .. 64 rows per workgroup) where the 16-row tiles would need more than one round; 0: never
+  k.fwd_wide_rmax = env_read("ULTR_FWD_WIDE_RMAX", 64);  // most rows per workgroup of dnn_fwdw_kernel (17 .. 64)
+  k.fwd_wide = env_read("ULTR_FWD_WIDE", 1);  // dnn_fwdw_kernel (17 .. 64 rows per workgroup): 0 never, 1 by the measured rule (fwd_wide_plan), 2 whenever legal
   k.loaded = true;
   g_knobs = k;
 }
@@ -4829,12 +4830,21 @@ static bool fwd_wide_plan(const DnnPlan& p, int64_t N, WidePlan* wp, size_t* lds
   }
   const int64_t fixed = ((int64_t)p.pv_total + 64) * 4, per_row = (int64_t)(w[0] + w[1]) * 4;
   int64_t rmax = (160 * 1024 - fixed) / per_row - 1;  // the buffers hold R + 1 rows (dnn_fwdw_kernel: the rows of the last MFMA tile beyond R land in row R)
-  if (rmax > 64) rmax = 64;  // four MFMA row tiles
+  const int cap = knobs().fwd_wide_rmax < 17 ? 17 : (knobs().fwd_wide_rmax > 64 ? 64 : knobs().fwd_wide_rmax);  // four MFMA row tiles at most
+  if (rmax > cap) rmax = cap;
   if (rmax < 17) return false;
   const int64_t cus = dnn_device_cus();
   const int64_t rounds = (N + cus * rmax - 1) / (cus * rmax);
   const int64_t R = (N + cus * rounds - 1) / (cus * rounds);
   if (R <= 16) return false;
+  // Several rounds of small workgroups behind a small weight set are what the 16-row kernel (two or three workgroups per CU, their
+  // phases overlapping) does well: validation of config 2's model at 100 candidates (25 600 rows, 0.4 MB of weights), forward us:
+  // 16-row tiles 63.7; wide 59.2 at 2 rounds x 50 rows, 67.3 at 3 x 34, 71.2 at 4 x 25.  Against that: config 3 (1 round x 40 rows,
+  // 0.94 MB) 60 -> 41, config 4 (2 x 25 rows, 2.1 MB) 151 -> 95.  Wide tiles when one round covers the batch, when the tiles are
+  // nearly full 48- / 64-row ones, or when the weights are what the 16-row tiles spend their time streaming.
+  int64_t wbytes = 0;
+  for (int j = 0; j < p.nl - 1; ++j) wbytes += (int64_t)round_up(p.K[j], 32) * p.M[j] * 4;
+  if (knobs().fwd_wide == 1 && rounds > 1 && R < 44 && wbytes < 768 * 1024) return false;
   memset(wp, 0, sizeof(*wp));
   wp->R = (int)R;
   wp->buf[0] = 0;
