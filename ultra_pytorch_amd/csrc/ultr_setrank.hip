@@ -37,6 +37,7 @@ extern "C" int ultr_gemm_trace_arm(int on) {  // slot 31 != 0: frozen
 }
 #endif
 #include "ultr_gemm.h"
+#include "ultr_h3.h"
 #include "ultr_plan.h"
 
 #define SR_EPS 1e-6f  // nn.LayerNorm(eps=1e-6) everywhere in SetRank.py (:100-101, :134)
@@ -68,7 +69,7 @@ struct SrPlan {
   int64_t sv_planes, planes_halves;
   int64_t sv_flag;   // float offset in `saved` of the range word behind the planes (ULTR_H3_FLAG_*: raised by sr_split_planes_kernel)
   int no_h3;         // ultr_setrank_desc::flags & ULTR_MODEL_FP32_PRODUCTS
-  struct SplitMat { int64_t off; int M, K, ldK, ldM; int64_t f_off, t_off; };
+  struct SplitMat { int64_t off; int M, K, ldK, ldM; int64_t f_off, t_off, g_off; };  // g_off: fragment-major forward copy (sr_block_fwd_kernel), -1: none
   int n_split;
   SplitMat split[32];
   // workspace (floats)
@@ -146,9 +147,18 @@ bool make_plan(const ultr_setrank_desc* c, int64_t T, SrPlan* p) {
       m.ldK = (int)((K + 31) / 32 * 32); m.ldM = (int)((M + 31) / 32 * 32);
       m.f_off = h; h += 2 * M * m.ldK;
       m.t_off = h; h += 2 * K * m.ldM;
+      m.g_off = -1;
     };
     add(p->w1, dff, F); add(p->w2, d, dff); add(p->wo1, dff, d);
     for (int l = 0; l < p->nl; ++l) { add(p->lay[l].wd, d, d); add(p->lay[l].wf1, dff, d); add(p->lay[l].wf2, d, dff); }
+    // fragment-major split-half copies (ultr_h3_index) of the encoder blocks' three matrices for the fused block kernel
+    if (d % 32 == 0 && dff % 32 == 0)
+      for (int k = 3; k < p->n_split; ++k) {
+        SrPlan::SplitMat& m = p->split[k];
+        h = (h + 7) & ~(int64_t)7;  // 16-byte aligned: the kernel streams it with 16-byte buffer loads
+        m.g_off = h;
+        h += 2 * (int64_t)m.M * m.ldK;
+      }
     p->sv_planes = (p->sv_total + 4 + 7) & ~(int64_t)7;
     p->planes_halves = h;
     p->sv_flag = p->sv_planes + (h + 1) / 2;  // (ultr_setrank_saved_bytes leaves four floats behind the planes)
@@ -1790,11 +1800,24 @@ struct SrSplitTable {
   int n;
   SrPlan::SplitMat m[32];
 };
-// blockIdx.y = 2 * matrix + phase (0: the forward planes [M][ldK], 1: the transposed planes [K][ldM]); one element per thread
+// blockIdx.y = 3 * matrix + phase (0: the forward planes [M][ldK], 1: the transposed planes [K][ldM], 2: the fragment-major forward copy
+// of the fused block kernel - ultr_h3_index - where the plan has one); one element per thread
 __global__ __launch_bounds__(256) void sr_split_planes_kernel(SrSplitTable tb, const float* __restrict__ params, _Float16* __restrict__ planes,
                                                               uint32_t* __restrict__ range_flag) {
-  const SrPlan::SplitMat m = tb.m[blockIdx.y >> 1];
-  const int phase = blockIdx.y & 1;
+  const SrPlan::SplitMat m = tb.m[blockIdx.y / 3];
+  const int phase = blockIdx.y % 3;
+  if (phase == 2) {
+    if (m.g_off < 0) return;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)m.M * m.ldK) return;
+    const int mm = (int)(e / m.ldK), k = (int)(e - (int64_t)mm * m.ldK);
+    const float w = k < m.K ? params[m.off + (int64_t)mm * m.K + k] * ULTR_H3_WSCALE : 0.f;
+    const _Float16 hi = (_Float16)w, lo = (_Float16)(w - (float)hi);
+    _Float16* dst = planes + m.g_off;
+    dst[ultr_h3_index(mm, k, m.ldK >> 5, 0)] = hi;
+    dst[ultr_h3_index(mm, k, m.ldK >> 5, 1)] = lo;
+    return;
+  }
   const int rows = phase ? m.K : m.M, ld = phase ? m.ldM : m.ldK, cols = phase ? m.M : m.K;
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= (int64_t)rows * ld) return;
@@ -2134,9 +2157,342 @@ void colsum_ln(const SrPlan& p, const float* dy, const float* s, const float* me
   fold(part, (int64_t)2 * W, p.n_cs, 2 * W, dst, st);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Everything of an encoder block behind the attention, one launch (round 5): the wide-tile geometry of dnn_fwdw_kernel
+// ---------------------------------------------------------------------------------------------------------
+//   s1 = x + (A Wd^T + bd),  out1 = LN1(s1),  f = relu(out1 Wf1^T + bf1),  s2 = out1 + (f Wf2^T + bf2),  x' = LN2(s2)
+// (SetRank.py:92-111) were two Linear + residual GEMMs, a Linear + ReLU GEMM and two LayerNorm launches: 1.1 GB of HBM traffic per
+// block at config 5 for five tensors the backward wants saved (s1, out1, f, s2, x': 0.45 GB) and two it has to read (A, x: 0.2 GB).
+// Here a workgroup of sixteen waves owns R <= 60 token rows through all of it: the three products run on split-half fragment
+// copies of the weights (384 KB per block at config 5, streamed once per workgroup; built next to the GEMM planes by
+// sr_split_planes_kernel), the row tiles of the d-wide products are split between two groups of eight waves (wave = one 32-column
+// chunk x two row tiles over the WHOLE contraction: no partial sums), the dff-wide product takes one wave per row tile so that the
+// row maximum its output planes are scaled by is a 16-lane reduction; activations live in three LDS buffers; every saved tensor
+// leaves through a buffer resource clipped to the rows that exist.
+struct SrBlockArgs {
+  int R, d, dff;
+  int64_t T;
+  int64_t bd, bf1, bf2, g1, b1, g2, b2;                  // float offsets into the parameter vector
+  int64_t gd, gf1, gf2;                                  // HALF offsets of the fragment-major copies of Wd, Wf1, Wf2 from the planes
+  int64_t A, x, s1, m1, r1, out1, f, s2, m2, r2, xn;     // float offsets into `saved`
+  int p0, p1, p2, pv;                                    // float offsets into dynamic LDS
+};
+
+__device__ __forceinline__ float2 buf_ld2(const Src& s, unsigned byte_off) {
+  const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(s.rs, byte_off, 0, 0);
+  return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
+// maximum over the 16 lanes of a DPP row (the lanes that hold one accumulator row group)
+__device__ __forceinline__ void row16_max4(float (&v)[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ULTR_DPP_MAX(v[k], "quad_perm:[1,0,3,2] row_mask:0xf");
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ULTR_DPP_MAX(v[k], "quad_perm:[2,3,0,1] row_mask:0xf");
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ULTR_DPP_MAX(v[k], "row_ror:4 row_mask:0xf");
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ULTR_DPP_MAX(v[k], "row_ror:8 row_mask:0xf");
+}
+
+__global__ __launch_bounds__(1024) void sr_block_fwd_kernel(SrBlockArgs a, const float* __restrict__ params,
+                                                            const _Float16* __restrict__ planes, float* __restrict__ sv) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NW = 16, NT = NW * 64, RT = 4;
+  const int R = a.R, d = a.d, dff = a.dff;
+  const int ld = d + 8, ldf = dff + 8;  // row strides: floats of an fp32 row = halves of a plane row
+  float* P0 = smem + a.p0;   // planes of the current d-wide A operand (attention output, then out1)
+  float* P1 = smem + a.p1;   // fp32 rows: s1 -> out1 -> s2
+  float* P2 = smem + a.p2;   // planes of f
+  float* PV = smem + a.pv;   // bd | g1 | b1 | bf2 | g2 | b2 | bf1
+  float* OS = PV + 6 * d + dff;  // [64] row scales of the d-wide operand, [64] of f
+  const int tid = threadIdx.x, lane_id = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t n0 = (int64_t)blockIdx.x * R;
+  const int vr = (int)((a.T - n0) < R ? (a.T - n0) : R);
+  const float* pbd = PV, *pg1 = PV + d, *pb1 = PV + 2 * d, *pbf2 = PV + 3 * d, *pg2 = PV + 4 * d, *pb2 = PV + 5 * d, *pbf1 = PV + 6 * d;
+  const float invd = 1.0f / (float)d;
+
+  // ---- prologue: parameter vectors to LDS; the attention rows as two fp16 planes scaled per row -------------------------------
+  {
+    const int lane = lane_id;
+    for (int e = tid; e < 6 * d + dff; e += NT) {
+      const int v = e / d;  // 0 .. 5: the d-long vectors; 6 ..: bf1
+      const int64_t src = v == 0 ? a.bd : v == 1 ? a.g1 : v == 2 ? a.b1 : v == 3 ? a.bf2 : v == 4 ? a.g2 : v == 5 ? a.b2 : a.bf1;
+      PV[e] = params[src + (v < 6 ? e - v * d : e - 6 * d)];
+    }
+    const Src as = make_src(sv + a.A + n0 * d, (int64_t)vr * d);
+    const int c = 4 * lane;
+    float4 av[RT];
+    float am[RT];
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+      const int r = wave + NW * q;
+      av[q] = buf_ld4(as, c < d ? (unsigned)(r * d + c) * 4u : ULTR_OOB);
+      am[q] = fmaxf(fmaxf(fabsf(av[q].x), fabsf(av[q].y)), fmaxf(fabsf(av[q].z), fabsf(av[q].w)));
+    }
+    wave_max_n<RT>(am);
+    _Float16* AH = reinterpret_cast<_Float16*>(P0);
+    _Float16* AL = AH + (R + 1) * ld;
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+      const int r = wave + NW * q, rc = r < R ? r : R;
+      float rs, inv;
+      fb_h3_scale(am[q], rs, inv);
+      if (c < d) {
+        fbh4 hi, lo;
+        fb_h3_split4(av[q], rs, hi, lo);
+        *reinterpret_cast<fbh4*>(AH + rc * ld + c) = hi;
+        *reinterpret_cast<fbh4*>(AL + rc * ld + c) = lo;
+      }
+      if (lane == 0) OS[r] = inv * (1.0f / ULTR_H3_WSCALE);
+    }
+  }
+  lds_barrier();
+
+  // a d-wide product: wave = (32-column chunk, pair of row tiles); Y = (planes . W) x row scale + bias + residual -> P1 + saved
+  auto product_d = [&](const float* Ap, int lda, int nks, int64_t gw, int Kw, const float* bias, const float* os, bool res_lds,
+                       int64_t res_off, int64_t out_off) {
+    int lane = lane_id;
+    asm volatile("" : "+v"(lane));
+    const int nch = d >> 5;
+    const int ch = wave & 7, g = wave >> 3;
+    const bool has = ch < nch;
+    const int i = lane & 15, q = lane >> 4;
+    const _Float16* AH = reinterpret_cast<const _Float16*>(Ap);
+    const int lo_off = (R + 1) * lda;
+    const _Float16* pa[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = 16 * (2 * g + t) + i;
+      pa[t] = AH + (row < R ? row : R) * lda + 8 * q;
+    }
+    const Src Wh = make_src(reinterpret_cast<const float*>(planes + gw), (int64_t)Kw * d / 2 * 2);
+    const int col = 32 * ch + 2 * i;
+    // residual from `saved` (x): requested before the product
+    const Src rs_ = make_src(sv + res_off + n0 * d, res_lds ? 0 : (int64_t)vr * d);
+    float2 res[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        res[t][r] = buf_ld2(rs_, has ? (unsigned)((16 * (2 * g + t) + 4 * q + r) * d + col) * 4u : ULTR_OOB);
+    PipeH3W<2, 2> ph;
+    ph.begin(Wh, ch, nks, 0, nks, has, lane);
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) acc[t][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    ph.run(pa, lo_off, Wh, has ? nks : 0, acc);
+    if (has) {
+      const Dst dout = make_dst(sv + out_off + n0 * d, (int64_t)vr * d);
+      const float2 bv = *reinterpret_cast<const float2*>(bias + col);
+      const unsigned gv = (unsigned)(4 * q * d + 2 * i) * 4u;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float4 o4 = ld4(os + 16 * (2 * g + t) + 4 * q);
+        const float o[4] = {o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * (2 * g + t) + 4 * q + r;
+          const int rc = row < R ? row : R;
+          float2* dst = reinterpret_cast<float2*>(P1 + rc * ld + col);
+          const float2 rv = res_lds ? *dst : res[t][r];
+          const float2 y = make_float2(rv.x + (acc[t][0][r] * o[r] + bv.x), rv.y + (acc[t][1][r] * o[r] + bv.y));
+          *dst = y;
+          buf_st2(dout, gv, (unsigned)((16 * (2 * g + t) + r) * d + 32 * ch) * 4u, y);
+        }
+      }
+    }
+  };
+  // LayerNorm of the rows in P1 (a wave owns rows wave + 16 q): statistics and the output to `saved`; planes: the output also stays
+  // in P1 (the residual of the next sum) and goes to P0 as the two fp16 planes of the next product's operand
+  auto layer_norm = [&](const float* gam, const float* bet, int64_t mean_off, int64_t rstd_off, int64_t out_off, bool to_planes) {
+    int lane = lane_id;
+    asm volatile("" : "+v"(lane));
+    const int c = 4 * lane;
+    const bool cok = c < d;
+    float4 v[RT];
+    float s[RT], qv[RT];
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+      const int r = wave + NW * q;
+      v[q] = cok ? ld4(P1 + (r < R ? r : R) * ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      s[q] = (v[q].x + v[q].y) + (v[q].z + v[q].w);
+    }
+    wave_sum_n<RT>(s);
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+      s[q] *= invd;
+      if (cok) {
+        v[q].x -= s[q]; v[q].y -= s[q]; v[q].z -= s[q]; v[q].w -= s[q];
+      }
+      qv[q] = (v[q].x * v[q].x + v[q].y * v[q].y) + (v[q].z * v[q].z + v[q].w * v[q].w);
+    }
+    wave_sum_n<RT>(qv);
+    const Dst dmean = make_dst(sv + mean_off + n0, vr), drstd = make_dst(sv + rstd_off + n0, vr);
+    const Dst dout = make_dst(sv + out_off + n0 * d, (int64_t)vr * d);
+    const unsigned l0 = lane == 0 ? 0u : ULTR_OOB;
+    const float4 g4 = cok ? ld4(gam + c) : make_float4(0.f, 0.f, 0.f, 0.f), b4 = cok ? ld4(bet + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float am[RT];
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+      const int r = wave + NW * q;
+      const float rstd = 1.0f / sqrtf(qv[q] * invd + SR_EPS);
+      v[q] = make_float4(v[q].x * rstd * g4.x + b4.x, v[q].y * rstd * g4.y + b4.y, v[q].z * rstd * g4.z + b4.z, v[q].w * rstd * g4.w + b4.w);
+      buf_st4(dout, cok ? (unsigned)c * 4u : ULTR_OOB, (unsigned)(r * d) * 4u, v[q]);
+      buf_st1(dmean, l0, (unsigned)r * 4u, s[q]);
+      buf_st1(drstd, l0, (unsigned)r * 4u, rstd);
+      am[q] = fmaxf(fmaxf(fabsf(v[q].x), fabsf(v[q].y)), fmaxf(fabsf(v[q].z), fabsf(v[q].w)));
+    }
+    if (to_planes) {
+      wave_max_n<RT>(am);
+      _Float16* AH = reinterpret_cast<_Float16*>(P0);
+      _Float16* AL = AH + (R + 1) * ld;
+#pragma unroll
+      for (int q = 0; q < RT; ++q) {
+        const int r = wave + NW * q, rc = r < R ? r : R;
+        float rs, inv;
+        fb_h3_scale(am[q], rs, inv);
+        if (cok) {
+          st4(P1 + rc * ld + c, v[q]);
+          fbh4 hi, lo;
+          fb_h3_split4(v[q], rs, hi, lo);
+          *reinterpret_cast<fbh4*>(AH + rc * ld + c) = hi;
+          *reinterpret_cast<fbh4*>(AL + rc * ld + c) = lo;
+        }
+        if (lane == 0) OS[r] = inv * (1.0f / ULTR_H3_WSCALE);
+      }
+    }
+  };
+
+  product_d(P0, ld, d >> 5, a.gd, d, pbd, OS, false, a.x, a.s1);   // s1 = x + (A Wd^T + bd)
+  lds_barrier();
+  layer_norm(pg1, pb1, a.m1, a.r1, a.out1, true);                   // out1 = LN1(s1)
+  lds_barrier();
+  // ---- f = relu(out1 Wf1^T + bf1): one wave per row tile over every 32-column chunk of dff; planes of f scaled by the row maximum
+  if (wave < RT) {
+    int lane = lane_id;
+    asm volatile("" : "+v"(lane));
+    const int i = lane & 15, q = lane >> 4, nks = d >> 5, nchf = dff >> 5;
+    const _Float16* AH = reinterpret_cast<const _Float16*>(P0);
+    const int lo_off = (R + 1) * ld;
+    const int rowi = 16 * wave + i;
+    const _Float16* pa[1] = {AH + (rowi < R ? rowi : R) * ld + 8 * q};
+    const Src Wh = make_src(reinterpret_cast<const float*>(planes + a.gf1), (int64_t)d * dff);
+    f32x4 acc[4][2];
+    PipeH3W<1, 2> ph;
+    ph.begin(Wh, 0, nks, 0, nks, true, lane);
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) acc[ch][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (ch < nchf) {
+        f32x4 one[1][2] = {{acc[ch][0], acc[ch][1]}};
+        ph.run(pa, lo_off, Wh, nks, one);
+        if (ch + 1 < nchf) ph.begin(Wh, ch + 1, nks, 0, nks, true, lane);
+        acc[ch][0] = one[0][0];
+        acc[ch][1] = one[0][1];
+      }
+    }
+    const float4 o4 = ld4(OS + 16 * wave + 4 * q);
+    const float o[4] = {o4.x, o4.y, o4.z, o4.w};
+    float m[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch)
+      if (ch < nchf) {
+        const float2 bv = *reinterpret_cast<const float2*>(pbf1 + 32 * ch + 2 * i);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          acc[ch][0][r] = fmaxf(acc[ch][0][r] * o[r] + bv.x, 0.f);
+          acc[ch][1][r] = fmaxf(acc[ch][1][r] * o[r] + bv.y, 0.f);
+          m[r] = fmaxf(m[r], fmaxf(acc[ch][0][r], acc[ch][1][r]));
+        }
+      }
+    row16_max4(m);
+    const Dst df = make_dst(sv + a.f + n0 * dff, (int64_t)vr * dff);
+    _Float16* FH = reinterpret_cast<_Float16*>(P2);
+    _Float16* FL = FH + (R + 1) * ldf;
+    typedef _Float16 fbh2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * wave + 4 * q + r, rc = row < R ? row : R;
+      float rs, inv;
+      fb_h3_scale(m[r], rs, inv);
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch)
+        if (ch < nchf) {
+          const int col = 32 * ch + 2 * i;
+          const float y0 = acc[ch][0][r], y1 = acc[ch][1][r];
+          buf_st2(df, (unsigned)(4 * q * dff + col) * 4u, (unsigned)((16 * wave + r) * dff) * 4u, make_float2(y0, y1));
+          const float s0 = y0 * rs, s1_ = y1 * rs;
+          fbh2 hi, lo;
+          hi[0] = (_Float16)s0; hi[1] = (_Float16)s1_;
+          lo[0] = (_Float16)(s0 - (float)hi[0]); lo[1] = (_Float16)(s1_ - (float)hi[1]);
+          *reinterpret_cast<fbh2*>(FH + rc * ldf + col) = hi;
+          *reinterpret_cast<fbh2*>(FL + rc * ldf + col) = lo;
+        }
+      if (i == 0) OS[64 + row] = inv * (1.0f / ULTR_H3_WSCALE);
+    }
+  }
+  lds_barrier();
+  product_d(P2, ldf, dff >> 5, a.gf2, dff, pbf2, OS + 64, true, 0, a.s2);  // s2 = out1 + (f Wf2^T + bf2)
+  lds_barrier();
+  layer_norm(pg2, pb2, a.m2, a.r2, a.xn, false);                          // x' = LN2(s2)
+}
+
+
+// sr_block_fwd_kernel: legal for widths that are multiples of 32 (d <= 256, dff <= 128) with the split-half products on; rows per
+// workgroup = whole rounds of one workgroup per CU, as many as the LDS holds (<= 60 at d = 256)
+int g_sr_knob_block = -1;
+bool block_fwd(const SrPlan& p, int l, const float* params, float* sv, hipStream_t st, int* rc) {
+  if (g_sr_knob_block < 0) {
+    const char* e = getenv("ULTR_SR_BLOCK");
+    g_sr_knob_block = (e && *e) ? atoi(e) : 1;
+  }
+  const int d = p.d, dff = p.dff;
+  if (!g_sr_knob_block || !sr_h3_enabled() || p.no_h3 || g_sr_h3.planes == nullptr || d % 32 != 0 || dff % 32 != 0 || d > 256 || dff > 128 || d < 32)
+    return false;
+  const SrPlan::SplitMat* md = sr_find_split(params + p.lay[l].wd, d, d);
+  const SrPlan::SplitMat* m1 = sr_find_split(params + p.lay[l].wf1, dff, d);
+  const SrPlan::SplitMat* m2 = sr_find_split(params + p.lay[l].wf2, d, dff);
+  if (!md || !m1 || !m2 || md->g_off < 0 || m1->g_off < 0 || m2->g_off < 0 || (((uintptr_t)sv | (uintptr_t)g_sr_h3.planes) & 15) != 0) return false;
+  const int64_t per_row = (int64_t)(2 * (d + 8) + (dff + 8)) * 4, fixed = (int64_t)(6 * d + dff + 128) * 4;
+  int64_t rmax = (160 * 1024 - fixed) / per_row - 1;
+  if (rmax > 64) rmax = 64;
+  if (rmax < 16) return false;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  const int64_t rounds = (p.T + (int64_t)cus * rmax - 1) / ((int64_t)cus * rmax);
+  int64_t R = (p.T + (int64_t)cus * rounds - 1) / ((int64_t)cus * rounds);
+  if (R < 16) R = 16;
+  SrBlockArgs a;
+  memset(&a, 0, sizeof(a));
+  a.R = (int)R; a.d = d; a.dff = dff; a.T = p.T;
+  const SrLayer& y = p.lay[l];
+  a.bd = y.bd; a.bf1 = y.bf1; a.bf2 = y.bf2; a.g1 = y.g1; a.b1 = y.b1; a.g2 = y.g2; a.b2 = y.b2;
+  a.gd = md->g_off; a.gf1 = m1->g_off; a.gf2 = m2->g_off;
+  a.A = p.sv_A[l]; a.x = p.sv_x[l]; a.s1 = p.sv_s1[l]; a.m1 = p.sv_m1[l]; a.r1 = p.sv_r1[l]; a.out1 = p.sv_out1[l]; a.f = p.sv_f[l];
+  a.s2 = p.sv_s2[l]; a.m2 = p.sv_m2[l]; a.r2 = p.sv_r2[l]; a.xn = p.sv_x[l + 1];
+  a.p0 = 0;
+  a.p1 = (int)((R + 1) * (d + 8));
+  a.p2 = 2 * a.p1;
+  a.pv = a.p2 + (int)((R + 1) * (dff + 8));
+  const size_t lds = (size_t)(a.pv + 6 * d + dff + 128) * sizeof(float);
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(sr_block_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    *rc = ULTR_E_UNSUPPORTED;
+    return true;
+  }
+  hipLaunchKernelGGL(sr_block_fwd_kernel, dim3((unsigned)((p.T + R - 1) / R)), dim3(1024), lds, st, a, params, g_sr_h3.planes, sv);
+  *rc = (int)hipGetLastError();
+  return true;
+}
 }  // namespace
 
-void ultr_setrank_knobs_reload() { g_sr_knob_h3 = -1; }
+void ultr_setrank_knobs_reload() {
+  g_sr_knob_h3 = -1;
+  g_sr_knob_block = -1;
+}
 
 extern "C" int64_t ultr_setrank_param_count(const ultr_setrank_desc* c) {
   SrPlan p;
@@ -2186,7 +2542,7 @@ extern "C" int ultr_setrank_forward(const ultr_setrank_desc* c, const float* par
       maxe = a > maxe ? a : maxe;
       maxe = b > maxe ? b : maxe;
     }
-    hipLaunchKernelGGL(sr_split_planes_kernel, dim3((unsigned)((maxe + 255) / 256), (unsigned)(2 * p.n_split)), dim3(256), 0, st, tb, params, planes,
+    hipLaunchKernelGGL(sr_split_planes_kernel, dim3((unsigned)((maxe + 255) / 256), (unsigned)(3 * p.n_split)), dim3(256), 0, st, tb, params, planes,
                        reinterpret_cast<uint32_t*>(sv + p.sv_flag));
     g_sr_h3 = {params, planes, &p};
   }
@@ -2216,6 +2572,13 @@ extern "C" int ultr_setrank_forward(const ultr_setrank_desc* c, const float* par
     // A Wd^T lands in out1's buffer, then out1 = LN1(x + (A Wd^T + bd)) in place (s1 keeps the pre-norm sum)
     // the Linear's epilogue writes the pre-norm sum s1 = x + (A Wd^T + bd) straight into `saved` (one pass over [T, d] less on
     // each side of the LayerNorm); shapes the tiled GEMM does not take: Linear, then the residual pass
+    {
+      int brc = 0;
+      if (block_fwd(p, l, params, sv, st, &brc)) {  // everything behind the attention in one launch (sr_block_fwd_kernel)
+        if (brc) return brc;
+        continue;
+      }
+    }
     const bool ln_v4 = (d == 256 || d == 512 || d == 768 || d == 1024);
     if (ln_v4 && gemm_xwT_res(sv + p.sv_A[l], params + y.wd, params + y.bd, x, sv + p.sv_s1[l], T, d, d, st)) {
       ln_residual_fwd(sv + p.sv_s1[l], nullptr, nullptr, T, d, params + y.g1, params + y.b1, nullptr, sv + p.sv_out1[l],
