@@ -2194,10 +2194,13 @@ __device__ __forceinline__ void row16_max4(float (&v)[4]) {
   for (int k = 0; k < 4; ++k) ULTR_DPP_MAX(v[k], "row_ror:8 row_mask:0xf");
 }
 
-__global__ __launch_bounds__(1024) void sr_block_fwd_kernel(SrBlockArgs a, const float* __restrict__ params,
+// NW = 16: up to 64 rows, one workgroup per CU; NW = 8: up to 32 rows and half the LDS - two workgroups per CU, each other's memory
+// waits and phases overlapping
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void sr_block_fwd_kernel(SrBlockArgs a, const float* __restrict__ params,
                                                             const _Float16* __restrict__ planes, float* __restrict__ sv) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int NW = 16, NT = NW * 64, RT = 4;
+  constexpr int NT = NW * 64, RT = 4;  // a wave owns rows wave + NW q, q < 4, in the row-wise phases
   const int R = a.R, d = a.d, dff = a.dff;
   const int ld = d + 8, ldf = dff + 8;  // row strides: floats of an fp32 row = halves of a plane row
   float* P0 = smem + a.p0;   // planes of the current d-wide A operand (attention output, then out1)
@@ -2370,7 +2373,7 @@ __global__ __launch_bounds__(1024) void sr_block_fwd_kernel(SrBlockArgs a, const
   layer_norm(pg1, pb1, a.m1, a.r1, a.out1, true);                   // out1 = LN1(s1)
   lds_barrier();
   // ---- f = relu(out1 Wf1^T + bf1): one wave per row tile over every 32-column chunk of dff; planes of f scaled by the row maximum
-  if (wave < RT) {
+  if (wave < NW / 4) {  // (NW / 4 row tiles of 16)
     int lane = lane_id;
     asm volatile("" : "+v"(lane));
     const int i = lane & 15, q = lane >> 4, nks = d >> 5, nchf = dff >> 5;
@@ -2447,7 +2450,7 @@ int g_sr_knob_block = -1;
 bool block_fwd(const SrPlan& p, int l, const float* params, float* sv, hipStream_t st, int* rc) {
   if (g_sr_knob_block < 0) {
     const char* e = getenv("ULTR_SR_BLOCK");
-    g_sr_knob_block = (e && *e) ? atoi(e) : 1;
+    g_sr_knob_block = (e && *e) ? atoi(e) : 2;  // 0: off; 1: one 16-wave workgroup per CU; 2: two 8-wave workgroups per CU
   }
   const int d = p.d, dff = p.dff;
   if (!g_sr_knob_block || !sr_h3_enabled() || p.no_h3 || g_sr_h3.planes == nullptr || d % 32 != 0 || dff % 32 != 0 || d > 256 || dff > 128 || d < 32)
@@ -2457,13 +2460,15 @@ bool block_fwd(const SrPlan& p, int l, const float* params, float* sv, hipStream
   const SrPlan::SplitMat* m2 = sr_find_split(params + p.lay[l].wf2, d, dff);
   if (!md || !m1 || !m2 || md->g_off < 0 || m1->g_off < 0 || m2->g_off < 0 || (((uintptr_t)sv | (uintptr_t)g_sr_h3.planes) & 15) != 0) return false;
   const int64_t per_row = (int64_t)(2 * (d + 8) + (dff + 8)) * 4, fixed = (int64_t)(6 * d + dff + 128) * 4;
-  int64_t rmax = (160 * 1024 - fixed) / per_row - 1;
-  if (rmax > 64) rmax = 64;
+  const bool two = g_sr_knob_block != 1;  // two 8-wave workgroups per CU (default) / 1: one 16-wave workgroup
+  int64_t rmax = ((two ? 80 : 160) * 1024 - fixed) / per_row - 1;
+  if (rmax > (two ? 32 : 64)) rmax = two ? 32 : 64;
   if (rmax < 16) return false;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-  const int64_t rounds = (p.T + (int64_t)cus * rmax - 1) / ((int64_t)cus * rmax);
-  int64_t R = (p.T + (int64_t)cus * rounds - 1) / ((int64_t)cus * rounds);
+  const int64_t slots = (int64_t)cus * (two ? 2 : 1);
+  const int64_t rounds = (p.T + slots * rmax - 1) / (slots * rmax);
+  int64_t R = (p.T + slots * rounds - 1) / (slots * rounds);
   if (R < 16) R = 16;
   SrBlockArgs a;
   memset(&a, 0, sizeof(a));
@@ -2479,11 +2484,13 @@ bool block_fwd(const SrPlan& p, int l, const float* params, float* sv, hipStream
   a.pv = a.p2 + (int)((R + 1) * (dff + 8));
   const size_t lds = (size_t)(a.pv + 6 * d + dff + 128) * sizeof(float);
   if (lds > 64 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(sr_block_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      hipFuncSetAttribute(two ? reinterpret_cast<const void*>(sr_block_fwd_kernel<8>) : reinterpret_cast<const void*>(sr_block_fwd_kernel<16>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
     *rc = ULTR_E_UNSUPPORTED;
     return true;
   }
-  hipLaunchKernelGGL(sr_block_fwd_kernel, dim3((unsigned)((p.T + R - 1) / R)), dim3(1024), lds, st, a, params, g_sr_h3.planes, sv);
+  if (two) hipLaunchKernelGGL(sr_block_fwd_kernel<8>, dim3((unsigned)((p.T + R - 1) / R)), dim3(512), lds, st, a, params, g_sr_h3.planes, sv);
+  else hipLaunchKernelGGL(sr_block_fwd_kernel<16>, dim3((unsigned)((p.T + R - 1) / R)), dim3(1024), lds, st, a, params, g_sr_h3.planes, sv);
   *rc = (int)hipGetLastError();
   return true;
 }
