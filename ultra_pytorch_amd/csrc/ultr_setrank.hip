@@ -36,6 +36,11 @@ extern "C" int ultr_gemm_trace_arm(int on) {  // slot 31 != 0: frozen
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ugemm_trace), z, sizeof(z));
 }
 #endif
+#ifndef UGEMM_TRACE_STAMP
+#define UGEMM_TRACE_STAMP(slot) \
+  do {                          \
+  } while (0)
+#endif
 #include "ultr_gemm.h"
 #include "ultr_h3.h"
 #include "ultr_plan.h"
@@ -153,8 +158,9 @@ bool make_plan(const ultr_setrank_desc* c, int64_t T, SrPlan* p) {
     for (int l = 0; l < p->nl; ++l) { add(p->lay[l].wd, d, d); add(p->lay[l].wf1, dff, d); add(p->lay[l].wf2, d, dff); }
     // fragment-major split-half copies (ultr_h3_index) of the encoder blocks' three matrices for the fused block kernel
     if (d % 32 == 0 && dff % 32 == 0)
-      for (int k = 3; k < p->n_split; ++k) {
+      for (int k = 0; k < p->n_split; ++k) {  // (every matrix: the embedding FFN and the output FFN have fused kernels too)
         SrPlan::SplitMat& m = p->split[k];
+        if (m.M % 32 != 0) continue;
         h = (h + 7) & ~(int64_t)7;  // 16-byte aligned: the kernel streams it with 16-byte buffer loads
         m.g_off = h;
         h += 2 * (int64_t)m.M * m.ldK;
@@ -2176,6 +2182,9 @@ struct SrBlockArgs {
   int64_t gd, gf1, gf2;                                  // HALF offsets of the fragment-major copies of Wd, Wf1, Wf2 from the planes
   int64_t A, x, s1, m1, r1, out1, f, s2, m2, r2, xn;     // float offsets into `saved`
   int p0, p1, p2, pv;                                    // float offsets into dynamic LDS
+  // the last block also runs the output FFN (SetRank.py:136, 153): oh = relu(x' Wo1^T + bo1), score = oh . wo2 + bo2
+  int head;
+  int64_t go1, bo1, wo2, bo2, oh;                        // fragment copy of Wo1 (halves), parameter offsets, saved oh
 };
 
 __device__ __forceinline__ float2 buf_ld2(const Src& s, unsigned byte_off) {
@@ -2183,6 +2192,16 @@ __device__ __forceinline__ float2 buf_ld2(const Src& s, unsigned byte_off) {
   return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
 }
 // maximum over the 16 lanes of a DPP row (the lanes that hold one accumulator row group)
+__device__ __forceinline__ void row16_sum4(float (&v)[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] += dpp_or<0xb1>(0.f, v[k]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] += dpp_or<0x4e>(0.f, v[k]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] += dpp_or<0x124>(0.f, v[k]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] += dpp_or<0x128>(0.f, v[k]);
+}
 __device__ __forceinline__ void row16_max4(float (&v)[4]) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) ULTR_DPP_MAX(v[k], "quad_perm:[1,0,3,2] row_mask:0xf");
@@ -2198,7 +2217,8 @@ __device__ __forceinline__ void row16_max4(float (&v)[4]) {
 // waits and phases overlapping
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void sr_block_fwd_kernel(SrBlockArgs a, const float* __restrict__ params,
-                                                            const _Float16* __restrict__ planes, float* __restrict__ sv) {
+                                                            const _Float16* __restrict__ planes, float* __restrict__ sv,
+                                                            float* __restrict__ scores) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = NW * 64, RT = 4;  // a wave owns rows wave + NW q, q < 4, in the row-wise phases
   const int R = a.R, d = a.d, dff = a.dff;
@@ -2206,14 +2226,15 @@ __global__ __launch_bounds__(NW * 64) void sr_block_fwd_kernel(SrBlockArgs a, co
   float* P0 = smem + a.p0;   // planes of the current d-wide A operand (attention output, then out1)
   float* P1 = smem + a.p1;   // fp32 rows: s1 -> out1 -> s2
   float* P2 = smem + a.p2;   // planes of f
-  float* PV = smem + a.pv;   // bd | g1 | b1 | bf2 | g2 | b2 | bf1
-  float* OS = PV + 6 * d + dff;  // [64] row scales of the d-wide operand, [64] of f
+  float* PV = smem + a.pv;   // bd | g1 | b1 | bf2 | g2 | b2 | bf1 | bo1 | wo2 | bo2 (+ 3 pad)
+  float* OS = PV + 6 * d + 3 * dff + 4;  // [64] row scales of the d-wide operand, [64] of f
   const int tid = threadIdx.x, lane_id = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t n0 = (int64_t)blockIdx.x * R;
   const int vr = (int)((a.T - n0) < R ? (a.T - n0) : R);
   const float* pbd = PV, *pg1 = PV + d, *pb1 = PV + 2 * d, *pbf2 = PV + 3 * d, *pg2 = PV + 4 * d, *pb2 = PV + 5 * d, *pbf1 = PV + 6 * d;
   const float invd = 1.0f / (float)d;
 
+  UGEMM_TRACE_STAMP(20);
   // ---- prologue: parameter vectors to LDS; the attention rows as two fp16 planes scaled per row -------------------------------
   {
     const int lane = lane_id;
@@ -2222,6 +2243,9 @@ __global__ __launch_bounds__(NW * 64) void sr_block_fwd_kernel(SrBlockArgs a, co
       const int64_t src = v == 0 ? a.bd : v == 1 ? a.g1 : v == 2 ? a.b1 : v == 3 ? a.bf2 : v == 4 ? a.g2 : v == 5 ? a.b2 : a.bf1;
       PV[e] = params[src + (v < 6 ? e - v * d : e - 6 * d)];
     }
+    if (a.head)
+      for (int e = tid; e < 2 * dff + 1; e += NT)
+        PV[6 * d + dff + e] = params[e < dff ? a.bo1 + e : e < 2 * dff ? a.wo2 + (e - dff) : a.bo2];
     const Src as = make_src(sv + a.A + n0 * d, (int64_t)vr * d);
     const int c = 4 * lane;
     float4 av[RT];
@@ -2368,98 +2392,138 @@ __global__ __launch_bounds__(NW * 64) void sr_block_fwd_kernel(SrBlockArgs a, co
     }
   };
 
-  product_d(P0, ld, d >> 5, a.gd, d, pbd, OS, false, a.x, a.s1);   // s1 = x + (A Wd^T + bd)
-  lds_barrier();
-  layer_norm(pg1, pb1, a.m1, a.r1, a.out1, true);                   // out1 = LN1(s1)
-  lds_barrier();
-  // ---- f = relu(out1 Wf1^T + bf1): one wave per row tile over every 32-column chunk of dff; planes of f scaled by the row maximum
-  if (wave < NW / 4) {  // (NW / 4 row tiles of 16)
+  // a dff-wide product with ReLU (dff = 32 / 64 / 128: 1 / 2 / 4 chunks of 32 columns): wave = (row tile, chunk, slice of the contraction),
+  // the partial tiles summed slice by slice into P2 as fp32 rows; then every wave finishes its own rows (wave + NW q): bias, ReLU, the
+  // row to `saved`, and either the two fp16 planes scaled by the row maximum (the block's f) or the dot product with a vector (the scorer).
+  // (The first version gave a whole row tile to ONE wave - the row maximum a 16-lane reduction - and two of eight waves did all of
+  // it: ~50 us of the launch's 190.)
+  auto product_f = [&](int64_t gw, const float* bias, int64_t out_off, const float* wdot, float bdot) {
+    float* F32 = P2;
+    {
+      int lane = lane_id;
+      asm volatile("" : "+v"(lane));
+      const int i = lane & 15, q = lane >> 4, nks = d >> 5, nchf = dff >> 5, ksplit = 4 / nchf;
+      const int rt = wave >> 2;
+      int ch = wave & 3, ks = 0;
+      while (ch >= nchf) { ch -= nchf; ++ks; }
+      const int len = (nks + ksplit - 1) / ksplit, k0 = ks * len;
+      const int cnt = k0 >= nks ? 0 : (k0 + len < nks ? len : nks - k0);
+      const _Float16* AH = reinterpret_cast<const _Float16*>(P0);
+      const int lo_off = (R + 1) * ld;
+      const int rowi = 16 * rt + i;
+      const _Float16* pa[1] = {AH + (rowi < R ? rowi : R) * ld + 8 * q + 32 * k0};
+      const Src Wh = make_src(reinterpret_cast<const float*>(planes + gw), (int64_t)d * dff);
+      f32x4 acc[1][2] = {{(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}}};
+      PipeH3W<1, 2> ph;
+      ph.begin(Wh, ch, nks, k0, cnt, cnt > 0, lane);
+      ph.run(pa, lo_off, Wh, cnt, acc);
+      const int col = 32 * ch + 2 * i;
+      for (int sl = 0; sl < ksplit; ++sl) {
+        if (ks == sl) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * rt + 4 * q + r, rc = row < R ? row : R;
+            float2* dst = reinterpret_cast<float2*>(F32 + rc * ldf + col);
+            float2 y = make_float2(acc[0][0][r], acc[0][1][r]);
+            if (sl > 0) {
+              const float2 o = *dst;
+              y.x += o.x;
+              y.y += o.y;
+            }
+            *dst = y;
+          }
+        }
+        lds_barrier();
+      }
+    }
     int lane = lane_id;
     asm volatile("" : "+v"(lane));
-    const int i = lane & 15, q = lane >> 4, nks = d >> 5, nchf = dff >> 5;
-    const _Float16* AH = reinterpret_cast<const _Float16*>(P0);
-    const int lo_off = (R + 1) * ld;
-    const int rowi = 16 * wave + i;
-    const _Float16* pa[1] = {AH + (rowi < R ? rowi : R) * ld + 8 * q};
-    const Src Wh = make_src(reinterpret_cast<const float*>(planes + a.gf1), (int64_t)d * dff);
-    f32x4 acc[4][2];
-    PipeH3W<1, 2> ph;
-    ph.begin(Wh, 0, nks, 0, nks, true, lane);
+    const int c = 4 * lane;
+    const bool cok = c < dff;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 b4 = cok ? ld4(bias + c) : z4, w4 = (cok && wdot != nullptr) ? ld4(wdot + c) : z4;
+    const Dst df = make_dst(sv + out_off + n0 * dff, (int64_t)vr * dff);
+    float4 v[RT];
+    float am[RT];
 #pragma unroll
-    for (int ch = 0; ch < 4; ++ch) {
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) acc[ch][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (ch < nchf) {
-        f32x4 one[1][2] = {{acc[ch][0], acc[ch][1]}};
-        ph.run(pa, lo_off, Wh, nks, one);
-        if (ch + 1 < nchf) ph.begin(Wh, ch + 1, nks, 0, nks, true, lane);
-        acc[ch][0] = one[0][0];
-        acc[ch][1] = one[0][1];
-      }
+    for (int q = 0; q < RT; ++q) {
+      const int r = wave + NW * q, rc = r < R ? r : R;
+      const float os = OS[r];
+      v[q] = cok ? ld4(F32 + rc * ldf + c) : z4;
+      v[q] = make_float4(fmaxf(v[q].x * os + b4.x, 0.f), fmaxf(v[q].y * os + b4.y, 0.f), fmaxf(v[q].z * os + b4.z, 0.f), fmaxf(v[q].w * os + b4.w, 0.f));
+      buf_st4(df, cok ? (unsigned)c * 4u : ULTR_OOB, (unsigned)(r * dff) * 4u, v[q]);
+      am[q] = wdot != nullptr ? (v[q].x * w4.x + v[q].y * w4.y) + (v[q].z * w4.z + v[q].w * w4.w)
+                              : fmaxf(fmaxf(v[q].x, v[q].y), fmaxf(v[q].z, v[q].w));
     }
-    const float4 o4 = ld4(OS + 16 * wave + 4 * q);
-    const float o[4] = {o4.x, o4.y, o4.z, o4.w};
-    float m[4] = {0.f, 0.f, 0.f, 0.f};
+    if (wdot != nullptr) {
+      wave_sum_n<RT>(am);
+      const Dst dsc = make_dst(scores + n0, vr);
 #pragma unroll
-    for (int ch = 0; ch < 4; ++ch)
-      if (ch < nchf) {
-        const float2 bv = *reinterpret_cast<const float2*>(pbf1 + 32 * ch + 2 * i);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          acc[ch][0][r] = fmaxf(acc[ch][0][r] * o[r] + bv.x, 0.f);
-          acc[ch][1][r] = fmaxf(acc[ch][1][r] * o[r] + bv.y, 0.f);
-          m[r] = fmaxf(m[r], fmaxf(acc[ch][0][r], acc[ch][1][r]));
-        }
-      }
-    row16_max4(m);
-    const Dst df = make_dst(sv + a.f + n0 * dff, (int64_t)vr * dff);
+      for (int q = 0; q < RT; ++q) buf_st1(dsc, lane == 0 ? 0u : ULTR_OOB, (unsigned)(wave + NW * q) * 4u, am[q] + bdot);
+      return;
+    }
+    wave_max_n<RT>(am);
+    lds_barrier();  // every wave holds its rows: the planes may overwrite them
     _Float16* FH = reinterpret_cast<_Float16*>(P2);
     _Float16* FL = FH + (R + 1) * ldf;
-    typedef _Float16 fbh2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 16 * wave + 4 * q + r, rc = row < R ? row : R;
+    for (int q = 0; q < RT; ++q) {
+      const int r = wave + NW * q, rc = r < R ? r : R;
       float rs, inv;
-      fb_h3_scale(m[r], rs, inv);
-#pragma unroll
-      for (int ch = 0; ch < 4; ++ch)
-        if (ch < nchf) {
-          const int col = 32 * ch + 2 * i;
-          const float y0 = acc[ch][0][r], y1 = acc[ch][1][r];
-          buf_st2(df, (unsigned)(4 * q * dff + col) * 4u, (unsigned)((16 * wave + r) * dff) * 4u, make_float2(y0, y1));
-          const float s0 = y0 * rs, s1_ = y1 * rs;
-          fbh2 hi, lo;
-          hi[0] = (_Float16)s0; hi[1] = (_Float16)s1_;
-          lo[0] = (_Float16)(s0 - (float)hi[0]); lo[1] = (_Float16)(s1_ - (float)hi[1]);
-          *reinterpret_cast<fbh2*>(FH + rc * ldf + col) = hi;
-          *reinterpret_cast<fbh2*>(FL + rc * ldf + col) = lo;
-        }
-      if (i == 0) OS[64 + row] = inv * (1.0f / ULTR_H3_WSCALE);
+      fb_h3_scale(am[q], rs, inv);
+      if (cok) {
+        fbh4 hi, lo;
+        fb_h3_split4(v[q], rs, hi, lo);
+        *reinterpret_cast<fbh4*>(FH + rc * ldf + c) = hi;
+        *reinterpret_cast<fbh4*>(FL + rc * ldf + c) = lo;
+      }
+      if (lane == 0) OS[64 + r] = inv * (1.0f / ULTR_H3_WSCALE);
     }
-  }
+  };
+
+  UGEMM_TRACE_STAMP(21);
+  product_d(P0, ld, d >> 5, a.gd, d, pbd, OS, false, a.x, a.s1);   // s1 = x + (A Wd^T + bd)
+  UGEMM_TRACE_STAMP(22);
   lds_barrier();
+  UGEMM_TRACE_STAMP(23);
+  layer_norm(pg1, pb1, a.m1, a.r1, a.out1, true);                   // out1 = LN1(s1)
+  UGEMM_TRACE_STAMP(24);
+  lds_barrier();
+  UGEMM_TRACE_STAMP(25);
+  product_f(a.gf1, pbf1, a.f, nullptr, 0.f);                      // f = relu(out1 Wf1^T + bf1)
+  UGEMM_TRACE_STAMP(26);
+  lds_barrier();
+  UGEMM_TRACE_STAMP(27);
   product_d(P2, ldf, dff >> 5, a.gf2, dff, pbf2, OS + 64, true, 0, a.s2);  // s2 = out1 + (f Wf2^T + bf2)
+  UGEMM_TRACE_STAMP(28);
   lds_barrier();
-  layer_norm(pg2, pb2, a.m2, a.r2, a.xn, false);                          // x' = LN2(s2)
+  UGEMM_TRACE_STAMP(29);
+  layer_norm(pg2, pb2, a.m2, a.r2, a.xn, a.head != 0);                    // x' = LN2(s2)
+  UGEMM_TRACE_STAMP(30);
+  if (a.head) {
+    lds_barrier();
+    const float* pbo1 = PV + 6 * d + dff;
+    product_f(a.go1, pbo1, a.oh, pbo1 + dff, pbo1[2 * dff]);               // oh = relu(x' Wo1^T + bo1), score = oh . wo2 + bo2
+  }
 }
 
 
 // sr_block_fwd_kernel: legal for widths that are multiples of 32 (d <= 256, dff <= 128) with the split-half products on; rows per
 // workgroup = whole rounds of one workgroup per CU, as many as the LDS holds (<= 60 at d = 256)
 int g_sr_knob_block = -1;
-bool block_fwd(const SrPlan& p, int l, const float* params, float* sv, hipStream_t st, int* rc) {
+bool block_fwd(const SrPlan& p, int l, const float* params, float* sv, float* scores, hipStream_t st, int* rc) {
   if (g_sr_knob_block < 0) {
     const char* e = getenv("ULTR_SR_BLOCK");
     g_sr_knob_block = (e && *e) ? atoi(e) : 2;  // 0: off; 1: one 16-wave workgroup per CU; 2: two 8-wave workgroups per CU
   }
   const int d = p.d, dff = p.dff;
-  if (!g_sr_knob_block || !sr_h3_enabled() || p.no_h3 || g_sr_h3.planes == nullptr || d % 32 != 0 || dff % 32 != 0 || d > 256 || dff > 128 || d < 32)
+  if (!g_sr_knob_block || !sr_h3_enabled() || p.no_h3 || g_sr_h3.planes == nullptr || d % 32 != 0 || (dff != 32 && dff != 64 && dff != 128) || d > 256 || d < 32)
     return false;
   const SrPlan::SplitMat* md = sr_find_split(params + p.lay[l].wd, d, d);
   const SrPlan::SplitMat* m1 = sr_find_split(params + p.lay[l].wf1, dff, d);
   const SrPlan::SplitMat* m2 = sr_find_split(params + p.lay[l].wf2, d, dff);
   if (!md || !m1 || !m2 || md->g_off < 0 || m1->g_off < 0 || m2->g_off < 0 || (((uintptr_t)sv | (uintptr_t)g_sr_h3.planes) & 15) != 0) return false;
-  const int64_t per_row = (int64_t)(2 * (d + 8) + (dff + 8)) * 4, fixed = (int64_t)(6 * d + dff + 128) * 4;
+  const int64_t per_row = (int64_t)(2 * (d + 8) + (dff + 8)) * 4, fixed = (int64_t)(6 * d + 3 * dff + 4 + 128) * 4;
   const bool two = g_sr_knob_block != 1;  // two 8-wave workgroups per CU (default) / 1: one 16-wave workgroup
   int64_t rmax = ((two ? 80 : 160) * 1024 - fixed) / per_row - 1;
   if (rmax > (two ? 32 : 64)) rmax = two ? 32 : 64;
@@ -2478,20 +2542,28 @@ bool block_fwd(const SrPlan& p, int l, const float* params, float* sv, hipStream
   a.gd = md->g_off; a.gf1 = m1->g_off; a.gf2 = m2->g_off;
   a.A = p.sv_A[l]; a.x = p.sv_x[l]; a.s1 = p.sv_s1[l]; a.m1 = p.sv_m1[l]; a.r1 = p.sv_r1[l]; a.out1 = p.sv_out1[l]; a.f = p.sv_f[l];
   a.s2 = p.sv_s2[l]; a.m2 = p.sv_m2[l]; a.r2 = p.sv_r2[l]; a.xn = p.sv_x[l + 1];
+  if (l == p.nl - 1 && p.bo2 == p.wo2 + dff) {  // the output FFN rides along with the last block
+    const SrPlan::SplitMat* mo = sr_find_split(params + p.wo1, dff, d);
+    if (mo != nullptr && mo->g_off >= 0 && scores != nullptr) {
+      a.head = 1;
+      a.go1 = mo->g_off; a.bo1 = p.bo1; a.wo2 = p.wo2; a.bo2 = p.bo2; a.oh = p.sv_oh;
+    }
+  }
   a.p0 = 0;
   a.p1 = (int)((R + 1) * (d + 8));
   a.p2 = 2 * a.p1;
   a.pv = a.p2 + (int)((R + 1) * (dff + 8));
-  const size_t lds = (size_t)(a.pv + 6 * d + dff + 128) * sizeof(float);
+  const size_t lds = (size_t)(a.pv + 6 * d + 3 * dff + 4 + 128) * sizeof(float);
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(two ? reinterpret_cast<const void*>(sr_block_fwd_kernel<8>) : reinterpret_cast<const void*>(sr_block_fwd_kernel<16>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
     *rc = ULTR_E_UNSUPPORTED;
     return true;
   }
-  if (two) hipLaunchKernelGGL(sr_block_fwd_kernel<8>, dim3((unsigned)((p.T + R - 1) / R)), dim3(512), lds, st, a, params, g_sr_h3.planes, sv);
-  else hipLaunchKernelGGL(sr_block_fwd_kernel<16>, dim3((unsigned)((p.T + R - 1) / R)), dim3(1024), lds, st, a, params, g_sr_h3.planes, sv);
+  if (two) hipLaunchKernelGGL(sr_block_fwd_kernel<8>, dim3((unsigned)((p.T + R - 1) / R)), dim3(512), lds, st, a, params, g_sr_h3.planes, sv, scores);
+  else hipLaunchKernelGGL(sr_block_fwd_kernel<16>, dim3((unsigned)((p.T + R - 1) / R)), dim3(1024), lds, st, a, params, g_sr_h3.planes, sv, scores);
   *rc = (int)hipGetLastError();
+  if (a.head && *rc == 0) *rc = -1;  // (-1: launched, and the output FFN is done as well)
   return true;
 }
 }  // namespace
@@ -2570,6 +2642,7 @@ extern "C" int ultr_setrank_forward(const ultr_setrank_desc* c, const float* par
       return ULTR_E_UNSUPPORTED;
   }
   const bool mfma_att = attn_mfma_ok(p, L);
+  bool head_done = false;
   for (int l = 0; l < p.nl; ++l) {
     const SrLayer& y = p.lay[l];
     const float* x = sv + p.sv_x[l];
@@ -2581,8 +2654,9 @@ extern "C" int ultr_setrank_forward(const ultr_setrank_desc* c, const float* par
     // each side of the LayerNorm); shapes the tiled GEMM does not take: Linear, then the residual pass
     {
       int brc = 0;
-      if (block_fwd(p, l, params, sv, st, &brc)) {  // everything behind the attention in one launch (sr_block_fwd_kernel)
-        if (brc) return brc;
+      if (block_fwd(p, l, params, sv, scores, st, &brc)) {  // everything behind the attention in one launch (sr_block_fwd_kernel)
+        if (brc > 0 || brc < -1) return brc;
+        head_done = brc == -1;
         continue;
       }
     }
@@ -2606,8 +2680,10 @@ extern "C" int ultr_setrank_forward(const ultr_setrank_desc* c, const float* par
     }
   }
   // output FFN (SetRank.py:136, 153)
-  SR_CHECK(gemm_xwT(sv + p.sv_x[p.nl], params + p.wo1, params + p.bo1, sv + p.sv_oh, T, d, dff, 1, st));
-  SR_CHECK(gemm_xwT(sv + p.sv_oh, params + p.wo2, params + p.bo2, scores, T, dff, 1, 0, st));
+  if (!head_done) {
+    SR_CHECK(gemm_xwT(sv + p.sv_x[p.nl], params + p.wo1, params + p.bo1, sv + p.sv_oh, T, d, dff, 1, st));
+    SR_CHECK(gemm_xwT(sv + p.sv_oh, params + p.wo2, params + p.bo2, scores, T, dff, 1, 0, st));
+  }
   return (int)hipGetLastError();
 }
 
