@@ -2566,6 +2566,276 @@ bool block_fwd(const SrPlan& p, int l, const float* params, float* sv, float* sc
   if (a.head && *rc == 0) *rc = -1;  // (-1: launched, and the output FFN is done as well)
   return true;
 }
+// ---------------------------------------------------------------------------------------------------------
+// The input side in one launch (round 5): gather + LayerNorm + embedding FFN (SetRank.py:134-135, 146)
+// ---------------------------------------------------------------------------------------------------------
+//   xg = features[ids],  xn0 = LN_in(xg),  h0 = relu(xn0 W1^T + b1),  x_0 = h0 W2^T + b2      (was: a gather + LayerNorm launch and two GEMMs)
+// Same geometry as sr_block_fwd_kernel: a workgroup owns R token rows, the two products run on the fragment-major split-half copies.
+struct SrEmbedArgs {
+  int R, F, d, dff;
+  int64_t T, n_docs;
+  int B, L;
+  int64_t g_in, b_in, b1, b2;              // float offsets into the parameter vector
+  int64_t gw1, gw2;                        // HALF offsets of the fragment copies of W1 [dff][F] and W2 [d][dff]
+  int64_t xg, mean_in, rstd_in, xn0, h0, x0;  // float offsets into `saved`
+  int p0, p2, pv;                          // float offsets into dynamic LDS
+};
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void sr_embed_fwd_kernel(SrEmbedArgs a, const float* __restrict__ params, const float* __restrict__ feats,
+                                                              const int32_t* __restrict__ docids, const _Float16* __restrict__ planes,
+                                                              float* __restrict__ sv) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NT = NW * 64, RT = 4;
+  const int R = a.R, F = a.F, d = a.d, dff = a.dff;
+  const int K16 = round_up(F, 32), ld0 = K16 + 8, ldf = dff + 8;
+  float* P0 = smem + a.p0;   // planes of xn0
+  float* P2 = smem + a.p2;   // fp32 partial tiles of h0, then its planes
+  float* PV = smem + a.pv;   // g_in | b_in | b1 | b2
+  float* OS = PV + 2 * F + dff + d;
+  const int tid = threadIdx.x, lane_id = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t n0 = (int64_t)blockIdx.x * R;
+  const int vr = (int)((a.T - n0) < R ? (a.T - n0) : R);
+  const float* pg = PV, *pb = PV + F, *pb1 = PV + 2 * F, *pb2 = PV + 2 * F + dff;
+
+  // ---- gather + LayerNorm: a wave owns rows wave + NW q; lane q < 4 resolves the id of row q ------------------------------------
+  {
+    const int lane = lane_id;
+    for (int e = tid; e < 2 * F + dff + d; e += NT)
+      PV[e] = params[e < F ? a.g_in + e : e < 2 * F ? a.b_in + (e - F) : e < 2 * F + dff ? a.b1 + (e - 2 * F) : a.b2 + (e - 2 * F - dff)];
+    const int rme = wave + NW * (lane < RT ? lane : 0);
+    const bool idok = lane < RT && rme < vr;
+    const uint32_t nme = idok ? (uint32_t)(n0 + rme) : 0u;
+    const int bb = (int)(nme / (uint32_t)a.L), ll = (int)(nme % (uint32_t)a.L);
+    const int id_raw = docids[(int64_t)ll * a.B + bb];
+    const int myid = (idok && id_raw >= 0 && id_raw < a.n_docs) ? id_raw : -1;  // PAD -> zero row
+    const Src fs = make_src(feats, a.n_docs * F);
+    const int c = 4 * lane;
+    const bool cok = c < F;
+    float4 v[RT];
+    float s[RT], qv[RT];
+    const Dst dxg = make_dst(sv + a.xg + n0 * F, (int64_t)vr * F);
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+      const int id = __builtin_amdgcn_readlane(myid, q);
+      v[q] = buf_ld4(fs, (id >= 0 && cok) ? (unsigned)(((int64_t)id * F + c) * 4) : ULTR_OOB);
+    }
+    lds_barrier();  // the parameter vectors are in LDS
+    const float invF = 1.0f / (float)F;
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+      buf_st4(dxg, cok ? (unsigned)c * 4u : ULTR_OOB, (unsigned)((wave + NW * q) * F) * 4u, v[q]);
+      s[q] = (v[q].x + v[q].y) + (v[q].z + v[q].w);
+    }
+    wave_sum_n<RT>(s);
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+      s[q] *= invF;
+      if (cok) {
+        v[q].x -= s[q]; v[q].y -= s[q]; v[q].z -= s[q]; v[q].w -= s[q];
+      }
+      qv[q] = (v[q].x * v[q].x + v[q].y * v[q].y) + (v[q].z * v[q].z + v[q].w * v[q].w);
+    }
+    wave_sum_n<RT>(qv);
+    const Dst dmean = make_dst(sv + a.mean_in + n0, vr), drstd = make_dst(sv + a.rstd_in + n0, vr);
+    const Dst dxn = make_dst(sv + a.xn0 + n0 * F, (int64_t)vr * F);
+    const unsigned l0 = lane == 0 ? 0u : ULTR_OOB;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 g4 = cok ? ld4(pg + c) : z4, b4 = cok ? ld4(pb + c) : z4;
+    float am[RT];
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+      const int r = wave + NW * q;
+      const float rstd = 1.0f / sqrtf(qv[q] * invF + SR_EPS);
+      v[q] = make_float4(v[q].x * rstd * g4.x + b4.x, v[q].y * rstd * g4.y + b4.y, v[q].z * rstd * g4.z + b4.z, v[q].w * rstd * g4.w + b4.w);
+      buf_st4(dxn, cok ? (unsigned)c * 4u : ULTR_OOB, (unsigned)(r * F) * 4u, v[q]);
+      buf_st1(dmean, l0, (unsigned)r * 4u, s[q]);
+      buf_st1(drstd, l0, (unsigned)r * 4u, rstd);
+      am[q] = fmaxf(fmaxf(fabsf(v[q].x), fabsf(v[q].y)), fmaxf(fabsf(v[q].z), fabsf(v[q].w)));
+    }
+    wave_max_n<RT>(am);
+    _Float16* AH = reinterpret_cast<_Float16*>(P0);
+    _Float16* AL = AH + (R + 1) * ld0;
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+      const int r = wave + NW * q, rc = r < R ? r : R;
+      float rs, inv;
+      fb_h3_scale(am[q], rs, inv);
+      if (c < K16) {  // (columns F .. K16 - 1: zeros - v is 0 * rstd * 0 + 0 there)
+        fbh4 hi, lo;
+        fb_h3_split4(v[q], rs, hi, lo);
+        *reinterpret_cast<fbh4*>(AH + rc * ld0 + c) = hi;
+        *reinterpret_cast<fbh4*>(AL + rc * ld0 + c) = lo;
+      }
+      if (lane == 0) OS[r] = inv * (1.0f / ULTR_H3_WSCALE);
+    }
+  }
+  lds_barrier();
+  // ---- h0 = relu(xn0 W1^T + b1): wave = (row tile, chunk, slice of the contraction) -> fp32 partial tiles in P2; then the owner waves
+  {
+    float* F32 = P2;
+    {
+      int lane = lane_id;
+      asm volatile("" : "+v"(lane));
+      const int i = lane & 15, q = lane >> 4, nks = K16 >> 5, nchf = dff >> 5, ksplit = 4 / nchf;
+      const int rt = wave >> 2;
+      int ch = wave & 3, ks = 0;
+      while (ch >= nchf) { ch -= nchf; ++ks; }
+      const int len = (nks + ksplit - 1) / ksplit, k0 = ks * len;
+      const int cnt = k0 >= nks ? 0 : (k0 + len < nks ? len : nks - k0);
+      const _Float16* AH = reinterpret_cast<const _Float16*>(P0);
+      const int lo_off = (R + 1) * ld0;
+      const int rowi = 16 * rt + i;
+      const _Float16* pa[1] = {AH + (rowi < R ? rowi : R) * ld0 + 8 * q + 32 * k0};
+      const Src Wh = make_src(reinterpret_cast<const float*>(planes + a.gw1), (int64_t)K16 * dff);
+      f32x4 acc[1][2] = {{(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}}};
+      PipeH3W<1, 2> ph;
+      ph.begin(Wh, ch, nks, k0, cnt, cnt > 0, lane);
+      ph.run(pa, lo_off, Wh, cnt, acc);
+      const int col = 32 * ch + 2 * i;
+      for (int sl = 0; sl < ksplit; ++sl) {
+        if (ks == sl) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * rt + 4 * q + r, rc = row < R ? row : R;
+            float2* dst = reinterpret_cast<float2*>(F32 + rc * ldf + col);
+            float2 y = make_float2(acc[0][0][r], acc[0][1][r]);
+            if (sl > 0) {
+              const float2 o = *dst;
+              y.x += o.x;
+              y.y += o.y;
+            }
+            *dst = y;
+          }
+        }
+        lds_barrier();
+      }
+    }
+    int lane = lane_id;
+    asm volatile("" : "+v"(lane));
+    const int c = 4 * lane;
+    const bool cok = c < dff;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 b4 = cok ? ld4(pb1 + c) : z4;
+    const Dst dh = make_dst(sv + a.h0 + n0 * dff, (int64_t)vr * dff);
+    float4 v[RT];
+    float am[RT];
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+      const int r = wave + NW * q, rc = r < R ? r : R;
+      const float os = OS[r];
+      v[q] = cok ? ld4(F32 + rc * ldf + c) : z4;
+      v[q] = make_float4(fmaxf(v[q].x * os + b4.x, 0.f), fmaxf(v[q].y * os + b4.y, 0.f), fmaxf(v[q].z * os + b4.z, 0.f), fmaxf(v[q].w * os + b4.w, 0.f));
+      buf_st4(dh, cok ? (unsigned)c * 4u : ULTR_OOB, (unsigned)(r * dff) * 4u, v[q]);
+      am[q] = fmaxf(fmaxf(v[q].x, v[q].y), fmaxf(v[q].z, v[q].w));
+    }
+    wave_max_n<RT>(am);
+    lds_barrier();  // every wave holds its rows: the planes may overwrite them
+    _Float16* FH = reinterpret_cast<_Float16*>(P2);
+    _Float16* FL = FH + (R + 1) * ldf;
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+      const int r = wave + NW * q, rc = r < R ? r : R;
+      float rs, inv;
+      fb_h3_scale(am[q], rs, inv);
+      if (cok) {
+        fbh4 hi, lo;
+        fb_h3_split4(v[q], rs, hi, lo);
+        *reinterpret_cast<fbh4*>(FH + rc * ldf + c) = hi;
+        *reinterpret_cast<fbh4*>(FL + rc * ldf + c) = lo;
+      }
+      if (lane == 0) OS[64 + r] = inv * (1.0f / ULTR_H3_WSCALE);
+    }
+  }
+  lds_barrier();
+  // ---- x_0 = h0 W2^T + b2: wave = (32-column chunk, pair of row tiles), straight to `saved` --------------------------------------
+  {
+    int lane = lane_id;
+    asm volatile("" : "+v"(lane));
+    const int nch = d >> 5, nks = dff >> 5;
+    const int ch = wave & 7, g = wave >> 3;
+    const bool has = ch < nch;
+    const int i = lane & 15, q = lane >> 4;
+    const _Float16* AH = reinterpret_cast<const _Float16*>(P2);
+    const int lo_off = (R + 1) * ldf;
+    const _Float16* pa[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = 16 * (2 * g + t) + i;
+      pa[t] = AH + (row < R ? row : R) * ldf + 8 * q;
+    }
+    const Src Wh = make_src(reinterpret_cast<const float*>(planes + a.gw2), (int64_t)dff * d);
+    PipeH3W<2, 2> ph;
+    ph.begin(Wh, ch, nks, 0, nks, has, lane);
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) acc[t][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    ph.run(pa, lo_off, Wh, has ? nks : 0, acc);
+    if (has) {
+      const int col = 32 * ch + 2 * i;
+      const Dst dout = make_dst(sv + a.x0 + n0 * d, (int64_t)vr * d);
+      const float2 bv = *reinterpret_cast<const float2*>(pb2 + col);
+      const unsigned gv = (unsigned)(4 * q * d + 2 * i) * 4u;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float4 o4 = ld4(OS + 64 + 16 * (2 * g + t) + 4 * q);
+        const float o[4] = {o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          buf_st2(dout, gv, (unsigned)((16 * (2 * g + t) + r) * d + 32 * ch) * 4u,
+                  make_float2(acc[t][0][r] * o[r] + bv.x, acc[t][1][r] * o[r] + bv.y));
+      }
+    }
+  }
+}
+
+// legal: F a multiple of 4 and at most 256, widths as for sr_block_fwd_kernel; two 8-wave workgroups per CU
+bool embed_fwd(const SrPlan& p, const float* params, const float* feats, const int32_t* docids, int64_t n_docs, int batch, int L, float* sv,
+               hipStream_t st, int* rc) {
+  const int F = p.F, d = p.d, dff = p.dff;
+  if (g_sr_knob_block < 0) {
+    const char* e = getenv("ULTR_SR_BLOCK");
+    g_sr_knob_block = (e && *e) ? atoi(e) : 2;
+  }
+  if (!g_sr_knob_block || !sr_h3_enabled() || p.no_h3 || g_sr_h3.planes == nullptr || F % 4 != 0 || F > 256 || d % 32 != 0 || d > 256 || d < 32 ||
+      (dff != 32 && dff != 64 && dff != 128) || n_docs * (int64_t)F * 4 >= ((int64_t)1 << 31))
+    return false;
+  const SrPlan::SplitMat* m1 = sr_find_split(params + p.w1, dff, F);
+  const SrPlan::SplitMat* m2 = sr_find_split(params + p.w2, d, dff);
+  if (!m1 || !m2 || m1->g_off < 0 || m2->g_off < 0 || (((uintptr_t)sv | (uintptr_t)g_sr_h3.planes | (uintptr_t)feats) & 15) != 0) return false;
+  const int K16 = (F + 31) / 32 * 32;
+  const int64_t per_row = (int64_t)((K16 + 8) + (dff + 8)) * 4, fixed = (int64_t)(2 * F + dff + d + 128) * 4;
+  int64_t rmax = (80 * 1024 - fixed) / per_row - 1;
+  if (rmax > 32) rmax = 32;
+  if (rmax < 16) return false;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  const int64_t slots = (int64_t)cus * 2;
+  const int64_t rounds = (p.T + slots * rmax - 1) / (slots * rmax);
+  int64_t R = (p.T + slots * rounds - 1) / (slots * rounds);
+  if (R < 16) R = 16;
+  SrEmbedArgs a;
+  memset(&a, 0, sizeof(a));
+  a.R = (int)R; a.F = F; a.d = d; a.dff = dff; a.T = p.T; a.n_docs = n_docs; a.B = batch; a.L = L;
+  a.g_in = p.g_in; a.b_in = p.b_in; a.b1 = p.b1; a.b2 = p.b2;
+  a.gw1 = m1->g_off; a.gw2 = m2->g_off;
+  a.xg = p.sv_xg; a.mean_in = p.sv_mean_in; a.rstd_in = p.sv_rstd_in; a.xn0 = p.sv_xn0; a.h0 = p.sv_h0; a.x0 = p.sv_x[0];
+  a.p0 = 0;
+  a.p2 = (int)((R + 1) * (K16 + 8));
+  a.pv = a.p2 + (int)((R + 1) * (dff + 8));
+  const size_t lds = (size_t)(a.pv + 2 * F + dff + d + 128) * sizeof(float);
+  if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(sr_embed_fwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int)lds) != hipSuccess) {
+    *rc = ULTR_E_UNSUPPORTED;
+    return true;
+  }
+  hipLaunchKernelGGL(sr_embed_fwd_kernel<8>, dim3((unsigned)((p.T + R - 1) / R)), dim3(512), lds, st, a, params, feats, docids, g_sr_h3.planes, sv);
+  *rc = (int)hipGetLastError();
+  return true;
+}
+
 }  // namespace
 
 void ultr_setrank_knobs_reload() {
@@ -2626,15 +2896,21 @@ extern "C" int ultr_setrank_forward(const ultr_setrank_desc* c, const float* par
     g_sr_h3 = {params, planes, &p};
   }
   // input LayerNorm on the gathered rows, then the embedding FFN (SetRank.py:134-135, 146)
-  if (F % 4 == 0 && F <= 1024 && ((uintptr_t)features & 15) == 0)
+  int erc = 0;
+  const bool embedded = n_docs > 0 && embed_fwd(p, params, features, docids, n_docs, (int)batch, L, sv, st, &erc);  // one launch (sr_embed_fwd_kernel)
+  if (embedded && erc) return erc;
+  if (embedded) {
+  } else if (F % 4 == 0 && F <= 1024 && ((uintptr_t)features & 15) == 0)
     hipLaunchKernelGGL(sr_ln_gather_v4_kernel, dim3(rblk), dim3(SR_ROWS * 64), 0, st, features, docids, n_docs, (int)batch, L, T, F,
                        params + p.g_in, params + p.b_in, sv + p.sv_xg, sv + p.sv_xn0, sv + p.sv_mean_in, sv + p.sv_rstd_in);
   else
     hipLaunchKernelGGL(sr_ln_fwd_kernel, dim3(rblk), dim3(SR_ROWS * 64), 0, st, features, (const float*)nullptr, (const float*)nullptr, docids, n_docs,
                        (int)batch, L, T, F, params + p.g_in, params + p.b_in, sv + p.sv_xg, sv + p.sv_xn0, sv + p.sv_mean_in,
                        sv + p.sv_rstd_in);
-  SR_CHECK(gemm_xwT(sv + p.sv_xn0, params + p.w1, params + p.b1, sv + p.sv_h0, T, F, dff, 1, st));
-  SR_CHECK(gemm_xwT(sv + p.sv_h0, params + p.w2, params + p.b2, sv + p.sv_x[0], T, dff, d, 0, st));
+  if (!embedded) {
+    SR_CHECK(gemm_xwT(sv + p.sv_xn0, params + p.w1, params + p.b1, sv + p.sv_h0, T, F, dff, 1, st));
+    SR_CHECK(gemm_xwT(sv + p.sv_h0, params + p.w2, params + p.b2, sv + p.sv_x[0], T, dff, d, 0, st));
+  }
   const size_t lds_att = ((size_t)L * (p.dh + 1) + 4 * (size_t)L) * sizeof(float);
   if (lds_att > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(sr_attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
