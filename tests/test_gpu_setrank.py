@@ -362,3 +362,55 @@ def test_setrank_weight_outside_the_split_half_range_falls_back(monkeypatch):
     finally:
         monkeypatch.undo()
         _lib.load().ultr_config_reload()
+
+
+FUSED_SHAPES = [(37, 30, 136, 64, 4, 2, 32),     # ragged last workgroup, PAD documents, d = 64, dff = 32
+                (200, 50, 220, 256, 8, 2, 64),   # config 5's widths, several workgroups per CU slot
+                (64, 40, 24, 128, 4, 1, 128)]    # four chunks in the dff-wide products
+
+
+@pytest.mark.parametrize("B,L,F,dm,H,nl,dff", FUSED_SHAPES)
+@pytest.mark.parametrize("block", ["1", "2"], ids=["one_16_wave_workgroup", "two_8_wave_workgroups"])
+def test_fused_block_kernels_against_the_separate_launches(B, L, F, dm, H, nl, dff, block, monkeypatch):
+    """sr_embed_fwd_kernel / sr_block_fwd_kernel (round 5: gather + LayerNorm + embedding FFN, and everything of an encoder block behind
+    the attention - incl. the output FFN on the last block - as ONE launch each) against the separate GEMM / LayerNorm launches they
+    replace (ULTR_SR_BLOCK=0): every saved activation and statistic the backward reads, the scores, and the step's gradients."""
+    from ultra_pytorch_amd import _lib, hip_ops, synthetic
+    from ultra_pytorch_amd.ranking_model.SetRank import init_setrank_params
+    shape = hip_ops.SetRankShape(F, dm, H, nl, dff)
+    rng = np.random.RandomState(4)
+    feats, ids, y = synthetic.make_batch(rng, B, L, F, n_pad=3)
+    ipw = np.asarray(synthetic.load_ipw(), np.float32)
+    p0 = init_setrank_params(shape, seed=2).numpy()
+    p0 += rng.normal(scale=0.02, size=p0.shape).astype(np.float32)  # LayerNorm parameters, biases away from (1, 0)
+    T = B * L
+
+    def up4(n):
+        return (n + 3) // 4 * 4
+    n_act = up4(T * F) * 2 + up4(T) * 2 + up4(T * dff) * 2 + (nl + 1) * up4(T * dm) + nl * (4 * up4(T * dm) + 4 * up4(T) + up4(T * dff) + up4(T * H))
+
+    def run(knob):
+        monkeypatch.setenv("ULTR_SR_BLOCK", knob)
+        _lib.load().ultr_config_reload()
+        saved = torch.zeros(shape.saved_bytes(T) // 4, device="cuda")
+        scores = torch.zeros(B, L, device="cuda")
+        p, f, i = dev(p0), dev(feats), dev(ids, torch.int32)
+        hip_ops.setrank_forward(shape, p, f, feats.shape[0], i, B, L, scores, saved)
+        torch.cuda.synchronize()
+        step = run_step(shape, B, L, dict(learning_rate=0.05, max_gradient_norm=5.0), p0, np.zeros_like(p0), feats, ids, y, ipw)
+        return saved[:n_act].cpu().numpy(), scores.cpu().numpy(), step
+
+    try:
+        ref_saved, ref_scores, ref_step = run("0")
+        saved, scores, step = run(block)
+    finally:
+        monkeypatch.undo()
+        _lib.load().ultr_config_reload()
+    # both paths compute the same split-half products in a different summation order: 1e-5 of the tensor's scale per element
+    scale = np.maximum(np.abs(ref_saved), 1.0)
+    bad = np.abs(saved - ref_saved) > 1e-5 * scale
+    assert not bad.any(), "%d saved activations differ, first at %d: %r vs %r" % (bad.sum(), np.argmax(bad), saved[np.argmax(bad)], ref_saved[np.argmax(bad)])
+    np.testing.assert_allclose(scores, ref_scores, atol=1e-5)
+    g, gref = step[1][: shape.n_params], ref_step[1][: shape.n_params]
+    np.testing.assert_allclose(g, gref, rtol=1e-4, atol=1e-5 * float(np.abs(gref).max()))
+    assert abs(step[4][0] - ref_step[4][0]) <= 1e-5 * max(1.0, abs(ref_step[4][0]))
