@@ -560,7 +560,7 @@ def short_config_run(key, device, lib, steps, warmup):
         rec["kernel_us"] = {KNAMES[k]: round(v, 2) for k, v in kus.items()}
         rec["stage_kernels"] = stage_kernels(lib, cfg)
     else:
-        rec["dominant_kernel"] = {"kernel": "whole step (47 launches, none dominant: profiles/r05_cfg5_pmc.md)", "bound": "mfma",
+        rec["dominant_kernel"] = {"kernel": "whole step (37 launches, none dominant: profiles/r05_cfg5_pmc.md)", "bound": "mfma",
                                   "achieved": rec["step_tflops"], "unit": "TFLOP/s", "frac": rec["step_frac_of_fp32_mfma_peak"]}
     W.eng.close()
     del W
@@ -1057,9 +1057,10 @@ def main():
         # `limited_by` says what the measurements show actually limits it
         limited_by = None
         if not dnn:
-            limited_by = ("HBM traffic + instruction issue, not the matrix pipes: ~9.9 GB cross HBM per step (profiles/r04_cfg5_pmc.md: 3.5 TB/s average; "
-                          "at the ~6.3 TB/s this part sustains that alone is 55 % of the step), the split-half GEMMs sit at 7-11 % matrix-core "
-                          "occupancy (~250 issued instructions per 12 MFMAs), the attention backward is VALU-bound")
+            limited_by = ("HBM traffic + instruction issue, not the matrix pipes: ~8.5 GB cross HBM per step (profiles/r05_cfg5_pmc.md; 9.9 GB "
+                          "before round 5 fused the forward's Linear / LayerNorm launches into sr_embed_fwd_kernel / sr_block_fwd_kernel), the "
+                          "remaining split-half GEMMs (the backward's dgrads) sit at 7-11 % matrix-core occupancy, the fused block kernels are "
+                          "chains of ~10k-cycle phases per workgroup, the attention backward is VALU-bound")
         if dnn and light and dom == 7:
             limited_by = ("a per-workgroup LATENCY CHAIN, nothing is at a bandwidth limit: one 10-document list per compute unit in a 16-row MFMA "
                           "tile (8 waves); 55 % of the kernel is dependent row-wise phases (LayerNorms, loss, backward row passes), 45 % the "
