@@ -2424,7 +2424,15 @@ __global__ __launch_bounds__(1024) void dnn_bwdw_kernel(DnnPlan p, BwdPlan bp, W
 #pragma unroll
       for (int k = 0; k < 2 * RT; ++k) red[k] = 0.f;
       if (j == 1) TRACE_STAMP_B(2, 12);
-      float4 pg[XC], pb[XC], pw[LAST ? XC : 1], wk[LAST ? XC : 1];
+      float4 pg[XC], pb[XC], pw[LAST ? XC : 1], wk[LAST ? XC : 1], bek[LAST ? XC : 1];
+      if constexpr (LAST) {  // beta and the scorer's row: requested with the x rows, not behind them
+#pragma unroll
+        for (int u = 0; u < XC; ++u) {
+          const int c = 4 * lane + 256 * u;
+          bek[u] = buf_ld4(pvs, c < K ? (unsigned)(p.pv_off[j] + K + c) * 4u : ULTR_OOB);
+          wk[u] = buf_ld4(pvs, c < K ? (unsigned)(p.pv_wlast + c) * 4u : ULTR_OOB);
+        }
+      }
 #pragma unroll
       for (int u = 0; u < XC; ++u) {
         const int c = 4 * lane + 256 * u;
@@ -2432,9 +2440,8 @@ __global__ __launch_bounds__(1024) void dnn_bwdw_kernel(DnnPlan p, BwdPlan bp, W
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         float4 be4 = z4, w4 = z4;
         if constexpr (LAST) {
-          be4 = buf_ld4(pvs, act ? (unsigned)(p.pv_off[j] + K + c) * 4u : ULTR_OOB);
-          w4 = buf_ld4(pvs, act ? (unsigned)(p.pv_wlast + c) * 4u : ULTR_OOB);
-          wk[u] = w4;
+          be4 = bek[u];
+          w4 = wk[u];
           pw[u] = z4;
         }
         pg[u] = pb[u] = z4;
