@@ -36,6 +36,8 @@ SHAPES = {
     "odd_slices": (220, [96, 64], 200, 40, "relu", 3),                    # 3 and 2 chunks: 4 and 3 slices of the contraction
     "chunks_beyond_waves": (136, [768, 32], 256, 40, "tanh", 0),          # 24 chunks on 16 waves; then ONE chunk in 12 slices
     "sigmoid_narrow": (48, [64, 64, 32], 128, 60, "sigmoid", 5),
+    "one_hidden_layer": (136, [256], 400, 30, "elu", 1),                  # backward: the scorer's row pass only, no product
+    "four_hidden_layers": (64, [128, 256, 128, 64], 350, 25, "elu", 0),
 }
 
 

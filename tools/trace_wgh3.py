@@ -28,10 +28,10 @@ aux = torch.ones(2 * L if algo != "dla" else L + 1, device=dev)
 for _ in range(10):
     eng.train_step(p, st if algo != "dla" else None, f, feats.shape[0], i_, y_, aux=aux)
 torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * (64 * 32))()
+buf = (ctypes.c_ulonglong * (3 * 64 * 32))()
 lib.ultr_trace_read.argtypes = [ctypes.c_void_p]
 lib.ultr_trace_read(buf)
-a = np.array(buf[:], dtype=np.uint64).reshape(64, 32).astype(np.int64)
+a = np.array(buf[:], dtype=np.uint64).reshape(3, 64, 32).astype(np.int64)[0]
 for blk in range(0, 17, 2):
     t = a[blk]
     if t[31] == 0:

@@ -3947,14 +3947,19 @@ __global__ __launch_bounds__(512) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan bp
   }
   lds_barrier();
   float* slab = ws + wl.slab_off + (int64_t)split * ((int64_t)M * K + M);
+  // layer-0 fold: the per-thread column partials of all four sub-blocks stay in registers through the slab writes and are folded in
+  // ONE pass behind them (two barriers; per sub-block it was three barriers and a 32-term sum by a quarter of the threads each time:
+  // the layer-0 workgroups - 8 of config 3's 18 tiles, 24 of config 4's 34 - ended 8k cycles after the others)
+  float4 l0pg[4], l0pb[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int sm_ = s >> 1, sk = s & 1;
     const int mB = m0 + 64 * sm_, kB = k0 + 64 * sk;
+    l0pg[s] = l0pb[s] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (mB >= M || kB >= K) continue;  // (uniform)
     const float* red = smem + s * 4096;
     const int kq = kB + (tid & 15) * 4;
-    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = g4, l0pg = g4, l0pb = g4;
+    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = g4;
     if (l0g && kq < K) {
       g4 = ld4(params + p.off_lnw[0] + kq);
       b4 = ld4(params + p.off_lnb[0] + kq);
@@ -3969,31 +3974,33 @@ __global__ __launch_bounds__(512) void dnn_wgrad_h3_kernel(DnnPlan p, BwdPlan bp
           // G -> dW_0 = gamma o G + S_m * beta;  partial column sums of W_0 o G and W_0 * S_m for d gamma_0 / d beta_0
           const float Sm = sm_bsum[64 * sm_ + ml] + sm_bsum[128 + 64 * sm_ + ml];
           const float4 w = w4[s][it];
-          l0pg.x += w.x * v.x; l0pg.y += w.y * v.y; l0pg.z += w.z * v.z; l0pg.w += w.w * v.w;
-          l0pb.x += w.x * Sm; l0pb.y += w.y * Sm; l0pb.z += w.z * Sm; l0pb.w += w.w * Sm;
+          l0pg[s].x += w.x * v.x; l0pg[s].y += w.y * v.y; l0pg[s].z += w.z * v.z; l0pg[s].w += w.w * v.w;
+          l0pb[s].x += w.x * Sm; l0pb[s].y += w.y * Sm; l0pb[s].z += w.z * Sm; l0pb[s].w += w.w * Sm;
           v.x = g4.x * v.x + b4.x * Sm; v.y = g4.y * v.y + b4.y * Sm; v.z = g4.z * v.z + b4.z * Sm; v.w = g4.w * v.w + b4.w * Sm;
         }
         st4_stream(slab + (int64_t)m * K + kq, v);
       }
     }
     if (kb2 == 0 && sk == 0 && tid < 64 && mB + tid < M) slab[(int64_t)M * K + mB + tid] = sm_bsum[64 * sm_ + tid] + sm_bsum[128 + 64 * sm_ + tid];
-    if (l0g) {
-      // fold scratch: sub-block 0's quarter of the overlay (s = 0 is never skipped and has been read by everyone past this barrier)
-      lds_barrier();
-      float* pgs = smem;            // [32][64]
-      float* pbs = smem + 32 * 64;  // [32][64]
-      st4(pgs + (tid >> 4) * 64 + (tid & 15) * 4, l0pg);
-      st4(pbs + (tid >> 4) * 64 + (tid & 15) * 4, l0pb);
-      lds_barrier();
-      if (tid < 128) {
-        const int which = tid >> 6, c = tid & 63;
-        const float* srcp = which ? pbs : pgs;
-        float a = 0.f;
+  }
+  if (l0g) {
+    // fold scratch: the four sub-blocks' overlay (everyone is past reading it behind this barrier): [sub-block][pg | pb][32 row groups][64]
+    lds_barrier();
 #pragma unroll
-        for (int gr = 0; gr < 32; ++gr) a += srcp[gr * 64 + c];
-        if (kB + c < K) ws[bp.l0part_off + ((int64_t)((2 * mb2 + sm_) * wl.nsplit + split) * 2 + which) * K + kB + c] = a;
-      }
-      lds_barrier();
+    for (int s = 0; s < 4; ++s) {
+      st4(smem + s * 4096 + (tid >> 4) * 64 + (tid & 15) * 4, l0pg[s]);
+      st4(smem + s * 4096 + 2048 + (tid >> 4) * 64 + (tid & 15) * 4, l0pb[s]);
+    }
+    lds_barrier();
+    {
+      const int s = tid >> 7, which = (tid >> 6) & 1, c = tid & 63;  // 512 threads = 4 sub-blocks x {d gamma, d beta} x 64 columns
+      const int sm_ = s >> 1, sk = s & 1;
+      const int mB = m0 + 64 * sm_, kB = k0 + 64 * sk;
+      const float* srcp = smem + s * 4096 + which * 2048;
+      float a = 0.f;
+#pragma unroll
+      for (int gr = 0; gr < 32; ++gr) a += srcp[gr * 64 + c];
+      if (mB < M && kB + c < K) ws[bp.l0part_off + ((int64_t)((2 * mb2 + sm_) * wl.nsplit + split) * 2 + which) * K + kB + c] = a;
     }
   }
   TRACE_STAMP(31);
