@@ -4775,7 +4775,7 @@ static bool bwd_wide_plan(const DnnPlan& p, int64_t N, WideBwd* wb, size_t* lds_
     const int64_t du = (R + 1) * wdu > cpmax ? (R + 1) * wdu : cpmax;
     return (R + 1) * wdz + du + 128;
   };
-  int64_t rmax = 48;
+  int64_t rmax = 64;  // four row tiles at most
   while (rmax > 16 && floats(rmax) * 4 > 160 * 1024) --rmax;
   if (rmax < 17) return false;
   const int64_t cus = dnn_device_cus();
@@ -5023,7 +5023,8 @@ static int backward_impl(const ultr_dnn_desc* d, const float* params, const floa
                 g_ultr_step_wt);                                                                                              \
   } while (0)
     if (wb.R <= 32) LAUNCH_BWDW(2);
-    else LAUNCH_BWDW(3);
+    else if (wb.R <= 48) LAUNCH_BWDW(3);
+    else LAUNCH_BWDW(4);
 #undef LAUNCH_BWDW
   } else if (big) {
     UltrProfScope prof(ULTR_K_BWD, st);
