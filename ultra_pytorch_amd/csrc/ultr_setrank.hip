@@ -2235,6 +2235,20 @@ __global__ __launch_bounds__(NW * 64) void sr_block_fwd_kernel(SrBlockArgs a, co
   const float invd = 1.0f / (float)d;
 
   UGEMM_TRACE_STAMP(20);
+  // the residual rows of x in the accumulator layout of the first product (wave = chunk x pair of row tiles): requested FIRST - they
+  // are the only HBM operand of that product's epilogue and land while the prologue and the product run (measured against a drained
+  // request: no difference, 2.57 - 2.59 ms either way - the phases wait for each other, not for HBM)
+  float2 xres[2][4];
+  {
+    const int ch = wave & 7, g = wave >> 3, i = lane_id & 15, q = lane_id >> 4;
+    const Src xs = make_src(sv + a.x + n0 * d, (int64_t)vr * d);
+    const int col = 32 * ch + 2 * i;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        xres[t][r] = buf_ld2(xs, ch < (d >> 5) ? (unsigned)((16 * (2 * g + t) + 4 * q + r) * d + col) * 4u : ULTR_OOB);
+  }
   // ---- prologue: parameter vectors to LDS; the attention rows as two fp16 planes scaled per row -------------------------------
   {
     const int lane = lane_id;
@@ -2277,7 +2291,7 @@ __global__ __launch_bounds__(NW * 64) void sr_block_fwd_kernel(SrBlockArgs a, co
 
   // a d-wide product: wave = (32-column chunk, pair of row tiles); Y = (planes . W) x row scale + bias + residual -> P1 + saved
   auto product_d = [&](const float* Ap, int lda, int nks, int64_t gw, int Kw, const float* bias, const float* os, bool res_lds,
-                       int64_t res_off, int64_t out_off) {
+                       int64_t out_off) {
     int lane = lane_id;
     asm volatile("" : "+v"(lane));
     const int nch = d >> 5;
@@ -2294,14 +2308,6 @@ __global__ __launch_bounds__(NW * 64) void sr_block_fwd_kernel(SrBlockArgs a, co
     }
     const Src Wh = make_src(reinterpret_cast<const float*>(planes + gw), (int64_t)Kw * d / 2 * 2);
     const int col = 32 * ch + 2 * i;
-    // residual from `saved` (x): requested before the product
-    const Src rs_ = make_src(sv + res_off + n0 * d, res_lds ? 0 : (int64_t)vr * d);
-    float2 res[2][4];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        res[t][r] = buf_ld2(rs_, has ? (unsigned)((16 * (2 * g + t) + 4 * q + r) * d + col) * 4u : ULTR_OOB);
     PipeH3W<2, 2> ph;
     ph.begin(Wh, ch, nks, 0, nks, has, lane);
     f32x4 acc[2][2];
@@ -2323,7 +2329,7 @@ __global__ __launch_bounds__(NW * 64) void sr_block_fwd_kernel(SrBlockArgs a, co
           const int row = 16 * (2 * g + t) + 4 * q + r;
           const int rc = row < R ? row : R;
           float2* dst = reinterpret_cast<float2*>(P1 + rc * ld + col);
-          const float2 rv = res_lds ? *dst : res[t][r];
+          const float2 rv = res_lds ? *dst : xres[t][r];
           const float2 y = make_float2(rv.x + (acc[t][0][r] * o[r] + bv.x), rv.y + (acc[t][1][r] * o[r] + bv.y));
           *dst = y;
           buf_st2(dout, gv, (unsigned)((16 * (2 * g + t) + r) * d + 32 * ch) * 4u, y);
@@ -2482,7 +2488,7 @@ __global__ __launch_bounds__(NW * 64) void sr_block_fwd_kernel(SrBlockArgs a, co
   };
 
   UGEMM_TRACE_STAMP(21);
-  product_d(P0, ld, d >> 5, a.gd, d, pbd, OS, false, a.x, a.s1);   // s1 = x + (A Wd^T + bd)
+  product_d(P0, ld, d >> 5, a.gd, d, pbd, OS, false, a.s1);   // s1 = x + (A Wd^T + bd)
   UGEMM_TRACE_STAMP(22);
   lds_barrier();
   UGEMM_TRACE_STAMP(23);
@@ -2494,7 +2500,7 @@ __global__ __launch_bounds__(NW * 64) void sr_block_fwd_kernel(SrBlockArgs a, co
   UGEMM_TRACE_STAMP(26);
   lds_barrier();
   UGEMM_TRACE_STAMP(27);
-  product_d(P2, ldf, dff >> 5, a.gf2, dff, pbf2, OS + 64, true, 0, a.s2);  // s2 = out1 + (f Wf2^T + bf2)
+  product_d(P2, ldf, dff >> 5, a.gf2, dff, pbf2, OS + 64, true, a.s2);  // s2 = out1 + (f Wf2^T + bf2)
   UGEMM_TRACE_STAMP(28);
   lds_barrier();
   UGEMM_TRACE_STAMP(29);
