@@ -1040,7 +1040,7 @@ def main():
         # the other BASELINE configs and the validation path on the SAME line: short synced runs
         evalleg = eval_leg(cfg, device, lib, params0)
         other = {}
-        for key, (n_st, n_wu) in (("3", (50, 10)), ("4pair", (30, 6)), ("4lambda", (30, 6)), ("5", (20, 3))):
+        for key, (n_st, n_wu) in (("3", (60, 30)), ("4pair", (40, 20)), ("4lambda", (40, 20)), ("5", (20, 4))):
             try:
                 other[key] = short_config_run(key, device, lib, n_st, n_wu)
             except Exception as ex:  # a secondary figure must never take the headline down
