@@ -5,6 +5,10 @@
 
 #include "../../include/ultr_hip.h"
 
+#ifndef ULTR_PROF_EVENT_FLAGS
+#define ULTR_PROF_EVENT_FLAGS hipEventDisableSystemFence
+#endif
+
 uint32_t g_ultr_prof_mask = 0;
 uint32_t g_ultr_prof_shadow = 0;
 bool g_ultr_prof_live = false;
@@ -61,9 +65,11 @@ extern "C" int ultr_prof_enable(uint32_t kernel_mask, int32_t max_samples) {
   if (max_samples <= 0) return ULTR_E_BADARG;
   while (g_pool.size() < (size_t)max_samples) {
     Sample s;
-    hipError_t e = hipEventCreate(&s.a);
+    // (no system-scope release when an event completes: the timestamps are the dispatch packet's own, nothing on the host reads
+    // device memory behind these events - they cost the timed launches ~1 us each with the default flags)
+    hipError_t e = hipEventCreateWithFlags(&s.a, ULTR_PROF_EVENT_FLAGS);
     if (e != hipSuccess) return (int)e;
-    e = hipEventCreate(&s.b);
+    e = hipEventCreateWithFlags(&s.b, ULTR_PROF_EVENT_FLAGS);
     if (e != hipSuccess) return (int)e;
     s.kid = -1;
     g_pool.push_back(s);
