@@ -2,7 +2,9 @@
 // Disabled by default: the launch sites pay one predictable branch.  When armed for a kernel id, that kernel is
 // launched through hipExtLaunchKernelGGL with a start and a stop event: the two timestamps are taken from the
 // kernel's OWN dispatch packet (what rocprofv3 --kernel-trace reports), not from extra marker packets around it.
-// (hipEventRecord brackets were measured at ~5 us per pair on the stream - more than the small kernels they timed.)
+// (hipEventRecord brackets were measured at ~5 us per pair on the stream - more than the small kernels they timed.)  The events are
+// created with hipEventDisableSystemFence (round 5): with the default flags every completion was a system-scope release, ~1.5 us of
+// the driver's 20-step figure per step.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
@@ -17,7 +19,7 @@ enum UltrKernelId {
 
 extern uint32_t g_ultr_prof_mask;
 extern bool g_ultr_prof_live;  // false on the steps the sampling stride skips
-// Kernels that get a start/stop event pair WITHOUT being counted ("shadow"): with a sampling stride only the armed kernel of one
+// (Off since round 5 - see ultr_prof_tick; ULTR_PROF_SHADOW=1 -)  Kernels that get a start/stop event pair WITHOUT being counted ("shadow"): with a sampling stride only the armed kernel of one
 // step in `stride` is timed, and a timed launch whose PREDECESSOR on the stream is untimed absorbs the tail of that predecessor
 // into its own interval (measured, tools/prof_mask_test.py: fused kernel 22.2 us with every kernel timed, 24.0 alone, 22.5 with
 // the update launch in front of it timed as well).  So the launches in front of the armed kernel are timed too, uncounted: the

@@ -1,6 +1,8 @@
 // ultr_prof.hip — HIP-event kernel timers behind ultr_prof_enable / ultr_prof_collect.
 #include "ultr_prof.h"
 
+#include <stdlib.h>
+
 #include <vector>
 
 #include "../../include/ultr_hip.h"
@@ -31,7 +33,10 @@ void ultr_prof_tick() {
   const uint64_t ph = g_ticks++ % (uint64_t)g_stride;
   g_ultr_prof_live = ph == (uint64_t)(g_stride / 2);
   g_ultr_prof_shadow = 0;
-  if (g_stride > 1) {
+  // (round 5: with events that carry no system-scope release - ultr_prof_enable - an untimed predecessor no longer leaks into the
+  // armed launch's interval: fused kernel 22.07 - 22.17 us without shadows, 21.9 - 22.2 with; ULTR_PROF_SHADOW=1 brings them back)
+  static const bool shadow = getenv("ULTR_PROF_SHADOW") != nullptr;
+  if (g_stride > 1 && shadow) {
     // launch order inside a step: fused | forward, loss, backward; weight gradients; reduction; update
     static const int order[ULTR_K_COUNT] = {0, 1, 2, 3, 4, 5, 6, 0};
     int first = 99;
