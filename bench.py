@@ -775,8 +775,9 @@ def main():
     dnn = cfg["model"] == "dnn"
     dom = None
     # Timers inside the timed region: ONLY the dominant kernel, on every stride-th step, by the start / stop timestamps of its
-    # own dispatch packet (what rocprofv3 --kernel-trace reports).  A timed launch costs ~5 us of stream time (tools/
-    # short_region.py: all kernels timed at stride 8 cost 2.3 us per step of the headline, 20 us per timed step), so the other
+    # own dispatch packet (what rocprofv3 --kernel-trace reports).  A timed launch cost ~5 us of stream time with default events (tools/
+    # short_region.py: all kernels timed at stride 8 cost 2.3 us per step of the headline, 20 us per timed step; round 5: events
+    # without a system-scope release and no shadow samples - five timed launches now cost ~0.3 us per step of a 20-step run), so the other
     # kernels' averages come from the calibration pass in front of the timed region (`kernel_us`, all timers armed; the
     # dominant kernel's figure there and inside the region agree to 1 %).
     # at least five timed launches inside the timed region whatever its length (two were thin)
