@@ -1046,9 +1046,9 @@ __global__ __launch_bounds__(SR_MAXT * 64) __attribute__((amdgpu_waves_per_eu(4,
   // A padding QUERY has lse = +inf -> P = 0 by itself; padding KEYS exist only in the last block and are masked there.
   const float c1 = scale * 1.44269504088896341f;
   const float l_own = st_l[wave * 16 + i], t_own = st_t[wave * 16 + i];
-  f32x4 acc[NC], ack[NC], acv[NC];  // dq, dk, dv: separate chains, summed at the end
+  f32x4 acc[NC], acv[NC];  // dq + dk, dv: separate chains, summed at the end
 #pragma unroll
-  for (int c = 0; c < NC; ++c) acc[c] = ack[c] = acv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < NC; ++c) acc[c] = acv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto partner_block = [&](int t, auto last_tag) {
     constexpr bool LAST = decltype(last_tag)::value;
     const float* xrow = xs + (t * 16 + i) * LDX + q * KQ;
@@ -1077,14 +1077,13 @@ __global__ __launch_bounds__(SR_MAXT * 64) __attribute__((amdgpu_waves_per_eu(4,
       const float dsa = (scale * pa) * (dpt[r] - t_own);
       // own token as key, partner as query
       const float pb = __builtin_amdgcn_exp2f(fmaf(sc[r], c1, -lq[r]));
-      const float dsb = (scale * pb) * (dpn[r] - tq[r]);
+      const float dsab = dsa + (scale * pb) * (dpn[r] - tq[r]);
       const float* xr = xs + pr * LDX + i;
       const float* gr = das + pr * LDX + i;
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const float xv = xr[c * 16];
-        acc[c] = mfma16(dsa, xv, acc[c]);            // dq: dS[own][partner] x[partner]
-        ack[c] = mfma16(dsb, xv, ack[c]);            // dk: dS[partner][own] x[partner]
+        acc[c] = mfma16(dsab, xv, acc[c]);           // dq + dk: (dS[own][partner] + dS[partner][own]) x[partner]  (q = k = x)
         acv[c] = mfma16(pb, gr[c * 16], acv[c]);     // dv: P[partner][own] dA[partner]
       }
     }
@@ -1096,7 +1095,7 @@ __global__ __launch_bounds__(SR_MAXT * 64) __attribute__((amdgpu_waves_per_eu(4,
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = wave * 16 + 4 * q + r;
-      if (row < L) dx[base + (int64_t)row * d + c * 16 + i] += (acc[c][r] + ack[c][r]) + acv[c][r];
+      if (row < L) dx[base + (int64_t)row * d + c * 16 + i] += acc[c][r] + acv[c][r];
     }
   }
 }
@@ -1291,9 +1290,9 @@ __global__ __launch_bounds__(SR_MAXT * 64) void sr_attn_bwd_f16_kernel(const flo
   }
   const float c1 = scale * 1.44269504088896341f;
   const float l_own = st_l[wave * 16 + i], t_own = st_t[wave * 16 + i];
-  f32x4 acc[NC], ack[NC], acv[NC];  // dq, dk, dv
+  f32x4 acc[NC], acv[NC];  // dq + dk, dv
 #pragma unroll
-  for (int c = 0; c < NC; ++c) acc[c] = ack[c] = acv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < NC; ++c) acc[c] = acv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
   // one partner block: the three NT tiles and the element-wise dS algebra; results in (dsa, dsb, pb) for tokens 16 t + 4 q + r
   auto block_vals = [&](int t, bool live, f32x4& dsa, f32x4& dsb, f32x4& pb) {
     dsa = dsb = pb = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1325,12 +1324,16 @@ __global__ __launch_bounds__(SR_MAXT * 64) void sr_attn_bwd_f16_kernel(const flo
     f32x4 a0, b0, p0, a1, b1, p1;
     block_vals(t, true, a0, b0, p0);
     block_vals(t + 1, t + 1 < NTL, a1, b1, p1);
-    const h8 ha = pack_h8(a0, a1), hb = pack_h8(b0, b1), hp = pack_h8(p0, p1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {  // q = k = x: dq and dk share the x[partner] operand - summed in fp32 before the conversion
+      a0[r] += b0[r];
+      a1[r] += b1[r];
+    }
+    const h8 ha = pack_h8(a0, a1), hp = pack_h8(p0, p1);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const h8 xb = srh_pair_b(xt, 16 * c + i, t, q), gb = srh_pair_b(gt, 16 * c + i, t, q);
-      acc[c] = mfma_h(ha, xb, acc[c]);  // dq: dS[own][partner] x[partner]
-      ack[c] = mfma_h(hb, xb, ack[c]);  // dk: dS[partner][own] x[partner]
+      acc[c] = mfma_h(ha, xb, acc[c]);  // dq + dk: (dS[own][partner] + dS[partner][own]) x[partner]
       acv[c] = mfma_h(hp, gb, acv[c]);  // dv: P[partner][own] dA[partner]
     }
   }
@@ -1339,7 +1342,7 @@ __global__ __launch_bounds__(SR_MAXT * 64) void sr_attn_bwd_f16_kernel(const flo
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = wave * 16 + 4 * q + r;
-      if (row < L) dx[base + (int64_t)row * d + c * 16 + i] += (acc[c][r] + ack[c][r]) + acv[c][r];
+      if (row < L) dx[base + (int64_t)row * d + c * 16 + i] += acc[c][r] + acv[c][r];
     }
   }
 }
@@ -1520,9 +1523,9 @@ __global__ __launch_bounds__(SR_MAXT * 64) void sr_attn_bwd_h3_kernel(const floa
   }
   const float c1 = (scale * isx) * isx * 1.44269504088896341f;  // logits * log2(e) from sx^2 S
   const float l_own = st_l[wave * 16 + i], t_own = st_t[wave * 16 + i] * sg;
-  f32x4 acc[NC], ack[NC], acv[NC];  // sx sg dq, sx sg dk, 4096 sg dv
+  f32x4 acc[NC], acv[NC];  // sx sg (dq + dk), 4096 sg dv
 #pragma unroll
-  for (int c = 0; c < NC; ++c) acc[c] = ack[c] = acv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < NC; ++c) acc[c] = acv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
   // one partner block: the three NT tiles and the element-wise dS algebra; results (sg dS[own][partner], sg dS[partner][own],
   // P[partner][own]) for tokens 16 t + 4 q + r
   auto block_vals = [&](int t, bool live, f32x4& dsa, f32x4& dsb, f32x4& pb) {
@@ -1549,20 +1552,23 @@ __global__ __launch_bounds__(SR_MAXT * 64) void sr_attn_bwd_h3_kernel(const floa
     f32x4 a0, b0, p0, a1, b1, p1;
     block_vals(t, true, a0, b0, p0);
     block_vals(t + 1, t + 1 < NTL, a1, b1, p1);
-    h8 hah, hal, hbh, hbl, hph, hpl;
+    // q = k = x (SetRank.py:54-59): dq and dk contract with the SAME x[partner] rows, so dS[own][partner] + dS[partner][own] is
+    // summed in fp32 BEFORE the split - one pack and three MFMAs per column tile less than two separate products
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      a0[r] += b0[r];
+      a1[r] += b1[r];
+    }
+    h8 hah, hal, hph, hpl;
     srs_pack(a0, a1, 1.0f, hah, hal);
-    srs_pack(b0, b1, 1.0f, hbh, hbl);
     srs_pack(p0, p1, 4096.0f, hph, hpl);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const h8 xbh = srs_pair_b(xth, lt, 16 * c + i, t, q), xbl = srs_pair_b(xtl, lt, 16 * c + i, t, q);
       const h8 gbh = srs_pair_b(gth, lt, 16 * c + i, t, q), gbl = srs_pair_b(gtl, lt, 16 * c + i, t, q);
-      acc[c] = mfma_h(hah, xbl, acc[c]);  // dq: dS[own][partner] x[partner]
+      acc[c] = mfma_h(hah, xbl, acc[c]);  // dq + dk: (dS[own][partner] + dS[partner][own]) x[partner]
       acc[c] = mfma_h(hal, xbh, acc[c]);
       acc[c] = mfma_h(hah, xbh, acc[c]);
-      ack[c] = mfma_h(hbh, xbl, ack[c]);  // dk: dS[partner][own] x[partner]
-      ack[c] = mfma_h(hbl, xbh, ack[c]);
-      ack[c] = mfma_h(hbh, xbh, ack[c]);
       acv[c] = mfma_h(hph, gbl, acv[c]);  // dv: P[partner][own] dA[partner]
       acv[c] = mfma_h(hpl, gbh, acv[c]);
       acv[c] = mfma_h(hph, gbh, acv[c]);
@@ -1574,7 +1580,7 @@ __global__ __launch_bounds__(SR_MAXT * 64) void sr_attn_bwd_h3_kernel(const floa
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = wave * 16 + 4 * q + r;
-      if (row < L) dx[base + (int64_t)row * d + c * 16 + i] += (acc[c][r] + ack[c][r]) * s1 + acv[c][r] * s2;
+      if (row < L) dx[base + (int64_t)row * d + c * 16 + i] += acc[c][r] * s1 + acv[c][r] * s2;
     }
   }
 }
