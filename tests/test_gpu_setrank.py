@@ -414,3 +414,49 @@ def test_fused_block_kernels_against_the_separate_launches(B, L, F, dm, H, nl, d
     g, gref = step[1][: shape.n_params], ref_step[1][: shape.n_params]
     np.testing.assert_allclose(g, gref, rtol=1e-4, atol=1e-5 * float(np.abs(gref).max()))
     assert abs(step[4][0] - ref_step[4][0]) <= 1e-5 * max(1.0, abs(ref_step[4][0]))
+
+
+BWD_FUSED_SHAPES = [(37, 30, 136, 256, 8, 2, 64),    # ragged last tile, PAD documents
+                    (200, 50, 220, 256, 8, 2, 64),   # config 5's widths, several tiles per workgroup on a small GPU slice
+                    (3, 100, 24, 256, 4, 1, 64),     # fewer tiles than compute units, one block
+                    (700, 100, 220, 256, 8, 2, 64)]  # 70 000 token rows: every workgroup walks over several tiles
+
+
+@pytest.mark.parametrize("B,L,F,dm,H,nl,dff", BWD_FUSED_SHAPES)
+def test_fused_backward_launches_against_the_separate_launches(B, L, F, dm, H, nl, dff, monkeypatch):
+    """sr_bwd_ffn_kernel / sr_bwd_proj_kernel (round 6: LayerNorm backward, the thin weight gradients and the dgrad products of an encoder
+    block's row-local chain as two persistent launches) against the seven launches they replace (ULTR_SR_BWD_FUSED=0): the step's
+    gradients, the loss and the updated parameters."""
+    from ultra_pytorch_amd import _lib, hip_ops, synthetic
+    from ultra_pytorch_amd.ranking_model.SetRank import init_setrank_params
+    shape = hip_ops.SetRankShape(F, dm, H, nl, dff)
+    rng = np.random.RandomState(5)
+    feats, ids, y = synthetic.make_batch(rng, B, L, F, n_pad=3)
+    ipw = np.asarray(synthetic.load_ipw(), np.float32)
+    p0 = init_setrank_params(shape, seed=3).numpy()
+    p0 += rng.normal(scale=0.02, size=p0.shape).astype(np.float32)
+
+    def run(knob):
+        monkeypatch.setenv("ULTR_SR_BWD_FUSED", knob)
+        _lib.load().ultr_config_reload()
+        return run_step(shape, B, L, dict(learning_rate=0.05, max_gradient_norm=5.0), p0, np.zeros_like(p0), feats, ids, y, ipw)
+
+    try:
+        ref = run("0")
+        got = run("1")
+        again = run("1")
+    finally:
+        monkeypatch.undo()
+        _lib.load().ultr_config_reload()
+    np.testing.assert_array_equal(got[0], ref[0])  # the forward is untouched
+    g, gref = got[1][: shape.n_params], ref[1][: shape.n_params]
+    assert np.isfinite(g).all()
+    # the same products in a different summation order (rows per partial, fold tree): 1e-5 of the largest entry + 1e-4 relative
+    np.testing.assert_allclose(g, gref, rtol=1e-4, atol=1e-5 * float(np.abs(gref).max()))
+    # per parameter tensor: no tensor may hide behind a larger one
+    for name, shp, off in shape.layout():
+        n = int(np.prod(shp))
+        a, b = g[off:off + n], gref[off:off + n]
+        assert np.abs(a - b).max() <= 2e-5 * max(float(np.abs(b).max()), 1e-30) + 1e-9, (name, float(np.abs(a - b).max()), float(np.abs(b).max()))
+    assert abs(got[4][0] - ref[4][0]) <= 1e-6 * max(1.0, abs(ref[4][0]))
+    np.testing.assert_array_equal(got[1], again[1])  # deterministic: persistent workgroups, fixed-order folds

@@ -44,6 +44,7 @@ extern "C" int ultr_gemm_trace_arm(int on) {  // slot 31 != 0: frozen
 #include "ultr_gemm.h"
 #include "ultr_h3.h"
 #include "ultr_plan.h"
+#include "ultr_sr_bwd.h"
 
 #define SR_EPS 1e-6f  // nn.LayerNorm(eps=1e-6) everywhere in SetRank.py (:100-101, :134)
 #define SR_ROWS 4     // rows per workgroup (= waves) of the row-wise kernels
@@ -74,7 +75,9 @@ struct SrPlan {
   int64_t sv_planes, planes_halves;
   int64_t sv_flag;   // float offset in `saved` of the range word behind the planes (ULTR_H3_FLAG_*: raised by sr_split_planes_kernel)
   int no_h3;         // ultr_setrank_desc::flags & ULTR_MODEL_FP32_PRODUCTS
-  struct SplitMat { int64_t off; int M, K, ldK, ldM; int64_t f_off, t_off, g_off; };  // g_off: fragment-major forward copy (sr_block_fwd_kernel), -1: none
+  struct SplitMat { int64_t off; int M, K, ldK, ldM; int64_t f_off, t_off, g_off, gt_off; };  // g_off: fragment-major forward copy (sr_block_fwd_kernel), -1: none
+                                                                                            // gt_off: fragment-major copy of W^T (out K, contraction M: the dgrad
+                                                                                            // products of ultr_sr_bwd.hip), -1: none
   int n_split;
   SplitMat split[32];
   // workspace (floats)
@@ -90,6 +93,7 @@ struct SrPlan {
   // cannot share scratch, each producer takes a fresh piece of this arena
   int64_t ws_arena, arena_floats;
   int64_t ws_total;
+  int bwd_fused;     // the widths ultr_sr_bwd.hip takes: transposed fragment copies exist, the arena holds its per-workgroup partials
 };
 
 // row chunks of sr_wgrad_kernel for an [M, K] gradient: about two workgroups per CU, chunks of a multiple of 32 rows
@@ -153,6 +157,7 @@ bool make_plan(const ultr_setrank_desc* c, int64_t T, SrPlan* p) {
       m.f_off = h; h += 2 * M * m.ldK;
       m.t_off = h; h += 2 * K * m.ldM;
       m.g_off = -1;
+      m.gt_off = -1;
     };
     add(p->w1, dff, F); add(p->w2, d, dff); add(p->wo1, dff, d);
     for (int l = 0; l < p->nl; ++l) { add(p->lay[l].wd, d, d); add(p->lay[l].wf1, dff, d); add(p->lay[l].wf2, d, dff); }
@@ -164,6 +169,15 @@ bool make_plan(const ultr_setrank_desc* c, int64_t T, SrPlan* p) {
         h = (h + 7) & ~(int64_t)7;  // 16-byte aligned: the kernel streams it with 16-byte buffer loads
         m.g_off = h;
         h += 2 * (int64_t)m.M * m.ldK;
+      }
+    // ... and of the transposes of the encoder blocks' matrices for the fused backward launches (ultr_sr_bwd.hip)
+    p->bwd_fused = (d == SR_BWD_D && dff == SR_BWD_DFF) ? 1 : 0;
+    if (p->bwd_fused)
+      for (int k = 3; k < p->n_split; ++k) {
+        SrPlan::SplitMat& m = p->split[k];
+        h = (h + 7) & ~(int64_t)7;
+        m.gt_off = h;
+        h += 2 * (int64_t)m.K * m.ldM;
       }
     p->sv_planes = (p->sv_total + 4 + 7) & ~(int64_t)7;
     p->planes_halves = h;
@@ -195,6 +209,7 @@ bool make_plan(const ultr_setrank_desc* c, int64_t T, SrPlan* p) {
   p->ws_wg = w; w += wg_floats;
   p->wg_floats = wg_floats;
   p->arena_floats = (int64_t)(3 * p->nl + 4) * ((wg_floats + 3) & ~(int64_t)3) + (int64_t)(2 * p->nl + 5) * p->n_lb * 3 * p->maxw;
+  if (p->bwd_fused) p->arena_floats += (int64_t)2 * p->nl * SR_BWD_MAXWG * (d * dff + dff + 3 * d + 4);
   p->ws_arena = w; w += p->arena_floats;
   p->ws_total = w;
   return true;
@@ -703,6 +718,15 @@ float* part_scratch(float* shared_region, int64_t floats) {
     return at;
   }
   return shared_region;
+}
+// a piece of the arena or NULL (producers whose partials do not fit the shared region)
+float* arena_piece(int64_t floats) {
+  FoldCtx& f = g_folds;
+  const int64_t need = (floats + 3) & ~(int64_t)3;
+  if (!(f.active && f.used + need <= f.cap && f.tab.n + 4 <= SR_MAX_FOLDS)) return nullptr;
+  float* at = f.arena + f.used;
+  f.used += need;
+  return at;
 }
 void fold(const float* part, int64_t stride, int nparts, int len, float* dst, hipStream_t st, bool own_buffer = false) {
   FoldCtx& f = g_folds;
@@ -1812,12 +1836,25 @@ struct SrSplitTable {
   int n;
   SrPlan::SplitMat m[32];
 };
-// blockIdx.y = 3 * matrix + phase (0: the forward planes [M][ldK], 1: the transposed planes [K][ldM], 2: the fragment-major forward copy
-// of the fused block kernel - ultr_h3_index - where the plan has one); one element per thread
+// blockIdx.y = 4 * matrix + phase (0: the forward planes [M][ldK], 1: the transposed planes [K][ldM], 2: the fragment-major forward copy
+// of the fused block kernel - ultr_h3_index - where the plan has one, 3: the fragment-major copy of the transpose for the fused backward
+// launches); one element per thread
 __global__ __launch_bounds__(256) void sr_split_planes_kernel(SrSplitTable tb, const float* __restrict__ params, _Float16* __restrict__ planes,
                                                               uint32_t* __restrict__ range_flag) {
-  const SrPlan::SplitMat m = tb.m[blockIdx.y / 3];
-  const int phase = blockIdx.y % 3;
+  const SrPlan::SplitMat m = tb.m[blockIdx.y / 4];
+  const int phase = blockIdx.y % 4;
+  if (phase == 3) {  // fragment-major copy of W^T: output column k of W, contraction over m
+    if (m.gt_off < 0) return;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)m.K * m.ldM) return;
+    const int k = (int)(e / m.ldM), mm = (int)(e - (int64_t)k * m.ldM);
+    const float w = mm < m.M ? params[m.off + (int64_t)mm * m.K + k] * ULTR_H3_WSCALE : 0.f;
+    const _Float16 hi = (_Float16)w, lo = (_Float16)(w - (float)hi);
+    _Float16* dst = planes + m.gt_off;
+    dst[ultr_h3_index(k, mm, m.ldM >> 5, 0)] = hi;
+    dst[ultr_h3_index(k, mm, m.ldM >> 5, 1)] = lo;
+    return;
+  }
   if (phase == 2) {
     if (m.g_off < 0) return;
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1852,7 +1889,7 @@ struct SrH3Ctx {
 };
 thread_local SrH3Ctx g_sr_h3 = {nullptr, nullptr, nullptr};
 // knobs of this file: read at first use, re-read after ultr_config_reload()
-int g_sr_knob_h3 = -1, g_sr_knob_attn_h3 = -1, g_sr_knob_attn_mask = 0, g_sr_knob_wg_h3 = -1;
+int g_sr_knob_h3 = -1, g_sr_knob_attn_h3 = -1, g_sr_knob_attn_mask = 0, g_sr_knob_wg_h3 = -1, g_sr_knob_bwd_fused = 1;
 void sr_knobs_load() {
   if (g_sr_knob_h3 >= 0) return;
   const char* e = getenv("ULTR_SR_H3");
@@ -1863,6 +1900,8 @@ void sr_knobs_load() {
   g_sr_knob_attn_mask = (e && *e) ? atoi(e) : -1;
   e = getenv("ULTR_SR_WG_H3");
   g_sr_knob_wg_h3 = (e && *e) ? atoi(e) : 1;
+  e = getenv("ULTR_SR_BWD_FUSED");  // 1 (default): the row-local chain of a block's backward as two launches (ultr_sr_bwd.hip); 0: seven
+  g_sr_knob_bwd_fused = (e && *e) ? atoi(e) : 1;
 }
 int sr_h3_enabled() {
   sr_knobs_load();
@@ -2903,7 +2942,7 @@ extern "C" int ultr_setrank_forward(const ultr_setrank_desc* c, const float* par
       maxe = a > maxe ? a : maxe;
       maxe = b > maxe ? b : maxe;
     }
-    hipLaunchKernelGGL(sr_split_planes_kernel, dim3((unsigned)((maxe + 255) / 256), (unsigned)(3 * p.n_split)), dim3(256), 0, st, tb, params, planes,
+    hipLaunchKernelGGL(sr_split_planes_kernel, dim3((unsigned)((maxe + 255) / 256), (unsigned)(4 * p.n_split)), dim3(256), 0, st, tb, params, planes,
                        reinterpret_cast<uint32_t*>(sv + p.sv_flag));
     g_sr_h3 = {params, planes, &p};
   }
@@ -3018,8 +3057,60 @@ extern "C" int ultr_setrank_backward(const ultr_setrank_desc* c, const float* pa
   }
   SR_CHECK(wgrad(p, G1, sv + p.sv_x[p.nl], grads + p.wo1, grads + p.bo1, T, d, dff, ws, st));
   SR_CHECK(gemm_dyw(G1, params + p.wo1, G0, nullptr, T, d, dff, 0, st));     // G0 = d x_nl  [T, d]
+  // the fused launches of ultr_sr_bwd.hip: config 5's widths, split-half products on, the transposed fragment copies built by this
+  // step's forward
+  int fz_R = 0, fz_tiles = 0, fz_nwg = 0;
+  bool fused = p.bwd_fused && g_sr_knob_bwd_fused != 0 && g_sr_h3.planes != nullptr && T * (int64_t)d * 4 < ((int64_t)1 << 31);
+  if (fused) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    fused = sr_bwd_geometry(T, cus, &fz_R, &fz_tiles, &fz_nwg);
+  }
   for (int l = p.nl - 1; l >= 0; --l) {
     const SrLayer& y = p.lay[l];
+    if (fused) {
+      const SrPlan::SplitMat* md = sr_find_split(params + y.wd, d, d);
+      const SrPlan::SplitMat* m1 = sr_find_split(params + y.wf1, dff, d);
+      const SrPlan::SplitMat* m2 = sr_find_split(params + y.wf2, d, dff);
+      const int64_t sa = (int64_t)d * dff + 3 * d, sb = (int64_t)dff * d + dff + 3 * d;
+      float* pa = nullptr;
+      float* pb = nullptr;
+      if (md && m1 && m2 && md->gt_off >= 0 && m1->gt_off >= 0 && m2->gt_off >= 0 && y.bf2 == y.wf2 + (int64_t)d * dff && y.b2 == y.g2 + d &&
+          y.bf1 == y.wf1 + (int64_t)dff * d && y.b1 == y.g1 + d && (pa = arena_piece(fz_nwg * sa)) != nullptr &&
+          (pb = arena_piece(fz_nwg * sb)) != nullptr) {
+        SrBwdFfnArgs fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.R = fz_R; fa.d = d; fa.dff = dff; fa.ntiles = fz_tiles; fa.T = T;
+        fa.dy = p.ws_g[0]; fa.dF = p.ws_g[1]; fa.dx = p.ws_g[2];
+        fa.s = p.sv_s2[l]; fa.mean = p.sv_m2[l]; fa.rstd = p.sv_r2[l]; fa.f = p.sv_f[l];
+        fa.gamma = y.g2; fa.gt2 = m2->gt_off; fa.gt1 = m1->gt_off;
+        fa.part = pa - ws; fa.part_stride = sa;
+        SR_CHECK(sr_bwd_ffn_launch(fa, fz_nwg, params, g_sr_h3.planes, sv, ws, st));  // G1 = d f, G2 = d out1
+        fold(pa, sa, fz_nwg, d * dff + d, grads + y.wf2, st);            // d Wf2 | d bf2
+        fold(pa + (int64_t)d * dff + d, sa, fz_nwg, 2 * d, grads + y.g2, st);  // d g2 | d b2
+        SrBwdProjArgs pr;
+        memset(&pr, 0, sizeof(pr));
+        pr.R = fz_R; pr.d = d; pr.dff = dff; pr.ntiles = fz_tiles; pr.T = T;
+        pr.dy = p.ws_g[2]; pr.dF = p.ws_g[1]; pr.ds = p.ws_g[0]; pr.dx = p.ws_g[2];
+        pr.s = p.sv_s1[l]; pr.mean = p.sv_m1[l]; pr.rstd = p.sv_r1[l];
+        pr.gamma = y.g1; pr.beta = y.b1; pr.gtd = md->gt_off;
+        pr.part = pb - ws; pr.part_stride = sb;
+        SR_CHECK(sr_bwd_proj_launch(pr, fz_nwg, params, g_sr_h3.planes, sv, ws, st));  // G0 = d s1 (= d x_l through the residual), G2 = d A
+        fold(pb, sb, fz_nwg, dff * d + dff, grads + y.wf1, st);                           // d Wf1 | d bf1
+        fold(pb + (int64_t)dff * d + dff, sb, fz_nwg, d, grads + y.bd, st);               // d bd
+        fold(pb + (int64_t)dff * d + dff + d, sb, fz_nwg, 2 * d, grads + y.g1, st);       // d g1 | d b1
+        SR_CHECK(wgrad(p, G0, sv + p.sv_A[l], grads + y.wd, nullptr, T, d, d, ws, st));
+        if (attn_f16_ok(p, L))    // G0 += attention path -> d x_l
+          SR_CHECK(attn_bwd_f16(p, sv + p.sv_x[l], G2, sv + p.sv_A[l], sv + p.sv_lse[l], batch, L, G0, st));
+        else if (attn_h3_ok(p, L, l, 1))
+          SR_CHECK(attn_bwd_h3(p, sv + p.sv_x[l], G2, sv + p.sv_A[l], sv + p.sv_lse[l], batch, L, G0, st));
+        else if (attn_mfma_ok(p, L))
+          SR_CHECK(attn_bwd_mfma(p, sv + p.sv_x[l], G2, sv + p.sv_A[l], sv + p.sv_lse[l], batch, L, G0, st));
+        else hipLaunchKernelGGL(sr_attn_bwd_kernel, dim3(batch, p.H), dim3(256), lds_att, st, sv + p.sv_x[l], (const float*)G2, L, d,
+                                p.dh, G0);
+        continue;
+      }
+    }
     // x_{l+1} = LN2(s2),  s2 = out1 + ffn
     if (d <= 1024) {  // g2 | b2, G2 = d s2 = d out1 (residual) = d ffn, bf2: one pass
       SR_CHECK(ln_bwd_cs(p, G0, sv + p.sv_s2[l], sv + p.sv_m2[l], sv + p.sv_r2[l], params + y.g2, d, G2, ws, grads + y.g2,

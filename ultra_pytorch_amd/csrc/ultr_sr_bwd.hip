@@ -1,0 +1,480 @@
+// ultr_sr_bwd.hip - SetRank backward, the row-local chain of an encoder block as TWO launches (round 6).
+//
+// Reference: ultra/ranking_model/SetRank.py:92-111 (MultiHeadSelfAttention's dense + residual + LayerNorm, the FFN + residual +
+// LayerNorm), differentiated.  Until round 5 the chain was seven launches per block - LayerNorm backward (+ column sums), two thin
+// weight-gradient launches, three dgrad GEMMs, LayerNorm backward again - each reading and writing [T, 256] tensors: 1.5 GB of HBM
+// traffic per block at BASELINE config 5 (T = 102 400 token rows).  Here a PERSISTENT workgroup per compute unit (eight waves, up
+// to 256 registers each, ~150 KB of LDS) walks over tiles of R <= 64 token rows and keeps everything of a tile on chip:
+//
+//   sr_bwd_ffn_kernel   d s2 = LN2'(d x')            row-wise, one wave per row, statistics from `saved`
+//                       d Wf2 += d s2^T f            fp32 matrix cores (v_mfma_f32_16x16x4_f32) straight from the fp32 rows in LDS;
+//                                                    the [256 x 64] accumulator lives in registers across ALL tiles of the workgroup
+//                       d f = (d s2 Wf2) o [f > 0]   split-half product (three f16 MFMAs, ultr_h3.h) on a fragment copy of Wf2^T
+//                       d out1 = d s2 + d f Wf1      split-half product on a fragment copy of Wf1^T, residual from LDS
+//   sr_bwd_proj_kernel  d s1 = LN1'(d out1)          (+ out1 recomputed from s1: the backward never reads the saved out1)
+//                       d Wf1 += d f^T out1          fp32 matrix cores, accumulator in registers across tiles
+//                       d A = d s1 Wd                split-half product on a fragment copy of Wd^T
+//
+// HBM traffic per block: reads d x', s2, f | d out1, s1, d f; writes d f, d out1 | d s1, d A  = 0.81 GB.  Column sums (LayerNorm
+// gamma / beta, the three biases) ride along in registers; one partial per workgroup leaves at the end (256 partials of 17 k floats
+// instead of a 64 KB slab per 800 rows), folded by sr_fold_all_kernel in fixed order: deterministic, no atomics.
+// Shapes: d_model 256, dff 64 (BASELINE config 5); ultr_setrank_backward keeps the separate launches for everything else.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ultr_hip.h"
+#include "ultr_device.h"
+#include "ultr_h3.h"
+#include "ultr_plan.h"
+#include "ultr_sr_bwd.h"
+
+#define SRB_EPS 1e-6f
+
+namespace {
+
+constexpr int NW = 8, NT = NW * 64;
+
+__device__ __forceinline__ float row16_max(float v) {  // maximum over the 16 lanes of a DPP row, in every lane of the row
+  ULTR_DPP_MAX(v, "quad_perm:[1,0,3,2] row_mask:0xf");
+  ULTR_DPP_MAX(v, "quad_perm:[2,3,0,1] row_mask:0xf");
+  ULTR_DPP_MAX(v, "row_ror:4 row_mask:0xf");
+  ULTR_DPP_MAX(v, "row_ror:8 row_mask:0xf");
+  return v;
+}
+__device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
+__device__ __forceinline__ float max4(float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
+
+// LayerNorm backward of four rows per wave (rows wave + 8 (4 half + k), lane = columns 4 lane .. + 3; d = 256):
+//   xh = (s - mean) rstd,  g = dy gamma,  v = rstd (g - mean(g) - xh mean(g xh))         (same expressions as sr_ln_bwd_cs_v4_kernel)
+// v goes to the fp16 plane pair in P0 scaled per row (OS[row] = the inverse scale x 2^-8: the weights are stored x 2^8) and, by MODE,
+//   MODE 0: to P1 as fp32 rows (the residual and the weight-gradient operand of the FFN kernel)
+//   MODE 1: to global memory (d s1), while P1 receives out1 = xh gamma + beta (the weight-gradient operand of the projection kernel)
+// Column sums: cg += dy xh, cb += dy, cd += v.
+template <int MODE>
+__device__ __forceinline__ void ln_bwd_rows(int half, int wave, int lane, int R, int ld, const Src& dys, const Src& ss, const Src& ms,
+                                            const Src& rs, const float4 g4, const float4 b4, const Dst& dso, float* P0, float* P1,
+                                            float* OS, float4& cg, float4& cb, float4& cd) {
+  constexpr int d = SR_BWD_D;
+  const int c = 4 * lane;
+  float4 dy[4], xh[4];
+  float m[4], rr[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = wave + NW * (4 * half + k);
+    dy[k] = buf_ld4(dys, (unsigned)(r * d + c) * 4u);
+    xh[k] = buf_ld4(ss, (unsigned)(r * d + c) * 4u);
+    m[k] = buf_ld1(ms, (unsigned)r * 4u);
+    rr[k] = buf_ld1(rs, (unsigned)r * 4u);
+  }
+  float s1[4], s2[4];
+  float4 g[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    xh[k] = make_float4((xh[k].x - m[k]) * rr[k], (xh[k].y - m[k]) * rr[k], (xh[k].z - m[k]) * rr[k], (xh[k].w - m[k]) * rr[k]);
+    g[k] = make_float4(dy[k].x * g4.x, dy[k].y * g4.y, dy[k].z * g4.z, dy[k].w * g4.w);
+    s1[k] = (g[k].x + g[k].y) + (g[k].z + g[k].w);
+    s2[k] = (g[k].x * xh[k].x + g[k].y * xh[k].y) + (g[k].z * xh[k].z + g[k].w * xh[k].w);
+    cg.x += dy[k].x * xh[k].x; cg.y += dy[k].y * xh[k].y; cg.z += dy[k].z * xh[k].z; cg.w += dy[k].w * xh[k].w;
+    cb.x += dy[k].x; cb.y += dy[k].y; cb.z += dy[k].z; cb.w += dy[k].w;
+  }
+  wave_sum_n<4>(s1);
+  wave_sum_n<4>(s2);
+  float am[4];
+  float4 v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float a1 = s1[k] * (1.0f / (float)d), a2 = s2[k] * (1.0f / (float)d);
+    v[k] = make_float4(rr[k] * (g[k].x - a1 - xh[k].x * a2), rr[k] * (g[k].y - a1 - xh[k].y * a2),
+                       rr[k] * (g[k].z - a1 - xh[k].z * a2), rr[k] * (g[k].w - a1 - xh[k].w * a2));
+    cd.x += v[k].x; cd.y += v[k].y; cd.z += v[k].z; cd.w += v[k].w;
+    am[k] = max4(v[k]);
+  }
+  wave_max_n<4>(am);
+  _Float16* AH = reinterpret_cast<_Float16*>(P0);
+  _Float16* AL = AH + (R + 1) * ld;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = wave + NW * (4 * half + k), rc = r < R ? r : R;
+    float sc, inv;
+    fb_h3_scale(am[k], sc, inv);
+    fbh4 hi, lo;
+    fb_h3_split4(v[k], sc, hi, lo);
+    *reinterpret_cast<fbh4*>(AH + rc * ld + c) = hi;
+    *reinterpret_cast<fbh4*>(AL + rc * ld + c) = lo;
+    if (lane == 0) OS[r] = inv * (1.0f / ULTR_H3_WSCALE);
+    if constexpr (MODE == 0) {
+      st4(P1 + rc * ld + c, v[k]);
+    } else {
+      buf_st4(dso, (unsigned)c * 4u, (unsigned)(r * d) * 4u, v[k]);
+      st4(P1 + rc * ld + c, make_float4(xh[k].x * g4.x + b4.x, xh[k].y * g4.y + b4.y, xh[k].z * g4.z + b4.z, xh[k].w * g4.w + b4.w));
+    }
+  }
+}
+
+// a d-wide split-half product over the tile's four 16-row tiles: wave = one 32-column chunk of the output, the A operand = the fp16
+// plane pair at Ap (row stride lda halves), the weights = fragment copy at planes + gw (nks steps of 32 along the contraction);
+// Y = acc x os[row] (+ the fp32 row in Pres); rows past the tile's valid rows are dropped by the destination's extent
+template <bool RES>
+__device__ __forceinline__ void product_d4(int wave, int lane, int R, const float* Ap, int lda, int nks, const _Float16* planes,
+                                           int64_t gw, int Kw, const float* os, const float* Pres, int ld, const Dst& dout) {
+  constexpr int d = SR_BWD_D;
+  asm volatile("" : "+v"(lane));
+  const int ch = wave;
+  const int i = lane & 15, q = lane >> 4;
+  const _Float16* AH = reinterpret_cast<const _Float16*>(Ap);
+  const int lo_off = (R + 1) * lda;
+  const _Float16* pa[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int row = 16 * t + i;
+    pa[t] = AH + (row < R ? row : R) * lda + 8 * q;
+  }
+  const Src Wh = make_src(reinterpret_cast<const float*>(planes + gw), (int64_t)Kw * d);
+  PipeH3W<4, 2> ph;
+  ph.begin(Wh, ch, nks, 0, nks, true, lane);
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) acc[t][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  ph.run(pa, lo_off, Wh, nks, acc);
+  const int col = 32 * ch + 2 * i;
+  const unsigned gv = (unsigned)(4 * q * d + 2 * i) * 4u;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const float4 o4 = ld4(os + 16 * t + 4 * q);
+    const float o[4] = {o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * t + 4 * q + r;
+      float2 y = make_float2(acc[t][0][r] * o[r], acc[t][1][r] * o[r]);
+      if constexpr (RES) {
+        const float2 rv = ld2(Pres + (row < R ? row : R) * ld + col);
+        y.x += rv.x;
+        y.y += rv.y;
+      }
+      buf_st2(dout, gv, (unsigned)((16 * t + r) * d + 32 * ch) * 4u, y);
+    }
+  }
+}
+
+// the eight waves' column sums through LDS, fixed order: smem[wave][nv][d] -> out[v * d + c]
+__device__ __forceinline__ void colsum_store(float* smem, int wave, int lane, const float4& c0, const float4& c1, const float4& c2) {
+  constexpr int d = SR_BWD_D;
+  float* mine = smem + wave * 3 * d;
+  st4(mine + 4 * lane, c0);
+  st4(mine + d + 4 * lane, c1);
+  st4(mine + 2 * d + 4 * lane, c2);
+}
+__device__ __forceinline__ float colsum_fold(const float* smem, int e) {
+  constexpr int d = SR_BWD_D;
+  float t = smem[e];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) t += smem[w * 3 * d + e];
+  return t;
+}
+
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void sr_bwd_ffn_kernel(SrBwdFfnArgs a, const float* __restrict__ params,
+                                                                                             const _Float16* __restrict__ planes,
+                                                                                             const float* __restrict__ sv, float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int d = SR_BWD_D, dff = SR_BWD_DFF, ld = d + 8, ldf = dff + 8;
+  const int R = a.R;
+  float* P0 = smem + a.p0;  // planes of d s2
+  float* P1 = smem + a.p1;  // fp32 rows of d s2
+  float* P2 = smem + a.p2;  // f (fp32 rows) -> d f before the mask (fp32 rows) -> planes of d f
+  float* OS = smem + a.os;  // [64] row scales of d s2, [64] of d f
+  const int tid = threadIdx.x, lane_id = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float* pg = params + a.gamma + 4 * lane_id;  // (parameter offsets are not 16-byte aligned)
+  const float4 g4 = make_float4(pg[0], pg[1], pg[2], pg[3]);
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 cg = z4, cb = z4, cd = z4;
+  f32x4 accW[4][2];  // d Wf2: rows 64 (wave >> 1) + 4 (4 q + r) + ta, columns 32 (wave & 1) + 2 i + tb
+#pragma unroll
+  for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) accW[ta][tb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int mblk = wave >> 1, nhalf = wave & 1;
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int64_t n0 = (int64_t)tile * R;
+    const int vr = (int)((a.T - n0) < R ? (a.T - n0) : R);
+    int lane = lane_id;
+    asm volatile("" : "+v"(lane));
+    // ---- row phase: LayerNorm_2 backward, f to LDS -------------------------------------------------------------------------
+    unsigned fmask = 0;
+    {
+      const Src dys = make_src(ws + a.dy + n0 * d, (int64_t)vr * d), ss = make_src(sv + a.s + n0 * d, (int64_t)vr * d);
+      const Src ms = make_src(sv + a.mean + n0, vr), rs = make_src(sv + a.rstd + n0, vr);
+      const Src fs = make_src(sv + a.f + n0 * dff, (int64_t)vr * dff);
+      const Dst none = make_dst(ws, 0);
+      float4 fv[2];
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+        const int row = 4 * (wave + NW * q2) + (lane >> 4);
+        fv[q2] = buf_ld4(fs, (unsigned)(row * dff + 4 * (lane & 15)) * 4u);
+      }
+      ln_bwd_rows<0>(0, wave, lane, R, ld, dys, ss, ms, rs, g4, z4, none, P0, P1, OS, cg, cb, cd);
+      ln_bwd_rows<0>(1, wave, lane, R, ld, dys, ss, ms, rs, g4, z4, none, P0, P1, OS, cg, cb, cd);
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+        const int row = 4 * (wave + NW * q2) + (lane >> 4), rc = row < R ? row : R;
+        st4(P2 + rc * ldf + 4 * (lane & 15), fv[q2]);
+        fmask |= ((fv[q2].x > 0.f ? 1u : 0u) | (fv[q2].y > 0.f ? 2u : 0u) | (fv[q2].z > 0.f ? 4u : 0u) | (fv[q2].w > 0.f ? 8u : 0u)) << (4 * q2);
+      }
+    }
+    lds_barrier();
+    // ---- d Wf2 += d s2^T f on the fp32 matrix cores; d f = d s2 Wf2 (before the mask) on the split-half copies ------------------
+    {
+      const int i = lane & 15, q = lane >> 4;
+      const float* pa = P1 + q * ld + 64 * mblk + 4 * i;
+      const float* pb = P2 + q * ldf + 32 * nhalf + 2 * i;
+      const int nk = R >> 2;
+#pragma unroll 2
+      for (int kk = 0; kk < nk; ++kk) {
+        const float4 av = ld4(pa + 4 * kk * ld);
+        const float2 bv = ld2(pb + 4 * kk * ldf);
+        const float aa[4] = {av.x, av.y, av.z, av.w};
+        const float bb[2] = {bv.x, bv.y};
+#pragma unroll
+        for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+          for (int tb = 0; tb < 2; ++tb) accW[ta][tb] = mfma16(aa[ta], bb[tb], accW[ta][tb]);
+      }
+    }
+    f32x4 accf[1][2] = {{(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}}};
+    const int rt = wave >> 1, chf = wave & 1;
+    {
+      const int i = lane & 15, q = lane >> 4;
+      const _Float16* AH = reinterpret_cast<const _Float16*>(P0);
+      const int rowi = 16 * rt + i;
+      const _Float16* pa[1] = {AH + (rowi < R ? rowi : R) * ld + 8 * q};
+      const Src Wh = make_src(reinterpret_cast<const float*>(planes + a.gt2), (int64_t)d * dff);
+      PipeH3W<1, 2> ph;
+      ph.begin(Wh, chf, d >> 5, 0, d >> 5, true, lane);
+      ph.run(pa, (R + 1) * ld, Wh, d >> 5, accf);
+    }
+    lds_barrier();  // every wave has read f
+    {
+      const int i = lane & 15, q = lane >> 4;
+      const float4 o4 = ld4(OS + 16 * rt + 4 * q);
+      const float o[4] = {o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * rt + 4 * q + r, rc = row < R ? row : R;
+        *reinterpret_cast<float2*>(P2 + rc * ldf + 32 * chf + 2 * i) = make_float2(accf[0][0][r] * o[r], accf[0][1][r] * o[r]);
+      }
+    }
+    lds_barrier();
+    // ---- the ReLU mask; d f to global memory and, scaled per row, to its plane pair ----------------------------------------------
+    {
+      const Dst dfo = make_dst(ws + a.dF + n0 * dff, (int64_t)vr * dff);
+      float4 v[2];
+      float am[2];
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+        const int row = 4 * (wave + NW * q2) + (lane >> 4), rc = row < R ? row : R;
+        v[q2] = ld4(P2 + rc * ldf + 4 * (lane & 15));
+        const unsigned mk = fmask >> (4 * q2);
+        v[q2].x = (mk & 1u) ? v[q2].x : 0.f;
+        v[q2].y = (mk & 2u) ? v[q2].y : 0.f;
+        v[q2].z = (mk & 4u) ? v[q2].z : 0.f;
+        v[q2].w = (mk & 8u) ? v[q2].w : 0.f;
+        buf_st4(dfo, (unsigned)(row * dff + 4 * (lane & 15)) * 4u, 0u, v[q2]);
+        am[q2] = row16_max(max4(v[q2]));
+      }
+      lds_barrier();  // every fp32 row has been read: the planes may overwrite them
+      _Float16* FH = reinterpret_cast<_Float16*>(P2);
+      _Float16* FL = FH + (R + 1) * ldf;
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+        const int row = 4 * (wave + NW * q2) + (lane >> 4), rc = row < R ? row : R;
+        float sc, inv;
+        fb_h3_scale(am[q2], sc, inv);
+        fbh4 hi, lo;
+        fb_h3_split4(v[q2], sc, hi, lo);
+        *reinterpret_cast<fbh4*>(FH + rc * ldf + 4 * (lane & 15)) = hi;
+        *reinterpret_cast<fbh4*>(FL + rc * ldf + 4 * (lane & 15)) = lo;
+        if ((lane & 15) == 0) OS[64 + row] = inv * (1.0f / ULTR_H3_WSCALE);
+      }
+    }
+    lds_barrier();
+    // ---- d out1 = d s2 + d f Wf1 ---------------------------------------------------------------------------------------------------
+    {
+      const Dst dxo = make_dst(ws + a.dx + n0 * d, (int64_t)vr * d);
+      product_d4<true>(wave, lane, R, P2, ldf, dff >> 5, planes, a.gt1, dff, OS + 64, P1, ld, dxo);
+    }
+    lds_barrier();
+  }
+  // ---- the workgroup's partial: d Wf2 | d bf2 | d g2 | d b2 -------------------------------------------------------------------------
+  float* pw = ws + a.part + (int64_t)blockIdx.x * a.part_stride;
+  {
+    const int i = lane_id & 15, q = lane_id >> 4;
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 64 * mblk + 4 * (4 * q + r) + ta;
+        *reinterpret_cast<float2*>(pw + m * dff + 32 * nhalf + 2 * i) = make_float2(accW[ta][0][r], accW[ta][1][r]);
+      }
+  }
+  colsum_store(smem, wave, lane_id, cd, cg, cb);
+  lds_barrier();
+  for (int e = tid; e < 3 * d; e += NT) pw[d * dff + e] = colsum_fold(smem, e);
+}
+
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void sr_bwd_proj_kernel(SrBwdProjArgs a, const float* __restrict__ params,
+                                                                                              const _Float16* __restrict__ planes,
+                                                                                              const float* __restrict__ sv, float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int d = SR_BWD_D, dff = SR_BWD_DFF, ld = d + 8, ldf = dff + 8;
+  const int R = a.R;
+  float* P0 = smem + a.p0;  // planes of d s1
+  float* P1 = smem + a.p1;  // fp32 rows of out1 (recomputed)
+  float* PF = smem + a.pf;  // fp32 rows of d f
+  float* OS = smem + a.os;  // [64] row scales of d s1
+  const int tid = threadIdx.x, lane_id = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float* pg = params + a.gamma + 4 * lane_id;  // (parameter offsets are not 16-byte aligned)
+  const float* pb = params + a.beta + 4 * lane_id;
+  const float4 g4 = make_float4(pg[0], pg[1], pg[2], pg[3]), b4 = make_float4(pb[0], pb[1], pb[2], pb[3]);
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 cg = z4, cb = z4, cd = z4, cf = z4;
+  f32x4 accW[4][2];  // d Wf1: rows 4 (4 q + r) + ta, columns 32 wave + 2 i + tb
+#pragma unroll
+  for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) accW[ta][tb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int64_t n0 = (int64_t)tile * R;
+    const int vr = (int)((a.T - n0) < R ? (a.T - n0) : R);
+    int lane = lane_id;
+    asm volatile("" : "+v"(lane));
+    {
+      const Src dys = make_src(ws + a.dy + n0 * d, (int64_t)vr * d), ss = make_src(sv + a.s + n0 * d, (int64_t)vr * d);
+      const Src ms = make_src(sv + a.mean + n0, vr), rs = make_src(sv + a.rstd + n0, vr);
+      const Src fs = make_src(ws + a.dF + n0 * dff, (int64_t)vr * dff);
+      const Dst dso = make_dst(ws + a.ds + n0 * d, (int64_t)vr * d);
+      float4 fv[2];
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+        const int row = 4 * (wave + NW * q2) + (lane >> 4);
+        fv[q2] = buf_ld4(fs, (unsigned)(row * dff + 4 * (lane & 15)) * 4u);
+      }
+      ln_bwd_rows<1>(0, wave, lane, R, ld, dys, ss, ms, rs, g4, b4, dso, P0, P1, OS, cg, cb, cd);
+      ln_bwd_rows<1>(1, wave, lane, R, ld, dys, ss, ms, rs, g4, b4, dso, P0, P1, OS, cg, cb, cd);
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+        const int row = 4 * (wave + NW * q2) + (lane >> 4), rc = row < R ? row : R;
+        st4(PF + rc * ldf + 4 * (lane & 15), fv[q2]);
+        cf.x += fv[q2].x; cf.y += fv[q2].y; cf.z += fv[q2].z; cf.w += fv[q2].w;
+      }
+    }
+    lds_barrier();
+    // ---- d A = d s1 Wd (in place over d out1 when a.dx == a.dy: this tile's rows were read above) -----------------------------------
+    {
+      const Dst dxo = make_dst(ws + a.dx + n0 * d, (int64_t)vr * d);
+      product_d4<false>(wave, lane, R, P0, ld, d >> 5, planes, a.gtd, d, OS, nullptr, ld, dxo);
+    }
+    // ---- d Wf1 += d f^T out1 ----------------------------------------------------------------------------------------------------------
+    {
+      const int i = lane & 15, q = lane >> 4;
+      const float* pa = PF + q * ldf + 4 * i;
+      const float* pb = P1 + q * ld + 32 * wave + 2 * i;
+      const int nk = R >> 2;
+#pragma unroll 2
+      for (int kk = 0; kk < nk; ++kk) {
+        const float4 av = ld4(pa + 4 * kk * ldf);
+        const float2 bv = ld2(pb + 4 * kk * ld);
+        const float aa[4] = {av.x, av.y, av.z, av.w};
+        const float bb[2] = {bv.x, bv.y};
+#pragma unroll
+        for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+          for (int tb = 0; tb < 2; ++tb) accW[ta][tb] = mfma16(aa[ta], bb[tb], accW[ta][tb]);
+      }
+    }
+    lds_barrier();
+  }
+  // ---- the workgroup's partial: d Wf1 | d bf1 | d bd | d g1 | d b1 ---------------------------------------------------------------------
+  float* pw = ws + a.part + (int64_t)blockIdx.x * a.part_stride;
+  {
+    const int i = lane_id & 15, q = lane_id >> 4;
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 4 * (4 * q + r) + ta;
+        *reinterpret_cast<float2*>(pw + m * d + 32 * wave + 2 * i) = make_float2(accW[ta][0][r], accW[ta][1][r]);
+      }
+  }
+  colsum_store(smem, wave, lane_id, cd, cg, cb);
+  float* sf = smem + NW * 3 * d;  // [8 waves x 4 row groups][dff]
+  st4(sf + (wave * 4 + (lane_id >> 4)) * dff + 4 * (lane_id & 15), cf);
+  lds_barrier();
+  if (tid < dff) {
+    float t = sf[tid];
+#pragma unroll
+    for (int k = 1; k < 4 * NW; ++k) t += sf[k * dff + tid];
+    pw[dff * d + tid] = t;
+  }
+  for (int e = tid; e < 3 * d; e += NT) pw[dff * d + dff + e] = colsum_fold(smem, e);
+}
+
+size_t tile_lds_floats(int R) {
+  const size_t tile = (size_t)(R + 1) * (2 * (SR_BWD_D + 8) + (SR_BWD_DFF + 8)) + 128;
+  const size_t tail = (size_t)NW * 3 * SR_BWD_D + (size_t)4 * NW * SR_BWD_DFF;
+  return tile > tail ? tile : tail;
+}
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+  if (bytes > 160 * 1024) return ULTR_E_UNSUPPORTED;
+  if (bytes > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+    return ULTR_E_UNSUPPORTED;
+  return 0;
+}
+
+}  // namespace
+
+// whole rounds of one workgroup per compute unit: as few rounds as 64-row tiles allow, rows per tile a multiple of 4 (the
+// weight-gradient products step over 4 rows)
+bool sr_bwd_geometry(int64_t T, int cus, int* R, int* ntiles, int* nwg) {
+  if (T <= 0 || T > 0x7fffffff / (4 * SR_BWD_D)) return false;
+  int n = cus > 0 ? cus : 256;
+  if (n > SR_BWD_MAXWG) n = SR_BWD_MAXWG;
+  const int64_t rounds = (T + (int64_t)n * 64 - 1) / ((int64_t)n * 64);
+  int64_t r = (T + n * rounds - 1) / (n * rounds);
+  r = (r + 3) / 4 * 4;
+  if (r < 4) r = 4;
+  if (r > 64) r = 64;
+  *R = (int)r;
+  *ntiles = (int)((T + r - 1) / r);
+  *nwg = *ntiles < n ? *ntiles : n;
+  return true;
+}
+
+int sr_bwd_ffn_launch(SrBwdFfnArgs a, int nwg, const float* params, const _Float16* planes, const float* sv, float* ws, hipStream_t st) {
+  if (a.d != SR_BWD_D || a.dff != SR_BWD_DFF || a.R < 4 || a.R > 64 || (a.R & 3) || nwg <= 0 || nwg > SR_BWD_MAXWG) return ULTR_E_UNSUPPORTED;
+  a.p0 = 0;
+  a.p1 = (a.R + 1) * (SR_BWD_D + 8);
+  a.p2 = 2 * a.p1;
+  a.os = a.p2 + (a.R + 1) * (SR_BWD_DFF + 8);
+  const size_t lds = tile_lds_floats(a.R) * sizeof(float);
+  const int rc = set_lds(sr_bwd_ffn_kernel, lds);
+  if (rc != 0) return rc;
+  hipLaunchKernelGGL(sr_bwd_ffn_kernel, dim3(nwg), dim3(NT), lds, st, a, params, planes, sv, ws);
+  return (int)hipGetLastError();
+}
+int sr_bwd_proj_launch(SrBwdProjArgs a, int nwg, const float* params, const _Float16* planes, const float* sv, float* ws, hipStream_t st) {
+  if (a.d != SR_BWD_D || a.dff != SR_BWD_DFF || a.R < 4 || a.R > 64 || (a.R & 3) || nwg <= 0 || nwg > SR_BWD_MAXWG) return ULTR_E_UNSUPPORTED;
+  a.p0 = 0;
+  a.p1 = (a.R + 1) * (SR_BWD_D + 8);
+  a.pf = 2 * a.p1;
+  a.os = a.pf + (a.R + 1) * (SR_BWD_DFF + 8);
+  const size_t lds = tile_lds_floats(a.R) * sizeof(float);
+  const int rc = set_lds(sr_bwd_proj_kernel, lds);
+  if (rc != 0) return rc;
+  hipLaunchKernelGGL(sr_bwd_proj_kernel, dim3(nwg), dim3(NT), lds, st, a, params, planes, sv, ws);
+  return (int)hipGetLastError();
+}
