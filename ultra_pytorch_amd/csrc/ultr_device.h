@@ -204,6 +204,12 @@ __device__ __forceinline__ float4 buf_ld4(const Src& s, unsigned byte_off) {
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(s.rs, byte_off, 0, 0);
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
+// lane offset + a wave-uniform (scalar register) offset: unrolled loads of several rows share ONE offset register per lane; the
+// range check covers the sum (gfx950: the ragged tiles of the fused SetRank kernels rely on it, tests/test_gpu_setrank.py)
+__device__ __forceinline__ float4 buf_ld4s(const Src& s, unsigned lane_off, unsigned uniform_off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(s.rs, lane_off, uniform_off, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
 __device__ __forceinline__ float buf_ld1(const Src& s, unsigned byte_off) {
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(s.rs, byte_off, 0, 0));
 }

@@ -173,11 +173,12 @@ bool make_plan(const ultr_setrank_desc* c, int64_t T, SrPlan* p) {
     // ... and of the transposes of the encoder blocks' matrices for the fused backward launches (ultr_sr_bwd.hip)
     p->bwd_fused = (d == SR_BWD_D && dff == SR_BWD_DFF) ? 1 : 0;
     if (p->bwd_fused)
-      for (int k = 3; k < p->n_split; ++k) {
+      for (int k = 0; k < p->n_split; ++k) {  // (every matrix: the output FFN and the embedding FFN have fused backward launches too)
         SrPlan::SplitMat& m = p->split[k];
         h = (h + 7) & ~(int64_t)7;
         m.gt_off = h;
-        h += 2 * (int64_t)m.K * m.ldM;
+        h += 2 * (int64_t)((m.K + 31) / 32 * 32) * m.ldM;  // whole 32-column chunks (a ragged last chunk keeps its tail unwritten: those
+                                                           // output columns do not exist)
       }
     p->sv_planes = (p->sv_total + 4 + 7) & ~(int64_t)7;
     p->planes_halves = h;
@@ -209,7 +210,7 @@ bool make_plan(const ultr_setrank_desc* c, int64_t T, SrPlan* p) {
   p->ws_wg = w; w += wg_floats;
   p->wg_floats = wg_floats;
   p->arena_floats = (int64_t)(3 * p->nl + 4) * ((wg_floats + 3) & ~(int64_t)3) + (int64_t)(2 * p->nl + 5) * p->n_lb * 3 * p->maxw;
-  if (p->bwd_fused) p->arena_floats += (int64_t)2 * p->nl * SR_BWD_MAXWG * (d * dff + dff + 3 * d + 4);
+  if (p->bwd_fused) p->arena_floats += (int64_t)(2 * p->nl + 3) * SR_BWD_MAXWG * (d * dff + dff + 3 * d + 4);
   p->ws_arena = w; w += p->arena_floats;
   p->ws_total = w;
   return true;
@@ -1900,8 +1901,8 @@ void sr_knobs_load() {
   g_sr_knob_attn_mask = (e && *e) ? atoi(e) : -1;
   e = getenv("ULTR_SR_WG_H3");
   g_sr_knob_wg_h3 = (e && *e) ? atoi(e) : 1;
-  e = getenv("ULTR_SR_BWD_FUSED");  // 1 (default): the row-local chain of a block's backward as two launches (ultr_sr_bwd.hip); 0: seven
-  g_sr_knob_bwd_fused = (e && *e) ? atoi(e) : 1;
+  e = getenv("ULTR_SR_BWD_FUSED");  // bits (default 7 = all): 1 the row-local chain of a block's backward as two launches (ultr_sr_bwd.hip)
+  g_sr_knob_bwd_fused = (e && *e) ? atoi(e) : 7;  // instead of seven, 2 the output FFN's backward as one instead of three, 4 the embedding FFN's
 }
 int sr_h3_enabled() {
   sr_knobs_load();
@@ -3045,6 +3046,33 @@ extern "C" int ultr_setrank_backward(const ultr_setrank_desc* c, const float* pa
   if (sr_h3_enabled() && !p.no_h3) g_sr_h3 = {params, reinterpret_cast<const _Float16*>(sv + p.sv_planes), &p};  // built by this step's forward
   // ---- output FFN:  s = oh wo2^T + bo2,  oh = relu(x_nl Wo1^T + bo1) ----------------------------------------------
   FoldScope folds(ws + p.ws_arena, p.arena_floats);  // every fold below is queued; ONE launch at the end
+  // the fused launches of ultr_sr_bwd.hip: config 5's widths, split-half products on, the transposed fragment copies built by this
+  // step's forward
+  int fz_R = 0, fz_tiles = 0, fz_nwg = 0;
+  bool fused = p.bwd_fused && g_sr_knob_bwd_fused != 0 && g_sr_h3.planes != nullptr && T * (int64_t)d * 4 < ((int64_t)1 << 31);
+  if (fused) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    fused = sr_bwd_geometry(T, cus, &fz_R, &fz_tiles, &fz_nwg);
+  }
+  bool head_done = false;
+  if (fused && (g_sr_knob_bwd_fused & 2) && p.bo1 == p.wo1 + (int64_t)dff * d && p.wo2 == p.bo1 + dff && p.bo2 == p.wo2 + dff) {
+    const SrPlan::SplitMat* mo = sr_find_split(params + p.wo1, dff, d);
+    const int64_t sh = (int64_t)dff * d + 2 * dff + 2;
+    float* ph = nullptr;
+    if (mo && mo->gt_off >= 0 && (ph = arena_piece(fz_nwg * sh)) != nullptr) {
+      SrBwdHeadArgs ha;
+      memset(&ha, 0, sizeof(ha));
+      ha.R = fz_R; ha.d = d; ha.dff = dff; ha.ntiles = fz_tiles; ha.T = T;
+      ha.dx = p.ws_g[0]; ha.x = p.sv_x[p.nl]; ha.oh = p.sv_oh; ha.wo2 = p.wo2; ha.gto1 = mo->gt_off;
+      ha.part = ph - ws; ha.part_stride = sh;
+      SR_CHECK(sr_bwd_head_launch(ha, fz_nwg, params, g_sr_h3.planes, sv, dscores, ws, st));  // G0 = d x_nl
+      fold(ph, sh, fz_nwg, dff * d + 2 * dff + 1, grads + p.wo1, st);                         // d Wo1 | d bo1 | d wo2 | d bo2
+      head_done = true;
+    }
+  }
+  if (head_done) {
+  } else
   if (dff <= 256 && p.bo2 == p.wo2 + dff) {  // one pass: G1 = d oh [T, dff] (ReLU mask fused), d wo2 | d bo2 partials
     float* hpart = part_scratch(ws + p.ws_part, (int64_t)p.n_cs * (dff + 1));
     hipLaunchKernelGGL(sr_head_bwd_kernel, dim3(p.n_cs), dim3(256), 0, st, dscores, (const float*)(sv + p.sv_oh), params + p.wo2, T, (int)dff,
@@ -3055,20 +3083,13 @@ extern "C" int ultr_setrank_backward(const ultr_setrank_desc* c, const float* pa
     colsum(p, dscores, nullptr, nullptr, nullptr, 1, 0, ws, grads + p.bo2, st);
     SR_CHECK(gemm_dyw(dscores, params + p.wo2, G1, sv + p.sv_oh, T, dff, 1, 0, st));  // G1 = d oh  [T, dff], ReLU mask fused
   }
-  SR_CHECK(wgrad(p, G1, sv + p.sv_x[p.nl], grads + p.wo1, grads + p.bo1, T, d, dff, ws, st));
-  SR_CHECK(gemm_dyw(G1, params + p.wo1, G0, nullptr, T, d, dff, 0, st));     // G0 = d x_nl  [T, d]
-  // the fused launches of ultr_sr_bwd.hip: config 5's widths, split-half products on, the transposed fragment copies built by this
-  // step's forward
-  int fz_R = 0, fz_tiles = 0, fz_nwg = 0;
-  bool fused = p.bwd_fused && g_sr_knob_bwd_fused != 0 && g_sr_h3.planes != nullptr && T * (int64_t)d * 4 < ((int64_t)1 << 31);
-  if (fused) {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    fused = sr_bwd_geometry(T, cus, &fz_R, &fz_tiles, &fz_nwg);
+  if (!head_done) {
+    SR_CHECK(wgrad(p, G1, sv + p.sv_x[p.nl], grads + p.wo1, grads + p.bo1, T, d, dff, ws, st));
+    SR_CHECK(gemm_dyw(G1, params + p.wo1, G0, nullptr, T, d, dff, 0, st));     // G0 = d x_nl  [T, d]
   }
   for (int l = p.nl - 1; l >= 0; --l) {
     const SrLayer& y = p.lay[l];
-    if (fused) {
+    if (fused && (g_sr_knob_bwd_fused & 1)) {
       const SrPlan::SplitMat* md = sr_find_split(params + y.wd, d, d);
       const SrPlan::SplitMat* m1 = sr_find_split(params + y.wf1, dff, d);
       const SrPlan::SplitMat* m2 = sr_find_split(params + y.wf2, d, dff);

@@ -35,7 +35,20 @@ struct SrBwdProjArgs {
   int64_t part, part_stride;
   int p0, p1, pf, os;
 };
+// sr_bwd_head_kernel: the output FFN's backward; per-workgroup partial [d Wo1 (dff x d) | d bo1 (dff) | d wo2 (dff) | d bo2 | pad]
+struct SrBwdHeadArgs {
+  int R, d, dff, ntiles;
+  int64_t T;
+  int64_t dx;                // workspace: d x_nl [T, d] out
+  int64_t x, oh;             // saved: x_nl, oh
+  int64_t wo2;               // parameters
+  int64_t gto1;              // HALVES: fragment copy of Wo1^T (out d, contraction dff)
+  int64_t part, part_stride;
+  int p0, p1, pf, os;
+};
 // rows per tile / tiles / workgroups / LDS bytes for T rows on `cus` compute units; false: T too small or too large
 bool sr_bwd_geometry(int64_t T, int cus, int* R, int* ntiles, int* nwg);
 int sr_bwd_ffn_launch(SrBwdFfnArgs a, int nwg, const float* params, const _Float16* planes, const float* sv, float* ws, hipStream_t st);
+int sr_bwd_head_launch(SrBwdHeadArgs a, int nwg, const float* params, const _Float16* planes, const float* sv, const float* dscores, float* ws,
+                       hipStream_t st);
 int sr_bwd_proj_launch(SrBwdProjArgs a, int nwg, const float* params, const _Float16* planes, const float* sv, float* ws, hipStream_t st);

@@ -28,7 +28,21 @@
 #include "ultr_plan.h"
 #include "ultr_sr_bwd.h"
 
-#define SRB_EPS 1e-6f
+#ifdef ULTR_TRACE
+// phase stamps (s_memtime) of wave 0 of the first 64 workgroups on their SECOND tile; slot 16 k + j: kernel k (0 ffn, 1 proj), stamp j
+__device__ unsigned long long g_srb_trace[64 * 32];
+#define SRB_STAMP(kern, slot)                                                                                         \
+  do {                                                                                                                \
+    if (threadIdx.x == 0 && blockIdx.x < 64 && tile == (int)(blockIdx.x + gridDim.x)) g_srb_trace[blockIdx.x * 32 + 16 * (kern) + (slot)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+extern "C" int ultr_srb_trace_read(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_srb_trace), sizeof(unsigned long long) * 64 * 32);
+}
+#else
+#define SRB_STAMP(kern, slot) \
+  do {                        \
+  } while (0)
+#endif
 
 namespace {
 
@@ -50,51 +64,81 @@ __device__ __forceinline__ float max4(float4 v) { return fmaxf(fmaxf(fabsf(v.x),
 //   MODE 0: to P1 as fp32 rows (the residual and the weight-gradient operand of the FFN kernel)
 //   MODE 1: to global memory (d s1), while P1 receives out1 = xh gamma + beta (the weight-gradient operand of the projection kernel)
 // Column sums: cg += dy xh, cb += dy, cd += v.
-template <int MODE>
-__device__ __forceinline__ void ln_bwd_rows(int half, int wave, int lane, int R, int ld, const Src& dys, const Src& ss, const Src& ms,
-                                            const Src& rs, const float4 g4, const float4 b4, const Dst& dso, float* P0, float* P1,
-                                            float* OS, float4& cg, float4& cb, float4& cd) {
+// the HBM operands of a tile's row phase, requested one tile ahead (the workgroup is alone on its CU: nobody else hides the latency):
+// rows wave + 8 q of d y and s, the dff-wide rows 4 (wave + 8 q2) + (lane >> 4), and the rows' statistics one per lane (lane k < 8:
+// row wave + 8 k; read back with v_readlane - two registers instead of sixteen.  Scalar loads were tried: they share the LDS counter,
+// so the first LDS read of the weight-gradient loop waited ~12k cycles for sixteen cold scalar-cache misses)
+struct RowRegs {
+  float4 dy[8], s[8];
+  float mv, rv;
+};
+__device__ __forceinline__ void load_rows(RowRegs& g, int wave, int lane, const float* dy, const float* s, const float* __restrict__ mean,
+                                          const float* __restrict__ rstd, int64_t n0, int vr) {
   constexpr int d = SR_BWD_D;
-  const int c = 4 * lane;
-  float4 dy[4], xh[4];
-  float m[4], rr[4];
+  const Src dys = make_src(dy + n0 * d, (int64_t)vr * d), ss = make_src(s + n0 * d, (int64_t)vr * d);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int r = wave + NW * (4 * half + k);
-    dy[k] = buf_ld4(dys, (unsigned)(r * d + c) * 4u);
-    xh[k] = buf_ld4(ss, (unsigned)(r * d + c) * 4u);
-    m[k] = buf_ld1(ms, (unsigned)r * 4u);
-    rr[k] = buf_ld1(rs, (unsigned)r * 4u);
+  for (int k = 0; k < 8; ++k) {
+    const int r = wave + NW * k;
+    g.dy[k] = buf_ld4s(dys, (unsigned)lane * 16u, (unsigned)(r * d) * 4u);
+    g.s[k] = buf_ld4s(ss, (unsigned)lane * 16u, (unsigned)(r * d) * 4u);
   }
-  float s1[4], s2[4];
-  float4 g[4];
+  const Src ms = make_src(mean + n0, vr), rs = make_src(rstd + n0, vr);
+  g.mv = buf_ld1(ms, lane < 8 ? (unsigned)(wave + NW * lane) * 4u : ULTR_OOB);
+  g.rv = buf_ld1(rs, lane < 8 ? (unsigned)(wave + NW * lane) * 4u : ULTR_OOB);
+}
+// the dff-wide rows 4 (wave + 8 q2) + (lane >> 4) of a tile: requested at the START of its row phase, used at its end (16 KB per tile:
+// the LayerNorm arithmetic covers the round trip; eight registers less to carry through the products)
+__device__ __forceinline__ void load_frows(float4 (&fv)[2], int wave, int lane, const float* f, int64_t n0, int vr) {
+  constexpr int dff = SR_BWD_DFF;
+  static_assert(dff == 64, "a wave reads four dff-wide rows as 64 consecutive float4");
+  const Src fs = make_src(f + n0 * dff, (int64_t)vr * dff);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int q2 = 0; q2 < 2; ++q2) fv[q2] = buf_ld4s(fs, (unsigned)lane * 16u, (unsigned)(4 * (wave + NW * q2) * dff) * 4u);
+}
+
+// rows 2 pr, 2 pr + 1 of the wave's eight (pr < 4)
+template <int MODE>
+__device__ __forceinline__ void ln_bwd_rows(int pr, int wave, int lane, int R, int ld, const RowRegs& rg, const float4 g4, const float4 b4,
+                                            const Dst& dso, float* P0, float* P1, float* OS, float4& cg, float4& cb, float4& cd) {
+  constexpr int d = SR_BWD_D, NR = 2;
+  const int c = 4 * lane;
+  float4 dy[NR], xh[NR];
+  float m[NR], rr[NR];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    dy[k] = rg.dy[NR * pr + k];
+    xh[k] = rg.s[NR * pr + k];
+    m[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rg.mv), NR * pr + k));
+    rr[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rg.rv), NR * pr + k));
+  }
+  float ss[2 * NR];
+  float4 g[NR];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
     xh[k] = make_float4((xh[k].x - m[k]) * rr[k], (xh[k].y - m[k]) * rr[k], (xh[k].z - m[k]) * rr[k], (xh[k].w - m[k]) * rr[k]);
     g[k] = make_float4(dy[k].x * g4.x, dy[k].y * g4.y, dy[k].z * g4.z, dy[k].w * g4.w);
-    s1[k] = (g[k].x + g[k].y) + (g[k].z + g[k].w);
-    s2[k] = (g[k].x * xh[k].x + g[k].y * xh[k].y) + (g[k].z * xh[k].z + g[k].w * xh[k].w);
+    ss[k] = (g[k].x + g[k].y) + (g[k].z + g[k].w);
+    ss[NR + k] = (g[k].x * xh[k].x + g[k].y * xh[k].y) + (g[k].z * xh[k].z + g[k].w * xh[k].w);
     cg.x += dy[k].x * xh[k].x; cg.y += dy[k].y * xh[k].y; cg.z += dy[k].z * xh[k].z; cg.w += dy[k].w * xh[k].w;
     cb.x += dy[k].x; cb.y += dy[k].y; cb.z += dy[k].z; cb.w += dy[k].w;
   }
-  wave_sum_n<4>(s1);
-  wave_sum_n<4>(s2);
-  float am[4];
-  float4 v[4];
+  wave_sum_n<2 * NR>(ss);
+  float am[NR];
+  float4 v[NR];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float a1 = s1[k] * (1.0f / (float)d), a2 = s2[k] * (1.0f / (float)d);
+  for (int k = 0; k < NR; ++k) {
+    const float a1 = ss[k] * (1.0f / (float)d), a2 = ss[NR + k] * (1.0f / (float)d);
     v[k] = make_float4(rr[k] * (g[k].x - a1 - xh[k].x * a2), rr[k] * (g[k].y - a1 - xh[k].y * a2),
                        rr[k] * (g[k].z - a1 - xh[k].z * a2), rr[k] * (g[k].w - a1 - xh[k].w * a2));
     cd.x += v[k].x; cd.y += v[k].y; cd.z += v[k].z; cd.w += v[k].w;
     am[k] = max4(v[k]);
   }
-  wave_max_n<4>(am);
+  wave_max_n<NR>(am);
   _Float16* AH = reinterpret_cast<_Float16*>(P0);
   _Float16* AL = AH + (R + 1) * ld;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int r = wave + NW * (4 * half + k), rc = r < R ? r : R;
+  for (int k = 0; k < NR; ++k) {
+    const int r = wave + NW * (NR * pr + k), rc = r < R ? r : R;
     float sc, inv;
     fb_h3_scale(am[k], sc, inv);
     fbh4 hi, lo;
@@ -158,6 +202,44 @@ __device__ __forceinline__ void product_d4(int wave, int lane, int R, const floa
   }
 }
 
+// d W [dff x d] += A^T B on the fp32 matrix cores, A = fp32 rows [R][dff] at PA (row stride dff + 8), B = fp32 rows [R][d] at PB (row
+// stride d + 8): wave = 32 output columns, lane (i, q) reads row 4 step + q - a float4 of A at column 4 i feeds the four 16-row
+// sub-tiles (rows 4 i + ta of d W), a float2 of B at column 32 wave + 2 i the two column sub-tiles.  The next step's operands leave LDS
+// while this step's eight MFMAs run.  accW[ta][tb][r] = d W[4 (4 q + r) + ta][32 wave + 2 i + tb].
+__device__ __forceinline__ void wgrad_thin_wide(f32x4 (&accW)[4][2], const float* PA, const float* PB, int R, int wave, int lane) {
+  constexpr int ld = SR_BWD_D + 8, ldf = SR_BWD_DFF + 8;
+  const int i = lane & 15, q = lane >> 4;
+  const float* pa = PA + q * ldf + 4 * i;
+  const float* pb = PB + q * ld + 32 * wave + 2 * i;
+  const int nk = R >> 2;
+  float4 av = ld4(pa);
+  float2 bv = ld2(pb);
+  for (int kk = 0; kk < nk; ++kk) {
+    const int kn = kk + 1 < nk ? kk + 1 : kk;
+    const float4 an = ld4(pa + 4 * kn * ldf);
+    const float2 bn = ld2(pb + 4 * kn * ld);
+    const float aa[4] = {av.x, av.y, av.z, av.w};
+    const float bb[2] = {bv.x, bv.y};
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb) accW[ta][tb] = mfma16(aa[ta], bb[tb], accW[ta][tb]);
+    av = an;
+    bv = bn;
+  }
+}
+__device__ __forceinline__ void wgrad_thin_wide_store(const f32x4 (&accW)[4][2], float* pw, int wave, int lane) {
+  constexpr int d = SR_BWD_D;
+  const int i = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = 4 * (4 * q + r) + ta;
+      *reinterpret_cast<float2*>(pw + m * d + 32 * wave + 2 * i) = make_float2(accW[ta][0][r], accW[ta][1][r]);
+    }
+}
+
 // the eight waves' column sums through LDS, fixed order: smem[wave][nv][d] -> out[v * d + c]
 __device__ __forceinline__ void colsum_store(float* smem, int wave, int lane, const float4& c0, const float4& c1, const float4& c2) {
   constexpr int d = SR_BWD_D;
@@ -185,8 +267,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   float* P2 = smem + a.p2;  // f (fp32 rows) -> d f before the mask (fp32 rows) -> planes of d f
   float* OS = smem + a.os;  // [64] row scales of d s2, [64] of d f
   const int tid = threadIdx.x, lane_id = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const float* pg = params + a.gamma + 4 * lane_id;  // (parameter offsets are not 16-byte aligned)
-  const float4 g4 = make_float4(pg[0], pg[1], pg[2], pg[3]);
+  float* PG = OS + 128;     // gamma (re-read per tile: four registers less across the products)
+  for (int e = tid; e < d; e += NT) PG[e] = params[a.gamma + e];
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 cg = z4, cb = z4, cd = z4;
   f32x4 accW[4][2];  // d Wf2: rows 64 (wave >> 1) + 4 (4 q + r) + ta, columns 32 (wave & 1) + 2 i + tb
@@ -196,26 +278,29 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     for (int tb = 0; tb < 2; ++tb) accW[ta][tb] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int mblk = wave >> 1, nhalf = wave & 1;
 
+  RowRegs rg;
+  auto request = [&](int tile) {  // past the last tile: empty extents, every load returns zero without touching memory
+    const int64_t n0 = (int64_t)tile * R;
+    const int vr = tile < a.ntiles ? (int)((a.T - n0) < R ? (a.T - n0) : R) : 0;
+    load_rows(rg, wave, lane_id, ws + a.dy, sv + a.s, sv + a.mean, sv + a.rstd, tile < a.ntiles ? n0 : 0, vr);
+  };
+  request(blockIdx.x);
+  lds_barrier();  // PG
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int64_t n0 = (int64_t)tile * R;
     const int vr = (int)((a.T - n0) < R ? (a.T - n0) : R);
     int lane = lane_id;
     asm volatile("" : "+v"(lane));
     // ---- row phase: LayerNorm_2 backward, f to LDS -------------------------------------------------------------------------
+    SRB_STAMP(0, 0);
     unsigned fmask = 0;
     {
-      const Src dys = make_src(ws + a.dy + n0 * d, (int64_t)vr * d), ss = make_src(sv + a.s + n0 * d, (int64_t)vr * d);
-      const Src ms = make_src(sv + a.mean + n0, vr), rs = make_src(sv + a.rstd + n0, vr);
-      const Src fs = make_src(sv + a.f + n0 * dff, (int64_t)vr * dff);
       const Dst none = make_dst(ws, 0);
       float4 fv[2];
+      load_frows(fv, wave, lane, sv + a.f, n0, vr);
+      const float4 g4 = ld4(PG + 4 * lane);
 #pragma unroll
-      for (int q2 = 0; q2 < 2; ++q2) {
-        const int row = 4 * (wave + NW * q2) + (lane >> 4);
-        fv[q2] = buf_ld4(fs, (unsigned)(row * dff + 4 * (lane & 15)) * 4u);
-      }
-      ln_bwd_rows<0>(0, wave, lane, R, ld, dys, ss, ms, rs, g4, z4, none, P0, P1, OS, cg, cb, cd);
-      ln_bwd_rows<0>(1, wave, lane, R, ld, dys, ss, ms, rs, g4, z4, none, P0, P1, OS, cg, cb, cd);
+      for (int pr = 0; pr < 4; ++pr) ln_bwd_rows<0>(pr, wave, lane, R, ld, rg, g4, z4, none, P0, P1, OS, cg, cb, cd);
 #pragma unroll
       for (int q2 = 0; q2 < 2; ++q2) {
         const int row = 4 * (wave + NW * q2) + (lane >> 4), rc = row < R ? row : R;
@@ -223,25 +308,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         fmask |= ((fv[q2].x > 0.f ? 1u : 0u) | (fv[q2].y > 0.f ? 2u : 0u) | (fv[q2].z > 0.f ? 4u : 0u) | (fv[q2].w > 0.f ? 8u : 0u)) << (4 * q2);
       }
     }
+    SRB_STAMP(0, 1);
     lds_barrier();
-    // ---- d Wf2 += d s2^T f on the fp32 matrix cores; d f = d s2 Wf2 (before the mask) on the split-half copies ------------------
-    {
-      const int i = lane & 15, q = lane >> 4;
-      const float* pa = P1 + q * ld + 64 * mblk + 4 * i;
-      const float* pb = P2 + q * ldf + 32 * nhalf + 2 * i;
-      const int nk = R >> 2;
-#pragma unroll 2
-      for (int kk = 0; kk < nk; ++kk) {
-        const float4 av = ld4(pa + 4 * kk * ld);
-        const float2 bv = ld2(pb + 4 * kk * ldf);
-        const float aa[4] = {av.x, av.y, av.z, av.w};
-        const float bb[2] = {bv.x, bv.y};
-#pragma unroll
-        for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-          for (int tb = 0; tb < 2; ++tb) accW[ta][tb] = mfma16(aa[ta], bb[tb], accW[ta][tb]);
-      }
-    }
+    SRB_STAMP(0, 2);
+    // ---- d f = d s2 Wf2 (before the mask) on the split-half copies; then the NEXT tile's rows are requested and
+    //      d Wf2 += d s2^T f runs on the fp32 matrix cores from LDS while they travel ---------------------------------------------------
     f32x4 accf[1][2] = {{(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}}};
     const int rt = wave >> 1, chf = wave & 1;
     {
@@ -254,7 +325,35 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       ph.begin(Wh, chf, d >> 5, 0, d >> 5, true, lane);
       ph.run(pa, (R + 1) * ld, Wh, d >> 5, accf);
     }
+    SRB_STAMP(0, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    request(tile + (int)gridDim.x);
+    __builtin_amdgcn_sched_barrier(0);
+    SRB_STAMP(0, 4);
+    {
+      const int i = lane & 15, q = lane >> 4;
+      const float* pa = P1 + q * ld + 64 * mblk + 4 * i;
+      const float* pb = P2 + q * ldf + 32 * nhalf + 2 * i;
+      const int nk = R >> 2;
+      float4 av = ld4(pa);
+      float2 bv = ld2(pb);
+      for (int kk = 0; kk < nk; ++kk) {  // the next step's operands leave LDS while this step's eight MFMAs run
+        const int kn = kk + 1 < nk ? kk + 1 : kk;
+        const float4 an = ld4(pa + 4 * kn * ld);
+        const float2 bn = ld2(pb + 4 * kn * ldf);
+        const float aa[4] = {av.x, av.y, av.z, av.w};
+        const float bb[2] = {bv.x, bv.y};
+#pragma unroll
+        for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+          for (int tb = 0; tb < 2; ++tb) accW[ta][tb] = mfma16(aa[ta], bb[tb], accW[ta][tb]);
+        av = an;
+        bv = bn;
+      }
+    }
+    SRB_STAMP(0, 5);
     lds_barrier();  // every wave has read f
+    SRB_STAMP(0, 6);
     {
       const int i = lane & 15, q = lane >> 4;
       const float4 o4 = ld4(OS + 16 * rt + 4 * q);
@@ -299,12 +398,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       }
     }
     lds_barrier();
+    SRB_STAMP(0, 7);
     // ---- d out1 = d s2 + d f Wf1 ---------------------------------------------------------------------------------------------------
     {
       const Dst dxo = make_dst(ws + a.dx + n0 * d, (int64_t)vr * d);
       product_d4<true>(wave, lane, R, P2, ldf, dff >> 5, planes, a.gt1, dff, OS + 64, P1, ld, dxo);
     }
+    SRB_STAMP(0, 8);
     lds_barrier();
+    SRB_STAMP(0, 9);
   }
   // ---- the workgroup's partial: d Wf2 | d bf2 | d g2 | d b2 -------------------------------------------------------------------------
   float* pw = ws + a.part + (int64_t)blockIdx.x * a.part_stride;
@@ -334,9 +436,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   float* PF = smem + a.pf;  // fp32 rows of d f
   float* OS = smem + a.os;  // [64] row scales of d s1
   const int tid = threadIdx.x, lane_id = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const float* pg = params + a.gamma + 4 * lane_id;  // (parameter offsets are not 16-byte aligned)
-  const float* pb = params + a.beta + 4 * lane_id;
-  const float4 g4 = make_float4(pg[0], pg[1], pg[2], pg[3]), b4 = make_float4(pb[0], pb[1], pb[2], pb[3]);
+  float* PG = OS + 128;     // gamma | beta (re-read per tile: eight registers less across the products)
+  for (int e = tid; e < 2 * d; e += NT) PG[e] = params[(e < d ? a.gamma : a.beta - d) + e];
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 cg = z4, cb = z4, cd = z4, cf = z4;
   f32x4 accW[4][2];  // d Wf1: rows 4 (4 q + r) + ta, columns 32 wave + 2 i + tb
@@ -345,24 +446,27 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
     for (int tb = 0; tb < 2; ++tb) accW[ta][tb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  RowRegs rg;
+  auto request = [&](int tile) {  // past the last tile: empty extents, every load returns zero without touching memory
+    const int64_t n0 = (int64_t)tile * R;
+    const int vr = tile < a.ntiles ? (int)((a.T - n0) < R ? (a.T - n0) : R) : 0;
+    load_rows(rg, wave, lane_id, ws + a.dy, sv + a.s, sv + a.mean, sv + a.rstd, tile < a.ntiles ? n0 : 0, vr);
+  };
+  request(blockIdx.x);
+  lds_barrier();  // PG
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int64_t n0 = (int64_t)tile * R;
     const int vr = (int)((a.T - n0) < R ? (a.T - n0) : R);
     int lane = lane_id;
     asm volatile("" : "+v"(lane));
+    SRB_STAMP(1, 0);
     {
-      const Src dys = make_src(ws + a.dy + n0 * d, (int64_t)vr * d), ss = make_src(sv + a.s + n0 * d, (int64_t)vr * d);
-      const Src ms = make_src(sv + a.mean + n0, vr), rs = make_src(sv + a.rstd + n0, vr);
-      const Src fs = make_src(ws + a.dF + n0 * dff, (int64_t)vr * dff);
       const Dst dso = make_dst(ws + a.ds + n0 * d, (int64_t)vr * d);
       float4 fv[2];
+      load_frows(fv, wave, lane, ws + a.dF, n0, vr);
+      const float4 g4 = ld4(PG + 4 * lane), b4 = ld4(PG + d + 4 * lane);
 #pragma unroll
-      for (int q2 = 0; q2 < 2; ++q2) {
-        const int row = 4 * (wave + NW * q2) + (lane >> 4);
-        fv[q2] = buf_ld4(fs, (unsigned)(row * dff + 4 * (lane & 15)) * 4u);
-      }
-      ln_bwd_rows<1>(0, wave, lane, R, ld, dys, ss, ms, rs, g4, b4, dso, P0, P1, OS, cg, cb, cd);
-      ln_bwd_rows<1>(1, wave, lane, R, ld, dys, ss, ms, rs, g4, b4, dso, P0, P1, OS, cg, cb, cd);
+      for (int pr = 0; pr < 4; ++pr) ln_bwd_rows<1>(pr, wave, lane, R, ld, rg, g4, b4, dso, P0, P1, OS, cg, cb, cd);
 #pragma unroll
       for (int q2 = 0; q2 < 2; ++q2) {
         const int row = 4 * (wave + NW * q2) + (lane >> 4), rc = row < R ? row : R;
@@ -370,44 +474,30 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         cf.x += fv[q2].x; cf.y += fv[q2].y; cf.z += fv[q2].z; cf.w += fv[q2].w;
       }
     }
+    SRB_STAMP(1, 1);
     lds_barrier();
+    SRB_STAMP(1, 2);
     // ---- d A = d s1 Wd (in place over d out1 when a.dx == a.dy: this tile's rows were read above) -----------------------------------
     {
       const Dst dxo = make_dst(ws + a.dx + n0 * d, (int64_t)vr * d);
       product_d4<false>(wave, lane, R, P0, ld, d >> 5, planes, a.gtd, d, OS, nullptr, ld, dxo);
     }
+    // the next tile's rows travel while the weight gradient runs from LDS (when d A overwrites d out1 in place, the next tile's rows
+    // are other rows: every tile belongs to exactly one workgroup)
+    SRB_STAMP(1, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    request(tile + (int)gridDim.x);
+    __builtin_amdgcn_sched_barrier(0);
+    SRB_STAMP(1, 4);
     // ---- d Wf1 += d f^T out1 ----------------------------------------------------------------------------------------------------------
-    {
-      const int i = lane & 15, q = lane >> 4;
-      const float* pa = PF + q * ldf + 4 * i;
-      const float* pb = P1 + q * ld + 32 * wave + 2 * i;
-      const int nk = R >> 2;
-#pragma unroll 2
-      for (int kk = 0; kk < nk; ++kk) {
-        const float4 av = ld4(pa + 4 * kk * ldf);
-        const float2 bv = ld2(pb + 4 * kk * ld);
-        const float aa[4] = {av.x, av.y, av.z, av.w};
-        const float bb[2] = {bv.x, bv.y};
-#pragma unroll
-        for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-          for (int tb = 0; tb < 2; ++tb) accW[ta][tb] = mfma16(aa[ta], bb[tb], accW[ta][tb]);
-      }
-    }
+    wgrad_thin_wide(accW, PF, P1, R, wave, lane);
+    SRB_STAMP(1, 5);
     lds_barrier();
+    SRB_STAMP(1, 6);
   }
   // ---- the workgroup's partial: d Wf1 | d bf1 | d bd | d g1 | d b1 ---------------------------------------------------------------------
   float* pw = ws + a.part + (int64_t)blockIdx.x * a.part_stride;
-  {
-    const int i = lane_id & 15, q = lane_id >> 4;
-#pragma unroll
-    for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = 4 * (4 * q + r) + ta;
-        *reinterpret_cast<float2*>(pw + m * d + 32 * wave + 2 * i) = make_float2(accW[ta][0][r], accW[ta][1][r]);
-      }
-  }
+  wgrad_thin_wide_store(accW, pw, wave, lane_id);
   colsum_store(smem, wave, lane_id, cd, cg, cb);
   float* sf = smem + NW * 3 * d;  // [8 waves x 4 row groups][dff]
   st4(sf + (wave * 4 + (lane_id >> 4)) * dff + 4 * (lane_id & 15), cf);
@@ -421,8 +511,112 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   for (int e = tid; e < 3 * d; e += NT) pw[dff * d + dff + e] = colsum_fold(smem, e);
 }
 
+// sr_bwd_head_kernel: the output FFN's backward (SetRank.py:136, 153 backwards): score = oh . wo2 + bo2, oh = relu(x Wo1^T + bo1)
+//   d oh = d score wo2 o [oh > 0],  d wo2 = sum d score oh,  d bo2 = sum d score,  d Wo1 += d oh^T x,  d bo1 = sum d oh,  d x = d oh Wo1
+// (was: sr_head_bwd_kernel + a thin weight-gradient launch + a dgrad GEMM - d oh written and read twice, x read once: 315 MB; here
+// 236 MB, and d oh never leaves the chip).  Partial per workgroup: [d Wo1 (dff x d) | d bo1 (dff) | d wo2 (dff) | d bo2 | pad].
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void sr_bwd_head_kernel(SrBwdHeadArgs a, const float* __restrict__ params,
+                                                                                              const _Float16* __restrict__ planes,
+                                                                                              const float* __restrict__ sv, const float* __restrict__ dscores,
+                                                                                              float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int d = SR_BWD_D, dff = SR_BWD_DFF, ld = d + 8, ldf = dff + 8;
+  const int R = a.R;
+  float* P0 = smem + a.p0;  // planes of d oh
+  float* P1 = smem + a.p1;  // fp32 rows of x
+  float* PF = smem + a.pf;  // fp32 rows of d oh
+  float* OS = smem + a.os;  // [64] row scales of d oh
+  const int tid = threadIdx.x, lane_id = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float* pw2 = params + a.wo2 + 4 * (lane_id & 15);
+  const float4 w4 = make_float4(pw2[0], pw2[1], pw2[2], pw2[3]);
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 cw = z4, cb1 = z4;
+  float cds = 0.f;
+  f32x4 accW[4][2];
+#pragma unroll
+  for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) accW[ta][tb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 xr[8];
+  auto request = [&](int tile) {
+    const int64_t n0 = (int64_t)tile * R;
+    const int vr = tile < a.ntiles ? (int)((a.T - n0) < R ? (a.T - n0) : R) : 0;
+    const Src xs = make_src(sv + a.x + (tile < a.ntiles ? n0 : 0) * d, (int64_t)vr * d);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xr[k] = buf_ld4s(xs, (unsigned)lane_id * 16u, (unsigned)((wave + NW * k) * d) * 4u);
+  };
+  request(blockIdx.x);
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int64_t n0 = (int64_t)tile * R;
+    const int vr = (int)((a.T - n0) < R ? (a.T - n0) : R);
+    int lane = lane_id;
+    asm volatile("" : "+v"(lane));
+    {
+      const Src dys = make_src(dscores + n0, vr), ohs = make_src(sv + a.oh + n0 * dff, (int64_t)vr * dff);
+      float4 ov[2];
+      float dsv[2];
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+        ov[q2] = buf_ld4s(ohs, (unsigned)lane * 16u, (unsigned)(4 * (wave + NW * q2) * dff) * 4u);
+        dsv[q2] = buf_ld1(dys, (unsigned)(4 * (wave + NW * q2) + (lane >> 4)) * 4u);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int r = wave + NW * k;
+        st4(P1 + (r < R ? r : R) * ld + 4 * lane, xr[k]);
+      }
+      _Float16* FH = reinterpret_cast<_Float16*>(P0);
+      _Float16* FL = FH + (R + 1) * ldf;
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+        const int row = 4 * (wave + NW * q2) + (lane >> 4), rc = row < R ? row : R;
+        const float ds = dsv[q2];
+        const float4 o = ov[q2];
+        const float4 g = make_float4(o.x > 0.f ? ds * w4.x : 0.f, o.y > 0.f ? ds * w4.y : 0.f, o.z > 0.f ? ds * w4.z : 0.f, o.w > 0.f ? ds * w4.w : 0.f);
+        cw.x = fmaf(ds, o.x, cw.x); cw.y = fmaf(ds, o.y, cw.y); cw.z = fmaf(ds, o.z, cw.z); cw.w = fmaf(ds, o.w, cw.w);
+        cb1.x += g.x; cb1.y += g.y; cb1.z += g.z; cb1.w += g.w;
+        cds += (lane & 15) == 0 ? ds : 0.f;
+        st4(PF + rc * ldf + 4 * (lane & 15), g);
+        const float am = row16_max(max4(g));
+        float sc, inv;
+        fb_h3_scale(am, sc, inv);
+        fbh4 hi, lo;
+        fb_h3_split4(g, sc, hi, lo);
+        *reinterpret_cast<fbh4*>(FH + rc * ldf + 4 * (lane & 15)) = hi;
+        *reinterpret_cast<fbh4*>(FL + rc * ldf + 4 * (lane & 15)) = lo;
+        if ((lane & 15) == 0) OS[row] = inv * (1.0f / ULTR_H3_WSCALE);
+      }
+    }
+    lds_barrier();
+    {
+      const Dst dxo = make_dst(ws + a.dx + n0 * d, (int64_t)vr * d);
+      product_d4<false>(wave, lane, R, P0, ldf, dff >> 5, planes, a.gto1, dff, OS, nullptr, ld, dxo);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    request(tile + (int)gridDim.x);
+    __builtin_amdgcn_sched_barrier(0);
+    wgrad_thin_wide(accW, PF, P1, R, wave, lane);
+    lds_barrier();
+  }
+  float* pw = ws + a.part + (int64_t)blockIdx.x * a.part_stride;
+  wgrad_thin_wide_store(accW, pw, wave, lane_id);
+  float* sf = smem;  // [8 waves x 4 row groups][2 dff + 1 (+ 3 pad)]
+  constexpr int sl = 2 * dff + 4;
+  float* mine = sf + (wave * 4 + (lane_id >> 4)) * sl;
+  st4(mine + 4 * (lane_id & 15), cb1);
+  st4(mine + dff + 4 * (lane_id & 15), cw);
+  if ((lane_id & 15) == 0) mine[2 * dff] = cds;
+  lds_barrier();
+  if (tid < 2 * dff + 1) {
+    float t = sf[tid];
+#pragma unroll
+    for (int k = 1; k < 4 * NW; ++k) t += sf[k * sl + tid];
+    pw[dff * d + tid] = t;
+  }
+}
+
 size_t tile_lds_floats(int R) {
-  const size_t tile = (size_t)(R + 1) * (2 * (SR_BWD_D + 8) + (SR_BWD_DFF + 8)) + 128;
+  const size_t tile = (size_t)(R + 1) * (2 * (SR_BWD_D + 8) + (SR_BWD_DFF + 8)) + 128 + 2 * SR_BWD_D;
   const size_t tail = (size_t)NW * 3 * SR_BWD_D + (size_t)4 * NW * SR_BWD_DFF;
   return tile > tail ? tile : tail;
 }
@@ -476,5 +670,22 @@ int sr_bwd_proj_launch(SrBwdProjArgs a, int nwg, const float* params, const _Flo
   const int rc = set_lds(sr_bwd_proj_kernel, lds);
   if (rc != 0) return rc;
   hipLaunchKernelGGL(sr_bwd_proj_kernel, dim3(nwg), dim3(NT), lds, st, a, params, planes, sv, ws);
+  return (int)hipGetLastError();
+}
+
+int sr_bwd_head_launch(SrBwdHeadArgs a, int nwg, const float* params, const _Float16* planes, const float* sv, const float* dscores, float* ws,
+                       hipStream_t st) {
+  if (a.d != SR_BWD_D || a.dff != SR_BWD_DFF || a.R < 4 || a.R > 64 || (a.R & 3) || nwg <= 0 || nwg > SR_BWD_MAXWG) return ULTR_E_UNSUPPORTED;
+  a.p0 = 0;
+  a.pf = (a.R + 1) * (SR_BWD_DFF + 8);
+  a.p1 = 2 * a.pf;
+  a.os = a.p1 + (a.R + 1) * (SR_BWD_D + 8);
+  size_t fl = (size_t)a.os + 64;
+  const size_t tail = (size_t)4 * NW * (2 * SR_BWD_DFF + 4);
+  if (fl < tail) fl = tail;
+  const size_t lds = fl * sizeof(float);
+  const int rc = set_lds(sr_bwd_head_kernel, lds);
+  if (rc != 0) return rc;
+  hipLaunchKernelGGL(sr_bwd_head_kernel, dim3(nwg), dim3(NT), lds, st, a, params, planes, sv, dscores, ws);
   return (int)hipGetLastError();
 }
