@@ -210,7 +210,8 @@ bool make_plan(const ultr_setrank_desc* c, int64_t T, SrPlan* p) {
   p->ws_wg = w; w += wg_floats;
   p->wg_floats = wg_floats;
   p->arena_floats = (int64_t)(3 * p->nl + 4) * ((wg_floats + 3) & ~(int64_t)3) + (int64_t)(2 * p->nl + 5) * p->n_lb * 3 * p->maxw;
-  if (p->bwd_fused) p->arena_floats += (int64_t)(2 * p->nl + 3) * SR_BWD_MAXWG * (d * dff + dff + 3 * d + 4);
+  if (p->bwd_fused)  // two per block, the output FFN's, the embedding FFN's
+    p->arena_floats += (int64_t)(2 * p->nl + 1) * SR_BWD_MAXWG * (d * dff + dff + 3 * d + 4) + (int64_t)SR_BWD_MAXWG * (2 * F + dff * F + dff + d * dff + d + 4);
   p->ws_arena = w; w += p->arena_floats;
   p->ws_total = w;
   return true;
@@ -3168,11 +3169,32 @@ extern "C" int ultr_setrank_backward(const ultr_setrank_desc* c, const float* pa
                             p.dh, G0);
   }
   // ---- embedding FFN and the input LayerNorm's parameters -------------------------------------------------------------
+  bool embed_done = false;
+  if (fused && (g_sr_knob_bwd_fused & 4) && F % 4 == 0 && F <= SR_BWD_D && p.b_in == p.g_in + F && p.w1 == p.b_in + F && p.b1 == p.w1 + (int64_t)dff * F &&
+      p.w2 == p.b1 + dff && p.b2 == p.w2 + (int64_t)d * dff) {
+    const SrPlan::SplitMat* m1 = sr_find_split(params + p.w1, dff, F);
+    const SrPlan::SplitMat* m2 = sr_find_split(params + p.w2, d, dff);
+    const int64_t se = (int64_t)2 * F + (int64_t)dff * F + dff + (int64_t)d * dff + d;
+    float* pe = nullptr;
+    if (m1 && m2 && m1->gt_off >= 0 && m2->gt_off >= 0 && (pe = arena_piece(fz_nwg * se)) != nullptr) {
+      SrBwdEmbedArgs ea;
+      memset(&ea, 0, sizeof(ea));
+      ea.R = fz_R; ea.d = d; ea.dff = dff; ea.F = F; ea.ntiles = fz_tiles; ea.T = T;
+      ea.dy = p.ws_g[0]; ea.h0 = p.sv_h0; ea.xg = p.sv_xg; ea.mean = p.sv_mean_in; ea.rstd = p.sv_rstd_in;
+      ea.g_in = p.g_in; ea.b_in = p.b_in; ea.gt2 = m2->gt_off; ea.gt1 = m1->gt_off;
+      ea.part = pe - ws; ea.part_stride = se;
+      SR_CHECK(sr_bwd_embed_launch(ea, fz_nwg, params, g_sr_h3.planes, sv, ws, st));
+      fold(pe, se, fz_nwg, (int)se, grads + p.g_in, st);  // d g_in | d b_in | d W1 | d b1 | d W2 | d b2
+      embed_done = true;
+    }
+  }
+  if (!embed_done) {
   SR_CHECK(wgrad(p, G0, sv + p.sv_h0, grads + p.w2, grads + p.b2, T, dff, d, ws, st));
   SR_CHECK(gemm_dyw(G0, params + p.w2, G1, sv + p.sv_h0, T, dff, d, 0, st));  // ReLU mask fused
   SR_CHECK(wgrad(p, G1, sv + p.sv_xn0, grads + p.w1, grads + p.b1, T, F, dff, ws, st));
   SR_CHECK(gemm_dyw(G1, params + p.w1, G2, nullptr, T, F, dff, 0, st));      // G2 = d xn0  [T, F]
   colsum_ln(p, G2, sv + p.sv_xg, sv + p.sv_mean_in, sv + p.sv_rstd_in, F, ws, grads + p.g_in, st);  // g_in | b_in
+  }
   // ---- step tail: fold the loss partials behind the gradient ----------------------------------------------------------
   if (loss_ws != nullptr && n_loss_parts > 0) {
     const int tail = (int)ultr_tail_len(list_size);

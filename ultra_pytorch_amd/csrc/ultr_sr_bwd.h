@@ -46,9 +46,22 @@ struct SrBwdHeadArgs {
   int64_t part, part_stride;
   int p0, p1, pf, os;
 };
+// sr_bwd_embed_kernel: the embedding FFN's and the input LayerNorm's backward; per-workgroup partial in the parameter vector's order
+// [d g_in (F) | d b_in (F) | d W1 (dff x F) | d b1 (dff) | d W2 (d x dff) | d b2 (d)]
+struct SrBwdEmbedArgs {
+  int R, d, dff, F, ntiles;
+  int64_t T;
+  int64_t dy;                       // workspace: d x_0 [T, d] in
+  int64_t h0, xg, mean, rstd;       // saved: h0, the gathered feature rows and their statistics
+  int64_t g_in, b_in;               // parameters
+  int64_t gt2, gt1;                 // HALVES: fragment copies of W2^T (out dff, contraction d) and W1^T (out F, contraction dff)
+  int64_t part, part_stride;
+  int p0, p1, p2, os;
+};
 // rows per tile / tiles / workgroups / LDS bytes for T rows on `cus` compute units; false: T too small or too large
 bool sr_bwd_geometry(int64_t T, int cus, int* R, int* ntiles, int* nwg);
 int sr_bwd_ffn_launch(SrBwdFfnArgs a, int nwg, const float* params, const _Float16* planes, const float* sv, float* ws, hipStream_t st);
 int sr_bwd_head_launch(SrBwdHeadArgs a, int nwg, const float* params, const _Float16* planes, const float* sv, const float* dscores, float* ws,
                        hipStream_t st);
+int sr_bwd_embed_launch(SrBwdEmbedArgs a, int nwg, const float* params, const _Float16* planes, const float* sv, float* ws, hipStream_t st);
 int sr_bwd_proj_launch(SrBwdProjArgs a, int nwg, const float* params, const _Float16* planes, const float* sv, float* ws, hipStream_t st);

@@ -615,6 +615,286 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   }
 }
 
+// sr_bwd_embed_kernel: the embedding FFN's and the input LayerNorm's backward (SetRank.py:134-135, 146 backwards):
+//   x_0 = h0 W2^T + b2,  h0 = relu(xn0 W1^T + b1),  xn0 = LN_in(xg) = xh g_in + b_in
+//   d W2 += d x_0^T h0,  d b2 = sum d x_0,  d h0 = (d x_0 W2) o [h0 > 0],  d b1 = sum d h0,
+//   d W1 = d h0^T xn0 = (d h0^T xh) diag(g_in) + d b1 (x) b_in   (xh is what LDS holds: the scale and the rank-one term are applied to the
+//                                                                   workgroup's partial - both are linear in the rows),
+//   d xn0 = d h0 W1,  d g_in = sum d xn0 o xh,  d b_in = sum d xn0          (no gradient flows into the features)
+// (was: two thin weight-gradient launches, two dgrad GEMMs and a column-sum launch: d h0 and d xn0 written and re-read, d x_0 read
+// three times - 0.65 GB; here d x_0, h0 and xg are read once, 0.22 GB, and nothing but the partials is written).
+// Partial per workgroup, in the parameter vector's order: [d g_in (F) | d b_in (F) | d W1 (dff x F) | d b1 (dff) | d W2 (d x dff) | d b2 (d)].
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void sr_bwd_embed_kernel(SrBwdEmbedArgs a, const float* __restrict__ params,
+                                                                                               const _Float16* __restrict__ planes,
+                                                                                               const float* __restrict__ sv, float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int d = SR_BWD_D, dff = SR_BWD_DFF, ld = d + 8, ldf = dff + 8;
+  const int R = a.R, F = a.F;
+  float* P0 = smem + a.p0;  // planes of d x_0 -> planes of d h0
+  float* P1 = smem + a.p1;  // fp32 rows of d x_0 -> fp32 rows of xh
+  float* P2 = smem + a.p2;  // fp32 rows of h0 -> d h0 before the mask -> d h0
+  float* OS = smem + a.os;  // [64] row scales of d x_0, [64] of d h0
+  const int tid = threadIdx.x, lane_id = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 cb2 = z4, cb1 = z4;
+  float cgi[2] = {0.f, 0.f}, cbi[2] = {0.f, 0.f};
+  f32x4 accW2[4][2], accW1[4][2];
+#pragma unroll
+  for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) accW2[ta][tb] = accW1[ta][tb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int mblk = wave >> 1, nhalf = wave & 1;
+  const int nchF = (F + 31) >> 5;
+  float4 xr[8];
+  auto request = [&](int tile) {
+    const int64_t n0 = (int64_t)tile * R;
+    const int vr = tile < a.ntiles ? (int)((a.T - n0) < R ? (a.T - n0) : R) : 0;
+    const Src xs = make_src(ws + a.dy + (tile < a.ntiles ? n0 : 0) * d, (int64_t)vr * d);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xr[k] = buf_ld4s(xs, (unsigned)lane_id * 16u, (unsigned)((wave + NW * k) * d) * 4u);
+  };
+  request(blockIdx.x);
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int64_t n0 = (int64_t)tile * R;
+    const int vr = (int)((a.T - n0) < R ? (a.T - n0) : R);
+    int lane = lane_id;
+    asm volatile("" : "+v"(lane));
+    // ---- row phase: d x_0 to LDS (fp32 rows + plane pair), h0 to LDS ------------------------------------------------------------------
+    unsigned hmask = 0;
+    {
+      float4 hv[2];
+      load_frows(hv, wave, lane, sv + a.h0, n0, vr);
+      float am[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        am[k] = max4(xr[k]);
+        cb2.x += xr[k].x; cb2.y += xr[k].y; cb2.z += xr[k].z; cb2.w += xr[k].w;
+      }
+      wave_max_n<8>(am);
+      _Float16* AH = reinterpret_cast<_Float16*>(P0);
+      _Float16* AL = AH + (R + 1) * ld;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int r = wave + NW * k, rc = r < R ? r : R;
+        float sc, inv;
+        fb_h3_scale(am[k], sc, inv);
+        fbh4 hi, lo;
+        fb_h3_split4(xr[k], sc, hi, lo);
+        *reinterpret_cast<fbh4*>(AH + rc * ld + 4 * lane) = hi;
+        *reinterpret_cast<fbh4*>(AL + rc * ld + 4 * lane) = lo;
+        if (lane == 0) OS[r] = inv * (1.0f / ULTR_H3_WSCALE);
+        st4(P1 + rc * ld + 4 * lane, xr[k]);
+      }
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+        const int row = 4 * (wave + NW * q2) + (lane >> 4), rc = row < R ? row : R;
+        st4(P2 + rc * ldf + 4 * (lane & 15), hv[q2]);
+        hmask |= ((hv[q2].x > 0.f ? 1u : 0u) | (hv[q2].y > 0.f ? 2u : 0u) | (hv[q2].z > 0.f ? 4u : 0u) | (hv[q2].w > 0.f ? 8u : 0u)) << (4 * q2);
+      }
+    }
+    lds_barrier();
+    // ---- d h0 = d x_0 W2 (before the mask); the next tile's rows requested; d W2 += d x_0^T h0 ----------------------------------------
+    f32x4 accf[1][2] = {{(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}}};
+    const int rt = wave >> 1, chf = wave & 1;
+    {
+      const int i = lane & 15, q = lane >> 4;
+      const _Float16* AH = reinterpret_cast<const _Float16*>(P0);
+      const int rowi = 16 * rt + i;
+      const _Float16* pa[1] = {AH + (rowi < R ? rowi : R) * ld + 8 * q};
+      const Src Wh = make_src(reinterpret_cast<const float*>(planes + a.gt2), (int64_t)d * dff);
+      PipeH3W<1, 2> ph;
+      ph.begin(Wh, chf, d >> 5, 0, d >> 5, true, lane);
+      ph.run(pa, (R + 1) * ld, Wh, d >> 5, accf);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // the feature rows of THIS tile: they travel while the weight gradient runs
+    float4 xg[8];
+    {
+      const Src gs = make_src(sv + a.xg + n0 * F, (int64_t)vr * F);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) xg[k] = buf_ld4s(gs, 4 * lane < F ? (unsigned)lane * 16u : ULTR_OOB, (unsigned)((wave + NW * k) * F) * 4u);
+    }
+    const Src ms = make_src(sv + a.mean + n0, vr), rs = make_src(sv + a.rstd + n0, vr);
+    const float mv = buf_ld1(ms, lane < 8 ? (unsigned)(wave + NW * lane) * 4u : ULTR_OOB);
+    const float rv = buf_ld1(rs, lane < 8 ? (unsigned)(wave + NW * lane) * 4u : ULTR_OOB);
+    {
+      const int i = lane & 15, q = lane >> 4;
+      const float* pa = P1 + q * ld + 64 * mblk + 4 * i;
+      const float* pb = P2 + q * ldf + 32 * nhalf + 2 * i;
+      const int nk = R >> 2;
+      float4 av = ld4(pa);
+      float2 bv = ld2(pb);
+      for (int kk = 0; kk < nk; ++kk) {
+        const int kn = kk + 1 < nk ? kk + 1 : kk;
+        const float4 an = ld4(pa + 4 * kn * ld);
+        const float2 bn = ld2(pb + 4 * kn * ldf);
+        const float aa[4] = {av.x, av.y, av.z, av.w};
+        const float bb[2] = {bv.x, bv.y};
+#pragma unroll
+        for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+          for (int tb = 0; tb < 2; ++tb) accW2[ta][tb] = mfma16(aa[ta], bb[tb], accW2[ta][tb]);
+        av = an;
+        bv = bn;
+      }
+    }
+    lds_barrier();  // d x_0 (fp32) and h0 have been read
+    {
+      const int i = lane & 15, q = lane >> 4;
+      const float4 o4 = ld4(OS + 16 * rt + 4 * q);
+      const float o[4] = {o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * rt + 4 * q + r, rc = row < R ? row : R;
+        *reinterpret_cast<float2*>(P2 + rc * ldf + 32 * chf + 2 * i) = make_float2(accf[0][0][r] * o[r], accf[0][1][r] * o[r]);
+      }
+      // xh = (xg - mean) rstd into P1 (columns past F keep d x_0's values: finite, never stored)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int r = wave + NW * k, rc = r < R ? r : R;
+        const float m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mv), k));
+        const float rr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv), k));
+        if (4 * lane < F) st4(P1 + rc * ld + 4 * lane, make_float4((xg[k].x - m) * rr, (xg[k].y - m) * rr, (xg[k].z - m) * rr, (xg[k].w - m) * rr));
+      }
+    }
+    lds_barrier();
+    // ---- the ReLU mask: d h0 back to its fp32 rows, its plane pair over d x_0's ----------------------------------------------------------
+    {
+      _Float16* FH = reinterpret_cast<_Float16*>(P0);
+      _Float16* FL = FH + (R + 1) * ldf;
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+        const int row = 4 * (wave + NW * q2) + (lane >> 4), rc = row < R ? row : R;
+        float4 v = ld4(P2 + rc * ldf + 4 * (lane & 15));
+        const unsigned mk = hmask >> (4 * q2);
+        v.x = (mk & 1u) ? v.x : 0.f;
+        v.y = (mk & 2u) ? v.y : 0.f;
+        v.z = (mk & 4u) ? v.z : 0.f;
+        v.w = (mk & 8u) ? v.w : 0.f;
+        st4(P2 + rc * ldf + 4 * (lane & 15), v);
+        cb1.x += v.x; cb1.y += v.y; cb1.z += v.z; cb1.w += v.w;
+        const float am = row16_max(max4(v));
+        float sc, inv;
+        fb_h3_scale(am, sc, inv);
+        fbh4 hi, lo;
+        fb_h3_split4(v, sc, hi, lo);
+        *reinterpret_cast<fbh4*>(FH + rc * ldf + 4 * (lane & 15)) = hi;
+        *reinterpret_cast<fbh4*>(FL + rc * ldf + 4 * (lane & 15)) = lo;
+        if ((lane & 15) == 0) OS[64 + row] = inv * (1.0f / ULTR_H3_WSCALE);
+      }
+    }
+    lds_barrier();
+    // ---- d xn0 = d h0 W1, folded on the spot into d g_in / d b_in; the NEXT tile's rows are requested; d W1' += d h0^T xh ---------------
+    {
+      const int ch = wave;
+      const bool has = ch < nchF;
+      const int i = lane & 15, q = lane >> 4;
+      const _Float16* AH = reinterpret_cast<const _Float16*>(P0);
+      const int lo_off = (R + 1) * ldf;
+      const _Float16* pa[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int row = 16 * t + i;
+        pa[t] = AH + (row < R ? row : R) * ldf + 8 * q;
+      }
+      const Src Wh = make_src(reinterpret_cast<const float*>(planes + a.gt1), (int64_t)dff * 32 * nchF);
+      PipeH3W<4, 2> ph;
+      ph.begin(Wh, ch, dff >> 5, 0, dff >> 5, has, lane);
+      f32x4 acc[4][2];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) acc[t][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      ph.run(pa, lo_off, Wh, has ? (dff >> 5) : 0, acc);
+      const int col = 32 * ch + 2 * i;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float4 o4 = ld4(OS + 64 + 16 * t + 4 * q);
+        const float o[4] = {o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * t + 4 * q + r;
+          const float2 xh = ld2(P1 + (row < R ? row : R) * ld + col);
+          const float y0 = row < vr ? acc[t][0][r] * o[r] : 0.f, y1 = row < vr ? acc[t][1][r] * o[r] : 0.f;
+          cgi[0] = fmaf(y0, xh.x, cgi[0]);
+          cgi[1] = fmaf(y1, xh.y, cgi[1]);
+          cbi[0] += y0;
+          cbi[1] += y1;
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    request(tile + (int)gridDim.x);
+    __builtin_amdgcn_sched_barrier(0);
+    wgrad_thin_wide(accW1, P2, P1, R, wave, lane);
+    lds_barrier();
+  }
+  // ---- the workgroup's partial -----------------------------------------------------------------------------------------------------------
+  float* pw = ws + a.part + (int64_t)blockIdx.x * a.part_stride;
+  const int oW1 = 2 * F, oB1 = oW1 + dff * F, oW2 = oB1 + dff, oB2 = oW2 + d * dff;
+  {
+    const int i = lane_id & 15, q = lane_id >> 4;
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 64 * mblk + 4 * (4 * q + r) + ta;
+        *reinterpret_cast<float2*>(pw + oW2 + m * dff + 32 * nhalf + 2 * i) = make_float2(accW2[ta][0][r], accW2[ta][1][r]);
+      }
+  }
+  // column sums through LDS: [8 waves][d] d b2 | [32][dff] d b1 | [8 waves][4 q][2 x 32] d g_in, d b_in
+  float* sB2 = smem;
+  float* sB1 = sB2 + NW * d;
+  float* sGI = sB1 + 4 * NW * dff;
+  float* sFin = sGI + NW * 4 * 64;  // [dff] d b1 of the workgroup, [2][256] d g_in | d b_in
+  st4(sB2 + wave * d + 4 * lane_id, cb2);
+  st4(sB1 + (wave * 4 + (lane_id >> 4)) * dff + 4 * (lane_id & 15), cb1);
+  {
+    const int i = lane_id & 15, q = lane_id >> 4;
+    float* g = sGI + (wave * 4 + q) * 64;
+    *reinterpret_cast<float2*>(g + 2 * i) = make_float2(cgi[0], cgi[1]);
+    *reinterpret_cast<float2*>(g + 32 + 2 * i) = make_float2(cbi[0], cbi[1]);
+  }
+  lds_barrier();
+  for (int e = tid; e < d; e += NT) {
+    float t = sB2[e];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) t += sB2[w * d + e];
+    pw[oB2 + e] = t;
+  }
+  if (tid < dff) {
+    float t = sB1[tid];
+#pragma unroll
+    for (int k = 1; k < 4 * NW; ++k) t += sB1[k * dff + tid];
+    pw[oB1 + tid] = t;
+    sFin[tid] = t;
+  }
+  {
+    // thread = (which: 0 g_in / 1 b_in, column c = 32 wave' + j): sum over the four row groups q in order
+    const int which = tid >> 8, c = tid & 255, wv = c >> 5, j = c & 31;
+    const float* g = sGI + wv * 4 * 64 + 32 * which + j;
+    const float t = ((g[0] + g[64]) + g[128]) + g[192];
+    if (c < F) pw[which * F + c] = t;
+  }
+  lds_barrier();
+  {
+    // d W1 = g_in[c] S[m][c] + b_in[c] d b1[m]
+    const int i = lane_id & 15, q = lane_id >> 4;
+    const int c = 32 * wave + 2 * i;
+    if (c < F) {
+      const float g0 = params[a.g_in + c], g1 = params[a.g_in + c + 1], b0 = params[a.b_in + c], b1 = params[a.b_in + c + 1];
+#pragma unroll
+      for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = 4 * (4 * q + r) + ta;
+          const float db = sFin[m];
+          *reinterpret_cast<float2*>(pw + oW1 + m * F + c) = make_float2(fmaf(g0, accW1[ta][0][r], b0 * db), fmaf(g1, accW1[ta][1][r], b1 * db));
+        }
+    }
+  }
+}
+
 size_t tile_lds_floats(int R) {
   const size_t tile = (size_t)(R + 1) * (2 * (SR_BWD_D + 8) + (SR_BWD_DFF + 8)) + 128 + 2 * SR_BWD_D;
   const size_t tail = (size_t)NW * 3 * SR_BWD_D + (size_t)4 * NW * SR_BWD_DFF;
@@ -687,5 +967,23 @@ int sr_bwd_head_launch(SrBwdHeadArgs a, int nwg, const float* params, const _Flo
   const int rc = set_lds(sr_bwd_head_kernel, lds);
   if (rc != 0) return rc;
   hipLaunchKernelGGL(sr_bwd_head_kernel, dim3(nwg), dim3(NT), lds, st, a, params, planes, sv, dscores, ws);
+  return (int)hipGetLastError();
+}
+
+int sr_bwd_embed_launch(SrBwdEmbedArgs a, int nwg, const float* params, const _Float16* planes, const float* sv, float* ws, hipStream_t st) {
+  if (a.d != SR_BWD_D || a.dff != SR_BWD_DFF || a.R < 4 || a.R > 64 || (a.R & 3) || nwg <= 0 || nwg > SR_BWD_MAXWG || a.F < 4 || a.F > SR_BWD_D ||
+      (a.F & 3))
+    return ULTR_E_UNSUPPORTED;
+  a.p0 = 0;
+  a.p1 = (a.R + 1) * (SR_BWD_D + 8);
+  a.p2 = 2 * a.p1;
+  a.os = a.p2 + (a.R + 1) * (SR_BWD_DFF + 8);
+  size_t fl = (size_t)a.os + 128;
+  const size_t tail = (size_t)NW * SR_BWD_D + (size_t)4 * NW * SR_BWD_DFF + (size_t)NW * 4 * 64 + SR_BWD_DFF + 8;
+  if (fl < tail) fl = tail;
+  const size_t lds = fl * sizeof(float);
+  const int rc = set_lds(sr_bwd_embed_kernel, lds);
+  if (rc != 0) return rc;
+  hipLaunchKernelGGL(sr_bwd_embed_kernel, dim3(nwg), dim3(NT), lds, st, a, params, planes, sv, ws);
   return (int)hipGetLastError();
 }
