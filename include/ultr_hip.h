@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ULTR_ABI_VERSION 6
+#define ULTR_ABI_VERSION 7
 #define ULTR_MAX_HIDDEN 7 /* hidden layers; Linear layers = hidden + 1 <= 8 */
 
 #define ULTR_E_BADARG (-1)
@@ -346,6 +346,14 @@ int ultr_train_step(const ultr_step_args* a, void* stream);
 int ultr_ndcg(const float* scores, const float* labels, const int32_t* docids, int64_t n_docs, int32_t batch,
               int32_t list_size, const int32_t* topn, int32_t n_topn, float* ndcg_out, int32_t* order_out,
               float* masked_out, float* ndcg_ws, void* stream);
+/* ABI 7: the same as ONE launch with the result in host-mapped memory.  The wave that finishes last (a device counter the caller
+ * provides zeroed once: 4 bytes, reset by every launch) sums the per-list values in ultr_ndcg's order (identical bits), writes
+ * ndcg_out and - host_report != NULL: a pinned, device-mapped page of >= 17 floats - host_report[0 .. n_topn) followed by the word
+ * host_report[16] = seq.  The host then reads a validation batch's metrics by spinning on that word instead of a stream
+ * synchronisation + device-to-host copy (the reference's `.item()` per metric, ipw_rank.py:204-210: 18 us per batch at config 2). */
+int ultr_ndcg_report(const float* scores, const float* labels, const int32_t* docids, int64_t n_docs, int32_t batch,
+                     int32_t list_size, const int32_t* topn, int32_t n_topn, float* ndcg_out, int32_t* order_out,
+                     float* masked_out, float* ndcg_ws, uint32_t* counter, float* host_report, uint32_t seq, void* stream);
 
 /* ---- next row: device-side click simulation + batch assembly -------------------
  * Counterpart of ClickSimulationFeed.get_batch (click_simulation_feed.py:70-174) + PositionBiasedModel
@@ -366,6 +374,27 @@ int ultr_click_batch(const int32_t* lists, const float* labels, int64_t n_querie
                      const float* exam_prob, int32_t n_exam, const float* click_prob, int32_t n_rel, int32_t click_model,
                      uint64_t seed, uint64_t step, int32_t batch, int32_t list_size, int32_t max_tries, int32_t* docids,
                      float* clicks, int32_t* query_idx, void* stream);
+/* ABI 7: the same call from a cached argument block (the host fills it once per feed and only advances `step`), and ONE host call
+ * for what `train(input_feed)` of a plugin algorithm does with a DeviceClickFeed batch: the step on the batch that is already
+ * drawn (exactly ultr_train_step(a, stream)) and, behind it on the same stream, the draw of the NEXT batch into the feed's other
+ * buffer (`next` may be NULL) - the draw depends on (seed, step) only, so it runs under the step's reduction / update while the host
+ * is still reading this step's loss (reference: main.py:153-156 get_batch + train per step; click_simulation_feed.py:101-174).
+ * ULTR_CLICK_UBM needs n_exam >= 2 (its table is rank x distance); ULTR_E_BADARG otherwise. */
+typedef struct ultr_click_args {
+  const int32_t* lists;
+  const float* labels;
+  int64_t n_queries, n_docs;
+  const float* exam_prob;
+  const float* click_prob;
+  int32_t lmax, n_exam, n_rel, click_model;
+  uint64_t seed, step;
+  int32_t batch, list_size, max_tries, pad_;
+  int32_t* docids;
+  float* clicks;
+  int32_t* query_idx;
+} ultr_click_args;
+int ultr_click_batch_args(const ultr_click_args* c, void* stream);
+int ultr_feed_train_step(const ultr_step_args* a, const ultr_click_args* next, void* stream);
 
 /* ---- e: data-parallel gradient exchange over xGMI -----------------------------
  * No reference counterpart: the reference is single-process.  One process per GPU; queries shard across ranks,

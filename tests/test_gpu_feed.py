@@ -193,3 +193,67 @@ def test_user_browsing_model_on_the_device():
         return out / c.shape[1]
 
     close(gap_hist(dev_clicks), gap_hist(host_clicks), "gap between the first two clicks")
+
+
+def test_batches_drawn_ahead_are_the_batches_drawn_on_the_spot():
+    """Round 6: a plugin algorithm's train(feed) draws the feed's NEXT batch behind its own step (ultr_feed_train_step,
+    DeviceClickFeed.next_click_args); a batch is a pure function of (seed, batch counter), so the sequence of batches must be the
+    one a feed hands out when nobody draws ahead - including across a change of get_batch's arguments and a second dataset."""
+    from ultra_pytorch_amd.input_layer import DeviceClickFeed
+    from ultra_pytorch_amd.utils import find_class
+    F, L, B = 16, 10, 64
+    ds, ds2 = DS(200, (10, 10), F, seed=3), DS(150, (10, 10), F, seed=4)
+    ds.pad(L)
+    ds2.pad(L)
+    exp = {"learning_algorithm": "ultra_pytorch_amd.learning_algorithm.IPWrank", "learning_algorithm_hparams": "",
+           "ranking_model": "ultra_pytorch_amd.ranking_model.DNN", "ranking_model_hparams": "hidden_layer_sizes=[32,16]",
+           "max_candidate_num": L, "selection_bias_cutoff": L, "metrics": ["ndcg"], "metrics_topn": [1, 3, 5, 10]}
+    algo = find_class(exp["learning_algorithm"])(ds, exp)
+    plan = [(ds, True), (ds, True), (ds, True), (ds, False), (ds2, True), (ds2, True), (ds, True)]
+
+    def sequence(train):
+        feed = DeviceClickFeed(algo, B, "", seed=11)
+        out = []
+        for data, check in plan:
+            f, info = feed.get_batch(data, check_validation=check)
+            out.append((f["docids"].cpu().numpy().copy(), f["labels"].cpu().numpy().copy(), info["rank_list_idxs"].cpu().numpy().copy()))
+            if train:
+                loss, _, _ = algo.train(f)
+                assert np.isfinite(loss)
+                # the step consumed THIS batch: its tensors are untouched by the draw of the next one (the other buffer)
+                np.testing.assert_array_equal(f["docids"].cpu().numpy(), out[-1][0])
+                np.testing.assert_array_equal(f["labels"].cpu().numpy(), out[-1][1])
+        return out
+
+    ahead, spot = sequence(True), sequence(False)
+    for k, (a, b) in enumerate(zip(ahead, spot)):
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y, err_msg="batch %d" % k)
+
+
+def test_ndcg_report_in_host_mapped_memory_equals_the_two_launch_form():
+    """ultr_ndcg_report (one launch, batch means by the last wave, values + sequence word in host-mapped memory) against ultr_ndcg
+    (per-list launch + mean launch): identical bits, permutation and masked scores included; repeated launches reuse the counter."""
+    from ultra_pytorch_amd import engine, hip_ops, synthetic
+    from ultra_pytorch_amd.ranking_model import init_flat_params
+    for B, L, F in ((256, 10, 136), (37, 100, 24), (5, 3, 8)):
+        shape = hip_ops.DnnShape(F, [32, 16], "elu")
+        rng = np.random.RandomState(B)
+        p = init_flat_params(shape, 1).cuda()
+        ev = engine.EvalEngine(shape, B, L, torch.device("cuda"))
+        for rep in range(3):
+            feats, ids, y = synthetic.make_batch(rng, B, L, F, clicks=False, n_pad=min(3, L - 1))
+            f, i_, y_ = torch.tensor(feats).cuda(), torch.tensor(ids).cuda(), torch.tensor(y).cuda()
+            ev.run(p, f, feats.shape[0], i_, y_)
+            got = ev.read_ndcg()
+            dev_vals = ev.ndcg.cpu().numpy()
+            order, masked = ev.order.cpu().numpy().copy(), ev.masked.cpu().numpy().copy()
+            ref = torch.zeros(4, device="cuda")
+            ws = torch.zeros(B * 4, device="cuda")
+            o2 = torch.zeros(B, L, dtype=torch.int32, device="cuda")
+            m2 = torch.zeros(B, L, device="cuda")
+            hip_ops.ndcg(ev.scores, y_, i_, feats.shape[0], B, L, [1, 3, 5, 10], ref, ws, order_out=o2, masked_out=m2)
+            np.testing.assert_array_equal(got, ref.cpu().numpy())
+            np.testing.assert_array_equal(dev_vals, got)
+            np.testing.assert_array_equal(order, o2.cpu().numpy())
+            np.testing.assert_array_equal(masked, m2.cpu().numpy())

@@ -25,6 +25,7 @@ class DnnDesc(ctypes.Structure):
 
 
 MODEL_FP32_PRODUCTS = 1  # ultr_dnn_desc / ultr_setrank_desc ::flags (include/ultr_hip.h, ABI 6)
+ABI_VERSION = 7          # include/ultr_hip.h: ULTR_ABI_VERSION - load() refuses a library that reports another one
 
 
 class UpdateDesc(ctypes.Structure):
@@ -33,6 +34,13 @@ class UpdateDesc(ctypes.Structure):
                 ("ranker_loss_weight", c_f32), ("propensity_learning_rate", c_f32), ("em_step_size", c_f32),
                 ("regulation_p", c_f32), ("l2_loss", c_f32), ("guard", c_vp), ("host_scalars", c_vp),
                 ("seq", ctypes.c_uint32), ("pad_", ctypes.c_uint32), ("range_flag", c_vp)]
+
+
+class ClickArgs(ctypes.Structure):  # ultr_click_args (ABI 7)
+    _fields_ = [("lists", c_vp), ("labels", c_vp), ("n_queries", c_i64), ("n_docs", c_i64), ("exam_prob", c_vp), ("click_prob", c_vp),
+                ("lmax", c_i32), ("n_exam", c_i32), ("n_rel", c_i32), ("click_model", c_i32), ("seed", ctypes.c_uint64),
+                ("step", ctypes.c_uint64), ("batch", c_i32), ("list_size", c_i32), ("max_tries", c_i32), ("pad_", c_i32),
+                ("docids", c_vp), ("clicks", c_vp), ("query_idx", c_vp)]
 
 
 class SetRankDesc(ctypes.Structure):
@@ -88,6 +96,8 @@ SIGNATURES = {
     "ultr_train_step": (c_i32, [ctypes.POINTER(StepArgs), c_vp]),
     "ultr_click_batch": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_i32, c_i32, ctypes.c_uint64, ctypes.c_uint64,
                                  c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "ultr_click_batch_args": (c_i32, [c_vp, c_vp]),
+    "ultr_feed_train_step": (c_i32, [c_vp, c_vp, c_vp]),
     "ultr_comm_create": (c_i32, [c_i32, c_i32, c_i64, ctypes.POINTER(c_vp)]),
     "ultr_comm_export": (c_i32, [c_vp, c_vp]),
     "ultr_comm_import": (c_i32, [c_vp, c_i32, c_vp]),
@@ -99,6 +109,8 @@ SIGNATURES = {
     "ultr_prof_set_stride": (c_i32, [c_i32]),
     "ultr_prof_collect": (c_i32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
     "ultr_ndcg": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, ctypes.POINTER(c_i32), c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "ultr_ndcg_report": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, ctypes.POINTER(c_i32), c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                 ctypes.c_uint32, c_vp]),
 }
 
 _LIB = None
@@ -123,6 +135,11 @@ def load(path=None):
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
+    got = int(lib.ultr_abi_version())
+    if got != ABI_VERSION:
+        # a stale or experimental build (ULTR_HIP_LIB) that happens to export every symbol would be called with shifted arguments
+        raise RuntimeError("%s reports ABI %d, this binding is written for ABI %d: rebuild the library "
+                           "(python -c 'import __graft_entry__ as g; g.build()')" % (p, got, ABI_VERSION))
     if path is None:
         _LIB = lib
     return lib

@@ -19,13 +19,23 @@ struct TopN {
   int n;
   int v[NDCG_MAX_TOPN];
 };
+// ultr_ndcg_report: the batch mean inside the SAME launch - the workgroup that arrives last at `counter` sums the per-list values in
+// the order ndcg_mean_kernel uses (same bits), writes ndcg_out and, when host != NULL, the values + the sequence number into
+// host-mapped memory (what the training step's report does for the loss: the host spins on one word instead of a stream
+// synchronisation + device-to-host copy).  counter == NULL: per-list values only (ultr_ndcg's second launch follows).
+struct NdcgTail {
+  uint32_t* counter;
+  float* out;
+  float* host;
+  uint32_t seq;
+};
 
 __global__ __launch_bounds__(NDCG_LPW * 64) void ndcg_list_kernel(const float* __restrict__ scores,
                                                                  const float* __restrict__ labels,
                                                                  const int32_t* __restrict__ docids, int64_t n_docs,
                                                                  int B, int L, TopN topn, float* __restrict__ per_list,
                                                                  int32_t* __restrict__ order_out,
-                                                                 float* __restrict__ masked_out) {
+                                                                 float* __restrict__ masked_out, NdcgTail tail) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sm_s = smem;                 // [LPW][L] masked + validated predictions
   float* sm_y = sm_s + NDCG_LPW * L;  // [LPW][L] validated labels
@@ -82,7 +92,35 @@ __global__ __launch_bounds__(NDCG_LPW * 64) void ndcg_list_kernel(const float* _
     }
     d = wave_sum(d);
     id = wave_sum(id);
-    if (lane == 0) per_list[(int64_t)b * topn.n + k] = (id == 0.f) ? 0.f : d / id;  // _safe_div
+    if (lane == 0) {
+      const float v = (id == 0.f) ? 0.f : d / id;  // _safe_div
+      if (tail.counter != nullptr) coh_st1(make_src(per_list, (int64_t)B * topn.n), (unsigned)(((int64_t)b * topn.n + k) * 4), v);  // written through
+      else per_list[(int64_t)b * topn.n + k] = v;
+    }
+  }
+  if (tail.counter == nullptr) return;
+  // ---- the last wave to arrive forms the batch means (every wave: stores acknowledged, then one relaxed agent-scope increment) ----
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  unsigned old = 0;
+  if (lane == 0) old = __hip_atomic_fetch_add(tail.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+  if (old != (unsigned)B - 1u) return;
+  const Src pl = make_src(per_list, (int64_t)B * topn.n);
+  float vals[NDCG_MAX_TOPN];
+  for (int k = 0; k < topn.n; ++k) {
+    float s = 0.f;
+    for (int bb = lane; bb < B; bb += 64) s += coh_ld1(pl, (unsigned)(((int64_t)bb * topn.n + k) * 4));  // served from the coherence point
+    s = wave_sum(s);
+    vals[k] = s / (float)B;
+  }
+  if (lane == 0) {
+    for (int k = 0; k < topn.n; ++k) tail.out[k] = vals[k];
+    __hip_atomic_store(tail.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch on this stream
+    if (tail.host != nullptr) {
+      for (int k = 0; k < topn.n; ++k) __hip_atomic_store(tail.host + k, vals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(reinterpret_cast<uint32_t*>(tail.host) + NDCG_MAX_TOPN, tail.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -113,11 +151,33 @@ extern "C" int ultr_ndcg(const float* scores, const float* labels, const int32_t
   {
     UltrProfScope prof(ULTR_K_NDCG, st);
     ULTR_LAUNCH(prof, ndcg_list_kernel, dim3((batch + NDCG_LPW - 1) / NDCG_LPW), dim3(NDCG_LPW * 64), lds, st, scores, labels, docids,
-                n_docs, (int)batch, (int)list_size, t, ndcg_ws, order_out, masked_out);
+                n_docs, (int)batch, (int)list_size, t, ndcg_ws, order_out, masked_out, NdcgTail{nullptr, nullptr, nullptr, 0u});
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(ndcg_mean_kernel, dim3(n_topn), dim3(64), 0, st, (const float*)ndcg_ws, (int)batch, (int)n_topn,
                      ndcg_out);
+  return (int)hipGetLastError();
+}
+
+// ONE launch: per-list NDCG, batch means by the last wave to finish, optional report into host-mapped memory (include/ultr_hip.h)
+extern "C" int ultr_ndcg_report(const float* scores, const float* labels, const int32_t* docids, int64_t n_docs, int32_t batch,
+                                int32_t list_size, const int32_t* topn, int32_t n_topn, float* ndcg_out, int32_t* order_out,
+                                float* masked_out, float* ndcg_ws, uint32_t* counter, float* host_report, uint32_t seq, void* stream) {
+  if (!scores || !labels || !topn || !ndcg_out || !ndcg_ws || !counter || batch <= 0 || list_size <= 0 || n_topn <= 0 ||
+      n_topn > NDCG_MAX_TOPN)
+    return ULTR_E_BADARG;
+  TopN t;
+  t.n = n_topn;
+  for (int k = 0; k < n_topn; ++k) {
+    if (topn[k] <= 0) return ULTR_E_BADARG;
+    t.v[k] = topn[k];
+  }
+  const size_t lds = (size_t)NDCG_LPW * 4 * list_size * sizeof(float);
+  if (lds > 64 * 1024) return ULTR_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  UltrProfScope prof(ULTR_K_NDCG, st);
+  ULTR_LAUNCH(prof, ndcg_list_kernel, dim3((batch + NDCG_LPW - 1) / NDCG_LPW), dim3(NDCG_LPW * 64), lds, st, scores, labels, docids,
+              n_docs, (int)batch, (int)list_size, t, ndcg_ws, order_out, masked_out, NdcgTail{counter, ndcg_out, host_report, seq});
   return (int)hipGetLastError();
 }

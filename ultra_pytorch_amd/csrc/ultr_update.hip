@@ -12,6 +12,7 @@
 #include "../../include/ultr_hip.h"
 #include "ultr_device.h"
 #include "ultr_plan.h"
+#include "ultr_feed.h"
 #include "ultr_prof.h"
 
 __device__ __forceinline__ float block_sum256(float v, float* sm) {
@@ -274,9 +275,15 @@ __global__ __launch_bounds__(256) void update_tiled_kernel(ultr_update_desc u, D
                                                            float* __restrict__ aux, float* __restrict__ wt,
                                                            const float* __restrict__ sumsq_part, int nsq,
                                                            float* __restrict__ scalars_out, int n_tile_blocks,
-                                                           const float* __restrict__ l2_sums, int nsq2) {
+                                                           const float* __restrict__ l2_sums, int nsq2, int rider_first, ultr_click_args rider) {
   __shared__ float sm[4];
   __shared__ float tile[TPW][16][17];
+  // workgroups behind the update's own: the click draw of the NEXT batch (ultr_feed_train_step) - independent of the update, and of
+  // its guard (a feed keeps drawing when a data-parallel step was refused)
+  if ((int)blockIdx.x >= rider_first) {
+    click_draw(rider, (int)blockIdx.x - rider_first);
+    return;
+  }
   if (update_guarded(u)) return;
   const int64_t P = u.n_params;
   const int n_tiles = dp.upd_tile_begin[dp.nl - 1];
@@ -437,14 +444,25 @@ int ultr_apply_update_ex(const ultr_update_desc* u, const ultr_dnn_desc* d, floa
   UltrProfScope prof(ULTR_K_UPDATE, (hipStream_t)stream);
   if (wt != nullptr) {
     const int n_tiles = dp.upd_tile_begin[dp.nl - 1], n_vec = dp.vs_begin[dp.n_vs];
+    // a click draw waiting for a launch to ride on (ultr_feed_train_step): its (batch + 3) / 4 workgroups follow the update's
+    ultr_click_args rider;
+    memset(&rider, 0, sizeof(rider));
+    int rider_blocks = 0;
+    if (g_ultr_click_rider != nullptr) {
+      rider = *g_ultr_click_rider;
+      rider_blocks = (rider.batch + 3) / 4;
+      g_ultr_click_rider = nullptr;
+    }
     if (n_tiles + (n_vec + 255) / 256 < 1536) {  // one unit per workgroup keeps the launch wide (config 2: 401 units, config 3: 940 -
                                                  // four per workgroup left 235 workgroups for 256 CUs: 7.0 -> 9.0 us)
-      ULTR_LAUNCH(prof, update_tiled_kernel<1>, dim3(n_tiles + (n_vec + 255) / 256), dim3(256), 0, (hipStream_t)stream, *u, dp, params, state,
-                  grads, aux, wt, (const float*)bwd_ws, nsq, scalars_out, n_tiles, l2_sums, nsq2);
+      const int own = n_tiles + (n_vec + 255) / 256;
+      ULTR_LAUNCH(prof, update_tiled_kernel<1>, dim3(own + rider_blocks), dim3(256), 0, (hipStream_t)stream, *u, dp, params, state,
+                  grads, aux, wt, (const float*)bwd_ws, nsq, scalars_out, n_tiles, l2_sums, nsq2, own, rider);
     } else {
       const int tb = (n_tiles + 3) / 4;
-      ULTR_LAUNCH(prof, update_tiled_kernel<4>, dim3(tb + (n_vec + 1023) / 1024), dim3(256), 0, (hipStream_t)stream, *u, dp, params, state,
-                  grads, aux, wt, (const float*)bwd_ws, nsq, scalars_out, tb, l2_sums, nsq2);
+      const int own = tb + (n_vec + 1023) / 1024;
+      ULTR_LAUNCH(prof, update_tiled_kernel<4>, dim3(own + rider_blocks), dim3(256), 0, (hipStream_t)stream, *u, dp, params, state,
+                  grads, aux, wt, (const float*)bwd_ws, nsq, scalars_out, tb, l2_sums, nsq2, own, rider);
     }
   } else {
     const int nblk = (int)((u->n_params + 255) / 256);

@@ -104,6 +104,8 @@ class StepEngine:
         u.seq = 0
         self.udesc = u
         self._args = None
+        self._cached = (None,) * 8  # the tensor objects behind the pointer fields of self._args (train_step)
+        self.next_click_source = None  # a DeviceClickFeed (set per step by the plugin algorithm): its next batch is drawn behind the step
 
     def _alloc(self, shape, device):
         self.saved = _f32(shape.saved_bytes(self.N) // 4, device)
@@ -248,17 +250,30 @@ class StepEngine:
             a.skip_update = 1 if (self.pg is not None and self.comm is None) else 0
             a.comm = self.comm.h if self.comm is not None else None
             self._fn = self.shape.lib.ultr_train_step
+            self._fn_feed = self.shape.lib.ultr_feed_train_step
+            self._aref = ctypes.byref(a)
         a.batch_total = self.batch_total  # per step: uneven data-parallel shards may change it (PairDebias' xB factor)
-        a.params = params.data_ptr()
+        # pointer fields are rewritten only when the tensor OBJECT behind them changed (a ctypes field store + data_ptr() is ~0.3 us;
+        # the same parameters / state / feature matrix / table come back every step, only the batch tensors alternate)
+        c = self._cached
+        a.params = params.data_ptr()  # (always: `.data = ...` re-seats a tensor object's storage)
         a.wt = hip_ops.weight_copy(self.shape).get(params).data_ptr()
         a.state = state.data_ptr() if state is not None else None
-        a.aux = aux.data_ptr() if aux is not None else None
-        a.features = features.data_ptr() if n_docs > 0 else None
-        a.n_docs = n_docs
-        a.docids, a.labels = docids.data_ptr(), labels.data_ptr()
-        a.pw = pw.data_ptr() if pw is not None else None
-        a.ipw_table = ipw_table.data_ptr() if ipw_table is not None else None
-        a.n_ipw = int(ipw_table.numel()) if ipw_table is not None else 0
+        if aux is not c[2]:
+            a.aux = aux.data_ptr() if aux is not None else None
+        if features is not c[3] or n_docs != a.n_docs:
+            a.features = features.data_ptr() if n_docs > 0 else None
+            a.n_docs = n_docs
+        if docids is not c[4]:
+            a.docids = docids.data_ptr()
+        if labels is not c[5]:
+            a.labels = labels.data_ptr()
+        if pw is not c[6]:
+            a.pw = pw.data_ptr() if pw is not None else None
+        if ipw_table is not c[7]:
+            a.ipw_table = ipw_table.data_ptr() if ipw_table is not None else None
+            a.n_ipw = int(ipw_table.numel()) if ipw_table is not None else 0
+        self._cached = (params, state, aux, features, docids, labels, pw, ipw_table)
         if self.algo == "regem":
             a.uniforms = uniforms.data_ptr() if uniforms is not None else None
             a.rng_seed, a.rng_step = self.rng_seed, self.rng_step
@@ -267,7 +282,16 @@ class StepEngine:
             a.comm_step = self.comm.step
             self.comm.step += 1
         self._next_seq()
-        _lib.check(self._fn(ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ultr_train_step")
+        src = self.next_click_source
+        nxt = src.next_click_args() if src is not None else None
+        if nxt is not None and a.skip_update == 0:
+            rc = self._fn_feed(self._aref, nxt, hip_ops.raw_stream())
+        else:
+            rc = self._fn(self._aref, hip_ops.raw_stream())
+            if nxt is not None and rc == 0:  # (process-group path: the draw follows the step's first half)
+                rc = self.shape.lib.ultr_click_batch_args(nxt, hip_ops.raw_stream())
+        if rc != 0:
+            _lib.check(rc, "ultr_train_step")
         if self.pg is not None and self.comm is None:
             self.dp_reduce()
             self.update(params, state, aux)
@@ -287,12 +311,42 @@ class EvalEngine:
         self.order = torch.empty(self.B, self.L, dtype=torch.int32, device=device)
         self.ndcg = _f32(len(self.topn), device)
         self.ndcg_ws = _f32(self.B * len(self.topn), device)
+        # the metric vector in HOST-mapped pinned memory + a sequence word (ultr_ndcg_report): read_ndcg() spins on the word instead
+        # of a stream synchronisation + device-to-host copy per validation batch
+        self._counter = torch.zeros(1, dtype=torch.int32, device=device)
+        self._hs = torch.zeros(32, dtype=torch.float32).pin_memory()
+        self._hs_f = self._hs.numpy()
+        self._hs_u = self._hs_f.view(np.uint32)
+        self._seq = 0
+        self._topn_arr = (ctypes.c_int32 * len(self.topn))(*self.topn)
+        self._lib = shape.lib
+
+    def _ndcg(self, labels, docids, n_docs):
+        self._seq = (self._seq % 0xFFFFFFFF) + 1
+        _lib.check(self._lib.ultr_ndcg_report(self.scores.data_ptr(), labels.data_ptr(), docids.data_ptr(), int(n_docs), self.B, self.L,
+                                              self._topn_arr, len(self.topn), self.ndcg.data_ptr(), self.order.data_ptr(),
+                                              self.masked.data_ptr(), self.ndcg_ws.data_ptr(), self._counter.data_ptr(),
+                                              self._hs.data_ptr(), self._seq, hip_ops.raw_stream()), "ultr_ndcg_report")
 
     def run(self, params, features, n_docs, docids, labels):
         hip_ops.dnn_forward(self.shape, params, features, n_docs, docids, self.B, self.L, self.scores, None)
-        hip_ops.ndcg(self.scores, labels, docids, n_docs, self.B, self.L, self.topn, self.ndcg, self.ndcg_ws,
-                     order_out=self.order, masked_out=self.masked)
+        self._ndcg(labels, docids, n_docs)
         return self.scores, self.ndcg
+
+    def read_ndcg(self, timeout_s=60.0):
+        """NDCG@topn of the LAST run() as a numpy array - the reference's `.item()` per metric (ipw_rank.py:204-210) without a stream
+        synchronisation: waits for the launch's report in host-mapped memory."""
+        seq, u, spins, t0 = self._seq, self._hs_u, 0, None
+        if seq == 0:
+            raise RuntimeError("read_ndcg() before the first run()")
+        while int(u[16]) != seq:
+            spins += 1
+            if spins & 0x3FF == 0:
+                now = time.perf_counter()
+                t0 = now if t0 is None else t0
+                if now - t0 > timeout_s:
+                    raise _lib.UltrHipError("no NDCG report from the GPU within %.0f s" % timeout_s)
+        return self._hs_f[:len(self.topn)].copy()
 
 
 def _setrank_draw(list_size):
@@ -342,7 +396,7 @@ class SetRankStepEngine(StepEngine):
                                                ctypes.c_void_p(self.grads.data_ptr()),
                                                ctypes.c_void_p(aux.data_ptr()) if aux is not None else None,
                                                ctypes.c_void_p(self.bwd_ws.data_ptr()), ctypes.c_void_p(self.scalars.data_ptr()),
-                                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ultr_apply_update")
+                                               hip_ops.raw_stream()), "ultr_apply_update")
 
     def train_step(self, params, state, features, n_docs, docids, labels, aux=None, ipw_table=None, pw=None, uniforms=None):
         self._next_seq()
@@ -353,6 +407,10 @@ class SetRankStepEngine(StepEngine):
             self.loss(labels, aux=aux, ipw_table=ipw_table, pw=pw)
         self.backward(params, features, n_docs, docids)
         self.update(params, state, aux)
+        src = self.next_click_source
+        nxt = src.next_click_args() if src is not None else None
+        if nxt is not None:
+            _lib.check(self.shape.lib.ultr_click_batch_args(nxt, hip_ops.raw_stream()), "ultr_click_batch")
         return self.scalars
 
 
@@ -371,6 +429,5 @@ class SetRankEvalEngine(EvalEngine):
             hip_ops.fall_back_to_fp32_products(self.shape, "a SetRank weight of magnitude >= 64 was loaded (the split-half weight planes "
                                                            "cover |w| < 128)")
             hip_ops.setrank_forward(self.shape, params, features, n_docs, docids, self.B, self.L, self.scores, self.saved)
-        hip_ops.ndcg(self.scores, labels, docids, n_docs, self.B, self.L, self.topn, self.ndcg, self.ndcg_ws,
-                     order_out=self.order, masked_out=self.masked)
+        self._ndcg(labels, docids, n_docs)
         return self.scores, self.ndcg

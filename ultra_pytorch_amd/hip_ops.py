@@ -18,8 +18,14 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+def raw_stream():
+    """The current HIP stream's handle as an int: torch's own C getter (what torch.cuda.current_stream().cuda_stream resolves to,
+    without building a Stream object and normalising the device argument: ~3 us -> ~0.3 us per call)."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(raw_stream())
 
 
 def _req(t, dtype, name):

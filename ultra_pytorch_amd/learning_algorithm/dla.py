@@ -59,7 +59,8 @@ class DLA(BaseAlgorithm):
         Adagrad accumulator never persists: state=None selects the stateless update.  max_propensity_weight is
         inert in the reference (clamps .grad of a grad-less tensor, dla.py:303-305) and is ignored here too."""
         self.rank_list_size = self.exp_settings["selection_bias_cutoff"]
-        self.model.train()
+        if not self.model.training:  # (nn.Module.train() walks every submodule: ~10 us a 47 us step does not have)
+            self.model.train()
         self.create_input_feed(input_feed, self.rank_list_size)
         eng = self._train_engine(self.batch_size, self.rank_list_size)
         sc = eng.train_step(self.model.flat_params, None, self.letor_features, self.n_docs, self.docid_inputs,

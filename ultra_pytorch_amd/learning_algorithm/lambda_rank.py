@@ -37,7 +37,8 @@ class LambdaRank(BaseAlgorithm):
         natural-log IDCG, all L^2 pairs incl. the (zero-weight) diagonal (Appendix A.7)."""
         self.rank_list_size = self.exp_settings["selection_bias_cutoff"]
         self.global_step += 1
-        self.model.train()
+        if not self.model.training:  # (nn.Module.train() walks every submodule: ~10 us a 47 us step does not have)
+            self.model.train()
         self.create_input_feed(input_feed, self.rank_list_size)
         eng = self._train_engine(self.batch_size, self.rank_list_size)
         sc = eng.train_step(self.model.flat_params, self.state_sum, self.letor_features, self.n_docs, self.docid_inputs,

@@ -37,7 +37,8 @@ class RegressionEM(BaseAlgorithm):
         """regression_EM.py:108-193: E-step posteriors from the current scores, Bernoulli pseudo-labels, BCE-with-logits
         (mean over B*L), clip + Adagrad, M-step on the propensity with the pre-update scores; global_step is
         incremented AFTER the step (:188)."""
-        self.model.train()
+        if not self.model.training:  # (nn.Module.train() walks every submodule: ~10 us a 47 us step does not have)
+            self.model.train()
         self.create_input_feed(input_feed, self.rank_list_size)
         eng = self._train_engine(self.batch_size, self.rank_list_size)
         sc = eng.train_step(self.model.flat_params, self.state_sum, self.letor_features, self.n_docs, self.docid_inputs,
