@@ -513,10 +513,31 @@ def dtype_label(cfg, attention_dtype="fp32"):
     return s
 
 
-def short_config_run(key, device, lib, steps, warmup):
+FP32_KNOBS = ("ULTR_FB_H3", "ULTR_FWD_H3", "ULTR_BWD_H3", "ULTR_WG_H3", "ULTR_SR_H3", "ULTR_SR_ATTN_H3", "ULTR_SR_WG_H3")
+
+
+def short_config_run(key, device, lib, steps, warmup, fp32=False):
     """One of the OTHER BASELINE configs on the driver's line: a short synced run - `steps` steps, each
-    followed by the host's read of its loss - after `warmup` steps and (DNN) a calibration pass with every kernel timer armed."""
+    followed by the host's read of its loss - after `warmup` steps and (DNN) a calibration pass with every kernel timer armed.
+    fp32=True: the same run with EVERY product on v_mfma_f32_16x16x4_f32 (the split-half knobs off: the reference's arithmetic,
+    DNN.py:43-56) - VERDICT r05 item 3: the strict-fp32 figure of every config on the driver's line."""
     from ultra_pytorch_amd import _lib
+    if fp32:
+        keep = {k: os.environ.get(k) for k in FP32_KNOBS}
+        try:
+            for k in keep:
+                os.environ[k] = "0"
+            rec = short_config_run(key, device, lib, steps, warmup)
+        finally:
+            for k, v in keep.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+            lib.ultr_config_reload()
+        out = {k: rec[k] for k in ("ms_per_step", "queries_per_sec", "step_frac_of_fp32_mfma_peak", "dominant_kernel", "final_loss", "wall_s") if k in rec}
+        out["what"] = " ".join("%s=0" % k for k in FP32_KNOBS) + ": every product on v_mfma_f32_16x16x4_f32"
+        return out
     t_setup = time.perf_counter()
     W = Workload(key, device)
     cfg = W.cfg
@@ -557,10 +578,16 @@ def short_config_run(key, device, lib, steps, warmup):
                                   "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
                                   "frac": ach / (PEAK_FP32_MFMA_TFLOPS if bound == "mfma" else PEAK_HBM_GBS),
                                   "source": "calibration pass of %d steps in front of the timed steps, every kernel timer armed" % ncal}
+        if bound == "mfma":
+            # what the kernel ISSUES against the peak of the pipe it issues on (`frac` prices algorithmic fp32 flops against the fp32 peak)
+            f16_issued, f32_issued = issued_matrix_work(cfg, dom)
+            pipe_s = f16_issued / (PEAK_F16_MFMA_TFLOPS * 1e12) + f32_issued / (PEAK_FP32_MFMA_TFLOPS * 1e12)
+            rec["dominant_kernel"]["frac_of_issued_dtype_peak"] = pipe_s / (1e-6 * kus[dom])
+            rec["dominant_kernel"]["mfma_dtype"] = ("f16 x3 (split hi/lo)" + ("" if f32_issued == 0 else " + f32")) if f16_issued > 0 else "f32"
         rec["kernel_us"] = {KNAMES[k]: round(v, 2) for k, v in kus.items()}
         rec["stage_kernels"] = stage_kernels(lib, cfg)
     else:
-        rec["dominant_kernel"] = {"kernel": "whole step (37 launches, none dominant: profiles/r05_cfg5_pmc.md)", "bound": "mfma",
+        rec["dominant_kernel"] = {"kernel": "whole step (21 launches, none dominant: profiles/r06_cfg5_pmc.md)", "bound": "mfma",
                                   "achieved": rec["step_tflops"], "unit": "TFLOP/s", "frac": rec["step_frac_of_fp32_mfma_peak"]}
     W.eng.close()
     del W
@@ -695,6 +722,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures (plugin API, device feed)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of configs 3 / 4pair / 4lambda / 5 and the eval leg")
+    ap.add_argument("--no-dp-selftest", action="store_true", help="--gpus N > 1: skip the exchange self-test (delayed publishes) in front of the timed region")
+    ap.add_argument("--dp-selftest-steps", type=int, default=1000)
     ap.add_argument("--spinup-ms", type=float, default=None,
                     help="untimed steps for this many ms in front of the W warm-up steps (shader clocks settle; default 300 for config 2)")
     ap.add_argument("--timer-stride", type=int, default=None, help="the dominant kernel is timed on every stride-th step of the timed region")
@@ -829,6 +858,57 @@ def main():
                                          process_group=pg, no_peer_comm=True)
             for i in range(args.warmup):
                 step(i)
+    # ---- data parallel: the exchange protocol under SKEW, before anything is timed: 1 000 steps on private
+    # copies of the replicas, every rank delaying every step by its own 0 - 50 us (a busy-wait kernel in front of the step: the
+    # publish of this rank's vector and its flags arrive that much later than its peers'), then: replicas bit-identical, every
+    # status word zero.  The first run on real peers yields a verdict on the protocol, not just a throughput number.
+    dp_selftest = None
+    if pg is not None and not args.no_dp_selftest:
+        n_self = args.dp_selftest_steps
+        sp, ss = params.clone(), None if state is None else state.clone()
+        sa = None if aux is None else aux.clone()
+        e_self = engs["selftest"] = eng_cls(shape, B, L, device, algo=cfg["algo"], learning_rate=LR, max_gradient_norm=CLIP, process_group=pg,
+                                            no_peer_comm=eng.comm is None)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        torch.cuda._sleep(2000000)
+        ev1.record()
+        torch.cuda.synchronize()
+        cyc_per_us = 2000000.0 / (1e3 * ev0.elapsed_time(ev1))
+        rs = np.random.RandomState(4242 + 7919 * rank)
+        delays = rs.randint(0, 51, size=n_self)
+        err = None
+        barrier()
+        ta = time.perf_counter()
+        try:
+            for i in range(n_self):
+                if delays[i] > 0:
+                    torch.cuda._sleep(int(delays[i] * cyc_per_us))
+                f, nd, ids, y, _ = pool[i % npool]
+                e_self.train_step(sp, ss, f, nd, ids, y, aux=sa, ipw_table=ipw)
+                if (i & 15) == 15:
+                    e_self.read_scalars()  # raises on a raised status word (exchange timeout on any rank)
+            e_self.read_scalars()
+        except Exception as ex:  # the verdict goes on the line; the run continues on whatever path still works
+            err = repr(ex)
+        barrier()
+        t_self = time.perf_counter() - ta
+        chk = torch.stack([sp.double().sum(), (sp.double() * torch.arange(P, device=device, dtype=torch.float64)).sum()])
+        lo, hi = chk.clone(), chk.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN, group=pg)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX, group=pg)
+        same = bool(torch.equal(lo, hi))
+        status = 0 if e_self.comm is None else int(e_self.comm.status())
+        st_t = torch.tensor([status if err is None else max(status, 1)], device=device)
+        torch.distributed.all_reduce(st_t, op=torch.distributed.ReduceOp.MAX, group=pg)
+        dp_selftest = {"steps": n_self, "delay_us": "0-50 per rank and step (seeded), a busy-wait kernel in front of the step",
+                       "exchange": "peer kernel" if e_self.comm is not None else "process-group all-reduce",
+                       "replicas_bit_identical": same, "status_words_zero": int(st_t.item()) == 0, "error": err,
+                       "passed": bool(same and int(st_t.item()) == 0 and err is None), "ms_per_step": 1e3 * t_self / n_self}
+        if not dp_selftest["passed"]:
+            print("WARNING: the data-parallel self-test FAILED: %r" % (dp_selftest,), file=sys.stderr)
+        e_self.close()
+        del engs["selftest"]
     # ---- the timed region: EXACTLY K steps, each followed by the host's read of its loss (the reference's loss.item()) ----
     def timed_region():
         barrier()
@@ -1062,8 +1142,9 @@ def main():
         for key, (n_st, n_wu) in (("3", (60, 30)), ("4pair", (40, 20)), ("4lambda", (40, 20)), ("5", (20, 4))):
             try:
                 other[key] = short_config_run(key, device, lib, n_st, n_wu)
+                other[key]["fp32_mfma_products"] = short_config_run(key, device, lib, max(10, n_st // 2), max(4, n_wu // 2), fp32=True)
             except Exception as ex:  # a secondary figure must never take the headline down
-                other[key] = {"error": repr(ex)}
+                other.setdefault(key, {})["error"] = repr(ex)
     if rank == 0:
         flops = step_flops(cfg)
         ms_step = 1e3 * elapsed / args.steps
@@ -1120,10 +1201,17 @@ def main():
             traffic = tj.get(kname if dnn else "setrank_whole_step")
             traffic_source = "file profiles/traffic.json (%s): rocprofv3 FETCH_SIZE/WRITE_SIZE passes of an earlier run of this " \
                              "command, NOT measured in this process" % tj.get("_source" if dnn else "_source_setrank", "tools/profile_round.sh")
+        dp_head = {}
+        if pg is not None:  # in front of the long strings: a record that keeps only the head of the line still shows what exchanged
+            dp_head = {"dp_exchange": NAME_PEER if eng.comm is not None else NAME_RCCL,  # the one `value` was measured with
+                       "rccl_ranks": rccl_ranks,  # world size of the RCCL communicator that all-reduced `grads` in THIS run
+                       "weak_scaling_efficiency": (world * B * args.steps / elapsed) / (world * B / (1e-3 * solo_ms)),
+                       "exchange_exposed_us": 1e3 * (1e3 * elapsed / args.steps - solo_ms),
+                       "dp_selftest": dp_selftest}
         out = {
             "metric": "queries/sec (training step)", "value": world * B * args.steps / elapsed, "unit": "queries/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, **dp_head,
             "dtype": dtype_label(cfg, args.attention_dtype),
             "data": "synthetic",
             "config": {"workload": cfg["workload"], "baseline_config": args.config, "global_batch": world * B, "list_size": L,
@@ -1134,6 +1222,10 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_source,
                          **roofline_extras,
                          "avg_launch_us": 1e6 * dom_s, "launches_timed": dom_samples, "algorithmic_per_launch": amount,
+                         # measurement hygiene of `value` (here, inside an object the driver stores whole): a timed region slower than
+                         # 1.6x the calibration sum is measured again (attempts > 1, the discarded figures listed); untimed spin-up
+                         "timed_region_attempts": 1 + len(discarded), "timed_region_discarded_ms_per_step": discarded,
+                         "spinup_ms": spinup_ms, "spinup_steps": spun,
                          "avg_launch_us_back_to_back": dom_stream_us,
                          "avg_launch_us_note": ("avg_launch_us (and `achieved`) is measured INSIDE the timed region, where every step "
                                                 "starts on a GPU that idled while the host read the previous loss; "
@@ -1167,15 +1259,11 @@ def main():
             out["queries_per_sec_no_host_sync"] = B * world / nosync
             out["ms_per_step_no_host_sync"] = 1e3 * nosync
         if pg is not None:
-            out["dp_exchange"] = NAME_PEER if eng.comm is not None else NAME_RCCL  # the one `value` was measured with
             out["dp_exchanges"] = dp_exchanges
-            out["rccl_ranks"] = rccl_ranks  # world size of the RCCL communicator that all-reduced `grads` in THIS run
             out["allreduce_us"] = allreduce_us
             out["dp_checks"] = dp_checks
             out["single_gpu_in_run"] = {"ms_per_step": solo_ms, "queries_per_sec": B / (1e-3 * solo_ms),
                                         "what": "the same synced step WITHOUT the exchange on every rank at once, in this run (slowest rank)"}
-            out["weak_scaling_efficiency"] = (world * B * args.steps / elapsed) / (world * B / (1e-3 * solo_ms))
-            out["exchange_exposed_us"] = 1e3 * (1e3 * elapsed / args.steps - solo_ms)
         if trb is not None:
             out["torch_rocm_baseline"] = trb
         if e2e is not None:

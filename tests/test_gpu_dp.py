@@ -370,3 +370,97 @@ def test_comm_timeout_freezes_the_update_and_raises():
     assert all(p.exitcode == 0 for p in procs)
     assert got[0]["raised"] is True and got[0]["params_unchanged"] and got[0]["state_unchanged"]
     assert got[0]["status"] == -4 and got[1]["status"] == -4  # ULTR_E_COMM_TIMEOUT on BOTH ranks
+
+
+# ---- round 6 -----------------------------------------------------------------------------------------------------------------------
+def _skew_worker(rank, world, port, q, shards, n_steps, delays, multi_gpu=False):
+    """n_steps product steps on this rank's shard of a fixed global batch, every step delayed by a busy-wait kernel of this rank's
+    own (seeded) length in front of it: the rank's publish arrives that much later than its peers'."""
+    sys.path.insert(0, ROOT)
+    local = rank if multi_gpu else 0
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local),
+                      ULTR_DP_COMM="peer", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+    from ultra_pytorch_amd import engine, hip_ops, parallel, synthetic
+    from oracle import ultr_oracle as O
+    torch.cuda.set_device(local)
+    _, _, _, pg = parallel.init_process_group_from_env(backend="nccl" if multi_gpu else "gloo")
+    dev = torch.device("cuda", local)
+    Ls = 10
+    Bl = shards[rank]
+    rng = np.random.RandomState(100 + rank)
+    feats, ids, y = synthetic.make_batch(rng, Bl, Ls, F)
+    shape = hip_ops.DnnShape(F, HIDDEN, "elu")
+    eng = engine.StepEngine(shape, Bl, Ls, dev, algo="softmax", process_group=pg, batch_total=int(sum(shards)))
+    p = torch.tensor(O.init_params(F, HIDDEN, seed=5), device=dev)
+    st = torch.zeros_like(p)
+    f, i_, yy = torch.tensor(feats, device=dev), torch.tensor(ids, device=dev), torch.tensor(y, device=dev)
+    ipw = torch.linspace(1.0, 3.0, 10, device=dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    torch.cuda._sleep(1000000)
+    ev1.record()
+    torch.cuda.synchronize()
+    cyc_per_us = 1000000.0 / (1e3 * ev0.elapsed_time(ev1))
+    rs = np.random.RandomState(9000 + rank)
+    err = None
+    try:
+        for k in range(n_steps):
+            d = int(rs.randint(0, 51)) if delays else 0
+            if d > 0:
+                torch.cuda._sleep(int(d * cyc_per_us))
+            eng.train_step(p, st, f, feats.shape[0], i_, yy, ipw_table=ipw)
+            if (k & 7) == 7:
+                eng.read_scalars()
+        eng.read_scalars()
+    except Exception as ex:
+        err = repr(ex)
+    torch.cuda.synchronize()
+    status = -1 if eng.comm is None else int(eng.comm.status())
+    q.put((rank, dict(params=p.cpu().numpy(), state=st.cpu().numpy(), status=status, err=err, peer=eng.comm is not None)))
+    if eng.comm is not None:
+        eng.comm.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _skew_case(world, shards, n_steps, delays, port, multi_gpu=False):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_skew_worker, args=(r, world, port, q, shards, n_steps, delays, multi_gpu)) for r in range(world)]
+    [p.start() for p in procs]
+    got = dict(q.get(timeout=600) for _ in range(world))
+    [p.join(180) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    for r in range(world):
+        assert got[r]["err"] is None, got[r]["err"]
+        assert got[r]["peer"] and got[r]["status"] == 0, "rank %d: status %r" % (r, got[r]["status"])
+        assert np.isfinite(got[r]["params"]).all()
+        assert np.array_equal(got[r]["params"], got[0]["params"]), "rank %d's replica differs from rank 0's" % r
+        assert np.array_equal(got[r]["state"], got[0]["state"])
+    return got
+
+
+@pytest.mark.parametrize("world", [2, 4, 7])
+def test_exchange_protocol_under_skew(world):
+    """The publish / flag / peer-read protocol of the one-kernel exchange with every rank late by its own 0 - 50 us per step (a
+    busy-wait kernel in front of the step), 300 steps, ranks sharing the one GPU: replicas stay bit-identical, no status word is
+    raised.  (bench.py --gpus N runs the same self-test at config 2 in front of its timed region: `dp_selftest` on its line.)"""
+    _skew_case(world, [3 + (r % 2) for r in range(world)], 300, True, 29820 + world)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_exchange_protocol_under_skew_physical_gpus(world):
+    if _n_gpus() < world:
+        pytest.skip("needs >= %d GPUs (found %d)" % (world, _n_gpus()))
+    _skew_case(world, [3 + (r % 2) for r in range(world)], 300, True, 29840 + world, multi_gpu=True)
+
+
+def test_mixed_exchange_paths_keep_replicas_bitwise_equal():
+    """with unequal local batches one rank's slab reduction runs the exchange itself and hands level-2
+    sum-of-squares partials to the update, while the other - more than 1024 loss partials: a two-level loss fold - takes the
+    stand-alone exchange and sums level-1 partials.  Both sums now associate identically (groups of four in order, then strided),
+    so the gradient norm, the clip coefficient and the replicas keep the same bits: 6 000 lists against 40, five steps."""
+    _skew_case(2, [6000, 40], 5, False, 29860)

@@ -165,3 +165,10 @@ def test_bench_multi_rank_logic_on_one_gpu():
     assert d["rccl_ranks"] == 2 and d["value"] > 0
     # the in-run single-GPU figure and what the driver's scaling run is read against (two ranks SHARE one GPU here: no bar on the value)
     assert d["single_gpu_in_run"]["ms_per_step"] > 0 and 0.0 < d["weak_scaling_efficiency"] < 1.5 and "exchange_exposed_us" in d
+    # round 6: the exchange self-test under skew (1 000 steps, every rank delayed by its own 0 - 50 us per step) ran in front of the
+    # timed region and its verdict, with the exchange's name and the scaling figures, sits in the HEAD of the line
+    st = d["dp_selftest"]
+    assert st["passed"] and st["replicas_bit_identical"] and st["status_words_zero"] and st["steps"] == 1000 and st["error"] is None
+    head = lines[0][:1500]
+    for key in ("dp_exchange", "rccl_ranks", "weak_scaling_efficiency", "exchange_exposed_us", "dp_selftest"):
+        assert '"%s"' % key in head, key

@@ -43,6 +43,11 @@ __global__ __launch_bounds__(NDCG_LPW * 64) void ndcg_list_kernel(const float* _
   float* sm_i = sm_d + NDCG_LPW * L;  // [LPW][L] discounted gains by ideal rank
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x * NDCG_LPW + wave;
+  unsigned* arrived = reinterpret_cast<unsigned*>(sm_i + NDCG_LPW * L);  // waves of this workgroup that finished their list (ultr_ndcg_report)
+  if (tail.counter != nullptr) {
+    if (threadIdx.x == 0) *arrived = 0u;
+    __syncthreads();  // (before the waves without a list leave)
+  }
   if (b >= B) return;
   float* ms = sm_s + wave * L;
   float* my = sm_y + wave * L;
@@ -99,12 +104,20 @@ __global__ __launch_bounds__(NDCG_LPW * 64) void ndcg_list_kernel(const float* _
     }
   }
   if (tail.counter == nullptr) return;
-  // ---- the last wave to arrive forms the batch means (every wave: stores acknowledged, then one relaxed agent-scope increment) ----
+  // ---- the last workgroup to arrive forms the batch means: every wave waits for its write-through stores to be acknowledged, the
+  // workgroup's waves meet (waves without a list left the kernel at its top: the counter counts LISTS, a workgroup adds its own
+  // number of them with one relaxed agent-scope increment - 64 increments on one address instead of 256 at config 2) ----------------
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const int lists_here = (B - (int)blockIdx.x * NDCG_LPW) < NDCG_LPW ? (B - (int)blockIdx.x * NDCG_LPW) : NDCG_LPW;
+  // (the waves of a partial last workgroup that returned early never reach this point: count arrivals instead of a barrier)
+  unsigned mine = 0;
+  if (lane == 0) mine = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+  mine = (unsigned)__builtin_amdgcn_readfirstlane((int)mine);
+  if (mine != (unsigned)lists_here - 1u) return;  // not the last wave of this workgroup
   unsigned old = 0;
-  if (lane == 0) old = __hip_atomic_fetch_add(tail.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane == 0) old = __hip_atomic_fetch_add(tail.counter, (unsigned)lists_here, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
-  if (old != (unsigned)B - 1u) return;
+  if (old + (unsigned)lists_here != (unsigned)B) return;
   const Src pl = make_src(per_list, (int64_t)B * topn.n);
   float vals[NDCG_MAX_TOPN];
   for (int k = 0; k < topn.n; ++k) {
@@ -145,7 +158,7 @@ extern "C" int ultr_ndcg(const float* scores, const float* labels, const int32_t
     if (topn[k] <= 0) return ULTR_E_BADARG;
     t.v[k] = topn[k];
   }
-  const size_t lds = (size_t)NDCG_LPW * 4 * list_size * sizeof(float);
+  const size_t lds = ((size_t)NDCG_LPW * 4 * list_size + 4) * sizeof(float);
   if (lds > 64 * 1024) return ULTR_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   {
@@ -173,7 +186,7 @@ extern "C" int ultr_ndcg_report(const float* scores, const float* labels, const 
     if (topn[k] <= 0) return ULTR_E_BADARG;
     t.v[k] = topn[k];
   }
-  const size_t lds = (size_t)NDCG_LPW * 4 * list_size * sizeof(float);
+  const size_t lds = ((size_t)NDCG_LPW * 4 * list_size + 4) * sizeof(float);
   if (lds > 64 * 1024) return ULTR_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   UltrProfScope prof(ULTR_K_NDCG, st);

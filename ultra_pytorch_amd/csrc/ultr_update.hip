@@ -47,6 +47,22 @@ __device__ __forceinline__ void host_report(const ultr_update_desc& u, const flo
   __hip_atomic_store(reinterpret_cast<uint32_t*>(hs) + 10, u.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// This thread's share of the sum of the level-1 sum-of-squares partials, ASSOCIATED AS THE LEVEL-2 PATH WOULD: groups of four in
+// order, ((p[4j] + p[4j+1]) + p[4j+2]) + p[4j+3] with missing partials = 0 (exactly what the reduction launches store as level-2
+// partial j), thread t taking groups t, t + 256, ...  A data-parallel step may reach the update through the exchange inside the slab
+// reduction (level-2 partials) on one rank and through the stand-alone exchange (level-1 only) on another - unequal local batches -
+// and both must produce the SAME bits for the gradient norm and the clip coefficient, or the replicas fork.
+__device__ __forceinline__ float sumsq_level1_as_level2(const float* __restrict__ part, int nsq, int t) {
+  float ss = 0.f;
+  const int ngroups = (nsq + 3) >> 2;
+  for (int j = t; j < ngroups; j += 256) {
+    const int k = 4 * j;
+    const float p0 = part[k], p1 = k + 1 < nsq ? part[k + 1] : 0.f, p2 = k + 2 < nsq ? part[k + 2] : 0.f, p3 = k + 3 < nsq ? part[k + 3] : 0.f;
+    ss += ((p0 + p1) + p2) + p3;
+  }
+  return ss;
+}
+
 // guard word set (a timed-out gradient exchange on this rank or on a peer): the launch must change nothing.  Block 0 still
 // reports, with the status, so that the host's read of the loss raises instead of waiting for a sequence number forever.
 __device__ __forceinline__ bool update_guarded(const ultr_update_desc& u) {
@@ -253,8 +269,7 @@ __global__ __launch_bounds__(256) void update_kernel(ultr_update_desc u, DnnPlan
     const float* s2 = sumsq_part + ultr_sumsq2_off(P);
     for (int k = threadIdx.x; k < nsq2; k += 256) ss += s2[k];
   } else {
-#pragma unroll 8
-    for (int k = threadIdx.x; k < nsq; k += 256) ss += sumsq_part[k];
+    ss = sumsq_level1_as_level2(sumsq_part, nsq, threadIdx.x);
   }
   ss = block_sum256(ss, sm);
   float pn[1];
@@ -329,8 +344,7 @@ __global__ __launch_bounds__(256) void update_tiled_kernel(ultr_update_desc u, D
     const float* s2 = sumsq_part + ultr_sumsq2_off(P);
     for (int k = tid; k < nsq2; k += 256) ss += s2[k];
   } else {
-#pragma unroll 8
-    for (int k = tid; k < nsq; k += 256) ss += sumsq_part[k];
+    ss = sumsq_level1_as_level2(sumsq_part, nsq, tid);
   }
   ss = block_sum256(ss, sm);
   float pn[TPW];
