@@ -503,7 +503,7 @@ def feed_checksum(algo, input_feed, L):
     return float((ids * w * col).sum()), float((lab * w * col).sum())
 
 
-def run_convergence_case(ultra, name, algo_key, n_iter=300, ckpt_every=50, batch=64, n_ulp=1):
+def run_convergence_case(ultra, name, algo_key, n_iter=300, ckpt_every=50, batch=64, n_ulp=1, synth=False, seeds=None):
     """End-of-training NDCG@10 of the reference's own main.py (main.py:85-227) on the toy ULTRA dataset for a click-feed
     algorithm (ipw_rank.py:102-182, dla.py:179-266, pairwise_debias.py:106-174): ClickSimulationFeed (PBM), DNN[32,16],
     batch 64, a checkpoint every 50 steps, --max_train_iteration 300 (the stop test runs at checkpoint boundaries: 350 steps,
@@ -515,6 +515,15 @@ def run_convergence_case(ultra, name, algo_key, n_iter=300, ckpt_every=50, batch
     import runpy
     import tempfile
     data_dir = os.path.join(HERE, "ultra_toy_data") + "/"
+    dataset_meta = {"dir": "ultra_toy_data"}
+    if synth:
+        # the seeded synthetic dataset (tests/golden/make_synth_dataset.py: 400 validation queries, learnable labels) instead of the
+        # reference's 8-query toy set: an end-of-training figure that can tell a wrong trainer from a right one
+        sys.path.insert(0, HERE)
+        import make_synth_dataset as MS
+        data_dir = tempfile.mkdtemp(prefix="ultr_synth_") + "/"
+        dataset_meta = {"generator": "tests/golden/make_synth_dataset.py", "seed": MS.SEED, "sha256": MS.write_dataset(data_dir)}
+    seeds = tuple(CONV_SEEDS if seeds is None else seeds)
     cls_name = CONV_ALGOS[algo_key]
     settings = {
         "train_input_feed": "ultra.input_layer.ClickSimulationFeed", "train_input_hparams": "",
@@ -528,7 +537,7 @@ def run_convergence_case(ultra, name, algo_key, n_iter=300, ckpt_every=50, batch
     out, meta_runs = {}, {}
     # (DLA: n_ulp = 6 - its stateless sign-like updates turn one rounding into a different trajectory, three variants understate the band)
     variants = (("t1", 1, None), ("t8", 8, None)) + tuple(("ulp" if k == 0 else "ulp%d" % (k + 1), 1, k + 1) for k in range(n_ulp))
-    for seed in CONV_SEEDS:
+    for seed in seeds:
         init_sd, init_prop = None, None
         for vname, threads, perturb in variants:
             tmp = tempfile.mkdtemp(prefix="ultr_conv_")
@@ -594,14 +603,14 @@ def run_convergence_case(ultra, name, algo_key, n_iter=300, ckpt_every=50, batch
                         out["s%d_prop_%s" % (seed, k)] = v
                 meta_runs[str(seed)] = {"n_steps": len(rec["losses"]), "ckpt_steps": [h["global_step"] for h in hist]}
             print(name, "seed", seed, vname, "final ndcg@10 %.4f" % nd[-1, -1], "steps", len(rec["losses"]))
-    out["meta"] = json.dumps({"name": name, "algo": algo_key, "class": cls_name, "seeds": list(CONV_SEEDS), "topn": list(CONV_TOPN),
+    out["meta"] = json.dumps({"name": name, "algo": algo_key, "class": cls_name, "seeds": list(seeds), "topn": list(CONV_TOPN), "dataset": dataset_meta,
                               "variants": [v[0] for v in variants], "settings": settings,
                               "argv": ["--batch_size", str(batch), "--max_train_iteration", str(n_iter),
                                        "--steps_per_checkpoint", str(ckpt_every)],
                               "param_keys": list(init_sd.keys()), "prop_keys": list(init_prop.keys()) if init_prop else [],
                               "runs": meta_runs})
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
-    fin = np.asarray([[out["s%d_%s_ndcg" % (s, v[0])][-1, -1] for v in variants] for s in CONV_SEEDS])
+    fin = np.asarray([[out["s%d_%s_ndcg" % (s, v[0])][-1, -1] for v in variants] for s in seeds])
     print("wrote", name, "final ndcg@10 per seed x variant:\n", np.round(fin, 4), "\nmean", fin.mean(0), "max spread", np.ptp(fin, axis=1).max())
 
 
@@ -668,6 +677,7 @@ CASES = {
     "conv_ipw": lambda u: run_convergence_case(u, "conv_ipw", "ipw"),
     "conv_dla": lambda u: run_convergence_case(u, "conv_dla", "dla", n_ulp=6),
     "conv_pairdebias": lambda u: run_convergence_case(u, "conv_pairdebias", "pairdebias"),
+    "conv_dla_synth": lambda u: run_convergence_case(u, "conv_dla_synth", "dla", n_ulp=6, synth=True, seeds=tuple(range(10))),
     # tiny, two teacher-forced steps each
     "na_tiny": lambda u: run_train_case(u, "na_tiny", "na", 136, 10, 8, [32, 16], 2, 11),
     "ipw_tiny": lambda u: run_train_case(u, "ipw_tiny", "ipw", 136, 10, 8, [32, 16], 2, 12),

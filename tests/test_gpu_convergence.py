@@ -31,7 +31,7 @@ def feed_checksum(algo, input_feed, L):
     return float((ids * w * col).sum()), float((lab * w * col).sum())
 
 
-def run_seed(d, m, seed, tmp_path, monkeypatch):
+def run_seed(d, m, seed, tmp_path, monkeypatch, data_dir=None):
     from ultra_pytorch_amd import learning_algorithm as LA
     from ultra_pytorch_amd import main as driver
     cls = getattr(LA, m["class"])
@@ -64,7 +64,7 @@ def run_seed(d, m, seed, tmp_path, monkeypatch):
     random.seed(seed)
     torch.manual_seed(seed)
     np.random.seed(seed)
-    argv = ["--data_dir", DATA, "--setting_file", sf, "--model_dir", model_dir, "--output_dir", work + "/out/"] + m["argv"]
+    argv = ["--data_dir", data_dir or DATA, "--setting_file", sf, "--model_dir", model_dir, "--output_dir", work + "/out/"] + m["argv"]
     _, history = driver.main(argv)
     monkeypatch.setattr(cls, "train", orig_train)
     return rec, history
@@ -112,3 +112,60 @@ def test_end_of_training_ndcg_matches_the_reference(name, tmp_path, monkeypatch,
     vmeans = np.mean(np.stack(var_finals), axis=0)
     mlo, mhi = float(vmeans.min()), float(vmeans.max())
     assert mlo - (mhi - mlo) - 0.005 <= np.mean(finals) <= mhi + (mhi - mlo) + 0.005, (np.mean(finals), mlo, mhi)
+
+
+def test_dla_end_of_training_on_the_synthetic_dataset(tmp_path, monkeypatch, capsys):
+    """DLA (dla.py:141-177, 179-266) end to end on a dataset where the figure can tell a right trainer from a wrong one (VERDICT r05
+    item 5): tests/golden/make_synth_dataset.py - 400 validation queries, learnable labels - regenerated here byte for byte (sha256 of
+    every file is in the fixture), 10 seeds x 350 steps of the counterpart driver from the reference's initial weights, against
+    tests/golden/conv_dla_synth.npz = the reference's own main.py in eight variants per seed (1 / 8 threads, six one-rounding
+    perturbations of the initial weights).  The reference's variants end 0.004 .. 0.018 apart per seed around NDCG@10 = 0.948:
+      (a) identical batch sequence (checksums of every batch), the first step's loss to 1e-5;
+      (b) per seed: the final NDCG@10 within 3.5 POOLED standard deviations of the seed's variant mean (pooled over the ten seeds'
+          deviations from their own means: 0.0039 - a seed's eight variants alone give a noisy scale, 0.0021 .. 0.0058), and at least
+          six of the ten seeds inside their own variants' [min, max] without any widening;
+      (c) the mean over seeds within 0.004 of the mean of the variant means (3.3 pooled deviations of a ten-seed mean; the variant
+          means themselves span 0.9467 .. 0.9497).
+    Why not "every seed inside [min, max] +- one std of its variants" (the form VERDICT r05 sketched): a NINTH run of the reference
+    itself leaves the [min, max] of eight exchangeable runs with probability 2/9, and the widened band with roughly one in ten - over
+    ten seeds the reference would fail its own test about every second time.  Measured here (round 6, MI355X): nine of ten seeds
+    inside the unwidened band, seed 1 at 0.9363 against [0.9429, 0.9500] (2.5 pooled deviations), mean 0.9477 against 0.9484.
+    The old toy-set test accepted any mean in [0.64, 0.87]."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import make_synth_dataset as MS
+    d = np.load(os.path.join(GOLDEN, "conv_dla_synth.npz"))
+    m = json.loads(str(d["meta"]))
+    data_dir = os.path.join(str(tmp_path), "synth") + "/"
+    assert MS.write_dataset(data_dir, seed=m["dataset"]["seed"]) == m["dataset"]["sha256"], "the synthetic dataset is not the fixture's"
+    topn = m["topn"]
+    i10 = topn.index(10)
+    finals, report, var_finals = [], [], []
+    for seed in m["seeds"]:
+        rec, history = run_seed(d, m, seed, tmp_path, monkeypatch, data_dir=data_dir)
+        run = m["runs"][str(seed)]
+        assert len(rec["losses"]) == run["n_steps"] and [h[0] for h in history] == run["ckpt_steps"]
+        np.testing.assert_array_equal(np.asarray(rec["sums"]), d["s%d_feed_sums" % seed])          # (a)
+        ref_losses = d["s%d_losses" % seed]
+        assert abs(rec["losses"][0] - ref_losses[0]) <= 1e-5 * max(1.0, abs(ref_losses[0]))
+        assert np.all(np.isfinite(rec["losses"]))
+        ours = np.asarray([[h[2]["ndcg_%d" % n] for n in topn] for h in history])
+        variants = np.stack([d["s%d_%s_ndcg" % (seed, v)] for v in m["variants"]])[:, -1, i10]
+        lo, hi, sd = float(variants.min()), float(variants.max()), float(variants.std())
+        finals.append(float(ours[-1, i10]))
+        var_finals.append(variants)
+        report.append((seed, finals[-1], lo, hi, sd, float(ours[0, i10])))
+    vmeans = np.mean(np.stack(var_finals), axis=0)
+    with capsys.disabled():
+        print("\nconv_dla_synth: seed, final NDCG@10 here, the reference variants' [min, max], their std, NDCG@10 at the first checkpoint")
+        for r in report:
+            print("   seed %d  %.4f  [%.4f, %.4f]  %.4f   (%.4f)" % r)
+        print("   mean over seeds here %.4f; the reference variants' means %.4f .. %.4f (mean %.4f)" % (np.mean(finals), vmeans.min(), vmeans.max(), vmeans.mean()))
+    dev = np.stack(var_finals) - np.stack(var_finals).mean(axis=1, keepdims=True)
+    pooled = float(np.sqrt((dev ** 2).sum() / (dev.size - dev.shape[0])))
+    inside = 0
+    for (seed, v, lo, hi, sd, _), vf in zip(report, var_finals):
+        assert abs(v - float(vf.mean())) <= 3.5 * pooled, (seed, v, float(vf.mean()), pooled)           # (b)
+        inside += int(lo <= v <= hi)
+    assert inside >= 6, (inside, report)
+    assert abs(np.mean(finals) - float(vmeans.mean())) <= 0.004, (np.mean(finals), float(vmeans.mean()), pooled)  # (c)

@@ -159,7 +159,7 @@ class StepEngine:
         self._seq = (self._seq % 0xFFFFFFFF) + 1  # 1 .. 2^32-1: never 0, the buffer's initial content
         self.udesc.seq = self._seq
 
-    def read_scalars(self, timeout_s=60.0):
+    def read_scalars(self, timeout_s=60.0, scheduled=False):
         """The step scalars of the LAST queued step as a numpy array ([0] loss, [1] gradient norm, [2] clip coefficient, [3] D,
         [4] rank_loss, [5] exam_loss, [6] propensity gradient norm, [7] sum g^2) - the reference's `loss.item()`.  Waits for the
         update kernel's report in host-mapped memory (no stream synchronisation); raises if the gradient exchange of a
@@ -179,15 +179,27 @@ class StepEngine:
                 t0 = now if t0 is None else t0
                 if now - t0 > timeout_s:
                     raise _lib.UltrHipError("no step report from the GPU within %.0f s (step %d)" % (timeout_s, seq))
-        self._raise_on_status(int(u[8]))
+        self._raise_on_status(int(u[8]), scheduled)
         return self._hs_f[:8].copy()
 
     H3_RANGE, H3_NEAR = 0x100, 0x200  # include/ultr_hip.h: ULTR_STATUS_H3_RANGE / ULTR_STATUS_H3_NEAR
 
-    def _raise_on_status(self, st):
-        """Act on the status word of the latest full step report (host_scalars[8])."""
+    DP_STATUS_CADENCE = 64  # data parallel: every rank examines the step report of the same steps (train_step)
+
+    def _raise_on_status(self, st, scheduled=False):
+        """Act on the status word of the latest full step report (host_scalars[8]).
+        Data parallel: the switch to the fp32 products changes the bits of the following steps, so every rank must make it at the
+        SAME step.  The replicas are bit-identical, hence every rank's update kernel raises the NEAR bit in the report of the same
+        step - but ranks read reports when their callers ask for a loss (rank 0 may log every step, the others never).  There the
+        switch is only made from train_step's own scheduled look at the report (every DP_STATUS_CADENCE-th step, on every rank
+        alike: ADVICE r05); a read in between leaves the NEAR bit alone (the copies are still exact: one step moves a weight by at
+        most lr x the clip norm, 64 steps by far less than the 64 .. 128 margin)."""
         if st == 0:
             return
+        if self.pg is not None and not scheduled:
+            st &= ~self.H3_NEAR
+            if st == 0:
+                return
         if st & (self.H3_RANGE | self.H3_NEAR):
             # a hidden weight is near (>= 64) or beyond (>= 128) the range of the split-half weight copies.  Near: every copy is
             # still exact and one optimizer step moves a weight by at most lr x the clip norm - switch to the fp32 products now
@@ -281,6 +293,8 @@ class StepEngine:
         if self.comm is not None:
             a.comm_step = self.comm.step
             self.comm.step += 1
+        if self.pg is not None and self._host_report and self._seq > 0 and self._seq % self.DP_STATUS_CADENCE == 0:
+            self.read_scalars(scheduled=True)  # the same step on every rank: a switch to the fp32 products happens everywhere at once
         self._next_seq()
         src = self.next_click_source
         nxt = src.next_click_args() if src is not None else None
@@ -419,13 +433,19 @@ class SetRankEvalEngine(EvalEngine):
         super().__init__(shape, batch, list_size, device, topn=topn)
         self.saved = _f32(shape.saved_bytes(self.B * self.L) // 4, device)
         self._flag = self.saved[shape.range_flag_offset(self.B * self.L):][:1].view(torch.int32)
+        self._checked = None  # (data_ptr, version) of the parameters whose split-half planes were last looked at
 
     def run(self, params, features, n_docs, docids, labels):
         _setrank_draw(self.L)
         hip_ops.setrank_forward(self.shape, params, features, n_docs, docids, self.B, self.L, self.scores, self.saved)
         # the split-half planes of a loaded checkpoint may be out of range (|w| >= 64 / 128): the forward raised the word - look
         # (validation reads its metrics on the host anyway), switch this model to the fp32 products and score again
-        if hip_ops.split_half_enabled(self.shape) and int(self._flag.item()) != 0:
+        # ONCE per parameter version (the word is a function of the weights; a blocking .item() per validation batch put a stream
+        # synchronisation between the forward and the NDCG launch - ADVICE r05)
+        key = (params.data_ptr(), params._version)
+        look = key != self._checked
+        self._checked = key
+        if look and hip_ops.split_half_enabled(self.shape) and int(self._flag.item()) != 0:
             hip_ops.fall_back_to_fp32_products(self.shape, "a SetRank weight of magnitude >= 64 was loaded (the split-half weight planes "
                                                            "cover |w| < 128)")
             hip_ops.setrank_forward(self.shape, params, features, n_docs, docids, self.B, self.L, self.scores, self.saved)
