@@ -391,6 +391,9 @@ def test_fused_block_kernels_against_the_separate_launches(B, L, F, dm, H, nl, d
 
     def run(knob):
         monkeypatch.setenv("ULTR_SR_BLOCK", knob)
+        # (the blocks' backward as separate launches: with the fused backward launches of round 6 the forward block kernel does not
+        # write out1 - they recompute it from s1 - and this test compares EVERY saved tensor)
+        monkeypatch.setenv("ULTR_SR_BWD_FUSED", "6")
         _lib.load().ultr_config_reload()
         saved = torch.zeros(shape.saved_bytes(T) // 4, device="cuda")
         scores = torch.zeros(B, L, device="cuda")

@@ -2231,6 +2231,7 @@ struct SrBlockArgs {
   int p0, p1, p2, pv;                                    // float offsets into dynamic LDS
   // the last block also runs the output FFN (SetRank.py:136, 153): oh = relu(x' Wo1^T + bo1), score = oh . wo2 + bo2
   int head;
+  int skip_out1;  // the backward recomputes out1 from s1 (sr_bwd_proj_kernel): the forward does not write it (105 MB per block at config 5)
   int64_t go1, bo1, wo2, bo2, oh;                        // fragment copy of Wo1 (halves), parameter offsets, saved oh
 };
 
@@ -2386,7 +2387,7 @@ __global__ __launch_bounds__(NW * 64) void sr_block_fwd_kernel(SrBlockArgs a, co
   };
   // LayerNorm of the rows in P1 (a wave owns rows wave + 16 q): statistics and the output to `saved`; planes: the output also stays
   // in P1 (the residual of the next sum) and goes to P0 as the two fp16 planes of the next product's operand
-  auto layer_norm = [&](const float* gam, const float* bet, int64_t mean_off, int64_t rstd_off, int64_t out_off, bool to_planes) {
+  auto layer_norm = [&](const float* gam, const float* bet, int64_t mean_off, int64_t rstd_off, int64_t out_off, bool to_planes, bool store_out = true) {
     int lane = lane_id;
     asm volatile("" : "+v"(lane));
     const int c = 4 * lane;
@@ -2419,7 +2420,7 @@ __global__ __launch_bounds__(NW * 64) void sr_block_fwd_kernel(SrBlockArgs a, co
       const int r = wave + NW * q;
       const float rstd = 1.0f / sqrtf(qv[q] * invd + SR_EPS);
       v[q] = make_float4(v[q].x * rstd * g4.x + b4.x, v[q].y * rstd * g4.y + b4.y, v[q].z * rstd * g4.z + b4.z, v[q].w * rstd * g4.w + b4.w);
-      buf_st4(dout, cok ? (unsigned)c * 4u : ULTR_OOB, (unsigned)(r * d) * 4u, v[q]);
+      buf_st4(dout, (cok && store_out) ? (unsigned)c * 4u : ULTR_OOB, (unsigned)(r * d) * 4u, v[q]);
       buf_st1(dmean, l0, (unsigned)r * 4u, s[q]);
       buf_st1(drstd, l0, (unsigned)r * 4u, rstd);
       am[q] = fmaxf(fmaxf(fabsf(v[q].x), fabsf(v[q].y)), fmaxf(fabsf(v[q].z), fabsf(v[q].w)));
@@ -2539,7 +2540,7 @@ __global__ __launch_bounds__(NW * 64) void sr_block_fwd_kernel(SrBlockArgs a, co
   UGEMM_TRACE_STAMP(22);
   lds_barrier();
   UGEMM_TRACE_STAMP(23);
-  layer_norm(pg1, pb1, a.m1, a.r1, a.out1, true);                   // out1 = LN1(s1)
+  layer_norm(pg1, pb1, a.m1, a.r1, a.out1, true, a.skip_out1 == 0);  // out1 = LN1(s1)
   UGEMM_TRACE_STAMP(24);
   lds_barrier();
   UGEMM_TRACE_STAMP(25);
@@ -2561,6 +2562,15 @@ __global__ __launch_bounds__(NW * 64) void sr_block_fwd_kernel(SrBlockArgs a, co
 }
 
 
+// Will the backward of this step run the encoder blocks' row-local chain as the fused launches of ultr_sr_bwd.hip?  ONE predicate
+// for the forward (which then does not write out1: sr_bwd_proj_kernel recomputes it from s1) and for the backward (which then
+// refuses to fall back to the launches that read out1).  A function of the plan and the knobs only.
+bool sr_bwd_blocks_fused(const SrPlan& p) {
+  sr_knobs_load();
+  int R = 0, nt = 0, nw = 0;
+  return p.bwd_fused && (g_sr_knob_bwd_fused & 1) && sr_h3_enabled() && !p.no_h3 && p.T * (int64_t)p.d * 4 < ((int64_t)1 << 31) &&
+         sr_bwd_geometry(p.T, 256, &R, &nt, &nw);
+}
 // sr_block_fwd_kernel: legal for widths that are multiples of 32 (d <= 256, dff <= 128) with the split-half products on; rows per
 // workgroup = whole rounds of one workgroup per CU, as many as the LDS holds (<= 60 at d = 256)
 int g_sr_knob_block = -1;
@@ -2595,6 +2605,7 @@ bool block_fwd(const SrPlan& p, int l, const float* params, float* sv, float* sc
   a.gd = md->g_off; a.gf1 = m1->g_off; a.gf2 = m2->g_off;
   a.A = p.sv_A[l]; a.x = p.sv_x[l]; a.s1 = p.sv_s1[l]; a.m1 = p.sv_m1[l]; a.r1 = p.sv_r1[l]; a.out1 = p.sv_out1[l]; a.f = p.sv_f[l];
   a.s2 = p.sv_s2[l]; a.m2 = p.sv_m2[l]; a.r2 = p.sv_r2[l]; a.xn = p.sv_x[l + 1];
+  a.skip_out1 = sr_bwd_blocks_fused(p) ? 1 : 0;
   if (l == p.nl - 1 && p.bo2 == p.wo2 + dff) {  // the output FFN rides along with the last block
     const SrPlan::SplitMat* mo = sr_find_split(params + p.wo1, dff, d);
     if (mo != nullptr && mo->g_off >= 0 && scores != nullptr) {
@@ -3133,6 +3144,8 @@ extern "C" int ultr_setrank_backward(const ultr_setrank_desc* c, const float* pa
         continue;
       }
     }
+    // (the forward did not write out1 when it expected the fused launches: sr_block_fwd_kernel's skip_out1 - same predicate)
+    if (sr_bwd_blocks_fused(p) && g_sr_knob_block != 0) return ULTR_E_UNSUPPORTED;
     // x_{l+1} = LN2(s2),  s2 = out1 + ffn
     if (d <= 1024) {  // g2 | b2, G2 = d s2 = d out1 (residual) = d ffn, bf2: one pass
       SR_CHECK(ln_bwd_cs(p, G0, sv + p.sv_s2[l], sv + p.sv_m2[l], sv + p.sv_r2[l], params + y.g2, d, G2, ws, grads + y.g2,
