@@ -464,3 +464,6 @@ def test_fused_backward_launches_against_the_separate_launches(B, L, F, dm, H, n
         assert np.abs(a - b).max() <= 2e-5 * float(np.abs(b).max()) + 1e-6 * float(np.abs(gref).max()), (name, float(np.abs(a - b).max()), float(np.abs(b).max()))
     assert abs(got[4][0] - ref[4][0]) <= 1e-6 * max(1.0, abs(ref[4][0]))
     np.testing.assert_array_equal(got[1], again[1])  # deterministic: persistent workgroups, fixed-order folds
+    from tests import margins
+    margins.check("setrank_fused_backward/B%d_L%d_F%d_nl%d" % (B, L, F, nl), "grads_max_abs_diff_over_max_abs_g",
+                  float(np.abs(g - gref).max() / np.abs(gref).max()))

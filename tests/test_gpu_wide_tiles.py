@@ -13,6 +13,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from tests.hipref import HipRun  # noqa: E402
+from tests import margins  # noqa: E402
 
 
 
@@ -77,6 +78,7 @@ def test_wide_forward_scores_match_oracle(name, train):
     scores = run.forward(params, train=train)
     ref = O.ranking_scores(torch.from_numpy(params), F, hidden, feats, ids, act).numpy()
     print("%s: %d rows per workgroup, max |score diff| %.2e" % (name, R, np.abs(scores - ref).max()))
+    margins.check("wide_tiles/%s_%s" % (name, "train" if train else "eval"), "scores_max_abs_diff", np.abs(scores - ref).max())
     np.testing.assert_allclose(scores, ref, atol=1e-5, rtol=1e-5)
 
 
@@ -100,6 +102,7 @@ def test_wide_forward_feeds_the_backward(name):
     terms = O.dnn_backward_manual(params, F, hidden, x, dsc, act, abs_terms=True)
     d = np.abs(g * gs - gref)
     print("%s: max |g - g_ref| / (|g_ref| + terms) = %.2e" % (name, (d / np.maximum(np.abs(gref) + terms, 1e-30)).max()))
+    margins.check("wide_tiles/%s_backward" % name, "grads_max_diff_over_abs_g_plus_terms", (d / np.maximum(np.abs(gref) + terms, 1e-30)).max())
     assert (d <= 1e-5 * (np.abs(gref) + terms)).all()
 
 

@@ -21,8 +21,8 @@
 extern "C" int ultr_trace_read(unsigned long long* host_out) {
   static unsigned long long part[3 * 64 * 32];
   memset(host_out, 0, sizeof(part));
-  int (*readers[3])(unsigned long long*) = {ultr_trace_read_fwd, ultr_trace_read_bwd, ultr_trace_read_fb};
-  for (int k = 0; k < 3; ++k) {
+  int (*readers[4])(unsigned long long*) = {ultr_trace_read_fwd, ultr_trace_read_bwd, ultr_trace_read_fb, ultr_trace_read_wgrad};
+  for (int k = 0; k < 4; ++k) {
     const int rc = readers[k](part);
     if (rc) return rc;
     for (int i = 0; i < 3 * 64 * 32; ++i) host_out[i] += part[i];

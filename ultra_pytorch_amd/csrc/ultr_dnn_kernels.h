@@ -632,7 +632,7 @@ __device__ __forceinline__ int pick_ct(int width, int nw) {
 #ifdef ULTR_TRACE
 // three banks: 0 = the 8-wave kernels (their slot numbers overlap each other: trace one kernel at a time), 1 = dnn_fwdw_kernel,
 // 2 = dnn_bwdw_kernel (a training step runs all of them).  One array PER TRANSLATION UNIT (the kernels of a bank live in one unit:
-// ultr_dnn_fwd.hip banks 0 / 1, ultr_dnn_bwd.hip 0 / 2, ultr_dnn_fb.hip 0); ultr_trace_read (ultr_dnn.hip) adds the units' arrays
+// ultr_dnn_fwd.hip banks 0 / 1, ultr_dnn_bwd.hip 0 / 2, ultr_dnn_fb.hip and ultr_dnn_wgrad.hip 0); ultr_trace_read (ultr_dnn.hip) adds the units' arrays
 static __device__ unsigned long long g_ultr_trace[3 * 64 * 32];
 #define TRACE_STAMP_B(bank, slot)                                                                   \
   do {                                                                                              \
@@ -787,4 +787,5 @@ int ultr_launch_grad_reduce_xchg(UltrProfScope& prof, const RedPlan& rp, const D
 int ultr_trace_read_fwd(unsigned long long* host_out);
 int ultr_trace_read_bwd(unsigned long long* host_out);
 int ultr_trace_read_fb(unsigned long long* host_out);
+int ultr_trace_read_wgrad(unsigned long long* host_out);
 #endif

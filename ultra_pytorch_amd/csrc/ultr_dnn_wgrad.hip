@@ -897,6 +897,8 @@ __global__ __launch_bounds__(64) void grad_sumsq_kernel(int64_t P, const float* 
 }
 
 
+ULTR_TRACE_READER(ultr_trace_read_wgrad)
+
 int ultr_launch_dnn_wgrad(UltrProfScope& prof, const DnnPlan& p, const BwdPlan& bp, bool av, bool h3, size_t wlds, dim3 wgrid, hipStream_t st,
                           const float* params, const float* features, int64_t n_docs, const int32_t* docids, int batch, int list_size,
                           const float* saved, float* ws, int l0_vec, float* grads, const float* lp, int nlp, int tail, const EarlyReport& er,
