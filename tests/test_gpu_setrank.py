@@ -370,7 +370,7 @@ FUSED_SHAPES = [(37, 30, 136, 64, 4, 2, 32),     # ragged last workgroup, PAD do
 
 
 @pytest.mark.parametrize("B,L,F,dm,H,nl,dff", FUSED_SHAPES)
-@pytest.mark.parametrize("block", ["1", "2"], ids=["one_16_wave_workgroup", "two_8_wave_workgroups"])
+@pytest.mark.parametrize("block", ["1", "2", "3"], ids=["one_16_wave_workgroup", "two_8_wave_workgroups", "persistent_workgroup_round6"])
 def test_fused_block_kernels_against_the_separate_launches(B, L, F, dm, H, nl, dff, block, monkeypatch):
     """sr_embed_fwd_kernel / sr_block_fwd_kernel (round 5: gather + LayerNorm + embedding FFN, and everything of an encoder block behind
     the attention - incl. the output FFN on the last block - as ONE launch each) against the separate GEMM / LayerNorm launches they

@@ -35,3 +35,13 @@ for nm, names, base in (("sr_bwd_ffn_kernel", ffn, 0), ("sr_bwd_proj_kernel", pr
     for blk in range(0, 64, 8):
         t = a[blk, base:base + len(names) + 1]
         print("  wg %3d:" % blk, " ".join("%s=%d" % (names[k], t[k + 1] - t[k]) for k in range(len(names))), " tile=%d" % (t[len(names)] - t[0]))
+
+if hasattr(lib, "ultr_srf_trace_read"):
+    lib.ultr_srf_trace_read.argtypes = [ctypes.c_void_p]
+    lib.ultr_srf_trace_read(buf)
+    a = np.array(buf[:], dtype=np.uint64).reshape(64, 32).astype(np.int64)
+    names = ["rows(A, x)", "product s1 (+sync)", "LN1 (+sync)", "f (+sync)", "product s2", "request+sync", "LN2", "head", "sync"]
+    print("sr_fwd_block_kernel (the LAST block's launch: with the output FFN)")
+    for blk in range(0, 64, 8):
+        t = a[blk, :10]
+        print("  wg %3d:" % blk, " ".join("%s=%d" % (names[k], t[k + 1] - t[k]) for k in range(9)), " tile=%d" % (t[9] - t[0]))

@@ -2577,7 +2577,7 @@ int g_sr_knob_block = -1;
 bool block_fwd(const SrPlan& p, int l, const float* params, float* sv, float* scores, hipStream_t st, int* rc) {
   if (g_sr_knob_block < 0) {
     const char* e = getenv("ULTR_SR_BLOCK");
-    g_sr_knob_block = (e && *e) ? atoi(e) : 2;  // 0: off; 1: one 16-wave workgroup per CU; 2: two 8-wave workgroups per CU
+    g_sr_knob_block = (e && *e) ? atoi(e) : 3;  // 0: off; 1: one 16-wave workgroup per CU; 2: two 8-wave workgroups per CU; 3 (default): the persistent kernel of round 6 where its widths apply, 2 elsewhere
   }
   const int d = p.d, dff = p.dff;
   if (!g_sr_knob_block || !sr_h3_enabled() || p.no_h3 || g_sr_h3.planes == nullptr || d % 32 != 0 || (dff != 32 && dff != 64 && dff != 128) || d > 256 || d < 32)
@@ -2586,6 +2586,32 @@ bool block_fwd(const SrPlan& p, int l, const float* params, float* sv, float* sc
   const SrPlan::SplitMat* m1 = sr_find_split(params + p.lay[l].wf1, dff, d);
   const SrPlan::SplitMat* m2 = sr_find_split(params + p.lay[l].wf2, d, dff);
   if (!md || !m1 || !m2 || md->g_off < 0 || m1->g_off < 0 || m2->g_off < 0 || (((uintptr_t)sv | (uintptr_t)g_sr_h3.planes) & 15) != 0) return false;
+  if (g_sr_knob_block >= 3 && d == SR_BWD_D && dff == SR_BWD_DFF && p.T * (int64_t)d * 4 < ((int64_t)1 << 31)) {
+    // round 6: ONE persistent 8-wave workgroup per CU over 60-row tiles (sr_fwd_block_kernel, ultr_sr_fwd.hip)
+    int dev = 0, cus = 256, R = 0, nt = 0, nw = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    if (sr_bwd_geometry(p.T, cus, &R, &nt, &nw)) {
+      const SrLayer& y = p.lay[l];
+      SrFwdBlockArgs fa;
+      memset(&fa, 0, sizeof(fa));
+      fa.R = R; fa.d = d; fa.dff = dff; fa.ntiles = nt; fa.T = p.T;
+      fa.bd = y.bd; fa.bf1 = y.bf1; fa.bf2 = y.bf2; fa.g1 = y.g1; fa.b1 = y.b1; fa.g2 = y.g2; fa.b2 = y.b2;
+      fa.gd = md->g_off; fa.gf1 = m1->g_off; fa.gf2 = m2->g_off;
+      fa.A = p.sv_A[l]; fa.x = p.sv_x[l]; fa.s1 = p.sv_s1[l]; fa.m1 = p.sv_m1[l]; fa.r1 = p.sv_r1[l]; fa.out1 = p.sv_out1[l]; fa.f = p.sv_f[l];
+      fa.s2 = p.sv_s2[l]; fa.m2 = p.sv_m2[l]; fa.r2 = p.sv_r2[l]; fa.xn = p.sv_x[l + 1];
+      fa.skip_out1 = sr_bwd_blocks_fused(p) ? 1 : 0;
+      if (l == p.nl - 1 && p.bo2 == p.wo2 + dff) {
+        const SrPlan::SplitMat* mo = sr_find_split(params + p.wo1, dff, d);
+        if (mo != nullptr && mo->g_off >= 0 && scores != nullptr) {
+          fa.head = 1;
+          fa.go1 = mo->g_off; fa.bo1 = p.bo1; fa.wo2 = p.wo2; fa.bo2 = p.bo2; fa.oh = p.sv_oh;
+        }
+      }
+      *rc = sr_fwd_block_launch(fa, nw, params, g_sr_h3.planes, sv, scores, st);
+      if (fa.head && *rc == 0) *rc = -1;
+      return true;
+    }
+  }
   const int64_t per_row = (int64_t)(2 * (d + 8) + (dff + 8)) * 4, fixed = (int64_t)(6 * d + 3 * dff + 4 + 128) * 4;
   const bool two = g_sr_knob_block != 1;  // two 8-wave workgroups per CU (default) / 1: one 16-wave workgroup
   int64_t rmax = ((two ? 80 : 160) * 1024 - fixed) / per_row - 1;
@@ -2861,7 +2887,7 @@ bool embed_fwd(const SrPlan& p, const float* params, const float* feats, const i
   const int F = p.F, d = p.d, dff = p.dff;
   if (g_sr_knob_block < 0) {
     const char* e = getenv("ULTR_SR_BLOCK");
-    g_sr_knob_block = (e && *e) ? atoi(e) : 2;
+    g_sr_knob_block = (e && *e) ? atoi(e) : 3;
   }
   if (!g_sr_knob_block || !sr_h3_enabled() || p.no_h3 || g_sr_h3.planes == nullptr || F % 4 != 0 || F > 256 || d % 32 != 0 || d > 256 || d < 32 ||
       (dff != 32 && dff != 64 && dff != 128) || n_docs * (int64_t)F * 4 >= ((int64_t)1 << 31))

@@ -58,6 +58,16 @@ struct SrBwdEmbedArgs {
   int64_t part, part_stride;
   int p0, p1, p2, os;
 };
+// sr_fwd_block_kernel (ultr_sr_fwd.hip): everything of an encoder block behind the attention - the forward - in the same persistent geometry
+struct SrFwdBlockArgs {
+  int R, d, dff, ntiles, head, skip_out1;
+  int64_t T;
+  int64_t bd, bf1, bf2, g1, b1, g2, b2, bo1, wo2, bo2;   // parameters
+  int64_t gd, gf1, gf2, go1;                             // HALVES: forward fragment copies of Wd, Wf1, Wf2, Wo1
+  int64_t A, x, s1, m1, r1, out1, f, s2, m2, r2, xn, oh; // saved
+  int p0, p1, p2, os;
+};
+int sr_fwd_block_launch(SrFwdBlockArgs a, int nwg, const float* params, const _Float16* planes, float* sv, float* scores, hipStream_t st);
 // rows per tile / tiles / workgroups / LDS bytes for T rows on `cus` compute units; false: T too small or too large
 bool sr_bwd_geometry(int64_t T, int cus, int* R, int* ntiles, int* nwg);
 int sr_bwd_ffn_launch(SrBwdFfnArgs a, int nwg, const float* params, const _Float16* planes, const float* sv, float* ws, hipStream_t st);

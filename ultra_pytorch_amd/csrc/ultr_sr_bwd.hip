@@ -27,6 +27,7 @@
 #include "ultr_h3.h"
 #include "ultr_plan.h"
 #include "ultr_sr_bwd.h"
+#include "ultr_sr_tiles.h"
 
 #ifdef ULTR_TRACE
 // phase stamps (s_memtime) of wave 0 of the first 64 workgroups on their SECOND tile; slot 16 k + j: kernel k (0 ffn, 1 proj), stamp j
@@ -46,24 +47,6 @@ extern "C" int ultr_srb_trace_read(unsigned long long* host_out) {
 
 namespace {
 
-constexpr int NW = 8, NT = NW * 64;
-
-__device__ __forceinline__ float row16_max(float v) {  // maximum over the 16 lanes of a DPP row, in every lane of the row
-  ULTR_DPP_MAX(v, "quad_perm:[1,0,3,2] row_mask:0xf");
-  ULTR_DPP_MAX(v, "quad_perm:[2,3,0,1] row_mask:0xf");
-  ULTR_DPP_MAX(v, "row_ror:4 row_mask:0xf");
-  ULTR_DPP_MAX(v, "row_ror:8 row_mask:0xf");
-  return v;
-}
-__device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
-__device__ __forceinline__ float max4(float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
-
-// LayerNorm backward of four rows per wave (rows wave + 8 (4 half + k), lane = columns 4 lane .. + 3; d = 256):
-//   xh = (s - mean) rstd,  g = dy gamma,  v = rstd (g - mean(g) - xh mean(g xh))         (same expressions as sr_ln_bwd_cs_v4_kernel)
-// v goes to the fp16 plane pair in P0 scaled per row (OS[row] = the inverse scale x 2^-8: the weights are stored x 2^8) and, by MODE,
-//   MODE 0: to P1 as fp32 rows (the residual and the weight-gradient operand of the FFN kernel)
-//   MODE 1: to global memory (d s1), while P1 receives out1 = xh gamma + beta (the weight-gradient operand of the projection kernel)
-// Column sums: cg += dy xh, cb += dy, cd += v.
 // the HBM operands of a tile's row phase, requested one tile ahead (the workgroup is alone on its CU: nobody else hides the latency):
 // rows wave + 8 q of d y and s, the dff-wide rows 4 (wave + 8 q2) + (lane >> 4), and the rows' statistics one per lane (lane k < 8:
 // row wave + 8 k; read back with v_readlane - two registers instead of sixteen.  Scalar loads were tried: they share the LDS counter,
@@ -151,53 +134,6 @@ __device__ __forceinline__ void ln_bwd_rows(int pr, int wave, int lane, int R, i
     } else {
       buf_st4(dso, (unsigned)c * 4u, (unsigned)(r * d) * 4u, v[k]);
       st4(P1 + rc * ld + c, make_float4(xh[k].x * g4.x + b4.x, xh[k].y * g4.y + b4.y, xh[k].z * g4.z + b4.z, xh[k].w * g4.w + b4.w));
-    }
-  }
-}
-
-// a d-wide split-half product over the tile's four 16-row tiles: wave = one 32-column chunk of the output, the A operand = the fp16
-// plane pair at Ap (row stride lda halves), the weights = fragment copy at planes + gw (nks steps of 32 along the contraction);
-// Y = acc x os[row] (+ the fp32 row in Pres); rows past the tile's valid rows are dropped by the destination's extent
-template <bool RES>
-__device__ __forceinline__ void product_d4(int wave, int lane, int R, const float* Ap, int lda, int nks, const _Float16* planes,
-                                           int64_t gw, int Kw, const float* os, const float* Pres, int ld, const Dst& dout) {
-  constexpr int d = SR_BWD_D;
-  asm volatile("" : "+v"(lane));
-  const int ch = wave;
-  const int i = lane & 15, q = lane >> 4;
-  const _Float16* AH = reinterpret_cast<const _Float16*>(Ap);
-  const int lo_off = (R + 1) * lda;
-  const _Float16* pa[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int row = 16 * t + i;
-    pa[t] = AH + (row < R ? row : R) * lda + 8 * q;
-  }
-  const Src Wh = make_src(reinterpret_cast<const float*>(planes + gw), (int64_t)Kw * d);
-  PipeH3W<4, 2> ph;
-  ph.begin(Wh, ch, nks, 0, nks, true, lane);
-  f32x4 acc[4][2];
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) acc[t][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  ph.run(pa, lo_off, Wh, nks, acc);
-  const int col = 32 * ch + 2 * i;
-  const unsigned gv = (unsigned)(4 * q * d + 2 * i) * 4u;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const float4 o4 = ld4(os + 16 * t + 4 * q);
-    const float o[4] = {o4.x, o4.y, o4.z, o4.w};
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 16 * t + 4 * q + r;
-      float2 y = make_float2(acc[t][0][r] * o[r], acc[t][1][r] * o[r]);
-      if constexpr (RES) {
-        const float2 rv = ld2(Pres + (row < R ? row : R) * ld + col);
-        y.x += rv.x;
-        y.y += rv.y;
-      }
-      buf_st2(dout, gv, (unsigned)((16 * t + r) * d + 32 * ch) * 4u, y);
     }
   }
 }
@@ -900,15 +836,6 @@ size_t tile_lds_floats(int R) {
   const size_t tail = (size_t)NW * 3 * SR_BWD_D + (size_t)4 * NW * SR_BWD_DFF;
   return tile > tail ? tile : tail;
 }
-template <typename K>
-int set_lds(K kernel, size_t bytes) {
-  if (bytes > 160 * 1024) return ULTR_E_UNSUPPORTED;
-  if (bytes > 64 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
-    return ULTR_E_UNSUPPORTED;
-  return 0;
-}
-
 }  // namespace
 
 // whole rounds of one workgroup per compute unit: as few rounds as 64-row tiles allow, rows per tile a multiple of 4 (the
