@@ -212,6 +212,7 @@ bool make_plan(const ultr_setrank_desc* c, int64_t T, SrPlan* p) {
   p->arena_floats = (int64_t)(3 * p->nl + 4) * ((wg_floats + 3) & ~(int64_t)3) + (int64_t)(2 * p->nl + 5) * p->n_lb * 3 * p->maxw;
   if (p->bwd_fused)  // two per block, the output FFN's, the embedding FFN's
     p->arena_floats += (int64_t)(2 * p->nl + 1) * SR_BWD_MAXWG * (d * dff + dff + 3 * d + 4) + (int64_t)SR_BWD_MAXWG * (2 * F + dff * F + dff + d * dff + d + 4);
+  w = (w + 3) & ~(int64_t)3;  // 16-byte pieces (the vector form of sr_fold_all_kernel)
   p->ws_arena = w; w += p->arena_floats;
   p->ws_total = w;
   return true;
@@ -679,7 +680,36 @@ __global__ __launch_bounds__(256) void sr_fold_all_kernel(FoldTable t) {
   while (j + 1 < t.n && (int)blockIdx.x >= t.job[j + 1].blk_begin) ++j;
   const FoldJob jb = t.job[j];
   const int b = (int)blockIdx.x - jb.blk_begin;
-  if (jb.wide) {
+  if (jb.wide == 2) {
+    // many partials of a long vector (the per-workgroup partials of ultr_sr_bwd.hip: 256 x 66 - 125 KB): the 16-group order of the
+    // `wide` form with FOUR columns per thread - a workgroup reads whole 256-byte runs of a partial instead of 64-byte pieces whose
+    // other halves a workgroup on another XCD fetched again (45 -> 2x fewer bytes from HBM); same sums, same order per column
+    const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int c = b * 64 + 4 * cl;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < jb.len) {
+#pragma unroll 8
+      for (int k = grp; k < jb.nparts; k += 16) {
+        const float4 v = ld4(jb.part + (int64_t)k * jb.stride + c);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
+    }
+    __shared__ float4 sm4[256];
+    sm4[grp * 16 + cl] = a;
+    __syncthreads();
+    if (grp == 0 && c < jb.len) {
+      float4 v = sm4[cl];
+#pragma unroll
+      for (int g = 1; g < 16; ++g) {
+        const float4 w = sm4[g * 16 + cl];
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+      }
+      const float o[4] = {v.x, v.y, v.z, v.w};  // (the destination sits at any float offset of the gradient vector)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (c + i < jb.len) jb.dst[c + i] = o[i];
+    }
+  } else if (jb.wide) {
     const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const int c = b * 16 + cl;
     float a = 0.f;
@@ -736,9 +766,11 @@ void fold(const float* part, int64_t stride, int nparts, int len, float* dst, hi
   const bool in_arena = f.active && part >= f.arena && part < f.arena + f.cap;
   if (f.active && (in_arena || own_buffer) && f.tab.n < SR_MAX_FOLDS) {
     FoldJob& j = f.tab.job[f.tab.n++];
-    j.part = part; j.dst = dst; j.stride = stride; j.nparts = nparts; j.len = len; j.wide = wide ? 1 : 0;
+    // (a partial is a 16-byte-aligned run of `stride` = 4 k floats and `part` starts 4 m floats into it: the last float4 of a row stays inside)
+    const bool vec4 = wide && len >= 1024 && (stride & 3) == 0 && ((uintptr_t)part & 15) == 0;
+    j.part = part; j.dst = dst; j.stride = stride; j.nparts = nparts; j.len = len; j.wide = vec4 ? 2 : (wide ? 1 : 0);
     j.blk_begin = f.tab.nblocks;
-    f.tab.nblocks += wide ? (len + 15) / 16 : (len + 63) / 64;
+    f.tab.nblocks += (wide && !vec4) ? (len + 15) / 16 : (len + 63) / 64;
     return;
   }
   if (wide) hipLaunchKernelGGL(sr_fold16_kernel, dim3((len + 15) / 16), dim3(256), 0, st, part, stride, nparts, len, dst);
@@ -3096,7 +3128,7 @@ extern "C" int ultr_setrank_backward(const ultr_setrank_desc* c, const float* pa
   bool head_done = false;
   if (fused && (g_sr_knob_bwd_fused & 2) && p.bo1 == p.wo1 + (int64_t)dff * d && p.wo2 == p.bo1 + dff && p.bo2 == p.wo2 + dff) {
     const SrPlan::SplitMat* mo = sr_find_split(params + p.wo1, dff, d);
-    const int64_t sh = (int64_t)dff * d + 2 * dff + 2;
+    const int64_t sh = ((int64_t)dff * d + 2 * dff + 2 + 3) & ~(int64_t)3;  // (whole float4s: sr_fold_all_kernel's vector form)
     float* ph = nullptr;
     if (mo && mo->gt_off >= 0 && (ph = arena_piece(fz_nwg * sh)) != nullptr) {
       SrBwdHeadArgs ha;
