@@ -686,10 +686,12 @@ def eval_leg(cfg, device, lib, params0):
                         "algorithmic_per_launch": fwd_flops},
             "ndcg": {"kernel": "ndcg_list_kernel", "avg_launch_us": ndcg_us, "bound": "hbm", "achieved": ndcg_bytes / (1e-6 * ndcg_us) / 1e9,
                      "unit": "GB/s", "frac": ndcg_bytes / (1e-6 * ndcg_us) / 1e9 / PEAK_HBM_GBS, "algorithmic_per_launch": ndcg_bytes,
-                     "limited_by": "launch latency: one wavefront-sorted list per workgroup, %d KB per launch" % int(ndcg_bytes / 1024)},
+                     "limited_by": "a chain of dependent round trips (labels, write-through per-list values, arrival counter, read-back, host report), "
+                                   "not bytes: %d KB per launch; fused into the forward's launch it measured SLOWER (24.8 us against 15.05 + 8.58)" % int(ndcg_bytes / 1024)},
             "ndcg_at_1_3_5_10": [float(v) for v in nd_host.tolist()],
-            "what": "EvalEngine.run = ultr_dnn_forward + ultr_ndcg (pad mask, label validation, rank sort, DCG / IDCG at the cut-offs), "
-                    "ndcg vector read on the host after every batch from the launch's host-mapped report (ultr_ndcg_report: one launch, no stream synchronisation)",
+            "what": "EvalEngine.run = ultr_dnn_forward_ndcg (one host call): the DNN forward, then ndcg_list_kernel (pad mask, label validation, rank "
+                    "sort, DCG / IDCG at the cut-offs, batch means by the last wave), the ndcg vector read on the host after every batch from the "
+                    "launch's host-mapped report (no stream synchronisation)",
         }
     return out
 

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ULTR_ABI_VERSION 7
+#define ULTR_ABI_VERSION 8
 #define ULTR_MAX_HIDDEN 7 /* hidden layers; Linear layers = hidden + 1 <= 8 */
 
 #define ULTR_E_BADARG (-1)
@@ -354,6 +354,12 @@ int ultr_ndcg(const float* scores, const float* labels, const int32_t* docids, i
 int ultr_ndcg_report(const float* scores, const float* labels, const int32_t* docids, int64_t n_docs, int32_t batch,
                      int32_t list_size, const int32_t* topn, int32_t n_topn, float* ndcg_out, int32_t* order_out,
                      float* masked_out, float* ndcg_ws, uint32_t* counter, float* host_report, uint32_t seq, void* stream);
+/* ABI 8: validation() as ONE host call: ultr_dnn_forward (saved = NULL) followed by ultr_ndcg_report of its scores on the same stream
+ * (base_algorithm.py:88-154 validation forward + metrics.py:456-495).  Same arguments, same results. */
+int ultr_dnn_forward_ndcg(const ultr_dnn_desc* d, const float* params, const float* wt, const float* features, int64_t n_docs,
+                          const int32_t* docids, const float* labels, int32_t batch, int32_t list_size, float* scores,
+                          const int32_t* topn, int32_t n_topn, float* ndcg_out, int32_t* order_out, float* masked_out,
+                          float* ndcg_ws, uint32_t* counter, float* host_report, uint32_t seq, void* stream);
 
 /* ---- next row: device-side click simulation + batch assembly -------------------
  * Counterpart of ClickSimulationFeed.get_batch (click_simulation_feed.py:70-174) + PositionBiasedModel

@@ -257,3 +257,33 @@ def test_ndcg_report_in_host_mapped_memory_equals_the_two_launch_form():
             np.testing.assert_array_equal(dev_vals, got)
             np.testing.assert_array_equal(order, o2.cpu().numpy())
             np.testing.assert_array_equal(masked, m2.cpu().numpy())
+
+
+@pytest.mark.parametrize("B,L,F,hidden", [(256, 10, 136, [512, 256, 128]), (37, 5, 24, [32, 16]), (9, 1, 8, [16]), (33, 17, 24, [32, 16])])
+def test_validation_as_one_host_call_equals_forward_plus_metric(B, L, F, hidden):
+    """ultr_dnn_forward_ndcg (EvalEngine.run) against ultr_dnn_forward + ultr_ndcg: scores, masked scores, permutation, per-batch NDCG and
+    the host report to the bit - with PAD documents and invalid labels."""
+    from ultra_pytorch_amd import engine, hip_ops, synthetic
+    from ultra_pytorch_amd.ranking_model import init_flat_params
+    shape = hip_ops.DnnShape(F, hidden, "elu")
+    p = init_flat_params(shape, 3).cuda()
+    dev = torch.device("cuda")
+    ev = engine.EvalEngine(shape, B, L, dev)
+    r2 = np.random.RandomState(7)
+    for rep in range(3):
+        feats, ids, y = synthetic.make_batch(r2, B, L, F, clicks=False, n_pad=min(3, L - 1))
+        y = y.copy()
+        y[r2.rand(*y.shape) < 0.1] = -1.0  # invalid labels (metrics.py:251-264)
+        f, i_, y_ = torch.tensor(feats).cuda(), torch.tensor(ids).cuda(), torch.tensor(y).cuda()
+        ev.run(p, f, feats.shape[0], i_, y_)
+        got = ev.read_ndcg()
+        sc = torch.empty(B, L, device=dev)
+        hip_ops.dnn_forward(shape, p, f, feats.shape[0], i_, B, L, sc, None)
+        assert torch.equal(sc, ev.scores)
+        ref, ws = torch.zeros(4, device=dev), torch.zeros(B * 4, device=dev)
+        o2, m2 = torch.zeros(B, L, dtype=torch.int32, device=dev), torch.zeros(B, L, device=dev)
+        hip_ops.ndcg(sc, y_, i_, feats.shape[0], B, L, [1, 3, 5, 10], ref, ws, order_out=o2, masked_out=m2)
+        np.testing.assert_array_equal(got, ref.cpu().numpy())
+        np.testing.assert_array_equal(ev.ndcg.cpu().numpy(), got)
+        assert torch.equal(ev.order, o2) and torch.equal(ev.masked, m2)
+        assert np.isfinite(got).all() and got[-1] > 0

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "libultr_hip.so does not export %s" % n
     assert set(names) == set(_lib.SIGNATURES), "ctypes table and header disagree: %s" % (set(names) ^ set(_lib.SIGNATURES))
-    assert _lib.load().ultr_abi_version() == _lib.ABI_VERSION == 7
+    assert _lib.load().ultr_abi_version() == _lib.ABI_VERSION == 8
 
 
 def test_header_is_plain_c(tmp_path):

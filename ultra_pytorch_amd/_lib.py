@@ -25,7 +25,7 @@ class DnnDesc(ctypes.Structure):
 
 
 MODEL_FP32_PRODUCTS = 1  # ultr_dnn_desc / ultr_setrank_desc ::flags (include/ultr_hip.h, ABI 6)
-ABI_VERSION = 7          # include/ultr_hip.h: ULTR_ABI_VERSION - load() refuses a library that reports another one
+ABI_VERSION = 8          # include/ultr_hip.h: ULTR_ABI_VERSION - load() refuses a library that reports another one
 
 
 class UpdateDesc(ctypes.Structure):
@@ -111,6 +111,8 @@ SIGNATURES = {
     "ultr_ndcg": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, ctypes.POINTER(c_i32), c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "ultr_ndcg_report": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, ctypes.POINTER(c_i32), c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                  ctypes.c_uint32, c_vp]),
+    "ultr_dnn_forward_ndcg": (c_i32, [ctypes.POINTER(DnnDesc), c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_vp, ctypes.POINTER(c_i32),
+                                      c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_uint32, c_vp]),
 }
 
 _LIB = None

@@ -706,6 +706,22 @@ extern "C" int ultr_dnn_forward(const ultr_dnn_desc* d, const float* params, con
                              vm);
 }
 
+// validation(): ultr_dnn_forward (saved = NULL) + ultr_ndcg_report of its scores behind ONE host call.  (Round 6 also built the ONE-LAUNCH
+// form - dnn_fwd_kernel with list-aligned tiles and ndcg_list_kernel's code as its epilogue, bit-identical - and measured it slower: 24.8 us
+// against 15.05 + 8.58 us of kernel time, 34.5 - 36.4 against 32.5 - 33.8 us per batch read on the host.  The metric's cost is its chain of
+// dependent memory round trips - labels, write-through per-list values, the arrival counter, the last wave's read-back, the host report -
+// not its launch, and behind the forward that chain is exposed in full instead of overlapping the forward's tail.  Removed)
+extern "C" int ultr_dnn_forward_ndcg(const ultr_dnn_desc* d, const float* params, const float* wt, const float* features, int64_t n_docs,
+                                     const int32_t* docids, const float* labels, int32_t batch, int32_t list_size, float* scores,
+                                     const int32_t* topn, int32_t n_topn, float* ndcg_out, int32_t* order_out, float* masked_out,
+                                     float* ndcg_ws, uint32_t* counter, float* host_report, uint32_t seq, void* stream) {
+  if (!labels || !topn || !ndcg_out || !ndcg_ws || !counter || n_topn <= 0) return ULTR_E_BADARG;
+  const int rc = ultr_dnn_forward(d, params, wt, features, n_docs, docids, batch, list_size, scores, nullptr, stream);
+  if (rc != 0) return rc;
+  return ultr_ndcg_report(scores, labels, docids, n_docs, batch, list_size, topn, n_topn, ndcg_out, order_out, masked_out, ndcg_ws, counter,
+                          host_report, seq, stream);
+}
+
 extern "C" int32_t ultr_dnn_forward_tile_rows(const ultr_dnn_desc* d, int64_t n_rows, int32_t training) {
   DnnPlan p;
   if (n_rows <= 0 || !ultr_make_dnn_plan(d, n_rows, &p)) return -1;

@@ -54,17 +54,20 @@ __global__ __launch_bounds__(NDCG_LPW * 64) void ndcg_list_kernel(const float* _
   float* md = sm_d + wave * L;
   float* mi = sm_i + wave * L;
   // pad mask, then metrics.py:251-264: invalid labels (< 0) -> label 0, prediction rowmin - 1e-6
+  // (score, doc id and label of a position are requested together: the kernel is a chain of dependent round trips, not bytes)
   float mn = INFINITY;
   for (int l = lane; l < L; l += 64) {
     float s = scores[(int64_t)b * L + l];
+    const float y = labels[(int64_t)l * B + b];
     if (docids != nullptr && (int64_t)docids[(int64_t)l * B + b] == n_docs) s = ULTR_PAD_SCORE;
     if (masked_out != nullptr) masked_out[(int64_t)b * L + l] = s;
     ms[l] = s;
+    my[l] = y;
     mn = fminf(mn, s);
   }
   mn = -wave_max(-mn);
   for (int l = lane; l < L; l += 64) {
-    const float y = labels[(int64_t)l * B + b];
+    const float y = my[l];
     const bool ok = y >= 0.f;
     my[l] = ok ? y : 0.f;
     if (!ok) ms[l] = -1e-6f + mn;

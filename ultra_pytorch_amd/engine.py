@@ -343,8 +343,15 @@ class EvalEngine:
                                               self._hs.data_ptr(), self._seq, hip_ops.raw_stream()), "ultr_ndcg_report")
 
     def run(self, params, features, n_docs, docids, labels):
-        hip_ops.dnn_forward(self.shape, params, features, n_docs, docids, self.B, self.L, self.scores, None)
-        self._ndcg(labels, docids, n_docs)
+        """ONE host call (ultr_dnn_forward_ndcg): the forward, then the metric launch with its report in host-mapped memory."""
+        self._seq = (self._seq % 0xFFFFFFFF) + 1
+        wt = hip_ops.weight_copy(self.shape).get(params)
+        _lib.check(self._lib.ultr_dnn_forward_ndcg(ctypes.byref(self.shape.desc), params.data_ptr(), wt.data_ptr() if wt is not None else None,
+                                                   features.data_ptr() if n_docs > 0 else None, int(n_docs), docids.data_ptr(),
+                                                   labels.data_ptr(), self.B, self.L, self.scores.data_ptr(), self._topn_arr, len(self.topn),
+                                                   self.ndcg.data_ptr(), self.order.data_ptr(), self.masked.data_ptr(), self.ndcg_ws.data_ptr(),
+                                                   self._counter.data_ptr(), self._hs.data_ptr(), self._seq, hip_ops.raw_stream()),
+                   "ultr_dnn_forward_ndcg")
         return self.scores, self.ndcg
 
     def read_ndcg(self, timeout_s=60.0):
