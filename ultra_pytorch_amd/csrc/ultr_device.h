@@ -318,6 +318,14 @@ struct Philox {
 };
 __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }  // [0, 1)
 
+__device__ __forceinline__ float quad_max(float v) {  // over the 4 lanes {i, i+16, i+32, i+48}
+  v = fmaxf(v, __shfl_xor(v, 16));
+  return fmaxf(v, __shfl_xor(v, 32));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __shfl_xor(v, 16);
+  return v + __shfl_xor(v, 32);
+}
 __host__ __device__ __forceinline__ int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // raise bits of a status / flag word other workgroups and later launches read (rare path: relaxed, agent scope)
