@@ -160,11 +160,14 @@ def test_dynamic_bias_eta_change_on_the_device():
     assert np.abs(d_new.mean(1) - d_old.mean(1)).max() > 0.02  # a steeper position bias
 
 
-def test_user_browsing_model_on_the_device():
+@pytest.mark.parametrize("table", ["reference_json", "six_rows_steep", "three_rows_eta2"])
+def test_user_browsing_model_on_the_device(table, tmp_path):
     """The user-browsing model (click_models.py:113-186: examination depends on the rank AND the distance to the last click)
     through ultr_click_batch: per-position click rates and the distribution of the GAP between consecutive clicks (what the
     rank x distance table shapes) agree with the host feed - bit-exact with the reference's - to 5 sigma; lists of 14 documents
-    reach beyond the 10-row table (its last row is reused)."""
+    reach beyond the table (its last row is reused).  Three tables: the reference's json, a 6-row table with a steep distance
+    decay and other click probabilities, a 3-row table with eta = 2."""
+    import json
     import os
     from ultra_pytorch_amd import synthetic
     from ultra_pytorch_amd.input_layer import ClickSimulationFeed, DeviceClickFeed
@@ -172,7 +175,16 @@ def test_user_browsing_model_on_the_device():
     ds = DS(300, (8, 14), F, seed=8)
     ds.pad(L)
     model = Model(F, L)
-    hp = "click_model_json=%s" % os.path.join(os.path.dirname(synthetic.PBM_JSON), "ubm_0.1_1_4_1.0.json")
+    path = os.path.join(os.path.dirname(synthetic.PBM_JSON), "ubm_0.1_1_4_1.0.json")
+    if table != "reference_json":
+        rows, eta, clickp = (6, 1.0, [0.05, 0.2, 0.45, 0.7, 0.95]) if table == "six_rows_steep" else (3, 2.0, [0.1, 0.3, 0.5, 0.7, 0.9])
+        rt = np.random.RandomState(rows)
+        exam = [[round(float(0.98 ** r * (0.55 ** (r - d) if table == "six_rows_steep" else 0.8 ** (r - d)) * rt.uniform(0.9, 1.0)), 4)
+                 for d in range(r + 1)] for r in range(rows)]  # row r: distance to the last click r - d ... 0 (the reference's triangle)
+        path = str(tmp_path / "ubm.json")
+        with open(path, "w") as f:
+            json.dump({"click_prob": clickp, "eta": eta, "exam_prob": exam, "model_name": "user_browsing_model"}, f)
+    hp = "click_model_json=%s" % path
     dev_clicks = _rates(DeviceClickFeed(model, B, hp, seed=21), ds, model, L, 8, host=False)
     random.seed(13)
     host_clicks = _rates(ClickSimulationFeed(model, B, hp), ds, model, L, 8, host=True)

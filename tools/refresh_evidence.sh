@@ -4,7 +4,7 @@
 if [ "$1" == "--collect" ]; then
   TAG=$2
   for f in gpurun_out/${TAG}_cfg*_bench.json gpurun_out/${TAG}_cfg*_kernel_stats.csv gpurun_out/${TAG}_final_default_bench.json \
-           gpurun_out/${TAG}_trace_phases.txt gpurun_out/${TAG}_trace_wide.txt gpurun_out/${TAG}_dnn_pmc.txt; do [ -s "$f" ] && cp "$f" profiles/; done
+           gpurun_out/${TAG}_trace_phases.txt gpurun_out/${TAG}_trace_wide.txt gpurun_out/${TAG}_trace_sr_bwd.txt gpurun_out/${TAG}_dnn_pmc.txt; do [ -s "$f" ] && cp "$f" profiles/; done
   python tools/summarize_profiles.py $TAG
   for C in 3 4pair 5; do [ -d gpurun_out/pmc_${TAG}_cfg$C ] && python tools/summarize_pmc.py $TAG $C > /dev/null; done
   exit 0
@@ -31,6 +31,7 @@ if [ -f ultra_pytorch_amd/lib/variants/libultr_trace.so ]; then
     echo "== config $C: dnn_fwdw_kernel"; timeout 300 python tools/trace_fwdw.py $C 2>&1 | grep -v amdgpu.ids
     echo "== config $C: dnn_bwdw_kernel"; timeout 300 python tools/trace_bwdw.py $C 2>&1 | grep -v amdgpu.ids
   done > gpurun_out/${TAG}_trace_wide.txt
+  timeout 300 python tools/trace_sr_bwd.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_trace_sr_bwd.txt
   rm -f ultra_pytorch_amd/lib/variants/libultr_trace.so
 fi
 echo done
