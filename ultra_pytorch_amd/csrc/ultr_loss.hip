@@ -282,7 +282,9 @@ extern "C" int ultr_dla_loss(const float* scores, const float* labels, const flo
 // with the reciprocals of t_plus / t_minus staged once.  A list is small (L^2 pairs) and there are only `batch` of them, so
 // the kernel is one wavefront's instruction stream long: PD_JW wavefronts share a list (each a slice of the j range; their
 // four partial sums per position are combined in fixed order through LDS).
-#define PD_JW 4  // wavefronts per list
+#ifndef PD_JW
+#define PD_JW 16  // wavefronts per list (round 6: 4 -> 16, one list per CU keeps four waves per SIMD busy: pairdebias 7.6 -> 6.2 us,
+#endif           // lambdarank 15.3 -> 12.7 us at config 4; tools/ab.sh "--config 4lambda" product jw8 jw16)
 __global__ __launch_bounds__(LPW * PD_JW * 64) void pairdebias_kernel(const float* __restrict__ scores,
                                                                      const float* __restrict__ labels,
                                                                      const float* __restrict__ t_plus,
