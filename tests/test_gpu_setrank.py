@@ -182,12 +182,14 @@ def test_setrank_full_size_properties():
     assert int((err > 5e-4 * gmax).sum()) <= n // 200
 
 
-def test_setrank_full_size_backward_against_the_oracle_on_three_lists():
+@pytest.mark.parametrize("algo", ["na", "ipw"])
+def test_setrank_full_size_backward_against_the_oracle_on_three_lists(algo):
     """BASELINE config 5's FULL geometry (1024 lists x 100 documents: the persistent fused kernels walk 1 707 tiles on 256 workgroups, the
     one-launch fold sums 256 partials) against the ORACLE's autograd: lists are independent and the loss is a sum over lists, so with the
     weight of every other list exactly zero (label -1e-7: the reference's (y + 1e-7) smoothing, ipw_rank.py / softmax_loss, cancels in fp32)
     the step's gradient is the gradient of three lists - the first, one in the middle, the last - which the oracle differentiates alone
-    (300 tokens).  Scores of those lists, loss, normaliser and every gradient entry at the golden tolerances."""
+    (300 tokens).  Scores of those lists, loss, normaliser and every gradient entry at the golden tolerances.  With the IPW table
+    (BASELINE config 5's algorithm) a list without clicks has weight zero by itself (propensity weights are zero off the clicks)."""
     from oracle import ultr_oracle as O
     from ultra_pytorch_amd import hip_ops, synthetic
     from ultra_pytorch_amd.ranking_model.SetRank import init_setrank_params
@@ -196,13 +198,14 @@ def test_setrank_full_size_backward_against_the_oracle_on_three_lists():
     rng = np.random.RandomState(17)
     feats, ids, y = synthetic.make_batch(rng, B, L, F, n_pad=3)
     sel = [0, 517, 1023]
-    y2 = np.full_like(y, np.float32(-1e-7))
+    ipw = np.asarray(synthetic.load_ipw(), np.float32) if algo == "ipw" else None
+    y2 = np.zeros_like(y) if algo == "ipw" else np.full_like(y, np.float32(-1e-7))
     y2[:, sel] = y[:, sel]
     assert float(np.float32(-1e-7) + np.float32(1e-7)) == 0.0
     p0 = init_setrank_params(shape, seed=4).numpy()
     p0 += rng.normal(scale=0.02, size=p0.shape).astype(np.float32)
-    scores, g, _, _, sc = run_step(shape, B, L, dict(learning_rate=0.05, max_gradient_norm=5.0), p0, np.zeros_like(p0), feats, ids, y2, None)
-    r = O.train_step_setrank_softmax(p0, np.zeros_like(p0), (F, dm, H, nl, dff), feats, ids[:, sel], y[:, sel], ipw_list=None, lr=0.05,
+    scores, g, _, _, sc = run_step(shape, B, L, dict(learning_rate=0.05, max_gradient_norm=5.0), p0, np.zeros_like(p0), feats, ids, y2, ipw)
+    r = O.train_step_setrank_softmax(p0, np.zeros_like(p0), (F, dm, H, nl, dff), feats, ids[:, sel], y[:, sel], ipw_list=ipw, lr=0.05,
                                      max_norm=5.0)
     np.testing.assert_allclose(scores[sel], r["scores"], atol=1e-5)
     assert abs(float(sc[0]) - r["loss"]) <= 1e-5 * max(1.0, abs(r["loss"]))
@@ -212,7 +215,7 @@ def test_setrank_full_size_backward_against_the_oracle_on_three_lists():
     gmax = float(np.abs(r["grads"]).max())
     d = np.abs(g[:n] * gs - r["grads"])
     from tests import margins
-    margins.check("setrank/full_size_three_lists", "grads_max_abs_diff_over_max", float(d.max()) / gmax)
+    margins.check("setrank/full_size_three_lists_%s" % algo, "grads_max_abs_diff_over_max", float(d.max()) / gmax)
     np.testing.assert_allclose(g[:n] * gs, r["grads"], rtol=1e-5, atol=2e-6 * max(1.0, gmax))
 
 
